@@ -1,0 +1,251 @@
+"""Deterministic synthetic inputs for tests, golden-vector generation and bench.py.
+
+No network, no CLIP vocabulary and no Stable Diffusion weights are available
+offline, so every benchmark/test input is synthetic:
+
+* tokenizer   - an in-memory ``CLIPTokenizer`` whose BPE vocabulary is
+                characters + whole-word merges for the prompt templates, so a
+                prompt such as ``"painting by c0042"`` is ~8 tokens (real CLIP
+                BPE gives a similar count for artist names).
+* encoder     - a seeded random-init ``CLIPTextModel`` at toy or real dims
+                (SD-v1.4 / SDXL-TE1: 768/3072/12 layers; SDXL-TE2: 1280/5120/32).
+* requests    - the reference's request dict schema
+                (reference: emcid/emcid_main.py:832-840, test_examples/*.json).
+* v* cache    - one ``v_star`` npz per request in the reference's path scheme
+                (reference: emcid/emcid_main.py:873-890, 951-968).
+* stats cache - ``mom2`` npz per layer in the reference's scheme
+                (reference: emcid/layer_stats.py:166-174).
+"""
+from __future__ import annotations
+
+import json
+import os
+import string
+from pathlib import Path
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+TEMPLATE_WORDS = [
+    "painting", "by", "artwork", "style", "of", "the", "in", "paint", "a", "an",
+    "photo", "image", "picture", "with", "and", "on", "at", "is", "famous",
+    "portrait", "landscape", "drawing", "sketch", "realist", "artist",
+]
+ARTIST_TEMPLATES = ["painting by {}", "artwork by {}", "style of {}"]
+
+ENCODER_DIMS = {
+    # name: (hidden, intermediate, layers, heads, act)
+    "toy": (32, 128, 5, 2, "quick_gelu"),
+    "toy2": (48, 192, 7, 3, "gelu"),
+    "sd-v1.4": (768, 3072, 12, 12, "quick_gelu"),
+    "sdxl-te1": (768, 3072, 12, 12, "quick_gelu"),
+    "sdxl-te2": (1280, 5120, 32, 20, "gelu"),
+}
+
+
+def synthetic_vocab(words: Sequence[str] = TEMPLATE_WORDS) -> Tuple[Dict[str, int], List[Tuple[str, str]]]:
+    """Character vocabulary plus left-to-right merge chains for ``words``."""
+    chars = list(string.ascii_lowercase + string.digits + ".,'-")
+    vocab: Dict[str, int] = {}
+    for c in chars:
+        vocab[c] = len(vocab)
+    for c in chars:
+        vocab[c + "</w>"] = len(vocab)
+    merges: List[Tuple[str, str]] = []
+    for w in words:
+        syms = list(w[:-1]) + [w[-1] + "</w>"]
+        cur = syms[0]
+        for s in syms[1:]:
+            if (cur, s) not in merges:
+                merges.append((cur, s))
+            cur = cur + s
+            if cur not in vocab:
+                vocab[cur] = len(vocab)
+    vocab["<|startoftext|>"] = len(vocab)
+    vocab["<|endoftext|>"] = len(vocab)
+    return vocab, merges
+
+
+def build_tokenizer(vocab: Optional[Dict[str, int]] = None, merges=None, model_max_length: int = 77):
+    from transformers import CLIPTokenizer
+
+    if vocab is None:
+        vocab, merges = synthetic_vocab()
+    merges = [tuple(m) for m in merges]
+    return CLIPTokenizer(vocab=dict(vocab), merges=merges, model_max_length=model_max_length)
+
+
+def build_text_encoder(kind: str = "toy", vocab_size: Optional[int] = None, seed: int = 0,
+                       name_or_path: str = "synthetic/clip-text"):
+    """Seeded random-init CLIPTextModel (fp32, eval, no grad)."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+
+    hidden, inter, layers, heads, act = ENCODER_DIMS[kind]
+    if vocab_size is None:
+        vocab_size = len(synthetic_vocab()[0])
+    cfg = CLIPTextConfig(
+        hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers,
+        num_attention_heads=heads, vocab_size=vocab_size, max_position_embeddings=77,
+        hidden_act=act, bos_token_id=vocab_size - 2, eos_token_id=vocab_size - 1,
+        pad_token_id=vocab_size - 1,
+    )
+    gen_state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    model = CLIPTextModel(cfg).eval()
+    torch.random.set_rng_state(gen_state)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    model.config._name_or_path = name_or_path
+    return model
+
+
+class SyntheticPipe(SimpleNamespace):
+    """Duck-typed stand-in for a diffusers pipeline: exactly the attributes the
+    edit path touches (.text_encoder, .tokenizer, .device,
+    [.text_encoder_2, .tokenizer_2])."""
+
+    @property
+    def device(self):
+        return next(self.text_encoder.parameters()).device
+
+    def to(self, device):
+        self.text_encoder.to(device)
+        if getattr(self, "text_encoder_2", None) is not None:
+            self.text_encoder_2.to(device)
+        return self
+
+
+def build_pipe(kind: str = "toy", device: str = "cpu", sdxl: bool = False, seed: int = 0) -> SyntheticPipe:
+    vocab, merges = synthetic_vocab()
+    tok = build_tokenizer(vocab, merges)
+    if not sdxl:
+        te = build_text_encoder(kind, len(vocab), seed=seed)
+        return SyntheticPipe(text_encoder=te.to(device), tokenizer=tok)
+    kind1, kind2 = ("toy", "toy2") if kind.startswith("toy") else ("sdxl-te1", "sdxl-te2")
+    te1 = build_text_encoder(kind1, len(vocab), seed=seed, name_or_path="synthetic/clip-text-1")
+    te2 = build_text_encoder(kind2, len(vocab), seed=seed + 1, name_or_path="synthetic/clip-text-2")
+    return SyntheticPipe(text_encoder=te1.to(device), tokenizer=tok,
+                         text_encoder_2=te2.to(device), tokenizer_2=build_tokenizer(vocab, merges))
+
+
+def make_requests(n: int, dest: str = "a realist artist", templates: Sequence[str] = ARTIST_TEMPLATES,
+                  seed_train: int = 2024, ragged: bool = False) -> List[Dict]:
+    """n unique synthetic concepts ``c0000`` … in the reference's request schema.
+    ``ragged`` gives requests differing prompt counts (1..len(templates))."""
+    reqs = []
+    for i in range(n):
+        k = len(templates) if not ragged else 1 + (i % len(templates))
+        reqs.append({
+            "source": f"c{i:04d}",
+            "dest": dest,
+            "prompts": list(templates[:k]),
+            "seed_train": seed_train,
+        })
+    return reqs
+
+
+def vstar_cache_path(cache_name: str, request: Dict, suffix: str = "") -> Path:
+    # reference: emcid/emcid_main.py:885-890 (SD) and :1157-1166 (SDXL "_2")
+    return Path(cache_name + f"source_{request['source']}_dest_{request['dest']}{suffix}.npz")
+
+
+def write_vstar_cache(cache_name: str, requests: Sequence[Dict], hidden: int, seed: int = 1,
+                      suffix: str = "", scale: float = 1.0) -> np.ndarray:
+    """Writes one ``v_star`` npz per request and returns the (N, hidden) array."""
+    rng = np.random.default_rng(seed)
+    vs = (rng.standard_normal((len(requests), hidden)) * scale).astype(np.float32)
+    for v, r in zip(vs, requests):
+        p = vstar_cache_path(cache_name, r, suffix)
+        p.parent.mkdir(parents=True, exist_ok=True)
+        np.savez(p, v_star=v)
+    return vs
+
+
+def stats_file(stats_dir, layer_name: str, n_samples: int, model_name: str = "text_encoder",
+               ds_name: str = "ccs_filtered", precision: str = "float32", batch_tokens: int = 3 * 1024) -> Path:
+    # reference: emcid/layer_stats.py:163-174
+    return Path(stats_dir) / f"{model_name}/{ds_name}_stats/{layer_name}_{precision}_mom2_t{batch_tokens}_{n_samples}.npz"
+
+
+def synthetic_second_moment(d: int, seed: int, t: int = 4096, anisotropy: float = 3.0) -> Tuple[np.ndarray, int]:
+    """mom2 = X^T X for X ~ N(0, diag(s)^2) with log-uniform column scales, fp32."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(t, d, generator=g, dtype=torch.float32)
+    scales = torch.exp(torch.linspace(0.0, -anisotropy, d))[torch.randperm(d, generator=g)]
+    x = x * scales
+    return (x.t() @ x).numpy(), t
+
+
+def write_stats_cache(stats_dir, layer_names: Sequence[str], d: int, n_samples: int, seed: int = 2,
+                      t: int = 4096, **kw) -> Dict[str, np.ndarray]:
+    """Writes a reference-format stats npz per layer (keys probed in SURVEY.md §5:
+    mom2.constructor, mom2.count, mom2.mom2, sample_size). Returns {layer_name: C}."""
+    out = {}
+    for i, ln in enumerate(layer_names):
+        mom2, count = synthetic_second_moment(d, seed + i, t=t)
+        f = stats_file(stats_dir, ln, n_samples, **kw)
+        f.parent.mkdir(parents=True, exist_ok=True)
+        np.savez(f, **{
+            "mom2.constructor": "util.runningstats.SecondMoment()",
+            "mom2.count": count,
+            "mom2.mom2": mom2,
+            "sample_size": n_samples,
+        })
+        out[ln] = mom2 / count
+    return out
+
+
+def make_captions(n: int, seed: int = 2, mean_words: float = 9.0) -> List[Dict[str, str]]:
+    """Synthetic caption set in the reference's JSON shape [{"caption": ...}]
+    (reference: dsets/stat_dataset.py:90-92)."""
+    rng = np.random.default_rng(seed)
+    words = TEMPLATE_WORDS
+    caps = []
+    for _ in range(n):
+        k = int(np.clip(rng.lognormal(np.log(mean_words), 0.45), 1, 60))
+        ws = [words[j] for j in rng.integers(0, len(words), size=k)]
+        if rng.random() < 0.5:
+            ws.append("c%04d" % rng.integers(0, 10000))
+        caps.append({"caption": " ".join(ws)})
+    return caps
+
+
+def write_captions(path, n: int, seed: int = 2) -> List[Dict[str, str]]:
+    caps = make_captions(n, seed)
+    os.makedirs(os.path.dirname(str(path)) or ".", exist_ok=True)
+    with open(path, "w") as f:
+        json.dump(caps, f)
+    return caps
+
+
+def sd_hparams_dict(layers=(7, 8, 9, 10), mom2_update_weight: int = 4000, edit_weight: float = 0.5,
+                    mom2_n_samples: int = 100000, prefix: str = "text_model.") -> Dict:
+    """Field-for-field the shipped ``ly-7-11`` JSON (reference:
+    hparams/dest_s-200_c-1.5_ly-7-11_lr-0.2_wd-5e-04_txt-align-0.01.json) with overridable layers."""
+    return {
+        "layers": list(layers), "clamp_norm_factor": 1.5, "layer_selection": "all",
+        "fact_token": "subject_last", "v_num_grad_steps": 100, "v_lr": 0.2, "v_weight_decay": 5e-4,
+        "mom2_adjustment": True, "mom2_update_weight": mom2_update_weight,
+        "rewrite_module_tmp": prefix + "encoder.layers.{}.mlp.fc2",
+        "layer_module_tmp": prefix + "encoder.layers.{}",
+        "mlp_module_tmp": prefix + "encoder.layers.{}.mlp",
+        "attn_module_tmp": prefix + "encoder.layers.{}.self_attn",
+        "ln_f_module": prefix + "final_layer_norm",
+        "mom2_dataset": "ccs_filtered", "mom2_n_samples": mom2_n_samples, "mom2_dtype": "float32",
+        "objective": "ablate-dest", "esd_mu": "None", "cal_text_repr_loss": True,
+        "text_repr_loss_scale_factor": 0.01, "edit_weight": edit_weight,
+    }
+
+
+def sdxl_hparams_dict(layers=(8, 9, 10), layers_2=(26, 27, 28, 29, 30), mom2_update_weight: int = 4000,
+                      mom2_update_weight_2: int = 10000, edit_weight: float = 0.5,
+                      mom2_n_samples: int = 100000, prefix: str = "text_model.") -> Dict:
+    """Field-for-field the shipped SDXL JSON (reference:
+    hparams/sdxl-dest_s-100_c-1.2_ly-8-11_ly2-26-31_lr-0.1_wd-8e-03_txt-align-0.01.json)."""
+    d = sd_hparams_dict(layers, mom2_update_weight, edit_weight, mom2_n_samples, prefix)
+    d.update({"layers_2": list(layers_2), "mom2_update_weight_2": mom2_update_weight_2,
+              "clamp_norm_factor": 1.2, "v_lr": 0.1, "v_weight_decay": 8e-3,
+              "text_repr_loss_scale_factor": 0.005})
+    return d

@@ -1,0 +1,354 @@
+"""ORACLE — CPU restatement of EMCID's closed-form mass-edit path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the *checker*, never the product: only tests/, __graft_entry__.smoke()
+and bench.py's `cpu_baseline` leg may import it.  The product (emcid_amd/) never does.
+
+It restates, op-for-op in PyTorch-CPU / numpy, what the reference computes on this
+path (two full hooked encoder forwards per edited layer, per-prompt Python gathers,
+fp32 residuals, fp64 `torch.linalg.solve`, fp32 `a.t().mm(a)` second moment), each
+function citing the reference file:line it follows.  Third-party arithmetic at the
+boundary is the same as the reference's: HF `CLIPTextModel.forward`
+(reference pins transformers==4.27.4, environment.yaml:31; this image has 5.15) and
+`torch.linalg.solve` (LAPACK getrf/getrs; reference pins torch==2.0.1).
+
+PARITY PIN: the reference holds no golden vectors for this path, so the
+oracle is pinned against outputs of the reference itself, run in the build container by
+tests/golden/make_golden.py and committed as tests/golden/*.npz (tests/test_oracle_golden.py).
+"""
+from __future__ import annotations
+
+import copy
+import json
+import math
+import random
+import unicodedata
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+# --------------------------------------------------------------------------------------
+# module lookup (reference: util/nethook.py:375-392)
+# --------------------------------------------------------------------------------------
+
+def _resolve(model, dotted: str, table) -> object:
+    """Named lookup; tolerates the transformers-4.x `text_model.` prefix on a 5.x model
+    and vice versa (SURVEY.md §8c shim 3 — data-level rename, no arithmetic)."""
+    names = dict(table)
+    if dotted in names:
+        return names[dotted]
+    alt = dotted[len("text_model."):] if dotted.startswith("text_model.") else "text_model." + dotted
+    if alt in names:
+        return names[alt]
+    raise LookupError(dotted)
+
+
+def get_module(model, name):
+    return _resolve(model, name, model.named_modules())
+
+
+def get_parameter(model, name):
+    return _resolve(model, name, model.named_parameters())
+
+
+# --------------------------------------------------------------------------------------
+# token range (reference: experiments/causal_trace.py:1046-1103)
+# --------------------------------------------------------------------------------------
+
+def find_token_range(tokenizer, token_array, substring_orig: str) -> Tuple[int, int]:
+    sub = substring_orig
+    n = len(token_array)
+    if sub == "[CLS]":
+        return (0, 1)
+    if sub in ("[EOS]", "", " "):
+        return (n - 1, n)
+    sub = sub.replace(" ", "").lower()
+    pieces = [tokenizer.decode([t]) for t in token_array]
+    whole = tokenizer.decode(token_array).replace(" ", "")
+    if "’" in sub:
+        whole = whole.replace("'", "’")
+    whole = unicodedata.normalize("NFKC", whole)
+    sub = unicodedata.normalize("NFKC", sub)
+    start_char = whole.index(sub)  # ValueError when absent, like the reference
+    end_char = start_char + len(sub)
+    pos = 0
+    first = last = None
+    for i, piece in enumerate(pieces):
+        if not ("ń" in sub and int(token_array[i]) == 78):
+            pos += len(piece)
+        if first is None and pos > start_char:
+            first = i
+        if last is None and pos >= end_char:
+            last = i + 1
+            break
+    return (first, last)
+
+
+# --------------------------------------------------------------------------------------
+# K/Z assembly (reference: emcid/compute_z.py:56-74, 2252-2325; emcid/compute_ks.py:21-41)
+# --------------------------------------------------------------------------------------
+
+def tokenize_prompts(prompts: List[str], tokenizer, device):
+    enc = tokenizer(prompts, return_tensors="pt", padding=True, truncation=True)
+    return {k: v.to(device) for k, v in enc.items()}
+
+
+def expand_requests(requests: Sequence[Dict]) -> Tuple[List[str], List[str], List[int]]:
+    """Prompt strings, per-prompt subject, prompts-per-request (compute_z.py:2270-2283, 2318-2320)."""
+    prompts, subjects, counts = [], [], []
+    pre = "source_prompts" in requests[0]
+    for r in requests:
+        ps = list(r["source_prompts"]) if pre else [p.format(r["source"]) for p in r["prompts"]]
+        prompts += ps
+        subjects += [r["source"]] * len(ps)
+        counts.append(len(r["prompts"]) if "prompts" in requests[0] else len(r["source_prompts"]))
+    return prompts, subjects, counts
+
+
+def module_input_output_at_words(text_encoder, tokenizer, requests, module_name) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One full encoder forward on all N*P prompts; fc2 input/output at the last subject
+    token of each prompt; mean over each request's prompts (num_fact_token == 1 branch)."""
+    device = next(text_encoder.parameters()).device
+    prompts, subjects, counts = expand_requests(requests)
+    inp = tokenize_prompts(prompts, tokenizer, device)
+    lookup = [find_token_range(tokenizer, ids, w)[-1] - 1 for ids, w in zip(inp["input_ids"], subjects)]
+    cap = {}
+
+    def hook(mod, args, out):
+        cap["in"], cap["out"] = args[0], out
+
+    h = get_module(text_encoder, module_name).register_forward_hook(hook)
+    try:
+        with torch.no_grad():
+            text_encoder(**inp)
+    finally:
+        h.remove()
+    rows_in = torch.stack([cap["in"][i, j, :] for i, j in enumerate(lookup)], 0).detach().clone()
+    rows_out = torch.stack([cap["out"][i, j, :] for i, j in enumerate(lookup)], 0).detach().clone()
+    edges = np.cumsum([0] + counts).tolist()
+    k = torch.stack([rows_in[edges[i]:edges[i + 1]].mean(0) for i in range(len(requests))], 0)
+    z = torch.stack([rows_out[edges[i]:edges[i + 1]].mean(0) for i in range(len(requests))], 0)
+    return k, z
+
+
+# --------------------------------------------------------------------------------------
+# second moment + Stage 0 (reference: util/runningstats.py:469-511, 1551-1600;
+# dsets/stat_dataset.py:71-172; emcid/layer_stats.py:140-220)
+# --------------------------------------------------------------------------------------
+
+class SecondMomentOracle:
+    def __init__(self):
+        self.count = 0
+        self.mom2 = None
+
+    def add(self, a: torch.Tensor):
+        if a.dim() != 2:
+            a = a.reshape(-1, a.shape[-1])
+        if len(a) == 0:
+            return
+        if self.count == 0:
+            self.mom2 = torch.zeros(a.shape[1], a.shape[1], dtype=a.dtype)
+        self.count += a.shape[0]
+        self.mom2 += a.t().mm(a)
+
+    def moment(self):
+        return self.mom2 / self.count
+
+
+def fixed_random_subset(n_items: int, sample_size: Optional[int], seed: int = 1) -> List[int]:
+    """FixedRandomSubsetSampler(dataset, seed=1, end=sample_size) (runningstats.py:1551-1556, 1595-1600)."""
+    order = list(range(n_items))
+    random.Random(seed).shuffle(order)
+    return order[:sample_size]
+
+
+def length_sorted_subbatches(items: List[List[int]], token_size: int) -> List[List[List[int]]]:
+    """length_collation: sort by -len; start a new sub-batch when width*(rows+1) > token_size
+    (stat_dataset.py:122-150). Returns lists of token-id rows (unpadded)."""
+    items = sorted(items, key=lambda ids: -len(ids))
+    groups, cur, width = [], [], 0
+    for ids in items:
+        if len(ids) == 0:
+            break
+        if width * (len(cur) + 1) > token_size:
+            groups.append(cur)
+            cur, width = [], 0
+        if not cur:
+            width = len(ids)
+        cur.append(ids)
+    if cur:
+        groups.append(cur)
+    return groups
+
+
+def pad_batch(rows: List[List[int]]) -> Dict[str, torch.Tensor]:
+    """make_padded_batch: zero-padded ids / position ids / mask (stat_dataset.py:153-163)."""
+    w = max(len(r) for r in rows)
+    ids = torch.zeros(len(rows), w, dtype=torch.long)
+    pos = torch.zeros(len(rows), w, dtype=torch.long)
+    msk = torch.zeros(len(rows), w, dtype=torch.long)
+    for i, r in enumerate(rows):
+        ids[i, :len(r)] = torch.tensor(r)
+        pos[i, :len(r)] = torch.arange(len(r))
+        msk[i, :len(r)] = 1
+    return {"input_ids": ids, "position_ids": pos, "attention_mask": msk}
+
+
+class _Stop(Exception):
+    pass
+
+
+def layer_stats_text_encoder(model, tokenizer, layer_name: str, captions: List[str], sample_size: Optional[int],
+                             batch_tokens: int = 3 * 1024, precision: str = "float32",
+                             batch_size: int = 100) -> SecondMomentOracle:
+    """Stage 0 for one layer: fixed random caption subset -> groups of 100 -> length-sorted
+    sub-batches -> forward stopped at `layer_name` -> attended tokens of its INPUT -> mom2 += a^T a."""
+    dtype = getattr(torch, precision)
+    stat = SecondMomentOracle()
+    order = fixed_random_subset(len(captions), sample_size)
+    cap = {}
+
+    def hook(mod, args, out):
+        cap["in"] = args[0]
+        raise _Stop()
+
+    h = get_module(model, layer_name).register_forward_hook(hook)
+    try:
+        with torch.no_grad():
+            for g in range(0, len(order), batch_size):
+                toks = [tokenizer.encode(captions[i], truncation=True, max_length=None) for i in order[g:g + batch_size]]
+                for rows in length_sorted_subbatches(toks, batch_tokens):
+                    batch = pad_batch(rows)
+                    try:
+                        model(**batch)
+                    except _Stop:
+                        pass
+                    feats = cap["in"].reshape(-1, cap["in"].shape[-1])[batch["attention_mask"].reshape(-1).nonzero()[:, 0]]
+                    stat.add(feats.to(dtype))
+    finally:
+        h.remove()
+    return stat
+
+
+# --------------------------------------------------------------------------------------
+# caches (reference: emcid/emcid_main.py:873-907, 2239-2276; emcid/layer_stats.py:163-174)
+# --------------------------------------------------------------------------------------
+
+def stats_path(stat_dir, layer_name, n_samples, precision="float32", model_name="text_encoder",
+               ds_name="ccs_filtered", batch_tokens=3 * 1024) -> Path:
+    return Path(stat_dir) / f"{model_name}/{ds_name}_stats/{layer_name}_{precision}_mom2_t{batch_tokens}_{n_samples}.npz"
+
+
+def load_cov(stat_dir, layer_name, n_samples, precision="float32") -> torch.Tensor:
+    """C = (mom2 / count).float() from the stats npz (emcid_main.py:2272; runningstats.py:499-510)."""
+    with np.load(stats_path(stat_dir, layer_name, n_samples, precision)) as z:
+        mom2 = torch.from_numpy(z["mom2.mom2"])
+        count = int(z["mom2.count"])
+    return (mom2 / count).float()
+
+
+def load_vstars(cache_name: str, requests, suffix: str = "") -> torch.Tensor:
+    """zs = stack(v_star, dim=1) -> (hidden, N) fp32 (emcid_main.py:885-899, 977)."""
+    vs = []
+    for r in requests:
+        with np.load(Path(cache_name + f"source_{r['source']}_dest_{r['dest']}{suffix}.npz")) as z:
+            vs.append(torch.from_numpy(z["v_star"]))
+    return torch.stack(vs, dim=1)
+
+
+# --------------------------------------------------------------------------------------
+# Stage 2 (reference: emcid/emcid_main.py:818-1082 SD; :1085-1425 SDXL; :769-815, :38-106 apply)
+# --------------------------------------------------------------------------------------
+
+def closed_form_layer(K: torch.Tensor, Zc: torch.Tensor, zs: torch.Tensor, C: torch.Tensor, lam: float,
+                      edit_weight: float, layers_left: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """The layer-loop body, emcid_main.py:1016-1050.  K (N,d) fp32, Zc (N,h) fp32, zs (h,N) fp32,
+    C (d,d) fp32.  Returns adj_k (d,N) f64, resid (h,N) f64, upd (h,d) f64."""
+    ks = K.t()
+    sources = zs - Zc.t()
+    cov = C * (1 - edit_weight) / 0.5
+    s = (edit_weight / 0.5) ** 0.5
+    ks64, src64 = ks.double() * s, sources.double() * s
+    adj_k = torch.linalg.solve(lam * cov.double() + ks64 @ ks64.T, ks64)
+    resid = src64 / layers_left
+    upd = resid @ adj_k.T
+    return adj_k, resid, upd
+
+
+def execute_text_encoder(text_encoder, tokenizer, requests, layers: Sequence[int], rewrite_module_tmp: str,
+                         zs: torch.Tensor, covs: Dict[int, torch.Tensor], lam: float, edit_weight: float,
+                         restore: bool = True, trace: Optional[list] = None):
+    """Sequential per-layer loop: K fwd, Zc fwd, solve, write W_orig + upd.float() into the live model
+    (emcid_main.py:981-1078).  `restore=False` reproduces the SDXL TE2 path (never restored)."""
+    names = [rewrite_module_tmp.format(l) + ".weight" for l in layers]
+    weights = {n: get_parameter(text_encoder, n) for n in names}
+    backup = {n: w.detach().clone() for n, w in weights.items()}
+    deltas = {}
+    with torch.no_grad():
+        for i, layer in enumerate(layers):
+            mod = rewrite_module_tmp.format(layer)
+            K, _ = module_input_output_at_words(text_encoder, tokenizer, requests, mod)
+            _, Zc = module_input_output_at_words(text_encoder, tokenizer, requests, mod)
+            adj_k, resid, upd = closed_form_layer(K, Zc, zs, covs[layer], lam, edit_weight, len(layers) - i)
+            n = mod + ".weight"
+            if upd.shape != weights[n].shape:
+                upd = upd.T
+            weights[n][...] = backup[n] + upd.float()
+            deltas[n] = (adj_k.detach().cpu(), resid.detach().cpu())
+            if trace is not None:
+                trace.append({"K": K.clone(), "Zc": Zc.clone(), "adj_k": adj_k, "resid": resid})
+        if restore:
+            for n, w in weights.items():
+                w[...] = backup[n]
+    return deltas
+
+
+def insert_deltas(text_encoder, deltas):
+    """w += (adj_k @ resid^T) matched to w.shape, .float() (emcid_main.py:802-809, 2279-2298)."""
+    with torch.no_grad():
+        for n, (adj_k, resid) in deltas.items():
+            w = get_parameter(text_encoder, n)
+            upd = adj_k @ resid.T
+            if upd.shape != w.shape:
+                upd = upd.T
+            w[...] += upd.float()
+
+
+def apply_emcid_to_text_encoder(pipe, requests, hparams: Dict, mom2_weight=None, edit_weight=None,
+                                cache_name=None, stats_dir=None, trace=None):
+    """emcid_main.py:769-815 with all v* and C pre-cached on disk.  `hparams` is a plain dict
+    (the JSON fields); it is mutated in place like the reference does (:846-847)."""
+    hparams["mom2_update_weight"] = mom2_weight if mom2_weight is not None else hparams["mom2_update_weight"]
+    hparams["edit_weight"] = edit_weight if edit_weight is not None else hparams.get("edit_weight", 0.5)
+    requests = copy.deepcopy(requests)
+    tmpl = hparams["rewrite_module_tmp"]
+    zs = load_vstars(cache_name, requests)
+    covs = {l: load_cov(stats_dir, tmpl.format(l), hparams["mom2_n_samples"], hparams["mom2_dtype"])
+            for l in hparams["layers"]}
+    deltas = execute_text_encoder(pipe.text_encoder, pipe.tokenizer, requests, hparams["layers"], tmpl, zs, covs,
+                                  hparams["mom2_update_weight"], hparams["edit_weight"], trace=trace)
+    insert_deltas(pipe.text_encoder, deltas)
+    return pipe, deltas
+
+
+def apply_emcid_to_sdxl_text_encoders(pipe, requests, hparams: Dict, mom2_weight=None, mom2_weight_2=None,
+                                      edit_weight=None, cache_name=None, stat_dir=None, stat_dir_2=None):
+    """emcid_main.py:38-106 + :1085-1425.  TE1 is restored before the deltas are inserted; TE2 is NOT
+    (reference :1410 vs :93-99), so TE2 ends at W + upd.float() + upd'.float() — reproduced as is."""
+    hparams["mom2_update_weight"] = mom2_weight if mom2_weight is not None else hparams["mom2_update_weight"]
+    hparams["mom2_update_weight_2"] = mom2_weight_2 if mom2_weight_2 is not None else hparams["mom2_update_weight_2"]
+    hparams["edit_weight"] = edit_weight if edit_weight is not None else hparams.get("edit_weight", 0.5)
+    requests = copy.deepcopy(requests)
+    tmpl = hparams["rewrite_module_tmp"]
+    zs = load_vstars(cache_name, requests)
+    zs2 = load_vstars(cache_name, requests, "_2")
+    covs = {l: load_cov(stat_dir, tmpl.format(l), hparams["mom2_n_samples"], hparams["mom2_dtype"]) for l in hparams["layers"]}
+    covs2 = {l: load_cov(stat_dir_2, tmpl.format(l), hparams["mom2_n_samples"], hparams["mom2_dtype"]) for l in hparams["layers_2"]}
+    d1 = execute_text_encoder(pipe.text_encoder, pipe.tokenizer, requests, hparams["layers"], tmpl, zs, covs,
+                              hparams["mom2_update_weight"], hparams["edit_weight"], restore=True)
+    d2 = execute_text_encoder(pipe.text_encoder_2, pipe.tokenizer_2, requests, hparams["layers_2"], tmpl, zs2, covs2,
+                              hparams["mom2_update_weight_2"], hparams["edit_weight"], restore=False)
+    insert_deltas(pipe.text_encoder, d1)
+    insert_deltas(pipe.text_encoder_2, d2)
+    return pipe, d1, d2

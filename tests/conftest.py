@@ -1,0 +1,64 @@
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+REPO = Path(__file__).resolve().parents[1]
+GOLDEN = REPO / "tests" / "golden"
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` tests must never be silently skipped on a GPU box; on CPU they are deselected by the marker.
+    pass
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+def load_golden(tag):
+    z = np.load(GOLDEN / f"{tag}.npz")
+    with open(GOLDEN / f"{tag}.json") as f:
+        meta = json.load(f)
+    return z, meta
+
+
+def pipe_from_golden(z, kind="toy", prefix="w/", device="cpu", name="synthetic/clip-text"):
+    """Rebuild the toy encoder from the fixture's stored state dict (not from the RNG)."""
+    from emcid_amd import synthetic as syn
+
+    te = syn.build_text_encoder(kind, name_or_path=name)
+    sd = {k[len(prefix):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(prefix)}
+    te.load_state_dict(sd, strict=True)
+    return te.to(device)
+
+
+def write_cov_npz(stats_dir, layer_name, cov, n_samples, batch_tokens=3 * 1024):
+    """Stats npz in the reference format whose moment() is exactly `cov` (count = 1)."""
+    from emcid_amd import synthetic as syn
+
+    f = syn.stats_file(stats_dir, layer_name, n_samples, batch_tokens=batch_tokens)
+    f.parent.mkdir(parents=True, exist_ok=True)
+    np.savez(f, **{"mom2.constructor": "util.runningstats.SecondMoment()", "mom2.count": 1,
+                   "mom2.mom2": np.asarray(cov, dtype=np.float32), "sample_size": n_samples})
+    return f
+
+
+def write_vstars(cache_name, requests, vstar, suffix=""):
+    from emcid_amd import synthetic as syn
+
+    for v, r in zip(vstar, requests):
+        p = syn.vstar_cache_path(cache_name, r, suffix)
+        p.parent.mkdir(parents=True, exist_ok=True)
+        np.savez(p, v_star=np.asarray(v, dtype=np.float32))

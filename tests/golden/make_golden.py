@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Mint golden vectors by running the REAL reference (/root/reference) on CPU.
+
+Run from the repo root, in the build container only (the GPU box has no
+/root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference has no golden vectors of its own for this path, so
+these fixtures pin the oracle.  The reference is imported UNMODIFIED with the
+four shims of SURVEY.md §8c:
+  1. stub modules for the absent `diffusers` / `torchvision` (import-only deps),
+  2. a scratch cwd holding `globals.yml` + `data/ccs_filtered.json`,
+  3. hparams module templates without the `text_model.` prefix (transformers 5.x),
+  4. `torch.cuda.device` patched to a null context (reference crashes on CPU).
+Only DATA is written to tests/golden/ (inputs + the reference's outputs).
+"""
+import contextlib
+import json
+import os
+import shutil
+import sys
+import tempfile
+import types
+from pathlib import Path
+
+sys.dont_write_bytecode = True
+REPO = Path(__file__).resolve().parents[2]
+REF = Path("/root/reference")
+OUT = REPO / "tests" / "golden"
+sys.path.insert(0, str(REPO))
+
+import numpy as np
+import torch
+from transformers import CLIPModel, CLIPProcessor, CLIPTokenizer, CLIPTextModel  # noqa: F401  (before stubs)
+from transformers import CLIPTextModelWithProjection, CLIPVisionModelWithProjection  # noqa: F401
+
+from emcid_amd import synthetic as syn
+
+
+def _install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Dummy:
+        def __init__(self, *a, **k):
+            pass
+
+    d = mod("diffusers", StableDiffusionPipeline=_Dummy, StableDiffusionXLPipeline=_Dummy,
+            DDPMScheduler=_Dummy, StableDiffusionPipelineSafe=_Dummy, EulerDiscreteScheduler=_Dummy,
+            UNet2DConditionModel=_Dummy, AutoencoderKL=_Dummy, DDIMScheduler=_Dummy,
+            LMSDiscreteScheduler=_Dummy, PNDMScheduler=_Dummy, DPMSolverMultistepScheduler=_Dummy)
+    d.models = mod("diffusers.models", UNet2DConditionModel=_Dummy)
+    d.utils = mod("diffusers.utils")
+    d.utils.logging = mod("diffusers.utils.logging", disable_progress_bar=lambda: None)
+    tv = mod("torchvision")
+    tv.transforms = mod("torchvision.transforms", Compose=_Dummy, Resize=_Dummy, CenterCrop=_Dummy,
+                        RandomHorizontalFlip=_Dummy, ToTensor=_Dummy, Normalize=_Dummy,
+                        InterpolationMode=types.SimpleNamespace(BILINEAR=0, BICUBIC=1))
+    tv.datasets = mod("torchvision.datasets", ImageNet=_Dummy)
+    tv.utils = mod("torchvision.utils", save_image=lambda *a, **k: None, make_grid=lambda *a, **k: None)
+
+
+class _NullCudaDevice(contextlib.AbstractContextManager):
+    def __init__(self, *a, **k):
+        pass
+
+    def __exit__(self, *a):
+        return False
+
+
+def import_reference(scratch: Path):
+    _install_stubs()
+    shutil.copy(REF / "globals.yml", scratch / "globals.yml")
+    (scratch / "data").mkdir(exist_ok=True)
+    os.chdir(scratch)
+    sys.path.insert(0, str(REF))
+    torch.cuda.device = _NullCudaDevice
+    torch.cuda.empty_cache = lambda: None
+    import emcid.emcid_main as em  # noqa
+    import emcid.layer_stats as ls  # noqa
+    import emcid.compute_z as cz  # noqa
+    from emcid.emcid_hparams import EMCIDHyperParams, EMCIDXLHyperParams
+    from experiments.causal_trace import find_token_range
+    return em, ls, cz, EMCIDHyperParams, EMCIDXLHyperParams, find_token_range
+
+
+def state_np(model, prefix="w/"):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+
+
+def record_kz(em, store):
+    """Wrap the reference's K/Z assembly so its per-call outputs are recorded."""
+    orig = em.get_module_input_output_at_words
+    import emcid.compute_ks as cks
+
+    def wrapped(*a, **k):
+        i, o = orig(*a, **k)
+        store.append((i.detach().clone(), o.detach().clone()))
+        return i, o
+
+    em.get_module_input_output_at_words = wrapped
+    cks.get_module_input_output_at_words = wrapped
+    return orig, cks
+
+
+def unrecord_kz(em, orig, cks):
+    em.get_module_input_output_at_words = orig
+    cks.get_module_input_output_at_words = orig
+
+
+def golden_sd(em, EMCIDHyperParams, scratch, tag, kind, n_req, layers, lam, ew, ragged, full):
+    """Reference execute_emcid_text_encoder + apply_emcid_to_text_encoder on a synthetic pipe."""
+    pipe = syn.build_pipe(kind, "cpu")
+    hidden, inter = syn.ENCODER_DIMS[kind][:2]
+    reqs = syn.make_requests(n_req, ragged=ragged)
+    hp_d = syn.sd_hparams_dict(layers=layers, mom2_update_weight=lam + 1, edit_weight=0.5, mom2_n_samples=1000, prefix="")
+    cache = str(scratch / f"cache_{tag}") + "/"
+    stats_dir = scratch / f"stats_{tag}"
+    vs = syn.write_vstar_cache(cache, reqs, hidden, seed=1, scale=0.5)
+    layer_names = [hp_d["rewrite_module_tmp"].format(l) for l in layers]
+    covs = syn.write_stats_cache(stats_dir, layer_names, inter, 1000, seed=2, t=max(2 * inter, 512))
+    em.COV_CACHE.clear()
+    hp = EMCIDHyperParams(**hp_d)
+    rec = []
+    orig, cks = record_kz(em, rec)
+    w0 = {n: em.nethook.get_parameter(pipe.text_encoder, n + ".weight").clone() for n in layer_names}
+    deltas = em.execute_emcid_text_encoder(pipe, reqs, hp, cache_name=cache, mom2_weight=lam,
+                                           edit_weight=ew, verbose=False, stat_dir=str(stats_dir))
+    unrecord_kz(em, orig, cks)
+    for n in layer_names:  # invariant: model restored
+        assert torch.equal(w0[n], em.nethook.get_parameter(pipe.text_encoder, n + ".weight"))
+    # fresh hparams (reference mutates them), full apply
+    hp2 = EMCIDHyperParams(**hp_d)
+    em.COV_CACHE.clear()
+    pipe2, orig_te = em.apply_emcid_to_text_encoder(pipe, reqs, hp2, "cpu", mom2_weight=lam, edit_weight=ew,
+                                                    return_orig_text_encoder=True, cache_name=cache,
+                                                    stats_dir=str(stats_dir), verbose=False)
+    assert hp2.mom2_update_weight == lam  # in-place mutation quirk
+    out = {"vstar": vs}
+    meta = {"kind": kind, "requests": reqs, "hparams": hp_d, "layers": list(layers), "lam": lam, "ew": ew,
+            "layer_names": layer_names}
+    g = torch.Generator().manual_seed(123)
+    probe = torch.randn(inter, 8, generator=g, dtype=torch.float64)
+    for li, n in enumerate(layer_names):
+        adj_k, resid = deltas[n + ".weight"]
+        k_in, _ = rec[2 * li]
+        _, z_out = rec[2 * li + 1]
+        w_new = em.nethook.get_parameter(pipe2.text_encoder, n + ".weight")
+        dw = (w_new.double() - w0[n].double())
+        if full:
+            out[f"cov/{li}"] = covs[n].astype(np.float32)
+            out[f"K/{li}"] = k_in.numpy()
+            out[f"Zc/{li}"] = z_out.numpy()
+            out[f"adj_k/{li}"] = adj_k.numpy()
+            out[f"resid/{li}"] = resid.numpy()
+            out[f"w_final/{li}"] = w_new.numpy()
+            out[f"w_orig/{li}"] = w0[n].numpy()
+        else:
+            out[f"K_probe/{li}"] = (k_in.double() @ probe).numpy()
+            out[f"Zc_rownorm/{li}"] = z_out.double().norm(dim=1).numpy()
+            out[f"adjk_probe/{li}"] = (probe.t() @ adj_k).numpy()          # (8, N)
+            out[f"resid_fro/{li}"] = np.array(resid.norm().item())
+            out[f"dw_probe/{li}"] = (dw @ probe).numpy()                   # (h, 8)
+            out[f"dw_fro/{li}"] = np.array(dw.norm().item())
+            out[f"dw_rownorm/{li}"] = dw.norm(dim=1).numpy()
+            out[f"dw_maxabs/{li}"] = np.array(dw.abs().max().item())
+    if full:
+        out.update(state_np(orig_te))
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump(meta, f, indent=1)
+    print(f"[golden] {tag}: wrote {len(out)} arrays")
+
+
+def golden_sdxl(em, EMCIDXLHyperParams, scratch, tag="toy_sdxl"):
+    pipe = syn.build_pipe("toy", "cpu", sdxl=True)
+    reqs = syn.make_requests(6)
+    layers, layers_2 = (2, 3), (3, 4, 5)
+    hp_d = syn.sdxl_hparams_dict(layers=layers, layers_2=layers_2, mom2_update_weight=40, mom2_update_weight_2=90,
+                                 mom2_n_samples=1000, prefix="")
+    cache = str(scratch / f"cache_{tag}") + "/"
+    sd1, sd2 = scratch / f"stats1_{tag}", scratch / f"stats2_{tag}"
+    h1, i1 = syn.ENCODER_DIMS["toy"][:2]
+    h2, i2 = syn.ENCODER_DIMS["toy2"][:2]
+    vs1 = syn.write_vstar_cache(cache, reqs, h1, seed=1, scale=0.5)
+    vs2 = syn.write_vstar_cache(cache, reqs, h2, seed=5, scale=0.5, suffix="_2")
+    n1 = [hp_d["rewrite_module_tmp"].format(l) for l in layers]
+    n2 = [hp_d["rewrite_module_tmp"].format(l) for l in layers_2]
+    c1 = syn.write_stats_cache(sd1, n1, i1, 1000, seed=2, t=512)
+    c2 = syn.write_stats_cache(sd2, n2, i2, 1000, seed=7, t=512)
+    em.COV_CACHE.clear()
+    w0_1 = {n: em.nethook.get_parameter(pipe.text_encoder, n + ".weight").clone() for n in n1}
+    w0_2 = {n: em.nethook.get_parameter(pipe.text_encoder_2, n + ".weight").clone() for n in n2}
+    hp = EMCIDXLHyperParams(**hp_d)
+    pipe, o1, o2 = em.apply_emcid_to_sdxl_text_encoders(
+        pipe, reqs, hp, "cpu", mom2_weight=50, mom2_weight_2=100, edit_weight=0.6,
+        return_orig_text_encoder=True, cache_name=cache, stat_dir=str(sd1), stat_dir_2=str(sd2), verbose=False)
+    out = {"vstar": vs1, "vstar_2": vs2}
+    for li, n in enumerate(n1):
+        out[f"cov/{li}"] = c1[n].astype(np.float32)
+        out[f"w_orig/{li}"] = w0_1[n].numpy()
+        out[f"w_final/{li}"] = em.nethook.get_parameter(pipe.text_encoder, n + ".weight").numpy()
+    for li, n in enumerate(n2):
+        out[f"cov_2/{li}"] = c2[n].astype(np.float32)
+        out[f"w_orig_2/{li}"] = w0_2[n].numpy()
+        out[f"w_final_2/{li}"] = em.nethook.get_parameter(pipe.text_encoder_2, n + ".weight").numpy()
+    out.update(state_np(o1, "w1/"))
+    out.update(state_np(o2, "w2/"))
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump({"requests": reqs, "hparams": hp_d, "layers": layers, "layers_2": layers_2,
+                   "mom2_weight": 50, "mom2_weight_2": 100, "edit_weight": 0.6,
+                   "layer_names": n1, "layer_names_2": n2}, f, indent=1)
+    print(f"[golden] {tag}: wrote {len(out)} arrays")
+
+
+def golden_stage0(ls, scratch, tag="toy_stage0"):
+    from tqdm import tqdm
+    caps = syn.write_captions(scratch / "data" / "ccs_filtered.json", 700, seed=2)
+    pipe = syn.build_pipe("toy", "cpu")
+    out = {}
+    layer_names = ["encoder.layers.1.mlp.fc2", "encoder.layers.4.mlp.fc2"]
+    for li, ln in enumerate(layer_names):
+        stat = ls.layer_stats_text_encoder(pipe.text_encoder, pipe.tokenizer, ln, str(scratch / "stats0"),
+                                           "ccs_filtered", ["mom2"], sample_size=500, precision="float32",
+                                           batch_tokens=600, progress=tqdm)
+        out[f"mom2/{li}"] = stat.mom2.mom2.numpy()
+        out[f"count/{li}"] = np.array(stat.mom2.count)
+        # the npz the reference wrote (format pin)
+        f = syn.stats_file(scratch / "stats0", ln, 500, batch_tokens=600)
+        with np.load(f) as z:
+            out[f"npz_keys/{li}"] = np.array(sorted(z.files))
+            assert int(z["sample_size"]) == 500
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump({"captions": caps, "layer_names": layer_names, "sample_size": 500, "batch_tokens": 600,
+                   "kind": "toy"}, f)
+    print(f"[golden] {tag}: wrote {len(out)} arrays")
+
+
+def golden_token_ranges(find_token_range, tag="token_ranges"):
+    tok = syn.build_tokenizer()
+    cases = [
+        ("painting by c0042", "c0042"), ("style of vincent van gogh", "Vincent van Gogh"),
+        ("a photo of tench", "tench"), ("artwork by the artist picasso in paint", "picasso"),
+        ("painting by c0042", "[CLS]"), ("painting by c0042", "[EOS]"), ("painting by c0042", ""),
+        ("painting by c0042", " "), ("a photo of a photo", "photo"), ("o'keeffe painting", "o'keeffe"),
+        ("style of claude-monet, famous", "claude-monet"), ("paint in the style of x", "x"),
+        ("an image of new york", "New York"), ("painting by zzz", "absent"),
+    ]
+    rows = []
+    prompts = [c[0] for c in cases]
+    enc = tok(prompts, return_tensors="pt", padding=True, truncation=True)
+    for (p, s), ids in zip(cases, enc["input_ids"]):
+        try:
+            r = find_token_range(tok, ids, s)
+            rows.append({"prompt": p, "subject": s, "ids": ids.tolist(), "range": [int(r[0]), int(r[1])]})
+        except ValueError:
+            rows.append({"prompt": p, "subject": s, "ids": ids.tolist(), "range": "ValueError"})
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump(rows, f, indent=1)
+    print(f"[golden] {tag}: {len(rows)} cases")
+
+
+def main():
+    scratch = Path(tempfile.mkdtemp(prefix="emcid_golden_"))
+    try:
+        em, ls, cz, HP, XLHP, ftr = import_reference(scratch)
+        torch.set_num_threads(8)
+        golden_token_ranges(ftr)
+        golden_sd(em, HP, scratch, "toy_sd", "toy", n_req=8, layers=(1, 2, 3, 4), lam=50, ew=0.6, ragged=True, full=True)
+        golden_sdxl(em, XLHP, scratch)
+        golden_stage0(ls, scratch)
+        if "--skip-real" not in sys.argv:
+            golden_sd(em, HP, scratch, "real_sd_summary", "sd-v1.4", n_req=24, layers=(7, 8, 9, 10), lam=4000,
+                      ew=0.5, ragged=False, full=False)
+    finally:
+        os.chdir(REPO)
+        shutil.rmtree(scratch, ignore_errors=True)
+    n_ref = sum(1 for _ in REF.rglob("*") if _.is_file())
+    print(f"[golden] reference tree files: {n_ref} (must stay 111; no __pycache__ written)")
+
+
+if __name__ == "__main__":
+    main()

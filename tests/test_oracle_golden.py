@@ -1,0 +1,119 @@
+"""Pins oracle/emcid_oracle.py against golden vectors minted from the REAL reference
+(tests/golden/make_golden.py).  CPU only."""
+import copy
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, pipe_from_golden, write_cov_npz, write_vstars
+from emcid_amd import synthetic as syn
+from oracle import emcid_oracle as orc
+
+
+def test_find_token_range_golden():
+    rows = json.load(open(GOLDEN / "token_ranges.json"))
+    tok = syn.build_tokenizer()
+    assert len(rows) >= 12
+    for r in rows:
+        ids = torch.tensor(r["ids"])
+        if r["range"] == "ValueError":
+            with pytest.raises(ValueError):
+                orc.find_token_range(tok, ids, r["subject"])
+        else:
+            assert list(orc.find_token_range(tok, ids, r["subject"])) == r["range"], r
+
+
+def _sd_setup(tmp_path, z, meta, kind):
+    te = pipe_from_golden(z, kind) if any(k.startswith("w/") for k in z.files) else syn.build_text_encoder(kind)
+    pipe = syn.SyntheticPipe(text_encoder=te, tokenizer=syn.build_tokenizer())
+    cache = str(tmp_path / "cache") + "/"
+    write_vstars(cache, meta["requests"], z["vstar"])
+    return pipe, cache
+
+
+def test_toy_sd_bit_level(tmp_path):
+    """Full-tensor parity on the toy SD edit: K, Zc, adj_k, resid and the final weights."""
+    z, meta = load_golden("toy_sd")
+    pipe, cache = _sd_setup(tmp_path, z, meta, meta["kind"])
+    for li, ln in enumerate(meta["layer_names"]):
+        write_cov_npz(tmp_path / "stats", ln, z[f"cov/{li}"], meta["hparams"]["mom2_n_samples"])
+    hp = copy.deepcopy(meta["hparams"])
+    trace = []
+    pipe, deltas = orc.apply_emcid_to_text_encoder(pipe, meta["requests"], hp, mom2_weight=meta["lam"],
+                                                   edit_weight=meta["ew"], cache_name=cache,
+                                                   stats_dir=str(tmp_path / "stats"), trace=trace)
+    assert hp["mom2_update_weight"] == meta["lam"]  # mutated in place like the reference
+    for li, ln in enumerate(meta["layer_names"]):
+        np.testing.assert_array_equal(trace[li]["K"].numpy(), z[f"K/{li}"])
+        np.testing.assert_array_equal(trace[li]["Zc"].numpy(), z[f"Zc/{li}"])
+        adj_k, resid = deltas[ln + ".weight"]
+        np.testing.assert_allclose(adj_k.numpy(), z[f"adj_k/{li}"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(resid.numpy(), z[f"resid/{li}"], rtol=1e-13, atol=0)
+        w = orc.get_parameter(pipe.text_encoder, ln + ".weight")
+        np.testing.assert_array_equal(w.numpy(), z[f"w_final/{li}"])
+
+
+def test_toy_sdxl_final_weights(tmp_path):
+    """SDXL dual-encoder edit incl. the TE2 double-apply quirk."""
+    z, meta = load_golden("toy_sdxl")
+    te1 = pipe_from_golden(z, "toy", "w1/")
+    te2 = pipe_from_golden(z, "toy2", "w2/")
+    tok = syn.build_tokenizer()
+    pipe = syn.SyntheticPipe(text_encoder=te1, tokenizer=tok, text_encoder_2=te2, tokenizer_2=tok)
+    cache = str(tmp_path / "cache") + "/"
+    write_vstars(cache, meta["requests"], z["vstar"])
+    write_vstars(cache, meta["requests"], z["vstar_2"], "_2")
+    ns = meta["hparams"]["mom2_n_samples"]
+    for li, ln in enumerate(meta["layer_names"]):
+        write_cov_npz(tmp_path / "s1", ln, z[f"cov/{li}"], ns)
+    for li, ln in enumerate(meta["layer_names_2"]):
+        write_cov_npz(tmp_path / "s2", ln, z[f"cov_2/{li}"], ns)
+    hp = copy.deepcopy(meta["hparams"])
+    orc.apply_emcid_to_sdxl_text_encoders(pipe, meta["requests"], hp, mom2_weight=meta["mom2_weight"],
+                                          mom2_weight_2=meta["mom2_weight_2"], edit_weight=meta["edit_weight"],
+                                          cache_name=cache, stat_dir=str(tmp_path / "s1"), stat_dir_2=str(tmp_path / "s2"))
+    for li, ln in enumerate(meta["layer_names"]):
+        w = orc.get_parameter(te1, ln + ".weight").numpy()
+        np.testing.assert_array_equal(w, z[f"w_final/{li}"])
+    for li, ln in enumerate(meta["layer_names_2"]):
+        w = orc.get_parameter(te2, ln + ".weight").numpy()
+        np.testing.assert_array_equal(w, z[f"w_final_2/{li}"])
+        # quirk: TE2 carries the update twice
+        dw = w.astype(np.float64) - z[f"w_orig_2/{li}"].astype(np.float64)
+        assert np.abs(dw).max() > 0
+
+
+def test_toy_stage0_second_moment():
+    z, meta = load_golden("toy_stage0")
+    pipe = syn.build_pipe(meta["kind"], "cpu")
+    caps = [c["caption"] for c in meta["captions"]]
+    for li, ln in enumerate(meta["layer_names"]):
+        stat = orc.layer_stats_text_encoder(pipe.text_encoder, pipe.tokenizer, ln, caps, meta["sample_size"],
+                                            batch_tokens=meta["batch_tokens"])
+        assert stat.count == int(z[f"count/{li}"])
+        np.testing.assert_array_equal(stat.mom2.numpy(), z[f"mom2/{li}"])
+        assert list(z[f"npz_keys/{li}"]) == ["mom2.constructor", "mom2.count", "mom2.mom2", "sample_size"]
+
+
+def test_real_dims_summary(tmp_path):
+    """SD-v1.4 dims (768/3072, layers 7-10), N=24: probe projections of dW from the reference."""
+    z, meta = load_golden("real_sd_summary")
+    pipe = syn.build_pipe(meta["kind"], "cpu")
+    cache = str(tmp_path / "cache") + "/"
+    write_vstars(cache, meta["requests"], z["vstar"])
+    inter = syn.ENCODER_DIMS[meta["kind"]][1]
+    ns = meta["hparams"]["mom2_n_samples"]
+    syn.write_stats_cache(tmp_path / "stats", meta["layer_names"], inter, ns, seed=2, t=max(2 * inter, 512))
+    w0 = {ln: orc.get_parameter(pipe.text_encoder, ln + ".weight").clone() for ln in meta["layer_names"]}
+    hp = copy.deepcopy(meta["hparams"])
+    orc.apply_emcid_to_text_encoder(pipe, meta["requests"], hp, mom2_weight=meta["lam"], edit_weight=meta["ew"],
+                                    cache_name=cache, stats_dir=str(tmp_path / "stats"))
+    g = torch.Generator().manual_seed(123)
+    probe = torch.randn(inter, 8, generator=g, dtype=torch.float64)
+    for li, ln in enumerate(meta["layer_names"]):
+        dw = orc.get_parameter(pipe.text_encoder, ln + ".weight").double() - w0[ln].double()
+        ref = z[f"dw_probe/{li}"]
+        np.testing.assert_allclose((dw @ probe).numpy(), ref, rtol=0, atol=1e-6 * np.abs(ref).max())
+        np.testing.assert_allclose(dw.norm().item(), float(z[f"dw_fro/{li}"]), rtol=1e-6)
