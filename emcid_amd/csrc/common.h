@@ -1,0 +1,51 @@
+// Shared host-side helpers for the emcid HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/emcid_hip.h"
+
+namespace emcid {
+
+extern thread_local char g_last_error[512];
+
+inline int fail(int code, const char* fn, const char* what) {
+    snprintf(g_last_error, sizeof(g_last_error), "%s: %s", fn, what);
+    return code;
+}
+
+inline int check_launch(const char* fn) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_last_error, sizeof(g_last_error), "%s: HIP error: %s", fn, hipGetErrorString(e));
+        return EMCID_ERR_HIP;
+    }
+    return EMCID_OK;
+}
+
+#define EMCID_CHECK_ARG(cond)                                                                   \
+    do {                                                                                        \
+        if (!(cond)) return ::emcid::fail(EMCID_ERR_BAD_ARG, __func__, "bad argument: " #cond); \
+    } while (0)
+
+#define EMCID_CHECK_LAUNCH()                          \
+    do {                                              \
+        int rc_ = ::emcid::check_launch(__func__);    \
+        if (rc_) return rc_;                          \
+    } while (0)
+
+#define EMCID_TRY(call)            \
+    do {                           \
+        int rc_ = (call);          \
+        if (rc_) return rc_;       \
+    } while (0)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+constexpr int NB = 128;  // Cholesky / TRSM block size (diagonal leaf)
+constexpr int NPAD = 64; // concept-count padding of the f64 K / X / R stacks
+
+}  // namespace emcid

@@ -1,0 +1,223 @@
+// fp64 MFMA tile GEMM for gfx950 (v_mfma_f64_16x16x4_f64), the contraction engine under the
+// Stage-2 closed form: SYRK (K^T K), Cholesky panel / trailing updates, blocked TRSM, dW = R^T X.
+//
+//   D[m][n] = sum_k opA(m,k) * opB(k,n),   epilogue functor decides what happens to D.
+//
+// Operand storage is a template flag per operand:
+//   KC = true  : stored [rows][K]  (K contiguous)  -> LDS image [rows][BK+2]
+//   KC = false : stored [K][rows]  (rows contiguous) -> LDS image [BK][rows+16]
+// Both images are straight 16-B copies of global memory (no transpose pass) and both give
+// conflict-free ds_read_b64 fragment reads: the f64 MFMA takes ONE double per lane,
+// A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15].
+//   KC image : lane address = (r0 + lane&15)*(BK+2) + k0 + (lane>>4): row stride 36 dwords ->
+//              the 16 rows of a k-pair land on 16 distinct 4-dword bank groups, k and k+1 on the
+//              two halves of each group (64 banks, each used once per 32-lane half).
+//   !KC image: lane address = (k0 + lane>>4)*(rows+16) + r0 + (lane&15): 16 consecutive doubles
+//              per k row; row stride == 32 (mod 64) dwords so k and k+1 use opposite bank halves.
+// C/D layout of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg  (NOT the f32 map).
+//
+// Pipeline: register-staged double buffering (global_load_dwordx4 for tile t+1 issued before the
+// MFMAs of tile t, ds_write_b128 after them, one barrier per K tile).  An f64 MFMA holds its SIMD
+// for 64 cycles, so staging traffic hides under the matrix pipe at one or two waves per SIMD.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace emcid {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+template <bool KC, int ROWS, int BK>
+struct OpTile {
+    static constexpr int LD = KC ? (BK + 2) : (ROWS + 16);
+    static constexpr int SIZE = KC ? ROWS * LD : BK * LD;  // doubles
+    static constexpr int NVEC = ROWS * BK / 2;             // 16-byte vectors per tile
+    __device__ static __forceinline__ int off(int r, int k) { return KC ? r * LD + k : k * LD + r; }
+};
+
+// Loads this thread's share of a (ROWS x BK) operand tile into registers, zero-filling out of range.
+template <bool KC, int ROWS, int BK, int NT>
+__device__ __forceinline__ void load_tile(v2d (&reg)[ROWS * BK / 2 / NT], const double* __restrict__ g, int64_t ld,
+                                          int row0, int rows_total, int k0, int K, int tid) {
+    constexpr int NV = ROWS * BK / 2 / NT;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * NT;
+        v2d x = {0.0, 0.0};
+        if (KC) {
+            const int r = row0 + v / (BK / 2);
+            const int k = k0 + 2 * (v % (BK / 2));
+            if (r < rows_total) {
+                const double* p = g + (int64_t)r * ld + k;
+                if (k + 1 < K) x = *reinterpret_cast<const v2d*>(p);
+                else if (k < K) x[0] = p[0];
+            }
+        } else {
+            const int k = k0 + v / (ROWS / 2);
+            const int r = row0 + 2 * (v % (ROWS / 2));
+            if (k < K) {
+                const double* p = g + (int64_t)k * ld + r;
+                if (r + 1 < rows_total) x = *reinterpret_cast<const v2d*>(p);
+                else if (r < rows_total) x[0] = p[0];
+            }
+        }
+        reg[i] = x;
+    }
+}
+
+template <bool KC, int ROWS, int BK, int NT>
+__device__ __forceinline__ void store_tile(const v2d (&reg)[ROWS * BK / 2 / NT], double* lds, int tid) {
+    constexpr int NV = ROWS * BK / 2 / NT;
+    using T = OpTile<KC, ROWS, BK>;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * NT;
+        int o;
+        if (KC) o = (v / (BK / 2)) * T::LD + 2 * (v % (BK / 2));
+        else    o = (v / (ROWS / 2)) * T::LD + 2 * (v % (ROWS / 2));
+        *reinterpret_cast<v2d*>(lds + o) = reg[i];
+    }
+}
+
+struct GemmShape {
+    const double* A; int64_t lda;
+    const double* B; int64_t ldb;
+    int M, N, K;
+    int lower_only;  // skip output tiles that lie entirely above the diagonal (SYRK / Cholesky updates)
+};
+
+// WGM x WGN waves per workgroup; each wave owns a (BM/WGM) x (BN/WGN) sub-tile.
+template <bool KCA, bool KCB, int BM, int BN, int BK, int WGM, int WGN, class Epi>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Epi epi) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int MI = WM / 16, NI = WN / 16;
+    using TA = OpTile<KCA, BM, BK>;
+    using TB = OpTile<KCB, BN, BK>;
+    constexpr int STAGE = TA::SIZE + TB::SIZE;
+    __shared__ __attribute__((aligned(16))) double smem[2 * STAGE];
+
+    const int bm = blockIdx.y, bn = blockIdx.x;
+    const int m0 = bm * BM, n0 = bn * BN;
+    if (p.lower_only && n0 > m0 + BM - 1) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    v4d acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    v2d ra[TA::NVEC / NT], rb[TB::NVEC / NT];
+    load_tile<KCA, BM, BK, NT>(ra, p.A, p.lda, m0, p.M, 0, p.K, tid);
+    load_tile<KCB, BN, BK, NT>(rb, p.B, p.ldb, n0, p.N, 0, p.K, tid);
+    store_tile<KCA, BM, BK, NT>(ra, smem, tid);
+    store_tile<KCB, BN, BK, NT>(rb, smem + TA::SIZE, tid);
+    __syncthreads();
+
+    const int T = (p.K + BK - 1) / BK;
+    for (int t = 0; t < T; ++t) {
+        const double* As = smem + (t & 1) * STAGE;
+        const double* Bs = As + TA::SIZE;
+        const bool more = (t + 1 < T);
+        if (more) {
+            load_tile<KCA, BM, BK, NT>(ra, p.A, p.lda, m0, p.M, (t + 1) * BK, p.K, tid);
+            load_tile<KCB, BN, BK, NT>(rb, p.B, p.ldb, n0, p.N, (t + 1) * BK, p.K, tid);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            double a[MI], b[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = As[TA::off(wm0 + i * 16 + l15, kk * 4 + l4)];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) b[j] = Bs[TB::off(wn0 + j * 16 + l15, kk * 4 + l4)];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            double* An = smem + ((t + 1) & 1) * STAGE;
+            store_tile<KCA, BM, BK, NT>(ra, An, tid);
+            store_tile<KCB, BN, BK, NT>(rb, An + TA::SIZE, tid);
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm0 + i * 16 + l4 + 4 * r;
+                const int n = n0 + wn0 + j * 16 + l15;
+                if (m < p.M && n < p.N) epi(m, n, acc[i][j][r]);
+            }
+}
+
+// ---- epilogues -------------------------------------------------------------------------------
+
+// C = alpha * D + beta * C
+struct EpiAxpby {
+    double* C; int64_t ldc; double alpha, beta;
+    __device__ __forceinline__ void operator()(int m, int n, double v) const {
+        double* c = C + (int64_t)m * ldc + n;
+        *c = (beta != 0.0) ? alpha * v + beta * *c : alpha * v;
+    }
+};
+
+// A = lam * double(fl32(fl32(C * cw) / 0.5f)) + D inside [0,d)^2 ; identity outside (padding to dp).
+// reference: emcid/emcid_main.py:1037 (`cov * (1 - edit_weight) / 0.5`, fp32) and :1046 (`lam * cov.double() + K K^T`).
+struct EpiAssemble {
+    const float* Cf; int64_t ldcf; double lam; float cw; double* A; int64_t lda; int d;
+    __device__ __forceinline__ void operator()(int m, int n, double v) const {
+        double out;
+        if (m < d && n < d) {
+            const float c1 = Cf[(int64_t)m * ldcf + n] * cw;
+            const float c2 = c1 / 0.5f;
+            out = lam * (double)c2 + v;
+        } else {
+            out = (m == n) ? 1.0 : 0.0;
+        }
+        A[(int64_t)m * lda + n] = out;
+    }
+};
+
+// U = D (f64, optional); dW = float(D) (optional); W = W0 + float(D) (optional).
+// reference: emcid/emcid_main.py:1050 (`resid @ adj_k.T`) and :1061 (`weights_copy + upd_matrix.float()`).
+struct EpiDeltaW {
+    const float* W0; float* W; int64_t ldw; float* dW; int64_t lddw; double* U; int64_t ldu;
+    __device__ __forceinline__ void operator()(int m, int n, double v) const {
+        const float f = (float)v;
+        if (U) U[(int64_t)m * ldu + n] = v;
+        if (dW) dW[(int64_t)m * lddw + n] = f;
+        if (W) W[(int64_t)m * ldw + n] = W0[(int64_t)m * ldw + n] + f;
+    }
+};
+
+// ---- launcher ----------------------------------------------------------------------------------
+
+template <bool KCA, bool KCB, class Epi>
+inline void launch_gemm_f64(const GemmShape& p, const Epi& epi, hipStream_t stream, int force_cfg = -1) {
+    // big tiles when they still fill the chip, else 64x64 tiles (4x the workgroups).
+    const int64_t tm = (p.M + 127) / 128, tn = (p.N + 127) / 128;
+    int64_t big_tiles = p.lower_only ? tm * (tm + 1) / 2 : tm * tn;
+    int cfg = (big_tiles >= 224) ? 0 : 1;
+    if (force_cfg >= 0) cfg = force_cfg;
+    if (cfg == 0) {
+        dim3 grid((p.N + 127) / 128, (p.M + 127) / 128);
+        hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 128, 128, 16, 2, 2, Epi>), grid, dim3(256), 0, stream, p, epi);
+    } else {
+        dim3 grid((p.N + 63) / 64, (p.M + 63) / 64);
+        hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 64, 64, 16, 2, 2, Epi>), grid, dim3(256), 0, stream, p, epi);
+    }
+}
+
+}  // namespace emcid

@@ -1,0 +1,203 @@
+"""ctypes binding of the C-ABI kernel library (include/emcid_hip.h -> csrc/libemcid_hip.so).
+
+There is NO fallback: if the library is missing or a call fails, the product path raises.
+torch is used here only to hand over device pointers and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libemcid_hip.so"
+_lib = None
+
+EXPORTS = [
+    "emcid_abi_version", "emcid_last_error", "emcid_gram_accumulate_f32", "emcid_symmetrize_lower_f32",
+    "emcid_gather_mean_f32", "emcid_edit_workspace_bytes", "emcid_edit_layer_f64", "emcid_assemble_spd_f64",
+    "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_axpy_f32",
+]
+
+ABI_VERSION = 1
+NB = 128      # Cholesky block (csrc/common.h)
+NPAD = 64     # concept padding of the f64 stacks (csrc/common.h)
+
+
+class EmcidHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load():
+    """dlopen the kernel library (works without a GPU: used by the CPU symbol-export test)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise EmcidHipError(
+            f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C {_LIB_PATH.parent}`. The MI355X path has no CPU fallback.")
+    lib = C.CDLL(str(_LIB_PATH))
+    p, i64, i32, f64, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_double, C.c_float
+    sig = {
+        "emcid_abi_version": (i32, []),
+        "emcid_last_error": (C.c_char_p, []),
+        "emcid_gram_accumulate_f32": (i32, [p, i64, i64, i64, p, i64, i32, p]),
+        "emcid_symmetrize_lower_f32": (i32, [p, i64, i64, p]),
+        "emcid_gather_mean_f32": (i32, [p, i64, i64, i64, i64, i64, p, p, i64, p, i64, p]),
+        "emcid_edit_workspace_bytes": (i64, [i64, i64, i64]),
+        "emcid_edit_layer_f64": (i32, [p, p, p, p, i64, i64, i64, f64, f64, i32, p, p, p, p, p, p, i64, p, p]),
+        "emcid_assemble_spd_f64": (i32, [p, i64, p, i64, i64, i64, f64, f32, p, i64, p]),
+        "emcid_cholesky_f64": (i32, [p, p, i64, i64, p, p, p]),
+        "emcid_cholesky_solve_f64": (i32, [p, i64, i64, p, p, p, i64, i64, p]),
+        "emcid_delta_w_f64": (i32, [p, i64, p, i64, i64, i64, i64, p, p, i64, p, p, p]),
+        "emcid_dgemm_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, p]),
+        "emcid_axpy_f32": (i32, [p, p, i64, p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    if lib.emcid_abi_version() != ABI_VERSION:
+        raise EmcidHipError(f"ABI mismatch: library {lib.emcid_abi_version()} vs binding {ABI_VERSION}; rebuild csrc/")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise EmcidHipError(f"{what} failed (rc={rc}): {load().emcid_last_error().decode()}")
+
+
+def _ptr(t: Optional[torch.Tensor], dtype=None, what="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise EmcidHipError(f"{what} must live in HBM (got device {t.device}); there is no CPU path")
+    if dtype is not None and t.dtype != dtype:
+        raise EmcidHipError(f"{what} must be {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+# ---- Stage 0 -----------------------------------------------------------------------------------------
+
+def gram_accumulate_(G: torch.Tensor, X: torch.Tensor, ksplit: int = 0):
+    """G (d,d) fp32 lower triangle += X^T X, X (t,d) fp32 with row stride multiple of 4 (runningstats.py:493)."""
+    assert X.dim() == 2 and G.dim() == 2 and G.shape[0] == G.shape[1] == X.shape[1]
+    assert X.stride(1) == 1 and G.stride(1) == 1
+    if X.shape[0] == 0:
+        return G
+    _check(load().emcid_gram_accumulate_f32(_ptr(X, torch.float32, "X"), X.shape[0], X.shape[1], X.stride(0),
+                                            _ptr(G, torch.float32, "G"), G.stride(0), ksplit, _stream(G)),
+           "emcid_gram_accumulate_f32")
+    return G
+
+
+def symmetrize_lower_(G: torch.Tensor):
+    _check(load().emcid_symmetrize_lower_f32(_ptr(G, torch.float32, "G"), G.shape[0], G.stride(0), _stream(G)),
+           "emcid_symmetrize_lower_f32")
+    return G
+
+
+# ---- K/Z assembly -------------------------------------------------------------------------------------
+
+def gather_mean(act: torch.Tensor, idx: torch.Tensor, seg: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """act (B,S,c) fp32, idx (B,) int64 token position per prompt, seg (N+1,) int64 prompt offsets per request."""
+    assert act.dim() == 3 and act.stride(2) == 1
+    B, S, c = act.shape
+    N = seg.numel() - 1
+    assert idx.numel() == B
+    if out is None:
+        out = torch.empty(N, c, dtype=torch.float32, device=act.device)
+    _check(load().emcid_gather_mean_f32(_ptr(act, torch.float32, "act"), B, S, c, act.stride(0), act.stride(1),
+                                        _ptr(idx, torch.int64, "idx"), _ptr(seg, torch.int64, "seg"), N,
+                                        _ptr(out, torch.float32, "out"), out.stride(0), _stream(act)),
+           "emcid_gather_mean_f32")
+    return out
+
+
+# ---- Stage 2 ------------------------------------------------------------------------------------------
+
+def edit_workspace_bytes(N: int, d: int, h: int) -> int:
+    return int(load().emcid_edit_workspace_bytes(N, d, h))
+
+
+class EditWorkspace:
+    """Reusable HBM workspace (+ the device `info` word) for emcid_edit_layer_f64."""
+
+    def __init__(self, N: int, d: int, h: int, device):
+        self.key = (N, d, h)
+        self.nbytes = edit_workspace_bytes(N, d, h)
+        self.buf = torch.empty(self.nbytes // 8, dtype=torch.float64, device=device)
+        self.info = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def edit_layer(K, Zc, zs_t, Cov, lam: float, edit_weight: float, layers_left: int, W0=None, W=None,
+               want_factors: bool = False, want_dw: bool = True, ws: Optional[EditWorkspace] = None):
+    """One edited layer of emcid_main.py:1016-1061 on the GPU.  Returns dict(Xt, Rt, dW) (entries may be None)."""
+    N, d = K.shape
+    h = Zc.shape[1]
+    assert Cov.shape == (d, d) and zs_t.shape == (N, h) and Zc.shape == (N, h)
+    for t, nm in ((K, "K"), (Zc, "Zc"), (zs_t, "zs_t"), (Cov, "C")):
+        assert t.is_contiguous(), nm
+    if ws is None or ws.key != (N, d, h):
+        ws = EditWorkspace(N, d, h, K.device)
+    dev = K.device
+    Xt = torch.empty(N, d, dtype=torch.float64, device=dev) if want_factors else None
+    Rt = torch.empty(N, h, dtype=torch.float64, device=dev) if want_factors else None
+    dW = torch.empty(h, d, dtype=torch.float32, device=dev) if want_dw else None
+    if W is not None:
+        assert W.is_contiguous() and W.shape == (h, d) and W0 is not None and W0.is_contiguous()
+    _check(load().emcid_edit_layer_f64(
+        _ptr(K, torch.float32, "K"), _ptr(Zc, torch.float32, "Zc"), _ptr(zs_t, torch.float32, "zs_t"),
+        _ptr(Cov, torch.float32, "C"), N, d, h, float(lam), float(edit_weight), int(layers_left),
+        _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"), _ptr(Xt), _ptr(Rt), _ptr(dW),
+        _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32, "info"), _stream(K)), "emcid_edit_layer_f64")
+    return {"Xt": Xt, "Rt": Rt, "dW": dW, "ws": ws}
+
+
+def dgemm(ta: int, tb: int, A, B, Cm, alpha=1.0, beta=0.0, M=None, N=None, K=None):
+    """Test hook for the fp64 MFMA GEMM. ta/tb = 0: operand stored [rows][K]; 1: stored [K][rows]."""
+    M = M if M is not None else (A.shape[0] if ta == 0 else A.shape[1])
+    K = K if K is not None else (A.shape[1] if ta == 0 else A.shape[0])
+    N = N if N is not None else (B.shape[0] if tb == 0 else B.shape[1])
+    _check(load().emcid_dgemm_f64(ta, tb, M, N, K, float(alpha), _ptr(A, torch.float64), A.stride(0),
+                                  _ptr(B, torch.float64), B.stride(0), float(beta), _ptr(Cm, torch.float64),
+                                  Cm.stride(0), _stream(Cm)), "emcid_dgemm_f64")
+    return Cm
+
+
+def axpy_(W: torch.Tensor, dW: torch.Tensor):
+    """W += dW, fp32 (emcid_main.py:809)."""
+    assert W.is_contiguous() and dW.is_contiguous() and W.numel() == dW.numel()
+    _check(load().emcid_axpy_f32(_ptr(W, torch.float32, "W"), _ptr(dW, torch.float32, "dW"), W.numel(), _stream(W)),
+           "emcid_axpy_f32")
+    return W
+
+
+def cholesky(A: torch.Tensor):
+    """Test hook: A (dp,dp) f64 contiguous, dp % 128 == 0.  Returns (L, invdiag, info)."""
+    dp = A.shape[0]
+    L = torch.zeros_like(A)
+    inv = torch.empty(dp // NB, NB, NB, dtype=torch.float64, device=A.device)
+    info = torch.zeros(1, dtype=torch.int32, device=A.device)
+    _check(load().emcid_cholesky_f64(_ptr(A, torch.float64), _ptr(L), dp, A.stride(0), _ptr(inv), _ptr(info), _stream(A)),
+           "emcid_cholesky_f64")
+    return L, inv, info
+
+
+def cholesky_solve_(L, inv, Bt):
+    """Test hook: Bt (Np,dp) f64 := Bt (L L^T)^{-1}."""
+    Y = torch.empty_like(Bt)
+    _check(load().emcid_cholesky_solve_f64(_ptr(L, torch.float64), L.shape[0], L.stride(0), _ptr(inv), _ptr(Bt), _ptr(Y),
+                                           Bt.shape[0], Bt.stride(0), _stream(Bt)), "emcid_cholesky_solve_f64")
+    return Bt

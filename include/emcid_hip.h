@@ -1,0 +1,118 @@
+/*
+ * emcid_hip.h — C ABI of the MI355X (gfx950) kernels under EMCID's closed-form mass-edit path.
+ *
+ * The reference (SilentView/EMCID) has no FFI: its boundary is the Python call
+ * apply_emcid_to_text_encoder (reference: emcid/emcid_main.py:769).  This library sits UNDER the
+ * Python mirror of that call (emcid_amd/emcid_main.py) and replaces the ATen ops the reference
+ * dispatches on the hot path.  Each entry point cites the reference line(s) it replaces.
+ *
+ * Conventions: all pointers are DEVICE pointers (HBM) unless named *_host; matrices are row-major
+ * with explicit leading dimensions in ELEMENTS; `stream` is a hipStream_t passed as void*; every
+ * call is asynchronous on `stream` and returns 0 (EMCID_OK) or a negative error code — no
+ * exceptions cross the ABI; the caller owns every buffer.  f64 buffers and leading dimensions must
+ * be 16-byte aligned / even (checked: EMCID_ERR_BAD_ARG).
+ */
+#ifndef EMCID_HIP_H
+#define EMCID_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMCID_OK 0
+#define EMCID_ERR_BAD_ARG (-1)
+#define EMCID_ERR_HIP (-2)
+#define EMCID_ERR_WORKSPACE (-3)
+
+#define EMCID_ABI_VERSION 1
+
+/* ABI version of the loaded library (host-only, no GPU needed). */
+int emcid_abi_version(void);
+/* Human-readable text of the last error on this thread (host-only). */
+const char* emcid_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage 0 — second moment.  Replaces `self.mom2 += a.t().mm(a)` (reference:
+ * util/runningstats.py:493) for a = X[t, d] fp32.  Only the LOWER triangle (incl. diagonal) of
+ * G[d, d] is accumulated (SYRK, T*d^2 flops instead of the reference's 2*T*d^2 GEMM);
+ * emcid_symmetrize_lower_f32 mirrors it when the moment is read (runningstats.py:499-507).
+ * ksplit > 1 splits the token dimension over workgroups that add their partial tiles with fp32
+ * atomics (not bitwise reproducible run to run); ksplit == 1 is deterministic.
+ * ------------------------------------------------------------------------------------------- */
+int emcid_gram_accumulate_f32(const float* X, int64_t t, int64_t d, int64_t ldx,
+                              float* G, int64_t ldg, int ksplit, void* stream);
+int emcid_symmetrize_lower_f32(float* G, int64_t d, int64_t ldg, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K/Z assembly gather.  Replaces the N*P Python indexings + per-request `.mean(0)` of
+ * get_module_input_output_at_words (reference: emcid/compute_z.py:2311-2325):
+ *   out[n, :] = ( sum_{p in [seg[n], seg[n+1])} act[p, idx[p], :] ) / (seg[n+1]-seg[n])
+ * summed in prompt order, fp32, true division (bit-compatible with torch-CPU mean over <= 8 rows).
+ * act is [B, S, c] with row stride lds_ (elements between consecutive s) and batch stride ldb.
+ * ------------------------------------------------------------------------------------------- */
+int emcid_gather_mean_f32(const float* act, int64_t B, int64_t S, int64_t c, int64_t ldb, int64_t lds_,
+                          const int64_t* idx, const int64_t* seg, int64_t N,
+                          float* out, int64_t ldo, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage 2 — per-layer closed form (reference: emcid/emcid_main.py:1016-1061).
+ *
+ * emcid_edit_workspace_bytes: bytes of f64 workspace emcid_edit_layer_f64 needs for (N, d, h).
+ *
+ * emcid_edit_layer_f64 does, for one edited layer, entirely on `stream`:
+ *   s    = sqrt(edit_weight/0.5)
+ *   Kt64 = double(K) * s                                   (:1040-1043)   K   [N, d] fp32
+ *   Rt   = double(zs_t - Zc) * s / layers_left             (:1016,:1049)  zs_t, Zc [N, h] fp32
+ *   A    = lam * double(C * (1-edit_weight) / 0.5) + Kt64^T Kt64   (:1037,:1046)  C [d, d] fp32
+ *   A    = L L^T  (blocked Cholesky, fp64 MFMA); Xt = Kt64 A^{-1}  (:1045-1048; Xt[n,:] = adj_k[:,n])
+ *   U    = Rt^T Xt            [h, d] f64                     (:1050)
+ *   W    = W0 + float(U)      [h, d] fp32                    (:1061)
+ * Outputs (any may be NULL to skip): Xt_out [N, d] f64 (adj_k^T), Rt_out [N, h] f64 (resid^T),
+ * dW_out [h, d] fp32 (= float(U)), W [h, d] fp32.  W0 may alias W.
+ * info_dev: device int; set to (1 + index of the first non-positive pivot) if A is not SPD
+ * (the reference's LU would still return numbers; the caller decides what to do), else left 0.
+ * ------------------------------------------------------------------------------------------- */
+int64_t emcid_edit_workspace_bytes(int64_t N, int64_t d, int64_t h);
+
+int emcid_edit_layer_f64(const float* K, const float* Zc, const float* zs_t, const float* C,
+                         int64_t N, int64_t d, int64_t h,
+                         double lam, double edit_weight, int layers_left,
+                         const float* W0, float* W,
+                         double* Xt_out, double* Rt_out, float* dW_out,
+                         void* workspace, int64_t workspace_bytes, int* info_dev, void* stream);
+
+/* The stages of emcid_edit_layer_f64 as separate calls (used by tests and micro-benchmarks). */
+
+/* A[d,d] (f64, ld lda, LOWER triangle valid) = lam_c * double(fl32(fl32(C*cw)/0.5f)) + Kt64^T Kt64,
+ * Kt64 [Np, d] f64 (rows >= N must be zero).  (:1037, :1046) */
+int emcid_assemble_spd_f64(const float* C, int64_t ldc, const double* Kt64, int64_t Np, int64_t d, int64_t ldk,
+                           double lam, float cw, double* A, int64_t lda, void* stream);
+/* Lower Cholesky A = L L^T of A[dp,dp] (dp a multiple of 128; a caller with d < dp identity-pads rows/cols
+ * d..dp).  A's lower triangle is consumed (overwritten by partial Schur complements); the factor is written
+ * to L (same leading dimension).  invdiag: [dp/128][128][128] f64 receives the inverses of the diagonal
+ * blocks of L (the later triangular solves are MFMA GEMMs against them).
+ * replaces the getrf half of torch.linalg.solve (:1045). */
+int emcid_cholesky_f64(double* A, double* L, int64_t dp, int64_t lda, double* invdiag, int* info_dev, void* stream);
+/* Bt[Np, dp] := Bt A^{-1} given the factor from emcid_cholesky_f64; Yt is [Np, dp] scratch.
+ * replaces the getrs half of torch.linalg.solve (:1045-1048). */
+int emcid_cholesky_solve_f64(const double* L, int64_t dp, int64_t lda, const double* invdiag,
+                             double* Bt, double* Yt, int64_t Np, int64_t ldb, void* stream);
+/* U = Rt^T Xt (f64, optional) ; dW = float(U) (optional) ; W = W0 + float(U) (optional).  (:1050,:1061) */
+int emcid_delta_w_f64(const double* Rt, int64_t ldr, const double* Xt, int64_t ldx, int64_t Np, int64_t h, int64_t d,
+                      const float* W0, float* W, int64_t ldw, float* dW, double* U, void* stream);
+
+/* Plain fp64 MFMA GEMM, exported for tests/micro-benchmarks:
+ * C[M,N] = alpha * opA(A) opB(B) + beta * C ; ta/tb: 0 = stored [rows][K] (K contiguous), 1 = stored [K][rows]. */
+int emcid_dgemm_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
+                    const double* A, int64_t lda, const double* B, int64_t ldb,
+                    double beta, double* C, int64_t ldc, void* stream);
+
+/* W[h,d] += dW[h,d]  (final insert, reference: emcid_main.py:802-809 `w[...] += upd_matrix.float()`). */
+int emcid_axpy_f32(float* W, const float* dW, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMCID_HIP_H */

@@ -1,0 +1,140 @@
+"""GPU parity tests of the HIP kernels, called through the C ABI (emcid_amd.hip -> libemcid_hip.so).
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from emcid_amd import hip
+from oracle import emcid_oracle as orc
+
+DEV = "cuda:0"
+
+
+def _rand(*shape, seed=0, dtype=torch.float64):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=dtype)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 50), (64, 320, 128), (1, 2, 3), (513, 129, 257)])
+def test_dgemm_layouts(ta, tb, M, N, K):
+    """All four operand layouts, ragged sizes, asymmetric data (catches a transposed C write)."""
+    Kp = K + (K % 2)
+    Mp, Np_ = M + (M % 2), N + (N % 2)
+    a = _rand(M, K, seed=1)
+    b = _rand(K, N, seed=2)
+    A = torch.zeros(M, Kp, dtype=torch.float64) if ta == 0 else torch.zeros(K, Mp, dtype=torch.float64)
+    B = torch.zeros(N, Kp, dtype=torch.float64) if tb == 0 else torch.zeros(K, Np_, dtype=torch.float64)
+    if ta == 0: A[:, :K] = a
+    else: A[:, :M] = a.t()
+    if tb == 0: B[:, :K] = b.t()
+    else: B[:, :N] = b
+    c0 = _rand(M, N, seed=3)
+    Cd = c0.clone().to(DEV)
+    hip.dgemm(ta, tb, A.to(DEV), B.to(DEV), Cd, alpha=-0.5, beta=2.0, M=M, N=N, K=K)
+    ref = -0.5 * (a @ b) + 2.0 * c0
+    torch.testing.assert_close(Cd.cpu(), ref, rtol=1e-12, atol=1e-12 * K)
+
+
+def test_dgemm_identity_asymmetric():
+    """A = I with an asymmetric B: catches row<->col swaps in the MFMA C/D map."""
+    n = 256
+    Bm = torch.arange(n * n, dtype=torch.float64).reshape(n, n)
+    out = torch.zeros(n, n, dtype=torch.float64, device=DEV)
+    hip.dgemm(0, 1, torch.eye(n, dtype=torch.float64, device=DEV), Bm.to(DEV), out)
+    assert torch.equal(out.cpu(), Bm)
+
+
+@pytest.mark.parametrize("dp", [128, 384, 1024])
+def test_cholesky_and_solve(dp):
+    x = _rand(dp + 64, dp, seed=4)
+    A = x.t() @ x + 0.5 * torch.eye(dp, dtype=torch.float64)
+    L, inv, info = hip.cholesky(A.clone().to(DEV))
+    assert int(info.item()) == 0
+    Lref = torch.linalg.cholesky(A)
+    torch.testing.assert_close(torch.tril(L.cpu()), Lref, rtol=1e-9, atol=1e-9)
+    for j in range(dp // 128):
+        blk = Lref[j * 128:(j + 1) * 128, j * 128:(j + 1) * 128]
+        torch.testing.assert_close(inv[j].cpu() @ blk, torch.eye(128, dtype=torch.float64), rtol=0, atol=1e-9)
+    Bt = _rand(192, dp, seed=5)
+    X = hip.cholesky_solve_(L, inv, Bt.clone().to(DEV)).cpu()
+    ref = torch.linalg.solve(A, Bt.t()).t()
+    torch.testing.assert_close(X, ref, rtol=1e-8, atol=1e-10)
+
+
+def test_cholesky_reports_non_spd():
+    dp = 256
+    A = torch.eye(dp, dtype=torch.float64)
+    A[130, 130] = -1.0
+    _, _, info = hip.cholesky(A.to(DEV))
+    assert int(info.item()) == 131
+
+
+def _edit_inputs(N, d, h, seed):
+    g = torch.Generator().manual_seed(seed)
+    K = torch.randn(N, d, generator=g) * 0.3
+    Zc = torch.randn(N, h, generator=g)
+    zs = torch.randn(h, N, generator=g)
+    x = torch.randn(2 * d, d, generator=g) * torch.exp(torch.linspace(0, -3, d))
+    Cov = (x.t() @ x) / (2 * d)
+    W0 = torch.randn(h, d, generator=g) * 0.02
+    return K, Zc, zs, Cov, W0
+
+
+@pytest.mark.parametrize("N,d,h,lam,ew,left", [(8, 128, 32, 50.0, 0.6, 3), (5, 192, 48, 90.0, 0.5, 1),
+                                              (100, 3072, 768, 4000.0, 0.5, 4), (1000, 3072, 768, 4000.0, 0.5, 2),
+                                              (1, 3072, 768, 4000.0, 0.5, 1), (130, 5120, 1280, 10000.0, 0.5, 5)])
+def test_edit_layer_vs_oracle(N, d, h, lam, ew, left):
+    """The whole per-layer closed form against the oracle's fp64 LU restatement on identical inputs.
+    Bar (BASELINE.json): dW max-abs error < 1e-4 and <= 1e-4 relative; observed ~1e-12."""
+    K, Zc, zs, Cov, W0 = _edit_inputs(N, d, h, seed=N + d)
+    adj_k, resid, upd = orc.closed_form_layer(K, Zc, zs, Cov, lam, ew, left)
+    Wd = torch.empty(h, d, dtype=torch.float32, device=DEV)
+    out = hip.edit_layer(K.to(DEV), Zc.to(DEV), zs.t().contiguous().to(DEV), Cov.to(DEV), lam, ew, left,
+                         W0=W0.to(DEV), W=Wd, want_factors=True)
+    assert int(out["ws"].info.item()) == 0
+    scale = upd.abs().max().item()
+    torch.testing.assert_close(out["Rt"].cpu(), resid.t().contiguous(), rtol=1e-14, atol=0)
+    assert (out["Xt"].cpu() - adj_k.t()).abs().max().item() <= 1e-9 * adj_k.abs().max().item()
+    dw_err = (out["dW"].cpu().double() - upd).abs().max().item()
+    assert dw_err <= 1e-6 * scale + 1e-12, (dw_err, scale)        # fp32 rounding of U only
+    assert dw_err < 1e-4
+    w_ref = W0 + upd.float()
+    assert (Wd.cpu() - w_ref).abs().max().item() <= 1e-6 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("t,d,ksplit", [(300, 128, 1), (1000, 3072, 1), (3072, 3072, 0), (17, 200, 1), (4097, 5120, 0)])
+def test_gram_accumulate(t, d, ksplit):
+    """G += X^T X (lower) then mirrored; twice, to check accumulation.  fp32: toleranced, not bitwise."""
+    X1 = _rand(t, d, seed=6, dtype=torch.float32)
+    X2 = _rand(t, d, seed=7, dtype=torch.float32)
+    G = torch.zeros(d, d, dtype=torch.float32, device=DEV)
+    hip.gram_accumulate_(G, X1.to(DEV), ksplit)
+    hip.gram_accumulate_(G, X2.to(DEV), ksplit)
+    hip.symmetrize_lower_(G)
+    ref = X1.double().t() @ X1.double() + X2.double().t() @ X2.double()
+    err = (G.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-6 * ref.abs().max().item() * np.sqrt(t / 100 + 1), err
+    assert torch.equal(G, G.t())
+
+
+def test_gram_empty_batch_is_noop():
+    G = torch.ones(128, 128, dtype=torch.float32, device=DEV)
+    hip.gram_accumulate_(G, torch.empty(0, 128, dtype=torch.float32, device=DEV))
+    assert torch.equal(G.cpu(), torch.ones(128, 128))
+
+
+def test_gather_mean_bitwise_vs_torch_cpu():
+    """Ragged prompt counts; bit-exact against torch-CPU's stack(...).mean(0) (compute_z.py:2311-2325)."""
+    g = torch.Generator().manual_seed(8)
+    B, S, c = 23, 11, 3072
+    act = torch.randn(B, S, c, generator=g)
+    idx = torch.randint(0, S, (B,), generator=g)
+    counts = [1, 3, 2, 5, 3, 1, 8]
+    seg = torch.tensor(np.cumsum([0] + counts))
+    rows = torch.stack([act[i, idx[i]] for i in range(B)])
+    ref = torch.stack([rows[seg[i]:seg[i + 1]].mean(0) for i in range(len(counts))])
+    out = hip.gather_mean(act.to(DEV), idx.to(DEV), seg.to(DEV))
+    assert torch.equal(out.cpu(), ref)
