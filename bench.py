@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py — concept-edits/sec of the closed-form mass-edit path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+
+Workload (config.workload): the 1 000-concept batch on SD-v1.4 dims the metric is quoted on — CLIP ViT-L/14
+text encoder (768 / 3072 / 12 layers, random init), layers [7, 8, 9, 10], lambda = 4000, edit_weight 0.5,
+3 prompts per concept, synthetic v* and synthetic second moments C_l (no network for real weights/captions).
+A STEP is one pass of the hot path over that batch with every input resident in HBM (token ids, lookup
+indices, v*, C_l, encoder weights): restore the original fc2 weights, then edit_engine.run_encoder_edit —
+one partial encoder forward whose fc2 hooks run gather -> assemble -> Cholesky -> TRSM -> dW on the HIP
+kernels.  Host preparation (tokenizer, subject search, npz reads) happens once before the timed region and is
+reported separately as `host_prepare_ms` (DESIGN.md §Measurement gives the all-inclusive rate).
+With N > 1 the 1 000 concepts are sharded over the ranks (strong scaling, fixed total work): each rank
+forwards its shard, K/Zc are all-gathered over RCCL per layer, every rank solves and updates redundantly.
+
+`roofline`: the fp64 MFMA Cholesky trailing-update GEMM is the dominant HIP kernel class of a step; its
+launches are bracketed with HIP events on the launch stream inside the timed region (emcid_profile_*).
+`cpu_baseline`: the oracle (op-for-op CPU port of the reference path) timed on the host cores on a
+100-concept sample of the same workload, rank 0, N == 1 only; the same run yields `dw_max_abs_err`.
+"""
+import argparse
+import json
+import os
+import shutil
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import torch
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak [external: AMD MI355X datasheet; MI355X_MICROARCH.md lists no fp64 row]
+LAYERS = (7, 8, 9, 10)
+LAM, EW = 4000, 0.5
+KIND = "sd-v1.4"
+
+
+def build_inputs(n_concepts, device, workdir, shard=None):
+    from emcid_amd import emcid_main as em, synthetic as syn
+    from emcid_amd.emcid_hparams import EMCIDHyperParams
+
+    pipe = syn.build_pipe(KIND, device)
+    hidden, inter = syn.ENCODER_DIMS[KIND][:2]
+    reqs = syn.make_requests(n_concepts)
+    hp_d = syn.sd_hparams_dict(layers=LAYERS, mom2_update_weight=LAM, edit_weight=EW)
+    cache = str(Path(workdir) / f"cache_{n_concepts}") + "/"
+    stats = Path(workdir) / "stats"
+    layer_names = [hp_d["rewrite_module_tmp"].format(l) for l in LAYERS]
+    if not Path(cache).exists():
+        syn.write_vstar_cache(cache, reqs, hidden, seed=1, scale=0.5)
+    if not stats.exists():
+        syn.write_stats_cache(stats, layer_names, inter, hp_d["mom2_n_samples"], seed=2, t=2 * inter)
+    return pipe, reqs, hp_d, cache, str(stats), layer_names
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--concepts", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from emcid_amd import emcid_main as em, hip
+    from emcid_amd.edit_engine import ConceptShard, run_encoder_edit, check_info
+    from emcid_amd.emcid_hparams import EMCIDHyperParams
+    from emcid_amd.nethook import get_parameter
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(device))
+    shard = ConceptShard(rank, world, None)
+
+    workdir = Path(tempfile.gettempdir()) / f"emcid_bench_{os.getuid()}"
+    if rank == 0:
+        workdir.mkdir(exist_ok=True)
+        build_inputs(args.concepts, "cpu", workdir)     # writes the synthetic v*/stats caches once
+    if world > 1:
+        dist.barrier()
+    pipe, reqs, hp_d, cache, stats, layer_names = build_inputs(args.concepts, device, workdir)
+
+    # ---- host preparation (outside the timed region): tokenizer, subject search, v*/C reads -> HBM ----------
+    hp = EMCIDHyperParams(**hp_d)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan = em.prepare_text_encoder_edit(pipe.text_encoder, pipe.tokenizer, reqs, hp, hp.layers, hp.mom2_update_weight,
+                                        stats, cache, "", verbose=False, shard=shard)
+    torch.cuda.synchronize()
+    host_prepare_ms = (time.perf_counter() - t0) * 1e3
+    originals = {l: get_parameter(pipe.text_encoder, plan.weight_name(l)).detach().clone() for l in LAYERS}
+
+    def step():
+        with torch.no_grad():
+            for l in LAYERS:
+                get_parameter(pipe.text_encoder, plan.weight_name(l)).copy_(originals[l])
+        return run_encoder_edit(plan, keep_factors=False, restore=False)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    prof_cls = "chol_trail"
+    hip.profile_enable([prof_cls])
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = hip.profile_collect()
+    hip.profile_enable([])
+    check_info(plan)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    value = args.concepts * args.steps / elapsed
+    d = 3072
+    # algorithmic flops of the dominant kernel class per launch: the right-looking trailing updates of one
+    # Cholesky sum to d^3/3 minus the leaf+panel share; per launch = that / (d/128 - 1) launches.
+    nb = d // 128
+    trail_flops_per_layer = sum((d - (j + 1) * 128) ** 2 * 128 for j in range(nb - 1))   # SYRK count m^2 * k
+    ms, launches = prof.get(prof_cls, (0.0, 0))
+    roofline = None
+    if launches:
+        flops_per_launch = trail_flops_per_layer / (nb - 1)
+        avg_s = ms * 1e-3 / launches
+        achieved = flops_per_launch / avg_s / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_f64_kernel<KC,KC,64,64,16,EpiAxpby> (Cholesky trailing update)",
+                    "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_us": avg_s * 1e6, "launches": launches}
+
+    out = {
+        "metric": "concept-edits/sec (1 000-concept batch, SD-v1.4)", "value": value, "unit": "concept-edits/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.concepts}-concept edit, SD-v1.4 text-encoder dims (768/3072/12L), layers 7-10, "
+                               f"lambda 4000, 3 prompts/concept, v* and C_l pre-cached in HBM",
+                   "concepts": args.concepts, "prompts": plan.batch.n_prompts * world if world == 1 else None,
+                   "seq_len": int(plan.batch.inputs["input_ids"].shape[1]), "parallelism": f"concept-shard x{world}"},
+        "host_prepare_ms": host_prepare_ms,
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out.update(cpu_baseline_and_error(workdir, device))
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_and_error(workdir, device, n_sample=100):
+    """Oracle on the host cores over a 100-concept sample of the workload + dW error of the HIP path on it."""
+    import copy
+    from emcid_amd import emcid_main as em, synthetic as syn
+    from emcid_amd.emcid_hparams import EMCIDHyperParams
+    from emcid_amd.nethook import get_parameter
+    from oracle import emcid_oracle as orc
+
+    cores = torch.get_num_threads()
+    pipe_c, reqs, hp_d, cache, stats, layer_names = build_inputs(n_sample, "cpu", workdir)
+    w0 = {ln: orc.get_parameter(pipe_c.text_encoder, ln + ".weight").clone() for ln in layer_names}
+    t0 = time.perf_counter()
+    orc.apply_emcid_to_text_encoder(pipe_c, reqs, copy.deepcopy(hp_d), cache_name=cache, stats_dir=stats)
+    cpu_s = time.perf_counter() - t0
+    pipe_g = syn.build_pipe(KIND, device)
+    em.apply_emcid_to_text_encoder(pipe_g, reqs, EMCIDHyperParams(**hp_d), device, cache_name=cache, stats_dir=stats,
+                                   verbose=False)
+    err_abs, err_rel = 0.0, 0.0
+    for ln in layer_names:
+        ref = orc.get_parameter(pipe_c.text_encoder, ln + ".weight").double() - w0[ln].double()
+        got = get_parameter(pipe_g.text_encoder, ln + ".weight").cpu().double() - w0[ln].double()
+        e = (got - ref).abs().max().item()
+        err_abs = max(err_abs, e)
+        err_rel = max(err_rel, e / ref.abs().max().item())
+    return {"cpu_baseline": {"value": n_sample / cpu_s, "unit": "concept-edits/s", "cores": cores, "kind": "port",
+                             "sample": f"{n_sample}-concept edit (300 prompts), same dims/layers/lambda, one run of the "
+                                       f"oracle's op-for-op port incl. its tokenization and npz reads ({cpu_s:.1f} s)"},
+            "dw_max_abs_err": err_abs, "dw_max_rel_err": err_rel}
+
+
+if __name__ == "__main__":
+    main()

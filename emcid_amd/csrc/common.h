@@ -45,6 +45,20 @@ inline int check_launch(const char* fn) {
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// ---- optional per-kernel-class HIP-event timing (bench.py's live roofline measurement) ------------------
+// A ScopedProf around a launch records an event pair on the launch stream when its class is enabled.
+enum KernelClass : int {
+    KC_PREP = 0, KC_ASSEMBLE = 1, KC_CHOL_LEAF = 2, KC_CHOL_PANEL = 3, KC_CHOL_TRAIL = 4, KC_TRSM_DIAG = 5,
+    KC_TRSM_UPDATE = 6, KC_DELTA_W = 7, KC_GRAM = 8, KC_GATHER = 9, KC_DGEMM = 10, KC_MISC = 11, KC_COUNT = 12
+};
+void prof_begin(int cls, hipStream_t st);
+void prof_end(int cls, hipStream_t st);
+struct ScopedProf {
+    int cls; hipStream_t st;
+    ScopedProf(int c, hipStream_t s) : cls(c), st(s) { prof_begin(cls, st); }
+    ~ScopedProf() { prof_end(cls, st); }
+};
+
 constexpr int NB = 128;  // Cholesky / TRSM block size (diagonal leaf)
 constexpr int NPAD = 64; // concept-count padding of the f64 K / X / R stacks
 

@@ -174,6 +174,7 @@ int emcid_gram_accumulate_f32(const float* X, int64_t t, int64_t d, int64_t ldx,
     int64_t kchunk = round_up((t + ksplit - 1) / ksplit, GBK);
     ksplit = (int)((t + kchunk - 1) / kchunk);
     dim3 grid(tiles, tiles, ksplit);
+    ScopedProf sp(KC_GRAM, (hipStream_t)stream);
     hipLaunchKernelGGL(gram_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, (int)t, (int)d, ldx, G, ldg, (int)kchunk,
                        ksplit > 1 ? 1 : 0);
     EMCID_CHECK_LAUNCH();
@@ -194,6 +195,7 @@ int emcid_gather_mean_f32(const float* act, int64_t B, int64_t S, int64_t c, int
     EMCID_CHECK_ARG(N < 65536 * 16 && c < (1 << 24));
     dim3 grid((unsigned)((c + 255) / 256), (unsigned)N);
     EMCID_CHECK_ARG(N <= 65535);
+    ScopedProf sp(KC_GATHER, (hipStream_t)stream);
     hipLaunchKernelGGL(gather_mean_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, act, ldb, lds_, (int)c, S, idx, seg,
                        out, ldo);
     EMCID_CHECK_LAUNCH();

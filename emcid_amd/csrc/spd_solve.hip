@@ -12,6 +12,27 @@ namespace emcid {
 
 thread_local char g_last_error[512] = "";
 
+// ---- profiling state ------------------------------------------------------------------------------------
+namespace {
+constexpr int PROF_MAX = 16384;
+unsigned g_prof_mask = 0;
+int g_prof_n = 0;
+hipEvent_t g_prof_ev[PROF_MAX][2];
+int g_prof_cls[PROF_MAX];
+bool g_prof_init = false;
+}  // namespace
+
+void prof_begin(int cls, hipStream_t st) {
+    if (!(g_prof_mask & (1u << cls)) || g_prof_n >= PROF_MAX) return;
+    g_prof_cls[g_prof_n] = cls;
+    hipEventRecord(g_prof_ev[g_prof_n][0], st);
+}
+void prof_end(int cls, hipStream_t st) {
+    if (!(g_prof_mask & (1u << cls)) || g_prof_n >= PROF_MAX) return;
+    hipEventRecord(g_prof_ev[g_prof_n][1], st);
+    ++g_prof_n;
+}
+
 // ---- element-wise preparation ---------------------------------------------------------------------
 
 // Kt64[n][j] = double(K[n][j]) * s (zero padded to [Np][dp]);
@@ -126,17 +147,26 @@ static int cholesky_impl(double* A, double* L, int64_t dp, int64_t lda, double* 
     for (int j = 0; j < nb; ++j) {
         const int64_t o = (int64_t)j * NB;
         double* inv = invdiag + (int64_t)j * NB * NB;
-        hipLaunchKernelGGL(chol_leaf_kernel, dim3(1), dim3(LEAF_T), 0, st, A + o * lda + o, lda, L + o * lda + o, lda, inv,
-                           info, (int)o);
+        {
+            ScopedProf sp(KC_CHOL_LEAF, st);
+            hipLaunchKernelGGL(chol_leaf_kernel, dim3(1), dim3(LEAF_T), 0, st, A + o * lda + o, lda, L + o * lda + o, lda,
+                               inv, info, (int)o);
+        }
         const int m = (int)(dp - o - NB);
         if (m == 0) break;
         // panel: L21 = A21 * inv(L11)^T
         GemmShape ps{A + (o + NB) * lda + o, lda, inv, NB, m, NB, NB, 0};
-        launch_gemm_f64<true, true>(ps, EpiAxpby{L + (o + NB) * lda + o, lda, 1.0, 0.0}, st, 1);
+        {
+            ScopedProf sp(KC_CHOL_PANEL, st);
+            launch_gemm_f64<true, true>(ps, EpiAxpby{L + (o + NB) * lda + o, lda, 1.0, 0.0}, st, 1);
+        }
         // trailing: A22 -= L21 * L21^T (lower tiles only)
         const double* L21 = L + (o + NB) * lda + o;
         GemmShape ts{L21, lda, L21, lda, m, m, NB, 1};
-        launch_gemm_f64<true, true>(ts, EpiAxpby{A + (o + NB) * lda + (o + NB), lda, -1.0, 1.0}, st, 1);
+        {
+            ScopedProf sp(KC_CHOL_TRAIL, st);
+            launch_gemm_f64<true, true>(ts, EpiAxpby{A + (o + NB) * lda + (o + NB), lda, -1.0, 1.0}, st, 1);
+        }
     }
     return check_launch("emcid_cholesky_f64");
 }
@@ -149,10 +179,14 @@ static int cholesky_solve_impl(const double* L, int64_t dp, int64_t lda, const d
         const int64_t o = (int64_t)j * NB;
         const double* inv = invdiag + (int64_t)j * NB * NB;
         GemmShape a{Bt + o, ldb, inv, NB, M, NB, NB, 0};
-        launch_gemm_f64<true, true>(a, EpiAxpby{Yt + o, ldb, 1.0, 0.0}, st, 1);
+        {
+            ScopedProf sp(KC_TRSM_DIAG, st);
+            launch_gemm_f64<true, true>(a, EpiAxpby{Yt + o, ldb, 1.0, 0.0}, st, 1);
+        }
         const int m = (int)(dp - o - NB);
         if (m > 0) {
             GemmShape b{Yt + o, ldb, L + (o + NB) * lda + o, lda, M, m, NB, 0};
+            ScopedProf sp(KC_TRSM_UPDATE, st);
             launch_gemm_f64<true, true>(b, EpiAxpby{Bt + o + NB, ldb, -1.0, 1.0}, st, 1);
         }
     }
@@ -160,9 +194,13 @@ static int cholesky_solve_impl(const double* L, int64_t dp, int64_t lda, const d
         const int64_t o = (int64_t)j * NB;
         const double* inv = invdiag + (int64_t)j * NB * NB;
         GemmShape a{Yt + o, ldb, inv, NB, M, NB, NB, 0};
-        launch_gemm_f64<true, false>(a, EpiAxpby{Bt + o, ldb, 1.0, 0.0}, st, 1);
+        {
+            ScopedProf sp(KC_TRSM_DIAG, st);
+            launch_gemm_f64<true, false>(a, EpiAxpby{Bt + o, ldb, 1.0, 0.0}, st, 1);
+        }
         if (o > 0) {
             GemmShape b{Bt + o, ldb, L + o * lda, lda, M, (int)o, NB, 0};
+            ScopedProf sp(KC_TRSM_UPDATE, st);
             launch_gemm_f64<true, false>(b, EpiAxpby{Yt, ldb, -1.0, 1.0}, st, 1);
         }
     }
@@ -194,6 +232,34 @@ using namespace emcid;
 extern "C" {
 
 int emcid_abi_version(void) { return EMCID_ABI_VERSION; }
+
+int emcid_profile_enable(unsigned class_mask) {
+    if (class_mask && !g_prof_init) {
+        for (int i = 0; i < PROF_MAX; ++i)
+            for (int j = 0; j < 2; ++j)
+                if (hipEventCreate(&g_prof_ev[i][j]) != hipSuccess) return fail(EMCID_ERR_HIP, __func__, "hipEventCreate");
+        g_prof_init = true;
+    }
+    g_prof_mask = class_mask;
+    g_prof_n = 0;
+    return EMCID_OK;
+}
+
+int emcid_profile_collect(double* ms_per_class, int64_t* launches_per_class, int n_classes) {
+    EMCID_CHECK_ARG(ms_per_class && launches_per_class && n_classes >= KC_COUNT);
+    for (int c = 0; c < n_classes; ++c) { ms_per_class[c] = 0.0; launches_per_class[c] = 0; }
+    for (int i = 0; i < g_prof_n; ++i) {
+        if (hipEventSynchronize(g_prof_ev[i][1]) != hipSuccess) return fail(EMCID_ERR_HIP, __func__, "hipEventSynchronize");
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]) != hipSuccess)
+            return fail(EMCID_ERR_HIP, __func__, "hipEventElapsedTime");
+        ms_per_class[g_prof_cls[i]] += ms;
+        launches_per_class[g_prof_cls[i]] += 1;
+    }
+    const int dropped = (g_prof_n >= PROF_MAX) ? 1 : 0;
+    g_prof_n = 0;
+    return dropped ? fail(EMCID_ERR_WORKSPACE, __func__, "event pool exhausted; enable fewer classes") : EMCID_OK;
+}
 const char* emcid_last_error(void) { return g_last_error; }
 
 int emcid_dgemm_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
@@ -204,6 +270,7 @@ int emcid_dgemm_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alph
     hipStream_t st = (hipStream_t)stream;
     GemmShape p{A, lda, B, ldb, (int)M, (int)N, (int)K, 0};
     EpiAxpby e{C, ldc, alpha, beta};
+    ScopedProf sp(KC_DGEMM, st);
     // ta/tb == 0: K contiguous ([rows][K]); 1: rows contiguous ([K][rows])
     if (ta == 0 && tb == 0) launch_gemm_f64<true, true>(p, e, st);
     else if (ta == 0 && tb == 1) launch_gemm_f64<true, false>(p, e, st);
@@ -219,7 +286,10 @@ int emcid_assemble_spd_f64(const float* C, int64_t ldc, const double* Kt64, int6
     const int64_t dp = round_up(d, NB);
     EMCID_CHECK_ARG(lda >= dp && ldk >= dp && ldc >= d && (ldk % 2 == 0) && aligned16(Kt64));
     GemmShape p{Kt64, ldk, Kt64, ldk, (int)dp, (int)dp, (int)Np, 1};
-    launch_gemm_f64<false, false>(p, EpiAssemble{C, ldc, lam, cw, A, lda, (int)d}, (hipStream_t)stream);
+    {
+        ScopedProf sp(KC_ASSEMBLE, (hipStream_t)stream);
+        launch_gemm_f64<false, false>(p, EpiAssemble{C, ldc, lam, cw, A, lda, (int)d}, (hipStream_t)stream);
+    }
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }
@@ -242,7 +312,10 @@ int emcid_delta_w_f64(const double* Rt, int64_t ldr, const double* Xt, int64_t l
     EMCID_CHECK_ARG(Rt && Xt && Np > 0 && h > 0 && d > 0 && ldr % 2 == 0 && ldx % 2 == 0 && aligned16(Rt) && aligned16(Xt));
     EMCID_CHECK_ARG((W == nullptr) || (W0 != nullptr));
     GemmShape p{Rt, ldr, Xt, ldx, (int)h, (int)d, (int)Np, 0};
-    launch_gemm_f64<false, false>(p, EpiDeltaW{W0, W, ldw, dW, d, U, d}, (hipStream_t)stream);
+    {
+        ScopedProf sp(KC_DELTA_W, (hipStream_t)stream);
+        launch_gemm_f64<false, false>(p, EpiDeltaW{W0, W, ldw, dW, d, U, d}, (hipStream_t)stream);
+    }
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }
@@ -279,8 +352,11 @@ int emcid_edit_layer_f64(const float* K, const float* Zc, const float* zs_t, con
     const double s = sqrt(edit_weight / 0.5);
     const float cw = (float)(1.0 - edit_weight);  // torch multiplies the fp32 tensor by the scalar rounded to fp32
 
-    hipLaunchKernelGGL(prep_kr_kernel, dim3((unsigned)ws.Np), dim3(256), 0, st, K, Zc, zs_t, (int)N, (int)d, (int)h, s,
-                       (double)layers_left, B, (int)ws.Np, (int)ws.dp, R, (int)ws.hp);
+    {
+        ScopedProf sp(KC_PREP, st);
+        hipLaunchKernelGGL(prep_kr_kernel, dim3((unsigned)ws.Np), dim3(256), 0, st, K, Zc, zs_t, (int)N, (int)d, (int)h, s,
+                           (double)layers_left, B, (int)ws.Np, (int)ws.dp, R, (int)ws.hp);
+    }
     EMCID_CHECK_LAUNCH();
     EMCID_TRY(emcid_assemble_spd_f64(C, d, B, ws.Np, d, ws.dp, lam, cw, A, ws.dp, stream));
     EMCID_TRY(cholesky_impl(A, L, ws.dp, ws.dp, inv, info_dev, st));

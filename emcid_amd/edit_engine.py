@@ -1,0 +1,174 @@
+"""The restructured Stage-2 pass: ONE forward per encoder, the closed form solved inside the fc2 hooks.
+
+The reference's layer loop (emcid/emcid_main.py:981-1073) runs the whole text encoder twice per edited layer
+(once for the keys :987, once more for the current fc2 outputs :1004) on all N*P prompts — 98 % of its
+wall-clock.  Layers are sequentially dependent: layer l+1's keys must see layer l's new
+weights.  That dependency is exactly the order of a single forward pass, so here:
+
+    forward(prompts)                                   # once
+      └─ at each edited layer's fc2 (forward hook, in layer order):
+           K  = gather_mean(fc2 input)                 # HIP, csrc/gram_f32.hip
+           Zc = gather_mean(fc2 output)                # pre-edit output, bias included (as :1002-1016)
+           [all-gather K, Zc over concept shards]      # RCCL, multi-GPU only
+           W  = W0 + float(R X^T)                      # HIP fp64 MFMA solve, csrc/spd_solve.hip
+           return fc2(input) with the NEW W            # the rest of the pass sees the edited layer
+      └─ the hook of the last edited layer aborts the pass (nothing downstream is needed)
+
+Same K, Zc, A, X, R, dW as the reference's loop (same inputs to every step), 1 partial forward instead of
+2*L full ones.  Host work (tokenizing, subject search, v*/C loading) happens once in ``prepare``; ``run``
+touches only HBM-resident inputs — that is the region bench.py times.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import hip
+from .compute_z import PromptBatch, build_prompt_batch, gather_request_means
+from .nethook import StopForward, get_module, get_parameter
+
+
+@dataclass
+class ConceptShard:
+    """This rank's contiguous slice [lo, hi) of the request list (concept sharding)."""
+    rank: int = 0
+    world: int = 1
+    group: object = None
+
+    def bounds(self, n: int, r: Optional[int] = None):
+        r = self.rank if r is None else r
+        return (n * r) // self.world, (n * (r + 1)) // self.world
+
+
+@dataclass
+class LayerEdit:
+    layer: int
+    weight_name: str
+    dW: torch.Tensor                       # (h, d) fp32 in HBM: float(resid @ adj_k^T)
+    Xt: Optional[torch.Tensor] = None      # (N, d) f64: adj_k^T
+    Rt: Optional[torch.Tensor] = None      # (N, h) f64: resid^T
+    K: Optional[torch.Tensor] = None       # (N, d) fp32 keys (kept when trace=True)
+    Zc: Optional[torch.Tensor] = None      # (N, h) fp32 current fc2 outputs
+
+
+@dataclass
+class EncoderEditPlan:
+    """Everything one encoder's Stage-2 pass needs, resident in HBM."""
+    text_encoder: torch.nn.Module
+    layers: List[int]
+    rewrite_module_tmp: str
+    lam: float
+    edit_weight: float
+    batch: PromptBatch                     # this rank's prompts
+    zs_t: torch.Tensor                     # (N, h) fp32: v* of ALL requests, row per request
+    covs: Dict[int, torch.Tensor]          # layer -> (d, d) fp32 second moment C
+    n_total: int                           # N over all ranks
+    shard: ConceptShard = field(default_factory=ConceptShard)
+    ws: Optional[hip.EditWorkspace] = None
+
+    def weight_name(self, layer):
+        return f"{self.rewrite_module_tmp.format(layer)}.weight"
+
+
+def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], layers, rewrite_module_tmp, lam,
+                         edit_weight, zs_t: torch.Tensor, covs: Dict[int, torch.Tensor],
+                         shard: Optional[ConceptShard] = None) -> EncoderEditPlan:
+    shard = shard or ConceptShard()
+    device = next(text_encoder.parameters()).device
+    lo, hi = shard.bounds(len(requests))
+    if hi <= lo:
+        raise ValueError(f"rank {shard.rank}/{shard.world} has no requests (N={len(requests)} < world size)")
+    batch = build_prompt_batch(tokenizer, list(requests[lo:hi]), device)
+    zs_t = zs_t.to(device=device, dtype=torch.float32).contiguous()
+    if zs_t.shape[0] != len(requests):
+        raise ValueError(f"v* stack has {zs_t.shape[0]} rows for {len(requests)} requests")
+    covs = {l: c.to(device=device, dtype=torch.float32).contiguous() for l, c in covs.items()}
+    return EncoderEditPlan(text_encoder, list(layers), rewrite_module_tmp, float(lam), float(edit_weight), batch,
+                           zs_t, covs, len(requests), shard)
+
+
+def _all_gather_rows(local: torch.Tensor, plan: EncoderEditPlan) -> torch.Tensor:
+    """Concatenate per-rank row blocks (uneven shards allowed) in rank order == request order."""
+    sh = plan.shard
+    if sh.world == 1:
+        return local
+    import torch.distributed as dist
+
+    sizes = [b - a for a, b in (sh.bounds(plan.n_total, r) for r in range(sh.world))]
+    nmax = max(sizes)
+    padded = local
+    if local.shape[0] < nmax:
+        padded = torch.zeros(nmax, local.shape[1], dtype=local.dtype, device=local.device)
+        padded[:local.shape[0]] = local
+    out = torch.empty(sh.world * nmax, local.shape[1], dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, padded.contiguous(), group=sh.group)
+    if all(s == nmax for s in sizes):
+        return out
+    return torch.cat([out[r * nmax:r * nmax + s] for r, s in enumerate(sizes)], dim=0)
+
+
+def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: bool = False,
+                     restore: bool = False) -> List[LayerEdit]:
+    """Device-only Stage 2 for one encoder.  On return the edited fc2 weights hold W0 + dW (``restore=False``)
+    or their original values (``restore=True``, the reference's execute_* invariant, emcid_main.py:1076-1078)."""
+    te = plan.text_encoder
+    L = len(plan.layers)
+    mods = {l: get_module(te, plan.rewrite_module_tmp.format(l)) for l in plan.layers}
+    weights = {l: get_parameter(te, plan.weight_name(l)) for l in plan.layers}
+    for l, w in weights.items():
+        if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+            raise hip.EmcidHipError(f"{plan.weight_name(l)} must be a contiguous fp32 tensor in HBM "
+                                    f"(got {w.dtype} on {w.device})")
+    backups = {l: w.detach().clone() for l, w in weights.items()}
+    d, h = weights[plan.layers[0]].shape[1], weights[plan.layers[0]].shape[0]
+    if plan.ws is None or plan.ws.key != (plan.n_total, d, h):
+        plan.ws = hip.EditWorkspace(plan.n_total, d, h, weights[plan.layers[0]].device)
+    plan.ws.info.zero_()
+    edits: List[LayerEdit] = []
+    last = plan.layers[-1]
+    handles = []
+
+    def make_hook(i, layer):
+        def hook(mod, inputs, output):
+            x = inputs[0]
+            K = _all_gather_rows(gather_request_means(x, plan.batch), plan)
+            Zc = _all_gather_rows(gather_request_means(output, plan.batch), plan)
+            res = hip.edit_layer(K, Zc, plan.zs_t, plan.covs[layer], plan.lam, plan.edit_weight, L - i,
+                                 W0=backups[layer], W=weights[layer].data, want_factors=keep_factors, ws=plan.ws)
+            edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], res["Xt"], res["Rt"],
+                                   K if trace else None, Zc if trace else None))
+            if layer == last:
+                raise StopForward()
+            return F.linear(x, mod.weight, mod.bias)
+        return hook
+
+    for i, l in enumerate(plan.layers):
+        handles.append(mods[l].register_forward_hook(make_hook(i, l)))
+    try:
+        with torch.no_grad():
+            try:
+                te(**plan.batch.inputs)
+            except StopForward:
+                pass
+    finally:
+        for hd in handles:
+            hd.remove()
+    if len(edits) != L:
+        raise RuntimeError(f"only {len(edits)} of {L} edited layers were reached by the forward pass "
+                           f"(hparams.layers must be in forward order)")
+    if restore:
+        with torch.no_grad():
+            for l, w in weights.items():
+                w.copy_(backups[l])
+    return edits
+
+
+def check_info(plan: EncoderEditPlan):
+    """One host sync at the very end: did any layer's A fail to be positive definite?"""
+    code = int(plan.ws.info.item())
+    if code != 0:
+        raise FloatingPointError(
+            f"lam*C + K K^T is not positive definite (non-positive pivot at column {code - 1}); the reference's LU "
+            f"(torch.linalg.solve, emcid_main.py:1045) would have returned numbers for an indefinite system — "
+            f"check the statistics file / mom2_update_weight")

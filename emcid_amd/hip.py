@@ -19,7 +19,10 @@ EXPORTS = [
     "emcid_abi_version", "emcid_last_error", "emcid_gram_accumulate_f32", "emcid_symmetrize_lower_f32",
     "emcid_gather_mean_f32", "emcid_edit_workspace_bytes", "emcid_edit_layer_f64", "emcid_assemble_spd_f64",
     "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_axpy_f32",
+    "emcid_profile_enable", "emcid_profile_collect",
 ]
+PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
+                "gram", "gather", "dgemm", "misc"]
 
 ABI_VERSION = 1
 NB = 128      # Cholesky block (csrc/common.h)
@@ -59,6 +62,8 @@ def load():
         "emcid_delta_w_f64": (i32, [p, i64, p, i64, i64, i64, i64, p, p, i64, p, p, p]),
         "emcid_dgemm_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, p]),
         "emcid_axpy_f32": (i32, [p, p, i64, p]),
+        "emcid_profile_enable": (i32, [C.c_uint]),
+        "emcid_profile_collect": (i32, [p, p, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
@@ -201,3 +206,20 @@ def cholesky_solve_(L, inv, Bt):
     _check(load().emcid_cholesky_solve_f64(_ptr(L, torch.float64), L.shape[0], L.stride(0), _ptr(inv), _ptr(Bt), _ptr(Y),
                                            Bt.shape[0], Bt.stride(0), _stream(Bt)), "emcid_cholesky_solve_f64")
     return Bt
+
+
+def profile_enable(classes=()):
+    """Start (or, with no classes, stop) HIP-event timing of the named kernel classes (PROF_CLASSES)."""
+    mask = 0
+    for c in classes:
+        mask |= 1 << PROF_CLASSES.index(c)
+    _check(load().emcid_profile_enable(mask), "emcid_profile_enable")
+
+
+def profile_collect():
+    """{class: (total_ms, launches)} for the classes that recorded launches since profile_enable."""
+    n = len(PROF_CLASSES)
+    ms = (C.c_double * n)()
+    cnt = (C.c_int64 * n)()
+    _check(load().emcid_profile_collect(ms, cnt, n), "emcid_profile_collect")
+    return {PROF_CLASSES[i]: (ms[i], int(cnt[i])) for i in range(n) if cnt[i]}

@@ -1,0 +1,158 @@
+"""Stage 0: per-layer second moment of the fc2 INPUT features over a caption set, npz-cached.
+
+Host-side counterpart of the reference's emcid/layer_stats.py (``layer_stats_text_encoder`` :140-220,
+``main`` :34-134).  Same sample (FixedRandomSubsetSampler seed 1), same groups of 100 captions, same
+length-sorted <= batch_tokens sub-batches, same attended-token selection, same npz path and keys.
+
+MI355X-first differences:
+* the Gram accumulate is the hand-written SYRK kernel behind ``SecondMoment`` (csrc/gram_f32.hip);
+* ``layer_stats_text_encoder_multi`` hooks EVERY requested layer in one forward (stopping after the
+  deepest), so 12 layers cost 12 layer-forwards per batch instead of the reference's 78 (it re-runs the
+  encoder from scratch for each layer, layer_stats.py:112-134);
+* ``shard=(rank, world)`` partitions the fixed caption sample over ranks; the per-rank Grams are summed
+  with one all-reduce per layer at the end (RCCL over xGMI on the GPU box).
+"""
+import argparse
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from tqdm.auto import tqdm
+
+from .globals import STATS_DIR
+from .nethook import StopForward, get_module, set_requires_grad
+from .runningstats import CombinedStat, SecondMoment, load_cached_state, save_cached_state, make_loader, tally
+from .stat_dataset import TokenizedDataset, dict_to_, flatten_masked_batch, length_collation
+
+STAT_TYPES = {"mom2": SecondMoment}
+CCS_PATH = "./data/ccs_filtered.json"   # reference: layer_stats.py:138 (hard-coded, cwd-relative)
+
+
+def get_ccs_filtered_ds(tokenizer, data_path=CCS_PATH):
+    return TokenizedDataset(data_path, tokenizer)
+
+
+def stats_filename(stats_dir, model_name, ds_name, layer_name, precision, to_collect, batch_tokens, sample_size) -> Path:
+    # reference: layer_stats.py:166-174
+    size_suffix = "" if sample_size is None else f"_{sample_size}"
+    size_suffix = f"_t{batch_tokens}" + size_suffix
+    return Path(stats_dir) / f"{model_name}/{ds_name}_stats/{layer_name}_{precision}_{'-'.join(sorted(to_collect))}{size_suffix}.npz"
+
+
+def _check_precision(precision):
+    if precision is None:
+        precision = "float64"   # the reference's default when unset (layer_stats.py:161-162)
+    if precision != "float32":
+        raise NotImplementedError(
+            f"precision={precision!r}: the MI355X SYRK kernel accumulates fp32 (the reference's CLI default, "
+            f"layer_stats.py:51, and every shipped hparams file); other precisions are not built")
+    return precision
+
+
+def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str], stats_dir=STATS_DIR,
+                                   ds_name="ccs_filtered", to_collect=("mom2",), model_name="text_encoder",
+                                   sample_size=None, precision="float32", batch_tokens=3 * 1024, progress=tqdm,
+                                   force_recompute=False, data_path=CCS_PATH, shard=None, group=None,
+                                   num_workers=2, batch_size=100) -> Dict[str, CombinedStat]:
+    """All ``layer_names`` in ONE pass over the captions.  Returns {layer_name: CombinedStat} (on cpu)."""
+    precision = _check_precision(precision)
+    to_collect = list(to_collect)
+    device = next(model.parameters()).device
+    args = {} if sample_size is None else {"sample_size": sample_size}
+    files = {ln: stats_filename(stats_dir, model_name, ds_name, ln, precision, to_collect, batch_tokens, sample_size)
+             for ln in layer_names}
+    stats: Dict[str, CombinedStat] = {}
+    todo: List[str] = []
+    for ln in layer_names:
+        st = CombinedStat(**{k: STAT_TYPES[k]() for k in to_collect})
+        cached = None if force_recompute else load_cached_state(files[ln], args, quiet=True)
+        if cached is not None:
+            st.load_state_dict(cached)
+        else:
+            todo.append(ln)
+        stats[ln] = st
+    if not todo:
+        return stats
+
+    ds = get_ccs_filtered_ds(tokenizer, data_path)
+    loader = make_loader(ds, sample_size=sample_size, batch_size=batch_size, random_sample=1, shard=shard,
+                         collate_fn=length_collation(batch_tokens), pin_memory=device.type == "cuda",
+                         num_workers=num_workers)
+    # forward order of the hooked modules decides which one is "deepest" (the one that stops the pass)
+    order = {name: i for i, (name, _) in enumerate(model.named_modules())}
+    mods = {ln: get_module(model, ln) for ln in todo}
+    rank_of = {ln: next(order[n] for n, m in model.named_modules() if m is mods[ln]) for ln in todo}
+    deepest = max(todo, key=lambda ln: rank_of[ln])
+    grabbed: Dict[str, torch.Tensor] = {}
+    handles = []
+    for ln in todo:
+        def hook(mod, inputs, output, ln=ln):
+            grabbed[ln] = inputs[0]
+            if ln == deepest:
+                raise StopForward()
+        handles.append(mods[ln].register_forward_hook(hook))
+    n_groups = -(-(len(loader.sampler) if loader.sampler is not None else len(ds)) // batch_size)
+    wrap = progress if progress is not None else (lambda it, total=None: it)
+    try:
+        with torch.no_grad():
+            for batch_group in wrap(loader, total=n_groups):
+                for batch in batch_group:
+                    batch = dict_to_(batch, device)
+                    try:
+                        model(**batch)
+                    except StopForward:
+                        pass
+                    for ln in todo:
+                        feats = flatten_masked_batch(grabbed[ln], batch["attention_mask"])
+                        stats[ln].add(feats.to(dtype=torch.float32))
+                    grabbed.clear()
+    finally:
+        for h in handles:
+            h.remove()
+    for ln in todo:
+        if shard is not None and shard[1] > 1:
+            stats[ln].all_reduce_(group)
+        stats[ln].to_(device="cpu")
+        if shard is None or shard[0] == 0:
+            save_cached_state(files[ln], stats[ln], args)
+    return stats
+
+
+def layer_stats_text_encoder(model, tokenizer, layer_name, stats_dir="data/stats", ds_name="ccs_filtered",
+                             to_collect=["mom2"], model_name="text_encoder", sample_size=None, precision=None,
+                             batch_tokens=3 * 1024, download=False, progress=tqdm, force_recompute=False,
+                             data_path=CCS_PATH, shard=None, group=None, num_workers=2):
+    """Load or compute the cached stats of ONE layer (the reference's signature, layer_stats.py:140-153)."""
+    if download:
+        raise NotImplementedError("Downloading stats from remote is not implemented yet.")  # as the reference (:178)
+    return layer_stats_text_encoder_multi(
+        model, tokenizer, [layer_name], stats_dir, ds_name, to_collect, model_name, sample_size, precision,
+        batch_tokens, progress, force_recompute, data_path, shard, group, num_workers)[layer_name]
+
+
+def main(argv=None):
+    """Pre-compute cached stats for a text encoder held by the caller's pipeline loader.
+
+    The reference's CLI (layer_stats.py:34-134) downloads Stable Diffusion from the hub; there is no network
+    here, so this entry point runs on the synthetic encoders (``--model_name toy|sd-v1.4|sdxl-te1|sdxl-te2``)."""
+    from . import synthetic as syn
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model_name", default="sd-v1.4", choices=list(syn.ENCODER_DIMS))
+    ap.add_argument("--layers", default=12, type=int)
+    ap.add_argument("--sample_size", default=100000, type=lambda x: None if x == "all" else int(x))
+    ap.add_argument("--batch_tokens", default=3 * 1024, type=int)
+    ap.add_argument("--precision", default="float32")
+    ap.add_argument("--stats_dir", default=str(STATS_DIR))
+    ap.add_argument("--data_path", default=CCS_PATH)
+    ap.add_argument("--device", default="cuda:0")
+    a = ap.parse_args(argv)
+    pipe = syn.build_pipe(a.model_name, a.device)
+    set_requires_grad(False, pipe.text_encoder)
+    names = [f"text_model.encoder.layers.{i}.mlp.fc2" for i in range(a.layers)]
+    layer_stats_text_encoder_multi(pipe.text_encoder, pipe.tokenizer, names, a.stats_dir, sample_size=a.sample_size,
+                                   precision=a.precision, batch_tokens=a.batch_tokens, data_path=a.data_path)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,367 @@
+"""Running second moment on the MI355X + the npz cache protocol around it.
+
+Host-side counterpart of the slice of the reference's util/runningstats.py that the edit path uses:
+``SecondMoment`` (:469-511), ``CombinedStat`` (:1347-1388), ``tally`` (:54-121), the npz cache I/O with
+NaN-boxed ``None`` (:1409-1512) and the deterministic subset samplers (:1515-1603).
+
+What differs by design (MI355X-first):
+* ``SecondMoment.add`` does not call ``a.t().mm(a)``.  Batches are appended to a token staging buffer in
+  HBM and flushed through the hand-written SYRK kernel (csrc/gram_f32.hip) once enough tokens are queued,
+  so one launch sees a long contraction dimension and only the lower triangle is ever computed; the
+  mirror happens when the statistic is read.
+* ``all_reduce_`` sums the statistic over ``torch.distributed`` ranks (RCCL on the GPU box) for the
+  caption-sharded Stage 0; the reference is single-process.
+The on-disk npz written by ``tally`` is byte-compatible with the reference's (keys ``mom2.constructor``,
+``mom2.count``, ``mom2.mom2``, ``sample_size``).
+"""
+import os
+import random
+import struct
+from typing import Optional
+
+import numpy
+import torch
+from torch.utils.data.sampler import Sampler
+
+from . import hip
+
+
+class Stat:
+    def __init__(self, state):
+        self.load_state_dict(resolve_state_dict(state))
+
+    def add(self, x, *args, **kwargs):
+        raise NotImplementedError
+
+    def load_state_dict(self, d):
+        raise NotImplementedError
+
+    def state_dict(self):
+        raise NotImplementedError
+
+    def to_(self, device):
+        pass
+
+    def save(self, filename):
+        save_cached_state(filename, self, {})
+
+    def load(self, filename):
+        self.load_state_dict(load_cached_state(filename, {}, quiet=True, throw=True))
+
+    def _normalize_add_shape(self, x):
+        if x.dim() != 2:
+            x = x.reshape(-1, x.shape[-1])
+        return x
+
+
+class SecondMoment(Stat):
+    """Non-centred second moment E[x x^T] accumulated in HBM.
+
+    ``stage_tokens`` is the capacity of the staging buffer (tokens queued before a SYRK launch);
+    ``ksplit`` is passed to the kernel (0 = choose, 1 = deterministic single pass)."""
+
+    CONSTRUCTOR = "util.runningstats.SecondMoment()"  # what the reference's state_dict records (:504)
+
+    def __init__(self, split_batch=True, state=None, stage_tokens: int = 16384, ksplit: int = 0):
+        self.count = 0
+        self._lower = None      # (d, d) device accumulator, lower triangle valid
+        self._full = None       # cached mirrored matrix (any device), invalidated by add()
+        self._stage = None
+        self._staged = 0
+        self.stage_tokens = stage_tokens
+        self.ksplit = ksplit
+        self.split_batch = split_batch
+        if state is not None:
+            super().__init__(state)
+
+    # -- accumulation --------------------------------------------------------------------------------
+    def add(self, a: torch.Tensor):
+        a = self._normalize_add_shape(a)
+        if len(a) == 0:
+            return
+        if not a.is_cuda:
+            raise hip.EmcidHipError("SecondMoment.add needs a tensor in HBM (no CPU path in emcid_amd)")
+        if a.dtype != torch.float32:
+            raise hip.EmcidHipError(f"SecondMoment.add accumulates fp32 (reference default precision); got {a.dtype}")
+        d = a.shape[1]
+        if self._lower is None:
+            if self._full is not None:   # resumed from a loaded state
+                self._lower = self._full.to(a.device, torch.float32).contiguous().clone()
+            else:
+                self._lower = torch.zeros(d, d, dtype=torch.float32, device=a.device)
+        self._full = None
+        self.count += a.shape[0]
+        if a.shape[0] >= self.stage_tokens:
+            self.flush()
+            hip.gram_accumulate_(self._lower, a.contiguous(), self.ksplit)
+            return
+        if self._stage is None:
+            self._stage = torch.empty(self.stage_tokens, d, dtype=torch.float32, device=a.device)
+        if self._staged + a.shape[0] > self.stage_tokens:
+            self.flush()
+        self._stage[self._staged:self._staged + a.shape[0]].copy_(a)
+        self._staged += a.shape[0]
+
+    def flush(self):
+        if self._staged:
+            hip.gram_accumulate_(self._lower, self._stage[:self._staged], self.ksplit)
+            self._staged = 0
+
+    # -- readout -------------------------------------------------------------------------------------
+    @property
+    def mom2(self) -> Optional[torch.Tensor]:
+        if self._full is None and self._lower is not None:
+            self.flush()
+            self._full = hip.symmetrize_lower_(self._lower.clone())
+        return self._full
+
+    def moment(self):
+        return self.mom2 / self.count
+
+    def to_(self, device):
+        if self._lower is not None or self._full is not None:
+            full = self.mom2.to(device)
+            self._full, self._lower, self._stage, self._staged = full, None, None, 0
+
+    def all_reduce_(self, group=None):
+        """Sum over ranks (caption-sharded Stage 0): mom2 with one all-reduce, count with another."""
+        import torch.distributed as dist
+
+        self.flush()
+        acc = self._lower if self._lower is not None else self._full
+        if acc is None:
+            raise RuntimeError("all_reduce_ on an empty SecondMoment")
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+        cnt = torch.tensor([self.count], dtype=torch.int64, device=acc.device)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+        self.count = int(cnt.item())
+        if self._lower is not None:
+            self._full = None
+
+    def state_dict(self):
+        return dict(constructor=self.CONSTRUCTOR, count=self.count, mom2=self.mom2.cpu().numpy())
+
+    def load_state_dict(self, state):
+        self.count = int(state["count"])
+        self._full = torch.from_numpy(numpy.asarray(state["mom2"]))
+        self._lower, self._stage, self._staged = None, None, 0
+
+
+class CombinedStat(Stat):
+    """Bundle of named stats sharing one ``add`` / one npz (keys are ``<name>.<key>``)."""
+
+    def __init__(self, state=None, **kwargs):
+        self._objs = kwargs
+        if state is not None:
+            super().__init__(state)
+
+    def __getattr__(self, k):
+        objs = self.__dict__.get("_objs", {})
+        if k in objs:
+            return objs[k]
+        raise AttributeError(k)
+
+    def add(self, d, *args, **kwargs):
+        for obj in self._objs.values():
+            obj.add(d, *args, **kwargs)
+
+    def load_state_dict(self, state):
+        for prefix, obj in self._objs.items():
+            obj.load_state_dict(pull_key_prefix(prefix, state))
+
+    def state_dict(self):
+        out = {}
+        for prefix, obj in self._objs.items():
+            out.update(push_key_prefix(prefix, obj.state_dict()))
+        return out
+
+    def to_(self, device):
+        for v in self._objs.values():
+            v.to_(device)
+
+    def all_reduce_(self, group=None):
+        for v in self._objs.values():
+            v.all_reduce_(group)
+
+
+def push_key_prefix(prefix, d):
+    return {f"{prefix}.{k}": v for k, v in d.items()}
+
+
+def pull_key_prefix(prefix, d):
+    head = prefix + "."
+    keys = d.files if hasattr(d, "files") else d.keys()
+    return {k[len(head):]: d[k] for k in keys if k.startswith(head)}
+
+
+# ---- npz cache protocol (None is stored as the NaN with payload 0xfff8000000000002) -----------------------
+
+_NULL_BITS = 0xFFF8000000000002
+null_numpy_value = numpy.array(struct.unpack(">d", struct.pack(">Q", _NULL_BITS))[0], dtype=numpy.float64)
+
+
+def is_null_numpy_value(v):
+    return (isinstance(v, numpy.ndarray) and numpy.ndim(v) == 0 and v.dtype == numpy.float64 and numpy.isnan(v)
+            and struct.unpack(">Q", struct.pack(">d", float(v)))[0] == _NULL_BITS)
+
+
+def box_numpy_null(d):
+    if isinstance(d, dict):
+        return {k: box_numpy_null(v) for k, v in d.items()}
+    return null_numpy_value if d is None else d
+
+
+def unbox_numpy_null(d):
+    if hasattr(d, "files"):
+        return {k: unbox_numpy_null(d[k]) for k in d.files}
+    if isinstance(d, dict):
+        return {k: unbox_numpy_null(v) for k, v in d.items()}
+    return None if is_null_numpy_value(d) else d
+
+
+def resolve_state_dict(s):
+    if isinstance(s, (str, os.PathLike)):
+        with numpy.load(s) as z:
+            return unbox_numpy_null(z)
+    return s
+
+
+global_load_cache_enabled = True
+
+
+class cache_load_enabled:
+    """``with cache_load_enabled(False):`` forces recomputation (reference :124-142)."""
+
+    def __init__(self, enabled=True):
+        self.prev, self.enabled = None, enabled
+
+    def __enter__(self):
+        global global_load_cache_enabled
+        self.prev, global_load_cache_enabled = global_load_cache_enabled, self.enabled
+
+    def __exit__(self, *a):
+        global global_load_cache_enabled
+        global_load_cache_enabled = self.prev
+
+
+def load_cached_state(cachefile, args, quiet=False, throw=False):
+    """None when caching is off, the file is absent/unreadable, or a recorded arg (``sample_size``) differs."""
+    if not global_load_cache_enabled or cachefile is None:
+        return None
+    try:
+        if isinstance(cachefile, dict):
+            dat, label = cachefile, "state"
+        else:
+            with numpy.load(cachefile) as z:
+                dat = unbox_numpy_null(z)
+            label = cachefile
+        for k, v in args.items():
+            if k not in dat or dat[k] != v:
+                if not quiet:
+                    print(f"{label} {k} changed from {dat.get(k)} to {v}")
+                return None
+    except (FileNotFoundError, ValueError) as e:
+        if throw:
+            raise e
+        return None
+    if not quiet:
+        print(f"Loading cached {label}")
+    return dat
+
+
+def save_cached_state(cachefile, obj, args):
+    if cachefile is None:
+        return
+    dat = obj.state_dict()
+    for k, v in args.items():
+        if k in dat:
+            assert dat[k] == v
+        dat[k] = v
+    if isinstance(cachefile, dict):
+        cachefile.clear()
+        cachefile.update(dat)
+    else:
+        os.makedirs(os.path.dirname(str(cachefile)) or ".", exist_ok=True)
+        numpy.savez(cachefile, **box_numpy_null(dat))
+
+
+# ---- deterministic subset sampling ----------------------------------------------------------------------
+
+class FixedSubsetSampler(Sampler):
+    def __init__(self, samples):
+        self.samples = list(samples)
+
+    def __iter__(self):
+        return iter(self.samples)
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, key):
+        return self.samples[key]
+
+    def dereference(self, indices):
+        return [self.samples[i] for i in indices]
+
+    def subset(self, new_subset):
+        return FixedSubsetSampler(self.dereference(new_subset))
+
+    def shard(self, rank: int, world: int):
+        """Contiguous 1/world slice of the SAME fixed sample (partitioned, never re-drawn)."""
+        n = len(self.samples)
+        lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+        return FixedSubsetSampler(self.samples[lo:hi])
+
+
+class FixedRandomSubsetSampler(FixedSubsetSampler):
+    """``random.Random(seed).shuffle(range(len(ds)))[start:end]`` — the reference's fixed pseudo-random sample."""
+
+    def __init__(self, data_source, start=None, end=None, seed=1):
+        order = list(range(len(data_source)))
+        random.Random(seed).shuffle(order)
+        self.data_source = data_source
+        super().__init__(order[start:end])
+
+
+def make_loader(dataset, sample_size=None, batch_size=1, sampler=None, random_sample=None, shard=None, **kwargs):
+    """DataLoader over a fixed sample subset.  ``shard=(rank, world)`` keeps this rank's slice of it."""
+    if callable(dataset) and not hasattr(dataset, "__len__"):
+        dataset = dataset()
+    if isinstance(dataset, torch.Tensor):
+        dataset = torch.utils.data.TensorDataset(dataset)
+    if sample_size is not None:
+        assert sampler is None, "sampler cannot be specified with sample_size"
+        if sample_size > len(dataset):
+            print(f"Warning: sample size {sample_size} > dataset size {len(dataset)}")
+            sample_size = len(dataset)
+        if random_sample is None:
+            sampler = FixedSubsetSampler(range(sample_size))
+        else:
+            sampler = FixedRandomSubsetSampler(dataset, seed=random_sample, end=sample_size)
+    if shard is not None:
+        if sampler is None:
+            sampler = FixedSubsetSampler(range(len(dataset)))
+        sampler = sampler.shard(*shard)
+    return torch.utils.data.DataLoader(dataset, sampler=sampler, batch_size=batch_size, **kwargs)
+
+
+def tally(stat, dataset, cache=None, quiet=False, shard=None, group=None, **kwargs):
+    """Loader whose exhaustion finalises ``stat``: (all-reduce over ranks if sharded) -> cpu -> npz cache.
+    If the cache already holds the statistic (same ``sample_size``) the stat is loaded and the loader is empty."""
+    assert isinstance(stat, Stat)
+    args = {k: kwargs[k] for k in ("sample_size",) if k in kwargs}
+    cached = load_cached_state(cache, args, quiet=quiet)
+    if cached is not None:
+        stat.load_state_dict(cached)
+        return iter(())
+    loader = make_loader(dataset, shard=shard, **kwargs)
+
+    def wrapped():
+        yield from loader
+        if shard is not None and shard[1] > 1:
+            stat.all_reduce_(group)
+        stat.to_(device="cpu")
+        if cache is not None and (shard is None or shard[0] == 0):
+            save_cached_state(cache, stat, args)
+
+    return wrapped()

@@ -33,6 +33,14 @@ int emcid_abi_version(void);
 /* Human-readable text of the last error on this thread (host-only). */
 const char* emcid_last_error(void);
 
+/* Optional per-kernel-class timing with HIP events recorded on the launch stream (bench.py's live
+ * roofline measurement).  class ids: 0 prep, 1 assemble(SYRK), 2 chol_leaf, 3 chol_panel, 4 chol_trail,
+ * 5 trsm_diag, 6 trsm_update, 7 delta_w, 8 gram, 9 gather, 10 dgemm, 11 misc.  enable(mask) resets the
+ * log; collect() synchronises the recorded events and returns summed milliseconds and launch counts. */
+#define EMCID_PROF_CLASSES 12
+int emcid_profile_enable(unsigned class_mask);
+int emcid_profile_collect(double* ms_per_class_host, int64_t* launches_per_class_host, int n_classes);
+
 /* ---------------------------------------------------------------------------------------------
  * Stage 0 — second moment.  Replaces `self.mom2 += a.t().mm(a)` (reference:
  * util/runningstats.py:493) for a = X[t, d] fp32.  Only the LOWER triangle (incl. diagonal) of

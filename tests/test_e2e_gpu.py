@@ -1,0 +1,225 @@
+"""End-to-end GPU parity: the drop-in entry points (HIP path) against the oracle and the golden vectors
+minted from the reference.  Run on the MI355X box:  python -m pytest tests -m gpu -x -q"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden, pipe_from_golden, write_cov_npz, write_vstars
+from emcid_amd import emcid_main as em, synthetic as syn
+from emcid_amd.emcid_hparams import EMCIDHyperParams, EMCIDXLHyperParams
+from emcid_amd.nethook import get_parameter
+from oracle import emcid_oracle as orc
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(autouse=True)
+def _fresh_caches():
+    em.clear_caches()
+    yield
+    em.clear_caches()
+
+
+def _toy_sd(tmp_path):
+    z, meta = load_golden("toy_sd")
+    te = pipe_from_golden(z, meta["kind"]).to(DEV)
+    pipe = syn.SyntheticPipe(text_encoder=te, tokenizer=syn.build_tokenizer())
+    cache = str(tmp_path / "cache") + "/"
+    write_vstars(cache, meta["requests"], z["vstar"])
+    for li, ln in enumerate(meta["layer_names"]):
+        write_cov_npz(tmp_path / "stats", ln, z[f"cov/{li}"], meta["hparams"]["mom2_n_samples"])
+    return z, meta, pipe, cache
+
+
+def test_toy_sd_execute_matches_reference_golden(tmp_path):
+    """execute_emcid_text_encoder: factors vs the REFERENCE's (golden), model unchanged afterwards."""
+    z, meta, pipe, cache = _toy_sd(tmp_path)
+    hp = EMCIDHyperParams(**meta["hparams"])
+    before = {ln: get_parameter(pipe.text_encoder, ln + ".weight").clone() for ln in meta["layer_names"]}
+    deltas = em.execute_emcid_text_encoder(pipe, meta["requests"], hp, cache_name=cache, mom2_weight=meta["lam"],
+                                           edit_weight=meta["ew"], verbose=False, stat_dir=str(tmp_path / "stats"))
+    assert hp.mom2_update_weight == meta["lam"] and hp.edit_weight == meta["ew"]   # mutated in place
+    assert list(deltas) == [ln + ".weight" for ln in meta["layer_names"]]
+    for li, ln in enumerate(meta["layer_names"]):
+        adj_k, resid = deltas[ln + ".weight"]
+        assert adj_k.device.type == "cpu" and adj_k.dtype == torch.float64
+        ref_a, ref_r = z[f"adj_k/{li}"], z[f"resid/{li}"]
+        assert adj_k.shape == ref_a.shape and resid.shape == ref_r.shape
+        # forward runs in fp32 on another device: K/Zc agree to ~1e-6, the fp64 algebra adds nothing visible
+        np.testing.assert_allclose(adj_k.numpy(), ref_a, rtol=0, atol=2e-4 * np.abs(ref_a).max())
+        np.testing.assert_allclose(resid.numpy(), ref_r, rtol=0, atol=2e-5 * np.abs(ref_r).max())
+        assert torch.equal(get_parameter(pipe.text_encoder, ln + ".weight"), before[ln])
+
+
+def test_toy_sd_apply_matches_reference_golden(tmp_path):
+    z, meta, pipe, cache = _toy_sd(tmp_path)
+    hp = EMCIDHyperParams(**meta["hparams"])
+    pipe2, orig = em.apply_emcid_to_text_encoder(pipe, meta["requests"], hp, DEV, mom2_weight=meta["lam"],
+                                                 edit_weight=meta["ew"], return_orig_text_encoder=True,
+                                                 cache_name=cache, stats_dir=str(tmp_path / "stats"), verbose=False)
+    assert pipe2 is pipe
+    for li, ln in enumerate(meta["layer_names"]):
+        w = get_parameter(pipe.text_encoder, ln + ".weight").cpu().numpy()
+        dw_ref = z[f"w_final/{li}"].astype(np.float64) - z[f"w_orig/{li}"]
+        dw = w.astype(np.float64) - z[f"w_orig/{li}"]
+        # BASELINE.json bar: dW max-abs error < 1e-4 and <= 1e-4 relative to max|dW|
+        err = np.abs(dw - dw_ref).max()
+        assert err < 1e-4 and err <= 1e-4 * np.abs(dw_ref).max(), (li, err, np.abs(dw_ref).max())
+        np.testing.assert_array_equal(get_parameter(orig, ln + ".weight").cpu().numpy(), z[f"w_orig/{li}"])
+
+
+def test_toy_sdxl_apply_matches_reference_golden(tmp_path):
+    """Dual-encoder edit incl. the TE2 = W + 2 dW quirk of the reference."""
+    z, meta = load_golden("toy_sdxl")
+    tok = syn.build_tokenizer()
+    pipe = syn.SyntheticPipe(text_encoder=pipe_from_golden(z, "toy", "w1/", name="synthetic/clip-text-1").to(DEV),
+                             tokenizer=tok,
+                             text_encoder_2=pipe_from_golden(z, "toy2", "w2/", name="synthetic/clip-text-2").to(DEV),
+                             tokenizer_2=tok)
+    cache = str(tmp_path / "cache") + "/"
+    write_vstars(cache, meta["requests"], z["vstar"])
+    write_vstars(cache, meta["requests"], z["vstar_2"], "_2")
+    ns = meta["hparams"]["mom2_n_samples"]
+    for li, ln in enumerate(meta["layer_names"]):
+        write_cov_npz(tmp_path / "s1", ln, z[f"cov/{li}"], ns)
+    for li, ln in enumerate(meta["layer_names_2"]):
+        write_cov_npz(tmp_path / "s2", ln, z[f"cov_2/{li}"], ns)
+    hp = EMCIDXLHyperParams(**meta["hparams"])
+    em.apply_emcid_to_model(pipe, meta["requests"], hp, DEV, mom2_weight=meta["mom2_weight"],
+                            mom2_weight_2=meta["mom2_weight_2"], edit_weight=meta["edit_weight"], cache_name=cache,
+                            stat_dir=str(tmp_path / "s1"), stat_dir_2=str(tmp_path / "s2"), verbose=False)
+    for names, enc, sfx in ((meta["layer_names"], pipe.text_encoder, ""), (meta["layer_names_2"], pipe.text_encoder_2, "_2")):
+        for li, ln in enumerate(names):
+            w = get_parameter(enc, ln + ".weight").cpu().numpy().astype(np.float64)
+            w0 = z[f"w_orig{sfx}/{li}"].astype(np.float64)
+            dw_ref = z[f"w_final{sfx}/{li}"].astype(np.float64) - w0
+            err = np.abs((w - w0) - dw_ref).max()
+            assert err < 1e-4 and err <= 1e-4 * np.abs(dw_ref).max(), (sfx, li, err)
+
+
+@pytest.mark.parametrize("n_req,ragged", [(24, False), (100, True), (1, False)])
+def test_real_dims_apply_vs_oracle(tmp_path, n_req, ragged):
+    """SD-v1.4 dims (768/3072, layers 7-10): HIP path vs the oracle's op-for-op CPU restatement."""
+    reqs = syn.make_requests(n_req, ragged=ragged)
+    hp_d = syn.sd_hparams_dict(prefix="text_model.")          # the reference's 4.x names resolve on 5.x too
+    layer_names = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers"]]
+    cache = str(tmp_path / "cache") + "/"
+    syn.write_vstar_cache(cache, reqs, 768, seed=1, scale=0.5)
+    syn.write_stats_cache(tmp_path / "stats", layer_names, 3072, hp_d["mom2_n_samples"], seed=2, t=6144)
+    cpu_pipe = syn.build_pipe("sd-v1.4", "cpu")
+    w0 = {ln: orc.get_parameter(cpu_pipe.text_encoder, ln + ".weight").clone() for ln in layer_names}
+    orc.apply_emcid_to_text_encoder(cpu_pipe, reqs, copy.deepcopy(hp_d), mom2_weight=4000, edit_weight=0.5,
+                                    cache_name=cache, stats_dir=str(tmp_path / "stats"))
+    gpu_pipe = syn.build_pipe("sd-v1.4", DEV)
+    em.apply_emcid_to_text_encoder(gpu_pipe, reqs, EMCIDHyperParams(**hp_d), DEV, mom2_weight=4000, edit_weight=0.5,
+                                   cache_name=cache, stats_dir=str(tmp_path / "stats"), verbose=False)
+    for ln in layer_names:
+        dw_ref = (orc.get_parameter(cpu_pipe.text_encoder, ln + ".weight").double() - w0[ln].double())
+        dw = get_parameter(gpu_pipe.text_encoder, ln + ".weight").cpu().double() - w0[ln].double()
+        err = (dw - dw_ref).abs().max().item()
+        assert err < 1e-4 and err <= 1e-4 * dw_ref.abs().max().item(), (ln, err, dw_ref.abs().max().item())
+
+
+def test_get_module_input_output_at_words_vs_oracle():
+    pipe = syn.build_pipe("toy", "cpu")
+    reqs = syn.make_requests(7, ragged=True)
+    k_ref, z_ref = orc.module_input_output_at_words(pipe.text_encoder, pipe.tokenizer, reqs, "encoder.layers.3.mlp.fc2")
+    from emcid_amd.compute_z import get_module_input_output_at_words
+    k, zc = get_module_input_output_at_words(pipe.text_encoder.to(DEV), pipe.tokenizer, reqs,
+                                             "text_model.encoder.layers.3.mlp.fc2")
+    torch.testing.assert_close(k.cpu(), k_ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(zc.cpu(), z_ref, rtol=1e-4, atol=1e-5)
+
+
+def test_missing_vstar_cache_is_loud(tmp_path):
+    pipe = syn.build_pipe("toy", DEV)
+    hp = EMCIDHyperParams(**syn.sd_hparams_dict(layers=(1, 2), mom2_n_samples=10, prefix=""))
+    with pytest.raises(NotImplementedError, match="Stage 1"):
+        em.apply_emcid_to_text_encoder(pipe, syn.make_requests(2), hp, DEV, cache_name=str(tmp_path / "none") + "/",
+                                       stats_dir=str(tmp_path), verbose=False)
+
+
+def test_bad_module_name_raises_lookuperror(tmp_path):
+    pipe = syn.build_pipe("toy", DEV)
+    d = syn.sd_hparams_dict(layers=(1, 2), mom2_n_samples=10, prefix="")
+    d["rewrite_module_tmp"] = "encoder.layers.{}.mlp.nope"
+    reqs = syn.make_requests(2)
+    cache = str(tmp_path / "cache") + "/"
+    syn.write_vstar_cache(cache, reqs, 32)
+    syn.write_stats_cache(tmp_path / "stats", [d["rewrite_module_tmp"].format(l) for l in (1, 2)], 128, 10, t=256)
+    with pytest.raises(LookupError):
+        em.apply_emcid_to_text_encoder(pipe, reqs, EMCIDHyperParams(**d), DEV, cache_name=cache,
+                                       stats_dir=str(tmp_path / "stats"), verbose=False)
+
+
+def test_subject_not_in_prompt_raises_valueerror(tmp_path):
+    pipe = syn.build_pipe("toy", DEV)
+    d = syn.sd_hparams_dict(layers=(1, 2), mom2_n_samples=10, prefix="")
+    reqs = [{"source": "zebra", "dest": "x", "prompts": ["a photo of tench"], "seed_train": 1}]
+    cache = str(tmp_path / "cache") + "/"
+    syn.write_vstar_cache(cache, reqs, 32)
+    syn.write_stats_cache(tmp_path / "stats", [d["rewrite_module_tmp"].format(l) for l in (1, 2)], 128, 10, t=256)
+    with pytest.raises(ValueError):
+        em.apply_emcid_to_text_encoder(pipe, reqs, EMCIDHyperParams(**d), DEV, cache_name=cache,
+                                       stats_dir=str(tmp_path / "stats"), verbose=False)
+
+
+def test_stage0_layer_stats_vs_reference_golden(tmp_path):
+    """Stage 0 on the GPU (single pass over both layers) vs the reference's own layer_stats output."""
+    import json
+    from emcid_amd.layer_stats import layer_stats_text_encoder_multi, layer_stats_text_encoder, stats_filename
+    z, meta = load_golden("toy_stage0")
+    data = tmp_path / "data" / "ccs_filtered.json"
+    data.parent.mkdir()
+    json.dump(meta["captions"], open(data, "w"))
+    pipe = syn.build_pipe(meta["kind"], DEV)
+    stats = layer_stats_text_encoder_multi(pipe.text_encoder, pipe.tokenizer, meta["layer_names"], tmp_path / "stats",
+                                           sample_size=meta["sample_size"], batch_tokens=meta["batch_tokens"],
+                                           data_path=str(data), progress=None, num_workers=0)
+    for li, ln in enumerate(meta["layer_names"]):
+        st = stats[ln]
+        assert st.mom2.count == int(z[f"count/{li}"])
+        ref = z[f"mom2/{li}"].astype(np.float64)
+        got = st.mom2.mom2.numpy().astype(np.float64)
+        assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()      # fp32 sums in another order
+        f = stats_filename(tmp_path / "stats", "text_encoder", "ccs_filtered", ln, "float32", ["mom2"],
+                           meta["batch_tokens"], meta["sample_size"])
+        with np.load(f) as npz:                                           # same npz schema as the reference
+            assert sorted(npz.files) == list(z[f"npz_keys/{li}"])
+            assert int(npz["sample_size"]) == meta["sample_size"] and int(npz["mom2.count"]) == st.mom2.count
+    # second call is served from the npz cache; per-layer entry point agrees
+    again = layer_stats_text_encoder(pipe.text_encoder, pipe.tokenizer, meta["layer_names"][0], tmp_path / "stats",
+                                     sample_size=meta["sample_size"], precision="float32",
+                                     batch_tokens=meta["batch_tokens"], data_path=str(tmp_path / "absent.json"),
+                                     progress=None)
+    np.testing.assert_array_equal(again.mom2.mom2.numpy(), stats[meta["layer_names"][0]].mom2.mom2.numpy())
+
+
+def test_cov_from_stage0_feeds_edit(tmp_path):
+    """get_cov_text_encoder computes Stage 0 on a cache miss and the edit consumes it (full path, no pre-made C)."""
+    import json, os
+    caps = syn.make_captions(300, seed=3)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        os.makedirs("data")
+        json.dump(caps, open("data/ccs_filtered.json", "w"))
+        pipe = syn.build_pipe("toy", DEV)
+        d = syn.sd_hparams_dict(layers=(2, 3), mom2_n_samples=200, prefix="")
+        reqs = syn.make_requests(5)
+        cache = str(tmp_path / "cache") + "/"
+        syn.write_vstar_cache(cache, reqs, 32, scale=0.5)
+        em.apply_emcid_to_text_encoder(pipe, reqs, EMCIDHyperParams(**d), DEV, mom2_weight=20, cache_name=cache,
+                                       stats_dir=str(tmp_path / "stats"), verbose=False)
+        cpu = syn.build_pipe("toy", "cpu")
+        orc.apply_emcid_to_text_encoder(cpu, reqs, dict(d), mom2_weight=20, cache_name=cache, stats_dir=str(tmp_path / "stats"))
+        for l in (2, 3):
+            n = f"encoder.layers.{l}.mlp.fc2.weight"
+            a, b = get_parameter(pipe.text_encoder, n).cpu(), orc.get_parameter(cpu.text_encoder, n)
+            assert (a - b).abs().max().item() < 1e-4
+    finally:
+        os.chdir(cwd)

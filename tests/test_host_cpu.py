@@ -1,0 +1,197 @@
+"""CPU tests: host logic of the drop-in boundary, cache formats, and that the C-ABI library loads and
+exports every symbol include/emcid_hip.h declares (no compute calls without a GPU)."""
+import ctypes
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, REPO
+from emcid_amd import hip, synthetic as syn
+from emcid_amd import runningstats as rs
+from emcid_amd.causal_trace import TokenRangeFinder, find_token_range
+from emcid_amd.compute_z import build_prompt_batch, expand_request_prompts
+from emcid_amd.emcid_hparams import EMCIDHyperParams, EMCIDXLHyperParams
+from emcid_amd.nethook import StopForward, Trace, TraceDict, get_module, get_parameter
+from emcid_amd.stat_dataset import TokenizedDataset, flatten_masked_batch, length_collation
+from oracle import emcid_oracle as orc
+
+
+def test_library_exports_every_declared_symbol():
+    header = (REPO / "include" / "emcid_hip.h").read_text()
+    declared = set(re.findall(r"\b(emcid_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(hip.EXPORTS), declared ^ set(hip.EXPORTS)
+    lib = ctypes.CDLL(str(hip.lib_path()))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert hip.load().emcid_abi_version() == hip.ABI_VERSION
+
+
+def test_c_abi_rejects_bad_arguments_without_gpu():
+    lib = hip.load()
+    assert lib.emcid_edit_workspace_bytes(0, 3072, 768) == 0
+    assert lib.emcid_edit_workspace_bytes(1000, 3072, 768) == 8 * (2 * 3072 * 3072 + 24 * 128 * 128 + 2 * 1024 * 3072 + 1024 * 768)
+    rc = lib.emcid_gram_accumulate_f32(None, 10, 128, 128, None, 128, 0, None)
+    assert rc == -1 and b"bad argument" in lib.emcid_last_error()
+    rc = lib.emcid_cholesky_f64(None, None, 100, 100, None, None, None)
+    assert rc == -1
+
+
+def test_product_refuses_cpu_tensors():
+    with pytest.raises(hip.EmcidHipError, match="HBM"):
+        hip.gram_accumulate_(torch.zeros(8, 8), torch.zeros(4, 8))
+    with pytest.raises(hip.EmcidHipError, match="HBM"):
+        rs.SecondMoment().add(torch.zeros(4, 8))
+
+
+def test_token_ranges_golden_and_memo():
+    tok = syn.build_tokenizer()
+    finder = TokenRangeFinder(tok)
+    for r in json.load(open(GOLDEN / "token_ranges.json")):
+        for fn in (finder, lambda ids, s: find_token_range(tok, torch.tensor(ids), s)):
+            if r["range"] == "ValueError":
+                with pytest.raises(ValueError):
+                    fn(r["ids"], r["subject"])
+            else:
+                assert list(fn(r["ids"], r["subject"])) == r["range"]
+
+
+def test_prompt_batch_matches_oracle_lookup():
+    tok = syn.build_tokenizer()
+    reqs = syn.make_requests(9, ragged=True)
+    reqs[3]["source"] = "Vincent van Gogh"
+    b = build_prompt_batch(tok, reqs, "cpu")
+    prompts, subjects, counts = orc.expand_requests(reqs)
+    enc = orc.tokenize_prompts(prompts, tok, "cpu")
+    look = [orc.find_token_range(tok, ids, w)[-1] - 1 for ids, w in zip(enc["input_ids"], subjects)]
+    assert b.lookup.tolist() == look and torch.equal(b.inputs["input_ids"], enc["input_ids"])
+    assert b.seg.tolist() == np.cumsum([0] + counts).tolist() and b.n_requests == 9
+
+
+def test_expand_requests_source_prompts_branch():
+    reqs = [{"source": "a", "dest": "b", "prompts": ["x {}", "y {}"], "source_prompts": ["pre a one", "pre a two"]},
+            {"source": "c", "dest": "b", "prompts": ["x {}", "y {}"], "source_prompts": ["pre c one", "pre c two"]}]
+    p, s, c = expand_request_prompts(reqs)
+    assert p == ["pre a one", "pre a two", "pre c one", "pre c two"] and s == ["a", "a", "c", "c"] and c == [2, 2]
+    assert (p, s, c) == orc.expand_requests(reqs)
+
+
+def test_nethook_prefix_tolerance_and_stop():
+    te = syn.build_text_encoder("toy")
+    m1 = get_module(te, "text_model.encoder.layers.2.mlp.fc2")
+    assert m1 is get_module(te, "encoder.layers.2.mlp.fc2")
+    assert get_parameter(te, "text_model.encoder.layers.2.mlp.fc2.weight") is m1.weight
+    with pytest.raises(LookupError):
+        get_module(te, "encoder.layers.99.mlp.fc2")
+    tok = syn.build_tokenizer()
+    enc = tok(["a photo of tench"], return_tensors="pt")
+    ran = []
+    h = get_module(te, "encoder.layers.3").register_forward_hook(lambda *a: ran.append(3))
+    with torch.no_grad(), Trace(te, "encoder.layers.2.mlp.fc2", retain_input=True, stop=True) as tr:
+        te(**enc)
+    h.remove()
+    assert ran == [] and tr.input.shape[-1] == 128 and tr.output.shape[-1] == 32
+    with torch.no_grad(), TraceDict(te, ["encoder.layers.0.mlp.fc2", "encoder.layers.1.mlp.fc2"], retain_input=True) as td:
+        te(**enc)
+    assert td["encoder.layers.1.mlp.fc2"].input.shape[-1] == 128
+
+
+def test_length_collation_matches_oracle(tmp_path):
+    tok = syn.build_tokenizer()
+    caps = syn.write_captions(tmp_path / "c.json", 120, seed=5)
+    ds = TokenizedDataset(str(tmp_path / "c.json"), tok)
+    items = [ds[i] for i in range(100)]
+    got = length_collation(300)(items)
+    ref = orc.length_sorted_subbatches([it["input_ids"].tolist() for it in items], 300)
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        pb = orc.pad_batch(r)
+        for k in ("input_ids", "position_ids", "attention_mask"):
+            assert torch.equal(g[k], pb[k])
+    data = torch.arange(2 * 3 * 4, dtype=torch.float32).reshape(2, 3, 4)
+    mask = torch.tensor([[1, 1, 0], [1, 0, 0]])
+    assert flatten_masked_batch(data, mask).shape == (3, 4)
+    with pytest.raises(FileNotFoundError):
+        TokenizedDataset(str(tmp_path / "missing.json"), tok)
+
+
+def test_fixed_random_subset_and_shards():
+    s = rs.FixedRandomSubsetSampler(range(1000), end=300, seed=1)
+    assert list(s) == orc.fixed_random_subset(1000, 300, seed=1)
+    parts = [list(s.shard(r, 3)) for r in range(3)]
+    assert sum(parts, []) == list(s)                       # partitioned, not re-drawn
+    assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def test_npz_cache_protocol_roundtrip(tmp_path):
+    st = rs.CombinedStat(mom2=rs.SecondMoment())
+    m = np.arange(16, dtype=np.float32).reshape(4, 4)
+    st.load_state_dict({"mom2.count": 7, "mom2.mom2": m, "mom2.constructor": "x"})
+    f = tmp_path / "a" / "s.npz"
+    rs.save_cached_state(f, st, {"sample_size": 50})
+    with np.load(f) as z:
+        assert sorted(z.files) == ["mom2.constructor", "mom2.count", "mom2.mom2", "sample_size"]
+        assert str(z["mom2.constructor"]) == "util.runningstats.SecondMoment()"
+    assert rs.load_cached_state(f, {"sample_size": 51}, quiet=True) is None     # invalidated by sample_size
+    dat = rs.load_cached_state(f, {"sample_size": 50}, quiet=True)
+    st2 = rs.CombinedStat(mom2=rs.SecondMoment())
+    st2.load_state_dict(dat)
+    assert st2.mom2.count == 7 and torch.equal(st2.mom2.moment(), torch.from_numpy(m) / 7)
+    with rs.cache_load_enabled(False):
+        assert rs.load_cached_state(f, {"sample_size": 50}, quiet=True) is None
+    # None <-> NaN-boxed null
+    boxed = rs.box_numpy_null({"a": None, "b": 3})
+    assert rs.is_null_numpy_value(boxed["a"]) and rs.unbox_numpy_null(boxed) == {"a": None, "b": 3}
+    assert not rs.is_null_numpy_value(np.array(np.nan))
+    # tally: cached -> empty loader
+    st3 = rs.CombinedStat(mom2=rs.SecondMoment())
+    assert list(rs.tally(st3, None, cache=f, sample_size=50, quiet=True)) == [] and st3.mom2.count == 7
+
+
+def test_hparams_load_shipped_schema(tmp_path):
+    d = syn.sd_hparams_dict()
+    p = tmp_path / "h.json"
+    json.dump(d, open(p, "w"))
+    hp = EMCIDHyperParams.from_json(p)
+    assert hp.layers == [7, 8, 9, 10] and hp.num_edit_tokens == 1 and hp.edit_weight == 0.5
+    x = EMCIDXLHyperParams.from_dict(syn.sdxl_hparams_dict())
+    assert x.layers_2 == [26, 27, 28, 29, 30] and x.mom2_update_weight_2 == 10000
+    with pytest.raises(TypeError):
+        EMCIDHyperParams(**{**d, "unknown_field": 1})
+
+
+def test_vstar_paths_and_loading(tmp_path):
+    from emcid_amd import emcid_main as em
+    hp = EMCIDHyperParams(**syn.sd_hparams_dict())
+    r = {"source": "tench", "dest": "goldfish", "source_cat": "fish"}
+    assert em.vstar_cache_file("c/", r, hp, 3).name == "source_tench_dest_goldfish.npz"
+    assert em.vstar_cache_file("c/", r, hp, 3, "_2").name == "source_tench_dest_goldfish_2.npz"
+    hp.objective = "esd"
+    assert em.vstar_cache_file("c/", r, hp, 3).name == "source_tench.npz"
+    hp.objective, hp.sld_supervision = "ablate-dest", True
+    assert em.vstar_cache_file("c/", r, hp, 3).name == "source_fish_3.npz"
+    assert em.vstar_cache_file(None, r, hp, 3) is None
+    hp.sld_supervision = False
+    reqs = syn.make_requests(4)
+    cache = str(tmp_path / "cache") + "/"
+    vs = syn.write_vstar_cache(cache, reqs, 32, seed=4)
+    got = em.load_v_stars(reqs, hp, cache)
+    assert got.dtype == torch.float32 and np.array_equal(got.numpy(), vs)
+    assert torch.equal(got.t(), orc.load_vstars(cache, reqs))                    # zs = rows transposed
+    with pytest.raises(NotImplementedError):
+        em.load_v_stars(syn.make_requests(5), hp, cache)
+    filled = em.load_v_stars(syn.make_requests(5), hp, cache, stage1=lambda req, sfx: torch.ones(32))
+    assert filled.shape == (5, 32) and (Path(cache) / "source_c0004_dest_a realist artist.npz").exists()
+
+
+def test_upd_matrix_match_shape():
+    from emcid_amd.emcid_main import upd_matrix_match_shape
+    m = torch.zeros(3, 5)
+    assert upd_matrix_match_shape(m, torch.Size([3, 5])) is m
+    assert upd_matrix_match_shape(m, torch.Size([5, 3])).shape == (5, 3)
+    assert upd_matrix_match_shape(torch.zeros(4, 6), torch.Size([4, 6, 1, 1])).shape == (4, 6, 1, 1)
+    with pytest.raises(ValueError):
+        upd_matrix_match_shape(m, torch.Size([2, 2]))
