@@ -21,6 +21,7 @@ import torch
 
 from . import hip
 from .causal_trace import TokenRangeFinder
+from .clip_attention import hip_attention
 from .nethook import StopForward, get_module
 
 
@@ -63,7 +64,8 @@ class PromptBatch:
         return int(self.lookup.numel())
 
 
-def build_prompt_batch(tokenizer, requests: Sequence[Dict], device, finder: Optional[TokenRangeFinder] = None) -> PromptBatch:
+def build_prompt_batch(tokenizer, requests: Sequence[Dict], device, finder: Optional[TokenRangeFinder] = None,
+                       truncate: bool = True) -> PromptBatch:
     prompts, subjects, counts = expand_request_prompts(requests)
     enc = tokenizer(prompts, return_tensors="pt", padding=True, truncation=True)
     finder = finder or TokenRangeFinder(tokenizer)
@@ -78,6 +80,11 @@ def build_prompt_batch(tokenizer, requests: Sequence[Dict], device, finder: Opti
     seg = np.cumsum([0] + counts)
     if seg[-1] != len(prompts):
         raise ValueError(f"request prompt counts ({seg[-1]}) do not cover the {len(prompts)} prompts")
+    if truncate:
+        # CLIP text attention is causal: nothing at or before a lookup token depends on later positions, so
+        # the columns after the last lookup index (EOS, padding) are never needed by the K/Z gather.
+        keep = max(lookup) + 1
+        enc = {k: v[:, :keep] for k, v in enc.items()}
     return PromptBatch(
         inputs={k: v.to(device) for k, v in enc.items()},
         lookup=torch.tensor(lookup, dtype=torch.int64, device=device),
@@ -113,7 +120,7 @@ def get_module_input_output_at_words(text_encoder, tok, requests: List[Dict], mo
 
     handle = get_module(text_encoder, module_name).register_forward_hook(hook)
     try:
-        with torch.no_grad():
+        with torch.no_grad(), hip_attention(text_encoder):
             try:
                 text_encoder(**batch.inputs)
             except StopForward:

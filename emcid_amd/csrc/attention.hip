@@ -1,0 +1,132 @@
+// Fused softmax(Q K^T * scale + mask) V for CLIP text-encoder shapes on gfx950: fp32, head_dim <= 128,
+// S <= 77 tokens, tens of thousands of (prompt, head) pairs.  Part of the K/Z assembly forward
+// (reference: emcid/compute_z.py:2296-2308 runs HF CLIPTextModel.forward; its attention is the eager
+// bmm + softmax + bmm of transformers' CLIPAttention).  The library SDPA kernel the framework would pick
+// takes ~1.35 ms per layer at B=3000, S=9 (rocprof, profiles/r01_a_*); this path is HBM-bound instead:
+// one wave owns one (prompt, head) pair, stages its Q/K/V rows (S x D floats each, coalesced 256-B rows)
+// into LDS once, and never writes the S x S scores to memory.
+//   scores : lane <-> (i, j) pair, dot product over D from LDS (rows padded to D+1 floats)
+//   softmax: lane <-> query row, exact expf
+//   P V    : lane <-> output column d, P[i][j] is an LDS broadcast, V[j][d] conflict-free
+// `causal` skips j > i (CLIP text is causal); an optional mask (bool keep-mask or additive float,
+// broadcastable over heads) covers right-padded prompts.
+#include "common.h"
+
+namespace emcid {
+
+struct AttnArgs {
+    const float* q; const float* k; const float* v;
+    int64_t sb, sh, ss;            // element strides of q/k/v for (batch, head, token); d-stride is 1
+    const void* mask; int mask_kind;  // 0 none, 1 uint8 keep-mask, 2 float additive
+    int64_t mb, mi;                // mask strides for (batch, query row); key stride is 1; head-broadcast
+    int causal; float scale;
+    int B, H, S, D;
+    float* out;                    // [B][S][H][D] contiguous
+};
+
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attention_f32_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int S = a.S, D = a.D, DP = D + 1, SP = S + 1;
+    const int per_wave = 3 * S * DP + S * SP;
+    float* Qs = smem + wave * per_wave;
+    float* Ks = Qs + S * DP;
+    float* Vs = Ks + S * DP;
+    float* P = Vs + S * DP;
+    const int64_t total = (int64_t)a.B * a.H;
+    int64_t pair = (int64_t)blockIdx.x * WAVES + wave;
+    const bool live = pair < total;
+    if (!live) pair = total - 1;   // keep every wave on the same barrier schedule; results are discarded
+    const int b = (int)(pair / a.H), h = (int)(pair % a.H);
+    const int64_t base = b * a.sb + h * a.sh;
+
+    for (int r = 0; r < S; ++r)
+        for (int d = lane; d < D; d += 64) {
+            const int64_t g = base + r * a.ss + d;
+            Qs[r * DP + d] = a.q[g];
+            Ks[r * DP + d] = a.k[g];
+            Vs[r * DP + d] = a.v[g];
+        }
+    __syncthreads();
+
+    for (int e = lane; e < S * S; e += 64) {
+        const int i = e / S, j = e % S;
+        float s;
+        if (a.causal && j > i) {
+            s = -INFINITY;
+        } else {
+            float acc = 0.f;
+            const float* qi = Qs + i * DP;
+            const float* kj = Ks + j * DP;
+#pragma unroll 8
+            for (int d = 0; d < D; ++d) acc = fmaf(qi[d], kj[d], acc);
+            s = acc * a.scale;
+            if (a.mask_kind == 1) {
+                if (!reinterpret_cast<const unsigned char*>(a.mask)[b * a.mb + i * a.mi + j]) s = -INFINITY;
+            } else if (a.mask_kind == 2) {
+                s += reinterpret_cast<const float*>(a.mask)[b * a.mb + i * a.mi + j];
+            }
+        }
+        P[i * SP + j] = s;
+    }
+    __syncthreads();
+
+    for (int i = lane; i < S; i += 64) {
+        float* row = P + i * SP;
+        float m = -INFINITY;
+        for (int j = 0; j < S; ++j) m = fmaxf(m, row[j]);
+        float sum = 0.f;
+        for (int j = 0; j < S; ++j) {
+            const float p = expf(row[j] - m);
+            row[j] = p;
+            sum += p;
+        }
+        const float inv = 1.f / sum;
+        for (int j = 0; j < S; ++j) row[j] *= inv;
+    }
+    __syncthreads();
+
+    if (live) {
+        for (int d = lane; d < D; d += 64) {
+            for (int i = 0; i < S; ++i) {
+                const int jend = a.causal ? i + 1 : S;
+                float acc = 0.f;
+                for (int j = 0; j < jend; ++j) acc = fmaf(P[i * SP + j], Vs[j * DP + d], acc);
+                a.out[(((int64_t)b * S + i) * a.H + h) * D + d] = acc;
+            }
+        }
+    }
+}
+
+}  // namespace emcid
+
+using namespace emcid;
+
+extern "C" int emcid_attention_f32(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t ss,
+                                   const void* mask, int mask_kind, int64_t mb, int64_t mi, int causal, float scale,
+                                   int64_t B, int64_t H, int64_t S, int64_t D, float* out, void* stream) {
+    EMCID_CHECK_ARG(q && k && v && out && B > 0 && H > 0 && S > 0 && D > 0);
+    EMCID_CHECK_ARG(S <= 128 && D <= 128 && B * H < (1LL << 31));
+    EMCID_CHECK_ARG(mask_kind >= 0 && mask_kind <= 2 && ((mask_kind == 0) == (mask == nullptr)));
+    AttnArgs a{q, k, v, sb, sh, ss, mask, mask_kind, mb, mi, causal, scale, (int)B, (int)H, (int)S, (int)D, out};
+    const size_t per_wave = (size_t)(3 * S * (D + 1) + S * (S + 1)) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    ScopedProf sp(KC_MISC, st);
+    const int64_t pairs = B * H;
+    if (per_wave * 4 <= 64 * 1024) {
+        hipLaunchKernelGGL(attention_f32_kernel<4>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), per_wave * 4, st, a);
+    } else {
+        if (per_wave > 160 * 1024) return fail(EMCID_ERR_BAD_ARG, __func__, "S x D too large for one wave's LDS image");
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f32_kernel<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return fail(EMCID_ERR_HIP, __func__, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attention_f32_kernel<1>, dim3((unsigned)pairs), dim3(64), per_wave, st, a);
+    }
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}

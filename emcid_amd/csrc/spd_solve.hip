@@ -25,11 +25,11 @@ bool g_prof_init = false;
 void prof_begin(int cls, hipStream_t st) {
     if (!(g_prof_mask & (1u << cls)) || g_prof_n >= PROF_MAX) return;
     g_prof_cls[g_prof_n] = cls;
-    hipEventRecord(g_prof_ev[g_prof_n][0], st);
+    (void)hipEventRecord(g_prof_ev[g_prof_n][0], st);
 }
 void prof_end(int cls, hipStream_t st) {
     if (!(g_prof_mask & (1u << cls)) || g_prof_n >= PROF_MAX) return;
-    hipEventRecord(g_prof_ev[g_prof_n][1], st);
+    (void)hipEventRecord(g_prof_ev[g_prof_n][1], st);
     ++g_prof_n;
 }
 
@@ -71,69 +71,201 @@ __global__ __launch_bounds__(256) void axpy_f32_kernel(float* __restrict__ W, co
     for (; i < n; i += stride) W[i] += dW[i];
 }
 
-// ---- diagonal leaf: Cholesky of one NB x NB block + its inverse, one workgroup, all in LDS ------------
+// ---- diagonal leaf: Cholesky of one NB x NB block + its inverse, one workgroup ---------------------------
+//
+// The leaf is the serial spine of the factorization (d sequential pivots), so it is built for latency:
+//  * the 128-block is processed as four 32-column panels;
+//  * a panel's 32x32 diagonal block is factored by ONE wave entirely in registers: lane i < 32 holds row i,
+//    and lanes 32..63 hold the rows of an identity appended below it.  Running the same right-looking
+//    elimination on the augmented [A; I] leaves L in the top lanes and Z = L^-T in the bottom lanes
+//    ([A; I] = [L; Z] L^T), so the block's inverse costs no extra instructions.  Pivot rows are broadcast
+//    with v_readlane (lane index is a compile-time constant after unrolling); 1/sqrt(pivot) is v_rsq_f64
+//    plus two Newton steps;
+//  * the rows below the diagonal block (panel solve P = A_below * Z) and the in-leaf trailing update
+//    (T -= P P^T) are f64 MFMAs straight out of the LDS image, all four waves;
+//  * the inverse of the whole 128-block is assembled from the four 32x32 inverses by two levels of
+//    inv([[A,0],[C,B]]) = [[A^-1,0],[-B^-1 C A^-1, B^-1]], again MFMA out of LDS.
+// LDS image S[128][130]: row stride 130 doubles (= 4*65 dwords) makes the k-contiguous MFMA fragment
+// reads (16 rows x 2 k) hit 64 distinct banks.
 
-constexpr int LEAF_T = 512;
-constexpr int SLD = NB + 1;
+constexpr int LEAF_T = 256;
+constexpr int SB = 32;        // register-factored diagonal sub-block
+constexpr int SLD = NB + 2;   // 130
+constexpr int ZLD = 48;       // temp tiles [32][48]: k-row stride == 32 (mod 64) dwords
+
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double rsqrt_f64(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    // two Newton steps: r <- r * (1.5 - 0.5 * d * r^2)
+    const double hd = 0.5 * d;
+    r = r * fma(-hd * r, r, 1.5);
+    r = r * fma(-hd * r, r, 1.5);
+    return r;
+}
+
+// one 16x16 output tile, K deep, operands fetched through address functors (doubles in LDS)
+template <int K, class FA, class FB>
+__device__ __forceinline__ v4d leaf_tile(const double* lds, FA fa, FB fb, int l15, int l4) {
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < K / 4; ++kk) {
+        const double a = lds[fa(l15, kk * 4 + l4)];
+        const double b = lds[fb(kk * 4 + l4, l15)];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
 
 __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restrict__ A, int64_t lda, double* __restrict__ L,
                                                             int64_t ldl, double* __restrict__ inv, int* info, int col0) {
-    __shared__ double S[NB * SLD];
-    __shared__ double sq[NB];
-    const int tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) double lds[NB * SLD + 2 * SB * ZLD];
+    double* S = lds;
+    constexpr int ZOFF = NB * SLD;          // two [32][48] temporaries behind S
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+
     for (int e = tid; e < NB * NB; e += LEAF_T) {
         const int i = e / NB, j = e % NB;
         S[i * SLD + j] = (j <= i) ? A[(int64_t)i * lda + j] : 0.0;
     }
     __syncthreads();
 
-    // Square-root-free right-looking elimination: column k keeps its UNSCALED values (= L[i][k]*sqrt(d_k)),
-    // so a step only writes columns > k and needs one barrier; the scaling is a parallel pass afterwards.
-    const int ty = tid >> 5, tx = tid & 31;
-    for (int k = 0; k < NB - 1; ++k) {
-        const double dkk = S[k * SLD + k];
-        const double invd = 1.0 / dkk;
-        for (int i = k + 1 + ty; i < NB; i += LEAF_T / 32) {
-            const double lik = S[i * SLD + k] * invd;
-            for (int j = k + 1 + tx; j <= i; j += 32) S[i * SLD + j] -= lik * S[j * SLD + k];
-        }
-        __syncthreads();
-    }
-    if (tid < NB) {
-        const double dkk = S[tid * SLD + tid];
-        if (!(dkk > 0.0)) atomicCAS(info, 0, col0 + tid + 1);  // not SPD (or NaN): report first seen pivot
-        sq[tid] = sqrt(dkk);
-    }
-    __syncthreads();
-    for (int e = tid; e < NB * NB; e += LEAF_T) {
-        const int i = e / NB, j = e % NB;
-        double v = 0.0;
-        if (j < i) v = S[i * SLD + j] / sq[j];
-        else if (j == i) v = sq[j];
-        S[i * SLD + j] = v;
-        L[(int64_t)i * ldl + j] = v;
-    }
-    __syncthreads();
+    int badcol = -1;   // first non-positive pivot seen by wave 0 (uniform)
+#pragma unroll 1
+    for (int p = 0; p < NB / SB; ++p) {
+        const int c0 = p * SB;
+        const int R0 = c0 + SB;               // first row below the diagonal block
+        const int mb = (NB - R0) / 16;        // 16-row blocks below
 
-    // In-place inverse of the lower-triangular block, last column first:
-    //   X[j][j] = 1/L[j][j];  X[i][j] = -X[j][j] * sum_{k=j+1..i} X[i][k] * L[k][j]   (i > j)
-    // row i is owned by 4 consecutive lanes that split the k range and reduce with DPP shuffles.
-    const int row = tid >> 2, part = tid & 3;
-    for (int j = NB - 1; j >= 0; --j) {
-        const double xjj = 1.0 / S[j * SLD + j];
-        double t = 0.0;
-        if (row > j) {
-            for (int k = j + 1 + part; k <= row; k += 4) t += S[row * SLD + k] * S[k * SLD + j];
+        // ---- phase A: wave 0 factors the diagonal block and its inverse in registers -----------------------
+        if (wave == 0) {
+            double a[SB];
+            const int r = lane & 31;
+            if (lane < 32) {
+#pragma unroll
+                for (int j = 0; j < SB; ++j) a[j] = S[(c0 + r) * SLD + c0 + j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < SB; ++j) a[j] = (j == r) ? 1.0 : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+                const double dkk = readlane_f64(a[k], k);
+                if (badcol < 0 && !(dkk > 0.0)) badcol = c0 + k;
+                const double rs = rsqrt_f64(dkk);
+                a[k] *= rs;                                   // column k of [L; Z]
+#pragma unroll
+                for (int j = k + 1; j < SB; ++j) {
+                    const double ljk = readlane_f64(a[k], j);  // L[j][k]
+                    a[j] = fma(-a[k], ljk, a[j]);
+                }
+            }
+            if (lane < 32) {
+                // L_pp -> global (lower valid, zeros above)
+#pragma unroll
+                for (int j = 0; j < SB; ++j) L[(int64_t)(c0 + r) * ldl + c0 + j] = (j <= r) ? a[j] : 0.0;
+            } else {
+                // Z = L^-T.  Zs[k][c] = Z[k][c] feeds the panel solve; inv_pp[rr][c] = Z[c][rr] replaces the
+                // diagonal block in S (nothing reads L_pp from LDS any more).
+#pragma unroll
+                for (int j = 0; j < SB; ++j) {
+                    lds[ZOFF + r * ZLD + j] = a[j];
+                    S[(c0 + j) * SLD + c0 + r] = a[j];
+                }
+            }
         }
-        t += __shfl_xor(t, 1);
-        t += __shfl_xor(t, 2);
-        __syncthreads();  // every read of column j (rows > j) is done
-        if (part == 0) {
-            if (row > j) S[row * SLD + j] = -xjj * t;
-            else if (row == j) S[j * SLD + j] = xjj;
+        __syncthreads();
+        if (mb == 0) break;
+
+        // ---- phase B: P = A_below * Z (rows R0.., 32 columns), in place; one wave owns a 16-row block ---------
+        for (int ib = wave; ib < mb; ib += LEAF_T / 64) {
+            const int r0 = R0 + ib * 16;
+            v4d acc[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+                acc[cb] = leaf_tile<SB>(lds, [&](int i, int k) { return (r0 + i) * SLD + c0 + k; },
+                                        [&](int k, int j) { return ZOFF + k * ZLD + cb * 16 + j; }, l15, l4);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = r0 + l4 + 4 * q, col = c0 + cb * 16 + l15;
+                    S[row * SLD + col] = acc[cb][q];
+                    L[(int64_t)row * ldl + col] = acc[cb][q];
+                }
+        }
+        __syncthreads();
+
+        // ---- phase C: trailing update T -= P P^T on the lower 16x16 tiles ---------------------------------------
+        const int ntiles = mb * (mb + 1) / 2;
+        for (int t = wave; t < ntiles; t += LEAF_T / 64) {
+            int ib = 0, rem = t;
+            while (rem > ib) { rem -= ib + 1; ++ib; }
+            const int jb = rem;
+            const int ri = R0 + ib * 16, rj = R0 + jb * 16;
+            const v4d acc = leaf_tile<SB>(lds, [&](int i, int k) { return (ri + i) * SLD + c0 + k; },
+                                          [&](int k, int j) { return (rj + j) * SLD + c0 + k; }, l15, l4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) S[(ri + l4 + 4 * q) * SLD + rj + l15] -= acc[q];
         }
         __syncthreads();
     }
+    if (wave == 0 && lane == 0 && badcol >= 0) atomicCAS(info, 0, col0 + badcol + 1);  // not SPD (or NaN pivot)
+
+    // ---- inverse assembly, level 1: the two 64-blocks.  X = -B (C A), A/B = 32x32 inverses, C = L block ------
+    {
+        const int q = wave >> 1;               // waves 0,1 -> block 0 ; waves 2,3 -> block 1
+        const int b = 64 * q;
+        const int toff = ZOFF + q * SB * ZLD;
+        // T1 = C A  (2x2 tiles, two per wave)
+        for (int t = (wave & 1); t < 4; t += 2) {
+            const int ti = t >> 1, tj = t & 1;
+            const v4d acc = leaf_tile<SB>(lds, [&](int i, int k) { return (b + 32 + ti * 16 + i) * SLD + b + k; },
+                                          [&](int k, int j) { return (b + k) * SLD + b + tj * 16 + j; }, l15, l4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lds[toff + (ti * 16 + l4 + 4 * r) * ZLD + tj * 16 + l15] = acc[r];
+        }
+        __syncthreads();
+        for (int t = (wave & 1); t < 4; t += 2) {
+            const int ti = t >> 1, tj = t & 1;
+            const v4d acc = leaf_tile<SB>(lds, [&](int i, int k) { return (b + 32 + ti * 16 + i) * SLD + b + 32 + k; },
+                                          [&](int k, int j) { return toff + k * ZLD + tj * 16 + j; }, l15, l4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(b + 32 + ti * 16 + l4 + 4 * r) * SLD + b + tj * 16 + l15] = -acc[r];
+        }
+        __syncthreads();
+    }
+    // ---- level 2: X64 = -B64 (C64 A64); T lives in the unused upper-right block S[0:64][64:128] ----------------
+    for (int t = wave; t < 16; t += LEAF_T / 64) {
+        const int ti = t >> 2, tj = t & 3;
+        const v4d acc = leaf_tile<64>(lds, [&](int i, int k) { return (64 + ti * 16 + i) * SLD + k; },
+                                      [&](int k, int j) { return k * SLD + tj * 16 + j; }, l15, l4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(ti * 16 + l4 + 4 * r) * SLD + 64 + tj * 16 + l15] = acc[r];
+    }
+    __syncthreads();
+    {
+        v4d acc[4];
+        int n = 0;
+        for (int t = wave; t < 16; t += LEAF_T / 64, ++n) {
+            const int ti = t >> 2, tj = t & 3;
+            acc[n] = leaf_tile<64>(lds, [&](int i, int k) { return (64 + ti * 16 + i) * SLD + 64 + k; },
+                                   [&](int k, int j) { return k * SLD + 64 + tj * 16 + j; }, l15, l4);
+        }
+        __syncthreads();   // all reads of B64 / T done before C64's place is overwritten
+        n = 0;
+        for (int t = wave; t < 16; t += LEAF_T / 64, ++n) {
+            const int ti = t >> 2, tj = t & 3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(64 + ti * 16 + l4 + 4 * r) * SLD + tj * 16 + l15] = -acc[n][r];
+        }
+    }
+    __syncthreads();
     for (int e = tid; e < NB * NB; e += LEAF_T) {
         const int i = e / NB, j = e % NB;
         inv[e] = (j <= i) ? S[i * SLD + j] : 0.0;

@@ -25,6 +25,7 @@ import torch
 import torch.nn.functional as F
 
 from . import hip
+from .clip_attention import hip_attention
 from .compute_z import PromptBatch, build_prompt_batch, gather_request_means
 from .nethook import StopForward, get_module, get_parameter
 
@@ -146,7 +147,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
     for i, l in enumerate(plan.layers):
         handles.append(mods[l].register_forward_hook(make_hook(i, l)))
     try:
-        with torch.no_grad():
+        with torch.no_grad(), hip_attention(te):
             try:
                 te(**plan.batch.inputs)
             except StopForward:

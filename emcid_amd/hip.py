@@ -19,7 +19,7 @@ EXPORTS = [
     "emcid_abi_version", "emcid_last_error", "emcid_gram_accumulate_f32", "emcid_symmetrize_lower_f32",
     "emcid_gather_mean_f32", "emcid_edit_workspace_bytes", "emcid_edit_layer_f64", "emcid_assemble_spd_f64",
     "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_axpy_f32",
-    "emcid_profile_enable", "emcid_profile_collect",
+    "emcid_profile_enable", "emcid_profile_collect", "emcid_attention_f32",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc"]
@@ -64,6 +64,7 @@ def load():
         "emcid_axpy_f32": (i32, [p, p, i64, p]),
         "emcid_profile_enable": (i32, [C.c_uint]),
         "emcid_profile_collect": (i32, [p, p, i32]),
+        "emcid_attention_f32": (i32, [p, p, p, i64, i64, i64, p, i32, i64, i64, i32, f32, i64, i64, i64, i64, p, p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
@@ -223,3 +224,32 @@ def profile_collect():
     cnt = (C.c_int64 * n)()
     _check(load().emcid_profile_collect(ms, cnt, n), "emcid_profile_collect")
     return {PROF_CLASSES[i]: (ms[i], int(cnt[i])) for i in range(n) if cnt[i]}
+
+
+def attention(q, k, v, mask=None, causal=False, scale=None):
+    """q/k/v: (B, H, S, D) fp32 views with unit stride over D and identical strides; mask: None, bool keep-mask or
+    additive float, shape (B|1, 1, S, S).  Returns (B, S, H, D) contiguous."""
+    B, H, S, D = q.shape
+    for t in (q, k, v):
+        if t.stride(3) != 1 or t.stride() != q.stride() or t.shape != q.shape:
+            raise EmcidHipError("attention: q/k/v must share shape/strides with unit stride over head_dim")
+    out = torch.empty(B, S, H, D, dtype=torch.float32, device=q.device)
+    kind, mptr, mb, mi = 0, None, 0, 0
+    if mask is not None:
+        if mask.dim() != 4 or mask.shape[1] != 1 or mask.shape[2] != S or mask.shape[3] != S or mask.stride(3) != 1:
+            mask = mask.expand(-1, 1, S, S).contiguous() if mask.dim() == 4 and mask.shape[1] == 1 else None
+            if mask is None:
+                raise EmcidHipError("attention: mask must be (B|1, 1, S, S)")
+        if mask.dtype == torch.bool:
+            kind, mptr = 1, _ptr(mask)
+        elif mask.dtype == torch.float32:
+            kind, mptr = 2, _ptr(mask)
+        else:
+            raise EmcidHipError(f"attention: mask dtype {mask.dtype} not supported")
+        mb = mask.stride(0) if mask.shape[0] > 1 else 0
+        mi = mask.stride(2)
+    scale = float(D ** -0.5 if scale is None else scale)
+    _check(load().emcid_attention_f32(_ptr(q, torch.float32, "q"), _ptr(k, torch.float32, "k"), _ptr(v, torch.float32, "v"),
+                                      q.stride(0), q.stride(1), q.stride(2), mptr, kind, mb, mi, int(bool(causal)), scale,
+                                      B, H, S, D, _ptr(out), _stream(q)), "emcid_attention_f32")
+    return out

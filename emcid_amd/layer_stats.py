@@ -19,6 +19,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 from tqdm.auto import tqdm
 
+from .clip_attention import hip_attention
 from .globals import STATS_DIR
 from .nethook import StopForward, get_module, set_requires_grad
 from .runningstats import CombinedStat, SecondMoment, load_cached_state, save_cached_state, make_loader, tally
@@ -94,7 +95,7 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
     n_groups = -(-(len(loader.sampler) if loader.sampler is not None else len(ds)) // batch_size)
     wrap = progress if progress is not None else (lambda it, total=None: it)
     try:
-        with torch.no_grad():
+        with torch.no_grad(), hip_attention(model):
             for batch_group in wrap(loader, total=n_groups):
                 for batch in batch_group:
                     batch = dict_to_(batch, device)

@@ -65,6 +65,19 @@ int emcid_gather_mean_f32(const float* act, int64_t B, int64_t S, int64_t c, int
                           float* out, int64_t ldo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K/Z assembly forward — fused attention for CLIP text shapes (fp32, S <= 128, head_dim <= 128):
+ *   out[b, i, h, :] = softmax_j(scale * q[b,h,i,:].k[b,h,j,:] + mask[b,i,j]) v[b,h,j,:]
+ * Replaces the eager bmm/softmax/bmm of transformers' CLIPAttention inside the hooked forward the reference
+ * runs (reference: emcid/compute_z.py:2296-2308).  q/k/v are [B,H,S,D] VIEWS with element strides
+ * (sb, sh, ss) and unit stride over D (the layout HF produces: proj(x).view(B,S,H,D).transpose(1,2));
+ * out is [B,S,H,D] contiguous.  mask_kind: 0 none; 1 uint8 keep-mask; 2 float additive; mask element
+ * (b, i, j) is at b*mb + i*mi + j (broadcast over heads).  causal != 0 additionally drops j > i.
+ * ------------------------------------------------------------------------------------------- */
+int emcid_attention_f32(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t ss,
+                        const void* mask, int mask_kind, int64_t mb, int64_t mi, int causal, float scale,
+                        int64_t B, int64_t H, int64_t S, int64_t D, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Stage 2 — per-layer closed form (reference: emcid/emcid_main.py:1016-1061).
  *
  * emcid_edit_workspace_bytes: bytes of f64 workspace emcid_edit_layer_f64 needs for (N, d, h).

@@ -63,12 +63,18 @@ def test_prompt_batch_matches_oracle_lookup():
     tok = syn.build_tokenizer()
     reqs = syn.make_requests(9, ragged=True)
     reqs[3]["source"] = "Vincent van Gogh"
-    b = build_prompt_batch(tok, reqs, "cpu")
+    b = build_prompt_batch(tok, reqs, "cpu", truncate=False)
     prompts, subjects, counts = orc.expand_requests(reqs)
     enc = orc.tokenize_prompts(prompts, tok, "cpu")
     look = [orc.find_token_range(tok, ids, w)[-1] - 1 for ids, w in zip(enc["input_ids"], subjects)]
     assert b.lookup.tolist() == look and torch.equal(b.inputs["input_ids"], enc["input_ids"])
     assert b.seg.tolist() == np.cumsum([0] + counts).tolist() and b.n_requests == 9
+    # default: columns after the last lookup token are dropped (causal encoder: they cannot matter)
+    bt = build_prompt_batch(tok, reqs, "cpu")
+    keep = max(look) + 1
+    assert bt.inputs["input_ids"].shape[1] == keep < enc["input_ids"].shape[1]
+    assert torch.equal(bt.inputs["input_ids"], enc["input_ids"][:, :keep]) and bt.lookup.tolist() == look
+    assert torch.equal(bt.inputs["attention_mask"], enc["attention_mask"][:, :keep])
 
 
 def test_expand_requests_source_prompts_branch():

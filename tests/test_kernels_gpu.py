@@ -138,3 +138,46 @@ def test_gather_mean_bitwise_vs_torch_cpu():
     ref = torch.stack([rows[seg[i]:seg[i + 1]].mean(0) for i in range(len(counts))])
     out = hip.gather_mean(act.to(DEV), idx.to(DEV), seg.to(DEV))
     assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("B,H,S,D", [(7, 4, 9, 64), (3, 12, 17, 64), (2, 20, 77, 64), (5, 2, 1, 16), (4, 3, 33, 24)])
+@pytest.mark.parametrize("mask_kind", ["none", "bool", "float"])
+def test_attention_vs_torch_fp32(B, H, S, D, mask_kind):
+    """Fused attention vs the plain-PyTorch fp32 eager formula (floating point: tolerance 2e-6 abs on O(1) values)."""
+    g = torch.Generator().manual_seed(9)
+    hidden = torch.randn(B, S, 3, H, D, generator=g).to(DEV)
+    q, k, v = (hidden[:, :, i].transpose(1, 2) for i in range(3))       # strided (B,H,S,D) views like HF's
+    lens = torch.randint(1, S + 1, (B,), generator=g)
+    keep = (torch.arange(S)[None, :] < lens[:, None])                    # right padding
+    causal = torch.ones(S, S, dtype=torch.bool).tril()
+    keep4 = (keep[:, None, None, :] & causal[None, None]).to(DEV)
+    if mask_kind == "none":
+        mask, ref_mask = None, causal.to(DEV)[None, None]
+    elif mask_kind == "bool":
+        mask, ref_mask = keep4, keep4
+    else:
+        mask = torch.zeros(B, 1, S, S, device=DEV).masked_fill(~keep4, float("-inf"))
+        ref_mask = keep4
+    scale = D ** -0.5
+    w = torch.matmul(q, k.transpose(-1, -2)) * scale
+    w = w.masked_fill(~ref_mask, float("-inf"))
+    ref = torch.matmul(torch.softmax(w, dim=-1), v).transpose(1, 2).contiguous()
+    out = hip.attention(q, k, v, mask, causal=True, scale=scale)
+    assert out.shape == (B, S, H, D)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-6)
+
+
+def test_hip_attention_inside_hf_forward():
+    """Encoder forward with the registered HIP attention == the same forward with HF's own attention."""
+    from emcid_amd import synthetic as syn
+    from emcid_amd.clip_attention import hip_attention
+    pipe = syn.build_pipe("toy", DEV)
+    enc = pipe.tokenizer(["painting by c0001", "a photo of tench in the style of vincent"], return_tensors="pt", padding=True)
+    enc = {k: v.to(DEV) for k, v in enc.items()}
+    with torch.no_grad():
+        ref = pipe.text_encoder(**enc).last_hidden_state
+        with hip_attention(pipe.text_encoder) as on:
+            assert on
+            got = pipe.text_encoder(**enc).last_hidden_state
+    keep = enc["attention_mask"].bool()
+    torch.testing.assert_close(got[keep], ref[keep], rtol=1e-4, atol=1e-5)
