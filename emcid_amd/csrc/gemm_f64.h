@@ -4,16 +4,19 @@
 //   D[m][n] = sum_k opA(m,k) * opB(k,n),   epilogue functor decides what happens to D.
 //
 // Operand storage is a template flag per operand:
-//   KC = true  : stored [rows][K]  (K contiguous)  -> LDS image [rows][BK+2]
-//   KC = false : stored [K][rows]  (rows contiguous) -> LDS image [BK][rows+16]
-// Both images are straight 16-B copies of global memory (no transpose pass) and both give
-// conflict-free ds_read_b64 fragment reads: the f64 MFMA takes ONE double per lane,
-// A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15].
-//   KC image : lane address = (r0 + lane&15)*(BK+2) + k0 + (lane>>4): row stride 36 dwords ->
-//              the 16 rows of a k-pair land on 16 distinct 4-dword bank groups, k and k+1 on the
-//              two halves of each group (64 banks, each used once per 32-lane half).
-//   !KC image: lane address = (k0 + lane>>4)*(rows+16) + r0 + (lane&15): 16 consecutive doubles
-//              per k row; row stride == 32 (mod 64) dwords so k and k+1 use opposite bank halves.
+//   KC = true  : stored [rows][K]  (K contiguous)  -> LDS image [rows][BK+4]
+//   KC = false : stored [K][rows]  (rows contiguous) -> LDS image [BK][rows]
+// Both images are straight 16-B copies of global memory (no transpose pass).  The f64 MFMA takes ONE
+// double per lane, A[i = lane&15][slot = lane>>4], B[slot = lane>>4][j = lane&15], and sums over the 4
+// slots.  Fragments are fetched 16 B per lane (ds_read_b128, 256 B/clk) — never as two 8-B reads, which
+// hipcc fuses into ds_read2_b64 (half rate, 32-bank rule: measured 2-way conflicts on every read):
+//   KC image : a lane reads k = 8*k8 + 2*slot + {0,1} of its row in one b128; the two halves feed two
+//              MFMAs, so over a k8 step slot s covers k = 2s (first MFMA) and 2s+1 (second).  Any
+//              permutation of k is legal as long as A and B use the same one.  Row stride BK+4
+//              doubles (== 4 mod 8) puts the 16 lanes of every b128 lane group on 16 distinct 16-B slots.
+//   !KC image: a lane reads rows {2*(lane&15), +1} of a 32-row group at one k in one b128; the halves
+//              belong to two adjacent 16-row MFMA tiles, whose row r then is global row 32*p + 2*r + e.
+//              Row stride = rows (a multiple of 32) keeps the lane groups conflict-free.
 // C/D layout of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg  (NOT the f32 map).
 //
 // Pipeline: register-staged double buffering (global_load_dwordx4 for tile t+1 issued before the
@@ -30,7 +33,32 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 template <bool KC, int ROWS, int BK>
 struct OpTile {
-    static constexpr int LD = KC ? (BK + 2) : (ROWS + 16);
+    static constexpr int LD = KC ? (BK + 4) : ROWS;
+    static_assert(KC || ROWS % 32 == 0, "row-contiguous tiles come in 32-row groups");
+    static_assert(BK % 8 == 0, "a k8 step is 8 deep");
+    // fragment values of the TILES 16-row MFMA tiles starting at tile row w0, for k8 step `k8`:
+    // f[e][t] feeds the e-th of the two MFMAs of this step for tile t.
+    template <int TILES>
+    __device__ static __forceinline__ void frags(const double* lds, int w0, int k8, int l15, int l4, double (&f)[2][TILES]) {
+        if (KC) {
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                const v2d x = *reinterpret_cast<const v2d*>(lds + (w0 + t * 16 + l15) * LD + 8 * k8 + 2 * l4);
+                f[0][t] = x[0]; f[1][t] = x[1];
+            }
+        } else {
+            static_assert(KC || TILES % 2 == 0, "row-contiguous operands are fetched as tile pairs");
+#pragma unroll
+            for (int p = 0; p < TILES / 2; ++p)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const v2d x = *reinterpret_cast<const v2d*>(lds + (8 * k8 + 2 * l4 + e) * LD + w0 + 32 * p + 2 * l15);
+                    f[e][2 * p] = x[0]; f[e][2 * p + 1] = x[1];
+                }
+        }
+    }
+    // global row (relative to the wave's origin w0) of MFMA row/col index r (0..15) of tile t
+    __device__ static __forceinline__ int index_of(int t, int r) { return KC ? t * 16 + r : 32 * (t >> 1) + 2 * r + (t & 1); }
     static constexpr int SIZE = KC ? ROWS * LD : BK * LD;  // doubles
     static constexpr int NVEC = ROWS * BK / 2;             // 16-byte vectors per tile
     __device__ static __forceinline__ int off(int r, int k) { return KC ? r * LD + k : k * LD + r; }
@@ -130,17 +158,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Ep
             load_tile<KCB, BN, BK, NT>(rb, p.B, p.ldb, n0, p.N, (t + 1) * BK, p.K, tid);
         }
 #pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            double a[MI], b[NI];
+        for (int k8 = 0; k8 < BK / 8; ++k8) {
+            double a[2][MI], b[2][NI];
+            TA::template frags<MI>(As, wm0, k8, l15, l4, a);
+            TB::template frags<NI>(Bs, wn0, k8, l15, l4, b);
 #pragma unroll
-            for (int i = 0; i < MI; ++i) a[i] = As[TA::off(wm0 + i * 16 + l15, kk * 4 + l4)];
+            for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int j = 0; j < NI; ++j) b[j] = Bs[TB::off(wn0 + j * 16 + l15, kk * 4 + l4)];
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e][i], b[e][j], acc[i][j], 0, 0, 0);
         }
         if (more) {
             double* An = smem + ((t + 1) & 1) * STAGE;
@@ -156,8 +184,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Ep
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm0 + i * 16 + l4 + 4 * r;
-                const int n = n0 + wn0 + j * 16 + l15;
+                const int m = m0 + wm0 + TA::index_of(i, l4 + 4 * r);
+                const int n = n0 + wn0 + TB::index_of(j, l15);
                 if (m < p.M && n < p.N) epi(m, n, acc[i][j][r]);
             }
 }
@@ -213,7 +241,7 @@ inline void launch_gemm_f64(const GemmShape& p, const Epi& epi, hipStream_t stre
     if (force_cfg >= 0) cfg = force_cfg;
     if (cfg == 0) {
         dim3 grid((p.N + 127) / 128, (p.M + 127) / 128);
-        hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 128, 128, 16, 2, 2, Epi>), grid, dim3(256), 0, stream, p, epi);
+        hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 128, 128, 16, 2, 4, Epi>), grid, dim3(512), 0, stream, p, epi);
     } else {
         dim3 grid((p.N + 63) / 64, (p.M + 63) / 64);
         hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 64, 64, 16, 2, 2, Epi>), grid, dim3(256), 0, stream, p, epi);

@@ -129,9 +129,26 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
 
-    for (int e = tid; e < NB * NB; e += LEAF_T) {
-        const int i = e / NB, j = e % NB;
-        S[i * SLD + j] = (j <= i) ? A[(int64_t)i * lda + j] : 0.0;
+    {
+        // 128 x 128 block = 8192 16-byte vectors, 32 per thread, fetched in batches of 8 independent loads
+        constexpr int VPR = NB / 2;   // vectors per row
+#pragma unroll 1
+        for (int b0 = 0; b0 < NB * VPR / LEAF_T; b0 += 8) {
+            v2d x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int v = tid + (b0 + u) * LEAF_T;
+                const int i = v / VPR, j = 2 * (v % VPR);
+                x[u] = (j <= i) ? *reinterpret_cast<const v2d*>(A + (int64_t)i * lda + j) : (v2d){0.0, 0.0};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int v = tid + (b0 + u) * LEAF_T;
+                const int i = v / VPR, j = 2 * (v % VPR);
+                if (j + 1 > i) x[u][1] = 0.0;   // strictly-upper element of a pair straddling the diagonal
+                *reinterpret_cast<v2d*>(S + i * SLD + j) = x[u];
+            }
+        }
     }
     __syncthreads();
 
@@ -266,9 +283,12 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
         }
     }
     __syncthreads();
-    for (int e = tid; e < NB * NB; e += LEAF_T) {
-        const int i = e / NB, j = e % NB;
-        inv[e] = (j <= i) ? S[i * SLD + j] : 0.0;
+    for (int v = tid; v < NB * NB / 2; v += LEAF_T) {
+        const int i = v / (NB / 2), j = 2 * (v % (NB / 2));
+        v2d x = *reinterpret_cast<const v2d*>(S + i * SLD + j);
+        if (j > i) x[0] = 0.0;
+        if (j + 1 > i) x[1] = 0.0;
+        *reinterpret_cast<v2d*>(inv + (int64_t)i * NB + j) = x;
     }
 }
 
