@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""A few edit_layer calls at N=1000, d=3072 — target for rocprofv3 --kernel-trace --stats."""
+import sys, torch
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from emcid_amd import hip
+N, d, h = 1000, int(sys.argv[1]) if len(sys.argv) > 1 else 3072, 768
+g = torch.Generator().manual_seed(0)
+K = (torch.randn(N, d, generator=g) * 0.3).cuda(); Zc = torch.randn(N, h, generator=g).cuda(); zs = torch.randn(N, h, generator=g).cuda()
+x = torch.randn(2 * d, d, generator=g).cuda(); Cov = (x.t() @ x) / (2 * d)
+W0 = (torch.randn(h, d, generator=g) * 0.02).cuda(); W = torch.empty_like(W0)
+ws = hip.EditWorkspace(N, d, h, "cuda:0")
+for _ in range(4):
+    hip.edit_layer(K, Zc, zs, Cov, 4000.0, 0.5, 4, W0=W0, W=W, ws=ws)
+torch.cuda.synchronize()
