@@ -71,6 +71,18 @@ __global__ __launch_bounds__(256) void axpy_f32_kernel(float* __restrict__ W, co
     for (; i < n; i += stride) W[i] += dW[i];
 }
 
+// W = W0 + float(U) ; dW = float(U)   (after the partial U of the concept shards were summed)
+__global__ __launch_bounds__(256) void apply_u_kernel(const double* __restrict__ U, const float* __restrict__ W0,
+                                                       float* __restrict__ W, float* __restrict__ dW, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        const float f = (float)U[i];
+        if (dW) dW[i] = f;
+        if (W) W[i] = W0[i] + f;
+    }
+}
+
 // ---- diagonal leaf: Cholesky of one NB x NB block + its inverse, one workgroup ---------------------------
 //
 // The leaf is the serial spine of the factorization (d sequential pivots), so it is built for latency:
@@ -486,12 +498,13 @@ int64_t emcid_edit_workspace_bytes(int64_t N, int64_t d, int64_t h) {
     return EditWorkspace(N, d, h).total * (int64_t)sizeof(double);
 }
 
-int emcid_edit_layer_f64(const float* K, const float* Zc, const float* zs_t, const float* C, int64_t N, int64_t d, int64_t h,
-                         double lam, double edit_weight, int layers_left, const float* W0, float* W, double* Xt_out,
-                         double* Rt_out, float* dW_out, void* workspace, int64_t workspace_bytes, int* info_dev,
-                         void* stream) {
+static int edit_layer_impl(const float* K, const float* Zc, const float* zs_t, const float* C, int64_t N, int64_t d, int64_t h,
+                           double lam, double edit_weight, int layers_left, int64_t n_lo, int64_t n_hi, const float* W0,
+                           float* W, double* Xt_out, double* Rt_out, float* dW_out, double* U_out, void* workspace,
+                           int64_t workspace_bytes, int* info_dev, void* stream) {
     EMCID_CHECK_ARG(K && Zc && zs_t && C && N > 0 && d > 0 && h > 0 && layers_left > 0 && workspace && info_dev);
     EMCID_CHECK_ARG(N < (1 << 24) && d <= 32768 && h <= 32768);
+    EMCID_CHECK_ARG(0 <= n_lo && n_lo < n_hi && n_hi <= N);
     EMCID_CHECK_ARG((W == nullptr) || (W0 != nullptr));
     EMCID_CHECK_ARG(aligned16(workspace));
     EditWorkspace ws(N, d, h);
@@ -503,6 +516,7 @@ int emcid_edit_layer_f64(const float* K, const float* Zc, const float* zs_t, con
     double *B = base + ws.off_B, *Y = base + ws.off_Y, *R = base + ws.off_R;
     const double s = sqrt(edit_weight / 0.5);
     const float cw = (float)(1.0 - edit_weight);  // torch multiplies the fp32 tensor by the scalar rounded to fp32
+    const int64_t rows = n_hi - n_lo;
 
     {
         ScopedProf sp(KC_PREP, st);
@@ -512,10 +526,42 @@ int emcid_edit_layer_f64(const float* K, const float* Zc, const float* zs_t, con
     EMCID_CHECK_LAUNCH();
     EMCID_TRY(emcid_assemble_spd_f64(C, d, B, ws.Np, d, ws.dp, lam, cw, A, ws.dp, stream));
     EMCID_TRY(cholesky_impl(A, L, ws.dp, ws.dp, inv, info_dev, st));
-    EMCID_TRY(cholesky_solve_impl(L, ws.dp, ws.dp, inv, B, Y, ws.Np, ws.dp, st));
-    if (W || dW_out) EMCID_TRY(emcid_delta_w_f64(R, ws.hp, B, ws.dp, ws.Np, h, d, W0, W, d, dW_out, nullptr, stream));
-    if (Xt_out) hipLaunchKernelGGL(copy2d_f64_kernel, dim3((unsigned)N), dim3(256), 0, st, B, ws.dp, Xt_out, d, (int)N, (int)d);
-    if (Rt_out) hipLaunchKernelGGL(copy2d_f64_kernel, dim3((unsigned)N), dim3(256), 0, st, R, ws.hp, Rt_out, h, (int)N, (int)h);
+    // only this shard's concept rows go through the triangular solves and the dW contraction
+    double* Bs = B + n_lo * ws.dp;
+    EMCID_TRY(cholesky_solve_impl(L, ws.dp, ws.dp, inv, Bs, Y + n_lo * ws.dp, rows, ws.dp, st));
+    if (W || dW_out || U_out)
+        EMCID_TRY(emcid_delta_w_f64(R + n_lo * ws.hp, ws.hp, Bs, ws.dp, rows, h, d, W0, W, d, dW_out, U_out, stream));
+    if (Xt_out)
+        hipLaunchKernelGGL(copy2d_f64_kernel, dim3((unsigned)rows), dim3(256), 0, st, Bs, ws.dp, Xt_out, d, (int)rows, (int)d);
+    if (Rt_out)
+        hipLaunchKernelGGL(copy2d_f64_kernel, dim3((unsigned)rows), dim3(256), 0, st, R + n_lo * ws.hp, ws.hp, Rt_out, h,
+                           (int)rows, (int)h);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+int emcid_edit_layer_f64(const float* K, const float* Zc, const float* zs_t, const float* C, int64_t N, int64_t d, int64_t h,
+                         double lam, double edit_weight, int layers_left, const float* W0, float* W, double* Xt_out,
+                         double* Rt_out, float* dW_out, void* workspace, int64_t workspace_bytes, int* info_dev,
+                         void* stream) {
+    return edit_layer_impl(K, Zc, zs_t, C, N, d, h, lam, edit_weight, layers_left, 0, N, W0, W, Xt_out, Rt_out, dW_out,
+                           nullptr, workspace, workspace_bytes, info_dev, stream);
+}
+
+int emcid_edit_layer_shard_f64(const float* K, const float* Zc, const float* zs_t, const float* C, int64_t N, int64_t d,
+                               int64_t h, double lam, double edit_weight, int layers_left, int64_t n_lo, int64_t n_hi,
+                               double* U_partial, double* Xt_out, double* Rt_out, void* workspace, int64_t workspace_bytes,
+                               int* info_dev, void* stream) {
+    EMCID_CHECK_ARG(U_partial != nullptr);
+    return edit_layer_impl(K, Zc, zs_t, C, N, d, h, lam, edit_weight, layers_left, n_lo, n_hi, nullptr, nullptr, Xt_out,
+                           Rt_out, nullptr, U_partial, workspace, workspace_bytes, info_dev, stream);
+}
+
+int emcid_apply_update_f32(const double* U, const float* W0, float* W, float* dW, int64_t n, void* stream) {
+    EMCID_CHECK_ARG(U && n > 0 && (W || dW) && ((W == nullptr) || (W0 != nullptr)));
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(apply_u_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, U, W0, W, dW, n);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }

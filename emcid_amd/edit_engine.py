@@ -89,6 +89,24 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
                            zs_t, covs, len(requests), shard)
 
 
+def _staged(group) -> bool:
+    """True when the process group cannot take HBM tensors (gloo): collectives are then staged through host
+    memory.  RCCL ("nccl") — the production backend — works on the device buffers directly."""
+    import torch.distributed as dist
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_reduce_sum(t: torch.Tensor, group):
+    import torch.distributed as dist
+    if t.is_cuda and _staged(group):
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def _all_gather_rows(local: torch.Tensor, plan: EncoderEditPlan) -> torch.Tensor:
     """Concatenate per-rank row blocks (uneven shards allowed) in rank order == request order."""
     sh = plan.shard
@@ -103,7 +121,12 @@ def _all_gather_rows(local: torch.Tensor, plan: EncoderEditPlan) -> torch.Tensor
         padded = torch.zeros(nmax, local.shape[1], dtype=local.dtype, device=local.device)
         padded[:local.shape[0]] = local
     out = torch.empty(sh.world * nmax, local.shape[1], dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, padded.contiguous(), group=sh.group)
+    if local.is_cuda and _staged(sh.group):
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, padded.cpu().contiguous(), group=sh.group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, padded.contiguous(), group=sh.group)
     if all(s == nmax for s in sizes):
         return out
     return torch.cat([out[r * nmax:r * nmax + s] for r, s in enumerate(sizes)], dim=0)
@@ -135,8 +158,17 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
             x = inputs[0]
             K = _all_gather_rows(gather_request_means(x, plan.batch), plan)
             Zc = _all_gather_rows(gather_request_means(output, plan.batch), plan)
-            res = hip.edit_layer(K, Zc, plan.zs_t, plan.covs[layer], plan.lam, plan.edit_weight, L - i,
-                                 W0=backups[layer], W=weights[layer].data, want_factors=keep_factors, ws=plan.ws)
+            if plan.shard.world > 1 and not keep_factors:
+                # every rank assembles and factors A from all N concepts; the triangular solves and the dW
+                # contraction are split by concept rows and the partial U summed over xGMI (fp64, h*d*8 bytes)
+                res = hip.edit_layer_shard(K, Zc, plan.zs_t, plan.covs[layer], plan.lam, plan.edit_weight, L - i,
+                                           plan.shard.bounds(plan.n_total), ws=plan.ws)
+                _all_reduce_sum(res["U"], plan.shard.group)
+                dW = hip.apply_update_(res["U"], backups[layer], weights[layer].data)
+                res = {"dW": dW, "Xt": None, "Rt": None}
+            else:
+                res = hip.edit_layer(K, Zc, plan.zs_t, plan.covs[layer], plan.lam, plan.edit_weight, L - i,
+                                     W0=backups[layer], W=weights[layer].data, want_factors=keep_factors, ws=plan.ws)
             edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], res["Xt"], res["Rt"],
                                    K if trace else None, Zc if trace else None))
             if layer == last:

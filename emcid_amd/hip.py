@@ -19,7 +19,8 @@ EXPORTS = [
     "emcid_abi_version", "emcid_last_error", "emcid_gram_accumulate_f32", "emcid_symmetrize_lower_f32",
     "emcid_gather_mean_f32", "emcid_edit_workspace_bytes", "emcid_edit_layer_f64", "emcid_assemble_spd_f64",
     "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_axpy_f32",
-    "emcid_profile_enable", "emcid_profile_collect", "emcid_attention_f32",
+    "emcid_profile_enable", "emcid_profile_collect", "emcid_attention_f32", "emcid_edit_layer_shard_f64",
+    "emcid_apply_update_f32",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc"]
@@ -56,6 +57,8 @@ def load():
         "emcid_gather_mean_f32": (i32, [p, i64, i64, i64, i64, i64, p, p, i64, p, i64, p]),
         "emcid_edit_workspace_bytes": (i64, [i64, i64, i64]),
         "emcid_edit_layer_f64": (i32, [p, p, p, p, i64, i64, i64, f64, f64, i32, p, p, p, p, p, p, i64, p, p]),
+        "emcid_edit_layer_shard_f64": (i32, [p, p, p, p, i64, i64, i64, f64, f64, i32, i64, i64, p, p, p, p, i64, p, p]),
+        "emcid_apply_update_f32": (i32, [p, p, p, p, i64, p]),
         "emcid_assemble_spd_f64": (i32, [p, i64, p, i64, i64, i64, f64, f32, p, i64, p]),
         "emcid_cholesky_f64": (i32, [p, p, i64, i64, p, p, p]),
         "emcid_cholesky_solve_f64": (i32, [p, i64, i64, p, p, p, i64, i64, p]),
@@ -169,6 +172,40 @@ def edit_layer(K, Zc, zs_t, Cov, lam: float, edit_weight: float, layers_left: in
         _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"), _ptr(Xt), _ptr(Rt), _ptr(dW),
         _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32, "info"), _stream(K)), "emcid_edit_layer_f64")
     return {"Xt": Xt, "Rt": Rt, "dW": dW, "ws": ws}
+
+
+def edit_layer_shard(K, Zc, zs_t, Cov, lam: float, edit_weight: float, layers_left: int, rows, want_factors=False,
+                     ws: Optional[EditWorkspace] = None):
+    """Concept-sharded layer: all N concepts assemble/factor A, only rows [lo, hi) are solved.
+    Returns dict(U=(h,d) f64 partial, Xt, Rt (shard rows or None), ws)."""
+    N, d = K.shape
+    h = Zc.shape[1]
+    lo, hi = rows
+    assert Cov.shape == (d, d) and zs_t.shape == (N, h) and Zc.shape == (N, h) and 0 <= lo < hi <= N
+    for t, nm in ((K, "K"), (Zc, "Zc"), (zs_t, "zs_t"), (Cov, "C")):
+        assert t.is_contiguous(), nm
+    if ws is None or ws.key != (N, d, h):
+        ws = EditWorkspace(N, d, h, K.device)
+    dev = K.device
+    U = torch.empty(h, d, dtype=torch.float64, device=dev)
+    Xt = torch.empty(hi - lo, d, dtype=torch.float64, device=dev) if want_factors else None
+    Rt = torch.empty(hi - lo, h, dtype=torch.float64, device=dev) if want_factors else None
+    _check(load().emcid_edit_layer_shard_f64(
+        _ptr(K, torch.float32, "K"), _ptr(Zc, torch.float32, "Zc"), _ptr(zs_t, torch.float32, "zs_t"),
+        _ptr(Cov, torch.float32, "C"), N, d, h, float(lam), float(edit_weight), int(layers_left), lo, hi,
+        _ptr(U), _ptr(Xt), _ptr(Rt), _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32, "info"), _stream(K)),
+        "emcid_edit_layer_shard_f64")
+    return {"U": U, "Xt": Xt, "Rt": Rt, "ws": ws}
+
+
+def apply_update_(U, W0, W, want_dw=True):
+    """W = W0 + float(U); returns dW = float(U) (or None)."""
+    assert U.is_contiguous() and W.is_contiguous() and W0.is_contiguous() and U.shape == W.shape
+    dW = torch.empty_like(W) if want_dw else None
+    _check(load().emcid_apply_update_f32(_ptr(U, torch.float64, "U"), _ptr(W0, torch.float32, "W0"),
+                                         _ptr(W, torch.float32, "W"), _ptr(dW), W.numel(), _stream(W)),
+           "emcid_apply_update_f32")
+    return dW
 
 
 def dgemm(ta: int, tb: int, A, B, Cm, alpha=1.0, beta=0.0, M=None, N=None, K=None):

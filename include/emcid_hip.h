@@ -104,6 +104,18 @@ int emcid_edit_layer_f64(const float* K, const float* Zc, const float* zs_t, con
                          double* Xt_out, double* Rt_out, float* dW_out,
                          void* workspace, int64_t workspace_bytes, int* info_dev, void* stream);
 
+/* Concept-sharded variant (multi-GPU): K, Zc, zs_t hold ALL N concepts (after the all-gather),
+ * A is assembled and factored from all of them, but only the rows [n_lo, n_hi) go through the triangular
+ * solves and the dW contraction.  U_partial [h, d] f64 receives sum_{n in shard} Rt[n,:]^T Xt[n,:]; the caller
+ * sums it over ranks (RCCL all-reduce) and finishes with emcid_apply_update_f32.  Xt_out / Rt_out (optional)
+ * receive the shard's rows, [n_hi-n_lo, d] and [n_hi-n_lo, h]. */
+int emcid_edit_layer_shard_f64(const float* K, const float* Zc, const float* zs_t, const float* C,
+                               int64_t N, int64_t d, int64_t h, double lam, double edit_weight, int layers_left,
+                               int64_t n_lo, int64_t n_hi, double* U_partial, double* Xt_out, double* Rt_out,
+                               void* workspace, int64_t workspace_bytes, int* info_dev, void* stream);
+/* W = W0 + float(U) (optional) ; dW = float(U) (optional), n = h*d elements.  (:1061) */
+int emcid_apply_update_f32(const double* U, const float* W0, float* W, float* dW, int64_t n, void* stream);
+
 /* The stages of emcid_edit_layer_f64 as separate calls (used by tests and micro-benchmarks). */
 
 /* A[d,d] (f64, ld lda, LOWER triangle valid) = lam_c * double(fl32(fl32(C*cw)/0.5f)) + Kt64^T Kt64,

@@ -1,0 +1,71 @@
+"""Two ranks sharing the one GPU of the test box (gloo rendezvous, collectives staged through the host):
+the concept-sharded edit must leave both ranks with the weights of the single-process edit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup(tmp, n_req):
+    from emcid_amd import synthetic as syn
+    reqs = syn.make_requests(n_req, ragged=True)
+    hp_d = syn.sd_hparams_dict(layers=(1, 2, 3, 4), mom2_update_weight=50, edit_weight=0.6, mom2_n_samples=1000)
+    names = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers"]]
+    cache = tmp + "/cache/"
+    if not os.path.exists(cache):
+        syn.write_vstar_cache(cache, reqs, 32, seed=1, scale=0.5)
+        syn.write_stats_cache(tmp + "/stats", names, 128, 1000, seed=2, t=512)
+    return reqs, hp_d, names, cache
+
+
+def _worker(rank, world, port, tmp, n_req):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from emcid_amd import emcid_main as em, synthetic as syn
+        from emcid_amd.emcid_hparams import EMCIDHyperParams
+        from emcid_amd.nethook import get_parameter
+        reqs, hp_d, names, cache = _setup(tmp, n_req)
+        pipe = syn.build_pipe("toy", "cuda:0")
+        em.apply_emcid_to_text_encoder(pipe, reqs, EMCIDHyperParams(**hp_d), "cuda:0", cache_name=cache,
+                                       stats_dir=tmp + "/stats", verbose=False)     # shard picked up from the process group
+        out = {n: get_parameter(pipe.text_encoder, n + ".weight").cpu().numpy() for n in names}
+        np.savez(f"{tmp}/rank{rank}.npz", **out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_req", [7, 8])
+def test_two_ranks_match_single_process(tmp_path, n_req):
+    from emcid_amd import emcid_main as em, synthetic as syn
+    from emcid_amd.emcid_hparams import EMCIDHyperParams
+    from emcid_amd.nethook import get_parameter
+    tmp = str(tmp_path)
+    reqs, hp_d, names, cache = _setup(tmp, n_req)
+    mp.spawn(_worker, args=(2, _free_port(), tmp, n_req), nprocs=2, join=True)
+    em.clear_caches()
+    pipe = syn.build_pipe("toy", "cuda:0")
+    w0 = {n: get_parameter(pipe.text_encoder, n + ".weight").cpu().numpy().copy() for n in names}
+    em.apply_emcid_to_text_encoder(pipe, reqs, EMCIDHyperParams(**hp_d), "cuda:0", cache_name=cache,
+                                   stats_dir=tmp + "/stats", verbose=False)
+    r0, r1 = np.load(f"{tmp}/rank0.npz"), np.load(f"{tmp}/rank1.npz")
+    for n in names:
+        single = get_parameter(pipe.text_encoder, n + ".weight").cpu().numpy()
+        np.testing.assert_array_equal(r0[n], r1[n])                      # ranks agree bit for bit
+        dw = single.astype(np.float64) - w0[n]
+        err = np.abs(r0[n].astype(np.float64) - single).max()
+        assert err <= 1e-5 * np.abs(dw).max(), (n, err)                  # different batch split in the fp32 forward

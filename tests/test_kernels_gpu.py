@@ -181,3 +181,25 @@ def test_hip_attention_inside_hf_forward():
             got = pipe.text_encoder(**enc).last_hidden_state
     keep = enc["attention_mask"].bool()
     torch.testing.assert_close(got[keep], ref[keep], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("N,d,h,parts", [(100, 3072, 768, 2), (37, 384, 64, 3), (1000, 3072, 768, 8)])
+def test_edit_layer_concept_shards_sum_to_full(N, d, h, parts):
+    """The multi-GPU split emulated on one GPU: per-shard partial U summed == the unsharded layer."""
+    K, Zc, zs, Cov, W0 = _edit_inputs(N, d, h, seed=3 * N + d)
+    Kd, Zd, zd, Cd, W0d = K.to(DEV), Zc.to(DEV), zs.t().contiguous().to(DEV), Cov.to(DEV), W0.to(DEV)
+    Wfull = torch.empty_like(W0d)
+    full = hip.edit_layer(Kd, Zd, zd, Cd, 4000.0, 0.5, 2, W0=W0d, W=Wfull, want_factors=True)
+    U = torch.zeros(h, d, dtype=torch.float64, device=DEV)
+    xs = []
+    for r in range(parts):
+        lo, hi = (N * r) // parts, (N * (r + 1)) // parts
+        part = hip.edit_layer_shard(Kd, Zd, zd, Cd, 4000.0, 0.5, 2, (lo, hi), want_factors=True)
+        U += part["U"]
+        xs.append(part["Xt"])
+    Wsh = torch.empty_like(W0d)
+    dW = hip.apply_update_(U, W0d, Wsh)
+    torch.testing.assert_close(torch.cat(xs), full["Xt"], rtol=1e-12, atol=1e-14)
+    scale = full["dW"].abs().max().item()
+    assert (dW - full["dW"]).abs().max().item() <= 2e-7 * scale          # fp64 sum order, then one fp32 rounding
+    assert (Wsh - Wfull).abs().max().item() <= 2e-7 * max(scale, 1.0)
