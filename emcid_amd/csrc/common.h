@@ -49,7 +49,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // A ScopedProf around a launch records an event pair on the launch stream when its class is enabled.
 enum KernelClass : int {
     KC_PREP = 0, KC_ASSEMBLE = 1, KC_CHOL_LEAF = 2, KC_CHOL_PANEL = 3, KC_CHOL_TRAIL = 4, KC_TRSM_DIAG = 5,
-    KC_TRSM_UPDATE = 6, KC_DELTA_W = 7, KC_GRAM = 8, KC_GATHER = 9, KC_DGEMM = 10, KC_MISC = 11, KC_COUNT = 12
+    KC_TRSM_UPDATE = 6, KC_DELTA_W = 7, KC_GRAM = 8, KC_GATHER = 9, KC_DGEMM = 10, KC_MISC = 11, KC_INV_BUILD = 12, KC_COUNT = 13
 };
 void prof_begin(int cls, hipStream_t st);
 void prof_end(int cls, hipStream_t st);
@@ -59,7 +59,10 @@ struct ScopedProf {
     ~ScopedProf() { prof_end(cls, st); }
 };
 
-constexpr int NB = 128;  // Cholesky / TRSM block size (diagonal leaf)
+constexpr int NB = 128;  // Cholesky block size (diagonal leaf)
+constexpr int OB = 512;  // outer block of the triangular solves: the inverse of each OB x OB diagonal block of L is formed
+constexpr int TB = 256;  // scratch tile of the block-inverse build
+inline int64_t inv_doubles(int64_t dp) { return ((dp + OB - 1) / OB) * ((int64_t)OB * OB + (int64_t)TB * TB); }
 constexpr int NPAD = 64; // concept-count padding of the f64 K / X / R stacks
 
 }  // namespace emcid

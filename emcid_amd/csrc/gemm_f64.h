@@ -113,11 +113,16 @@ struct GemmShape {
     const double* B; int64_t ldb;
     int M, N, K;
     int lower_only;  // skip output tiles that lie entirely above the diagonal (SYRK / Cholesky updates)
+    int64_t sA = 0, sB = 0;  // element strides between the problems of a batch (blockIdx.z)
+    int batch = 1;
 };
 
 // WGM x WGN waves per workgroup; each wave owns a (BM/WGM) x (BN/WGN) sub-tile.
 template <bool KCA, bool KCB, int BM, int BN, int BK, int WGM, int WGN, class Epi>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Epi epi) {
+    p.A += (int64_t)blockIdx.z * p.sA;
+    p.B += (int64_t)blockIdx.z * p.sB;
+    epi.batch(blockIdx.z);
     constexpr int NT = WGM * WGN * 64;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 16, NI = WN / 16;
@@ -194,7 +199,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Ep
 
 // C = alpha * D + beta * C
 struct EpiAxpby {
-    double* C; int64_t ldc; double alpha, beta;
+    double* C; int64_t ldc; double alpha, beta; int64_t sC = 0;
+    __device__ __forceinline__ void batch(int z) { C += (int64_t)z * sC; }
     __device__ __forceinline__ void operator()(int m, int n, double v) const {
         double* c = C + (int64_t)m * ldc + n;
         *c = (beta != 0.0) ? alpha * v + beta * *c : alpha * v;
@@ -205,6 +211,7 @@ struct EpiAxpby {
 // reference: emcid/emcid_main.py:1037 (`cov * (1 - edit_weight) / 0.5`, fp32) and :1046 (`lam * cov.double() + K K^T`).
 struct EpiAssemble {
     const float* Cf; int64_t ldcf; double lam; float cw; double* A; int64_t lda; int d;
+    __device__ __forceinline__ void batch(int) {}
     __device__ __forceinline__ void operator()(int m, int n, double v) const {
         double out;
         if (m < d && n < d) {
@@ -222,6 +229,7 @@ struct EpiAssemble {
 // reference: emcid/emcid_main.py:1050 (`resid @ adj_k.T`) and :1061 (`weights_copy + upd_matrix.float()`).
 struct EpiDeltaW {
     const float* W0; float* W; int64_t ldw; float* dW; int64_t lddw; double* U; int64_t ldu;
+    __device__ __forceinline__ void batch(int) {}
     __device__ __forceinline__ void operator()(int m, int n, double v) const {
         const float f = (float)v;
         if (U) U[(int64_t)m * ldu + n] = v;
@@ -240,10 +248,10 @@ inline void launch_gemm_f64(const GemmShape& p, const Epi& epi, hipStream_t stre
     int cfg = (big_tiles >= 224) ? 0 : 1;
     if (force_cfg >= 0) cfg = force_cfg;
     if (cfg == 0) {
-        dim3 grid((p.N + 127) / 128, (p.M + 127) / 128);
+        dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, p.batch);
         hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 128, 128, 16, 2, 4, Epi>), grid, dim3(512), 0, stream, p, epi);
     } else {
-        dim3 grid((p.N + 63) / 64, (p.M + 63) / 64);
+        dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, p.batch);
         hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 64, 64, 16, 2, 2, Epi>), grid, dim3(256), 0, stream, p, epi);
     }
 }

@@ -134,7 +134,8 @@ __device__ __forceinline__ v4d leaf_tile(const double* lds, FA fa, FB fb, int l1
 }
 
 __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restrict__ A, int64_t lda, double* __restrict__ L,
-                                                            int64_t ldl, double* __restrict__ inv, int* info, int col0) {
+                                                            int64_t ldl, double* __restrict__ inv, int64_t ldinv, int* info,
+                                                            int col0) {
     __shared__ __attribute__((aligned(16))) double lds[NB * SLD + 2 * SB * ZLD];
     double* S = lds;
     constexpr int ZOFF = NB * SLD;          // two [32][48] temporaries behind S
@@ -300,26 +301,73 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
         v2d x = *reinterpret_cast<const v2d*>(S + i * SLD + j);
         if (j > i) x[0] = 0.0;
         if (j + 1 > i) x[1] = 0.0;
-        *reinterpret_cast<v2d*>(inv + (int64_t)i * NB + j) = x;
+        *reinterpret_cast<v2d*>(inv + (int64_t)i * ldinv + j) = x;
     }
 }
 
 // ---- host orchestration -------------------------------------------------------------------------------
 
-static int cholesky_impl(double* A, double* L, int64_t dp, int64_t lda, double* invdiag, int* info, hipStream_t st) {
+// invw: [ceil(dp/OB)] x (OB*OB inverse block, ld OB) followed by ceil(dp/OB) x (TB*TB scratch)
+static inline double* inv_block(double* invw, int64_t J) { return invw + J * (int64_t)OB * OB; }
+static inline const double* inv_block(const double* invw, int64_t J) { return invw + J * (int64_t)OB * OB; }
+
+// Completes inv(L_JJ) for every OB x OB diagonal block from the leaf's 128 x 128 inverses, two levels of
+//   inv([[A,0],[C,B]]) = [[A^-1, 0], [-B^-1 C A^-1, B^-1]]      (batched over the blocks)
+static void build_block_inverses(const double* L, int64_t dp, int64_t lda, double* invw, hipStream_t st) {
+    const int64_t nob = (dp + OB - 1) / OB, nfull = dp / OB, rem = dp % OB;
+    double* tmp = invw + nob * (int64_t)OB * OB;
+    auto product = [&](const double* A, int64_t ldA, int64_t sA, bool a_dummy, const double* B, int64_t ldB, int64_t sB,
+                       double* C, int64_t ldC, int64_t sC, int M, int N, int K, double alpha, int cnt) {
+        (void)a_dummy;
+        GemmShape p{A, ldA, B, ldB, M, N, K, 0, sA, sB, cnt};
+        launch_gemm_f64<true, false>(p, EpiAxpby{C, ldC, alpha, 0.0, sC}, st, 1);
+    };
+    ScopedProf sp(KC_INV_BUILD, st);
+    const int64_t sI = (int64_t)OB * OB, sT = (int64_t)TB * TB, sL = (int64_t)OB * lda + OB;
+    // level a: 256-blocks from pairs of 128-inverses.  u selects the pair inside an OB block.
+    for (int u = 0; u < 2; ++u) {
+        auto level_a = [&](int64_t J0, int cnt) {
+            const double* Cb = L + ((J0 * 4 + 2 * u + 1) * NB) * lda + (J0 * 4 + 2 * u) * NB;
+            double* Ai = inv_block(invw, J0) + (2 * u * NB) * (int64_t)(OB + 1);
+            double* Bi = inv_block(invw, J0) + ((2 * u + 1) * NB) * (int64_t)(OB + 1);
+            double* X = inv_block(invw, J0) + ((2 * u + 1) * NB) * (int64_t)OB + 2 * u * NB;
+            double* T = tmp + J0 * sT;
+            product(Cb, lda, sL, true, Ai, OB, sI, T, TB, sT, NB, NB, NB, 1.0, cnt);      // T = C A^-1
+            product(Bi, OB, sI, true, T, TB, sT, X, OB, sI, NB, NB, NB, -1.0, cnt);       // X = -B^-1 T
+        };
+        if (nfull > 0) level_a(0, (int)nfull);
+        if (rem >= (u + 1) * 2 * NB) level_a(nfull, 1);
+    }
+    // level b: the OB block from its two 256-halves (the lower half may be short in the last block)
+    auto level_b = [&](int64_t J0, int cnt, int mrows) {
+        const double* Cb = L + ((J0 * 4 + 2) * NB) * lda + (J0 * 4) * NB;
+        double* Ai = inv_block(invw, J0);
+        double* Bi = inv_block(invw, J0) + (2 * NB) * (int64_t)(OB + 1);
+        double* X = inv_block(invw, J0) + (2 * NB) * (int64_t)OB;
+        double* T = tmp + J0 * sT;
+        product(Cb, lda, sL, true, Ai, OB, sI, T, TB, sT, mrows, 2 * NB, 2 * NB, 1.0, cnt);
+        product(Bi, OB, sI, true, T, TB, sT, X, OB, sI, mrows, 2 * NB, mrows, -1.0, cnt);
+    };
+    if (nfull > 0) level_b(0, (int)nfull, 2 * NB);
+    if (rem > 2 * NB) level_b(nfull, 1, (int)(rem - 2 * NB));
+}
+
+static int cholesky_impl(double* A, double* L, int64_t dp, int64_t lda, double* invw, int* info, hipStream_t st) {
     const int nb = (int)(dp / NB);
+    if (hipMemsetAsync(invw, 0, inv_doubles(dp) * sizeof(double), st) != hipSuccess)
+        return fail(EMCID_ERR_HIP, "emcid_cholesky_f64", "hipMemsetAsync");
     for (int j = 0; j < nb; ++j) {
         const int64_t o = (int64_t)j * NB;
-        double* inv = invdiag + (int64_t)j * NB * NB;
+        double* inv = inv_block(invw, j / (OB / NB)) + ((j % (OB / NB)) * NB) * (int64_t)(OB + 1);
         {
             ScopedProf sp(KC_CHOL_LEAF, st);
             hipLaunchKernelGGL(chol_leaf_kernel, dim3(1), dim3(LEAF_T), 0, st, A + o * lda + o, lda, L + o * lda + o, lda,
-                               inv, info, (int)o);
+                               inv, (int64_t)OB, info, (int)o);
         }
         const int m = (int)(dp - o - NB);
         if (m == 0) break;
         // panel: L21 = A21 * inv(L11)^T
-        GemmShape ps{A + (o + NB) * lda + o, lda, inv, NB, m, NB, NB, 0};
+        GemmShape ps{A + (o + NB) * lda + o, lda, inv, OB, m, NB, NB, 0};
         {
             ScopedProf sp(KC_CHOL_PANEL, st);
             launch_gemm_f64<true, true>(ps, EpiAxpby{L + (o + NB) * lda + o, lda, 1.0, 0.0}, st, 1);
@@ -332,40 +380,45 @@ static int cholesky_impl(double* A, double* L, int64_t dp, int64_t lda, double* 
             launch_gemm_f64<true, true>(ts, EpiAxpby{A + (o + NB) * lda + (o + NB), lda, -1.0, 1.0}, st, 1);
         }
     }
+    build_block_inverses(L, dp, lda, invw, st);
     return check_launch("emcid_cholesky_f64");
 }
 
-static int cholesky_solve_impl(const double* L, int64_t dp, int64_t lda, const double* invdiag, double* Bt, double* Yt,
-                               int64_t Np, int64_t ldb, hipStream_t st) {
-    const int nb = (int)(dp / NB);
-    const int M = (int)Np;
-    for (int j = 0; j < nb; ++j) {  // forward: Yt L^T = Bt
-        const int64_t o = (int64_t)j * NB;
-        const double* inv = invdiag + (int64_t)j * NB * NB;
-        GemmShape a{Bt + o, ldb, inv, NB, M, NB, NB, 0};
+// Bt[M, dp] := Bt (L L^T)^-1, right-looking over OB-wide column blocks: multiply by the inverted diagonal
+// block, then one rank-OB GEMM update of every remaining column (forward), the same backward.
+static int cholesky_solve_impl(const double* L, int64_t dp, int64_t lda, const double* invw, double* Bt, double* Yt,
+                               int64_t Mrows, int64_t ldb, hipStream_t st) {
+    const int nob = (int)((dp + OB - 1) / OB);
+    const int M = (int)Mrows;
+    for (int J = 0; J < nob; ++J) {  // forward: Yt L^T = Bt
+        const int64_t c = (int64_t)J * OB;
+        const int w = (int)((dp - c) < OB ? (dp - c) : OB);
+        const double* inv = inv_block(invw, J);
+        GemmShape a{Bt + c, ldb, inv, OB, M, w, w, 0};
         {
             ScopedProf sp(KC_TRSM_DIAG, st);
-            launch_gemm_f64<true, true>(a, EpiAxpby{Yt + o, ldb, 1.0, 0.0}, st, 1);
+            launch_gemm_f64<true, true>(a, EpiAxpby{Yt + c, ldb, 1.0, 0.0}, st);
         }
-        const int m = (int)(dp - o - NB);
+        const int m = (int)(dp - c - w);
         if (m > 0) {
-            GemmShape b{Yt + o, ldb, L + (o + NB) * lda + o, lda, M, m, NB, 0};
+            GemmShape b{Yt + c, ldb, L + (c + w) * lda + c, lda, M, m, w, 0};
             ScopedProf sp(KC_TRSM_UPDATE, st);
-            launch_gemm_f64<true, true>(b, EpiAxpby{Bt + o + NB, ldb, -1.0, 1.0}, st, 1);
+            launch_gemm_f64<true, true>(b, EpiAxpby{Bt + c + w, ldb, -1.0, 1.0}, st);
         }
     }
-    for (int j = nb - 1; j >= 0; --j) {  // backward: Xt L = Yt, Xt written over Bt
-        const int64_t o = (int64_t)j * NB;
-        const double* inv = invdiag + (int64_t)j * NB * NB;
-        GemmShape a{Yt + o, ldb, inv, NB, M, NB, NB, 0};
+    for (int J = nob - 1; J >= 0; --J) {  // backward: Xt L = Yt, Xt written over Bt
+        const int64_t c = (int64_t)J * OB;
+        const int w = (int)((dp - c) < OB ? (dp - c) : OB);
+        const double* inv = inv_block(invw, J);
+        GemmShape a{Yt + c, ldb, inv, OB, M, w, w, 0};
         {
             ScopedProf sp(KC_TRSM_DIAG, st);
-            launch_gemm_f64<true, false>(a, EpiAxpby{Bt + o, ldb, 1.0, 0.0}, st, 1);
+            launch_gemm_f64<true, false>(a, EpiAxpby{Bt + c, ldb, 1.0, 0.0}, st);
         }
-        if (o > 0) {
-            GemmShape b{Bt + o, ldb, L + o * lda, lda, M, (int)o, NB, 0};
+        if (c > 0) {
+            GemmShape b{Bt + c, ldb, L + c * lda, lda, M, (int)c, w, 0};
             ScopedProf sp(KC_TRSM_UPDATE, st);
-            launch_gemm_f64<true, false>(b, EpiAxpby{Yt, ldb, -1.0, 1.0}, st, 1);
+            launch_gemm_f64<true, false>(b, EpiAxpby{Yt, ldb, -1.0, 1.0}, st);
         }
     }
     return check_launch("emcid_cholesky_solve_f64");
@@ -381,7 +434,7 @@ struct EditWorkspace {
         int64_t o = 0;
         off_A = o; o += dp * dp;
         off_L = o; o += dp * dp;
-        off_inv = o; o += (dp / NB) * NB * NB;
+        off_inv = o; o += inv_doubles(dp);
         off_B = o; o += Np * dp;
         off_Y = o; o += Np * dp;
         off_R = o; o += Np * hp;
@@ -457,6 +510,8 @@ int emcid_assemble_spd_f64(const float* C, int64_t ldc, const double* Kt64, int6
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }
+
+int64_t emcid_inverse_workspace_doubles(int64_t dp) { return dp > 0 ? inv_doubles(round_up(dp, NB)) : 0; }
 
 int emcid_cholesky_f64(double* A, double* L, int64_t dp, int64_t lda, double* invdiag, int* info_dev, void* stream) {
     EMCID_CHECK_ARG(A && L && invdiag && info_dev && dp > 0 && dp % NB == 0 && lda >= dp && lda % 2 == 0);

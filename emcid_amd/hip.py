@@ -20,10 +20,10 @@ EXPORTS = [
     "emcid_gather_mean_f32", "emcid_edit_workspace_bytes", "emcid_edit_layer_f64", "emcid_assemble_spd_f64",
     "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_axpy_f32",
     "emcid_profile_enable", "emcid_profile_collect", "emcid_attention_f32", "emcid_edit_layer_shard_f64",
-    "emcid_apply_update_f32",
+    "emcid_apply_update_f32", "emcid_inverse_workspace_doubles",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
-                "gram", "gather", "dgemm", "misc"]
+                "gram", "gather", "dgemm", "misc", "inv_build"]
 
 ABI_VERSION = 1
 NB = 128      # Cholesky block (csrc/common.h)
@@ -61,6 +61,7 @@ def load():
         "emcid_apply_update_f32": (i32, [p, p, p, p, i64, p]),
         "emcid_assemble_spd_f64": (i32, [p, i64, p, i64, i64, i64, f64, f32, p, i64, p]),
         "emcid_cholesky_f64": (i32, [p, p, i64, i64, p, p, p]),
+        "emcid_inverse_workspace_doubles": (i64, [i64]),
         "emcid_cholesky_solve_f64": (i32, [p, i64, i64, p, p, p, i64, i64, p]),
         "emcid_delta_w_f64": (i32, [p, i64, p, i64, i64, i64, i64, p, p, i64, p, p, p]),
         "emcid_dgemm_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, p]),
@@ -228,10 +229,11 @@ def axpy_(W: torch.Tensor, dW: torch.Tensor):
 
 
 def cholesky(A: torch.Tensor):
-    """Test hook: A (dp,dp) f64 contiguous, dp % 128 == 0.  Returns (L, invdiag, info)."""
+    """Test hook: A (dp,dp) f64 contiguous, dp % 128 == 0.  Returns (L, inverse workspace, info); the first
+    ceil(dp/512) slots of 512*512 doubles of the workspace are the inverted 512-blocks of L (ld 512)."""
     dp = A.shape[0]
     L = torch.zeros_like(A)
-    inv = torch.empty(dp // NB, NB, NB, dtype=torch.float64, device=A.device)
+    inv = torch.empty(int(load().emcid_inverse_workspace_doubles(dp)), dtype=torch.float64, device=A.device)
     info = torch.zeros(1, dtype=torch.int32, device=A.device)
     _check(load().emcid_cholesky_f64(_ptr(A, torch.float64), _ptr(L), dp, A.stride(0), _ptr(inv), _ptr(info), _stream(A)),
            "emcid_cholesky_f64")

@@ -35,9 +35,9 @@ const char* emcid_last_error(void);
 
 /* Optional per-kernel-class timing with HIP events recorded on the launch stream (bench.py's live
  * roofline measurement).  class ids: 0 prep, 1 assemble(SYRK), 2 chol_leaf, 3 chol_panel, 4 chol_trail,
- * 5 trsm_diag, 6 trsm_update, 7 delta_w, 8 gram, 9 gather, 10 dgemm, 11 misc.  enable(mask) resets the
+ * 5 trsm_diag, 6 trsm_update, 7 delta_w, 8 gram, 9 gather, 10 dgemm, 11 misc, 12 inverse build.  enable(mask) resets the
  * log; collect() synchronises the recorded events and returns summed milliseconds and launch counts. */
-#define EMCID_PROF_CLASSES 12
+#define EMCID_PROF_CLASSES 13
 int emcid_profile_enable(unsigned class_mask);
 int emcid_profile_collect(double* ms_per_class_host, int64_t* launches_per_class_host, int n_classes);
 
@@ -124,9 +124,11 @@ int emcid_assemble_spd_f64(const float* C, int64_t ldc, const double* Kt64, int6
                            double lam, float cw, double* A, int64_t lda, void* stream);
 /* Lower Cholesky A = L L^T of A[dp,dp] (dp a multiple of 128; a caller with d < dp identity-pads rows/cols
  * d..dp).  A's lower triangle is consumed (overwritten by partial Schur complements); the factor is written
- * to L (same leading dimension).  invdiag: [dp/128][128][128] f64 receives the inverses of the diagonal
- * blocks of L (the later triangular solves are MFMA GEMMs against them).
+ * to L (same leading dimension).  invdiag: f64 scratch of emcid_inverse_workspace_doubles(dp) elements; its
+ * first ceil(dp/512) x [512][512] slots receive the inverses of the 512 x 512 diagonal blocks of L (the later
+ * triangular solves are MFMA GEMMs against them).
  * replaces the getrf half of torch.linalg.solve (:1045). */
+int64_t emcid_inverse_workspace_doubles(int64_t dp);
 int emcid_cholesky_f64(double* A, double* L, int64_t dp, int64_t lda, double* invdiag, int* info_dev, void* stream);
 /* Bt[Np, dp] := Bt A^{-1} given the factor from emcid_cholesky_f64; Yt is [Np, dp] scratch.
  * replaces the getrs half of torch.linalg.solve (:1045-1048). */

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_c_abi_rejects_bad_arguments_without_gpu():
     lib = hip.load()
     assert lib.emcid_edit_workspace_bytes(0, 3072, 768) == 0
-    assert lib.emcid_edit_workspace_bytes(1000, 3072, 768) == 8 * (2 * 3072 * 3072 + 24 * 128 * 128 + 2 * 1024 * 3072 + 1024 * 768)
+    assert lib.emcid_edit_workspace_bytes(1000, 3072, 768) == 8 * (2 * 3072 * 3072 + 6 * (512 * 512 + 256 * 256) + 2 * 1024 * 3072 + 1024 * 768)
     rc = lib.emcid_gram_accumulate_f32(None, 10, 128, 128, None, 128, 0, None)
     assert rc == -1 and b"bad argument" in lib.emcid_last_error()
     rc = lib.emcid_cholesky_f64(None, None, 100, 100, None, None, None)

@@ -47,7 +47,7 @@ def test_dgemm_identity_asymmetric():
     assert torch.equal(out.cpu(), Bm)
 
 
-@pytest.mark.parametrize("dp", [128, 384, 1024])
+@pytest.mark.parametrize("dp", [128, 256, 384, 512, 640, 1024, 1408])
 def test_cholesky_and_solve(dp):
     x = _rand(dp + 64, dp, seed=4)
     A = x.t() @ x + 0.5 * torch.eye(dp, dtype=torch.float64)
@@ -55,9 +55,12 @@ def test_cholesky_and_solve(dp):
     assert int(info.item()) == 0
     Lref = torch.linalg.cholesky(A)
     torch.testing.assert_close(torch.tril(L.cpu()), Lref, rtol=1e-9, atol=1e-9)
-    for j in range(dp // 128):
-        blk = Lref[j * 128:(j + 1) * 128, j * 128:(j + 1) * 128]
-        torch.testing.assert_close(inv[j].cpu() @ blk, torch.eye(128, dtype=torch.float64), rtol=0, atol=1e-9)
+    for J in range((dp + 511) // 512):
+        w = min(512, dp - 512 * J)
+        blk = Lref[J * 512:J * 512 + w, J * 512:J * 512 + w]
+        got = inv[J * 512 * 512:(J + 1) * 512 * 512].view(512, 512)[:w, :w].cpu()
+        torch.testing.assert_close(got @ blk, torch.eye(w, dtype=torch.float64), rtol=0, atol=1e-9)
+        assert torch.equal(got, torch.tril(got))
     Bt = _rand(192, dp, seed=5)
     X = hip.cholesky_solve_(L, inv, Bt.clone().to(DEV)).cpu()
     ref = torch.linalg.solve(A, Bt.t()).t()
