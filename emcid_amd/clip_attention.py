@@ -41,15 +41,38 @@ def register() -> bool:
     return _registered
 
 
+class _HipQuickGELU(torch.nn.Module):
+    def forward(self, x):
+        if x.is_cuda and x.dtype == torch.float32:
+            return hip.quick_gelu(x)
+        return x * torch.sigmoid(1.702 * x)
+
+
+def _swap_quick_gelu(text_encoder):
+    """Replace every QuickGELU activation module (3 elementwise passes in HF) by the fused kernel; returns the
+    (module, attribute, original) list to undo it."""
+    undo = []
+    for mod in text_encoder.modules():
+        act = getattr(mod, "activation_fn", None)
+        if isinstance(act, torch.nn.Module) and type(act).__name__ == "QuickGELUActivation":
+            undo.append((mod, "activation_fn", act))
+            mod.activation_fn = _HipQuickGELU()
+    return undo
+
+
 @contextlib.contextmanager
 def hip_attention(text_encoder, enabled=True):
+    """Within the block the encoder's attention (and quick_gelu) run on the hand-written HIP kernels."""
     cfg = getattr(text_encoder, "config", None)
     if not (enabled and cfg is not None and hasattr(cfg, "_attn_implementation") and register()):
         yield False
         return
     prev = cfg._attn_implementation
     cfg._attn_implementation = NAME
+    undo = _swap_quick_gelu(text_encoder)
     try:
         yield True
     finally:
         cfg._attn_implementation = prev
+        for mod, name, orig in undo:
+            setattr(mod, name, orig)

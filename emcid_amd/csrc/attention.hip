@@ -99,9 +99,38 @@ __global__ __launch_bounds__(WAVES * 64) void attention_f32_kernel(AttnArgs a) {
     }
 }
 
+// y = x * sigmoid(1.702 x)  (CLIP's quick_gelu; HF runs it as mul -> sigmoid -> mul, three passes over HBM)
+__global__ __launch_bounds__(256) void quick_gelu_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4,
+                                                              int64_t n) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n4; i += stride) {
+        const v4f a = reinterpret_cast<const v4f*>(x)[i];
+        v4f r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = a[e] * (1.0f / (1.0f + expf(-1.702f * a[e])));
+        reinterpret_cast<v4f*>(y)[i] = r;
+    }
+    if (blockIdx.x == 0)
+        for (int64_t j = n4 * 4 + threadIdx.x; j < n; j += 256) y[j] = x[j] * (1.0f / (1.0f + expf(-1.702f * x[j])));
+}
+
 }  // namespace emcid
 
 using namespace emcid;
+
+extern "C" int emcid_quick_gelu_f32(const float* x, float* y, int64_t n, void* stream) {
+    EMCID_CHECK_ARG(x && y && n > 0 && aligned16(x) && aligned16(y));
+    const int64_t n4 = n / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    ScopedProf sp(KC_MISC, (hipStream_t)stream);
+    hipLaunchKernelGGL(quick_gelu_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, n4, n);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
 
 extern "C" int emcid_attention_f32(const float* q, const float* k, const float* v, int64_t sb, int64_t sh, int64_t ss,
                                    const void* mask, int mask_kind, int64_t mb, int64_t mi, int causal, float scale,

@@ -20,7 +20,7 @@ EXPORTS = [
     "emcid_gather_mean_f32", "emcid_edit_workspace_bytes", "emcid_edit_layer_f64", "emcid_assemble_spd_f64",
     "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_axpy_f32",
     "emcid_profile_enable", "emcid_profile_collect", "emcid_attention_f32", "emcid_edit_layer_shard_f64",
-    "emcid_apply_update_f32", "emcid_inverse_workspace_doubles",
+    "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build"]
@@ -66,6 +66,7 @@ def load():
         "emcid_delta_w_f64": (i32, [p, i64, p, i64, i64, i64, i64, p, p, i64, p, p, p]),
         "emcid_dgemm_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, p]),
         "emcid_axpy_f32": (i32, [p, p, i64, p]),
+        "emcid_quick_gelu_f32": (i32, [p, p, i64, p]),
         "emcid_profile_enable": (i32, [C.c_uint]),
         "emcid_profile_collect": (i32, [p, p, i32]),
         "emcid_attention_f32": (i32, [p, p, p, i64, i64, i64, p, i32, i64, i64, i32, f32, i64, i64, i64, i64, p, p]),
@@ -292,3 +293,11 @@ def attention(q, k, v, mask=None, causal=False, scale=None):
                                       q.stride(0), q.stride(1), q.stride(2), mptr, kind, mb, mi, int(bool(causal)), scale,
                                       B, H, S, D, _ptr(out), _stream(q)), "emcid_attention_f32")
     return out
+
+
+def quick_gelu(x: torch.Tensor) -> torch.Tensor:
+    """x * sigmoid(1.702 x), fp32, one pass."""
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _check(load().emcid_quick_gelu_f32(_ptr(x, torch.float32, "x"), _ptr(y), x.numel(), _stream(x)), "emcid_quick_gelu_f32")
+    return y

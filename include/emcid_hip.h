@@ -77,6 +77,10 @@ int emcid_attention_f32(const float* q, const float* k, const float* v, int64_t 
                         const void* mask, int mask_kind, int64_t mb, int64_t mi, int causal, float scale,
                         int64_t B, int64_t H, int64_t S, int64_t D, float* out, void* stream);
 
+/* y = x * sigmoid(1.702 x), fp32, n elements (CLIP quick_gelu inside the same hooked forward; one HBM pass
+ * instead of the framework's three).  x may alias y. */
+int emcid_quick_gelu_f32(const float* x, float* y, int64_t n, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Stage 2 — per-layer closed form (reference: emcid/emcid_main.py:1016-1061).
  *

@@ -206,3 +206,10 @@ def test_edit_layer_concept_shards_sum_to_full(N, d, h, parts):
     scale = full["dW"].abs().max().item()
     assert (dW - full["dW"]).abs().max().item() <= 2e-7 * scale          # fp64 sum order, then one fp32 rounding
     assert (Wsh - Wfull).abs().max().item() <= 2e-7 * max(scale, 1.0)
+
+
+def test_quick_gelu_vs_torch():
+    x = torch.randn(1237, 3072, generator=torch.Generator().manual_seed(10)).to(DEV) * 3
+    torch.testing.assert_close(hip.quick_gelu(x), x * torch.sigmoid(1.702 * x), rtol=2e-6, atol=1e-6)
+    y = torch.randn(7, device=DEV)
+    torch.testing.assert_close(hip.quick_gelu(y), y * torch.sigmoid(1.702 * y), rtol=2e-6, atol=1e-6)
