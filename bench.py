@@ -43,9 +43,9 @@ def build_inputs(n_concepts, device, workdir, shard=None):
     from emcid_amd import emcid_main as em, synthetic as syn
     from emcid_amd.emcid_hparams import EMCIDHyperParams
 
-    pipe = syn.build_pipe(KIND, device)
+    pipe = syn.build_pipe(KIND, device, syllables=True)
     hidden, inter = syn.ENCODER_DIMS[KIND][:2]
-    reqs = syn.make_requests(n_concepts)
+    reqs = syn.make_requests(n_concepts, names="syllable")   # 3-token names, 7-token prompts like real CLIP BPE
     hp_d = syn.sd_hparams_dict(layers=LAYERS, mom2_update_weight=LAM, edit_weight=EW)
     cache = str(Path(workdir) / f"cache_{n_concepts}") + "/"
     stats = Path(workdir) / "stats"
@@ -156,8 +156,11 @@ def main():
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.concepts}-concept edit, SD-v1.4 text-encoder dims (768/3072/12L), layers 7-10, "
                                f"lambda 4000, 3 prompts/concept, v* and C_l pre-cached in HBM",
-                   "concepts": args.concepts, "prompts": plan.batch.n_prompts * world if world == 1 else None,
-                   "seq_len": int(plan.batch.inputs["input_ids"].shape[1]), "parallelism": f"concept-shard x{world}"},
+                   "concepts": args.concepts, "prompts_per_rank": plan.batch.n_prompts,
+                   "seq_len": int(plan.batch.inputs["input_ids"].shape[1]),
+                   "forward": ("prefix-trie: %d unique rows of %d tokens" % (plan.trie.n_nodes, plan.trie.n_tokens_dense))
+                   if plan.trie is not None else "hooked HF forward",
+                   "parallelism": f"concept-shard x{world}"},
         "host_prepare_ms": host_prepare_ms,
         "roofline": roofline,
     }
@@ -184,7 +187,7 @@ def cpu_baseline_and_error(workdir, device, n_sample=100):
     t0 = time.perf_counter()
     orc.apply_emcid_to_text_encoder(pipe_c, reqs, copy.deepcopy(hp_d), cache_name=cache, stats_dir=stats)
     cpu_s = time.perf_counter() - t0
-    pipe_g = syn.build_pipe(KIND, device)
+    pipe_g = syn.build_pipe(KIND, device, syllables=True)
     em.apply_emcid_to_text_encoder(pipe_g, reqs, EMCIDHyperParams(**hp_d), device, cache_name=cache, stats_dir=stats,
                                    verbose=False)
     err_abs, err_rel = 0.0, 0.0

@@ -1,0 +1,185 @@
+"""Prefix-deduplicated ("trie") forward of a HF CLIP text encoder for the K/Z assembly.
+
+The reference forwards every prompt of every request in full, twice per edited layer
+(emcid/compute_z.py:2296-2308 via emcid/emcid_main.py:987,:1004).  Mass-edit prompts are a handful of templates
+times many concept names, so most token positions are shared causal prefixes ("<bos> painting by ...").  A causal
+text encoder's state at a token depends only on the tokens before it; here every DISTINCT prefix is a node of a
+trie and is computed once:
+
+    rows            = trie nodes (unique (prefix, token) pairs up to each prompt's lookup token)
+    embeddings      = token_embedding[token[u]] + position_embedding[depth[u]]
+    per layer       = LN1 -> q/k/v projections (row-wise GEMMs) -> attention over the ancestor chain
+                      (csrc/attention.hip: tree_attention_f32) -> out_proj -> +res -> LN2 -> fc1 -> act -> fc2 -> +res
+    edited layer    = K / Zc gathered at the prompts' lookup nodes, closed form solved, fc2 recomputed with W_new
+    last edited one = only the lookup nodes go through q/attention/out_proj/MLP (k/v still for every node)
+
+Same arithmetic as the HF module tree (its own weights, LayerNorm eps, activation), only fewer rows; results
+match the hooked HF forward to fp32 rounding (tests/test_e2e_gpu.py).  Encoders that do not look like HF's
+CLIPTextModel raise ``UnsupportedEncoder`` and the engine falls back to the hooked HF forward.
+"""
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import hip
+from .nethook import get_module
+
+
+class UnsupportedEncoder(Exception):
+    pass
+
+
+@dataclass
+class ClipLayer:
+    ln1: torch.nn.LayerNorm
+    q: torch.nn.Linear
+    k: torch.nn.Linear
+    v: torch.nn.Linear
+    out: torch.nn.Linear
+    ln2: torch.nn.LayerNorm
+    fc1: torch.nn.Linear
+    act: object
+    fc2: torch.nn.Linear
+    heads: int
+    scale: float
+
+
+@dataclass
+class ClipTextGraph:
+    token_embedding: torch.nn.Embedding
+    position_embedding: torch.nn.Embedding
+    layers: List[ClipLayer]
+
+
+def discover(text_encoder, layer_module_tmp: str) -> ClipTextGraph:
+    """Resolve the sub-modules by the hparams' own name templates (``layer_module_tmp``) and HF CLIP attribute names."""
+    try:
+        root = getattr(text_encoder, "text_model", text_encoder)
+        emb = root.embeddings
+        tok_e, pos_e = emb.token_embedding, emb.position_embedding
+        n_layers = len(root.encoder.layers)
+        layers = []
+        for i in range(n_layers):
+            lm = get_module(text_encoder, layer_module_tmp.format(i))
+            at, mlp = lm.self_attn, lm.mlp
+            heads = int(at.num_heads)
+            hd = at.q_proj.out_features // heads
+            if hd > 64 or hd % 4:
+                raise UnsupportedEncoder(f"head_dim {hd} not supported by the tree-attention kernel")
+            act = mlp.activation_fn
+            if type(act).__name__ == "QuickGELUActivation":
+                act = hip.quick_gelu
+            layers.append(ClipLayer(lm.layer_norm1, at.q_proj, at.k_proj, at.v_proj, at.out_proj, lm.layer_norm2,
+                                    mlp.fc1, act, mlp.fc2, heads, float(getattr(at, "scale", hd ** -0.5))))
+        for l in layers:
+            for m in (l.q, l.k, l.v, l.out, l.fc1, l.fc2):
+                if not isinstance(m, torch.nn.Linear):
+                    raise UnsupportedEncoder("projection is not nn.Linear")
+        return ClipTextGraph(tok_e, pos_e, layers)
+    except (AttributeError, LookupError, TypeError) as e:
+        raise UnsupportedEncoder(str(e))
+
+
+@dataclass
+class TokenTrie:
+    """Unique causal prefixes of a prompt batch (host-built, device-resident index arrays)."""
+    token: torch.Tensor        # (U,) int64
+    depth: torch.Tensor        # (U,) int32  position id of the node
+    anc: torch.Tensor          # (U, Dmax) int32 ancestor chain root..node (padded with 0)
+    lookup_node: torch.Tensor  # (B,) int64 node of each prompt's lookup token
+    query_rows: torch.Tensor   # (R,) int32 distinct lookup nodes (sorted)
+    lookup_in_query: torch.Tensor  # (B,) int64 index of each prompt's lookup node inside query_rows
+    n_nodes: int
+    n_tokens_dense: int        # B * S the dense forward would process
+
+
+def build_trie(input_ids: Sequence[Sequence[int]], lookup: Sequence[int], device) -> TokenTrie:
+    index: Dict[tuple, int] = {}
+    token, parent, depth = [], [], []
+    lookup_node = []
+    for ids, lk in zip(input_ids, lookup):
+        p = -1
+        for pos in range(lk + 1):
+            key = (p, ids[pos])
+            u = index.get(key)
+            if u is None:
+                u = index[key] = len(token)
+                token.append(ids[pos])
+                parent.append(p)
+                depth.append(pos)
+            p = u
+        lookup_node.append(p)
+    U = len(token)
+    dmax = max(depth) + 1
+    if dmax > 128:
+        raise UnsupportedEncoder("prompt longer than 128 tokens")
+    anc = np.zeros((U, dmax), dtype=np.int32)
+    par = np.asarray(parent)
+    dep = np.asarray(depth)
+    for u in range(U):          # parents precede children, so their rows are complete
+        d = dep[u]
+        if d:
+            anc[u, :d] = anc[par[u], :d]
+        anc[u, d] = u
+    ln = np.asarray(lookup_node)
+    q_rows, inverse = np.unique(ln, return_inverse=True)
+    return TokenTrie(torch.tensor(token, dtype=torch.int64, device=device),
+                     torch.tensor(dep, dtype=torch.int32, device=device),
+                     torch.from_numpy(anc).to(device), torch.from_numpy(ln).to(device),
+                     torch.from_numpy(q_rows.astype(np.int32)).to(device),
+                     torch.from_numpy(inverse.astype(np.int64)).to(device), U,
+                     len(input_ids) * len(input_ids[0]))
+
+
+def _check_fp32(graph: ClipTextGraph):
+    w = graph.layers[0].fc2.weight
+    if not (w.is_cuda and w.dtype == torch.float32):
+        raise hip.EmcidHipError(f"the trie forward runs fp32 in HBM (got {w.dtype} on {w.device})")
+
+
+def embed(graph: ClipTextGraph, trie: TokenTrie) -> torch.Tensor:
+    return graph.token_embedding(trie.token) + graph.position_embedding(trie.depth.long())
+
+
+def layer_attention_block(layer: ClipLayer, hs: torch.Tensor, trie: TokenTrie, rows: Optional[torch.Tensor]):
+    """hs (U, h) -> residual stream after the attention block, for every node (rows None) or the query rows only."""
+    x = layer.ln1(hs)
+    k = layer.k(x)
+    v = layer.v(x)
+    if rows is None:
+        q = layer.q(x)
+        res = hs
+    else:
+        idx = rows.long()
+        q = layer.q(x.index_select(0, idx))
+        res = hs.index_select(0, idx)
+    ctx = hip.tree_attention(q, k, v, trie.anc, trie.depth, layer.heads, layer.scale, rows)
+    return res + layer.out(ctx)
+
+
+def mlp_hidden(layer: ClipLayer, hs_mid: torch.Tensor) -> torch.Tensor:
+    """fc2 INPUT (the "key" space): act(fc1(LN2(hs_mid)))."""
+    return layer.act(layer.fc1(layer.ln2(hs_mid)))
+
+
+def run_layers(graph: ClipTextGraph, trie: TokenTrie, upto: int, on_fc2=None, last_rows_only: bool = True):
+    """Layers 0..upto (inclusive).  ``on_fc2(i, x, out) -> out'`` is called with the fc2 input/output of every layer
+    (rows = all nodes, or the query rows at layer ``upto`` when ``last_rows_only``); whatever it returns is used
+    as fc2's output.  Returns the residual stream after layer ``upto`` (query rows only if ``last_rows_only``)."""
+    _check_fp32(graph)
+    hs = embed(graph, trie)
+    for i in range(upto + 1):
+        layer = graph.layers[i]
+        rows = trie.query_rows if (last_rows_only and i == upto) else None
+        mid = layer_attention_block(layer, hs, trie, rows)
+        x = mlp_hidden(layer, mid)
+        out = layer.fc2(x)
+        if on_fc2 is not None:
+            out = on_fc2(i, x, out)
+            if out is None:
+                return None
+        hs = mid + out
+    return hs

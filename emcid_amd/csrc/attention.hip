@@ -99,6 +99,85 @@ __global__ __launch_bounds__(WAVES * 64) void attention_f32_kernel(AttnArgs a) {
     }
 }
 
+// ---- attention over a token trie ------------------------------------------------------------------------------
+// The prompts of a mass edit share causal prefixes ("painting by ...", BOS).  A causal encoder's state at a token
+// depends only on the tokens before it, so every distinct prefix is computed ONCE: tokens are the nodes of a
+// trie and a node attends to its ancestor chain.  q/k/v are [U, H*D] rows (one per node); anc[u][0..depth[u]]
+// lists the chain root..u.  One workgroup per query node, one wave per head (round robin); a wave takes 4 keys
+// per step: lane = (key slot, 16-byte chunk of the head), so a key row is one coalesced 256-B read.
+struct TreeAttnArgs {
+    const float* q; int64_t ldq; const float* k; const float* v; int64_t ld;
+    const int* anc; int64_t anc_ld; const int* depth; const int* rows; int n_rows;
+    int H, D; float scale; float* out; int64_t ldo;
+};
+
+__global__ __launch_bounds__(256) void tree_attention_f32_kernel(TreeAttnArgs a) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __shared__ int pth[128];
+    __shared__ float sc[4][128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = lane >> 4, dl = lane & 15;
+    const int qi = blockIdx.x;
+    const int u = a.rows ? a.rows[qi] : qi;
+    const int nk = a.depth[u] + 1;
+    if (tid < nk) pth[tid] = a.anc[(int64_t)u * a.anc_ld + tid];
+    __syncthreads();
+    const bool dok = 4 * dl < a.D;
+    const int rounds = (a.H + 3) / 4;
+    for (int hh = 0; hh < rounds; ++hh) {
+        const int h = hh * 4 + wave;
+        const bool live = h < a.H;
+        const int64_t col = (int64_t)(live ? h : 0) * a.D + 4 * dl;
+        v4f q4 = {0.f, 0.f, 0.f, 0.f};
+        if (dok) q4 = *reinterpret_cast<const v4f*>(a.q + (int64_t)qi * a.ldq + col);   // q rows follow the QUERY order
+        for (int j0 = 0; j0 < nk; j0 += 4) {
+            const int j = j0 + slot;
+            float part = 0.f;
+            if (j < nk && dok) {
+                const v4f k4 = *reinterpret_cast<const v4f*>(a.k + (int64_t)pth[j] * a.ld + col);
+                part = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
+            }
+            part += __shfl_xor(part, 8);
+            part += __shfl_xor(part, 4);
+            part += __shfl_xor(part, 2);
+            part += __shfl_xor(part, 1);
+            if (dl == 0 && j < nk) sc[wave][j] = part * a.scale;
+        }
+        __syncthreads();
+        float m = -INFINITY;
+        for (int j = lane; j < nk; j += 64) m = fmaxf(m, sc[wave][j]);
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float l = 0.f;
+        for (int j = lane; j < nk; j += 64) {
+            const float p = expf(sc[wave][j] - m);
+            sc[wave][j] = p;
+            l += p;
+        }
+        for (int o = 32; o >= 1; o >>= 1) l += __shfl_xor(l, o);
+        __syncthreads();
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < nk; j0 += 4) {
+            const int j = j0 + slot;
+            if (j < nk && dok) {
+                const float p = sc[wave][j];
+                const v4f v4 = *reinterpret_cast<const v4f*>(a.v + (int64_t)pth[j] * a.ld + col);
+                acc[0] += p * v4[0]; acc[1] += p * v4[1]; acc[2] += p * v4[2]; acc[3] += p * v4[3];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[e] += __shfl_xor(acc[e], 16);
+            acc[e] += __shfl_xor(acc[e], 32);
+        }
+        if (live && slot == 0 && dok) {
+            const float inv = 1.f / l;
+            v4f o4 = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+            *reinterpret_cast<v4f*>(a.out + (int64_t)qi * a.ldo + col) = o4;
+        }
+        __syncthreads();
+    }
+}
+
 // y = x * sigmoid(1.702 x)  (CLIP's quick_gelu; HF runs it as mul -> sigmoid -> mul, three passes over HBM)
 __global__ __launch_bounds__(256) void quick_gelu_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n4,
                                                               int64_t n) {
@@ -119,6 +198,19 @@ __global__ __launch_bounds__(256) void quick_gelu_f32_kernel(const float* __rest
 }  // namespace emcid
 
 using namespace emcid;
+
+extern "C" int emcid_tree_attention_f32(const float* q, int64_t ldq, const float* k, const float* v, int64_t ld, const int* anc,
+                                        int64_t anc_ld, const int* depth, const int* rows, int64_t n_rows, int64_t H,
+                                        int64_t D, float scale, float* out, int64_t ldo, void* stream) {
+    EMCID_CHECK_ARG(q && k && v && anc && depth && out && n_rows > 0 && H > 0 && D > 0);
+    EMCID_CHECK_ARG(D <= 64 && D % 4 == 0 && ld % 4 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && anc_ld >= 1 && anc_ld <= 128);
+    EMCID_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out) && n_rows < (1LL << 31));
+    TreeAttnArgs a{q, ldq, k, v, ld, anc, anc_ld, depth, rows, (int)n_rows, (int)H, (int)D, scale, out, ldo};
+    ScopedProf sp(KC_MISC, (hipStream_t)stream);
+    hipLaunchKernelGGL(tree_attention_f32_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, a);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
 
 extern "C" int emcid_quick_gelu_f32(const float* x, float* y, int64_t n, void* stream) {
     EMCID_CHECK_ARG(x && y && n > 0 && aligned16(x) && aligned16(y));

@@ -25,6 +25,7 @@ import torch
 import torch.nn.functional as F
 
 from . import hip
+from . import clip_forward
 from .clip_attention import hip_attention
 from .compute_z import PromptBatch, build_prompt_batch, gather_request_means
 from .nethook import StopForward, get_module, get_parameter
@@ -67,14 +68,20 @@ class EncoderEditPlan:
     n_total: int                           # N over all ranks
     shard: ConceptShard = field(default_factory=ConceptShard)
     ws: Optional[hip.EditWorkspace] = None
+    graph: Optional[clip_forward.ClipTextGraph] = None   # set -> prefix-deduplicated forward (clip_forward.py)
+    trie: Optional[clip_forward.TokenTrie] = None
 
     def weight_name(self, layer):
         return f"{self.rewrite_module_tmp.format(layer)}.weight"
 
 
+FORWARD_MODE = "trie"   # "trie": prefix-deduplicated forward when the encoder is a HF CLIP text model; "hf": hooked HF forward
+
+
 def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], layers, rewrite_module_tmp, lam,
                          edit_weight, zs_t: torch.Tensor, covs: Dict[int, torch.Tensor],
-                         shard: Optional[ConceptShard] = None) -> EncoderEditPlan:
+                         shard: Optional[ConceptShard] = None, layer_module_tmp: Optional[str] = None,
+                         forward_mode: Optional[str] = None) -> EncoderEditPlan:
     shard = shard or ConceptShard()
     device = next(text_encoder.parameters()).device
     lo, hi = shard.bounds(len(requests))
@@ -85,8 +92,20 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
     if zs_t.shape[0] != len(requests):
         raise ValueError(f"v* stack has {zs_t.shape[0]} rows for {len(requests)} requests")
     covs = {l: c.to(device=device, dtype=torch.float32).contiguous() for l, c in covs.items()}
-    return EncoderEditPlan(text_encoder, list(layers), rewrite_module_tmp, float(lam), float(edit_weight), batch,
+    plan = EncoderEditPlan(text_encoder, list(layers), rewrite_module_tmp, float(lam), float(edit_weight), batch,
                            zs_t, covs, len(requests), shard)
+    mode = forward_mode or FORWARD_MODE
+    if mode == "trie" and layer_module_tmp is not None and device.type == "cuda":
+        try:
+            graph = clip_forward.discover(text_encoder, layer_module_tmp)
+            for l in plan.layers:   # the edited weights must be the very tensors the explicit forward multiplies with
+                if graph.layers[l].fc2.weight is not get_parameter(text_encoder, plan.weight_name(l)):
+                    raise clip_forward.UnsupportedEncoder("rewrite_module_tmp is not the layer's mlp.fc2")
+            plan.trie = clip_forward.build_trie(batch.inputs["input_ids"].tolist(), batch.lookup_host, device)
+            plan.graph = graph
+        except (clip_forward.UnsupportedEncoder, IndexError, LookupError):
+            plan.graph = plan.trie = None
+    return plan
 
 
 def _staged(group) -> bool:
@@ -153,40 +172,66 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
     last = plan.layers[-1]
     handles = []
 
-    def make_hook(i, layer):
-        def hook(mod, inputs, output):
-            x = inputs[0]
-            K = _all_gather_rows(gather_request_means(x, plan.batch), plan)
-            Zc = _all_gather_rows(gather_request_means(output, plan.batch), plan)
-            if plan.shard.world > 1 and not keep_factors:
-                # every rank assembles and factors A from all N concepts; the triangular solves and the dW
-                # contraction are split by concept rows and the partial U summed over xGMI (fp64, h*d*8 bytes)
-                res = hip.edit_layer_shard(K, Zc, plan.zs_t, plan.covs[layer], plan.lam, plan.edit_weight, L - i,
-                                           plan.shard.bounds(plan.n_total), ws=plan.ws)
-                _all_reduce_sum(res["U"], plan.shard.group)
-                dW = hip.apply_update_(res["U"], backups[layer], weights[layer].data)
-                res = {"dW": dW, "Xt": None, "Rt": None}
-            else:
-                res = hip.edit_layer(K, Zc, plan.zs_t, plan.covs[layer], plan.lam, plan.edit_weight, L - i,
-                                     W0=backups[layer], W=weights[layer].data, want_factors=keep_factors, ws=plan.ws)
-            edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], res["Xt"], res["Rt"],
-                                   K if trace else None, Zc if trace else None))
-            if layer == last:
-                raise StopForward()
-            return F.linear(x, mod.weight, mod.bias)
-        return hook
+    def solve(i, layer, K_local, Zc_local):
+        """All-gather the shard's K/Zc rows, run the closed form, leave W0 + dW in the live weight."""
+        K = _all_gather_rows(K_local, plan)
+        Zc = _all_gather_rows(Zc_local, plan)
+        if plan.shard.world > 1 and not keep_factors:
+            # every rank assembles and factors A from all N concepts; the triangular solves and the dW
+            # contraction are split by concept rows and the partial U summed over xGMI (fp64, h*d*8 bytes)
+            res = hip.edit_layer_shard(K, Zc, plan.zs_t, plan.covs[layer], plan.lam, plan.edit_weight, L - i,
+                                       plan.shard.bounds(plan.n_total), ws=plan.ws)
+            _all_reduce_sum(res["U"], plan.shard.group)
+            dW = hip.apply_update_(res["U"], backups[layer], weights[layer].data)
+            res = {"dW": dW, "Xt": None, "Rt": None}
+        else:
+            res = hip.edit_layer(K, Zc, plan.zs_t, plan.covs[layer], plan.lam, plan.edit_weight, L - i,
+                                 W0=backups[layer], W=weights[layer].data, want_factors=keep_factors, ws=plan.ws)
+        edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], res["Xt"], res["Rt"],
+                               K if trace else None, Zc if trace else None))
 
-    for i, l in enumerate(plan.layers):
-        handles.append(mods[l].register_forward_hook(make_hook(i, l)))
-    try:
-        with torch.no_grad(), hip_attention(te):
-            try:
-                te(**plan.batch.inputs)
-            except StopForward:
-                pass
-    finally:
-        for hd in handles:
-            hd.remove()
+    if plan.trie is not None:
+        trie, order = plan.trie, {l: i for i, l in enumerate(plan.layers)}
+        if sorted(plan.layers) != plan.layers:
+            raise RuntimeError("hparams.layers must be in forward order")
+        B = trie.lookup_node.numel()
+
+        def rows_at(x, idx):   # (rows, c) activations -> per-request means at each prompt's lookup row
+            return hip.gather_mean(x.unsqueeze(0).expand(B, -1, -1), idx, plan.batch.seg)
+
+        def on_fc2(li, x, out):
+            if li not in order:
+                return out
+            idx = trie.lookup_in_query if li == last else trie.lookup_node
+            solve(order[li], li, rows_at(x, idx), rows_at(out, idx))
+            if li == last:
+                return None
+            m = mods[li]
+            return F.linear(x, m.weight, m.bias)
+
+        with torch.no_grad():
+            clip_forward.run_layers(plan.graph, trie, last, on_fc2)
+    else:
+        def make_hook(i, layer):
+            def hook(mod, inputs, output):
+                x = inputs[0]
+                solve(i, layer, gather_request_means(x, plan.batch), gather_request_means(output, plan.batch))
+                if layer == last:
+                    raise StopForward()
+                return F.linear(x, mod.weight, mod.bias)
+            return hook
+
+        for i, l in enumerate(plan.layers):
+            handles.append(mods[l].register_forward_hook(make_hook(i, l)))
+        try:
+            with torch.no_grad(), hip_attention(te):
+                try:
+                    te(**plan.batch.inputs)
+                except StopForward:
+                    pass
+        finally:
+            for hd in handles:
+                hd.remove()
     if len(edits) != L:
         raise RuntimeError(f"only {len(edits)} of {L} edited layers were reached by the forward pass "
                            f"(hparams.layers must be in forward order)")

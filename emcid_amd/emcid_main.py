@@ -160,7 +160,8 @@ def prepare_text_encoder_edit(text_encoder, tokenizer, requests, hparams, layers
     for layer in layers:   # resolve every edited weight now: LookupError before any GPU work, like the reference (:858-863)
         nethook.get_parameter(text_encoder, f"{hparams.rewrite_module_tmp.format(layer)}.weight")
     return prepare_encoder_edit(text_encoder, tokenizer, requests, layers, hparams.rewrite_module_tmp, lam,
-                                hparams.edit_weight, zs_t, covs, _shard_from_env(shard))
+                                hparams.edit_weight, zs_t, covs, _shard_from_env(shard),
+                                layer_module_tmp=getattr(hparams, "layer_module_tmp", None))
 
 
 def _deltas_to_host(edits: List[LayerEdit]) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:

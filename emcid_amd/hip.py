@@ -20,7 +20,7 @@ EXPORTS = [
     "emcid_gather_mean_f32", "emcid_edit_workspace_bytes", "emcid_edit_layer_f64", "emcid_assemble_spd_f64",
     "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_axpy_f32",
     "emcid_profile_enable", "emcid_profile_collect", "emcid_attention_f32", "emcid_edit_layer_shard_f64",
-    "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32",
+    "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32", "emcid_tree_attention_f32",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build"]
@@ -67,6 +67,7 @@ def load():
         "emcid_dgemm_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, p]),
         "emcid_axpy_f32": (i32, [p, p, i64, p]),
         "emcid_quick_gelu_f32": (i32, [p, p, i64, p]),
+        "emcid_tree_attention_f32": (i32, [p, i64, p, p, i64, p, i64, p, p, i64, i64, i64, f32, p, i64, p]),
         "emcid_profile_enable": (i32, [C.c_uint]),
         "emcid_profile_collect": (i32, [p, p, i32]),
         "emcid_attention_f32": (i32, [p, p, p, i64, i64, i64, p, i32, i64, i64, i32, f32, i64, i64, i64, i64, p, p]),
@@ -301,3 +302,26 @@ def quick_gelu(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty_like(x)
     _check(load().emcid_quick_gelu_f32(_ptr(x, torch.float32, "x"), _ptr(y), x.numel(), _stream(x)), "emcid_quick_gelu_f32")
     return y
+
+
+def tree_attention(q, k, v, anc, depth, H: int, scale=None, rows=None):
+    """k/v (U, H*D) fp32 row views sharing one leading dimension; q (n, H*D) in query order; anc (U, S) int32;
+    depth (U,) int32; rows: optional (n,) int32 query nodes (None: all U nodes, q has U rows).  Returns (n, H*D)."""
+    U, HD = k.shape
+    D = HD // H
+    for t in (q, k, v):
+        if t.stride(1) != 1 or t.shape[1] != HD:
+            raise EmcidHipError("tree_attention: q/k/v must be row-major")
+    if k.stride(0) != v.stride(0):
+        raise EmcidHipError("tree_attention: k and v must share a leading dimension")
+    n = U if rows is None else rows.numel()
+    if q.shape[0] != n:
+        raise EmcidHipError(f"tree_attention: {q.shape[0]} query rows for {n} query nodes")
+    out = torch.empty(n, HD, dtype=torch.float32, device=q.device)
+    scale = float(D ** -0.5 if scale is None else scale)
+    _check(load().emcid_tree_attention_f32(
+        _ptr(q, torch.float32, "q"), q.stride(0), _ptr(k, torch.float32, "k"), _ptr(v, torch.float32, "v"), k.stride(0),
+        _ptr(anc, torch.int32, "anc"), anc.stride(0), _ptr(depth, torch.int32, "depth"),
+        _ptr(rows, torch.int32, "rows") if rows is not None else None, n, H, D, scale, _ptr(out), out.stride(0),
+        _stream(q)), "emcid_tree_attention_f32")
+    return out

@@ -45,8 +45,16 @@ ENCODER_DIMS = {
 }
 
 
-def synthetic_vocab(words: Sequence[str] = TEMPLATE_WORDS) -> Tuple[Dict[str, int], List[Tuple[str, str]]]:
-    """Character vocabulary plus left-to-right merge chains for ``words``."""
+CONSONANTS = "bcdfghjklmnprstvwz"
+VOWELS = "aeiou"
+SYLLABLES = [c + v for c in CONSONANTS for v in VOWELS]          # 90 consonant-vowel syllables
+
+
+def synthetic_vocab(words: Sequence[str] = TEMPLATE_WORDS, syllables: bool = False
+                    ) -> Tuple[Dict[str, int], List[Tuple[str, str]]]:
+    """Character vocabulary plus left-to-right merge chains for ``words``.  ``syllables=True`` (the benchmark
+    vocabulary) also merges every consonant-vowel pair, so a name such as ``kazumi`` is 3 tokens — the token
+    count real CLIP BPE gives a typical artist name (the golden fixtures keep the plain vocabulary)."""
     chars = list(string.ascii_lowercase + string.digits + ".,'-")
     vocab: Dict[str, int] = {}
     for c in chars:
@@ -63,9 +71,29 @@ def synthetic_vocab(words: Sequence[str] = TEMPLATE_WORDS) -> Tuple[Dict[str, in
             cur = cur + s
             if cur not in vocab:
                 vocab[cur] = len(vocab)
+    if syllables:   # lower priority than the word chains above, so template words still become one token
+        for c in CONSONANTS:
+            for v in VOWELS:
+                for tail in ("", "</w>"):
+                    if (c, v + tail) not in merges:
+                        merges.append((c, v + tail))
+                    if c + v + tail not in vocab:
+                        vocab[c + v + tail] = len(vocab)
     vocab["<|startoftext|>"] = len(vocab)
     vocab["<|endoftext|>"] = len(vocab)
     return vocab, merges
+
+
+def syllable_names(n: int, seed: int = 3, syllables_per_name: int = 3) -> List[str]:
+    """n distinct pronounceable names (``kazumi``), deterministic."""
+    rng = np.random.default_rng(seed)
+    names, seen = [], set()
+    while len(names) < n:
+        nm = "".join(SYLLABLES[i] for i in rng.integers(0, len(SYLLABLES), size=syllables_per_name))
+        if nm not in seen:
+            seen.add(nm)
+            names.append(nm)
+    return names
 
 
 def build_tokenizer(vocab: Optional[Dict[str, int]] = None, merges=None, model_max_length: int = 77):
@@ -117,8 +145,9 @@ class SyntheticPipe(SimpleNamespace):
         return self
 
 
-def build_pipe(kind: str = "toy", device: str = "cpu", sdxl: bool = False, seed: int = 0) -> SyntheticPipe:
-    vocab, merges = synthetic_vocab()
+def build_pipe(kind: str = "toy", device: str = "cpu", sdxl: bool = False, seed: int = 0,
+               syllables: bool = False) -> SyntheticPipe:
+    vocab, merges = synthetic_vocab(syllables=syllables)
     tok = build_tokenizer(vocab, merges)
     if not sdxl:
         te = build_text_encoder(kind, len(vocab), seed=seed)
@@ -131,14 +160,16 @@ def build_pipe(kind: str = "toy", device: str = "cpu", sdxl: bool = False, seed:
 
 
 def make_requests(n: int, dest: str = "a realist artist", templates: Sequence[str] = ARTIST_TEMPLATES,
-                  seed_train: int = 2024, ragged: bool = False) -> List[Dict]:
-    """n unique synthetic concepts ``c0000`` … in the reference's request schema.
+                  seed_train: int = 2024, ragged: bool = False, names: str = "index") -> List[Dict]:
+    """n unique synthetic concepts in the reference's request schema: ``c0000`` … (``names="index"``) or
+    3-syllable names (``names="syllable"``, needs the ``syllables=True`` vocabulary to tokenize compactly).
     ``ragged`` gives requests differing prompt counts (1..len(templates))."""
     reqs = []
+    sources = syllable_names(n) if names == "syllable" else [f"c{i:04d}" for i in range(n)]
     for i in range(n):
         k = len(templates) if not ragged else 1 + (i % len(templates))
         reqs.append({
-            "source": f"c{i:04d}",
+            "source": sources[i],
             "dest": dest,
             "prompts": list(templates[:k]),
             "seed_train": seed_train,

@@ -77,6 +77,16 @@ int emcid_attention_f32(const float* q, const float* k, const float* v, int64_t 
                         const void* mask, int mask_kind, int64_t mb, int64_t mi, int causal, float scale,
                         int64_t B, int64_t H, int64_t S, int64_t D, float* out, void* stream);
 
+/* Attention over a token trie (prefix-deduplicated causal forward): k/v [U, H*D] fp32 rows with leading
+ * dimension ld (one row per distinct prompt prefix); anc [U, anc_ld] int32 lists each node's ancestor chain
+ * root..node (depth[u]+1 entries, <= 128); rows (optional, n_rows int32) selects the query nodes, NULL = all
+ * U nodes (then n_rows = U); q [n_rows, H*D] (leading dimension ldq) holds the queries IN QUERY ORDER.
+ * out [n_rows, H*D]:  out[i] = softmax_j(scale * q[i].k[anc[u][j]]) v[anc[u][j]],  u = rows ? rows[i] : i.
+ * head_dim D <= 64, multiple of 4. */
+int emcid_tree_attention_f32(const float* q, int64_t ldq, const float* k, const float* v, int64_t ld, const int* anc, int64_t anc_ld,
+                             const int* depth, const int* rows, int64_t n_rows, int64_t H, int64_t D, float scale,
+                             float* out, int64_t ldo, void* stream);
+
 /* y = x * sigmoid(1.702 x), fp32, n elements (CLIP quick_gelu inside the same hooked forward; one HBM pass
  * instead of the framework's three).  x may alias y. */
 int emcid_quick_gelu_f32(const float* x, float* y, int64_t n, void* stream);

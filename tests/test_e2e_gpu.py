@@ -223,3 +223,37 @@ def test_cov_from_stage0_feeds_edit(tmp_path):
             assert (a - b).abs().max().item() < 1e-4
     finally:
         os.chdir(cwd)
+
+
+@pytest.mark.parametrize("kind,layers,n_req", [("toy", (1, 2, 3, 4), 9), ("sd-v1.4", (7, 8, 9, 10), 40)])
+def test_trie_forward_matches_hooked_hf_forward(tmp_path, kind, layers, n_req):
+    """The prefix-deduplicated forward and the hooked HF forward must hand the SAME K / Zc to every layer's
+    solve (fp32 rounding apart) and end in the same weights."""
+    from emcid_amd import edit_engine as ee
+    hidden, inter = syn.ENCODER_DIMS[kind][:2]
+    reqs = syn.make_requests(n_req, ragged=True, names="syllable")
+    hp_d = syn.sd_hparams_dict(layers=layers, mom2_update_weight=60, mom2_n_samples=100)
+    names = [hp_d["rewrite_module_tmp"].format(l) for l in layers]
+    cache = str(tmp_path / "cache") + "/"
+    syn.write_vstar_cache(cache, reqs, hidden, seed=1, scale=0.5)
+    syn.write_stats_cache(tmp_path / "stats", names, inter, 100, seed=2, t=2 * inter)
+    results = {}
+    for mode in ("hf", "trie"):
+        em.clear_caches()
+        pipe = syn.build_pipe(kind, DEV, syllables=True)
+        hp = EMCIDHyperParams(**hp_d)
+        plan = em.prepare_text_encoder_edit(pipe.text_encoder, pipe.tokenizer, reqs, hp, hp.layers, 60,
+                                            str(tmp_path / "stats"), cache, verbose=False)
+        if mode == "hf":
+            plan.graph = plan.trie = None
+        else:
+            assert plan.trie is not None and plan.trie.n_nodes < plan.trie.n_tokens_dense
+        edits = ee.run_encoder_edit(plan, trace=True)
+        ee.check_info(plan)
+        results[mode] = (edits, {n: get_parameter(pipe.text_encoder, n + ".weight").clone() for n in names})
+    for eh, et in zip(results["hf"][0], results["trie"][0]):
+        torch.testing.assert_close(et.K, eh.K, rtol=2e-4, atol=2e-5)
+        torch.testing.assert_close(et.Zc, eh.Zc, rtol=2e-4, atol=2e-5)
+        assert (et.dW - eh.dW).abs().max().item() <= 1e-4 * eh.dW.abs().max().item()
+    for n in names:
+        assert (results["hf"][1][n] - results["trie"][1][n]).abs().max().item() < 1e-5

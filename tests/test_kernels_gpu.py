@@ -213,3 +213,39 @@ def test_quick_gelu_vs_torch():
     torch.testing.assert_close(hip.quick_gelu(x), x * torch.sigmoid(1.702 * x), rtol=2e-6, atol=1e-6)
     y = torch.randn(7, device=DEV)
     torch.testing.assert_close(hip.quick_gelu(y), y * torch.sigmoid(1.702 * y), rtol=2e-6, atol=1e-6)
+
+
+def test_tree_attention_vs_dense_reference():
+    """Random trie: every node attends to its ancestor chain; compare with per-node dense softmax in torch."""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    U, H, D = 300, 3, 16
+    parent = [-1] + [int(rng.integers(max(0, u - 40), u)) for u in range(1, U)]
+    depth, anc = [], []
+    for u in range(U):
+        chain = [u]
+        while parent[chain[-1]] >= 0:
+            chain.append(parent[chain[-1]])
+        chain = chain[::-1]
+        depth.append(len(chain) - 1)
+        anc.append(chain)
+    dmax = max(depth) + 1
+    anc_t = torch.zeros(U, dmax, dtype=torch.int32)
+    for u, ch in enumerate(anc):
+        anc_t[u, :len(ch)] = torch.tensor(ch, dtype=torch.int32)
+    g = torch.Generator().manual_seed(12)
+    qkv = torch.randn(U, 3, H * D, generator=g).to(DEV)
+    q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]                    # strided row views
+    out = hip.tree_attention(q, k, v, anc_t.to(DEV), torch.tensor(depth, dtype=torch.int32, device=DEV), H)
+    rows = torch.tensor([5, 17, 299, 0, 123], dtype=torch.int32, device=DEV)
+    out_rows = hip.tree_attention(q[rows.long()].contiguous(), k, v, anc_t.to(DEV),
+                                  torch.tensor(depth, dtype=torch.int32, device=DEV), H, rows=rows)
+    ref = torch.empty(U, H * D)
+    qc, kc, vc = q.cpu(), k.cpu(), v.cpu()
+    for u, ch in enumerate(anc):
+        for h in range(H):
+            sl = slice(h * D, (h + 1) * D)
+            w = torch.softmax((kc[ch][:, sl] @ qc[u, sl]) * D ** -0.5, dim=0)
+            ref[u, sl] = w @ vc[ch][:, sl]
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(out_rows.cpu(), ref[rows.cpu().long()], rtol=1e-5, atol=2e-6)
