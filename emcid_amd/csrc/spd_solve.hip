@@ -65,6 +65,14 @@ __global__ __launch_bounds__(256) void copy2d_f64_kernel(const double* __restric
     for (int c = threadIdx.x; c < cols; c += 256) dst[(int64_t)r * ldd + c] = src[(int64_t)r * lds_ + c];
 }
 
+// zero fill by kernel: a hipMemset node inside a captured graph binds the allocation object of capture time, which
+// goes stale when the caller's allocator recycles the address range; a kernel only carries the raw pointer
+__global__ __launch_bounds__(256) void zero_f64_kernel(double* __restrict__ p, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n; i += stride) p[i] = 0.0;
+}
+
 __global__ __launch_bounds__(256) void axpy_f32_kernel(float* __restrict__ W, const float* __restrict__ dW, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -352,10 +360,26 @@ static void build_block_inverses(const double* L, int64_t dp, int64_t lda, doubl
     if (rem > 2 * NB) level_b(nfull, 1, (int)(rem - 2 * NB));
 }
 
-static int cholesky_impl(double* A, double* L, int64_t dp, int64_t lda, double* invw, int* info, hipStream_t st) {
+// Graphs are captured on an internal stream: the caller's stream may be the legacy default stream, which cannot capture.
+namespace {
+hipStream_t g_capture_stream = nullptr;
+int capture_stream_init() {
+    if (g_capture_stream) return EMCID_OK;
+    if (hipStreamCreateWithFlags(&g_capture_stream, hipStreamNonBlocking) != hipSuccess)
+        return fail(EMCID_ERR_HIP, "emcid_edit_layer_f64", "hipStreamCreateWithFlags");
+    return EMCID_OK;
+}
+}  // namespace
+
+static int env_flag(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+// Right-looking blocked Cholesky, NB = 128, single stream: leaf -> panel -> trailing update per 128-column block.
+static int cholesky_serial(double* A, double* L, int64_t dp, int64_t lda, double* invw, int* info, hipStream_t st) {
     const int nb = (int)(dp / NB);
-    if (hipMemsetAsync(invw, 0, inv_doubles(dp) * sizeof(double), st) != hipSuccess)
-        return fail(EMCID_ERR_HIP, "emcid_cholesky_f64", "hipMemsetAsync");
+    hipLaunchKernelGGL(zero_f64_kernel, dim3(1024), dim3(256), 0, st, invw, inv_doubles(dp));
     for (int j = 0; j < nb; ++j) {
         const int64_t o = (int64_t)j * NB;
         double* inv = inv_block(invw, j / (OB / NB)) + ((j % (OB / NB)) * NB) * (int64_t)(OB + 1);
@@ -366,13 +390,11 @@ static int cholesky_impl(double* A, double* L, int64_t dp, int64_t lda, double* 
         }
         const int m = (int)(dp - o - NB);
         if (m == 0) break;
-        // panel: L21 = A21 * inv(L11)^T
         GemmShape ps{A + (o + NB) * lda + o, lda, inv, OB, m, NB, NB, 0};
         {
             ScopedProf sp(KC_CHOL_PANEL, st);
             launch_gemm_f64<true, true>(ps, EpiAxpby{L + (o + NB) * lda + o, lda, 1.0, 0.0}, st, 1);
         }
-        // trailing: A22 -= L21 * L21^T (lower tiles only)
         const double* L21 = L + (o + NB) * lda + o;
         GemmShape ts{L21, lda, L21, lda, m, m, NB, 1};
         {
@@ -382,6 +404,13 @@ static int cholesky_impl(double* A, double* L, int64_t dp, int64_t lda, double* 
     }
     build_block_inverses(L, dp, lda, invw, st);
     return check_launch("emcid_cholesky_f64");
+}
+
+// (A two-stream look-ahead schedule — spine leaf -> one panel block -> diagonal update on the caller's stream, bulk
+// panel/trailing on a side stream — was built and measured 6-11 % SLOWER, eager and as a graph: the leaf needs a
+// whole CU's LDS, so it cannot start while the bulk GEMM keeps every CU populated.  Kept serial.)
+static int cholesky_impl(double* A, double* L, int64_t dp, int64_t lda, double* invw, int* info, hipStream_t st) {
+    return cholesky_serial(A, L, dp, lda, invw, info, st);
 }
 
 // Bt[M, dp] := Bt (L L^T)^-1, right-looking over OB-wide column blocks: multiply by the inverted diagonal
@@ -422,6 +451,71 @@ static int cholesky_solve_impl(const double* L, int64_t dp, int64_t lda, const d
         }
     }
     return check_launch("emcid_cholesky_solve_f64");
+}
+
+// ---- factor + solve as one cached hipGraph -----------------------------------------------------------------------
+// The ~100 launches of one layer's Cholesky + block-inverse build + triangular solves take only workspace
+// pointers and sizes, so the whole chain (is captured once
+// per (workspace, shape) and replayed: dependent-kernel boundaries inside a graph cost ~1.2 us instead of a host
+// launch each.  Not used while per-kernel event timing is on (the events would be recorded at capture time).
+namespace {
+struct GraphKey {
+    const void *A, *L, *inv, *info, *B, *Y;
+    int64_t dp, lda, rows, ldb;
+    bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
+};
+struct GraphSlot { GraphKey key; hipGraphExec_t exec; hipGraph_t graph; uint64_t used; };
+constexpr int GRAPH_SLOTS = 16;
+GraphSlot g_graphs[GRAPH_SLOTS];
+int g_graph_n = 0;
+uint64_t g_graph_clock = 0;
+}  // namespace
+
+static int factor_and_solve(double* A, double* L, int64_t dp, int64_t lda, double* invw, int* info, double* B, double* Y,
+                            int64_t rows, int64_t ldb, hipStream_t st) {
+    static const int use_graph = env_flag("EMCID_GRAPH", 1);
+    if (!use_graph || g_prof_mask != 0) {
+        EMCID_TRY(cholesky_impl(A, L, dp, lda, invw, info, st));
+        return cholesky_solve_impl(L, dp, lda, invw, B, Y, rows, ldb, st);
+    }
+    GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.A = A; key.L = L; key.inv = invw; key.info = info; key.B = B; key.Y = Y;
+    key.dp = dp; key.lda = lda; key.rows = rows; key.ldb = ldb;
+    GraphSlot* slot = nullptr;
+    for (int i = 0; i < g_graph_n; ++i)
+        if (g_graphs[i].key == key) { slot = &g_graphs[i]; break; }
+    if (!slot) {
+        EMCID_TRY(capture_stream_init());
+        hipStream_t cap = g_capture_stream;
+        if (hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) != hipSuccess)
+            return fail(EMCID_ERR_HIP, "emcid_edit_layer_f64", "hipStreamBeginCapture");
+        int rc = cholesky_impl(A, L, dp, lda, invw, info, cap);
+        if (!rc) rc = cholesky_solve_impl(L, dp, lda, invw, B, Y, rows, ldb, cap);
+        hipGraph_t graph = nullptr;
+        const hipError_t ec = hipStreamEndCapture(cap, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ec != hipSuccess || !graph) return fail(EMCID_ERR_HIP, "emcid_edit_layer_f64", "hipStreamEndCapture");
+        hipGraphExec_t exec = nullptr;
+        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGraphDestroy(graph);
+            return fail(EMCID_ERR_HIP, "emcid_edit_layer_f64", "hipGraphInstantiate");
+        }
+        if (g_graph_n < GRAPH_SLOTS) {
+            slot = &g_graphs[g_graph_n++];
+        } else {   // evict the least recently used graph
+            slot = &g_graphs[0];
+            for (int i = 1; i < GRAPH_SLOTS; ++i)
+                if (g_graphs[i].used < slot->used) slot = &g_graphs[i];
+            (void)hipDeviceSynchronize();   // the evicted graph may still be executing
+            (void)hipGraphExecDestroy(slot->exec);
+            (void)hipGraphDestroy(slot->graph);
+        }
+        slot->key = key; slot->exec = exec; slot->graph = graph;
+    }
+    slot->used = ++g_graph_clock;
+    if (hipGraphLaunch(slot->exec, st) != hipSuccess) return fail(EMCID_ERR_HIP, "emcid_edit_layer_f64", "hipGraphLaunch");
+    return EMCID_OK;
 }
 
 struct EditWorkspace {
@@ -580,10 +674,9 @@ static int edit_layer_impl(const float* K, const float* Zc, const float* zs_t, c
     }
     EMCID_CHECK_LAUNCH();
     EMCID_TRY(emcid_assemble_spd_f64(C, d, B, ws.Np, d, ws.dp, lam, cw, A, ws.dp, stream));
-    EMCID_TRY(cholesky_impl(A, L, ws.dp, ws.dp, inv, info_dev, st));
     // only this shard's concept rows go through the triangular solves and the dW contraction
     double* Bs = B + n_lo * ws.dp;
-    EMCID_TRY(cholesky_solve_impl(L, ws.dp, ws.dp, inv, Bs, Y + n_lo * ws.dp, rows, ws.dp, st));
+    EMCID_TRY(factor_and_solve(A, L, ws.dp, ws.dp, inv, info_dev, Bs, Y + n_lo * ws.dp, rows, ws.dp, st));
     if (W || dW_out || U_out)
         EMCID_TRY(emcid_delta_w_f64(R + n_lo * ws.hp, ws.hp, Bs, ws.dp, rows, h, d, W0, W, d, dW_out, U_out, stream));
     if (Xt_out)
