@@ -8,14 +8,16 @@ text encoder (768 / 3072 / 12 layers, random init), layers [7, 8, 9, 10], lambda
 3 prompts per concept, synthetic v* and synthetic second moments C_l (no network for real weights/captions).
 A STEP is one pass of the hot path over that batch with every input resident in HBM (token ids, lookup
 indices, v*, C_l, encoder weights): restore the original fc2 weights, then edit_engine.run_encoder_edit —
-one partial encoder forward whose fc2 hooks run gather -> assemble -> Cholesky -> TRSM -> dW on the HIP
-kernels.  Host preparation (tokenizer, subject search, npz reads) happens once before the timed region and is
+one partial, prefix-deduplicated encoder forward (clip_forward.py) that runs gather -> assemble -> Cholesky ->
+TRSM -> dW on the HIP kernels at each edited layer's fc2.  Host preparation (tokenizer, subject search, npz reads) happens once before the timed region and is
 reported separately as `host_prepare_ms` (DESIGN.md §Measurement gives the all-inclusive rate).
 With N > 1 the 1 000 concepts are sharded over the ranks (strong scaling, fixed total work): each rank
-forwards its shard, K/Zc are all-gathered over RCCL per layer, every rank solves and updates redundantly.
+forwards its shard, K/Zc are all-gathered over RCCL per layer, every rank assembles and factors A, the triangular
+solves and dW are split by concept rows and the partial U (h x d, fp64) is all-reduced.
 
-`roofline`: the fp64 MFMA Cholesky trailing-update GEMM is the dominant HIP kernel class of a step; its
-launches are bracketed with HIP events on the launch stream inside the timed region (emcid_profile_*).
+`roofline`: after the timed region the same K steps run once more with every fp64-MFMA kernel class of the solve
+bracketed by HIP events on the launch stream (emcid_profile_*); the class with the most time is reported with its
+ALGORITHMIC flops per launch (SURVEY.md §8d counts); `kernel_classes` lists all of them.
 `cpu_baseline`: the oracle (op-for-op CPU port of the reference path) timed on the host cores on a
 100-concept sample of the same workload, rank 0, N == 1 only; the same run yields `dw_max_abs_err`.
 """
@@ -117,38 +119,62 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    prof_cls = "chol_trail"
-    hip.profile_enable([prof_cls])
-    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    prof = hip.profile_collect()
-    hip.profile_enable([])
     check_info(plan)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-
     value = args.concepts * args.steps / elapsed
-    d = 3072
-    # algorithmic flops of the dominant kernel class per launch: the right-looking trailing updates of one
-    # Cholesky sum to d^3/3 minus the leaf+panel share; per launch = that / (d/128 - 1) launches.
-    nb = d // 128
-    trail_flops_per_layer = sum((d - (j + 1) * 128) ** 2 * 128 for j in range(nb - 1))   # SYRK count m^2 * k
-    ms, launches = prof.get(prof_cls, (0.0, 0))
+
+    # ---- roofline: the same K steps once more with every MFMA kernel class of the solve bracketed by HIP events
+    # on the launch stream (emcid_profile_*; the graph replay is bypassed while events are recorded, the kernels and
+    # their arguments are identical).  The class with the most time is reported. --------------------------------------
+    mfma_classes = ["assemble", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w", "inv_build"]
+    hip.profile_enable(mfma_classes + ["chol_leaf"])
+    for _ in range(args.steps):
+        step()
+    sync()
+    prof = hip.profile_collect()
+    hip.profile_enable([])
+    d, h = 3072, 768
+    n_rows = (lambda b: b[1] - b[0])(shard.bounds(args.concepts)) if world > 1 else args.concepts
+    nbk, nob = d // 128, d // 512
+    per_layer_flops = {   # ALGORITHMIC flops of one edited layer per class (SURVEY.md §8d counts)
+        "assemble": args.concepts * d * d,                                              # SYRK  N d^2
+        "chol_trail": sum((d - (j + 1) * 128) ** 2 * 128 for j in range(nbk - 1)),     # SYRK-count trailing updates
+        "chol_panel": sum((d - (j + 1) * 128) * 128 * 128 for j in range(nbk - 1)),    # triangular panel solves
+        # blocked TRSM, both directions; diag + update sum to the algorithmic 2 N d^2 (triangular count)
+        "trsm_update": 2 * (2 * n_rows * 512 * sum(d - (J + 1) * 512 for J in range(nob))),
+        "trsm_diag": 2 * (n_rows * nob * 512 * 512),
+        "delta_w": 2 * h * n_rows * d,
+    }
+    launches_per_layer = {"assemble": 1, "chol_trail": nbk - 1, "chol_panel": nbk - 1, "trsm_update": 2 * (nob - 1),
+                          "trsm_diag": 2 * nob, "delta_w": 1}
+    classes = {c: {"ms_per_step": prof[c][0] / args.steps, "launches_per_step": prof[c][1] / args.steps}
+               for c in prof}
     roofline = None
-    if launches:
-        flops_per_launch = trail_flops_per_layer / (nb - 1)
+    cands = [c for c in per_layer_flops if c in prof and prof[c][1]]
+    if cands:
+        top = max(cands, key=lambda c: prof[c][0])
+        ms, launches = prof[top]
         avg_s = ms * 1e-3 / launches
+        flops_per_launch = per_layer_flops[top] / launches_per_layer[top]
         achieved = flops_per_launch / avg_s / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_f64_kernel<KC,KC,64,64,16,EpiAxpby> (Cholesky trailing update)",
-                    "achieved": achieved, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / F64_MFMA_PEAK_TFLOPS, "traffic": None,
-                    "avg_launch_us": avg_s * 1e6, "launches": launches}
+        names = {"assemble": "gemm_f64_kernel<!KC,!KC,128,128,16,2,4,EpiAssemble> (A = lam C' + K^T K, SYRK)",
+                 "chol_trail": "gemm_f64_kernel<KC,KC,64,64,16,2,2,EpiAxpby> launched as Cholesky trailing update",
+                 "chol_panel": "gemm_f64_kernel<KC,KC,64,64,16,2,2,EpiAxpby> launched as Cholesky panel solve",
+                 "trsm_update": "gemm_f64_kernel<KC,*,*,*,16,EpiAxpby> launched as rank-512 TRSM update",
+                 "trsm_diag": "gemm_f64_kernel<KC,*,64,64,16,2,2,EpiAxpby> launched as TRSM diagonal-block multiply",
+                 "delta_w": "gemm_f64_kernel<!KC,!KC,64,64,16,2,2,EpiDeltaW> (dW = R^T X)"}
+        roofline = {"bound": "mfma", "kernel": names[top], "class": top, "achieved": achieved,
+                    "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F64_MFMA_PEAK_TFLOPS,
+                    "traffic": None, "avg_launch_us": avg_s * 1e6, "launches": launches,
+                    "flops_per_launch": flops_per_launch}
 
     out = {
         "metric": "concept-edits/sec (1 000-concept batch, SD-v1.4)", "value": value, "unit": "concept-edits/s",
@@ -163,6 +189,7 @@ def main():
                    "parallelism": f"concept-shard x{world}"},
         "host_prepare_ms": host_prepare_ms,
         "roofline": roofline,
+        "kernel_classes": classes,
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

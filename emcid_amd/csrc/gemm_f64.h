@@ -115,6 +115,9 @@ struct GemmShape {
     int lower_only;  // skip output tiles that lie entirely above the diagonal (SYRK / Cholesky updates)
     int64_t sA = 0, sB = 0;  // element strides between the problems of a batch (blockIdx.z)
     int batch = 1;
+    // triangular B operand (the inverted diagonal blocks): 1 = B(k, n) is zero for k > n, 2 = zero for k < n.
+    // The K loop of an output tile then only covers the k range that can contribute.
+    int tri = 0;
 };
 
 // WGM x WGN waves per workgroup; each wave owns a (BM/WGM) x (BN/WGN) sub-tile.
@@ -146,18 +149,22 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Ep
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
+    // K tiles [t0, t1) that can contribute to this output tile
+    int t0 = 0, t1 = (p.K + BK - 1) / BK;
+    if (p.tri == 1) { const int ke = min(p.K, n0 + BN); t1 = (ke + BK - 1) / BK; }
+    else if (p.tri == 2) { t0 = min(n0, p.K) / BK; }
+
     v2d ra[TA::NVEC / NT], rb[TB::NVEC / NT];
-    load_tile<KCA, BM, BK, NT>(ra, p.A, p.lda, m0, p.M, 0, p.K, tid);
-    load_tile<KCB, BN, BK, NT>(rb, p.B, p.ldb, n0, p.N, 0, p.K, tid);
+    load_tile<KCA, BM, BK, NT>(ra, p.A, p.lda, m0, p.M, t0 * BK, p.K, tid);
+    load_tile<KCB, BN, BK, NT>(rb, p.B, p.ldb, n0, p.N, t0 * BK, p.K, tid);
     store_tile<KCA, BM, BK, NT>(ra, smem, tid);
     store_tile<KCB, BN, BK, NT>(rb, smem + TA::SIZE, tid);
     __syncthreads();
 
-    const int T = (p.K + BK - 1) / BK;
-    for (int t = 0; t < T; ++t) {
-        const double* As = smem + (t & 1) * STAGE;
+    for (int t = t0; t < t1; ++t) {
+        const double* As = smem + ((t - t0) & 1) * STAGE;
         const double* Bs = As + TA::SIZE;
-        const bool more = (t + 1 < T);
+        const bool more = (t + 1 < t1);
         if (more) {
             load_tile<KCA, BM, BK, NT>(ra, p.A, p.lda, m0, p.M, (t + 1) * BK, p.K, tid);
             load_tile<KCB, BN, BK, NT>(rb, p.B, p.ldb, n0, p.N, (t + 1) * BK, p.K, tid);
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Ep
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e][i], b[e][j], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            double* An = smem + ((t + 1) & 1) * STAGE;
+            double* An = smem + ((t + 1 - t0) & 1) * STAGE;
             store_tile<KCA, BM, BK, NT>(ra, An, tid);
             store_tile<KCB, BN, BK, NT>(rb, An + TA::SIZE, tid);
         }
@@ -242,17 +249,30 @@ struct EpiDeltaW {
 
 template <bool KCA, bool KCB, class Epi>
 inline void launch_gemm_f64(const GemmShape& p, const Epi& epi, hipStream_t stream, int force_cfg = -1) {
-    // big tiles when they still fill the chip, else 64x64 tiles (4x the workgroups).
-    const int64_t tm = (p.M + 127) / 128, tn = (p.N + 127) / 128;
-    int64_t big_tiles = p.lower_only ? tm * (tm + 1) / 2 : tm * tn;
+    // cfg 0: 128x128 tile, 8 waves  — when that many tiles still fill the chip
+    // cfg 1: 64x64 tile, 4 waves    — 4x the workgroups
+    // cfg 2: 32x64 tile, 4 waves    — skinny problems (M ~ number of concepts); needs a K-contiguous A operand
+    auto tiles = [&](int64_t b) {   // output tiles of edge b that are actually computed
+        const int64_t tm = (p.M + b - 1) / b, tn = (p.N + b - 1) / b;
+        const int64_t skipped = p.lower_only ? (tn < tm ? tn : tm) * ((tn < tm ? tn : tm) - 1) / 2 : 0;
+        return (tm * tn - skipped) * p.batch;
+    };
+    const int64_t big_tiles = tiles(128), mid_tiles = tiles(64);
     int cfg = (big_tiles >= 224) ? 0 : 1;
+    if (cfg == 1 && KCA && mid_tiles < 256) cfg = 2;
     if (force_cfg >= 0) cfg = force_cfg;
+    if (cfg == 2 && !KCA) cfg = 1;
     if (cfg == 0) {
         dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, p.batch);
         hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 128, 128, 16, 2, 4, Epi>), grid, dim3(512), 0, stream, p, epi);
-    } else {
+    } else if (cfg == 1) {
         dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, p.batch);
         hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 64, 64, 16, 2, 2, Epi>), grid, dim3(256), 0, stream, p, epi);
+    } else {
+        if constexpr (KCA) {
+            dim3 grid((p.N + 63) / 64, (p.M + 31) / 32, p.batch);
+            hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 32, 64, 16, 2, 2, Epi>), grid, dim3(256), 0, stream, p, epi);
+        }
     }
 }
 

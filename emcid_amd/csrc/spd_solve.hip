@@ -324,10 +324,10 @@ static inline const double* inv_block(const double* invw, int64_t J) { return in
 static void build_block_inverses(const double* L, int64_t dp, int64_t lda, double* invw, hipStream_t st) {
     const int64_t nob = (dp + OB - 1) / OB, nfull = dp / OB, rem = dp % OB;
     double* tmp = invw + nob * (int64_t)OB * OB;
-    auto product = [&](const double* A, int64_t ldA, int64_t sA, bool a_dummy, const double* B, int64_t ldB, int64_t sB,
+    auto product = [&](const double* A, int64_t ldA, int64_t sA, bool b_lower, const double* B, int64_t ldB, int64_t sB,
                        double* C, int64_t ldC, int64_t sC, int M, int N, int K, double alpha, int cnt) {
-        (void)a_dummy;
         GemmShape p{A, ldA, B, ldB, M, N, K, 0, sA, sB, cnt};
+        p.tri = b_lower ? 2 : 0;   // B stored [k][n] and lower triangular: zero for k < n
         launch_gemm_f64<true, false>(p, EpiAxpby{C, ldC, alpha, 0.0, sC}, st, 1);
     };
     ScopedProf sp(KC_INV_BUILD, st);
@@ -341,7 +341,7 @@ static void build_block_inverses(const double* L, int64_t dp, int64_t lda, doubl
             double* X = inv_block(invw, J0) + ((2 * u + 1) * NB) * (int64_t)OB + 2 * u * NB;
             double* T = tmp + J0 * sT;
             product(Cb, lda, sL, true, Ai, OB, sI, T, TB, sT, NB, NB, NB, 1.0, cnt);      // T = C A^-1
-            product(Bi, OB, sI, true, T, TB, sT, X, OB, sI, NB, NB, NB, -1.0, cnt);       // X = -B^-1 T
+            product(Bi, OB, sI, false, T, TB, sT, X, OB, sI, NB, NB, NB, -1.0, cnt);      // X = -B^-1 T
         };
         if (nfull > 0) level_a(0, (int)nfull);
         if (rem >= (u + 1) * 2 * NB) level_a(nfull, 1);
@@ -354,7 +354,7 @@ static void build_block_inverses(const double* L, int64_t dp, int64_t lda, doubl
         double* X = inv_block(invw, J0) + (2 * NB) * (int64_t)OB;
         double* T = tmp + J0 * sT;
         product(Cb, lda, sL, true, Ai, OB, sI, T, TB, sT, mrows, 2 * NB, 2 * NB, 1.0, cnt);
-        product(Bi, OB, sI, true, T, TB, sT, X, OB, sI, mrows, 2 * NB, mrows, -1.0, cnt);
+        product(Bi, OB, sI, false, T, TB, sT, X, OB, sI, mrows, 2 * NB, mrows, -1.0, cnt);
     };
     if (nfull > 0) level_b(0, (int)nfull, 2 * NB);
     if (rem > 2 * NB) level_b(nfull, 1, (int)(rem - 2 * NB));
@@ -376,30 +376,46 @@ static int env_flag(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-// Right-looking blocked Cholesky, NB = 128, single stream: leaf -> panel -> trailing update per 128-column block.
+// Two-level blocked Cholesky on one stream.  Outer blocks of OB = 512 columns are brought up to date LEFT-looking
+// (one GEMM against all previous columns, contraction depth = their count, so the Schur complement is read and
+// written once per 512 columns instead of once per 128); inside an outer block the classic right-looking
+// leaf -> panel -> trailing-update runs with NB = 128, its updates confined to the block's own <= 384 remaining columns.
 static int cholesky_serial(double* A, double* L, int64_t dp, int64_t lda, double* invw, int* info, hipStream_t st) {
-    const int nb = (int)(dp / NB);
     hipLaunchKernelGGL(zero_f64_kernel, dim3(1024), dim3(256), 0, st, invw, inv_doubles(dp));
-    for (int j = 0; j < nb; ++j) {
-        const int64_t o = (int64_t)j * NB;
-        double* inv = inv_block(invw, j / (OB / NB)) + ((j % (OB / NB)) * NB) * (int64_t)(OB + 1);
-        {
-            ScopedProf sp(KC_CHOL_LEAF, st);
-            hipLaunchKernelGGL(chol_leaf_kernel, dim3(1), dim3(LEAF_T), 0, st, A + o * lda + o, lda, L + o * lda + o, lda,
-                               inv, (int64_t)OB, info, (int)o);
-        }
-        const int m = (int)(dp - o - NB);
-        if (m == 0) break;
-        GemmShape ps{A + (o + NB) * lda + o, lda, inv, OB, m, NB, NB, 0};
-        {
-            ScopedProf sp(KC_CHOL_PANEL, st);
-            launch_gemm_f64<true, true>(ps, EpiAxpby{L + (o + NB) * lda + o, lda, 1.0, 0.0}, st, 1);
-        }
-        const double* L21 = L + (o + NB) * lda + o;
-        GemmShape ts{L21, lda, L21, lda, m, m, NB, 1};
-        {
+    const int nob = (int)((dp + OB - 1) / OB);
+    for (int J = 0; J < nob; ++J) {
+        const int64_t c0 = (int64_t)J * OB;
+        const int w = (int)((dp - c0) < OB ? (dp - c0) : OB);
+        if (J > 0) {
+            // A[c0:, c0:c0+w] -= L[c0:, 0:c0] L[c0:c0+w, 0:c0]^T   (its top-left corner is on the diagonal)
+            const double* Lr = L + c0 * lda;
+            GemmShape g{Lr, lda, Lr, lda, (int)(dp - c0), w, (int)c0, 1};
             ScopedProf sp(KC_CHOL_TRAIL, st);
-            launch_gemm_f64<true, true>(ts, EpiAxpby{A + (o + NB) * lda + (o + NB), lda, -1.0, 1.0}, st, 1);
+            launch_gemm_f64<true, true>(g, EpiAxpby{A + c0 * lda + c0, lda, -1.0, 1.0}, st);
+        }
+        for (int jj = 0; jj < w / NB; ++jj) {
+            const int64_t o = c0 + (int64_t)jj * NB;
+            double* inv = inv_block(invw, J) + (jj * NB) * (int64_t)(OB + 1);
+            {
+                ScopedProf sp(KC_CHOL_LEAF, st);
+                hipLaunchKernelGGL(chol_leaf_kernel, dim3(1), dim3(LEAF_T), 0, st, A + o * lda + o, lda, L + o * lda + o,
+                                   lda, inv, (int64_t)OB, info, (int)o);
+            }
+            const int m = (int)(dp - o - NB);
+            if (m == 0) break;
+            GemmShape ps{A + (o + NB) * lda + o, lda, inv, OB, m, NB, NB, 0};
+            ps.tri = 1;   // inv(L11) is lower triangular: B(k, n) = inv[n][k] vanishes for k > n
+            {
+                ScopedProf sp(KC_CHOL_PANEL, st);
+                launch_gemm_f64<true, true>(ps, EpiAxpby{L + (o + NB) * lda + o, lda, 1.0, 0.0}, st);
+            }
+            const int wi = (int)(c0 + w - (o + NB));   // columns of this outer block still to the right
+            if (wi > 0) {
+                const double* L21 = L + (o + NB) * lda + o;
+                GemmShape ts{L21, lda, L21, lda, m, wi, NB, 1};
+                ScopedProf sp(KC_CHOL_INNER, st);
+                launch_gemm_f64<true, true>(ts, EpiAxpby{A + (o + NB) * lda + (o + NB), lda, -1.0, 1.0}, st);
+            }
         }
     }
     build_block_inverses(L, dp, lda, invw, st);
@@ -424,6 +440,7 @@ static int cholesky_solve_impl(const double* L, int64_t dp, int64_t lda, const d
         const int w = (int)((dp - c) < OB ? (dp - c) : OB);
         const double* inv = inv_block(invw, J);
         GemmShape a{Bt + c, ldb, inv, OB, M, w, w, 0};
+        a.tri = 1;   // B(k, n) = inv[n][k], zero for k > n
         {
             ScopedProf sp(KC_TRSM_DIAG, st);
             launch_gemm_f64<true, true>(a, EpiAxpby{Yt + c, ldb, 1.0, 0.0}, st);
@@ -440,6 +457,7 @@ static int cholesky_solve_impl(const double* L, int64_t dp, int64_t lda, const d
         const int w = (int)((dp - c) < OB ? (dp - c) : OB);
         const double* inv = inv_block(invw, J);
         GemmShape a{Yt + c, ldb, inv, OB, M, w, w, 0};
+        a.tri = 2;   // B(k, n) = inv[k][n], zero for k < n
         {
             ScopedProf sp(KC_TRSM_DIAG, st);
             launch_gemm_f64<true, false>(a, EpiAxpby{Bt + c, ldb, 1.0, 0.0}, st);

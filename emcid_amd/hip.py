@@ -23,7 +23,7 @@ EXPORTS = [
     "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32", "emcid_tree_attention_f32",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
-                "gram", "gather", "dgemm", "misc", "inv_build"]
+                "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner"]
 
 ABI_VERSION = 1
 NB = 128      # Cholesky block (csrc/common.h)
