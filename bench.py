@@ -134,7 +134,7 @@ def main():
     # ---- roofline: the same K steps once more with every MFMA kernel class of the solve bracketed by HIP events
     # on the launch stream (emcid_profile_*; the graph replay is bypassed while events are recorded, the kernels and
     # their arguments are identical).  The class with the most time is reported. --------------------------------------
-    mfma_classes = ["assemble", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w", "inv_build"]
+    mfma_classes = ["assemble", "chol_panel", "chol_trail", "chol_inner", "trsm_diag", "trsm_update", "delta_w", "inv_build"]
     hip.profile_enable(mfma_classes + ["chol_leaf"])
     for _ in range(args.steps):
         step()
@@ -146,14 +146,19 @@ def main():
     nbk, nob = d // 128, d // 512
     per_layer_flops = {   # ALGORITHMIC flops of one edited layer per class (SURVEY.md §8d counts)
         "assemble": args.concepts * d * d,                                              # SYRK  N d^2
-        "chol_trail": sum((d - (j + 1) * 128) ** 2 * 128 for j in range(nbk - 1)),     # SYRK-count trailing updates
+        # two-level trailing updates (SYRK count): inner ones stay inside a 512-column block, the left-looking
+        # ones bring a whole block column up to date against all previous columns
+        "chol_inner": sum(((d - (j + 1) * 128) * w - w * w // 2) * 128
+                          for j in range(nbk - 1) for w in [(j // 4 + 1) * 512 - (j + 1) * 128] if w > 0),
+        "chol_trail": sum(((d - J * 512) * 512 - 512 * 512 // 2) * (J * 512) for J in range(1, nob)),
         "chol_panel": sum((d - (j + 1) * 128) * 128 * 128 for j in range(nbk - 1)),    # triangular panel solves
         # blocked TRSM, both directions; diag + update sum to the algorithmic 2 N d^2 (triangular count)
         "trsm_update": 2 * (2 * n_rows * 512 * sum(d - (J + 1) * 512 for J in range(nob))),
         "trsm_diag": 2 * (n_rows * nob * 512 * 512),
         "delta_w": 2 * h * n_rows * d,
     }
-    launches_per_layer = {"assemble": 1, "chol_trail": nbk - 1, "chol_panel": nbk - 1, "trsm_update": 2 * (nob - 1),
+    launches_per_layer = {"assemble": 1, "chol_trail": nob - 1, "chol_inner": nbk - nob, "chol_panel": nbk - 1,
+                          "trsm_update": 2 * (nob - 1),
                           "trsm_diag": 2 * nob, "delta_w": 1}
     classes = {c: {"ms_per_step": prof[c][0] / args.steps, "launches_per_step": prof[c][1] / args.steps}
                for c in prof}
@@ -166,7 +171,8 @@ def main():
         flops_per_launch = per_layer_flops[top] / launches_per_layer[top]
         achieved = flops_per_launch / avg_s / 1e12
         names = {"assemble": "gemm_f64_kernel<!KC,!KC,128,128,16,2,4,EpiAssemble> (A = lam C' + K^T K, SYRK)",
-                 "chol_trail": "gemm_f64_kernel<KC,KC,64,64,16,2,2,EpiAxpby> launched as Cholesky trailing update",
+                 "chol_trail": "gemm_f64_kernel<KC,KC,64,64,16,2,2,EpiAxpby> launched as left-looking Cholesky block-column update",
+                 "chol_inner": "gemm_f64_kernel<KC,KC,*,64,16,2,2,EpiAxpby> launched as in-block Cholesky trailing update",
                  "chol_panel": "gemm_f64_kernel<KC,KC,64,64,16,2,2,EpiAxpby> launched as Cholesky panel solve",
                  "trsm_update": "gemm_f64_kernel<KC,*,*,*,16,EpiAxpby> launched as rank-512 TRSM update",
                  "trsm_diag": "gemm_f64_kernel<KC,*,64,64,16,2,2,EpiAxpby> launched as TRSM diagonal-block multiply",

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void apply_u_kernel(const double* __restrict__
 // LDS image S[128][130]: row stride 130 doubles (= 4*65 dwords) makes the k-contiguous MFMA fragment
 // reads (16 rows x 2 k) hit 64 distinct banks.
 
-constexpr int LEAF_T = 256;
+constexpr int LEAF_T = 512;   // 8 waves: wave 0 factors the diagonal sub-blocks, all 8 run the MFMA phases
 constexpr int SB = 32;        // register-factored diagonal sub-block
 constexpr int SLD = NB + 2;   // 130
 constexpr int ZLD = 48;       // temp tiles [32][48]: k-row stride == 32 (mod 64) dwords
@@ -131,24 +131,33 @@ __device__ __forceinline__ double rsqrt_f64(double d) {
 // one 16x16 output tile, K deep, operands fetched through address functors (doubles in LDS)
 template <int K, class FA, class FB>
 __device__ __forceinline__ v4d leaf_tile(const double* lds, FA fa, FB fb, int l15, int l4) {
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};   // two chains: dependent f64 MFMAs do not issue back to back
 #pragma unroll
-    for (int kk = 0; kk < K / 4; ++kk) {
-        const double a = lds[fa(l15, kk * 4 + l4)];
-        const double b = lds[fb(kk * 4 + l4, l15)];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    for (int kk = 0; kk < K / 4; kk += 2) {
+        const double a0 = lds[fa(l15, kk * 4 + l4)];
+        const double b0 = lds[fb(kk * 4 + l4, l15)];
+        const double a1 = lds[fa(l15, kk * 4 + 4 + l4)];
+        const double b1 = lds[fb(kk * 4 + 4 + l4, l15)];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
     }
-    return acc;
+    return acc0 + acc1;
 }
 
 __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restrict__ A, int64_t lda, double* __restrict__ L,
                                                             int64_t ldl, double* __restrict__ inv, int64_t ldinv, int* info,
-                                                            int col0) {
+                                                            int col0, long long* dbg = nullptr) {
     __shared__ __attribute__((aligned(16))) double lds[NB * SLD + 2 * SB * ZLD];
     double* S = lds;
     constexpr int ZOFF = NB * SLD;          // two [32][48] temporaries behind S
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
+    int nstamp = 0;
+    auto stamp = [&]() {   // diagnostic only (dbg != nullptr): shader-clock stamps of wave 0 at phase boundaries
+        if (dbg && tid == 0) dbg[nstamp] = (long long)__builtin_amdgcn_s_memtime();
+        ++nstamp;
+    };
+    stamp();
 
     {
         // 128 x 128 block = 8192 16-byte vectors, 32 per thread, fetched in batches of 8 independent loads
@@ -172,6 +181,7 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
         }
     }
     __syncthreads();
+    stamp();
 
     int badcol = -1;   // first non-positive pivot seen by wave 0 (uniform)
 #pragma unroll 1
@@ -218,6 +228,7 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
             }
         }
         __syncthreads();
+        stamp();
         if (mb == 0) break;
 
         // ---- phase B: P = A_below * Z (rows R0.., 32 columns), in place; one wave owns a 16-row block ---------
@@ -238,6 +249,7 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
                 }
         }
         __syncthreads();
+        stamp();
 
         // ---- phase C: trailing update T -= P P^T on the lower 16x16 tiles ---------------------------------------
         const int ntiles = mb * (mb + 1) / 2;
@@ -252,25 +264,24 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
             for (int q = 0; q < 4; ++q) S[(ri + l4 + 4 * q) * SLD + rj + l15] -= acc[q];
         }
         __syncthreads();
+        stamp();
     }
     if (wave == 0 && lane == 0 && badcol >= 0) atomicCAS(info, 0, col0 + badcol + 1);  // not SPD (or NaN pivot)
 
     // ---- inverse assembly, level 1: the two 64-blocks.  X = -B (C A), A/B = 32x32 inverses, C = L block ------
     {
-        const int q = wave >> 1;               // waves 0,1 -> block 0 ; waves 2,3 -> block 1
-        const int b = 64 * q;
-        const int toff = ZOFF + q * SB * ZLD;
-        // T1 = C A  (2x2 tiles, two per wave)
-        for (int t = (wave & 1); t < 4; t += 2) {
-            const int ti = t >> 1, tj = t & 1;
+        constexpr int NW = LEAF_T / 64;
+        // 8 tiles: (block q, tile ti, tj)
+        for (int t = wave; t < 8; t += NW) {     // T1 = C A
+            const int q = t >> 2, ti = (t >> 1) & 1, tj = t & 1, b = 64 * q, toff = ZOFF + q * SB * ZLD;
             const v4d acc = leaf_tile<SB>(lds, [&](int i, int k) { return (b + 32 + ti * 16 + i) * SLD + b + k; },
                                           [&](int k, int j) { return (b + k) * SLD + b + tj * 16 + j; }, l15, l4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) lds[toff + (ti * 16 + l4 + 4 * r) * ZLD + tj * 16 + l15] = acc[r];
         }
         __syncthreads();
-        for (int t = (wave & 1); t < 4; t += 2) {
-            const int ti = t >> 1, tj = t & 1;
+        for (int t = wave; t < 8; t += NW) {     // X = -B T1, written over C
+            const int q = t >> 2, ti = (t >> 1) & 1, tj = t & 1, b = 64 * q, toff = ZOFF + q * SB * ZLD;
             const v4d acc = leaf_tile<SB>(lds, [&](int i, int k) { return (b + 32 + ti * 16 + i) * SLD + b + 32 + k; },
                                           [&](int k, int j) { return toff + k * ZLD + tj * 16 + j; }, l15, l4);
 #pragma unroll
@@ -278,6 +289,7 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
         }
         __syncthreads();
     }
+    stamp();
     // ---- level 2: X64 = -B64 (C64 A64); T lives in the unused upper-right block S[0:64][64:128] ----------------
     for (int t = wave; t < 16; t += LEAF_T / 64) {
         const int ti = t >> 2, tj = t & 3;
@@ -288,7 +300,7 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
     }
     __syncthreads();
     {
-        v4d acc[4];
+        v4d acc[(16 + LEAF_T / 64 - 1) / (LEAF_T / 64)];
         int n = 0;
         for (int t = wave; t < 16; t += LEAF_T / 64, ++n) {
             const int ti = t >> 2, tj = t & 3;
@@ -304,6 +316,7 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
         }
     }
     __syncthreads();
+    stamp();
     for (int v = tid; v < NB * NB / 2; v += LEAF_T) {
         const int i = v / (NB / 2), j = 2 * (v % (NB / 2));
         v2d x = *reinterpret_cast<const v2d*>(S + i * SLD + j);
@@ -311,6 +324,8 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
         if (j + 1 > i) x[1] = 0.0;
         *reinterpret_cast<v2d*>(inv + (int64_t)i * ldinv + j) = x;
     }
+    __syncthreads();
+    stamp();
 }
 
 // ---- host orchestration -------------------------------------------------------------------------------
@@ -619,6 +634,15 @@ int emcid_assemble_spd_f64(const float* C, int64_t ldc, const double* Kt64, int6
         ScopedProf sp(KC_ASSEMBLE, (hipStream_t)stream);
         launch_gemm_f64<false, false>(p, EpiAssemble{C, ldc, lam, cw, A, lda, (int)d}, (hipStream_t)stream);
     }
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+/* diagnostic: one leaf on a 128x128 SPD block with phase stamps (shader clock ticks) written to stamps_dev[32] */
+int emcid_debug_leaf_stamps(const double* A, double* L, double* inv, int* info_dev, long long* stamps_dev, void* stream) {
+    EMCID_CHECK_ARG(A && L && inv && info_dev && stamps_dev);
+    hipLaunchKernelGGL(chol_leaf_kernel, dim3(1), dim3(LEAF_T), 0, (hipStream_t)stream, A, (int64_t)NB, L, (int64_t)NB, inv,
+                       (int64_t)NB, info_dev, 0, stamps_dev);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }

@@ -20,7 +20,7 @@ EXPORTS = [
     "emcid_gather_mean_f32", "emcid_edit_workspace_bytes", "emcid_edit_layer_f64", "emcid_assemble_spd_f64",
     "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_axpy_f32",
     "emcid_profile_enable", "emcid_profile_collect", "emcid_attention_f32", "emcid_edit_layer_shard_f64",
-    "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32", "emcid_tree_attention_f32",
+    "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32", "emcid_tree_attention_f32", "emcid_debug_leaf_stamps",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner"]
@@ -62,6 +62,7 @@ def load():
         "emcid_assemble_spd_f64": (i32, [p, i64, p, i64, i64, i64, f64, f32, p, i64, p]),
         "emcid_cholesky_f64": (i32, [p, p, i64, i64, p, p, p]),
         "emcid_inverse_workspace_doubles": (i64, [i64]),
+        "emcid_debug_leaf_stamps": (i32, [p, p, p, p, p, p]),
         "emcid_cholesky_solve_f64": (i32, [p, i64, i64, p, p, p, i64, i64, p]),
         "emcid_delta_w_f64": (i32, [p, i64, p, i64, i64, i64, i64, p, p, i64, p, p, p]),
         "emcid_dgemm_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, p]),

@@ -143,6 +143,9 @@ int emcid_assemble_spd_f64(const float* C, int64_t ldc, const double* Kt64, int6
  * triangular solves are MFMA GEMMs against them).
  * replaces the getrf half of torch.linalg.solve (:1045). */
 int64_t emcid_inverse_workspace_doubles(int64_t dp);
+/* Diagnostic: runs the diagonal leaf on one contiguous 128x128 SPD block and writes shader-clock stamps of its
+ * phase boundaries to stamps_dev[32] (load | per panel: factor, panel solve, trailing | inverse levels | store). */
+int emcid_debug_leaf_stamps(const double* A, double* L, double* inv, int* info_dev, long long* stamps_dev, void* stream);
 int emcid_cholesky_f64(double* A, double* L, int64_t dp, int64_t lda, double* invdiag, int* info_dev, void* stream);
 /* Bt[Np, dp] := Bt A^{-1} given the factor from emcid_cholesky_f64; Yt is [Np, dp] scratch.
  * replaces the getrs half of torch.linalg.solve (:1045-1048). */
