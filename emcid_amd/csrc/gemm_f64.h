@@ -25,6 +25,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace emcid {
 
@@ -118,14 +119,18 @@ struct GemmShape {
     // triangular B operand (the inverted diagonal blocks): 1 = B(k, n) is zero for k > n, 2 = zero for k < n.
     // The K loop of an output tile then only covers the k range that can contribute.
     int tri = 0;
+    // split the K range of every output tile over ksplit workgroups (blockIdx.z = batch * ksplit + split); only for
+    // epilogues that ACCUMULATE into C (EpiAxpby with beta == 1), which then add their partial with f64 atomics
+    int ksplit = 1;
 };
 
 // WGM x WGN waves per workgroup; each wave owns a (BM/WGM) x (BN/WGN) sub-tile.
 template <bool KCA, bool KCB, int BM, int BN, int BK, int WGM, int WGN, class Epi>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Epi epi) {
-    p.A += (int64_t)blockIdx.z * p.sA;
-    p.B += (int64_t)blockIdx.z * p.sB;
-    epi.batch(blockIdx.z);
+    const int zb = blockIdx.z / p.ksplit, zs = blockIdx.z % p.ksplit;
+    p.A += (int64_t)zb * p.sA;
+    p.B += (int64_t)zb * p.sB;
+    epi.batch(zb);
     constexpr int NT = WGM * WGN * 64;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 16, NI = WN / 16;
@@ -153,6 +158,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Ep
     int t0 = 0, t1 = (p.K + BK - 1) / BK;
     if (p.tri == 1) { const int ke = min(p.K, n0 + BN); t1 = (ke + BK - 1) / BK; }
     else if (p.tri == 2) { t0 = min(n0, p.K) / BK; }
+    if (p.ksplit > 1) {
+        const int per = (t1 - t0 + p.ksplit - 1) / p.ksplit;
+        t0 += zs * per;
+        t1 = min(t1, t0 + per);
+        if (t0 >= t1) return;
+    }
 
     v2d ra[TA::NVEC / NT], rb[TB::NVEC / NT];
     load_tile<KCA, BM, BK, NT>(ra, p.A, p.lda, m0, p.M, t0 * BK, p.K, tid);
@@ -206,11 +217,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Ep
 
 // C = alpha * D + beta * C
 struct EpiAxpby {
-    double* C; int64_t ldc; double alpha, beta; int64_t sC = 0;
+    double* C; int64_t ldc; double alpha, beta; int64_t sC = 0; int atomic = 0;
     __device__ __forceinline__ void batch(int z) { C += (int64_t)z * sC; }
     __device__ __forceinline__ void operator()(int m, int n, double v) const {
         double* c = C + (int64_t)m * ldc + n;
-        *c = (beta != 0.0) ? alpha * v + beta * *c : alpha * v;
+        if (atomic) unsafeAtomicAdd(c, alpha * v);   // split-K partial of C += alpha * D (global_atomic_add_f64)
+        else *c = (beta != 0.0) ? alpha * v + beta * *c : alpha * v;
     }
 };
 
@@ -247,30 +259,50 @@ struct EpiDeltaW {
 
 // ---- launcher ----------------------------------------------------------------------------------
 
+template <class Epi> inline bool epi_accumulates(const Epi&) { return false; }
+inline bool epi_accumulates(const EpiAxpby& e) { return e.beta == 1.0; }
+template <class Epi> inline void epi_set_atomic(Epi&) {}
+inline void epi_set_atomic(EpiAxpby& e) { e.atomic = 1; }
+
 template <bool KCA, bool KCB, class Epi>
-inline void launch_gemm_f64(const GemmShape& p, const Epi& epi, hipStream_t stream, int force_cfg = -1) {
+inline void launch_gemm_f64(GemmShape p, Epi epi, hipStream_t stream, int force_cfg = -1) {
     // cfg 0: 128x128 tile, 8 waves  — when that many tiles still fill the chip
     // cfg 1: 64x64 tile, 4 waves    — 4x the workgroups
     // cfg 2: 32x64 tile, 4 waves    — skinny problems (M ~ number of concepts); needs a K-contiguous A operand
-    auto tiles = [&](int64_t b) {   // output tiles of edge b that are actually computed
-        const int64_t tm = (p.M + b - 1) / b, tn = (p.N + b - 1) / b;
-        const int64_t skipped = p.lower_only ? (tn < tm ? tn : tm) * ((tn < tm ? tn : tm) - 1) / 2 : 0;
+    auto tiles = [&](int64_t bm, int64_t bn) {   // output tiles that are actually computed (estimate for lower_only)
+        const int64_t tm = (p.M + bm - 1) / bm, tn = (p.N + bn - 1) / bn;
+        const int64_t sq = tn * bn < tm * bm ? tn * bn : tm * bm;          // edge of the square part on the diagonal
+        const int64_t skipped = p.lower_only ? (sq / bm) * (sq / bn) / 2 : 0;
         return (tm * tn - skipped) * p.batch;
     };
-    const int64_t big_tiles = tiles(128), mid_tiles = tiles(64);
-    int cfg = (big_tiles >= 224) ? 0 : 1;
-    if (cfg == 1 && KCA && mid_tiles < 256) cfg = 2;
+    const int64_t big_tiles = tiles(128, 128), mid_tiles = tiles(64, 64);
+    // measured on the M ~ 1000 solve shapes (scripts/mb_shapes.py): 32x64 beats 64x64 whenever 128x128 cannot fill the chip
+    int cfg = (big_tiles >= 224) ? 0 : (KCA ? 2 : 1);
     if (force_cfg >= 0) cfg = force_cfg;
+    static const int env_cfg = [] { const char* v = getenv("EMCID_GEMM_CFG"); return v ? atoi(v) : -1; }();      // experiments
+    static const int env_split = [] { const char* v = getenv("EMCID_GEMM_KSPLIT"); return v ? atoi(v) : -1; }();
+    if (env_cfg >= 0) cfg = env_cfg;
     if (cfg == 2 && !KCA) cfg = 1;
+    // too few workgroups to hide the global->LDS latency of a shallow tile: split K (accumulating epilogues only)
+    const int64_t wgs = cfg == 0 ? big_tiles : cfg == 1 ? mid_tiles : tiles(32, 64);
+    const int ktiles = (p.K + 15) / 16;
+    if (p.ksplit == 1 && epi_accumulates(epi) && cfg != 0 && wgs < 512 && ktiles >= 16) {
+        const int64_t want = (768 + wgs - 1) / wgs, cap = ktiles / 8;
+        p.ksplit = (int)(want < cap ? want : cap);
+        if (p.ksplit < 1) p.ksplit = 1;
+    }
+    if (env_split >= 0 && epi_accumulates(epi)) p.ksplit = env_split > 0 ? env_split : 1;
+    if (p.ksplit > 1) epi_set_atomic(epi);
+    const unsigned gz = (unsigned)(p.batch * p.ksplit);
     if (cfg == 0) {
-        dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, p.batch);
+        dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, gz);
         hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 128, 128, 16, 2, 4, Epi>), grid, dim3(512), 0, stream, p, epi);
     } else if (cfg == 1) {
-        dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, p.batch);
+        dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, gz);
         hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 64, 64, 16, 2, 2, Epi>), grid, dim3(256), 0, stream, p, epi);
     } else {
         if constexpr (KCA) {
-            dim3 grid((p.N + 63) / 64, (p.M + 31) / 32, p.batch);
+            dim3 grid((p.N + 63) / 64, (p.M + 31) / 32, gz);
             hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 32, 64, 16, 2, 2, Epi>), grid, dim3(256), 0, stream, p, epi);
         }
     }
