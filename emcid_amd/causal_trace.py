@@ -33,7 +33,14 @@ class TokenRangeFinder:
             out.append(s)
         return out
 
-    def __call__(self, token_array, substring_orig: str) -> Tuple[int, int]:
+    def batch(self, token_arrays, substrings) -> List[Tuple[int, int]]:
+        """All prompts of a request list at once: ONE ``batch_decode`` for the whole-prompt strings (the same text
+        ``decode`` gives per prompt) instead of one tokenizer call per prompt."""
+        rows = [[int(t) for t in ids] for ids in token_arrays]
+        wholes = self.tokenizer.batch_decode(rows)
+        return [self(ids, sub, whole) for ids, sub, whole in zip(rows, substrings, wholes)]
+
+    def __call__(self, token_array, substring_orig: str, whole_decoded: str = None) -> Tuple[int, int]:
         ids = [int(t) for t in token_array]
         n = len(ids)
         sub = substring_orig
@@ -42,7 +49,7 @@ class TokenRangeFinder:
         if sub == "[EOS]" or sub == "" or sub == " ":
             return (n - 1, n)
         sub = sub.replace(" ", "").lower()
-        whole = self.tokenizer.decode(ids).replace(" ", "")
+        whole = (self.tokenizer.decode(ids) if whole_decoded is None else whole_decoded).replace(" ", "")
         if "’" in sub:
             whole = whole.replace("'", "’")
         whole = unicodedata.normalize("NFKC", whole)

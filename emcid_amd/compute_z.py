@@ -70,7 +70,7 @@ def build_prompt_batch(tokenizer, requests: Sequence[Dict], device, finder: Opti
     enc = tokenizer(prompts, return_tensors="pt", padding=True, truncation=True)
     finder = finder or TokenRangeFinder(tokenizer)
     ids_host = enc["input_ids"].tolist()
-    lookup = [finder(ids, subj)[-1] - 1 for ids, subj in zip(ids_host, subjects)]
+    lookup = [r[-1] - 1 for r in finder.batch(ids_host, subjects)]
     if len(ids_host) != len(lookup):
         raise ValueError("The number of prompts and lookup indices should be the same.")
     S = enc["input_ids"].shape[1]

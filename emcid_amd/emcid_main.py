@@ -111,14 +111,20 @@ def load_v_stars(requests: Sequence[Dict], hparams, cache_name: Optional[str], s
                  stage1: Optional[Stage1Fn] = None) -> torch.Tensor:
     """(N, hidden) fp32 on the host: one row per request, the transpose of the reference's ``zs`` (:977)."""
     rows = []
+    files = [vstar_cache_file(cache_name, request, hparams, idx, suffix) for idx, request in enumerate(requests)]
+
+    def read(f):
+        if f is None or not f.exists():
+            return None
+        try:
+            return _read_vstar(f)
+        except Exception as e:  # unreadable cache -> recompute, as the reference (:903-904)
+            print(f"Error reading cache file due to {e}. Recomputing...")
+            return None
+
+    loaded = [read(f) for f in files]   # (a thread pool was measured 6x SLOWER here: np.load of tiny files is GIL-bound)
     for idx, request in enumerate(requests):
-        f = vstar_cache_file(cache_name, request, hparams, idx, suffix)
-        v = None
-        if f is not None and f.exists():
-            try:
-                v = _read_vstar(f)
-            except Exception as e:  # unreadable cache -> recompute, as the reference (:903-904)
-                print(f"Error reading cache file due to {e}. Recomputing...")
+        f, v = files[idx], loaded[idx]
         if v is None:
             if stage1 is None:
                 raise NotImplementedError(
