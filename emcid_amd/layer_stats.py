@@ -22,8 +22,9 @@ from tqdm.auto import tqdm
 from .clip_attention import hip_attention
 from .globals import STATS_DIR
 from .nethook import StopForward, get_module, set_requires_grad
-from .runningstats import CombinedStat, SecondMoment, load_cached_state, save_cached_state, make_loader, tally
-from .stat_dataset import TokenizedDataset, dict_to_, flatten_masked_batch, length_collation
+from .runningstats import (CombinedStat, SecondMoment, load_cached_state, make_loader, make_sampler,
+                           save_cached_state, tally)
+from .stat_dataset import TokenizedDataset, collate_token_lists, dict_to_, flatten_masked_batch, length_collation
 
 STAT_TYPES = {"mom2": SecondMoment}
 CCS_PATH = "./data/ccs_filtered.json"   # reference: layer_stats.py:138 (hard-coded, cwd-relative)
@@ -54,8 +55,13 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
                                    ds_name="ccs_filtered", to_collect=("mom2",), model_name="text_encoder",
                                    sample_size=None, precision="float32", batch_tokens=3 * 1024, progress=tqdm,
                                    force_recompute=False, data_path=CCS_PATH, shard=None, group=None,
-                                   num_workers=2, batch_size=100) -> Dict[str, CombinedStat]:
-    """All ``layer_names`` in ONE pass over the captions.  Returns {layer_name: CombinedStat} (on cpu)."""
+                                   num_workers=2, batch_size=100, device_batch_tokens=32768) -> Dict[str, CombinedStat]:
+    """All ``layer_names`` in ONE pass over the captions.  Returns {layer_name: CombinedStat} (on cpu).
+
+    ``batch_tokens`` names the cache file like the reference (``_t3072_``) but the device batches are larger:
+    captions are pooled ``device_batch_tokens`` at a time, length-sorted and padded — the reference's 100-caption /
+    3 072-token sub-batches keep a 12-layer forward at ~2 ms of GPU work under ~4 ms of Python.  The statistic is a
+    sum over attended tokens, so the batch shape only changes the fp32 summation order."""
     precision = _check_precision(precision)
     to_collect = list(to_collect)
     device = next(model.parameters()).device
@@ -76,9 +82,19 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
         return stats
 
     ds = get_ccs_filtered_ds(tokenizer, data_path)
-    loader = make_loader(ds, sample_size=sample_size, batch_size=batch_size, random_sample=1, shard=shard,
-                         collate_fn=length_collation(batch_tokens), pin_memory=device.type == "cuda",
-                         num_workers=num_workers)
+    # Same fixed sample, same groups of ``batch_size`` captions, same length_collation as the reference's DataLoader
+    # (layer_stats.py:196-206) — but the captions are tokenized with ONE batched tokenizer call up front instead of
+    # one ``encode`` per item inside DataLoader workers (the pass was host-bound on that: 62k -> tokens/s).
+    sample = list(make_sampler(ds, sample_size=sample_size, random_sample=1, shard=shard))
+    all_ids = tokenizer([ds.data[i] for i in sample], truncation=True, max_length=ds.maxlen)["input_ids"] if sample else []
+
+    pool = max(batch_size, (device_batch_tokens // 16) // batch_size * batch_size)   # captions pooled per collation
+
+    def groups():
+        for g in range(0, len(all_ids), pool):
+            yield collate_token_lists(all_ids[g:g + pool], max(batch_tokens, device_batch_tokens))
+
+    loader = groups()
     # forward order of the hooked modules decides which one is "deepest" (the one that stops the pass)
     order = {name: i for i, (name, _) in enumerate(model.named_modules())}
     mods = {ln: get_module(model, ln) for ln in todo}
@@ -92,19 +108,21 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
             if ln == deepest:
                 raise StopForward()
         handles.append(mods[ln].register_forward_hook(hook))
-    n_groups = -(-(len(loader.sampler) if loader.sampler is not None else len(ds)) // batch_size)
+    n_groups = -(-len(all_ids) // pool)
     wrap = progress if progress is not None else (lambda it, total=None: it)
     try:
         with torch.no_grad(), hip_attention(model):
             for batch_group in wrap(loader, total=n_groups):
                 for batch in batch_group:
+                    attended = batch.pop("attended").to(device, non_blocking=True)   # host-computed: no device nonzero
                     batch = dict_to_(batch, device)
                     try:
                         model(**batch)
                     except StopForward:
                         pass
                     for ln in todo:
-                        feats = flatten_masked_batch(grabbed[ln], batch["attention_mask"])
+                        x = grabbed[ln]
+                        feats = x.reshape(-1, x.size(-1)).index_select(0, attended)  # == flatten_masked_batch(x, mask)
                         stats[ln].add(feats.to(dtype=torch.float32))
                     grabbed.clear()
     finally:

@@ -323,6 +323,22 @@ class FixedRandomSubsetSampler(FixedSubsetSampler):
         super().__init__(order[start:end])
 
 
+def make_sampler(dataset, sample_size=None, sampler=None, random_sample=None, shard=None):
+    """The fixed sample subset ``make_loader`` would iterate (same order), as a FixedSubsetSampler."""
+    if sample_size is not None:
+        assert sampler is None, "sampler cannot be specified with sample_size"
+        sample_size = min(sample_size, len(dataset))
+        if random_sample is None:
+            sampler = FixedSubsetSampler(range(sample_size))
+        else:
+            sampler = FixedRandomSubsetSampler(dataset, seed=random_sample, end=sample_size)
+    if sampler is None:
+        sampler = FixedSubsetSampler(range(len(dataset)))
+    if shard is not None:
+        sampler = sampler.shard(*shard)
+    return sampler
+
+
 def make_loader(dataset, sample_size=None, batch_size=1, sampler=None, random_sample=None, shard=None, **kwargs):
     """DataLoader over a fixed sample subset.  ``shard=(rank, world)`` keeps this rank's slice of it."""
     if callable(dataset) and not hasattr(dataset, "__len__"):

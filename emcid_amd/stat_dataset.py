@@ -75,3 +75,38 @@ def flatten_masked_batch(data: torch.Tensor, mask: torch.Tensor) -> torch.Tensor
     """(B, S, c) -> (T_attended, c): drops padded positions, keeps BOS/EOS."""
     flat = data.reshape(-1, data.size(-1))
     return flat[mask.reshape(-1).nonzero()[:, 0]]
+
+
+def collate_token_lists(rows, token_size: int):
+    """``length_collation(token_size)`` applied to plain token-id lists, vectorised: same ordering (longest first,
+    stable), same split rule, same zero padding, plus the flat indices of the attended positions (what
+    ``flatten_masked_batch`` selects) computed on the host so the device never has to run ``nonzero``.
+    Returns a list of dicts {input_ids, position_ids, attention_mask (rows, width), attended (T,)} of CPU tensors."""
+    import numpy as np
+
+    order = sorted(range(len(rows)), key=lambda i: -len(rows[i]))
+    groups, cur, width = [], [], 0
+    for i in order:
+        w = len(rows[i])
+        if w == 0:
+            break
+        if width * (len(cur) + 1) > token_size:
+            groups.append(cur)
+            cur, width = [], 0
+        if not cur:
+            width = w
+        cur.append(i)
+    if cur:
+        groups.append(cur)
+    out = []
+    for g in groups:
+        lens = np.fromiter((len(rows[i]) for i in g), dtype=np.int64, count=len(g))
+        w = int(lens.max())
+        mask = np.arange(w)[None, :] < lens[:, None]
+        ids = np.zeros((len(g), w), dtype=np.int64)
+        ids[mask] = np.concatenate([np.asarray(rows[i], dtype=np.int64) for i in g])
+        pos = np.where(mask, np.arange(w)[None, :], 0)
+        out.append({"input_ids": torch.from_numpy(ids), "position_ids": torch.from_numpy(pos),
+                    "attention_mask": torch.from_numpy(mask.astype(np.int64)),
+                    "attended": torch.from_numpy(np.flatnonzero(mask.reshape(-1)))})
+    return out

@@ -117,6 +117,13 @@ def test_length_collation_matches_oracle(tmp_path):
         pb = orc.pad_batch(r)
         for k in ("input_ids", "position_ids", "attention_mask"):
             assert torch.equal(g[k], pb[k])
+    from emcid_amd.stat_dataset import collate_token_lists
+    fast = collate_token_lists([it["input_ids"].tolist() for it in items], 300)
+    assert len(fast) == len(got)
+    for f, g in zip(fast, got):
+        for k in ("input_ids", "position_ids", "attention_mask"):
+            assert torch.equal(f[k], g[k])
+        assert torch.equal(f["attended"], g["attention_mask"].reshape(-1).nonzero()[:, 0])
     data = torch.arange(2 * 3 * 4, dtype=torch.float32).reshape(2, 3, 4)
     mask = torch.tensor([[1, 1, 0], [1, 0, 0]])
     assert flatten_masked_batch(data, mask).shape == (3, 4)
