@@ -286,6 +286,33 @@ def apply_emcid_to_sdxl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
     return pipe, o1, o2
 
 
+# ---- edited-weight export (the reference never saves its edits) --------------------------------
+
+def export_edited_weights(text_encoder, hparams, path, layers: Optional[Sequence[int]] = None) -> List[str]:
+    """Write the (edited) fc2 weights of ``layers`` (default ``hparams.layers``) to a safetensors file keyed by
+    the parameter names of ``hparams.rewrite_module_tmp``; returns the names written."""
+    from safetensors.torch import save_file
+    layers = list(hparams.layers if layers is None else layers)
+    names = [f"{hparams.rewrite_module_tmp.format(l)}.weight" for l in layers]
+    tensors = {n: nethook.get_parameter(text_encoder, n).detach().to("cpu").contiguous() for n in names}
+    Path(path).parent.mkdir(parents=True, exist_ok=True)
+    save_file(tensors, str(path), metadata={"format": "pt", "producer": "emcid_amd"})
+    return names
+
+
+def load_edited_weights(text_encoder, path) -> List[str]:
+    """Copy the tensors of an ``export_edited_weights`` file into the encoder (shape-checked, in place)."""
+    from safetensors.torch import load_file
+    tensors = load_file(str(path))
+    with torch.no_grad():
+        for n, t in tensors.items():
+            w = nethook.get_parameter(text_encoder, n)
+            if w.shape != t.shape:
+                raise ValueError(f"{n}: file has {tuple(t.shape)}, model has {tuple(w.shape)}")
+            w.copy_(t.to(w.device, w.dtype))
+    return list(tensors)
+
+
 def apply_emcid_to_model(pipe, requests, hparams, device, **kwargs):
     """Dispatching alias (the entry-point name used by BASELINE.json; absent from the reference)."""
     if isinstance(hparams, EMCIDXLHyperParams) or hasattr(hparams, "layers_2"):

@@ -208,3 +208,18 @@ def test_upd_matrix_match_shape():
     assert upd_matrix_match_shape(torch.zeros(4, 6), torch.Size([4, 6, 1, 1])).shape == (4, 6, 1, 1)
     with pytest.raises(ValueError):
         upd_matrix_match_shape(m, torch.Size([2, 2]))
+
+
+def test_export_and_load_edited_weights(tmp_path):
+    from emcid_amd import emcid_main as em
+    te = syn.build_text_encoder("toy")
+    hp = EMCIDHyperParams(**syn.sd_hparams_dict(layers=(1, 3)))
+    w = get_parameter(te, "encoder.layers.3.mlp.fc2.weight")
+    with torch.no_grad():
+        w += 1.0
+    names = em.export_edited_weights(te, hp, tmp_path / "out" / "edit.safetensors")
+    assert names == ["text_model.encoder.layers.1.mlp.fc2.weight", "text_model.encoder.layers.3.mlp.fc2.weight"]
+    fresh = syn.build_text_encoder("toy")
+    assert not torch.equal(get_parameter(fresh, names[1]), w)
+    assert em.load_edited_weights(fresh, tmp_path / "out" / "edit.safetensors") == names
+    assert torch.equal(get_parameter(fresh, names[1]), w)
