@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <initializer_list>
 
 #include "../../include/emcid_hip.h"
 

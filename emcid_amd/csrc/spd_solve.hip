@@ -146,7 +146,12 @@ __device__ __forceinline__ v4d leaf_tile(const double* lds, FA fa, FB fb, int l1
 
 __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restrict__ A, int64_t lda, double* __restrict__ L,
                                                             int64_t ldl, double* __restrict__ inv, int64_t ldinv, int* info,
-                                                            int col0, long long* dbg = nullptr) {
+                                                            int col0, long long* dbg = nullptr, int64_t s_mat = 0,
+                                                            int64_t s_inv = 0) {
+    // blockIdx.x = which matrix of a batch (independent factorizations share the launch: their serial spines overlap)
+    A += blockIdx.x * s_mat;
+    L += blockIdx.x * s_mat;
+    inv += blockIdx.x * s_inv;
     __shared__ __attribute__((aligned(16))) double lds[NB * SLD + 2 * SB * ZLD];
     double* S = lds;
     constexpr int ZOFF = NB * SLD;          // two [32][48] temporaries behind S
@@ -395,8 +400,11 @@ static int env_flag(const char* name, int dflt) {
 // (one GEMM against all previous columns, contraction depth = their count, so the Schur complement is read and
 // written once per 512 columns instead of once per 128); inside an outer block the classic right-looking
 // leaf -> panel -> trailing-update runs with NB = 128, its updates confined to the block's own <= 384 remaining columns.
-static int cholesky_serial(double* A, double* L, int64_t dp, int64_t lda, double* invw, int* info, hipStream_t st) {
-    hipLaunchKernelGGL(zero_f64_kernel, dim3(1024), dim3(256), 0, st, invw, inv_doubles(dp));
+static int cholesky_serial(double* A, double* L, int64_t dp, int64_t lda, double* invw, int* info, hipStream_t st,
+                           int nbatch = 1, int64_t s_mat = 0, int64_t s_inv = 0) {
+    // nbatch independent matrices (A + b*s_mat, L + b*s_mat, invw + b*s_inv; s_inv == inv_doubles(dp)) are factored by
+    // the same launches: every GEMM is batched over blockIdx.z and the leaf runs one workgroup per matrix.
+    hipLaunchKernelGGL(zero_f64_kernel, dim3(1024), dim3(256), 0, st, invw, inv_doubles(dp) * nbatch);
     const int nob = (int)((dp + OB - 1) / OB);
     for (int J = 0; J < nob; ++J) {
         const int64_t c0 = (int64_t)J * OB;
@@ -404,36 +412,36 @@ static int cholesky_serial(double* A, double* L, int64_t dp, int64_t lda, double
         if (J > 0) {
             // A[c0:, c0:c0+w] -= L[c0:, 0:c0] L[c0:c0+w, 0:c0]^T   (its top-left corner is on the diagonal)
             const double* Lr = L + c0 * lda;
-            GemmShape g{Lr, lda, Lr, lda, (int)(dp - c0), w, (int)c0, 1};
+            GemmShape g{Lr, lda, Lr, lda, (int)(dp - c0), w, (int)c0, 1, s_mat, s_mat, nbatch};
             ScopedProf sp(KC_CHOL_TRAIL, st);
-            launch_gemm_f64<true, true>(g, EpiAxpby{A + c0 * lda + c0, lda, -1.0, 1.0}, st);
+            launch_gemm_f64<true, true>(g, EpiAxpby{A + c0 * lda + c0, lda, -1.0, 1.0, s_mat}, st);
         }
         for (int jj = 0; jj < w / NB; ++jj) {
             const int64_t o = c0 + (int64_t)jj * NB;
             double* inv = inv_block(invw, J) + (jj * NB) * (int64_t)(OB + 1);
             {
                 ScopedProf sp(KC_CHOL_LEAF, st);
-                hipLaunchKernelGGL(chol_leaf_kernel, dim3(1), dim3(LEAF_T), 0, st, A + o * lda + o, lda, L + o * lda + o,
-                                   lda, inv, (int64_t)OB, info, (int)o);
+                hipLaunchKernelGGL(chol_leaf_kernel, dim3(nbatch), dim3(LEAF_T), 0, st, A + o * lda + o, lda, L + o * lda + o,
+                                   lda, inv, (int64_t)OB, info, (int)o, (long long*)nullptr, s_mat, s_inv);
             }
             const int m = (int)(dp - o - NB);
             if (m == 0) break;
-            GemmShape ps{A + (o + NB) * lda + o, lda, inv, OB, m, NB, NB, 0};
+            GemmShape ps{A + (o + NB) * lda + o, lda, inv, OB, m, NB, NB, 0, s_mat, s_inv, nbatch};
             ps.tri = 1;   // inv(L11) is lower triangular: B(k, n) = inv[n][k] vanishes for k > n
             {
                 ScopedProf sp(KC_CHOL_PANEL, st);
-                launch_gemm_f64<true, true>(ps, EpiAxpby{L + (o + NB) * lda + o, lda, 1.0, 0.0}, st);
+                launch_gemm_f64<true, true>(ps, EpiAxpby{L + (o + NB) * lda + o, lda, 1.0, 0.0, s_mat}, st);
             }
             const int wi = (int)(c0 + w - (o + NB));   // columns of this outer block still to the right
             if (wi > 0) {
                 const double* L21 = L + (o + NB) * lda + o;
-                GemmShape ts{L21, lda, L21, lda, m, wi, NB, 1};
+                GemmShape ts{L21, lda, L21, lda, m, wi, NB, 1, s_mat, s_mat, nbatch};
                 ScopedProf sp(KC_CHOL_INNER, st);
-                launch_gemm_f64<true, true>(ts, EpiAxpby{A + (o + NB) * lda + (o + NB), lda, -1.0, 1.0}, st);
+                launch_gemm_f64<true, true>(ts, EpiAxpby{A + (o + NB) * lda + (o + NB), lda, -1.0, 1.0, s_mat}, st);
             }
         }
     }
-    build_block_inverses(L, dp, lda, invw, st);
+    for (int b = 0; b < nbatch; ++b) build_block_inverses(L + b * s_mat, dp, lda, invw + b * s_inv, st);
     return check_launch("emcid_cholesky_f64");
 }
 
@@ -493,28 +501,33 @@ static int cholesky_solve_impl(const double* L, int64_t dp, int64_t lda, const d
 // launch each.  Not used while per-kernel event timing is on (the events would be recorded at capture time).
 namespace {
 struct GraphKey {
-    const void *A, *L, *inv, *info, *B, *Y;
-    int64_t dp, lda, rows, ldb;
+    const void* ptr[8];
+    int64_t num[6];
     bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
 };
 struct GraphSlot { GraphKey key; hipGraphExec_t exec; hipGraph_t graph; uint64_t used; };
-constexpr int GRAPH_SLOTS = 16;
+constexpr int GRAPH_SLOTS = 32;
 GraphSlot g_graphs[GRAPH_SLOTS];
 int g_graph_n = 0;
 uint64_t g_graph_clock = 0;
+
+GraphKey make_key(int tag, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> nums) {
+    GraphKey k;
+    memset(&k, 0, sizeof(k));
+    int i = 0;
+    for (const void* p : ptrs) k.ptr[i++] = p;
+    i = 0;
+    k.num[5] = tag;
+    for (int64_t n : nums) k.num[i++] = n;
+    return k;
+}
 }  // namespace
 
-static int factor_and_solve(double* A, double* L, int64_t dp, int64_t lda, double* invw, int* info, double* B, double* Y,
-                            int64_t rows, int64_t ldb, hipStream_t st) {
+// Runs `body(stream)` — a chain of launches whose arguments are fully determined by `key` — as a cached hipGraph.
+template <class F>
+static int with_graph(const GraphKey& key, hipStream_t st, F&& body) {
     static const int use_graph = env_flag("EMCID_GRAPH", 1);
-    if (!use_graph || g_prof_mask != 0) {
-        EMCID_TRY(cholesky_impl(A, L, dp, lda, invw, info, st));
-        return cholesky_solve_impl(L, dp, lda, invw, B, Y, rows, ldb, st);
-    }
-    GraphKey key;
-    memset(&key, 0, sizeof(key));
-    key.A = A; key.L = L; key.inv = invw; key.info = info; key.B = B; key.Y = Y;
-    key.dp = dp; key.lda = lda; key.rows = rows; key.ldb = ldb;
+    if (!use_graph || g_prof_mask != 0) return body(st);
     GraphSlot* slot = nullptr;
     for (int i = 0; i < g_graph_n; ++i)
         if (g_graphs[i].key == key) { slot = &g_graphs[i]; break; }
@@ -522,17 +535,16 @@ static int factor_and_solve(double* A, double* L, int64_t dp, int64_t lda, doubl
         EMCID_TRY(capture_stream_init());
         hipStream_t cap = g_capture_stream;
         if (hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) != hipSuccess)
-            return fail(EMCID_ERR_HIP, "emcid_edit_layer_f64", "hipStreamBeginCapture");
-        int rc = cholesky_impl(A, L, dp, lda, invw, info, cap);
-        if (!rc) rc = cholesky_solve_impl(L, dp, lda, invw, B, Y, rows, ldb, cap);
+            return fail(EMCID_ERR_HIP, "emcid graph", "hipStreamBeginCapture");
+        const int rc = body(cap);
         hipGraph_t graph = nullptr;
         const hipError_t ec = hipStreamEndCapture(cap, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-        if (ec != hipSuccess || !graph) return fail(EMCID_ERR_HIP, "emcid_edit_layer_f64", "hipStreamEndCapture");
+        if (ec != hipSuccess || !graph) return fail(EMCID_ERR_HIP, "emcid graph", "hipStreamEndCapture");
         hipGraphExec_t exec = nullptr;
         if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
             (void)hipGraphDestroy(graph);
-            return fail(EMCID_ERR_HIP, "emcid_edit_layer_f64", "hipGraphInstantiate");
+            return fail(EMCID_ERR_HIP, "emcid graph", "hipGraphInstantiate");
         }
         if (g_graph_n < GRAPH_SLOTS) {
             slot = &g_graphs[g_graph_n++];
@@ -547,9 +559,83 @@ static int factor_and_solve(double* A, double* L, int64_t dp, int64_t lda, doubl
         slot->key = key; slot->exec = exec; slot->graph = graph;
     }
     slot->used = ++g_graph_clock;
-    if (hipGraphLaunch(slot->exec, st) != hipSuccess) return fail(EMCID_ERR_HIP, "emcid_edit_layer_f64", "hipGraphLaunch");
+    if (hipGraphLaunch(slot->exec, st) != hipSuccess) return fail(EMCID_ERR_HIP, "emcid graph", "hipGraphLaunch");
     return EMCID_OK;
 }
+
+static int factor_and_solve(double* A, double* L, int64_t dp, int64_t lda, double* invw, int* info, double* B, double* Y,
+                            int64_t rows, int64_t ldb, hipStream_t st) {
+    return with_graph(make_key(1, {A, L, invw, info, B, Y}, {dp, lda, rows, ldb}), st, [&](hipStream_t s) {
+        EMCID_TRY(cholesky_impl(A, L, dp, lda, invw, info, s));
+        return cholesky_solve_impl(L, dp, lda, invw, B, Y, rows, ldb, s);
+    });
+}
+
+// ---- dual (Woodbury) solver -----------------------------------------------------------------------------------------
+// A = M + Kt^T Kt with M = lam*C' independent of the concepts.  Then  Xt = Kt A^-1 = (I + Pt Kt^T)^-1 Pt,  Pt = Kt M^-1:
+// the d x d factorization is of M only — done for ALL edited layers at once, batched, before (and concurrently with)
+// the forward pass — and each layer factors just the Np x Np matrix S = I + Pt Kt^T.
+
+// M[l] = lam * double(fl32(fl32(C[l]*cw)/0.5f)) on the lower triangle, identity on the padding (as EpiAssemble)
+struct CovPtrs { const float* c[32]; };
+__global__ __launch_bounds__(256) void scale_cov_kernel(CovPtrs cov, int d, int dp, double lam, float cw, double* __restrict__ M,
+                                                         int64_t s_mat) {
+    const int l = blockIdx.y;
+    const int i = blockIdx.x;
+    const float* C = cov.c[l];
+    double* row = M + l * s_mat + (int64_t)i * dp;
+    for (int j = threadIdx.x; j <= i; j += 256) {
+        double v;
+        if (i < d) {
+            const float c1 = C[(int64_t)i * d + j] * cw;
+            v = lam * (double)(c1 / 0.5f);
+        } else {
+            v = (i == j) ? 1.0 : 0.0;
+        }
+        row[j] = v;
+    }
+}
+
+// S = D + I (lower tiles), D = Pt Kt^T
+struct EpiPlusIdentity {
+    double* S; int64_t lds_;
+    static constexpr bool splittable = false;
+    __device__ __forceinline__ void batch(int) {}
+    __device__ __forceinline__ void operator()(int m, int n, double v) const { S[(int64_t)m * lds_ + n] = v + (m == n ? 1.0 : 0.0); }
+};
+
+__global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst,
+                                                             int64_t ldd, int rows, int cols) {
+    __shared__ double tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        tile[r][tx] = (by + r < rows && bx + tx < cols) ? src[(int64_t)(by + r) * lds_ + bx + tx] : 0.0;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (bx + r < cols && by + tx < rows) dst[(int64_t)(bx + r) * ldd + by + tx] = tile[tx][r];
+}
+
+struct DualWorkspace {
+    int64_t Np, dp, hp;
+    int64_t off_K, off_P, off_Y, off_R, off_S, off_LS, off_invS, off_PT, off_Y2, total;   // doubles
+    DualWorkspace(int64_t N, int64_t d, int64_t h) {
+        Np = round_up(N, NB);
+        dp = round_up(d, NB);
+        hp = round_up(h, 2);
+        int64_t o = 0;
+        off_K = o; o += Np * dp;
+        off_P = o; o += Np * dp;
+        off_Y = o; o += Np * dp;
+        off_R = o; o += Np * hp;
+        off_S = o; o += Np * Np;
+        off_LS = o; o += Np * Np;
+        off_invS = o; o += inv_doubles(Np);
+        off_PT = o; o += dp * Np;
+        off_Y2 = o; o += dp * Np;
+        total = o;
+    }
+};
 
 struct EditWorkspace {
     int64_t Np, dp, hp;
@@ -752,6 +838,116 @@ int emcid_apply_update_f32(const double* U, const float* W0, float* W, float* dW
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(apply_u_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, U, W0, W, dW, n);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+/* ---- dual (Woodbury) solver ------------------------------------------------------------------------------------- */
+
+int64_t emcid_cov_factor_workspace_bytes(int64_t n_layers, int64_t d) {
+    if (n_layers <= 0 || d <= 0) return 0;
+    const int64_t dp = round_up(d, NB);
+    return n_layers * (2 * dp * dp + inv_doubles(dp)) * (int64_t)sizeof(double);
+}
+
+int emcid_factor_cov_f64(const float* const* C_host_list, int64_t n_layers, int64_t d, double lam, double edit_weight,
+                         void* workspace, int64_t workspace_bytes, int* info_dev, void* stream) {
+    EMCID_CHECK_ARG(C_host_list && n_layers > 0 && n_layers <= 32 && d > 0 && d <= 32768 && workspace && info_dev);
+    EMCID_CHECK_ARG(aligned16(workspace));
+    if (workspace_bytes < emcid_cov_factor_workspace_bytes(n_layers, d))
+        return fail(EMCID_ERR_WORKSPACE, __func__, "workspace too small (see emcid_cov_factor_workspace_bytes)");
+    const int64_t dp = round_up(d, NB), s_mat = dp * dp, s_inv = inv_doubles(dp);
+    double* Mb = (double*)workspace;                 // [n_layers][dp*dp]  lam*C' (consumed by the factorization)
+    double* Lb = Mb + n_layers * s_mat;              // [n_layers][dp*dp]  factors
+    double* Ib = Lb + n_layers * s_mat;              // [n_layers][inv_doubles]
+    CovPtrs cp;
+    for (int i = 0; i < 32; ++i) cp.c[i] = i < n_layers ? C_host_list[i] : nullptr;
+    for (int i = 0; i < n_layers; ++i) EMCID_CHECK_ARG(cp.c[i] != nullptr);
+    const float cw = (float)(1.0 - edit_weight);
+    hipStream_t st = (hipStream_t)stream;
+    GraphKey key = make_key(2, {Mb, info_dev}, {n_layers, d, 0, 0, 0});
+    memcpy(&key.num[2], &lam, sizeof(double));
+    memcpy(&key.num[3], &cw, sizeof(float));
+    for (int i = 0; i < n_layers; ++i)   // every C pointer takes part in the key (6 slots, then folded)
+        if (i < 6) key.ptr[2 + i] = cp.c[i]; else key.num[4] = key.num[4] * 1000003 + (int64_t)(uintptr_t)cp.c[i];
+    return with_graph(key, st, [&](hipStream_t s) {
+        hipLaunchKernelGGL(scale_cov_kernel, dim3((unsigned)dp, (unsigned)n_layers), dim3(256), 0, s, cp, (int)d, (int)dp, lam, cw,
+                           Mb, s_mat);
+        return cholesky_serial(Mb, Lb, dp, dp, Ib, info_dev, s, (int)n_layers, s_mat, s_inv);
+    });
+}
+
+int64_t emcid_edit_dual_workspace_bytes(int64_t N, int64_t d, int64_t h) {
+    if (N <= 0 || d <= 0 || h <= 0) return 0;
+    return DualWorkspace(N, d, h).total * (int64_t)sizeof(double);
+}
+
+/* stage 1: Kt64 = s*K, Rt, and the shard's rows of Pt = Kt64 M^-1 (into Pt_rows_out if given, else only the workspace) */
+int emcid_edit_dual_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
+                               double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
+                               int64_t layer_index, int64_t n_lo, int64_t n_hi, void* workspace, int64_t workspace_bytes,
+                               void* stream) {
+    EMCID_CHECK_ARG(K && Zc && zs_t && N > 0 && d > 0 && h > 0 && layers_left > 0 && cov_factor_ws && workspace);
+    EMCID_CHECK_ARG(0 <= layer_index && layer_index < n_layers && 0 <= n_lo && n_lo < n_hi && n_hi <= N);
+    DualWorkspace ws(N, d, h);
+    if (workspace_bytes < ws.total * (int64_t)sizeof(double)) return fail(EMCID_ERR_WORKSPACE, __func__, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double* base = (double*)workspace;
+    double *Kt = base + ws.off_K, *Pt = base + ws.off_P, *Y = base + ws.off_Y, *R = base + ws.off_R;
+    const int64_t dp = ws.dp, s_mat = dp * dp;
+    const double* Lb = (const double*)cov_factor_ws + n_layers * s_mat + layer_index * s_mat;
+    const double* Ib = (const double*)cov_factor_ws + 2 * n_layers * s_mat + layer_index * inv_doubles(dp);
+    const double s = sqrt(edit_weight / 0.5);
+    {
+        ScopedProf sp(KC_PREP, st);
+        hipLaunchKernelGGL(prep_kr_kernel, dim3((unsigned)ws.Np), dim3(256), 0, st, K, Zc, zs_t, (int)N, (int)d, (int)h, s,
+                           (double)layers_left, Kt, (int)ws.Np, (int)dp, R, (int)ws.hp);
+    }
+    const int64_t rows = n_hi - n_lo;
+    if (hipMemcpyAsync(Pt + n_lo * dp, Kt + n_lo * dp, rows * dp * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(EMCID_ERR_HIP, __func__, "hipMemcpyAsync");
+    return with_graph(make_key(3, {Lb, Ib, Pt + n_lo * dp, Y + n_lo * dp}, {dp, rows}), st, [&](hipStream_t q) {
+        return cholesky_solve_impl(Lb, dp, dp, Ib, Pt + n_lo * dp, Y + n_lo * dp, rows, dp, q);
+    });
+}
+
+/* pointer to the Pt stack [Np, dp] inside a dual workspace (multi-GPU: ranks all-gather their row blocks in place) */
+double* emcid_edit_dual_pt(void* workspace, int64_t N, int64_t d, int64_t h) {
+    if (!workspace || N <= 0 || d <= 0 || h <= 0) return nullptr;
+    return (double*)workspace + DualWorkspace(N, d, h).off_P;
+}
+
+/* stage 2 (needs ALL rows of Pt): S = I + Pt Kt^T, S = L_S L_S^T, adj_k = (S^-1 Pt)^T  [d, Np], U = Rt^T Xt, W = W0 + float(U) */
+int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, const float* W0, float* W, double* adjk_out, double* Rt_out,
+                               float* dW_out, void* workspace, int64_t workspace_bytes, int* info_dev, void* stream) {
+    EMCID_CHECK_ARG(N > 0 && d > 0 && h > 0 && workspace && info_dev && ((W == nullptr) || (W0 != nullptr)));
+    DualWorkspace ws(N, d, h);
+    if (workspace_bytes < ws.total * (int64_t)sizeof(double)) return fail(EMCID_ERR_WORKSPACE, __func__, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double* base = (double*)workspace;
+    double *Kt = base + ws.off_K, *Pt = base + ws.off_P, *R = base + ws.off_R, *S = base + ws.off_S, *LS = base + ws.off_LS;
+    double *invS = base + ws.off_invS, *PT = base + ws.off_PT, *Y2 = base + ws.off_Y2;
+    const int64_t dp = ws.dp, Np = ws.Np;
+    EMCID_TRY(with_graph(make_key(4, {Kt, Pt, S, LS, invS, PT, Y2, info_dev}, {dp, Np, N}), st, [&](hipStream_t q) {
+        if (Np > N)   // rows of the padding concepts: zero (their Kt rows are zero, so S gets identity rows there)
+            hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, q, Pt + N * dp, (Np - N) * dp);
+        {
+            ScopedProf sp(KC_ASSEMBLE, q);
+            GemmShape g{Pt, dp, Kt, dp, (int)Np, (int)Np, (int)dp, 1};
+            launch_gemm_f64<true, true>(g, EpiPlusIdentity{S, Np}, q);
+        }
+        EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q));
+        hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)(dp / 32), (unsigned)(Np / 32)), dim3(256), 0, q, Pt, dp, PT, Np,
+                           (int)Np, (int)dp);
+        return cholesky_solve_impl(LS, Np, Np, invS, PT, Y2, dp, Np, q);   // PT := PT S^-1  ->  adj_k padded [dp, Np]
+    }));
+    if (W || dW_out) {
+        ScopedProf sp(KC_DELTA_W, st);
+        GemmShape g{R, ws.hp, PT, Np, (int)h, (int)d, (int)Np, 0};
+        launch_gemm_f64<false, true>(g, EpiDeltaW{W0, W, d, dW_out, d, nullptr, d}, st);
+    }
+    if (adjk_out) hipLaunchKernelGGL(copy2d_f64_kernel, dim3((unsigned)d), dim3(256), 0, st, PT, Np, adjk_out, N, (int)d, (int)N);
+    if (Rt_out) hipLaunchKernelGGL(copy2d_f64_kernel, dim3((unsigned)N), dim3(256), 0, st, R, ws.hp, Rt_out, h, (int)N, (int)h);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }

@@ -68,6 +68,10 @@ class EncoderEditPlan:
     n_total: int                           # N over all ranks
     shard: ConceptShard = field(default_factory=ConceptShard)
     ws: Optional[hip.EditWorkspace] = None
+    dual_ws: Optional[hip.DualWorkspace] = None          # dual (Woodbury) solver state, see run_encoder_edit
+    cov_factors: Optional[hip.CovFactors] = None
+    side_stream: Optional[torch.cuda.Stream] = None
+    solver: str = "auto"                                 # "direct" | "dual" | "auto" (dual when N is well below d)
     graph: Optional[clip_forward.ClipTextGraph] = None   # set -> prefix-deduplicated forward (clip_forward.py)
     trie: Optional[clip_forward.TokenTrie] = None
 
@@ -76,6 +80,18 @@ class EncoderEditPlan:
 
 
 FORWARD_MODE = "trie"   # "trie": prefix-deduplicated forward when the encoder is a HF CLIP text model; "hf": hooked HF forward
+SOLVER = None           # None: plan.solver decides; "direct" / "dual" force it (tests, experiments; env EMCID_SOLVER too)
+
+
+def _use_dual(plan, d: int) -> bool:
+    import os
+    mode = SOLVER or os.environ.get("EMCID_SOLVER") or plan.solver
+    if mode == "dual":
+        return True
+    if mode == "direct":
+        return False
+    np_, dp = -(-plan.n_total // hip.NB) * hip.NB, -(-d // hip.NB) * hip.NB
+    return np_ * 5 <= dp * 3      # N x N system + two extra solves pay off when N is well below d
 
 
 def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], layers, rewrite_module_tmp, lam,
@@ -165,17 +181,49 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                                     f"(got {w.dtype} on {w.device})")
     backups = {l: w.detach().clone() for l, w in weights.items()}
     d, h = weights[plan.layers[0]].shape[1], weights[plan.layers[0]].shape[0]
-    if plan.ws is None or plan.ws.key != (plan.n_total, d, h):
-        plan.ws = hip.EditWorkspace(plan.n_total, d, h, weights[plan.layers[0]].device)
-    plan.ws.info.zero_()
+    dev = weights[plan.layers[0]].device
+    dual = _use_dual(plan, d)
     edits: List[LayerEdit] = []
     last = plan.layers[-1]
     handles = []
+    fac_done = None
+    if dual:
+        # lam * C'_l does not depend on the concepts: factor it for ALL edited layers in one batched pass on a side
+        # stream, underneath the encoder forward that produces the first layer's keys
+        if plan.dual_ws is None or plan.dual_ws.key != (plan.n_total, d, h):
+            plan.dual_ws = hip.DualWorkspace(plan.n_total, d, h, dev)
+        plan.dual_ws.info.zero_()
+        if plan.side_stream is None:
+            plan.side_stream = torch.cuda.Stream(device=dev)
+        plan.side_stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(plan.side_stream):
+            if plan.cov_factors is not None:
+                plan.cov_factors.info.zero_()
+            plan.cov_factors = hip.factor_cov([plan.covs[l] for l in plan.layers], plan.lam, plan.edit_weight,
+                                              plan.cov_factors)
+            fac_done = torch.cuda.Event()
+            fac_done.record(plan.side_stream)
+    else:
+        if plan.ws is None or plan.ws.key != (plan.n_total, d, h):
+            plan.ws = hip.EditWorkspace(plan.n_total, d, h, dev)
+        plan.ws.info.zero_()
 
     def solve(i, layer, K_local, Zc_local):
         """All-gather the shard's K/Zc rows, run the closed form, leave W0 + dW in the live weight."""
         K = _all_gather_rows(K_local, plan)
         Zc = _all_gather_rows(Zc_local, plan)
+        if dual:
+            torch.cuda.current_stream(dev).wait_event(fac_done)
+            sharded = plan.shard.world > 1
+            res = hip.edit_layer_dual(
+                K, Zc, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, W0=backups[layer], W=weights[layer].data,
+                want_factors=keep_factors, ws=plan.dual_ws,
+                rows=plan.shard.bounds(plan.n_total) if sharded else None,
+                gather_pt=(lambda rows_: _all_gather_rows(rows_.contiguous(), plan)) if sharded else None)
+            xt = res["adj_k"].t() if res["adj_k"] is not None else None
+            edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], xt, res["Rt"],
+                                   K if trace else None, Zc if trace else None))
+            return
         if plan.shard.world > 1 and not keep_factors:
             # every rank assembles and factors A from all N concepts; the triangular solves and the dW
             # contraction are split by concept rows and the partial U summed over xGMI (fp64, h*d*8 bytes)
@@ -243,8 +291,11 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
 
 
 def check_info(plan: EncoderEditPlan):
-    """One host sync at the very end: did any layer's A fail to be positive definite?"""
-    code = int(plan.ws.info.item())
+    """One host sync at the very end: did any factorization meet a non-positive pivot?"""
+    code = 0
+    for holder in (plan.ws, plan.dual_ws, plan.cov_factors):
+        if holder is not None and code == 0:
+            code = int(holder.info.item())
     if code != 0:
         raise FloatingPointError(
             f"lam*C + K K^T is not positive definite (non-positive pivot at column {code - 1}); the reference's LU "

@@ -21,6 +21,8 @@ EXPORTS = [
     "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_axpy_f32",
     "emcid_profile_enable", "emcid_profile_collect", "emcid_attention_f32", "emcid_edit_layer_shard_f64",
     "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32", "emcid_tree_attention_f32", "emcid_debug_leaf_stamps",
+    "emcid_cov_factor_workspace_bytes", "emcid_factor_cov_f64", "emcid_edit_dual_workspace_bytes",
+    "emcid_edit_dual_stage1_f64", "emcid_edit_dual_pt", "emcid_edit_dual_stage2_f64",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner"]
@@ -63,6 +65,12 @@ def load():
         "emcid_cholesky_f64": (i32, [p, p, i64, i64, p, p, p]),
         "emcid_inverse_workspace_doubles": (i64, [i64]),
         "emcid_debug_leaf_stamps": (i32, [p, p, p, p, p, p]),
+        "emcid_cov_factor_workspace_bytes": (i64, [i64, i64]),
+        "emcid_factor_cov_f64": (i32, [p, i64, i64, f64, f64, p, i64, p, p]),
+        "emcid_edit_dual_workspace_bytes": (i64, [i64, i64, i64]),
+        "emcid_edit_dual_stage1_f64": (i32, [p, p, p, i64, i64, i64, f64, i32, p, i64, i64, i64, i64, p, i64, p]),
+        "emcid_edit_dual_pt": (p, [p, i64, i64, i64]),
+        "emcid_edit_dual_stage2_f64": (i32, [i64, i64, i64, p, p, p, p, p, p, i64, p, p]),
         "emcid_cholesky_solve_f64": (i32, [p, i64, i64, p, p, p, i64, i64, p]),
         "emcid_delta_w_f64": (i32, [p, i64, p, i64, i64, i64, i64, p, p, i64, p, p, p]),
         "emcid_dgemm_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, p]),
@@ -326,3 +334,73 @@ def tree_attention(q, k, v, anc, depth, H: int, scale=None, rows=None):
         _ptr(rows, torch.int32, "rows") if rows is not None else None, n, H, D, scale, _ptr(out), out.stride(0),
         _stream(q)), "emcid_tree_attention_f32")
     return out
+
+
+# ---- dual (Woodbury) solver ---------------------------------------------------------------------------------------------
+
+class CovFactors:
+    """Cholesky factors of M_l = lam * C'_l for every edited layer (batched factorization, one workspace)."""
+
+    def __init__(self, n_layers: int, d: int, device):
+        self.n_layers, self.d = n_layers, d
+        self.nbytes = int(load().emcid_cov_factor_workspace_bytes(n_layers, d))
+        self.buf = torch.empty(self.nbytes // 8, dtype=torch.float64, device=device)
+        self.info = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def factor_cov(covs, lam: float, edit_weight: float, factors: Optional[CovFactors] = None) -> CovFactors:
+    """covs: list of (d, d) fp32 contiguous HBM tensors (one per edited layer, forward order).  Asynchronous on the
+    current stream."""
+    d = covs[0].shape[0]
+    for c in covs:
+        assert c.shape == (d, d) and c.is_contiguous()
+    if factors is None or factors.n_layers != len(covs) or factors.d != d:
+        factors = CovFactors(len(covs), d, covs[0].device)
+    arr = (C.c_void_p * len(covs))(*[_ptr(c, torch.float32, "C").value for c in covs])
+    _check(load().emcid_factor_cov_f64(arr, len(covs), d, float(lam), float(edit_weight), _ptr(factors.buf), factors.nbytes,
+                                       _ptr(factors.info, torch.int32), _stream(covs[0])), "emcid_factor_cov_f64")
+    return factors
+
+
+class DualWorkspace:
+    def __init__(self, N: int, d: int, h: int, device):
+        self.key = (N, d, h)
+        self.nbytes = int(load().emcid_edit_dual_workspace_bytes(N, d, h))
+        self.buf = torch.empty(self.nbytes // 8, dtype=torch.float64, device=device)
+        self.info = torch.zeros(1, dtype=torch.int32, device=device)
+        self.Np, self.dp = (N + NB - 1) // NB * NB, (d + NB - 1) // NB * NB
+        pt = load().emcid_edit_dual_pt(_ptr(self.buf), N, d, h)
+        off = (pt - self.buf.data_ptr()) // 8
+        self.Pt = self.buf[off:off + self.Np * self.dp].view(self.Np, self.dp)   # the Pt stack, rows = concepts
+
+
+def edit_layer_dual(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_weight: float, layers_left: int,
+                    W0=None, W=None, want_factors: bool = False, want_dw: bool = True, ws: Optional[DualWorkspace] = None,
+                    rows=None, gather_pt=None):
+    """One edited layer through the dual solver.  ``rows=(lo, hi)`` + ``gather_pt(Pt_rows) -> all rows`` split the
+    M-solves over ranks.  Returns dict(adj_k (d,N) | None, Rt (N,h) | None, dW, ws)."""
+    N, d = K.shape
+    h = Zc.shape[1]
+    for t, nm in ((K, "K"), (Zc, "Zc"), (zs_t, "zs_t")):
+        assert t.is_contiguous(), nm
+    assert zs_t.shape == (N, h) and factors.d == d
+    if ws is None or ws.key != (N, d, h):
+        ws = DualWorkspace(N, d, h, K.device)
+    lo, hi = rows if rows is not None else (0, N)
+    lib = load()
+    _check(lib.emcid_edit_dual_stage1_f64(
+        _ptr(K, torch.float32, "K"), _ptr(Zc, torch.float32, "Zc"), _ptr(zs_t, torch.float32, "zs_t"), N, d, h,
+        float(edit_weight), int(layers_left), _ptr(factors.buf), factors.n_layers, int(layer_index), lo, hi,
+        _ptr(ws.buf), ws.nbytes, _stream(K)), "emcid_edit_dual_stage1_f64")
+    if gather_pt is not None:
+        ws.Pt[:N].copy_(gather_pt(ws.Pt[lo:hi]))
+    dev = K.device
+    adj_k = torch.empty(d, N, dtype=torch.float64, device=dev) if want_factors else None
+    Rt = torch.empty(N, h, dtype=torch.float64, device=dev) if want_factors else None
+    dW = torch.empty(h, d, dtype=torch.float32, device=dev) if want_dw else None
+    if W is not None:
+        assert W.is_contiguous() and W.shape == (h, d) and W0 is not None and W0.is_contiguous()
+    _check(lib.emcid_edit_dual_stage2_f64(N, d, h, _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"), _ptr(adj_k),
+                                          _ptr(Rt), _ptr(dW), _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32),
+                                          _stream(K)), "emcid_edit_dual_stage2_f64")
+    return {"adj_k": adj_k, "Rt": Rt, "dW": dW, "ws": ws}

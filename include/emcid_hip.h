@@ -130,6 +130,30 @@ int emcid_edit_layer_shard_f64(const float* K, const float* Zc, const float* zs_
 /* W = W0 + float(U) (optional) ; dW = float(U) (optional), n = h*d elements.  (:1061) */
 int emcid_apply_update_f32(const double* U, const float* W0, float* W, float* dW, int64_t n, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Dual (Woodbury) form of the same layer solve, for N < d:  with M = lam * C' (independent of the concepts)
+ *     Xt = Kt64 (M + Kt64^T Kt64)^-1 = (I + Pt Kt64^T)^-1 Pt,      Pt = Kt64 M^-1 .
+ * emcid_factor_cov_f64 factors M for ALL edited layers in one batched pass (their serial pivot spines overlap, and
+ * the pass can run on a second stream underneath the encoder forward); each layer then only factors the
+ * Np x Np matrix S = I + Pt Kt64^T (Np = N rounded up to 128).  Same inputs, same scaling rules and outputs as
+ * emcid_edit_layer_f64; results agree to ~1e-10 relative (fp64 rounding of a different but exact identity).
+ *   emcid_factor_cov_f64      C_host_list: HOST array of n_layers device pointers to C_l [d,d] fp32.
+ *   emcid_edit_dual_stage1    Kt64, Rt, and rows [n_lo, n_hi) of Pt (two triangular solves against M's factor).
+ *   emcid_edit_dual_pt        address of the Pt stack [Np, dp] inside the workspace (multi-GPU: all-gather rows there).
+ *   emcid_edit_dual_stage2    needs all rows of Pt: S, its Cholesky, adj_k = (S^-1 Pt)^T [d,N], U = Rt^T Xt, W = W0 + float(U).
+ * ------------------------------------------------------------------------------------------- */
+int64_t emcid_cov_factor_workspace_bytes(int64_t n_layers, int64_t d);
+int emcid_factor_cov_f64(const float* const* C_host_list, int64_t n_layers, int64_t d, double lam, double edit_weight,
+                         void* workspace, int64_t workspace_bytes, int* info_dev, void* stream);
+int64_t emcid_edit_dual_workspace_bytes(int64_t N, int64_t d, int64_t h);
+int emcid_edit_dual_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
+                               double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
+                               int64_t layer_index, int64_t n_lo, int64_t n_hi, void* workspace, int64_t workspace_bytes,
+                               void* stream);
+double* emcid_edit_dual_pt(void* workspace, int64_t N, int64_t d, int64_t h);
+int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, const float* W0, float* W, double* adjk_out, double* Rt_out,
+                               float* dW_out, void* workspace, int64_t workspace_bytes, int* info_dev, void* stream);
+
 /* The stages of emcid_edit_layer_f64 as separate calls (used by tests and micro-benchmarks). */
 
 /* A[d,d] (f64, ld lda, LOWER triangle valid) = lam_c * double(fl32(fl32(C*cw)/0.5f)) + Kt64^T Kt64,

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 4 on ONE MI355X: SDXL dual text-encoder edit (TE1 768/3072 layers 8-10, TE2 1280/5120
+layers 26-30), 1 000 concepts, inputs resident in HBM; the two encoders run on two HIP streams.  One JSON line."""
+import json, sys, tempfile, time
+from pathlib import Path
+import torch
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from emcid_amd import emcid_main as em, synthetic as syn
+from emcid_amd.edit_engine import run_encoder_edit, check_info
+from emcid_amd.emcid_hparams import EMCIDXLHyperParams
+from emcid_amd.nethook import get_parameter
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+dev = "cuda:0"
+tmp = Path(tempfile.mkdtemp())
+pipe = syn.build_pipe("sd-v1.4", dev, sdxl=True, syllables=True)
+reqs = syn.make_requests(N, names="syllable")
+hp_d = syn.sdxl_hparams_dict()
+hp = EMCIDXLHyperParams(**hp_d)
+cache = str(tmp / "cache") + "/"
+syn.write_vstar_cache(cache, reqs, 768, seed=1, scale=0.5)
+syn.write_vstar_cache(cache, reqs, 1280, seed=5, scale=0.5, suffix="_2")
+n1 = [hp.rewrite_module_tmp.format(l) for l in hp.layers]
+n2 = [hp.rewrite_module_tmp.format(l) for l in hp.layers_2]
+syn.write_stats_cache(tmp / "s1", n1, 3072, hp.mom2_n_samples, seed=2, t=6144)
+syn.write_stats_cache(tmp / "s2", n2, 5120, hp.mom2_n_samples, seed=7, t=10240)
+t0 = time.perf_counter()
+p1, p2 = em._sdxl_plans(pipe, reqs, hp, cache, str(tmp / "s1"), str(tmp / "s2"), False, None, None)
+torch.cuda.synchronize()
+prep_ms = (time.perf_counter() - t0) * 1e3
+w1 = {l: get_parameter(pipe.text_encoder, p1.weight_name(l)).clone() for l in hp.layers}
+w2 = {l: get_parameter(pipe.text_encoder_2, p2.weight_name(l)).clone() for l in hp.layers_2}
+s2 = torch.cuda.Stream()
+
+def step():
+    with torch.no_grad():
+        for l, w in w1.items(): get_parameter(pipe.text_encoder, p1.weight_name(l)).copy_(w)
+        for l, w in w2.items(): get_parameter(pipe.text_encoder_2, p2.weight_name(l)).copy_(w)
+    s2.wait_stream(torch.cuda.current_stream())
+    run_encoder_edit(p1)
+    with torch.cuda.stream(s2):
+        run_encoder_edit(p2)
+    torch.cuda.current_stream().wait_stream(s2)
+
+for _ in range(2): step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+K = 5
+for _ in range(K): step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / K
+check_info(p1); check_info(p2)
+# each encoder alone
+def alone(p, ws, te):
+    def f():
+        with torch.no_grad():
+            for l, w in ws.items(): get_parameter(te, p.weight_name(l)).copy_(w)
+        run_encoder_edit(p)
+    for _ in range(2): f()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(K): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / K
+t1, t2 = alone(p1, w1, pipe.text_encoder), alone(p2, w2, pipe.text_encoder_2)
+print(json.dumps({"config": "sdxl dual text-encoder edit, 1 GPU", "concepts": N, "ms_per_step": dt * 1e3,
+                  "concept_edits_per_s": N / dt, "te1_alone_ms": t1 * 1e3, "te2_alone_ms": t2 * 1e3,
+                  "host_prepare_ms": prep_ms, "trie_rows": [p1.trie.n_nodes, p2.trie.n_nodes],
+                  "algorithmic_solve_flops": 8.1e11}))

@@ -249,3 +249,33 @@ def test_tree_attention_vs_dense_reference():
             ref[u, sl] = w @ vc[ch][:, sl]
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=2e-6)
     torch.testing.assert_close(out_rows.cpu(), ref[rows.cpu().long()], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("N,d,h,lam,ew,left", [(8, 128, 32, 50.0, 0.6, 3), (5, 192, 48, 90.0, 0.5, 1),
+                                              (100, 3072, 768, 4000.0, 0.5, 4), (1000, 3072, 768, 4000.0, 0.5, 2),
+                                              (300, 5120, 1280, 10000.0, 0.5, 5)])
+def test_dual_solver_vs_oracle(N, d, h, lam, ew, left):
+    """The Woodbury form (batched factor of lam*C', N x N system per layer) against the oracle's fp64 LU."""
+    K, Zc, zs, Cov, W0 = _edit_inputs(N, d, h, seed=N + d)
+    Cov2 = Cov * 1.5 + torch.eye(d) * 1e-3                       # a second layer's statistics in the same batch
+    adj_k, resid, upd = orc.closed_form_layer(K, Zc, zs, Cov, lam, ew, left)
+    fac = hip.factor_cov([Cov2.to(DEV), Cov.to(DEV)], lam, ew)
+    Wd = torch.empty(h, d, dtype=torch.float32, device=DEV)
+    out = hip.edit_layer_dual(K.to(DEV), Zc.to(DEV), zs.t().contiguous().to(DEV), fac, 1, ew, left,
+                              W0=W0.to(DEV), W=Wd, want_factors=True)
+    assert int(fac.info.item()) == 0 and int(out["ws"].info.item()) == 0
+    torch.testing.assert_close(out["Rt"].cpu(), resid.t().contiguous(), rtol=1e-14, atol=0)
+    assert (out["adj_k"].cpu() - adj_k).abs().max().item() <= 1e-8 * adj_k.abs().max().item()
+    scale = upd.abs().max().item()
+    dw_err = (out["dW"].cpu().double() - upd).abs().max().item()
+    assert dw_err <= 1e-6 * scale + 1e-12 and dw_err < 1e-4, (dw_err, scale)
+    assert (Wd.cpu() - (W0 + upd.float())).abs().max().item() <= 1e-6 * max(scale, 1.0)
+    # row-sharded M-solves (multi-GPU split) give the same Pt rows
+    ws2 = hip.DualWorkspace(N, d, h, DEV)
+    if N >= 4:
+        parts = []
+        for lo, hi in ((0, N // 2), (N // 2, N)):
+            hip.edit_layer_dual(K.to(DEV), Zc.to(DEV), zs.t().contiguous().to(DEV), fac, 1, ew, left, ws=ws2, rows=(lo, hi),
+                                want_dw=False)
+            parts.append(ws2.Pt[lo:hi].clone())
+        torch.testing.assert_close(torch.cat(parts), out["ws"].Pt[:N], rtol=1e-12, atol=1e-14)
