@@ -143,44 +143,62 @@ def main():
     hip.profile_enable([])
     d, h = 3072, 768
     n_rows = (lambda b: b[1] - b[0])(shard.bounds(args.concepts)) if world > 1 else args.concepts
-    nbk, nob = d // 128, d // 512
-    per_layer_flops = {   # ALGORITHMIC flops of one edited layer per class (SURVEY.md §8d counts)
-        "assemble": args.concepts * d * d,                                              # SYRK  N d^2
-        # two-level trailing updates (SYRK count): inner ones stay inside a 512-column block, the left-looking
-        # ones bring a whole block column up to date against all previous columns
-        "chol_inner": sum(((d - (j + 1) * 128) * w - w * w // 2) * 128
-                          for j in range(nbk - 1) for w in [(j // 4 + 1) * 512 - (j + 1) * 128] if w > 0),
-        "chol_trail": sum(((d - J * 512) * 512 - 512 * 512 // 2) * (J * 512) for J in range(1, nob)),
-        "chol_panel": sum((d - (j + 1) * 128) * 128 * 128 for j in range(nbk - 1)),    # triangular panel solves
-        # blocked TRSM, both directions; diag + update sum to the algorithmic 2 N d^2 (triangular count)
-        "trsm_update": 2 * (2 * n_rows * 512 * sum(d - (J + 1) * 512 for J in range(nob))),
-        "trsm_diag": 2 * (n_rows * nob * 512 * 512),
-        "delta_w": 2 * h * n_rows * d,
-    }
-    launches_per_layer = {"assemble": 1, "chol_trail": nob - 1, "chol_inner": nbk - nob, "chol_panel": nbk - 1,
-                          "trsm_update": 2 * (nob - 1),
-                          "trsm_diag": 2 * nob, "delta_w": 1}
+    N, L = args.concepts, len(LAYERS)
+    dual = plan.dual_ws is not None
+    Np = -(-N // 128) * 128
+
+    def chol_flops(n):          # (leaf+panel excluded) trailing updates of one n x n Cholesky, SYRK count, two-level schedule
+        nbk_, nob_ = n // 128, n // 512
+        inner = sum(((n - (j + 1) * 128) * w - w * w // 2) * 128
+                    for j in range(nbk_ - 1) for w in [(j // 4 + 1) * 512 - (j + 1) * 128] if w > 0)
+        trail = sum(((n - J * 512) * 512 - 512 * 512 // 2) * (J * 512) for J in range(1, nob_))
+        panel = sum((n - (j + 1) * 128) * 128 * 128 for j in range(nbk_ - 1))
+        return {"chol_inner": inner, "chol_trail": trail, "chol_panel": panel}
+
+    def trsm_flops(rows, n):    # right-sided two-level TRSM of `rows` rows against an n x n factor, both directions
+        nob_ = n // 512
+        return {"trsm_update": 2 * (2 * rows * 512 * sum(n - (J + 1) * 512 for J in range(nob_))),
+                "trsm_diag": 2 * (rows * nob_ * 512 * 512)}
+
+    # ALGORITHMIC flops per STEP and class (SURVEY.md §8d counting: SYRK = n^2 k, triangular solves = rows * n^2)
+    per_step_flops = {c: 0 for c in ("assemble", "chol_inner", "chol_trail", "chol_panel", "trsm_update", "trsm_diag", "delta_w")}
+    per_step_flops["delta_w"] = L * 2 * h * (N if dual else n_rows) * d
+    if dual:    # batched Cholesky of lam*C' (d x d) for L layers + per layer: M-solves on N rows, S = I + Pt Kt^T, S-solves on d rows
+        per_step_flops["assemble"] = L * N * N * d
+        for c, f in chol_flops(d).items():
+            per_step_flops[c] += L * f
+        for c, f in chol_flops(Np).items():
+            per_step_flops[c] += L * f
+        for c, f in trsm_flops(n_rows, d).items():
+            per_step_flops[c] += L * f
+        for c, f in trsm_flops(d, Np).items():
+            per_step_flops[c] += L * f
+    else:
+        per_step_flops["assemble"] = L * N * d * d
+        for c, f in chol_flops(d).items():
+            per_step_flops[c] += L * f
+        for c, f in trsm_flops(n_rows, d).items():
+            per_step_flops[c] += L * f
     classes = {c: {"ms_per_step": prof[c][0] / args.steps, "launches_per_step": prof[c][1] / args.steps}
                for c in prof}
     roofline = None
-    cands = [c for c in per_layer_flops if c in prof and prof[c][1]]
+    cands = [c for c in per_step_flops if c in prof and prof[c][1] and per_step_flops[c] > 0]
     if cands:
         top = max(cands, key=lambda c: prof[c][0])
         ms, launches = prof[top]
-        avg_s = ms * 1e-3 / launches
-        flops_per_launch = per_layer_flops[top] / launches_per_layer[top]
-        achieved = flops_per_launch / avg_s / 1e12
-        names = {"assemble": "gemm_f64_kernel<!KC,!KC,128,128,16,2,4,EpiAssemble> (A = lam C' + K^T K, SYRK)",
-                 "chol_trail": "gemm_f64_kernel<KC,KC,64,64,16,2,2,EpiAxpby> launched as left-looking Cholesky block-column update",
+        achieved = per_step_flops[top] * args.steps / (ms * 1e-3) / 1e12      # = flops per launch / average launch duration
+        names = {"assemble": "gemm_f64_kernel<...> launched as SYRK (K^T K, or Pt Kt^T in the dual solver)",
+                 "chol_trail": "gemm_f64_kernel<KC,KC,*,*,16,EpiAxpby> launched as left-looking Cholesky block-column update",
                  "chol_inner": "gemm_f64_kernel<KC,KC,*,64,16,2,2,EpiAxpby> launched as in-block Cholesky trailing update",
-                 "chol_panel": "gemm_f64_kernel<KC,KC,64,64,16,2,2,EpiAxpby> launched as Cholesky panel solve",
+                 "chol_panel": "gemm_f64_kernel<KC,KC,32,64,16,2,2,EpiAxpby> launched as Cholesky panel solve",
                  "trsm_update": "gemm_f64_kernel<KC,*,*,*,16,EpiAxpby> launched as rank-512 TRSM update",
-                 "trsm_diag": "gemm_f64_kernel<KC,*,64,64,16,2,2,EpiAxpby> launched as TRSM diagonal-block multiply",
-                 "delta_w": "gemm_f64_kernel<!KC,!KC,64,64,16,2,2,EpiDeltaW> (dW = R^T X)"}
+                 "trsm_diag": "gemm_f64_kernel<KC,*,32,64,16,2,2,EpiAxpby> launched as TRSM diagonal-block multiply",
+                 "delta_w": "gemm_f64_kernel<!KC,*,64,64,16,2,2,EpiDeltaW> (dW = R^T X)"}
         roofline = {"bound": "mfma", "kernel": names[top], "class": top, "achieved": achieved,
                     "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F64_MFMA_PEAK_TFLOPS,
-                    "traffic": None, "avg_launch_us": avg_s * 1e6, "launches": launches,
-                    "flops_per_launch": flops_per_launch}
+                    "traffic": None, "avg_launch_us": ms * 1e3 / launches, "launches": launches,
+                    "flops_per_launch": per_step_flops[top] * args.steps / launches,
+                    "solver": "dual" if dual else "direct"}
 
     out = {
         "metric": "concept-edits/sec (1 000-concept batch, SD-v1.4)", "value": value, "unit": "concept-edits/s",

@@ -31,9 +31,10 @@ def _setup(tmp, n_req):
     return reqs, hp_d, names, cache
 
 
-def _worker(rank, world, port, tmp, n_req):
+def _worker(rank, world, port, tmp, n_req, solver):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      EMCID_SOLVER=solver)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from emcid_amd import emcid_main as em, synthetic as syn
@@ -49,14 +50,15 @@ def _worker(rank, world, port, tmp, n_req):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_req", [7, 8])
-def test_two_ranks_match_single_process(tmp_path, n_req):
+@pytest.mark.parametrize("n_req,solver", [(7, "direct"), (8, "direct"), (7, "dual"), (8, "dual")])
+def test_two_ranks_match_single_process(tmp_path, n_req, solver, monkeypatch):
     from emcid_amd import emcid_main as em, synthetic as syn
     from emcid_amd.emcid_hparams import EMCIDHyperParams
     from emcid_amd.nethook import get_parameter
     tmp = str(tmp_path)
     reqs, hp_d, names, cache = _setup(tmp, n_req)
-    mp.spawn(_worker, args=(2, _free_port(), tmp, n_req), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), tmp, n_req, solver), nprocs=2, join=True)
+    monkeypatch.setenv("EMCID_SOLVER", solver)
     em.clear_caches()
     pipe = syn.build_pipe("toy", "cuda:0")
     w0 = {n: get_parameter(pipe.text_encoder, n + ".weight").cpu().numpy().copy() for n in names}
