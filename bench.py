@@ -80,11 +80,17 @@ def main():
     if args.gpus != world:
         if args.gpus > 1:
             raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+    backend = os.environ.get("EMCID_BENCH_BACKEND", "nccl")      # "gloo": functional test of this script on a 1-GPU box
+    if backend == "gloo":
+        local = 0                                                 # every rank shares cuda:0, collectives staged via host
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
     shard = ConceptShard(rank, world, None)
 
     workdir = Path(tempfile.gettempdir()) / f"emcid_bench_{os.getuid()}"
@@ -126,7 +132,7 @@ def main():
     elapsed = time.perf_counter() - t0
     check_info(plan)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     value = args.concepts * args.steps / elapsed

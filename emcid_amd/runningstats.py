@@ -131,8 +131,14 @@ class SecondMoment(Stat):
         acc = self._lower if self._lower is not None else self._full
         if acc is None:
             raise RuntimeError("all_reduce_ on an empty SecondMoment")
-        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
-        cnt = torch.tensor([self.count], dtype=torch.int64, device=acc.device)
+        staged = acc.is_cuda and dist.get_backend(group) == "gloo"   # gloo (tests) cannot take HBM tensors; RCCL does
+        if staged:
+            host = acc.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            acc.copy_(host)
+        else:
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+        cnt = torch.tensor([self.count], dtype=torch.int64, device="cpu" if staged else acc.device)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
         self.count = int(cnt.item())
         if self._lower is not None:

@@ -71,3 +71,39 @@ def test_two_ranks_match_single_process(tmp_path, n_req, solver, monkeypatch):
         dw = single.astype(np.float64) - w0[n]
         err = np.abs(r0[n].astype(np.float64) - single).max()
         assert err <= 1e-5 * np.abs(dw).max(), (n, err)                  # different batch split in the fp32 forward
+
+
+def _stage0_worker(rank, world, port, tmp):
+    import json
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from emcid_amd import synthetic as syn
+        from emcid_amd.layer_stats import layer_stats_text_encoder_multi
+        pipe = syn.build_pipe("toy", "cuda:0")
+        names = ["encoder.layers.1.mlp.fc2", "encoder.layers.3.mlp.fc2"]
+        layer_stats_text_encoder_multi(pipe.text_encoder, pipe.tokenizer, names, tmp + "/stats_sharded", sample_size=300,
+                                       batch_tokens=600, data_path=tmp + "/caps.json", progress=None,
+                                       shard=(rank, world))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stage0_caption_shards_sum_to_single_process(tmp_path):
+    """Caption-sharded Stage 0 on two ranks (all-reduce of mom2/count) == the single-process statistic."""
+    from emcid_amd import synthetic as syn
+    from emcid_amd.layer_stats import layer_stats_text_encoder_multi, stats_filename
+    tmp = str(tmp_path)
+    syn.write_captions(tmp + "/caps.json", 400, seed=4)
+    mp.spawn(_stage0_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+    pipe = syn.build_pipe("toy", "cuda:0")
+    names = ["encoder.layers.1.mlp.fc2", "encoder.layers.3.mlp.fc2"]
+    single = layer_stats_text_encoder_multi(pipe.text_encoder, pipe.tokenizer, names, tmp + "/stats_single", sample_size=300,
+                                            batch_tokens=600, data_path=tmp + "/caps.json", progress=None)
+    for n in names:
+        f = stats_filename(tmp + "/stats_sharded", "text_encoder", "ccs_filtered", n, "float32", ["mom2"], 600, 300)
+        with np.load(f) as z:
+            assert int(z["mom2.count"]) == single[n].mom2.count
+            ref = single[n].mom2.mom2.numpy()
+            assert np.abs(z["mom2.mom2"] - ref).max() <= 2e-5 * np.abs(ref).max()
