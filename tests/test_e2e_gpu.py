@@ -292,3 +292,31 @@ def test_dual_and_direct_solvers_agree_end_to_end(tmp_path, kind, layers, n_req,
             torch.testing.assert_close(r_dir, r_dual, rtol=1e-12, atol=0)
         dw = (out["direct"][1][n] - out["dual"][1][n]).abs().max().item()
         assert dw <= 1e-5, (li, dw)
+
+
+def test_sdxl_real_dims_apply_vs_oracle(tmp_path):
+    """BASELINE config 4 dims: TE1 768/3072 layers 8-10 (lam 4000) + TE2 1280/5120 layers 26-30 (lam 10000),
+    two encoders on two HIP streams, TE2 double-apply quirk included — vs the oracle's CPU restatement."""
+    reqs = syn.make_requests(12, names="syllable")
+    hp_d = syn.sdxl_hparams_dict()
+    n1 = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers"]]
+    n2 = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers_2"]]
+    cache = str(tmp_path / "cache") + "/"
+    syn.write_vstar_cache(cache, reqs, 768, seed=1, scale=0.5)
+    syn.write_vstar_cache(cache, reqs, 1280, seed=5, scale=0.5, suffix="_2")
+    syn.write_stats_cache(tmp_path / "s1", n1, 3072, hp_d["mom2_n_samples"], seed=2, t=6144)
+    syn.write_stats_cache(tmp_path / "s2", n2, 5120, hp_d["mom2_n_samples"], seed=7, t=10240)
+    cpu = syn.build_pipe("sd-v1.4", "cpu", sdxl=True, syllables=True)
+    w0 = {("1", n): orc.get_parameter(cpu.text_encoder, n + ".weight").clone() for n in n1}
+    w0.update({("2", n): orc.get_parameter(cpu.text_encoder_2, n + ".weight").clone() for n in n2})
+    orc.apply_emcid_to_sdxl_text_encoders(cpu, reqs, copy.deepcopy(hp_d), cache_name=cache, stat_dir=str(tmp_path / "s1"),
+                                          stat_dir_2=str(tmp_path / "s2"))
+    gpu = syn.build_pipe("sd-v1.4", DEV, sdxl=True, syllables=True)
+    em.apply_emcid_to_sdxl_text_encoders(gpu, reqs, EMCIDXLHyperParams(**hp_d), DEV, cache_name=cache,
+                                         stat_dir=str(tmp_path / "s1"), stat_dir_2=str(tmp_path / "s2"), verbose=False)
+    for tag, names, ce, ge in (("1", n1, cpu.text_encoder, gpu.text_encoder), ("2", n2, cpu.text_encoder_2, gpu.text_encoder_2)):
+        for n in names:
+            ref = orc.get_parameter(ce, n + ".weight").double() - w0[(tag, n)].double()
+            got = get_parameter(ge, n + ".weight").cpu().double() - w0[(tag, n)].double()
+            err = (got - ref).abs().max().item()
+            assert err < 1e-4 and err <= 1e-4 * ref.abs().max().item(), (tag, n, err, ref.abs().max().item())
