@@ -320,3 +320,26 @@ def test_sdxl_real_dims_apply_vs_oracle(tmp_path):
             got = get_parameter(ge, n + ".weight").cpu().double() - w0[(tag, n)].double()
             err = (got - ref).abs().max().item()
             assert err < 1e-4 and err <= 1e-4 * ref.abs().max().item(), (tag, n, err, ref.abs().max().item())
+
+
+def test_eleven_layer_edit_vs_oracle(tmp_path):
+    """The shipped `ly-11` hparams edit layers 0..10 (L = 11): batched factorization of eleven lam*C' matrices,
+    residual split over 11 layers — HIP path vs the oracle at SD-v1.4 dims."""
+    layers = tuple(range(11))
+    reqs = syn.make_requests(30, ragged=True, names="syllable")
+    hp_d = syn.sd_hparams_dict(layers=layers, mom2_update_weight=10000)
+    names = [hp_d["rewrite_module_tmp"].format(l) for l in layers]
+    cache = str(tmp_path / "cache") + "/"
+    syn.write_vstar_cache(cache, reqs, 768, seed=1, scale=0.5)
+    syn.write_stats_cache(tmp_path / "stats", names, 3072, hp_d["mom2_n_samples"], seed=2, t=6144)
+    cpu = syn.build_pipe("sd-v1.4", "cpu", syllables=True)
+    w0 = {n: orc.get_parameter(cpu.text_encoder, n + ".weight").clone() for n in names}
+    orc.apply_emcid_to_text_encoder(cpu, reqs, copy.deepcopy(hp_d), cache_name=cache, stats_dir=str(tmp_path / "stats"))
+    gpu = syn.build_pipe("sd-v1.4", DEV, syllables=True)
+    em.apply_emcid_to_text_encoder(gpu, reqs, EMCIDHyperParams(**hp_d), DEV, cache_name=cache,
+                                   stats_dir=str(tmp_path / "stats"), verbose=False)
+    for n in names:
+        ref = orc.get_parameter(cpu.text_encoder, n + ".weight").double() - w0[n].double()
+        got = get_parameter(gpu.text_encoder, n + ".weight").cpu().double() - w0[n].double()
+        err = (got - ref).abs().max().item()
+        assert err < 1e-4 and err <= 1e-4 * ref.abs().max().item(), (n, err, ref.abs().max().item())
