@@ -161,30 +161,35 @@ def main():
         panel = sum((n - (j + 1) * 128) * 128 * 128 for j in range(nbk_ - 1))
         return {"chol_inner": inner, "chol_trail": trail, "chol_panel": panel}
 
-    def trsm_flops(rows, n):    # right-sided two-level TRSM of `rows` rows against an n x n factor, both directions
+    def trsm_flops(rows, n, directions=2):    # right-sided two-level TRSM of `rows` rows against an n x n factor
         nob_ = n // 512
-        return {"trsm_update": 2 * (2 * rows * 512 * sum(n - (J + 1) * 512 for J in range(nob_))),
-                "trsm_diag": 2 * (rows * nob_ * 512 * 512)}
+        return {"trsm_update": directions * (2 * rows * 512 * sum(n - (J + 1) * 512 for J in range(nob_))),
+                "trsm_diag": directions * (rows * nob_ * 512 * 512)}
 
-    # ALGORITHMIC flops per STEP and class (SURVEY.md §8d counting: SYRK = n^2 k, triangular solves = rows * n^2)
+    # flops per STEP and class, counted like SURVEY.md §8d (SYRK = n^2 k, triangular solve = rows * n^2 per direction)
+    # for the launches each solver actually makes
     per_step_flops = {c: 0 for c in ("assemble", "chol_inner", "chol_trail", "chol_panel", "trsm_update", "trsm_diag", "delta_w")}
-    per_step_flops["delta_w"] = L * 2 * h * (N if dual else n_rows) * d
-    if dual:    # batched Cholesky of lam*C' (d x d) for L layers + per layer: M-solves on N rows, S = I + Pt Kt^T, S-solves on d rows
+
+    def add(table, times=1):
+        for c, f in table.items():
+            per_step_flops[c] += times * f
+
+    if dual:
+        # batched Cholesky of lam*C' (d x d) for the L layers; per layer (apply-only form): forward solve of the N concept
+        # rows against M's factor, SYRK S = I + Yt Yt^T, Cholesky of S, two solves of h rows against S's factor,
+        # V = Z^T Yt, backward solve of h rows against M's factor
+        add(chol_flops(d), L)
+        add(chol_flops(Np), L)
+        add(trsm_flops(n_rows, d, 1), L)
+        add(trsm_flops(h, Np, 2), L)
+        add(trsm_flops(h, d, 1), L)
         per_step_flops["assemble"] = L * N * N * d
-        for c, f in chol_flops(d).items():
-            per_step_flops[c] += L * f
-        for c, f in chol_flops(Np).items():
-            per_step_flops[c] += L * f
-        for c, f in trsm_flops(n_rows, d).items():
-            per_step_flops[c] += L * f
-        for c, f in trsm_flops(d, Np).items():
-            per_step_flops[c] += L * f
+        per_step_flops["delta_w"] = L * 2 * h * N * d
     else:
+        add(chol_flops(d), L)
+        add(trsm_flops(n_rows, d, 2), L)
         per_step_flops["assemble"] = L * N * d * d
-        for c, f in chol_flops(d).items():
-            per_step_flops[c] += L * f
-        for c, f in trsm_flops(n_rows, d).items():
-            per_step_flops[c] += L * f
+        per_step_flops["delta_w"] = L * 2 * h * n_rows * d
     classes = {c: {"ms_per_step": prof[c][0] / args.steps, "launches_per_step": prof[c][1] / args.steps}
                for c in prof}
     roofline = None

@@ -91,6 +91,17 @@ __global__ __launch_bounds__(256) void apply_u_kernel(const double* __restrict__
     }
 }
 
+// W = W0 + float(U), dW = float(U) with U[h][ldu] (the apply-only dual path leaves U with the padded leading dimension)
+__global__ __launch_bounds__(256) void apply_u2d_kernel(const double* __restrict__ U, int64_t ldu, const float* __restrict__ W0,
+                                                         float* __restrict__ W, float* __restrict__ dW, int d) {
+    const int i = blockIdx.x;
+    for (int j = threadIdx.x; j < d; j += 256) {
+        const float f = (float)U[(int64_t)i * ldu + j];
+        if (dW) dW[(int64_t)i * d + j] = f;
+        if (W) W[(int64_t)i * d + j] = W0[(int64_t)i * d + j] + f;
+    }
+}
+
 // ---- diagonal leaf: Cholesky of one NB x NB block + its inverse, one workgroup ---------------------------
 //
 // The leaf is the serial spine of the factorization (d sequential pivots), so it is built for latency:
@@ -454,11 +465,11 @@ static int cholesky_impl(double* A, double* L, int64_t dp, int64_t lda, double* 
 
 // Bt[M, dp] := Bt (L L^T)^-1, right-looking over OB-wide column blocks: multiply by the inverted diagonal
 // block, then one rank-OB GEMM update of every remaining column (forward), the same backward.
-static int cholesky_solve_impl(const double* L, int64_t dp, int64_t lda, const double* invw, double* Bt, double* Yt,
-                               int64_t Mrows, int64_t ldb, hipStream_t st) {
+// forward half:  Yt L^T = Bt   (Bt is consumed as scratch)
+static void trsm_forward(const double* L, int64_t dp, int64_t lda, const double* invw, double* Bt, double* Yt, int M,
+                         int64_t ldb, hipStream_t st) {
     const int nob = (int)((dp + OB - 1) / OB);
-    const int M = (int)Mrows;
-    for (int J = 0; J < nob; ++J) {  // forward: Yt L^T = Bt
+    for (int J = 0; J < nob; ++J) {
         const int64_t c = (int64_t)J * OB;
         const int w = (int)((dp - c) < OB ? (dp - c) : OB);
         const double* inv = inv_block(invw, J);
@@ -475,7 +486,13 @@ static int cholesky_solve_impl(const double* L, int64_t dp, int64_t lda, const d
             launch_gemm_f64<true, true>(b, EpiAxpby{Bt + c + w, ldb, -1.0, 1.0}, st);
         }
     }
-    for (int J = nob - 1; J >= 0; --J) {  // backward: Xt L = Yt, Xt written over Bt
+}
+
+// backward half:  Xt L = Yt   (Yt is consumed as scratch, Xt may be any buffer of the same shape)
+static void trsm_backward(const double* L, int64_t dp, int64_t lda, const double* invw, double* Yt, double* Xt, int M,
+                          int64_t ldb, hipStream_t st) {
+    const int nob = (int)((dp + OB - 1) / OB);
+    for (int J = nob - 1; J >= 0; --J) {
         const int64_t c = (int64_t)J * OB;
         const int w = (int)((dp - c) < OB ? (dp - c) : OB);
         const double* inv = inv_block(invw, J);
@@ -483,14 +500,20 @@ static int cholesky_solve_impl(const double* L, int64_t dp, int64_t lda, const d
         a.tri = 2;   // B(k, n) = inv[k][n], zero for k < n
         {
             ScopedProf sp(KC_TRSM_DIAG, st);
-            launch_gemm_f64<true, false>(a, EpiAxpby{Bt + c, ldb, 1.0, 0.0}, st);
+            launch_gemm_f64<true, false>(a, EpiAxpby{Xt + c, ldb, 1.0, 0.0}, st);
         }
         if (c > 0) {
-            GemmShape b{Bt + c, ldb, L + c * lda, lda, M, (int)c, w, 0};
+            GemmShape b{Xt + c, ldb, L + c * lda, lda, M, (int)c, w, 0};
             ScopedProf sp(KC_TRSM_UPDATE, st);
             launch_gemm_f64<true, false>(b, EpiAxpby{Yt, ldb, -1.0, 1.0}, st);
         }
     }
+}
+
+static int cholesky_solve_impl(const double* L, int64_t dp, int64_t lda, const double* invw, double* Bt, double* Yt,
+                               int64_t Mrows, int64_t ldb, hipStream_t st) {
+    trsm_forward(L, dp, lda, invw, Bt, Yt, (int)Mrows, ldb, st);
+    trsm_backward(L, dp, lda, invw, Yt, Bt, (int)Mrows, ldb, st);   // Xt written over Bt
     return check_launch("emcid_cholesky_solve_f64");
 }
 
@@ -618,7 +641,7 @@ __global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __rest
 
 struct DualWorkspace {
     int64_t Np, dp, hp;
-    int64_t off_K, off_P, off_Y, off_R, off_S, off_LS, off_invS, off_PT, off_Y2, total;   // doubles
+    int64_t off_K, off_P, off_Y, off_R, off_S, off_LS, off_invS, off_PT, off_Y2, off_V, off_U, total;   // doubles
     DualWorkspace(int64_t N, int64_t d, int64_t h) {
         Np = round_up(N, NB);
         dp = round_up(d, NB);
@@ -633,6 +656,8 @@ struct DualWorkspace {
         off_invS = o; o += inv_doubles(Np);
         off_PT = o; o += dp * Np;
         off_Y2 = o; o += dp * Np;
+        off_V = o; o += hp * dp;
+        off_U = o; o += hp * dp;
         total = o;
     }
 };
@@ -948,6 +973,85 @@ int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, const float* W0,
     }
     if (adjk_out) hipLaunchKernelGGL(copy2d_f64_kernel, dim3((unsigned)d), dim3(256), 0, st, PT, Np, adjk_out, N, (int)d, (int)N);
     if (Rt_out) hipLaunchKernelGGL(copy2d_f64_kernel, dim3((unsigned)N), dim3(256), 0, st, R, ws.hp, Rt_out, h, (int)N, (int)h);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+/* ---- dual solver, apply-only form: adj_k is never formed -----------------------------------------------------------
+ * With M = L L^T:  Yt = Kt64 L^-T,  S = I + Yt Yt^T,  Z = S^-1 Rt,  U = Rt^T Xt = (Z^T Yt) L^-1,  W = W0 + float(U).
+ * One forward solve on the N concept rows, a true SYRK, the N x N Cholesky, two solves with only h right-hand sides,
+ * one GEMM and one backward solve on h rows.  Same algebra as stage1 + stage2 by associativity. */
+int emcid_edit_dual_apply_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
+                                     double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
+                                     int64_t layer_index, int64_t n_lo, int64_t n_hi, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+    EMCID_CHECK_ARG(K && Zc && zs_t && N > 0 && d > 0 && h > 0 && layers_left > 0 && cov_factor_ws && workspace);
+    EMCID_CHECK_ARG(0 <= layer_index && layer_index < n_layers && 0 <= n_lo && n_lo < n_hi && n_hi <= N);
+    DualWorkspace ws(N, d, h);
+    if (workspace_bytes < ws.total * (int64_t)sizeof(double)) return fail(EMCID_ERR_WORKSPACE, __func__, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double* base = (double*)workspace;
+    double *Kt = base + ws.off_K, *Bs = base + ws.off_P, *Yt = base + ws.off_Y, *R = base + ws.off_R;
+    const int64_t dp = ws.dp, s_mat = dp * dp;
+    const double* Lb = (const double*)cov_factor_ws + n_layers * s_mat + layer_index * s_mat;
+    const double* Ib = (const double*)cov_factor_ws + 2 * n_layers * s_mat + layer_index * inv_doubles(dp);
+    const double s = sqrt(edit_weight / 0.5);
+    {
+        ScopedProf sp(KC_PREP, st);
+        hipLaunchKernelGGL(prep_kr_kernel, dim3((unsigned)ws.Np), dim3(256), 0, st, K, Zc, zs_t, (int)N, (int)d, (int)h, s,
+                           (double)layers_left, Kt, (int)ws.Np, (int)dp, R, (int)ws.hp);
+    }
+    const int64_t rows = n_hi - n_lo;
+    if (hipMemcpyAsync(Bs + n_lo * dp, Kt + n_lo * dp, rows * dp * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(EMCID_ERR_HIP, __func__, "hipMemcpyAsync");
+    return with_graph(make_key(5, {Lb, Ib, Bs + n_lo * dp, Yt + n_lo * dp}, {dp, rows}), st, [&](hipStream_t q) {
+        trsm_forward(Lb, dp, dp, Ib, Bs + n_lo * dp, Yt + n_lo * dp, (int)rows, dp, q);
+        return check_launch("emcid_edit_dual_apply_stage1_f64");
+    });
+}
+
+/* address of the Yt stack [Np, dp] inside a dual workspace (multi-GPU: ranks all-gather their row blocks there) */
+double* emcid_edit_dual_yt(void* workspace, int64_t N, int64_t d, int64_t h) {
+    if (!workspace || N <= 0 || d <= 0 || h <= 0) return nullptr;
+    return (double*)workspace + DualWorkspace(N, d, h).off_Y;
+}
+
+int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void* cov_factor_ws, int64_t n_layers,
+                                     int64_t layer_index, const float* W0, float* W, float* dW_out, void* workspace,
+                                     int64_t workspace_bytes, int* info_dev, void* stream) {
+    EMCID_CHECK_ARG(N > 0 && d > 0 && h > 0 && workspace && info_dev && cov_factor_ws && ((W == nullptr) || (W0 != nullptr)));
+    EMCID_CHECK_ARG(0 <= layer_index && layer_index < n_layers && (W || dW_out));
+    DualWorkspace ws(N, d, h);
+    if (workspace_bytes < ws.total * (int64_t)sizeof(double)) return fail(EMCID_ERR_WORKSPACE, __func__, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double* base = (double*)workspace;
+    double *Yt = base + ws.off_Y, *R = base + ws.off_R, *S = base + ws.off_S, *LS = base + ws.off_LS, *invS = base + ws.off_invS;
+    double *RT = base + ws.off_PT, *Y2 = base + ws.off_Y2, *V = base + ws.off_V, *U = base + ws.off_U;
+    const int64_t dp = ws.dp, Np = ws.Np, hp = ws.hp, s_mat = dp * dp;
+    const double* Lb = (const double*)cov_factor_ws + n_layers * s_mat + layer_index * s_mat;
+    const double* Ib = (const double*)cov_factor_ws + 2 * n_layers * s_mat + layer_index * inv_doubles(dp);
+    EMCID_TRY(with_graph(make_key(6, {Yt, R, S, LS, RT, V, U, info_dev}, {dp, Np, N, hp, (int64_t)(uintptr_t)Lb}), st,
+                         [&](hipStream_t q) {
+        if (Np > N) hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, q, Yt + N * dp, (Np - N) * dp);
+        {
+            ScopedProf sp(KC_ASSEMBLE, q);      // S = I + Yt Yt^T (lower tiles)
+            GemmShape g{Yt, dp, Yt, dp, (int)Np, (int)Np, (int)dp, 1};
+            launch_gemm_f64<true, true>(g, EpiPlusIdentity{S, Np}, q);
+        }
+        EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q));
+        // RT[h, Np] = Rt^T ; Z^T = RT S^-1 (two solves with h rows)
+        hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)((hp + 31) / 32), (unsigned)(Np / 32)), dim3(256), 0, q, R, hp, RT,
+                           Np, (int)Np, (int)hp);
+        EMCID_TRY(cholesky_solve_impl(LS, Np, Np, invS, RT, Y2, h, Np, q));
+        {
+            ScopedProf sp(KC_DELTA_W, q);       // V[h, dp] = Z^T Yt
+            GemmShape g{RT, Np, Yt, dp, (int)h, (int)dp, (int)Np, 0};
+            launch_gemm_f64<true, false>(g, EpiAxpby{V, dp, 1.0, 0.0}, q);
+        }
+        trsm_backward(Lb, dp, dp, Ib, V, U, (int)h, dp, q);   // U L = V
+        return check_launch("emcid_edit_dual_apply_stage2_f64");
+    }));
+    hipLaunchKernelGGL(apply_u2d_kernel, dim3((unsigned)h), dim3(256), 0, st, U, dp, W0, W, dW_out, (int)d);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }

@@ -215,6 +215,14 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
         if dual:
             torch.cuda.current_stream(dev).wait_event(fac_done)
             sharded = plan.shard.world > 1
+            if not keep_factors:   # only the edited weights are wanted: the form that never builds adj_k
+                res = hip.edit_layer_dual_apply(
+                    K, Zc, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, backups[layer], weights[layer].data,
+                    ws=plan.dual_ws, rows=plan.shard.bounds(plan.n_total) if sharded else None,
+                    gather_yt=(lambda rows_: _all_gather_rows(rows_.contiguous(), plan)) if sharded else None)
+                edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], None, None,
+                                       K if trace else None, Zc if trace else None))
+                return
             res = hip.edit_layer_dual(
                 K, Zc, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, W0=backups[layer], W=weights[layer].data,
                 want_factors=keep_factors, ws=plan.dual_ws,

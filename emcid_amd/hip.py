@@ -23,6 +23,7 @@ EXPORTS = [
     "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32", "emcid_tree_attention_f32", "emcid_debug_leaf_stamps",
     "emcid_cov_factor_workspace_bytes", "emcid_factor_cov_f64", "emcid_edit_dual_workspace_bytes",
     "emcid_edit_dual_stage1_f64", "emcid_edit_dual_pt", "emcid_edit_dual_stage2_f64",
+    "emcid_edit_dual_apply_stage1_f64", "emcid_edit_dual_yt", "emcid_edit_dual_apply_stage2_f64",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner"]
@@ -71,6 +72,9 @@ def load():
         "emcid_edit_dual_stage1_f64": (i32, [p, p, p, i64, i64, i64, f64, i32, p, i64, i64, i64, i64, p, i64, p]),
         "emcid_edit_dual_pt": (p, [p, i64, i64, i64]),
         "emcid_edit_dual_stage2_f64": (i32, [i64, i64, i64, p, p, p, p, p, p, i64, p, p]),
+        "emcid_edit_dual_apply_stage1_f64": (i32, [p, p, p, i64, i64, i64, f64, i32, p, i64, i64, i64, i64, p, i64, p]),
+        "emcid_edit_dual_yt": (p, [p, i64, i64, i64]),
+        "emcid_edit_dual_apply_stage2_f64": (i32, [i64, i64, i64, p, i64, i64, p, p, p, p, i64, p, p]),
         "emcid_cholesky_solve_f64": (i32, [p, i64, i64, p, p, p, i64, i64, p]),
         "emcid_delta_w_f64": (i32, [p, i64, p, i64, i64, i64, i64, p, p, i64, p, p, p]),
         "emcid_dgemm_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, p]),
@@ -372,6 +376,9 @@ class DualWorkspace:
         pt = load().emcid_edit_dual_pt(_ptr(self.buf), N, d, h)
         off = (pt - self.buf.data_ptr()) // 8
         self.Pt = self.buf[off:off + self.Np * self.dp].view(self.Np, self.dp)   # the Pt stack, rows = concepts
+        yt = load().emcid_edit_dual_yt(_ptr(self.buf), N, d, h)
+        off = (yt - self.buf.data_ptr()) // 8
+        self.Yt = self.buf[off:off + self.Np * self.dp].view(self.Np, self.dp)   # the Yt stack of the apply-only form
 
 
 def edit_layer_dual(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_weight: float, layers_left: int,
@@ -404,3 +411,29 @@ def edit_layer_dual(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_wei
                                           _ptr(Rt), _ptr(dW), _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32),
                                           _stream(K)), "emcid_edit_dual_stage2_f64")
     return {"adj_k": adj_k, "Rt": Rt, "dW": dW, "ws": ws}
+
+
+def edit_layer_dual_apply(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_weight: float, layers_left: int,
+                          W0, W, want_dw: bool = True, ws: Optional[DualWorkspace] = None, rows=None, gather_yt=None):
+    """Apply-only dual solver: W = W0 + float(U) without ever forming adj_k.  Returns dict(dW, ws)."""
+    N, d = K.shape
+    h = Zc.shape[1]
+    for t, nm in ((K, "K"), (Zc, "Zc"), (zs_t, "zs_t"), (W, "W"), (W0, "W0")):
+        assert t.is_contiguous(), nm
+    assert zs_t.shape == (N, h) and factors.d == d and W.shape == (h, d)
+    if ws is None or ws.key != (N, d, h):
+        ws = DualWorkspace(N, d, h, K.device)
+    lo, hi = rows if rows is not None else (0, N)
+    lib = load()
+    _check(lib.emcid_edit_dual_apply_stage1_f64(
+        _ptr(K, torch.float32, "K"), _ptr(Zc, torch.float32, "Zc"), _ptr(zs_t, torch.float32, "zs_t"), N, d, h,
+        float(edit_weight), int(layers_left), _ptr(factors.buf), factors.n_layers, int(layer_index), lo, hi,
+        _ptr(ws.buf), ws.nbytes, _stream(K)), "emcid_edit_dual_apply_stage1_f64")
+    if gather_yt is not None:
+        ws.Yt[:N].copy_(gather_yt(ws.Yt[lo:hi]))
+    dW = torch.empty(h, d, dtype=torch.float32, device=K.device) if want_dw else None
+    _check(lib.emcid_edit_dual_apply_stage2_f64(N, d, h, _ptr(factors.buf), factors.n_layers, int(layer_index),
+                                                _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"), _ptr(dW),
+                                                _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32), _stream(K)),
+           "emcid_edit_dual_apply_stage2_f64")
+    return {"dW": dW, "ws": ws}

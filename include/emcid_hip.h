@@ -154,6 +154,19 @@ double* emcid_edit_dual_pt(void* workspace, int64_t N, int64_t d, int64_t h);
 int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, const float* W0, float* W, double* adjk_out, double* Rt_out,
                                float* dW_out, void* workspace, int64_t workspace_bytes, int* info_dev, void* stream);
 
+/* Apply-only form of the dual solver (adj_k is never formed; used when only the edited weights are wanted):
+ *   Yt = Kt64 L^-T (M = L L^T),  S = I + Yt Yt^T,  Z = S^-1 Rt,  U = (Z^T Yt) L^-1,  W = W0 + float(U).
+ * stage1 computes rows [n_lo, n_hi) of Yt (one forward solve), emcid_edit_dual_yt gives the Yt stack [Np, dp] inside the
+ * workspace (multi-GPU all-gather target), stage2 needs all rows of Yt. */
+int emcid_edit_dual_apply_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
+                                     double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
+                                     int64_t layer_index, int64_t n_lo, int64_t n_hi, void* workspace,
+                                     int64_t workspace_bytes, void* stream);
+double* emcid_edit_dual_yt(void* workspace, int64_t N, int64_t d, int64_t h);
+int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void* cov_factor_ws, int64_t n_layers,
+                                     int64_t layer_index, const float* W0, float* W, float* dW_out, void* workspace,
+                                     int64_t workspace_bytes, int* info_dev, void* stream);
+
 /* The stages of emcid_edit_layer_f64 as separate calls (used by tests and micro-benchmarks). */
 
 /* A[d,d] (f64, ld lda, LOWER triangle valid) = lam_c * double(fl32(fl32(C*cw)/0.5f)) + Kt64^T Kt64,

@@ -270,6 +270,13 @@ def test_dual_solver_vs_oracle(N, d, h, lam, ew, left):
     dw_err = (out["dW"].cpu().double() - upd).abs().max().item()
     assert dw_err <= 1e-6 * scale + 1e-12 and dw_err < 1e-4, (dw_err, scale)
     assert (Wd.cpu() - (W0 + upd.float())).abs().max().item() <= 1e-6 * max(scale, 1.0)
+    # apply-only form (adj_k never formed): same weights
+    Wa = torch.empty(h, d, dtype=torch.float32, device=DEV)
+    oa = hip.edit_layer_dual_apply(K.to(DEV), Zc.to(DEV), zs.t().contiguous().to(DEV), fac, 1, ew, left, W0.to(DEV), Wa)
+    assert int(oa["ws"].info.item()) == 0
+    dwa_err = (oa["dW"].cpu().double() - upd).abs().max().item()
+    assert dwa_err <= 1e-6 * scale + 1e-12 and dwa_err < 1e-4, (dwa_err, scale)
+    assert (Wa.cpu() - (W0 + upd.float())).abs().max().item() <= 1e-6 * max(scale, 1.0)
     # row-sharded M-solves (multi-GPU split) give the same Pt rows
     ws2 = hip.DualWorkspace(N, d, h, DEV)
     if N >= 4:
