@@ -45,6 +45,15 @@ class ClipLayer:
     fc2: torch.nn.Linear
     heads: int
     scale: float
+    qkv_w: Optional[torch.Tensor] = None   # [3h, h] rows of q, k, v stacked: one projection GEMM instead of three
+    qkv_b: Optional[torch.Tensor] = None
+
+    def fuse_qkv(self):
+        """Snapshot q/k/v into one stacked weight (they are never edited by this path; call again if they change)."""
+        with torch.no_grad():
+            self.qkv_w = torch.cat([self.q.weight, self.k.weight, self.v.weight], 0).contiguous()
+            if self.q.bias is not None and self.k.bias is not None and self.v.bias is not None:
+                self.qkv_b = torch.cat([self.q.bias, self.k.bias, self.v.bias], 0).contiguous()
 
 
 @dataclass
@@ -78,6 +87,9 @@ def discover(text_encoder, layer_module_tmp: str) -> ClipTextGraph:
             for m in (l.q, l.k, l.v, l.out, l.fc1, l.fc2):
                 if not isinstance(m, torch.nn.Linear):
                     raise UnsupportedEncoder("projection is not nn.Linear")
+        for l in layers:
+            if (l.q.bias is None) == (l.k.bias is None) == (l.v.bias is None) and l.q.weight.is_cuda:
+                l.fuse_qkv()
         return ClipTextGraph(tok_e, pos_e, layers)
     except (AttributeError, LookupError, TypeError) as e:
         raise UnsupportedEncoder(str(e))
@@ -92,11 +104,14 @@ class TokenTrie:
     lookup_node: torch.Tensor  # (B,) int64 node of each prompt's lookup token
     query_rows: torch.Tensor   # (R,) int32 distinct lookup nodes (sorted)
     lookup_in_query: torch.Tensor  # (B,) int64 index of each prompt's lookup node inside query_rows
-    n_nodes: int
+    n_nodes: int               # distinct prefixes (the arrays above are padded to a multiple of ROW_BUCKET rows)
     n_tokens_dense: int        # B * S the dense forward would process
 
 
-def build_trie(input_ids: Sequence[Sequence[int]], lookup: Sequence[int], device) -> TokenTrie:
+ROW_BUCKET = 256   # node / query-row counts are padded to a multiple of this: a few GEMM shapes per encoder, not one per batch
+
+
+def build_trie(input_ids: Sequence[Sequence[int]], lookup: Sequence[int], device, bucket: int = ROW_BUCKET) -> TokenTrie:
     index: Dict[tuple, int] = {}
     token, parent, depth = [], [], []
     lookup_node = []
@@ -112,10 +127,16 @@ def build_trie(input_ids: Sequence[Sequence[int]], lookup: Sequence[int], device
                 depth.append(pos)
             p = u
         lookup_node.append(p)
-    U = len(token)
+    n_real = len(token)
     dmax = max(depth) + 1
     if dmax > 128:
         raise UnsupportedEncoder("prompt longer than 128 tokens")
+    # padding nodes: copies of the root token at depth 0 that attend to themselves; nothing ever looks them up
+    pad = (-n_real) % bucket if bucket > 1 else 0
+    token += [token[0]] * pad
+    parent += [-1] * pad
+    depth += [0] * pad
+    U = len(token)
     anc = np.zeros((U, dmax), dtype=np.int32)
     par = np.asarray(parent)
     dep = np.asarray(depth)
@@ -126,12 +147,81 @@ def build_trie(input_ids: Sequence[Sequence[int]], lookup: Sequence[int], device
         anc[u, d] = u
     ln = np.asarray(lookup_node)
     q_rows, inverse = np.unique(ln, return_inverse=True)
+    if bucket > 1 and len(q_rows) % bucket:       # query rows of the last layer: repeat the first one as padding
+        q_rows = np.concatenate([q_rows, np.full((-len(q_rows)) % bucket, q_rows[0], dtype=q_rows.dtype)])
     return TokenTrie(torch.tensor(token, dtype=torch.int64, device=device),
                      torch.tensor(dep, dtype=torch.int32, device=device),
                      torch.from_numpy(anc).to(device), torch.from_numpy(ln).to(device),
                      torch.from_numpy(q_rows.astype(np.int32)).to(device),
-                     torch.from_numpy(inverse.astype(np.int64)).to(device), U,
+                     torch.from_numpy(inverse.astype(np.int64)).to(device), n_real,
                      len(input_ids) * len(input_ids[0]))
+
+
+class tuned_gemms:
+    """Context: route torch's fp32 GEMMs through TunableOp's table (results of ``tune_projections``) for the duration
+    of the forward, and put the process-wide switches back afterwards.  No tuning happens inside the context."""
+
+    def __enter__(self):
+        t = torch.cuda.tunable
+        self.prev = (t.is_enabled(), t.tuning_is_enabled())
+        if _TUNED["done"]:
+            t.enable(True)
+            t.tuning_enable(False)
+        return self
+
+    def __exit__(self, *exc):
+        t = torch.cuda.tunable
+        t.tuning_enable(self.prev[1])
+        t.enable(self.prev[0])
+        return False
+
+
+_TUNED = {"done": False, "shapes": set()}
+
+
+def tune_projections(graph: ClipTextGraph, trie: TokenTrie, upto: int) -> float:
+    """Let TunableOp time the GEMM libraries' solutions for the projection shapes this trie produces (rows are
+    bucketed, so a handful of shapes per encoder) and keep the fastest: on MI355X the default heuristic leaves
+    10-35 % on the table for (rows x 768) @ (768 x {768, 2304, 3072}).  Idempotent per shape; a few seconds the
+    first time (results are also written to TunableOp's file under the temp dir).  Returns the seconds spent."""
+    import os
+    import tempfile
+    import time
+    layer = graph.layers[upto]
+    dev = layer.fc2.weight.device
+    rows_all, rows_q = int(trie.token.numel()), int(trie.query_rows.numel())
+    todo = []
+    for rows in {rows_all, rows_q}:
+        mods = [layer.out, layer.fc1, layer.fc2, layer.q, layer.k]
+        for m in mods:
+            todo.append((rows, m.in_features, m.out_features, m.bias is not None))
+        if layer.qkv_w is not None:
+            todo.append((rows, layer.qkv_w.shape[1], layer.qkv_w.shape[0], layer.qkv_b is not None))
+    todo = [s for s in dict.fromkeys(todo) if s not in _TUNED["shapes"]]
+    if not todo:
+        return 0.0
+    t = torch.cuda.tunable
+    prev = (t.is_enabled(), t.tuning_is_enabled())
+    t0 = time.perf_counter()
+    try:
+        t.enable(True)
+        t.tuning_enable(True)
+        t.set_filename(os.path.join(tempfile.gettempdir(), f"emcid_tunableop_{os.getuid()}.csv"))
+        t.set_max_tuning_duration(100)
+        t.set_max_tuning_iterations(20)
+        with torch.no_grad():
+            for rows, k, n, has_bias in todo:
+                x = torch.randn(rows, k, device=dev)
+                w = torch.randn(n, k, device=dev)
+                b = torch.randn(n, device=dev) if has_bias else None
+                F.linear(x, w, b)
+        torch.cuda.synchronize(dev)
+        _TUNED["shapes"].update(todo)
+        _TUNED["done"] = True
+    finally:
+        t.tuning_enable(prev[1])
+        t.enable(prev[0])
+    return time.perf_counter() - t0
 
 
 def _check_fp32(graph: ClipTextGraph):
@@ -147,6 +237,12 @@ def embed(graph: ClipTextGraph, trie: TokenTrie) -> torch.Tensor:
 def layer_attention_block(layer: ClipLayer, hs: torch.Tensor, trie: TokenTrie, rows: Optional[torch.Tensor]):
     """hs (U, h) -> residual stream after the attention block, for every node (rows None) or the query rows only."""
     x = layer.ln1(hs)
+    if rows is None and layer.qkv_w is not None:
+        hdim = layer.q.out_features
+        qkv = F.linear(x, layer.qkv_w, layer.qkv_b)          # (U, 3h): q | k | v as strided row views
+        ctx = hip.tree_attention(qkv[:, :hdim], qkv[:, hdim:2 * hdim], qkv[:, 2 * hdim:], trie.anc, trie.depth, layer.heads,
+                                 layer.scale, None)
+        return hs + layer.out(ctx)
     k = layer.k(x)
     v = layer.v(x)
     if rows is None:
@@ -170,6 +266,11 @@ def run_layers(graph: ClipTextGraph, trie: TokenTrie, upto: int, on_fc2=None, la
     (rows = all nodes, or the query rows at layer ``upto`` when ``last_rows_only``); whatever it returns is used
     as fc2's output.  Returns the residual stream after layer ``upto`` (query rows only if ``last_rows_only``)."""
     _check_fp32(graph)
+    with tuned_gemms():
+        return _run_layers(graph, trie, upto, on_fc2, last_rows_only)
+
+
+def _run_layers(graph, trie, upto, on_fc2, last_rows_only):
     hs = embed(graph, trie)
     for i in range(upto + 1):
         layer = graph.layers[i]

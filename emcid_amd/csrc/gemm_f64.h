@@ -116,12 +116,16 @@ struct GemmShape {
     int lower_only;  // skip output tiles that lie entirely above the diagonal (SYRK / Cholesky updates)
     int64_t sA = 0, sB = 0;  // element strides between the problems of a batch (blockIdx.z)
     int batch = 1;
-    // triangular B operand (the inverted diagonal blocks): 1 = B(k, n) is zero for k > n, 2 = zero for k < n.
-    // The K loop of an output tile then only covers the k range that can contribute.
+    // triangular operands (inverted diagonal blocks, explicit inverse factors), bit mask:
+    //   1 = B(k, n) is zero for k > n,  2 = B(k, n) zero for k < n,  4 = A(m, k) zero for k > m,  8 = A(m, k) zero for k < m.
+    // The K loop of an output tile then only covers the k range that can contribute; tiles are issued heaviest first.
     int tri = 0;
     // split the K range of every output tile over ksplit workgroups (blockIdx.z = batch * ksplit + split); only for
     // epilogues that ACCUMULATE into C (EpiAxpby with beta == 1), which then add their partial with f64 atomics
     int ksplit = 1;
+    // kchunk > 0: instead of an even split, every workgroup takes a fixed run of kchunk K-tiles (blockIdx.z picks the
+    // run; runs past the tile's own K range exit at once) — equal work units when `tri` makes the ranges differ
+    int kchunk = 0;
 };
 
 // WGM x WGN waves per workgroup; each wave owns a (BM/WGM) x (BN/WGN) sub-tile.
@@ -139,7 +143,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Ep
     constexpr int STAGE = TA::SIZE + TB::SIZE;
     __shared__ __attribute__((aligned(16))) double smem[2 * STAGE];
 
-    const int bm = blockIdx.y, bn = blockIdx.x;
+    // tiles whose K range grows with n (tri & 1) or m (tri & 4) are numbered from the far end: long ranges start first
+    const int bm = (p.tri & 4) ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+    const int bn = (p.tri & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const int m0 = bm * BM, n0 = bn * BN;
     if (p.lower_only && n0 > m0 + BM - 1) return;
 
@@ -156,9 +162,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Ep
 
     // K tiles [t0, t1) that can contribute to this output tile
     int t0 = 0, t1 = (p.K + BK - 1) / BK;
-    if (p.tri == 1) { const int ke = min(p.K, n0 + BN); t1 = (ke + BK - 1) / BK; }
-    else if (p.tri == 2) { t0 = min(n0, p.K) / BK; }
-    if (p.ksplit > 1) {
+    if (p.tri & 1) t1 = min(t1, (min(p.K, n0 + BN) + BK - 1) / BK);
+    if (p.tri & 2) t0 = max(t0, min(n0, p.K) / BK);
+    if (p.tri & 4) t1 = min(t1, (min(p.K, m0 + BM) + BK - 1) / BK);
+    if (p.tri & 8) t0 = max(t0, min(m0, p.K) / BK);
+    if (p.kchunk > 0) {
+        t0 += zs * p.kchunk;
+        t1 = min(t1, t0 + p.kchunk);
+        if (t0 >= t1) return;
+    } else if (p.ksplit > 1) {
         const int per = (t1 - t0 + p.ksplit - 1) / p.ksplit;
         t0 += zs * per;
         t1 = min(t1, t0 + per);
@@ -292,6 +304,10 @@ inline void launch_gemm_f64(GemmShape p, Epi epi, hipStream_t stream, int force_
         if (p.ksplit < 1) p.ksplit = 1;
     }
     if (env_split >= 0 && epi_accumulates(epi)) p.ksplit = env_split > 0 ? env_split : 1;
+    if (p.kchunk > 0) {   // fixed-length runs: as many z-slices as the longest K range needs
+        p.ksplit = epi_accumulates(epi) ? (ktiles + p.kchunk - 1) / p.kchunk : 1;
+        if (p.ksplit == 1) p.kchunk = 0;
+    }
     if (p.ksplit > 1) epi_set_atomic(epi);
     const unsigned gz = (unsigned)(p.batch * p.ksplit);
     if (cfg == 0) {

@@ -517,6 +517,77 @@ static int cholesky_solve_impl(const double* L, int64_t dp, int64_t lda, const d
     return check_launch("emcid_cholesky_solve_f64");
 }
 
+// X = inv(L), explicit, for `nbatch` factors at once (the dual solver's M = lam*C' factors: they do not depend on the
+// concepts, so every layer's two triangular solves become two GEMMs against X).  Block rows of OB:
+//   X[J][J] = inv(L_JJ)                         (already formed by build_block_inverses)
+//   X[I][0:I] = -inv(L_II) * (L[I][0:I] * X[0:I][0:I])      I = 1 .. nob-1
+// Both products skip the structurally zero part of their triangular operand, so the build costs ~dp^3/3 flops.
+// T: scratch, nbatch x (>= OB * dp) doubles with stride s_mat.  Only the lower triangle of X (and the zeros inside its
+// diagonal 128-blocks) is written; consumers never read anything else.
+__global__ __launch_bounds__(256) void copy_diag_inverse_kernel(const double* __restrict__ invw, int64_t s_inv, double* __restrict__ X,
+                                                                 int64_t ldx, int64_t s_x, int64_t dp) {
+    const int64_t r = blockIdx.x;                 // global row
+    const int64_t J = r / OB, i = r % OB;
+    const int w = (int)((dp - J * OB) < OB ? (dp - J * OB) : OB);
+    const double* src = invw + blockIdx.y * s_inv + J * (int64_t)OB * OB + i * OB;
+    double* dst = X + blockIdx.y * s_x + r * ldx + J * OB;
+    // zeros only where a diagonal 128-block could be read above the diagonal
+    const int hi = (int)((i / NB + 1) * NB);
+    for (int j = threadIdx.x; j < (hi < w ? hi : w); j += 256) dst[j] = (j <= i) ? src[j] : 0.0;
+}
+
+__global__ __launch_bounds__(256) void zero2d_f64_kernel(double* __restrict__ p, int64_t ld, int64_t s_batch, int cols) {
+    double* row = p + blockIdx.y * s_batch + (int64_t)blockIdx.x * ld;
+    for (int j = threadIdx.x; j < cols; j += 256) row[j] = 0.0;
+}
+
+static int build_full_inverse(const double* L, int64_t dp, int64_t lda, const double* invw, double* X, double* T, int nbatch,
+                              int64_t s_mat, int64_t s_inv, hipStream_t st) {
+    ScopedProf sp(KC_INV_BUILD, st);
+    hipLaunchKernelGGL(copy_diag_inverse_kernel, dim3((unsigned)dp, (unsigned)nbatch), dim3(256), 0, st, invw, s_inv, X, lda, s_mat, dp);
+    const int nob = (int)((dp + OB - 1) / OB);
+    static const int cfg_a = env_flag("EMCID_INV_CFG_A", -1), cfg_b = env_flag("EMCID_INV_CFG_B", -1);   // experiments
+    static const int kchunk = env_flag("EMCID_INV_KCHUNK", 0);
+    for (int I = 1; I < nob; ++I) {
+        const int64_t r0 = (int64_t)I * OB;
+        const int rI = (int)((dp - r0) < OB ? (dp - r0) : OB);
+        GemmShape a{L + r0 * lda, lda, X, lda, rI, (int)r0, (int)r0, 0, s_mat, s_mat, nbatch};
+        a.tri = 2;   // B(k, n) = X[k][n], zero for k < n
+        const bool split = kchunk > 0 && r0 / 16 > kchunk;
+        if (split) {   // deep, uneven K ranges: equal runs of K-tiles per workgroup, partials added atomically into a zeroed T
+            hipLaunchKernelGGL(zero2d_f64_kernel, dim3((unsigned)rI, (unsigned)nbatch), dim3(256), 0, st, T, lda, s_mat, (int)r0);
+            a.kchunk = kchunk;
+        }
+        launch_gemm_f64<true, false>(a, EpiAxpby{T, lda, 1.0, split ? 1.0 : 0.0, s_mat}, st, cfg_a);
+        GemmShape b{inv_block(invw, I), OB, T, lda, rI, (int)r0, rI, 0, s_inv, s_mat, nbatch};
+        b.tri = 4;   // A(m, k) = inv(L_II)[m][k], zero for k > m
+        launch_gemm_f64<true, false>(b, EpiAxpby{X + r0 * lda, lda, -1.0, 0.0, s_mat}, st, cfg_b);
+    }
+    return check_launch("build_full_inverse");
+}
+
+// Yt[rows, dp] = Kt[rows, dp] * X^T  (= Kt L^-T: the forward substitution as one GEMM)
+static void apply_inverse_forward(const double* X, int64_t dp, const double* Kt, double* Yt, int rows, hipStream_t st) {
+    ScopedProf sp(KC_INV_APPLY, st);
+    GemmShape g{Kt, dp, X, dp, rows, (int)dp, (int)dp, 0};
+    g.tri = 1;       // B(k, n) = X[n][k], zero for k > n
+    launch_gemm_f64<true, true>(g, EpiAxpby{Yt, dp, 1.0, 0.0}, st, 1);
+}
+
+// C[rows, ncols] = V[rows, dp] * X  (= V L^-1: the backward substitution as one GEMM), through any epilogue
+template <class Epi>
+static void apply_inverse_backward(const double* X, int64_t dp, const double* V, int rows, int ncols, Epi epi, hipStream_t st) {
+    ScopedProf sp(KC_INV_APPLY, st);
+    GemmShape g{V, dp, X, dp, rows, ncols, (int)dp, 0};
+    g.tri = 2;       // B(k, n) = X[k][n], zero for k < n
+    launch_gemm_f64<true, false>(g, epi, st, 2);
+}
+
+// layout of the covariance-factor workspace (emcid_factor_cov_f64): [M | L | 512-block inverses | X = inv(L)] x n_layers
+static inline const double* cov_inverse(const void* cov_factor_ws, int64_t n_layers, int64_t dp, int64_t layer) {
+    return (const double*)cov_factor_ws + n_layers * (2 * dp * dp + inv_doubles(dp)) + layer * dp * dp;
+}
+
 // ---- factor + solve as one cached hipGraph -----------------------------------------------------------------------
 // The ~100 launches of one layer's Cholesky + block-inverse build + triangular solves take only workspace
 // pointers and sizes, so the whole chain (is captured once
@@ -619,13 +690,23 @@ __global__ __launch_bounds__(256) void scale_cov_kernel(CovPtrs cov, int d, int 
     }
 }
 
-// S = D + I (lower tiles), D = Pt Kt^T
-struct EpiPlusIdentity {
-    double* S; int64_t lds_;
-    static constexpr bool splittable = false;
-    __device__ __forceinline__ void batch(int) {}
-    __device__ __forceinline__ void operator()(int m, int n, double v) const { S[(int64_t)m * lds_ + n] = v + (m == n ? 1.0 : 0.0); }
-};
+
+// S = I (full square): start value of the split-K accumulation S += Yt Yt^T
+__global__ __launch_bounds__(256) void eye_f64_kernel(double* __restrict__ S, int n) {
+    const int i = blockIdx.x;
+    for (int j = threadIdx.x; j < n; j += 256) S[(int64_t)i * n + j] = (i == j) ? 1.0 : 0.0;
+}
+
+// S[Np, Np] = I + P Q^T on the lower tiles, K = dp deep.  Np x Np is too few output tiles for the chip, so the
+// contraction is split over workgroups that add their partials into the identity with f64 atomics.
+static void assemble_dual_system(const double* P, const double* Q, int64_t dp, double* S, int Np, hipStream_t st) {
+    ScopedProf sp(KC_ASSEMBLE, st);
+    hipLaunchKernelGGL(eye_f64_kernel, dim3((unsigned)Np), dim3(256), 0, st, S, Np);
+    GemmShape g{P, dp, Q, dp, Np, Np, (int)dp, 1};
+    const int kt = (int)(dp / 16);
+    g.ksplit = kt >= 64 ? 4 : kt >= 32 ? 2 : 1;
+    launch_gemm_f64<true, true>(g, EpiAxpby{S, Np, 1.0, 1.0}, st, Np >= 512 ? 1 : 2);
+}
 
 __global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst,
                                                              int64_t ldd, int rows, int cols) {
@@ -731,6 +812,28 @@ int emcid_dgemm_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alph
     else if (ta == 0 && tb == 1) launch_gemm_f64<true, false>(p, e, st);
     else if (ta == 1 && tb == 0) launch_gemm_f64<false, true>(p, e, st);
     else launch_gemm_f64<false, false>(p, e, st);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+int emcid_dgemm_ex_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                       const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int flags, int cfg, int ksplit,
+                       void* stream) {
+    EMCID_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C);
+    EMCID_CHECK_ARG(aligned16(A) && aligned16(B) && (lda % 2 == 0) && (ldb % 2 == 0));
+    EMCID_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30) && cfg >= -1 && cfg <= 2 && (flags & ~31) == 0);
+    EMCID_CHECK_ARG(ksplit == 0 || beta == 1.0);
+    hipStream_t st = (hipStream_t)stream;
+    GemmShape p{A, lda, B, ldb, (int)M, (int)N, (int)K, (flags >> 4) & 1};
+    p.tri = flags & 15;
+    if (ksplit > 0) p.ksplit = ksplit;
+    if (ksplit < 0) p.kchunk = -ksplit;
+    EpiAxpby e{C, ldc, alpha, beta};
+    ScopedProf sp(KC_DGEMM, st);
+    if (ta == 0 && tb == 0) launch_gemm_f64<true, true>(p, e, st, cfg);
+    else if (ta == 0 && tb == 1) launch_gemm_f64<true, false>(p, e, st, cfg);
+    else if (ta == 1 && tb == 0) launch_gemm_f64<false, true>(p, e, st, cfg);
+    else launch_gemm_f64<false, false>(p, e, st, cfg);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }
@@ -872,7 +975,7 @@ int emcid_apply_update_f32(const double* U, const float* W0, float* W, float* dW
 int64_t emcid_cov_factor_workspace_bytes(int64_t n_layers, int64_t d) {
     if (n_layers <= 0 || d <= 0) return 0;
     const int64_t dp = round_up(d, NB);
-    return n_layers * (2 * dp * dp + inv_doubles(dp)) * (int64_t)sizeof(double);
+    return n_layers * (3 * dp * dp + inv_doubles(dp)) * (int64_t)sizeof(double);
 }
 
 int emcid_factor_cov_f64(const float* const* C_host_list, int64_t n_layers, int64_t d, double lam, double edit_weight,
@@ -885,6 +988,7 @@ int emcid_factor_cov_f64(const float* const* C_host_list, int64_t n_layers, int6
     double* Mb = (double*)workspace;                 // [n_layers][dp*dp]  lam*C' (consumed by the factorization)
     double* Lb = Mb + n_layers * s_mat;              // [n_layers][dp*dp]  factors
     double* Ib = Lb + n_layers * s_mat;              // [n_layers][inv_doubles]
+    // [n_layers][dp*dp] after Ib: X = inv(L), explicit, built per layer by emcid_cov_inverse_f64
     CovPtrs cp;
     for (int i = 0; i < 32; ++i) cp.c[i] = i < n_layers ? C_host_list[i] : nullptr;
     for (int i = 0; i < n_layers; ++i) EMCID_CHECK_ARG(cp.c[i] != nullptr);
@@ -902,6 +1006,22 @@ int emcid_factor_cov_f64(const float* const* C_host_list, int64_t n_layers, int6
     });
 }
 
+/* X_l = inv(L_l) for ONE layer of a factored workspace (needs emcid_factor_cov_f64 earlier on the same stream, or an
+ * event dependency on it).  Per layer so that the first edited layer's solve can start while the later layers' inverse
+ * factors are still being built underneath it. */
+int emcid_cov_inverse_f64(void* cov_factor_ws, int64_t n_layers, int64_t d, int64_t first_layer, int64_t count, void* stream) {
+    EMCID_CHECK_ARG(cov_factor_ws && n_layers > 0 && n_layers <= 32 && d > 0 && d <= 32768 && aligned16(cov_factor_ws));
+    EMCID_CHECK_ARG(0 <= first_layer && count > 0 && first_layer + count <= n_layers);
+    const int64_t dp = round_up(d, NB), s_mat = dp * dp, s_inv = inv_doubles(dp);
+    double* Mb = (double*)cov_factor_ws + first_layer * s_mat;          // consumed by the factorization: scratch now
+    const double* Lb = (const double*)cov_factor_ws + (n_layers + first_layer) * s_mat;
+    const double* Ib = (const double*)cov_factor_ws + 2 * n_layers * s_mat + first_layer * s_inv;
+    double* Xb = (double*)cov_factor_ws + n_layers * (2 * s_mat + s_inv) + first_layer * s_mat;
+    return with_graph(make_key(7, {Mb, Lb, Ib, Xb}, {dp, count}), (hipStream_t)stream, [&](hipStream_t s) {
+        return build_full_inverse(Lb, dp, dp, Ib, Xb, Mb, (int)count, s_mat, s_inv, s);   // batched over the range
+    });
+}
+
 int64_t emcid_edit_dual_workspace_bytes(int64_t N, int64_t d, int64_t h) {
     if (N <= 0 || d <= 0 || h <= 0) return 0;
     return DualWorkspace(N, d, h).total * (int64_t)sizeof(double);
@@ -910,8 +1030,8 @@ int64_t emcid_edit_dual_workspace_bytes(int64_t N, int64_t d, int64_t h) {
 /* stage 1: Kt64 = s*K, Rt, and the shard's rows of Pt = Kt64 M^-1 (into Pt_rows_out if given, else only the workspace) */
 int emcid_edit_dual_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
                                double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
-                               int64_t layer_index, int64_t n_lo, int64_t n_hi, void* workspace, int64_t workspace_bytes,
-                               void* stream) {
+                               int64_t layer_index, int64_t n_lo, int64_t n_hi, int use_inverse, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
     EMCID_CHECK_ARG(K && Zc && zs_t && N > 0 && d > 0 && h > 0 && layers_left > 0 && cov_factor_ws && workspace);
     EMCID_CHECK_ARG(0 <= layer_index && layer_index < n_layers && 0 <= n_lo && n_lo < n_hi && n_hi <= N);
     DualWorkspace ws(N, d, h);
@@ -929,6 +1049,14 @@ int emcid_edit_dual_stage1_f64(const float* K, const float* Zc, const float* zs_
                            (double)layers_left, Kt, (int)ws.Np, (int)dp, R, (int)ws.hp);
     }
     const int64_t rows = n_hi - n_lo;
+    if (use_inverse) {
+        // Pt = (Kt X^T) X : both triangular solves against M = L L^T are GEMMs against the explicit X = inv(L)
+        const double* Xb = cov_inverse(cov_factor_ws, n_layers, dp, layer_index);
+        apply_inverse_forward(Xb, dp, Kt + n_lo * dp, Y + n_lo * dp, (int)rows, st);
+        apply_inverse_backward(Xb, dp, Y + n_lo * dp, (int)rows, (int)dp, EpiAxpby{Pt + n_lo * dp, dp, 1.0, 0.0}, st);
+        EMCID_CHECK_LAUNCH();
+        return EMCID_OK;
+    }
     if (hipMemcpyAsync(Pt + n_lo * dp, Kt + n_lo * dp, rows * dp * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return fail(EMCID_ERR_HIP, __func__, "hipMemcpyAsync");
     return with_graph(make_key(3, {Lb, Ib, Pt + n_lo * dp, Y + n_lo * dp}, {dp, rows}), st, [&](hipStream_t q) {
@@ -956,11 +1084,7 @@ int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, const float* W0,
     EMCID_TRY(with_graph(make_key(4, {Kt, Pt, S, LS, invS, PT, Y2, info_dev}, {dp, Np, N}), st, [&](hipStream_t q) {
         if (Np > N)   // rows of the padding concepts: zero (their Kt rows are zero, so S gets identity rows there)
             hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, q, Pt + N * dp, (Np - N) * dp);
-        {
-            ScopedProf sp(KC_ASSEMBLE, q);
-            GemmShape g{Pt, dp, Kt, dp, (int)Np, (int)Np, (int)dp, 1};
-            launch_gemm_f64<true, true>(g, EpiPlusIdentity{S, Np}, q);
-        }
+        assemble_dual_system(Pt, Kt, dp, S, (int)Np, q);
         EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q));
         hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)(dp / 32), (unsigned)(Np / 32)), dim3(256), 0, q, Pt, dp, PT, Np,
                            (int)Np, (int)dp);
@@ -983,7 +1107,7 @@ int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, const float* W0,
  * one GEMM and one backward solve on h rows.  Same algebra as stage1 + stage2 by associativity. */
 int emcid_edit_dual_apply_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
                                      double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
-                                     int64_t layer_index, int64_t n_lo, int64_t n_hi, void* workspace,
+                                     int64_t layer_index, int64_t n_lo, int64_t n_hi, int use_inverse, void* workspace,
                                      int64_t workspace_bytes, void* stream) {
     EMCID_CHECK_ARG(K && Zc && zs_t && N > 0 && d > 0 && h > 0 && layers_left > 0 && cov_factor_ws && workspace);
     EMCID_CHECK_ARG(0 <= layer_index && layer_index < n_layers && 0 <= n_lo && n_lo < n_hi && n_hi <= N);
@@ -1002,6 +1126,12 @@ int emcid_edit_dual_apply_stage1_f64(const float* K, const float* Zc, const floa
                            (double)layers_left, Kt, (int)ws.Np, (int)dp, R, (int)ws.hp);
     }
     const int64_t rows = n_hi - n_lo;
+    if (use_inverse) {
+        apply_inverse_forward(cov_inverse(cov_factor_ws, n_layers, dp, layer_index), dp, Kt + n_lo * dp, Yt + n_lo * dp, (int)rows,
+                              st);
+        EMCID_CHECK_LAUNCH();
+        return EMCID_OK;
+    }
     if (hipMemcpyAsync(Bs + n_lo * dp, Kt + n_lo * dp, rows * dp * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return fail(EMCID_ERR_HIP, __func__, "hipMemcpyAsync");
     return with_graph(make_key(5, {Lb, Ib, Bs + n_lo * dp, Yt + n_lo * dp}, {dp, rows}), st, [&](hipStream_t q) {
@@ -1017,8 +1147,8 @@ double* emcid_edit_dual_yt(void* workspace, int64_t N, int64_t d, int64_t h) {
 }
 
 int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void* cov_factor_ws, int64_t n_layers,
-                                     int64_t layer_index, const float* W0, float* W, float* dW_out, void* workspace,
-                                     int64_t workspace_bytes, int* info_dev, void* stream) {
+                                     int64_t layer_index, int use_inverse, const float* W0, float* W, float* dW_out,
+                                     void* workspace, int64_t workspace_bytes, int* info_dev, void* stream) {
     EMCID_CHECK_ARG(N > 0 && d > 0 && h > 0 && workspace && info_dev && cov_factor_ws && ((W == nullptr) || (W0 != nullptr)));
     EMCID_CHECK_ARG(0 <= layer_index && layer_index < n_layers && (W || dW_out));
     DualWorkspace ws(N, d, h);
@@ -1030,14 +1160,10 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
     const int64_t dp = ws.dp, Np = ws.Np, hp = ws.hp, s_mat = dp * dp;
     const double* Lb = (const double*)cov_factor_ws + n_layers * s_mat + layer_index * s_mat;
     const double* Ib = (const double*)cov_factor_ws + 2 * n_layers * s_mat + layer_index * inv_doubles(dp);
-    EMCID_TRY(with_graph(make_key(6, {Yt, R, S, LS, RT, V, U, info_dev}, {dp, Np, N, hp, (int64_t)(uintptr_t)Lb}), st,
+    EMCID_TRY(with_graph(make_key(6, {Yt, R, S, LS, RT, V, U, info_dev}, {dp, Np, N, hp, (int64_t)(uintptr_t)Lb, use_inverse}), st,
                          [&](hipStream_t q) {
         if (Np > N) hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, q, Yt + N * dp, (Np - N) * dp);
-        {
-            ScopedProf sp(KC_ASSEMBLE, q);      // S = I + Yt Yt^T (lower tiles)
-            GemmShape g{Yt, dp, Yt, dp, (int)Np, (int)Np, (int)dp, 1};
-            launch_gemm_f64<true, true>(g, EpiPlusIdentity{S, Np}, q);
-        }
+        assemble_dual_system(Yt, Yt, dp, S, (int)Np, q);      // S = I + Yt Yt^T (lower tiles)
         EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q));
         // RT[h, Np] = Rt^T ; Z^T = RT S^-1 (two solves with h rows)
         hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)((hp + 31) / 32), (unsigned)(Np / 32)), dim3(256), 0, q, R, hp, RT,
@@ -1048,10 +1174,14 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
             GemmShape g{RT, Np, Yt, dp, (int)h, (int)dp, (int)Np, 0};
             launch_gemm_f64<true, false>(g, EpiAxpby{V, dp, 1.0, 0.0}, q);
         }
-        trsm_backward(Lb, dp, dp, Ib, V, U, (int)h, dp, q);   // U L = V
+        if (!use_inverse) trsm_backward(Lb, dp, dp, Ib, V, U, (int)h, dp, q);   // U L = V by block substitution
         return check_launch("emcid_edit_dual_apply_stage2_f64");
     }));
-    hipLaunchKernelGGL(apply_u2d_kernel, dim3((unsigned)h), dim3(256), 0, st, U, dp, W0, W, dW_out, (int)d);
+    if (use_inverse)   // U = V inv(L), straight into W = W0 + float(U)  (V's padding columns are zero: Kt's are, X is I there)
+        apply_inverse_backward(cov_inverse(cov_factor_ws, n_layers, dp, layer_index), dp, V, (int)h, (int)d,
+                               EpiDeltaW{W0, W, d, dW_out, d, nullptr, d}, st);
+    else
+        hipLaunchKernelGGL(apply_u2d_kernel, dim3((unsigned)h), dim3(256), 0, st, U, dp, W0, W, dW_out, (int)d);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }

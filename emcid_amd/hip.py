@@ -18,17 +18,18 @@ _lib = None
 EXPORTS = [
     "emcid_abi_version", "emcid_last_error", "emcid_gram_accumulate_f32", "emcid_symmetrize_lower_f32",
     "emcid_gather_mean_f32", "emcid_edit_workspace_bytes", "emcid_edit_layer_f64", "emcid_assemble_spd_f64",
-    "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_axpy_f32",
+    "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_dgemm_ex_f64", "emcid_axpy_f32",
     "emcid_profile_enable", "emcid_profile_collect", "emcid_attention_f32", "emcid_edit_layer_shard_f64",
     "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32", "emcid_tree_attention_f32", "emcid_debug_leaf_stamps",
-    "emcid_cov_factor_workspace_bytes", "emcid_factor_cov_f64", "emcid_edit_dual_workspace_bytes",
+    "emcid_cov_factor_workspace_bytes", "emcid_factor_cov_f64", "emcid_cov_inverse_f64",
+    "emcid_edit_dual_workspace_bytes",
     "emcid_edit_dual_stage1_f64", "emcid_edit_dual_pt", "emcid_edit_dual_stage2_f64",
     "emcid_edit_dual_apply_stage1_f64", "emcid_edit_dual_yt", "emcid_edit_dual_apply_stage2_f64",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
-                "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner"]
+                "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply"]
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NB = 128      # Cholesky block (csrc/common.h)
 NPAD = 64     # concept padding of the f64 stacks (csrc/common.h)
 
@@ -68,16 +69,18 @@ def load():
         "emcid_debug_leaf_stamps": (i32, [p, p, p, p, p, p]),
         "emcid_cov_factor_workspace_bytes": (i64, [i64, i64]),
         "emcid_factor_cov_f64": (i32, [p, i64, i64, f64, f64, p, i64, p, p]),
+        "emcid_cov_inverse_f64": (i32, [p, i64, i64, i64, i64, p]),
         "emcid_edit_dual_workspace_bytes": (i64, [i64, i64, i64]),
-        "emcid_edit_dual_stage1_f64": (i32, [p, p, p, i64, i64, i64, f64, i32, p, i64, i64, i64, i64, p, i64, p]),
+        "emcid_edit_dual_stage1_f64": (i32, [p, p, p, i64, i64, i64, f64, i32, p, i64, i64, i64, i64, i32, p, i64, p]),
         "emcid_edit_dual_pt": (p, [p, i64, i64, i64]),
         "emcid_edit_dual_stage2_f64": (i32, [i64, i64, i64, p, p, p, p, p, p, i64, p, p]),
-        "emcid_edit_dual_apply_stage1_f64": (i32, [p, p, p, i64, i64, i64, f64, i32, p, i64, i64, i64, i64, p, i64, p]),
+        "emcid_edit_dual_apply_stage1_f64": (i32, [p, p, p, i64, i64, i64, f64, i32, p, i64, i64, i64, i64, i32, p, i64, p]),
         "emcid_edit_dual_yt": (p, [p, i64, i64, i64]),
-        "emcid_edit_dual_apply_stage2_f64": (i32, [i64, i64, i64, p, i64, i64, p, p, p, p, i64, p, p]),
+        "emcid_edit_dual_apply_stage2_f64": (i32, [i64, i64, i64, p, i64, i64, i32, p, p, p, p, i64, p, p]),
         "emcid_cholesky_solve_f64": (i32, [p, i64, i64, p, p, p, i64, i64, p]),
         "emcid_delta_w_f64": (i32, [p, i64, p, i64, i64, i64, i64, p, p, i64, p, p, p]),
         "emcid_dgemm_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, p]),
+        "emcid_dgemm_ex_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, i32, i32, i32, p]),
         "emcid_axpy_f32": (i32, [p, p, i64, p]),
         "emcid_quick_gelu_f32": (i32, [p, p, i64, p]),
         "emcid_tree_attention_f32": (i32, [p, i64, p, p, i64, p, i64, p, p, i64, i64, i64, f32, p, i64, p]),
@@ -235,6 +238,17 @@ def dgemm(ta: int, tb: int, A, B, Cm, alpha=1.0, beta=0.0, M=None, N=None, K=Non
     return Cm
 
 
+def dgemm_ex(ta: int, tb: int, A, B, Cm, alpha=1.0, beta=0.0, flags=0, cfg=-1, ksplit=0):
+    """Test hook: the GEMM with the solver's structure hints (triangular operands, lower-only, tile config, K split)."""
+    M = A.shape[0] if ta == 0 else A.shape[1]
+    K = A.shape[1] if ta == 0 else A.shape[0]
+    N = B.shape[0] if tb == 0 else B.shape[1]
+    _check(load().emcid_dgemm_ex_f64(ta, tb, M, N, K, float(alpha), _ptr(A, torch.float64), A.stride(0),
+                                     _ptr(B, torch.float64), B.stride(0), float(beta), _ptr(Cm, torch.float64),
+                                     Cm.stride(0), int(flags), int(cfg), int(ksplit), _stream(Cm)), "emcid_dgemm_ex_f64")
+    return Cm
+
+
 def axpy_(W: torch.Tensor, dW: torch.Tensor):
     """W += dW, fp32 (emcid_main.py:809)."""
     assert W.is_contiguous() and dW.is_contiguous() and W.numel() == dW.numel()
@@ -348,13 +362,35 @@ class CovFactors:
     def __init__(self, n_layers: int, d: int, device):
         self.n_layers, self.d = n_layers, d
         self.nbytes = int(load().emcid_cov_factor_workspace_bytes(n_layers, d))
-        self.buf = torch.empty(self.nbytes // 8, dtype=torch.float64, device=device)
+        self.buf = torch.zeros(self.nbytes // 8, dtype=torch.float64, device=device)
         self.info = torch.zeros(1, dtype=torch.int32, device=device)
+        self.dp = (d + NB - 1) // NB * NB
+        self._inv = ((self.dp + 511) // 512) * (512 * 512 + 256 * 256)   # csrc/common.h inv_doubles
+        self.have_inverse = set()                                        # layers whose X = inv(L) has been built
+
+    def L(self, layer: int) -> torch.Tensor:
+        """(dp, dp) view of the Cholesky factor of lam*C'_layer (lower triangle valid)."""
+        o = (self.n_layers + layer) * self.dp * self.dp
+        return self.buf[o:o + self.dp * self.dp].view(self.dp, self.dp)
+
+    def X(self, layer: int) -> torch.Tensor:
+        """(dp, dp) view of inv(L_layer), explicit (lower triangle valid; nothing above it is ever read)."""
+        o = self.n_layers * (2 * self.dp * self.dp + self._inv) + layer * self.dp * self.dp
+        return self.buf[o:o + self.dp * self.dp].view(self.dp, self.dp)
 
 
-def factor_cov(covs, lam: float, edit_weight: float, factors: Optional[CovFactors] = None) -> CovFactors:
+def cov_inverse(factors: "CovFactors", first: int = 0, count: Optional[int] = None):
+    """Build X = inv(L) for layers [first, first + count) of a factored workspace (default: all), batched.
+    Asynchronous on the current stream; needs factor_cov earlier on it."""
+    count = factors.n_layers - first if count is None else count
+    _check(load().emcid_cov_inverse_f64(_ptr(factors.buf), factors.n_layers, factors.d, int(first), int(count),
+                                        _stream(factors.buf)), "emcid_cov_inverse_f64")
+    factors.have_inverse.update(range(first, first + count))
+
+
+def factor_cov(covs, lam: float, edit_weight: float, factors: Optional[CovFactors] = None, inverse: bool = True) -> CovFactors:
     """covs: list of (d, d) fp32 contiguous HBM tensors (one per edited layer, forward order).  Asynchronous on the
-    current stream."""
+    current stream.  ``inverse=False`` leaves the explicit inverse factors to per-layer ``cov_inverse`` calls."""
     d = covs[0].shape[0]
     for c in covs:
         assert c.shape == (d, d) and c.is_contiguous()
@@ -363,6 +399,9 @@ def factor_cov(covs, lam: float, edit_weight: float, factors: Optional[CovFactor
     arr = (C.c_void_p * len(covs))(*[_ptr(c, torch.float32, "C").value for c in covs])
     _check(load().emcid_factor_cov_f64(arr, len(covs), d, float(lam), float(edit_weight), _ptr(factors.buf), factors.nbytes,
                                        _ptr(factors.info, torch.int32), _stream(covs[0])), "emcid_factor_cov_f64")
+    factors.have_inverse = set()
+    if inverse:
+        cov_inverse(factors)
     return factors
 
 
@@ -383,9 +422,12 @@ class DualWorkspace:
 
 def edit_layer_dual(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_weight: float, layers_left: int,
                     W0=None, W=None, want_factors: bool = False, want_dw: bool = True, ws: Optional[DualWorkspace] = None,
-                    rows=None, gather_pt=None):
+                    rows=None, gather_pt=None, use_inverse: Optional[bool] = None):
     """One edited layer through the dual solver.  ``rows=(lo, hi)`` + ``gather_pt(Pt_rows) -> all rows`` split the
-    M-solves over ranks.  Returns dict(adj_k (d,N) | None, Rt (N,h) | None, dW, ws)."""
+    M-solves over ranks.  ``use_inverse``: solve against M with GEMMs on X = inv(L) (default: if cov_inverse built it)
+    or by block substitution with L.  Returns dict(adj_k (d,N) | None, Rt (N,h) | None, dW, ws)."""
+    if use_inverse is None:
+        use_inverse = layer_index in factors.have_inverse
     N, d = K.shape
     h = Zc.shape[1]
     for t, nm in ((K, "K"), (Zc, "Zc"), (zs_t, "zs_t")):
@@ -398,7 +440,7 @@ def edit_layer_dual(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_wei
     _check(lib.emcid_edit_dual_stage1_f64(
         _ptr(K, torch.float32, "K"), _ptr(Zc, torch.float32, "Zc"), _ptr(zs_t, torch.float32, "zs_t"), N, d, h,
         float(edit_weight), int(layers_left), _ptr(factors.buf), factors.n_layers, int(layer_index), lo, hi,
-        _ptr(ws.buf), ws.nbytes, _stream(K)), "emcid_edit_dual_stage1_f64")
+        int(bool(use_inverse)), _ptr(ws.buf), ws.nbytes, _stream(K)), "emcid_edit_dual_stage1_f64")
     if gather_pt is not None:
         ws.Pt[:N].copy_(gather_pt(ws.Pt[lo:hi]))
     dev = K.device
@@ -414,8 +456,11 @@ def edit_layer_dual(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_wei
 
 
 def edit_layer_dual_apply(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_weight: float, layers_left: int,
-                          W0, W, want_dw: bool = True, ws: Optional[DualWorkspace] = None, rows=None, gather_yt=None):
+                          W0, W, want_dw: bool = True, ws: Optional[DualWorkspace] = None, rows=None, gather_yt=None,
+                          use_inverse: Optional[bool] = None):
     """Apply-only dual solver: W = W0 + float(U) without ever forming adj_k.  Returns dict(dW, ws)."""
+    if use_inverse is None:
+        use_inverse = layer_index in factors.have_inverse
     N, d = K.shape
     h = Zc.shape[1]
     for t, nm in ((K, "K"), (Zc, "Zc"), (zs_t, "zs_t"), (W, "W"), (W0, "W0")):
@@ -428,12 +473,12 @@ def edit_layer_dual_apply(K, Zc, zs_t, factors: CovFactors, layer_index: int, ed
     _check(lib.emcid_edit_dual_apply_stage1_f64(
         _ptr(K, torch.float32, "K"), _ptr(Zc, torch.float32, "Zc"), _ptr(zs_t, torch.float32, "zs_t"), N, d, h,
         float(edit_weight), int(layers_left), _ptr(factors.buf), factors.n_layers, int(layer_index), lo, hi,
-        _ptr(ws.buf), ws.nbytes, _stream(K)), "emcid_edit_dual_apply_stage1_f64")
+        int(bool(use_inverse)), _ptr(ws.buf), ws.nbytes, _stream(K)), "emcid_edit_dual_apply_stage1_f64")
     if gather_yt is not None:
         ws.Yt[:N].copy_(gather_yt(ws.Yt[lo:hi]))
     dW = torch.empty(h, d, dtype=torch.float32, device=K.device) if want_dw else None
     _check(lib.emcid_edit_dual_apply_stage2_f64(N, d, h, _ptr(factors.buf), factors.n_layers, int(layer_index),
-                                                _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"), _ptr(dW),
+                                                int(bool(use_inverse)), _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"), _ptr(dW),
                                                 _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32), _stream(K)),
            "emcid_edit_dual_apply_stage2_f64")
     return {"dW": dW, "ws": ws}

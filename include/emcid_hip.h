@@ -26,7 +26,7 @@ extern "C" {
 #define EMCID_ERR_HIP (-2)
 #define EMCID_ERR_WORKSPACE (-3)
 
-#define EMCID_ABI_VERSION 1
+#define EMCID_ABI_VERSION 2
 
 /* ABI version of the loaded library (host-only, no GPU needed). */
 int emcid_abi_version(void);
@@ -35,9 +35,10 @@ const char* emcid_last_error(void);
 
 /* Optional per-kernel-class timing with HIP events recorded on the launch stream (bench.py's live
  * roofline measurement).  class ids: 0 prep, 1 assemble(SYRK), 2 chol_leaf, 3 chol_panel, 4 chol_trail,
- * 5 trsm_diag, 6 trsm_update, 7 delta_w, 8 gram, 9 gather, 10 dgemm, 11 misc, 12 inverse build, 13 chol_inner.  enable(mask) resets the
+ * 5 trsm_diag, 6 trsm_update, 7 delta_w, 8 gram, 9 gather, 10 dgemm, 11 misc, 12 inverse build, 13 chol_inner,
+ * 14 inverse apply (GEMMs against the explicit inverse factor).  enable(mask) resets the
  * log; collect() synchronises the recorded events and returns summed milliseconds and launch counts. */
-#define EMCID_PROF_CLASSES 14
+#define EMCID_PROF_CLASSES 15
 int emcid_profile_enable(unsigned class_mask);
 int emcid_profile_collect(double* ms_per_class_host, int64_t* launches_per_class_host, int n_classes);
 
@@ -117,6 +118,7 @@ int emcid_edit_layer_f64(const float* K, const float* Zc, const float* zs_t, con
                          const float* W0, float* W,
                          double* Xt_out, double* Rt_out, float* dW_out,
                          void* workspace, int64_t workspace_bytes, int* info_dev, void* stream);
+int emcid_cov_inverse_f64(void* cov_factor_ws, int64_t n_layers, int64_t d, int64_t first_layer, int64_t count, void* stream);
 
 /* Concept-sharded variant (multi-GPU): K, Zc, zs_t hold ALL N concepts (after the all-gather),
  * A is assembled and factored from all of them, but only the rows [n_lo, n_hi) go through the triangular
@@ -138,7 +140,12 @@ int emcid_apply_update_f32(const double* U, const float* W0, float* W, float* dW
  * Np x Np matrix S = I + Pt Kt64^T (Np = N rounded up to 128).  Same inputs, same scaling rules and outputs as
  * emcid_edit_layer_f64; results agree to ~1e-10 relative (fp64 rounding of a different but exact identity).
  *   emcid_factor_cov_f64      C_host_list: HOST array of n_layers device pointers to C_l [d,d] fp32.
- *   emcid_edit_dual_stage1    Kt64, Rt, and rows [n_lo, n_hi) of Pt (two triangular solves against M's factor).
+ *   emcid_cov_inverse_f64     X_l = inv(L_l), explicit, for layers [first_layer, first_layer + count) of the factored
+ *                             workspace in batched launches (~d^3/3 flops per layer, GEMMs).  Solves against those M_l
+ *                             can then run as two GEMMs against X_l (use_inverse = 1 below) instead of block
+ *                             substitutions with L_l (use_inverse = 0, needs no X_l).  A range, so that the first
+ *                             layer's edit can start on L alone while the later layers' X are built underneath it.
+ *   emcid_edit_dual_stage1    Kt64, Rt, and rows [n_lo, n_hi) of Pt = Kt64 M^-1 (= (Kt64 X^T) X with use_inverse).
  *   emcid_edit_dual_pt        address of the Pt stack [Np, dp] inside the workspace (multi-GPU: all-gather rows there).
  *   emcid_edit_dual_stage2    needs all rows of Pt: S, its Cholesky, adj_k = (S^-1 Pt)^T [d,N], U = Rt^T Xt, W = W0 + float(U).
  * ------------------------------------------------------------------------------------------- */
@@ -148,8 +155,8 @@ int emcid_factor_cov_f64(const float* const* C_host_list, int64_t n_layers, int6
 int64_t emcid_edit_dual_workspace_bytes(int64_t N, int64_t d, int64_t h);
 int emcid_edit_dual_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
                                double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
-                               int64_t layer_index, int64_t n_lo, int64_t n_hi, void* workspace, int64_t workspace_bytes,
-                               void* stream);
+                               int64_t layer_index, int64_t n_lo, int64_t n_hi, int use_inverse, void* workspace,
+                               int64_t workspace_bytes, void* stream);
 double* emcid_edit_dual_pt(void* workspace, int64_t N, int64_t d, int64_t h);
 int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, const float* W0, float* W, double* adjk_out, double* Rt_out,
                                float* dW_out, void* workspace, int64_t workspace_bytes, int* info_dev, void* stream);
@@ -160,12 +167,12 @@ int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, const float* W0,
  * workspace (multi-GPU all-gather target), stage2 needs all rows of Yt. */
 int emcid_edit_dual_apply_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
                                      double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
-                                     int64_t layer_index, int64_t n_lo, int64_t n_hi, void* workspace,
+                                     int64_t layer_index, int64_t n_lo, int64_t n_hi, int use_inverse, void* workspace,
                                      int64_t workspace_bytes, void* stream);
 double* emcid_edit_dual_yt(void* workspace, int64_t N, int64_t d, int64_t h);
 int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void* cov_factor_ws, int64_t n_layers,
-                                     int64_t layer_index, const float* W0, float* W, float* dW_out, void* workspace,
-                                     int64_t workspace_bytes, int* info_dev, void* stream);
+                                     int64_t layer_index, int use_inverse, const float* W0, float* W, float* dW_out,
+                                     void* workspace, int64_t workspace_bytes, int* info_dev, void* stream);
 
 /* The stages of emcid_edit_layer_f64 as separate calls (used by tests and micro-benchmarks). */
 
@@ -197,6 +204,14 @@ int emcid_delta_w_f64(const double* Rt, int64_t ldr, const double* Xt, int64_t l
 int emcid_dgemm_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
                     const double* A, int64_t lda, const double* B, int64_t ldb,
                     double beta, double* C, int64_t ldc, void* stream);
+/* The same GEMM with the structure hints the solver uses (tests / micro-benchmarks of those shapes):
+ * flags bits 0-3 = triangular operands (1: B(k,n)=0 for k>n, 2: B(k,n)=0 for k<n, 4: A(m,k)=0 for k>m, 8: A(m,k)=0 for
+ * k<m), bit 4 = compute only output tiles that touch the lower triangle; cfg: -1 auto, 0 = 128x128, 1 = 64x64,
+ * 2 = 32x64 tiles; ksplit: 0 auto, n > 0 = even n-way split of K, n < 0 = fixed runs of |n| K-tiles (16 deep) per
+ * workgroup; splits need beta == 1 (partials are added with f64 atomics). */
+int emcid_dgemm_ex_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
+                       const double* A, int64_t lda, const double* B, int64_t ldb,
+                       double beta, double* C, int64_t ldc, int flags, int cfg, int ksplit, void* stream);
 
 /* W[h,d] += dW[h,d]  (final insert, reference: emcid_main.py:802-809 `w[...] += upd_matrix.float()`). */
 int emcid_axpy_f32(float* W, const float* dW, int64_t n, void* stream);

@@ -87,6 +87,7 @@ def _edit_inputs(N, d, h, seed):
 
 
 @pytest.mark.parametrize("N,d,h,lam,ew,left", [(8, 128, 32, 50.0, 0.6, 3), (5, 192, 48, 90.0, 0.5, 1),
+                                              (50, 1400, 96, 300.0, 0.5, 2),     # dp = 1408: short last 512-block
                                               (100, 3072, 768, 4000.0, 0.5, 4), (1000, 3072, 768, 4000.0, 0.5, 2),
                                               (1, 3072, 768, 4000.0, 0.5, 1), (130, 5120, 1280, 10000.0, 0.5, 5)])
 def test_edit_layer_vs_oracle(N, d, h, lam, ew, left):
@@ -252,6 +253,7 @@ def test_tree_attention_vs_dense_reference():
 
 
 @pytest.mark.parametrize("N,d,h,lam,ew,left", [(8, 128, 32, 50.0, 0.6, 3), (5, 192, 48, 90.0, 0.5, 1),
+                                              (50, 1400, 96, 300.0, 0.5, 2),     # dp = 1408: short last 512-block
                                               (100, 3072, 768, 4000.0, 0.5, 4), (1000, 3072, 768, 4000.0, 0.5, 2),
                                               (300, 5120, 1280, 10000.0, 0.5, 5)])
 def test_dual_solver_vs_oracle(N, d, h, lam, ew, left):
@@ -260,6 +262,11 @@ def test_dual_solver_vs_oracle(N, d, h, lam, ew, left):
     Cov2 = Cov * 1.5 + torch.eye(d) * 1e-3                       # a second layer's statistics in the same batch
     adj_k, resid, upd = orc.closed_form_layer(K, Zc, zs, Cov, lam, ew, left)
     fac = hip.factor_cov([Cov2.to(DEV), Cov.to(DEV)], lam, ew)
+    # the explicit inverse factor the per-layer GEMMs run against: X L = I on the lower triangles
+    for l in (0, 1):
+        Lm, Xm = torch.tril(fac.L(l)), torch.tril(fac.X(l))
+        eye = torch.eye(fac.dp, dtype=torch.float64, device=DEV)
+        assert (Xm @ Lm - eye).abs().max().item() < 1e-9
     Wd = torch.empty(h, d, dtype=torch.float32, device=DEV)
     out = hip.edit_layer_dual(K.to(DEV), Zc.to(DEV), zs.t().contiguous().to(DEV), fac, 1, ew, left,
                               W0=W0.to(DEV), W=Wd, want_factors=True)
@@ -277,6 +284,15 @@ def test_dual_solver_vs_oracle(N, d, h, lam, ew, left):
     dwa_err = (oa["dW"].cpu().double() - upd).abs().max().item()
     assert dwa_err <= 1e-6 * scale + 1e-12 and dwa_err < 1e-4, (dwa_err, scale)
     assert (Wa.cpu() - (W0 + upd.float())).abs().max().item() <= 1e-6 * max(scale, 1.0)
+    # block substitution with L instead of GEMMs against X = inv(L) (what the first edited layer runs): same weights
+    Wt = torch.empty(h, d, dtype=torch.float32, device=DEV)
+    ot = hip.edit_layer_dual_apply(K.to(DEV), Zc.to(DEV), zs.t().contiguous().to(DEV), fac, 1, ew, left, W0.to(DEV), Wt,
+                                   use_inverse=False)
+    dwt_err = (ot["dW"].cpu().double() - upd).abs().max().item()
+    assert dwt_err <= 1e-6 * scale + 1e-12 and dwt_err < 1e-4, (dwt_err, scale)
+    ofull = hip.edit_layer_dual(K.to(DEV), Zc.to(DEV), zs.t().contiguous().to(DEV), fac, 1, ew, left, want_factors=True,
+                                use_inverse=False)
+    assert (ofull["adj_k"].cpu() - adj_k).abs().max().item() <= 1e-8 * adj_k.abs().max().item()
     # row-sharded M-solves (multi-GPU split) give the same Pt rows
     ws2 = hip.DualWorkspace(N, d, h, DEV)
     if N >= 4:
