@@ -155,6 +155,194 @@ __device__ __forceinline__ v4d leaf_tile(const double* lds, FA fa, FB fb, int l1
     return acc0 + acc1;
 }
 
+// ---- phase A on the matrix pipe ---------------------------------------------------------------------------------------
+// The 32x32 diagonal block W = [T | E] (T symmetric, E = I) is held by ONE wave as 16x16 f64 MFMA accumulator tiles
+// (element (row, col) of a tile sits in lane (col, row & 3), register row >> 2) and eliminated four pivot rows at a
+// time:   R = inv(chol(T[p,p])) * W[p, :]   (the pivot rows become rows of [L^T | L^-1]),
+//         W[i, :] -= R[:, i]^T * R           (rows below)
+// In that layout a 4 x 16 slab of pivot rows is at once the MFMA B operand (k = pivot row, n = column) and — read as
+// "column tile i" — the A operand of the update of row tile i (m = row, k = pivot row): no data movement between
+// steps.  Scaling the slab by the inverse 4x4 factor is one more MFMA whose A operand carries that inverse in its
+// first four rows; only the 4x4 factorization itself (10 values fetched with v_readlane, ~40 scalar-uniform flops)
+// is outside the matrix pipe.  The lower-left T tile is never needed (its rows' pivots come later and read only
+// columns right of the diagonal), so three T tiles and three E tiles are live.
+struct Inv44 { double w00, w10, w11, w20, w21, w22, w30, w31, w32, w33; };
+
+__device__ __forceinline__ v4d mfma_f64(double a, double b, v4d c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+// 1/sqrt(p) on the pivot chain: hardware estimate + ONE third-order correction (4 dependent fp64 ops instead of the
+// 6 of two Newton steps):  e = 1 - p r^2,  r <- r + r e (1/2 + 3/8 e)   (error ~ e^3)
+__device__ __forceinline__ double rsqrt_chain(double p) {
+    const double r = __builtin_amdgcn_rsq(p);
+    const double e = fma(-p * r, r, 1.0);
+    return fma(r * e, fma(e, 0.375, 0.5), r);
+}
+
+// src holds the 4x4 SPD block D at lanes 16*a + lane0 + b (a = row, b = col); returns inv(chol(D)); bad = first
+// non-positive pivot (0..3) or 4.  Written for dependency depth: everything that does not need the newest
+// reciprocal root is formed before it arrives.
+__device__ __forceinline__ Inv44 inv_chol44(double src, int lane0, int& bad) {
+    double d[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) d[a][b] = readlane_f64(src, 16 * a + lane0 + b);
+    // Pivots are taken in PAIRS: for [[a, b], [b, c]] the second pivot is det/a with det = a c - b^2 (the same
+    // cancellation as c - (b/sqrt a)^2), so 1/sqrt(a) and 1/sqrt(det) are refined side by side and
+    // r1 = 1/sqrt(det/a) = (a r0) rsqrt(det): two reciprocal roots for the latency of one.
+    const double a = d[0][0], b = d[1][0];
+    const double det01 = fma(a, d[1][1], -(b * b));
+    const double r0 = rsqrt_chain(a), rd01 = rsqrt_chain(det01);
+    const double r1 = (a * r0) * rd01;
+    const double l10 = b * r0, l20 = d[2][0] * r0, l30 = d[3][0] * r0;
+    const double t21 = fma(-l20, l10, d[2][1]), t31 = fma(-l30, l10, d[3][1]);
+    const double q22a = fma(-l20, l20, d[2][2]), q32a = fma(-l30, l20, d[3][2]), q33a = fma(-l30, l30, d[3][3]);
+    const double l21 = t21 * r1, l31 = t31 * r1;
+    const double p2 = fma(-l21, l21, q22a), t32 = fma(-l31, l21, q32a), q33b = fma(-l31, l31, q33a);
+    const double det23 = fma(p2, q33b, -(t32 * t32));
+    const double r2 = rsqrt_chain(p2), rd23 = rsqrt_chain(det23);
+    const double r3 = (p2 * r2) * rd23;
+    const double l32 = t32 * r2;
+    // first non-positive (or NaN) pivot, 4 = none (pivot 1 = det01/a, pivot 3 = det23/p2); independent selects + min
+    // instead of an early-exit chain, which the compiler turns into scalar branches in the middle of the chain
+    const int b0 = a > 0.0 ? 4 : 0, b1 = det01 > 0.0 ? 4 : 1, b2 = p2 > 0.0 ? 4 : 2, b3 = det23 > 0.0 ? 4 : 3;
+    bad = min(min(b0, b1), min(b2, b3));
+    // inverse of the factor, row by row; each row's last multiply is by its own reciprocal root
+    Inv44 w;
+    w.w00 = r0;
+    const double u10 = -l10 * r0;                     // w10 = u10 * r1
+    w.w10 = u10 * r1; w.w11 = r1;
+    const double l20r0 = l20 * r0;
+    w.w20 = -fma(l21, w.w10, l20r0) * r2; w.w21 = -(l21 * r1) * r2; w.w22 = r2;
+    const double s30 = fma(l31, w.w10, l30 * r0), s31 = l31 * r1;
+    w.w30 = -fma(l32, w.w20, s30) * r3; w.w31 = -fma(l32, w.w21, s31) * r3; w.w32 = -(l32 * r2) * r3; w.w33 = r3;
+    return w;
+}
+
+// One wave.  In: the lower triangle of the block at S[c0.., c0..].  Out: L^-1 -> the same block of S (the panel solve
+// multiplies by its transpose), L^T tiles -> 12 staging rows of 64 doubles (flush_diag_block), first bad pivot -> badcol.
+__device__ __forceinline__ void factor32_mfma(double* S, double* stage, int c0, int lane, int& badcol, long long* dbg = nullptr) {
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int nst = 0;
+    auto stamp = [&]() {
+        if (dbg && lane == 0) dbg[nst] = (long long)__builtin_amdgcn_s_memtime();
+        ++nst;
+    };
+    stamp();
+    v4d T00, T01, T11, E00, E10, E11;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = l4 + 4 * r, col = l15;
+        const int hi = row > col ? row : col, lo = row > col ? col : row;
+        T00[r] = S[(c0 + hi) * SLD + c0 + lo];
+        T01[r] = S[(c0 + 16 + col) * SLD + c0 + row];
+        T11[r] = S[(c0 + 16 + hi) * SLD + c0 + 16 + lo];
+        E00[r] = row == col ? 1.0 : 0.0;
+        E11[r] = E00[r];
+        E10[r] = 0.0;
+    }
+    stamp();
+    const v4d zero = {0.0, 0.0, 0.0, 0.0};
+    // lane (m, k) of the scaling MFMA's A operand carries inv[m][k] (m < 4, k <= m), zero elsewhere.  Bitwise select
+    // with lane-constant masks: plain AND/OR on the pivot chain (a ternary chain here gets compiled into a
+    // dynamically indexed private array, i.e. a scratch-memory round trip per step)
+    auto lane_mask = [&](int m, int k) { return (l15 == m && l4 == k) ? ~0ull : 0ull; };
+    const unsigned long long M00 = lane_mask(0, 0), M10 = lane_mask(1, 0), M11 = lane_mask(1, 1), M20 = lane_mask(2, 0),
+                             M21 = lane_mask(2, 1), M22 = lane_mask(2, 2), M30 = lane_mask(3, 0), M31 = lane_mask(3, 1),
+                             M32 = lane_mask(3, 2), M33 = lane_mask(3, 3);
+    auto bits = [](double x) { return (unsigned long long)__double_as_longlong(x); };
+    auto a_operand = [&](const Inv44& w) {
+        const unsigned long long v = (bits(w.w00) & M00) | (bits(w.w10) & M10) | (bits(w.w11) & M11) | (bits(w.w20) & M20) |
+                                     (bits(w.w21) & M21) | (bits(w.w22) & M22) | (bits(w.w30) & M30) | (bits(w.w31) & M31) |
+                                     (bits(w.w32) & M32) | (bits(w.w33) & M33);
+        return __longlong_as_double((long long)v);
+    };
+    // the scaled pivot rows (final rows of [L^T | L^-1]) are kept apart from the accumulators: nothing reads an
+    // accumulator's pivot rows again (the update's A operand is zero there)
+    double fT00[4], fT01[4], fE00[4], fT11[4], fE10[4], fE11[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {               // pivot rows 4q .. 4q+3 (row tile 0)
+        int bad;
+        const Inv44 w = inv_chol44(T00[q], 4 * q, bad);
+        badcol = (badcol < 0 && bad < 4) ? c0 + 4 * q + bad : badcol;
+        const double aw = a_operand(w);
+        // the next pivot block lives in T00 (q < 3) or T11 (q == 3): its slab and its update go down the matrix pipe first
+        const double sT0 = mfma_f64(aw, T00[q], zero)[0];
+        const double a0 = l15 >= 4 * q + 4 ? -sT0 : 0.0;         // rows of tile 0 below the pivot rows
+        if (q < 3) T00 = mfma_f64(a0, sT0, T00);
+        __builtin_amdgcn_sched_barrier(0);                       // keep this pair ahead of the independent slabs
+        const double sT1 = mfma_f64(aw, T01[q], zero)[0];
+        const double a1 = -sT1;                                  // every row of tile 1
+        if (q == 3) { T11 = mfma_f64(a1, sT1, T11); __builtin_amdgcn_sched_barrier(0); }
+        const double sE0 = mfma_f64(aw, E00[q], zero)[0];
+        fT00[q] = sT0; fT01[q] = sT1; fE00[q] = sE0;
+        if (q < 3) {
+            T01 = mfma_f64(a0, sT1, T01);
+            E00 = mfma_f64(a0, sE0, E00);
+            T11 = mfma_f64(a1, sT1, T11);
+        }
+        E10 = mfma_f64(a1, sE0, E10);
+        stamp();
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {               // pivot rows 16 + 4q .. (row tile 1)
+        int bad;
+        const Inv44 w = inv_chol44(T11[q], 4 * q, bad);
+        badcol = (badcol < 0 && bad < 4) ? c0 + 16 + 4 * q + bad : badcol;
+        const double aw = a_operand(w);
+#ifdef EMCID_LEAF_MIDSTAMP
+        stamp();
+#endif
+        const double sT1 = mfma_f64(aw, T11[q], zero)[0];
+        const double a1 = l15 >= 4 * q + 4 ? -sT1 : 0.0;
+        if (q < 3) T11 = mfma_f64(a1, sT1, T11);
+        __builtin_amdgcn_sched_barrier(0);
+        const double sE0 = mfma_f64(aw, E10[q], zero)[0];
+        const double sE1 = mfma_f64(aw, E11[q], zero)[0];
+        fT11[q] = sT1; fE10[q] = sE0; fE11[q] = sE1;
+        if (q < 3) {
+            E10 = mfma_f64(a1, sE0, E10);
+            E11 = mfma_f64(a1, sE1, E11);
+        }
+        stamp();
+    }
+    // ---- outputs.  fT* hold L^T (valid for row <= col), fE* hold L^-1 (upper right tile = 0).
+    stamp();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = l4 + 4 * r, col = l15;
+        // L^-1 replaces the block in S (the panel solve reads it from there, transposed)
+        S[(c0 + row) * SLD + c0 + col] = fE00[r];
+        S[(c0 + row) * SLD + c0 + 16 + col] = 0.0;
+        S[(c0 + 16 + row) * SLD + c0 + col] = fE10[r];
+        S[(c0 + 16 + row) * SLD + c0 + 16 + col] = fE11[r];
+    }
+    stamp();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // L^T tiles -> staging rows (lane-linear, conflict free); another wave takes them to global
+        stage[(0 + r) * SLD + lane] = fT00[r];
+        stage[(4 + r) * SLD + lane] = fT01[r];
+        stage[(8 + r) * SLD + lane] = fT11[r];
+    }
+    stamp();
+}
+
+// second half of phase A's output, by a wave that is not on the pivot chain: L_pp -> global from the staged L^T tiles
+// (L[i][j] = L^T[j][i]; a lane's four rows are adjacent columns of L; zeros above the diagonal)
+__device__ __forceinline__ void flush_diag_block(const double* stage, int c0, double* __restrict__ L, int64_t ldl, int lane) {
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = l4 + 4 * r, col = l15;
+        double* Lc = L + (int64_t)(c0 + col) * ldl + c0;
+        Lc[row] = row <= col ? stage[(0 + r) * SLD + lane] : 0.0;
+        Lc[16 + row] = 0.0;
+        double* Lc1 = Lc + 16 * ldl;
+        Lc1[row] = stage[(4 + r) * SLD + lane];
+        Lc1[16 + row] = row <= col ? stage[(8 + r) * SLD + lane] : 0.0;
+    }
+}
+
 __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restrict__ A, int64_t lda, double* __restrict__ L,
                                                             int64_t ldl, double* __restrict__ inv, int64_t ldinv, int* info,
                                                             int col0, long long* dbg = nullptr, int64_t s_mat = 0,
@@ -206,45 +394,13 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
         const int R0 = c0 + SB;               // first row below the diagonal block
         const int mb = (NB - R0) / 16;        // 16-row blocks below
 
-        // ---- phase A: wave 0 factors the diagonal block and its inverse in registers -----------------------
-        if (wave == 0) {
-            double a[SB];
-            const int r = lane & 31;
-            if (lane < 32) {
-#pragma unroll
-                for (int j = 0; j < SB; ++j) a[j] = S[(c0 + r) * SLD + c0 + j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < SB; ++j) a[j] = (j == r) ? 1.0 : 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < SB; ++k) {
-                const double dkk = readlane_f64(a[k], k);
-                if (badcol < 0 && !(dkk > 0.0)) badcol = c0 + k;
-                const double rs = rsqrt_f64(dkk);
-                a[k] *= rs;                                   // column k of [L; Z]
-#pragma unroll
-                for (int j = k + 1; j < SB; ++j) {
-                    const double ljk = readlane_f64(a[k], j);  // L[j][k]
-                    a[j] = fma(-a[k], ljk, a[j]);
-                }
-            }
-            if (lane < 32) {
-                // L_pp -> global (lower valid, zeros above)
-#pragma unroll
-                for (int j = 0; j < SB; ++j) L[(int64_t)(c0 + r) * ldl + c0 + j] = (j <= r) ? a[j] : 0.0;
-            } else {
-                // Z = L^-T.  Zs[k][c] = Z[k][c] feeds the panel solve; inv_pp[rr][c] = Z[c][rr] replaces the
-                // diagonal block in S (nothing reads L_pp from LDS any more).
-#pragma unroll
-                for (int j = 0; j < SB; ++j) {
-                    lds[ZOFF + r * ZLD + j] = a[j];
-                    S[(c0 + j) * SLD + c0 + r] = a[j];
-                }
-            }
-        }
+        // ---- phase A: wave 0 factors the diagonal block and its inverse on the matrix pipe (factor32_mfma) ------------
+        // staging rows: the never-touched upper right quadrant S[0:64][64:128] (12 rows per panel; lvl2 reuses it later)
+        double* stage = S + (12 * p) * SLD + 64;
+        if (wave == 0) factor32_mfma(S, stage, c0, lane, badcol, (dbg && p == 1) ? dbg + 16 : nullptr);
         __syncthreads();
         stamp();
+        if (wave == LEAF_T / 64 - 1) flush_diag_block(stage, c0, L, ldl, lane);   // the last wave has the fewest panel rows
         if (mb == 0) break;
 
         // ---- phase B: P = A_below * Z (rows R0.., 32 columns), in place; one wave owns a 16-row block ---------
@@ -254,7 +410,7 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
                 acc[cb] = leaf_tile<SB>(lds, [&](int i, int k) { return (r0 + i) * SLD + c0 + k; },
-                                        [&](int k, int j) { return ZOFF + k * ZLD + cb * 16 + j; }, l15, l4);
+                                        [&](int k, int j) { return (c0 + cb * 16 + j) * SLD + c0 + k; }, l15, l4);   // Z[k][c] = inv[c][k]
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll

@@ -21,3 +21,12 @@ for n, a, b in zip(names[1:], vals[:-1], vals[1:]):
 print("total", vals[-1] - vals[0])
 err = (torch.tril(L) @ torch.tril(L).t() - A).abs().max().item()
 print("factor err", err, "inv err", (inv @ torch.tril(L) - torch.eye(128, dtype=torch.float64, device="cuda:0")).abs().max().item())
+import os
+mid = os.environ.get("MIDSTAMP") == "1"
+a = s[16:16 + (17 if mid else 13)]
+if any(a):
+    names2 = ["load"] + [f"step{i}" for i in range(4)] + (sum([[f"step{i} valu", f"step{i} mfma"] for i in range(4, 8)], []) if mid else [f"step{i}" for i in range(4, 8)]) + ["(stamp)", "out-lds", "out-stage"]
+    print("phase A (panel 1) detail:")
+    for n, x, y in zip(names2, a[:-1], a[1:]):
+        if y:
+            print(f"  {n:10s} {y - x:8d}")
