@@ -142,13 +142,18 @@ def main():
     # on the launch stream (emcid_profile_*; the graph replay is bypassed while events are recorded, the kernels and
     # their arguments are identical).  The class with the most time is reported. --------------------------------------
     mfma_classes = ["assemble", "chol_panel", "chol_trail", "chol_inner", "trsm_diag", "trsm_update", "delta_w", "inv_build",
-                    "inv_apply"]
+                    "inv_apply", "inv_block"]
+    # For this pass the covariance factorization runs on the SAME stream as everything else: with the two streams
+    # overlapped, an event pair around a small kernel of one stream also counts the time it queued behind the other's.
+    side = plan.side_stream
+    plan.side_stream = torch.cuda.current_stream()
     hip.profile_enable(mfma_classes + ["chol_leaf"])
     for _ in range(args.steps):
         step()
     sync()
     prof = hip.profile_collect()
     hip.profile_enable([])
+    plan.side_stream = side
     d, h = 3072, 768
     n_rows = (lambda b: b[1] - b[0])(shard.bounds(args.concepts)) if world > 1 else args.concepts
     N, L = args.concepts, len(LAYERS)
@@ -185,10 +190,13 @@ def main():
         add(chol_flops(d), L)
         add(chol_flops(Np), L)
         add(trsm_flops(h, Np, 2), L)
-        per_step_flops["inv_apply"] = L * (n_rows + h) * d * d
-        per_step_flops["inv_build"] = L * sum(512 * (512 * i) ** 2 + 512 * 512 * (512 * i) for i in range(1, d // 512))
-        per_step_flops["assemble"] = L * N * N * d
-        per_step_flops["delta_w"] = L * 2 * h * N * d
+        # the first edited layer(s) substitute with L (forward on the concept rows, backward on h rows); the others
+        # multiply by X = inv(L), which is built for them only (edit_engine: EMCID_INVERSE_FROM, default 1)
+        first_x = min(L, max(0, int(os.environ.get("EMCID_INVERSE_FROM", "1"))))
+        add(trsm_flops(n_rows, d, 1), first_x)
+        add(trsm_flops(h, d, 1), first_x)
+        per_step_flops["inv_apply"] = (L - first_x) * (n_rows + h) * d * d
+        per_step_flops["inv_build"] = (L - first_x) * (d ** 3 // 3 - (d // 512) * 512 ** 3 // 3)   # minus the 512-blocks
     else:
         add(chol_flops(d), L)
         add(trsm_flops(n_rows, d, 2), L)
@@ -211,7 +219,7 @@ def main():
                  "delta_w": "gemm_f64_kernel<!KC,*,64,64,16,2,2,EpiDeltaW> (dW = R^T X)",
                  "inv_apply": "gemm_f64_kernel<KC,*,*,64,16,2,2,*> launched as GEMM against the explicit inverse factor "
                               "(Kt X^T, V X; triangular K range)",
-                 "inv_build": "gemm_f64_kernel<KC,!KC,*,*,16,*> launched as block-row build of X = inv(L)"}
+                 "inv_build": "gemm_f64_kernel<KC,!KC,*,*,16,*> launched as recursive-halving build of X = inv(L)"}
         roofline = {"bound": "mfma", "kernel": names[top], "class": top, "achieved": achieved,
                     "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F64_MFMA_PEAK_TFLOPS,
                     "traffic": None, "avg_launch_us": ms * 1e3 / launches, "launches": launches,

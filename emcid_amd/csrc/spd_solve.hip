@@ -517,7 +517,7 @@ static void build_block_inverses(const double* L, int64_t dp, int64_t lda, doubl
         p.tri = b_lower ? 2 : 0;   // B stored [k][n] and lower triangular: zero for k < n
         launch_gemm_f64<true, false>(p, EpiAxpby{C, ldC, alpha, 0.0, sC}, st, 1);
     };
-    ScopedProf sp(KC_INV_BUILD, st);
+    ScopedProf sp(KC_INV_BLOCK, st);
     const int64_t sI = (int64_t)OB * OB, sT = (int64_t)TB * TB, sL = (int64_t)OB * lda + OB;
     // level a: 256-blocks from pairs of 128-inverses.  u selects the pair inside an OB block.
     for (int u = 0; u < 2; ++u) {
@@ -674,12 +674,13 @@ static int cholesky_solve_impl(const double* L, int64_t dp, int64_t lda, const d
 }
 
 // X = inv(L), explicit, for `nbatch` factors at once (the dual solver's M = lam*C' factors: they do not depend on the
-// concepts, so every layer's two triangular solves become two GEMMs against X).  Block rows of OB:
-//   X[J][J] = inv(L_JJ)                         (already formed by build_block_inverses)
-//   X[I][0:I] = -inv(L_II) * (L[I][0:I] * X[0:I][0:I])      I = 1 .. nob-1
-// Both products skip the structurally zero part of their triangular operand, so the build costs ~dp^3/3 flops.
-// T: scratch, nbatch x (>= OB * dp) doubles with stride s_mat.  Only the lower triangle of X (and the zeros inside its
-// diagonal 128-blocks) is written; consumers never read anything else.
+// concepts, so a layer's two triangular solves become two GEMMs against X).  Recursive halving over the OB-blocks:
+//   inv([[L11, 0], [L21, L22]]) = [[X11, 0], [-X22 (L21 X11), X22]]
+// with the diagonal OB-blocks taken from build_block_inverses.  Three quarters of the ~dp^3/3 flops sit in the two
+// products of the top split (dp/2 cubed, one operand triangular: its zero part is skipped), which is what makes this
+// form run at GEMM rates; a block-row recurrence has the same flops in 512-row slivers.
+// T: scratch, nbatch x (>= (dp/2)^2 with leading dimension lda) doubles, stride s_mat.  Only the lower triangle of X
+// (and the zeros inside its diagonal 128-blocks) is written; consumers never read anything else.
 __global__ __launch_bounds__(256) void copy_diag_inverse_kernel(const double* __restrict__ invw, int64_t s_inv, double* __restrict__ X,
                                                                  int64_t ldx, int64_t s_x, int64_t dp) {
     const int64_t r = blockIdx.x;                 // global row
@@ -703,21 +704,31 @@ static int build_full_inverse(const double* L, int64_t dp, int64_t lda, const do
     hipLaunchKernelGGL(copy_diag_inverse_kernel, dim3((unsigned)dp, (unsigned)nbatch), dim3(256), 0, st, invw, s_inv, X, lda, s_mat, dp);
     const int nob = (int)((dp + OB - 1) / OB);
     static const int cfg_a = env_flag("EMCID_INV_CFG_A", -1), cfg_b = env_flag("EMCID_INV_CFG_B", -1);   // experiments
-    static const int kchunk = env_flag("EMCID_INV_KCHUNK", 0);
-    for (int I = 1; I < nob; ++I) {
-        const int64_t r0 = (int64_t)I * OB;
-        const int rI = (int)((dp - r0) < OB ? (dp - r0) : OB);
-        GemmShape a{L + r0 * lda, lda, X, lda, rI, (int)r0, (int)r0, 0, s_mat, s_mat, nbatch};
-        a.tri = 2;   // B(k, n) = X[k][n], zero for k < n
-        const bool split = kchunk > 0 && r0 / 16 > kchunk;
-        if (split) {   // deep, uneven K ranges: equal runs of K-tiles per workgroup, partials added atomically into a zeroed T
-            hipLaunchKernelGGL(zero2d_f64_kernel, dim3((unsigned)rI, (unsigned)nbatch), dim3(256), 0, st, T, lda, s_mat, (int)r0);
-            a.kchunk = kchunk;
+    struct Range { int b0, b1; };
+    // post-order over the halving tree, iteratively (depth <= log2(64))
+    Range stack[64];
+    bool expanded[64];
+    int sp_ = 0;
+    stack[sp_] = {0, nob}; expanded[sp_++] = false;
+    while (sp_ > 0) {
+        const Range r = stack[sp_ - 1];
+        if (r.b1 - r.b0 <= 1) { --sp_; continue; }
+        const int mid = r.b0 + (r.b1 - r.b0) / 2;
+        if (!expanded[sp_ - 1]) {
+            expanded[sp_ - 1] = true;
+            stack[sp_] = {r.b0, mid}; expanded[sp_++] = false;
+            stack[sp_] = {mid, r.b1}; expanded[sp_++] = false;
+            continue;
         }
-        launch_gemm_f64<true, false>(a, EpiAxpby{T, lda, 1.0, split ? 1.0 : 0.0, s_mat}, st, cfg_a);
-        GemmShape b{inv_block(invw, I), OB, T, lda, rI, (int)r0, rI, 0, s_inv, s_mat, nbatch};
-        b.tri = 4;   // A(m, k) = inv(L_II)[m][k], zero for k > m
-        launch_gemm_f64<true, false>(b, EpiAxpby{X + r0 * lda, lda, -1.0, 0.0, s_mat}, st, cfg_b);
+        --sp_;
+        const int64_t r0 = (int64_t)r.b0 * OB, rm = (int64_t)mid * OB, r1 = (int64_t)r.b1 * OB < dp ? (int64_t)r.b1 * OB : dp;
+        const int m = (int)(r1 - rm), n = (int)(rm - r0);
+        GemmShape a{L + rm * lda + r0, lda, X + r0 * lda + r0, lda, m, n, n, 0, s_mat, s_mat, nbatch};
+        a.tri = 2;   // B(k, n) = X11[k][n], zero for k < n
+        launch_gemm_f64<true, false>(a, EpiAxpby{T, lda, 1.0, 0.0, s_mat}, st, cfg_a);
+        GemmShape b{X + rm * lda + rm, lda, T, lda, m, n, m, 0, s_mat, s_mat, nbatch};
+        b.tri = 4;   // A(m, k) = X22[m][k], zero for k > m
+        launch_gemm_f64<true, false>(b, EpiAxpby{X + rm * lda + r0, lda, -1.0, 0.0, s_mat}, st, cfg_b);
     }
     return check_launch("build_full_inverse");
 }

@@ -27,7 +27,7 @@ EXPORTS = [
     "emcid_edit_dual_apply_stage1_f64", "emcid_edit_dual_yt", "emcid_edit_dual_apply_stage2_f64",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
-                "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply"]
+                "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block"]
 
 ABI_VERSION = 2
 NB = 128      # Cholesky block (csrc/common.h)

@@ -36,9 +36,9 @@ const char* emcid_last_error(void);
 /* Optional per-kernel-class timing with HIP events recorded on the launch stream (bench.py's live
  * roofline measurement).  class ids: 0 prep, 1 assemble(SYRK), 2 chol_leaf, 3 chol_panel, 4 chol_trail,
  * 5 trsm_diag, 6 trsm_update, 7 delta_w, 8 gram, 9 gather, 10 dgemm, 11 misc, 12 inverse build, 13 chol_inner,
- * 14 inverse apply (GEMMs against the explicit inverse factor).  enable(mask) resets the
+ * 14 inverse apply (GEMMs against the explicit inverse factor), 15 inverse of the 512-blocks (many small products).  enable(mask) resets the
  * log; collect() synchronises the recorded events and returns summed milliseconds and launch counts. */
-#define EMCID_PROF_CLASSES 15
+#define EMCID_PROF_CLASSES 16
 int emcid_profile_enable(unsigned class_mask);
 int emcid_profile_collect(double* ms_per_class_host, int64_t* launches_per_class_host, int n_classes);
 

@@ -14,11 +14,11 @@ for l in range(L):
 fac = hip.factor_cov(covs, 4000.0, 0.5)
 torch.cuda.synchronize()
 for _ in range(3):
-    hip.cov_inverse(fac, -1)
+    hip.cov_inverse(fac)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(10):
-    hip.cov_inverse(fac, -1)
+    hip.cov_inverse(fac)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 10
 flops = L * sum(512 * (512 * i) ** 2 + 512 * 512 * (512 * i) for i in range(1, d // 512))

@@ -92,3 +92,15 @@ for n, e in marks[idx:]:
     print(f"{t0.elapsed_time(e):8.3f} ms  {n}")
 for n, e in side_marks[-3:]:
     print(f"{t0.elapsed_time(e):8.3f} ms  {n}")
+
+# steady state: start-to-start distance of consecutive steps (same marks, no extra instrumentation)
+hip.gather_mean, hip.edit_layer_dual_apply, hip.factor_cov, hip.cov_inverse = o_gather, o_apply, o_fac, o_inv
+marks.clear()
+torch.cuda.synchronize()
+for _ in range(8):
+    step()
+torch.cuda.synchronize()
+starts = [e for n, e in marks if n == "step start"]
+ends = [e for n, e in marks if n == "step end"]
+print("start-to-start ms:", " ".join(f"{a.elapsed_time(b):.2f}" for a, b in zip(starts[:-1], starts[1:])))
+print("start-to-end   ms:", " ".join(f"{a.elapsed_time(b):.2f}" for a, b in zip(starts, ends)))
