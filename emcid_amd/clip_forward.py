@@ -206,7 +206,8 @@ def tune_projections(graph: ClipTextGraph, trie: TokenTrie, upto: int) -> float:
     try:
         t.enable(True)
         t.tuning_enable(True)
-        t.set_filename(os.path.join(tempfile.gettempdir(), f"emcid_tunableop_{os.getuid()}.csv"))
+        # one results file per device and rank: processes of a multi-GPU job must not write the same file at exit
+        t.set_filename(os.path.join(tempfile.gettempdir(), f"emcid_tunableop_{os.getuid()}_gpu{dev.index or 0}_r{os.environ.get('RANK', '0')}.csv"))
         t.set_max_tuning_duration(100)
         t.set_max_tuning_iterations(20)
         with torch.no_grad():
