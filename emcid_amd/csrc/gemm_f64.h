@@ -126,26 +126,21 @@ struct GemmShape {
     // kchunk > 0: instead of an even split, every workgroup takes a fixed run of kchunk K-tiles (blockIdx.z picks the
     // run; runs past the tile's own K range exit at once) — equal work units when `tri` makes the ranges differ
     int kchunk = 0;
+    // pair = 1 (with a triangular operand): one workgroup computes tile j and tile ntiles-1-j of the triangular
+    // dimension, so all workgroups do equal work; the grid is halved along that dimension
+    int pair = 0;
 };
 
 // WGM x WGN waves per workgroup; each wave owns a (BM/WGM) x (BN/WGN) sub-tile.
+// One output tile (bm, bn), K tiles restricted by `tri`, split zs of the K range.
 template <bool KCA, bool KCB, int BM, int BN, int BK, int WGM, int WGN, class Epi>
-__global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Epi epi) {
-    const int zb = blockIdx.z / p.ksplit, zs = blockIdx.z % p.ksplit;
-    p.A += (int64_t)zb * p.sA;
-    p.B += (int64_t)zb * p.sB;
-    epi.batch(zb);
+__device__ __forceinline__ void gemm_f64_tile(const GemmShape& p, const Epi& epi, int bm, int bn, int zs, double* smem) {
     constexpr int NT = WGM * WGN * 64;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 16, NI = WN / 16;
     using TA = OpTile<KCA, BM, BK>;
     using TB = OpTile<KCB, BN, BK>;
     constexpr int STAGE = TA::SIZE + TB::SIZE;
-    __shared__ __attribute__((aligned(16))) double smem[2 * STAGE];
-
-    // tiles whose K range grows with n (tri & 1) or m (tri & 4) are numbered from the far end: long ranges start first
-    const int bm = (p.tri & 4) ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
-    const int bn = (p.tri & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const int m0 = bm * BM, n0 = bn * BN;
     if (p.lower_only && n0 > m0 + BM - 1) return;
 
@@ -223,6 +218,34 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Ep
                 const int n = n0 + wn0 + TB::index_of(j, l15);
                 if (m < p.M && n < p.N) epi(m, n, acc[i][j][r]);
             }
+}
+
+template <bool KCA, bool KCB, int BM, int BN, int BK, int WGM, int WGN, class Epi>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Epi epi) {
+    const int zb = blockIdx.z / p.ksplit, zs = blockIdx.z % p.ksplit;
+    p.A += (int64_t)zb * p.sA;
+    p.B += (int64_t)zb * p.sB;
+    epi.batch(zb);
+    using TA = OpTile<KCA, BM, BK>;
+    using TB = OpTile<KCB, BN, BK>;
+    __shared__ __attribute__((aligned(16))) double smem[2 * (TA::SIZE + TB::SIZE)];
+    if (p.pair) {
+        // triangular K ranges: the workgroup takes column (tri & 3) or row (tri & 12) tile j and its mirror image
+        // ntiles-1-j one after the other — every workgroup then contracts over the same total depth
+        const bool by_n = (p.tri & 3) != 0;
+        const int nt = by_n ? (p.N + BN - 1) / BN : (p.M + BM - 1) / BM;
+        const int j = by_n ? blockIdx.x : blockIdx.y;
+        const int first = (p.tri & (by_n ? 1 : 4)) ? nt - 1 - j : j;       // the long range first
+        const int second = nt - 1 - first;
+        gemm_f64_tile<KCA, KCB, BM, BN, BK, WGM, WGN>(p, epi, by_n ? (int)blockIdx.y : first, by_n ? first : (int)blockIdx.x, zs, smem);
+        if (second != first)
+            gemm_f64_tile<KCA, KCB, BM, BN, BK, WGM, WGN>(p, epi, by_n ? (int)blockIdx.y : second, by_n ? second : (int)blockIdx.x, zs, smem);
+        return;
+    }
+    // tiles whose K range grows with n (tri & 1) or m (tri & 4) are numbered from the far end: long ranges start first
+    const int bm = (p.tri & 4) ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+    const int bn = (p.tri & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    gemm_f64_tile<KCA, KCB, BM, BN, BK, WGM, WGN>(p, epi, bm, bn, zs, smem);
 }
 
 // ---- epilogues -------------------------------------------------------------------------------
@@ -310,15 +333,18 @@ inline void launch_gemm_f64(GemmShape p, Epi epi, hipStream_t stream, int force_
     }
     if (p.ksplit > 1) epi_set_atomic(epi);
     const unsigned gz = (unsigned)(p.batch * p.ksplit);
+    if (p.pair && (p.tri == 0 || p.lower_only)) p.pair = 0;
+    const bool pair_n = p.pair && (p.tri & 3), pair_m = p.pair && !(p.tri & 3);
+    auto half = [](unsigned n, bool h) { return h ? (n + 1) / 2 : n; };
     if (cfg == 0) {
-        dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, gz);
+        dim3 grid(half((p.N + 127) / 128, pair_n), half((p.M + 127) / 128, pair_m), gz);
         hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 128, 128, 16, 2, 4, Epi>), grid, dim3(512), 0, stream, p, epi);
     } else if (cfg == 1) {
-        dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, gz);
+        dim3 grid(half((p.N + 63) / 64, pair_n), half((p.M + 63) / 64, pair_m), gz);
         hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 64, 64, 16, 2, 2, Epi>), grid, dim3(256), 0, stream, p, epi);
     } else {
         if constexpr (KCA) {
-            dim3 grid((p.N + 63) / 64, (p.M + 31) / 32, gz);
+            dim3 grid(half((p.N + 63) / 64, pair_n), half((p.M + 31) / 32, pair_m), gz);
             hipLaunchKernelGGL((gemm_f64_kernel<KCA, KCB, 32, 64, 16, 2, 2, Epi>), grid, dim3(256), 0, stream, p, epi);
         }
     }
