@@ -142,6 +142,8 @@ class SyntheticPipe(SimpleNamespace):
         self.text_encoder.to(device)
         if getattr(self, "text_encoder_2", None) is not None:
             self.text_encoder_2.to(device)
+        if getattr(self, "unet", None) is not None:
+            self.unet.to(device)
         return self
 
 
@@ -157,6 +159,92 @@ def build_pipe(kind: str = "toy", device: str = "cpu", sdxl: bool = False, seed:
     te2 = build_text_encoder(kind2, len(vocab), seed=seed + 1, name_or_path="synthetic/clip-text-2")
     return SyntheticPipe(text_encoder=te1.to(device), tokenizer=tok,
                          text_encoder_2=te2.to(device), tokenizer_2=build_tokenizer(vocab, merges))
+
+
+# ---- cross-attention K/V stand-in for the UNet -------------------------------------------------------------------
+# Channel widths of the 16 cross-attention blocks: SD-v1.4 [external: its UNet config], and a toy set.  The tree of
+# module NAMES is what the reference addresses (util/globals.py:37-38 through emcid/layer_stats.py:470-495).
+UNET_BLOCK_CHANNELS = {"sd-v1.4": (320, 640, 1280, 1280), "toy": (16, 32, 48, 48)}
+
+
+class _CrossAttention(torch.nn.Module):
+    def __init__(self, text_hidden, channels):
+        super().__init__()
+        self.to_k = torch.nn.Linear(text_hidden, channels, bias=False)
+        self.to_v = torch.nn.Linear(text_hidden, channels, bias=False)
+
+
+class _TransformerBlock(torch.nn.Module):
+    def __init__(self, text_hidden, channels):
+        super().__init__()
+        self.attn2 = _CrossAttention(text_hidden, channels)
+
+
+class _Transformer2D(torch.nn.Module):
+    def __init__(self, text_hidden, channels):
+        super().__init__()
+        self.transformer_blocks = torch.nn.ModuleList([_TransformerBlock(text_hidden, channels)])
+
+
+class _UNetBlock(torch.nn.Module):
+    def __init__(self, text_hidden, channels, n_attn):
+        super().__init__()
+        if n_attn:
+            self.attentions = torch.nn.ModuleList([_Transformer2D(text_hidden, channels) for _ in range(n_attn)])
+
+
+class SyntheticUNet(torch.nn.Module):
+    """The part of a diffusers UNet2DConditionModel the cross-attention edit touches: the ``attn2.to_k`` / ``to_v``
+    projections of the text embedding, under the real module names (down 0-2: two each, down 3: none, mid: one,
+    up 0: none, up 1-3: three each — 16 blocks, 32 matrices for SD-v1.x).  ``forward`` feeds
+    ``encoder_hidden_states`` through every projection, so hooks on them see what they would see in a real UNet."""
+
+    def __init__(self, text_hidden: int, kind: str = "toy", seed: int = 11):
+        super().__init__()
+        c = UNET_BLOCK_CHANNELS[kind]
+        st = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        self.down_blocks = torch.nn.ModuleList([_UNetBlock(text_hidden, c[i], 2 if i < 3 else 0) for i in range(4)])
+        self.mid_block = _UNetBlock(text_hidden, c[3], 1)
+        self.up_blocks = torch.nn.ModuleList([_UNetBlock(text_hidden, c[3 - i], 3 if i > 0 else 0) for i in range(4)])
+        torch.random.set_rng_state(st)
+        for p in self.parameters():
+            p.requires_grad_(False)
+        self.config = SimpleNamespace(_name_or_path=f"synthetic/unet-{kind}", in_channels=4, sample_size=8)
+
+    def forward(self, sample, timestep, encoder_hidden_states=None, **kw):
+        for m in self.modules():
+            if isinstance(m, _CrossAttention):
+                m.to_k(encoder_hidden_states)
+                m.to_v(encoder_hidden_states)
+        return SimpleNamespace(sample=sample)
+
+
+def add_unet(pipe: "SyntheticPipe", kind: str = "toy", seed: int = 11) -> "SyntheticPipe":
+    """Attach a SyntheticUNet (+ the scheduler attribute the reference reads for its dummy timesteps) to a pipe."""
+    hidden = pipe.text_encoder.config.hidden_size
+    dev = pipe.device
+    pipe.unet = SyntheticUNet(hidden, kind, seed).to(dev)
+    pipe.scheduler = SimpleNamespace(config=SimpleNamespace(num_train_timesteps=1000))
+    return pipe
+
+
+def xattn_vstar_cache_path(cache_name: str, request: Dict) -> Path:
+    # reference: emcid/emcid_main.py:373-377
+    return Path(cache_name + f"source_{request['source']}.npz")
+
+
+def write_xattn_vstar_cache(cache_name: str, requests: Sequence[Dict], layer_dims: Dict[str, int], seed: int = 1,
+                            scale: float = 1.0) -> Dict[str, np.ndarray]:
+    """One npz per request in the reference's format (emcid_main.py:411-420): key = layer name, value = a pickled
+    ``{"v_star": array}``.  Returns {layer_name: (N, out_dim)}."""
+    rng = np.random.default_rng(seed)
+    vs = {ln: (rng.standard_normal((len(requests), dim)) * scale).astype(np.float32) for ln, dim in layer_dims.items()}
+    for i, r in enumerate(requests):
+        p = xattn_vstar_cache_path(cache_name, r)
+        p.parent.mkdir(parents=True, exist_ok=True)
+        np.savez(p, **{ln: {"v_star": vs[ln][i]} for ln in layer_dims})
+    return vs
 
 
 def make_requests(n: int, dest: str = "a realist artist", templates: Sequence[str] = ARTIST_TEMPLATES,

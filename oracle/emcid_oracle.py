@@ -352,3 +352,131 @@ def apply_emcid_to_sdxl_text_encoders(pipe, requests, hparams: Dict, mom2_weight
     insert_deltas(pipe.text_encoder, d1)
     insert_deltas(pipe.text_encoder_2, d2)
     return pipe, d1, d2
+
+
+# --------------------------------------------------------------------------------------
+# Cross-attention K/V edit (reference: emcid/emcid_main.py:314-548; emcid/compute_ks.py:52-141;
+# emcid/layer_stats.py:333-427, :470-495, :555-575; util/globals.py:37-38)
+# --------------------------------------------------------------------------------------
+
+UNET_EDIT_TEMPLATES = {   # util/globals.py:37-38 (the two templates this path uses)
+    "cross-k": "{}.{}.attentions.{}.transformer_blocks.0.attn2.to_k",
+    "cross-v": "{}.{}.attentions.{}.transformer_blocks.0.attn2.to_v",
+}
+
+
+def get_to_edit_layername_unet(template_key, block_type, block_idx, sub_idx) -> str:
+    """layer_stats.py:555-575 restricted to the cross-k / cross-v templates."""
+    name = UNET_EDIT_TEMPLATES[template_key].format(block_type, block_idx, sub_idx)
+    if "mid_block" in block_type:
+        name = name.replace(f"mid_block.{block_idx}.", "mid_block.")
+    return name
+
+
+def get_all_cross_attn_kv_layer_names(unet) -> List[str]:
+    """layer_stats.py:470-495: block types in this order, per block every cross-k then every cross-v, names that do
+    not resolve on the UNet are skipped."""
+    names = []
+    for block_type, count in (("down_blocks", 4), ("up_blocks", 4), ("mid_block", 1)):
+        for idx in range(count):
+            for key in ("cross-k", "cross-v"):
+                for sub in (0, 1, 2):
+                    name = get_to_edit_layername_unet(key, block_type, idx, sub)
+                    obj = unet
+                    try:
+                        for part in name.split("."):
+                            obj = getattr(obj, part)
+                    except AttributeError:
+                        continue
+                    names.append(name)
+    return names
+
+
+def layers_input_output_at_words_cross_attn(pipe, requests, module_names) -> Tuple[Dict, Dict]:
+    """compute_ks.py:52-141.  Text encoder on all N*P prompts; per request one UNet forward on its P prompts'
+    embeddings with hooks on every to_k / to_v; input / output rows at each prompt's last subject token, mean over
+    the request's prompts.  Returns ({name: (N, hidden)}, {name: (N, out)})."""
+    device = pipe.device
+    prompts, subjects, counts = expand_requests(requests)
+    assert len(set(counts)) == 1, "All the requests should have the same number of prompts."
+    batch_size = counts[0]
+    inp = tokenize_prompts(prompts, pipe.tokenizer, device)
+    lookup = [find_token_range(pipe.tokenizer, ids, w)[-1] - 1 for ids, w in zip(inp["input_ids"], subjects)]
+    with torch.no_grad():
+        rep = pipe.text_encoder(**inp)[0]                       # last hidden state (final LayerNorm applied)
+    latents = torch.zeros(batch_size, pipe.unet.config.in_channels, pipe.unet.config.sample_size,
+                          pipe.unet.config.sample_size, device=device)     # dummies: the projections only see `rep`
+    timesteps = torch.zeros(batch_size, dtype=torch.long, device=device)
+    mods = dict(pipe.unet.named_modules())
+    ins = {n: [] for n in module_names}
+    outs = {n: [] for n in module_names}
+    for b in range(rep.shape[0] // batch_size):
+        cap = {}
+        hooks = [mods[n].register_forward_hook(lambda m, a, o, n=n: cap.__setitem__(n, (a[0], o))) for n in module_names]
+        try:
+            with torch.no_grad():
+                pipe.unet(latents, timesteps, encoder_hidden_states=rep[b * batch_size:(b + 1) * batch_size])
+        finally:
+            for h in hooks:
+                h.remove()
+        idx = lookup[b * batch_size:(b + 1) * batch_size]
+        for n in module_names:
+            ins[n].append(torch.stack([cap[n][0][i, j, :] for i, j in enumerate(idx)], 0).detach().clone().mean(0))
+            outs[n].append(torch.stack([cap[n][1][i, j, :] for i, j in enumerate(idx)], 0).detach().clone().mean(0))
+    return {n: torch.stack(v, 0) for n, v in ins.items()}, {n: torch.stack(v, 0) for n, v in outs.items()}
+
+
+def load_cov_cross_attn(stats_dir, layer_name, n_samples, precision="float32") -> torch.Tensor:
+    """emcid_main.py:2217-2232 with the statistics already cached on disk (layer_stats.py:361: model_name "unet")."""
+    with np.load(stats_path(stats_dir, layer_name, n_samples, precision, model_name="unet")) as z:
+        return (torch.from_numpy(z["mom2.mom2"]) / int(z["mom2.count"])).float()
+
+
+def load_vstars_cross_attn(cache_name: str, requests, layer_names) -> Dict[str, torch.Tensor]:
+    """emcid_main.py:373-391 + :424-426: per request one npz whose entries are pickled {"v_star": array};
+    zs[name] = stack(dim=1) -> (out, N)."""
+    per = {n: [] for n in layer_names}
+    for r in requests:
+        data = np.load(Path(cache_name + f"source_{r['source']}.npz"), allow_pickle=True)
+        for n in layer_names:
+            per[n].append(torch.from_numpy(data[n].item()["v_star"]))
+    return {n: torch.stack(v, dim=1) for n, v in per.items()}
+
+
+def execute_cross_attn(pipe, requests, hparams: Dict, cache_name, stats_dir, mom2_weight=None, edit_weight=None,
+                       trace: Optional[dict] = None):
+    """emcid_main.py:314-508.  Every to_k / to_v gets the closed form with the SAME keys (the text embedding at the
+    subject token), its own targets and statistics, resid NOT divided by a layer count (:473).  The UNet is restored."""
+    hparams["mom2_update_weight"] = mom2_weight if mom2_weight is not None else hparams["mom2_update_weight"]
+    hparams["edit_weight"] = edit_weight if edit_weight is not None else hparams["edit_weight"]
+    requests = copy.deepcopy(requests)
+    names = get_all_cross_attn_kv_layer_names(pipe.unet)
+    params = dict(pipe.unet.named_parameters())
+    weights = {f"{n}.weight": params[f"{n}.weight"] for n in names}
+    backup = {k: v.detach().clone() for k, v in weights.items()}
+    zs = load_vstars_cross_attn(cache_name, requests, names)
+    deltas = {}
+    with torch.no_grad():
+        ks, cur = layers_input_output_at_words_cross_attn(pipe, requests, names)
+        for n in names:
+            C = load_cov_cross_attn(stats_dir, n, hparams["mom2_n_samples"], hparams["mom2_dtype"])
+            adj_k, resid, upd = closed_form_layer(ks[n], cur[n], zs[n].to(ks[n].device), C, hparams["mom2_update_weight"],
+                                                  hparams["edit_weight"], 1)
+            w = weights[f"{n}.weight"]
+            if upd.shape != w.shape:
+                upd = upd.T
+            w[...] = backup[f"{n}.weight"] + upd.float()
+            deltas[f"{n}.weight"] = (adj_k.detach().cpu(), resid.detach().cpu())
+            if trace is not None:
+                trace[n] = {"K": ks[n].clone(), "Zc": cur[n].clone()}
+        for k, v in weights.items():
+            v[...] = backup[k]
+    return deltas
+
+
+def apply_emcid_to_cross_attn(pipe, requests, hparams: Dict, cache_name, stats_dir, mom2_weight=None, edit_weight=None,
+                              trace=None):
+    """emcid_main.py:511-548: w += float(adj_k @ resid^T matched to w.shape)."""
+    deltas = execute_cross_attn(pipe, requests, hparams, cache_name, stats_dir, mom2_weight, edit_weight, trace)
+    insert_deltas(pipe.unet, deltas)
+    return pipe, deltas

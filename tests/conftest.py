@@ -55,6 +55,36 @@ def write_cov_npz(stats_dir, layer_name, cov, n_samples, batch_tokens=3 * 1024):
     return f
 
 
+def write_cov_npz_model(stats_dir, layer_name, cov, n_samples, model_name):
+    from emcid_amd import synthetic as syn
+
+    f = syn.stats_file(stats_dir, layer_name, n_samples, model_name=model_name)
+    f.parent.mkdir(parents=True, exist_ok=True)
+    np.savez(f, **{"mom2.constructor": "util.runningstats.SecondMoment()", "mom2.count": 1,
+                   "mom2.mom2": np.asarray(cov, dtype=np.float32), "sample_size": n_samples})
+    return f
+
+
+def xattn_from_golden(z, meta, tmp_path, device="cpu"):
+    """Pipe (toy text encoder from the stored state dict + SyntheticUNet whose projections are the fixture's w_orig),
+    v* cache and statistics files of the toy cross-attention fixture.  Returns (pipe, cache_name, stats_dir)."""
+    from emcid_amd import synthetic as syn
+
+    te = pipe_from_golden(z, meta["kind"], prefix="te/")
+    pipe = syn.add_unet(syn.SyntheticPipe(text_encoder=te, tokenizer=syn.build_tokenizer()), meta["kind"],
+                        seed=meta["unet_seed"])
+    mods = dict(pipe.unet.named_modules())
+    cache = str(tmp_path / "xcache") + "/"
+    for li, n in enumerate(meta["layer_names"]):
+        mods[n].weight.data.copy_(torch.from_numpy(z[f"w_orig/{li}"]))
+        write_cov_npz_model(tmp_path / "xstats", n, z[f"cov/{li}"], meta["hparams"]["mom2_n_samples"], "unet")
+    for i, r in enumerate(meta["requests"]):
+        p_ = syn.xattn_vstar_cache_path(cache, r)
+        p_.parent.mkdir(parents=True, exist_ok=True)
+        np.savez(p_, **{n: {"v_star": z[f"vstar/{li}"][i]} for li, n in enumerate(meta["layer_names"])})
+    return pipe.to(device), cache, str(tmp_path / "xstats")
+
+
 def write_vstars(cache_name, requests, vstar, suffix=""):
     from emcid_amd import synthetic as syn
 

@@ -242,6 +242,63 @@ def golden_stage0(ls, scratch, tag="toy_stage0"):
     print(f"[golden] {tag}: wrote {len(out)} arrays")
 
 
+def golden_xattn(em, EMCIDHyperParams, scratch, tag="toy_xattn"):
+    """Reference execute_emcid_cross_attn + apply_emcid_to_cross_attn (emcid_main.py:314-548) on a synthetic pipe whose
+    `unet` is the module tree of cross-attention K/V projections (emcid_amd/synthetic.py: SyntheticUNet)."""
+    pipe = syn.add_unet(syn.build_pipe("toy", "cpu"), "toy")
+    hidden = syn.ENCODER_DIMS["toy"][0]
+    reqs = syn.make_requests(6)
+    lam, ew = 30, 0.6
+    hp_d = syn.sd_hparams_dict(layers=(1,), mom2_update_weight=lam + 1, edit_weight=0.5, mom2_n_samples=1000, prefix="")
+    names = em.get_all_cross_attn_kv_layer_names(pipe)
+    mods = dict(pipe.unet.named_modules())
+    dims = {n: mods[n].out_features for n in names}
+    cache = str(scratch / f"cache_{tag}") + "/"
+    vs = syn.write_xattn_vstar_cache(cache, reqs, dims, seed=4, scale=0.5)
+    # the reference reads these from its module-level STATS_DIR ("data/stats" under the scratch cwd)
+    covs = syn.write_stats_cache(scratch / "data" / "stats", names, hidden, 1000, seed=9, t=512, model_name="unet")
+    em.COV_CACHE.clear()
+    rec = {}
+    orig = em.get_layers_input_output_at_words_cross_attn
+
+    def wrapped(*a, **k):
+        i, o = orig(*a, **k)
+        rec["K"] = {n: v.detach().clone() for n, v in i.items()}
+        rec["Zc"] = {n: v.detach().clone() for n, v in o.items()}
+        return i, o
+
+    em.get_layers_input_output_at_words_cross_attn = wrapped
+    w0 = {n: em.nethook.get_parameter(pipe.unet, n + ".weight").clone() for n in names}
+    hp = EMCIDHyperParams(**hp_d)
+    deltas = em.execute_emcid_cross_attn(pipe, reqs, hp, cache_name=cache, mom2_weight=lam, edit_weight=ew, verbose=False)
+    for n in names:   # invariant: UNet restored
+        assert torch.equal(w0[n], em.nethook.get_parameter(pipe.unet, n + ".weight"))
+    assert hp.mom2_update_weight == lam and hp.edit_weight == ew      # in-place mutation, as in the text-encoder path
+    hp2 = EMCIDHyperParams(**hp_d)
+    em.COV_CACHE.clear()
+    pipe2, orig_unet = em.apply_emcid_to_cross_attn(pipe, reqs, hp2, "cpu", mom2_weight=lam, edit_weight=ew,
+                                                    return_orig_text_model=True, cache_name=cache)
+    em.get_layers_input_output_at_words_cross_attn = orig
+    out = {}
+    for li, n in enumerate(names):
+        adj_k, resid = deltas[n + ".weight"]
+        out[f"vstar/{li}"] = vs[n]
+        out[f"cov/{li}"] = covs[n].astype(np.float32)
+        out[f"K/{li}"] = rec["K"][n].numpy()
+        out[f"Zc/{li}"] = rec["Zc"][n].numpy()
+        out[f"adj_k/{li}"] = adj_k.numpy()
+        out[f"resid/{li}"] = resid.numpy()
+        out[f"w_orig/{li}"] = w0[n].numpy()
+        out[f"w_final/{li}"] = em.nethook.get_parameter(pipe2.unet, n + ".weight").numpy()
+        assert torch.equal(em.nethook.get_parameter(orig_unet, n + ".weight"), w0[n])
+    out.update(state_np(pipe.text_encoder, "te/"))
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump({"kind": "toy", "requests": reqs, "hparams": hp_d, "lam": lam, "ew": ew, "layer_names": names,
+                   "unet_seed": 11}, f, indent=1)
+    print(f"[golden] {tag}: wrote {len(out)} arrays, {len(names)} projections")
+
+
 def golden_token_ranges(find_token_range, tag="token_ranges"):
     tok = syn.build_tokenizer()
     cases = [
@@ -275,6 +332,7 @@ def main():
         golden_sd(em, HP, scratch, "toy_sd", "toy", n_req=8, layers=(1, 2, 3, 4), lam=50, ew=0.6, ragged=True, full=True)
         golden_sdxl(em, XLHP, scratch)
         golden_stage0(ls, scratch)
+        golden_xattn(em, HP, scratch)
         if "--skip-real" not in sys.argv:
             golden_sd(em, HP, scratch, "real_sd_summary", "sd-v1.4", n_req=24, layers=(7, 8, 9, 10), lam=4000,
                       ew=0.5, ragged=False, full=False)

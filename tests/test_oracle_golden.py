@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, load_golden, pipe_from_golden, write_cov_npz, write_vstars
+from conftest import GOLDEN, load_golden, pipe_from_golden, write_cov_npz, write_vstars, xattn_from_golden
 from emcid_amd import synthetic as syn
 from oracle import emcid_oracle as orc
 
@@ -117,3 +117,24 @@ def test_real_dims_summary(tmp_path):
         ref = z[f"dw_probe/{li}"]
         np.testing.assert_allclose((dw @ probe).numpy(), ref, rtol=0, atol=1e-6 * np.abs(ref).max())
         np.testing.assert_allclose(dw.norm().item(), float(z[f"dw_fro/{li}"]), rtol=1e-6)
+
+
+def test_toy_cross_attn_bit_level(tmp_path):
+    """Cross-attention K/V edit (reference emcid_main.py:314-548): layer names and order, keys, current values,
+    adj_k, resid and the 32 final projection matrices against the reference's own outputs."""
+    z, meta = load_golden("toy_xattn")
+    pipe, cache, stats = xattn_from_golden(z, meta, tmp_path)
+    assert orc.get_all_cross_attn_kv_layer_names(pipe.unet) == meta["layer_names"]
+    hp = copy.deepcopy(meta["hparams"])
+    trace = {}
+    pipe, deltas = orc.apply_emcid_to_cross_attn(pipe, meta["requests"], hp, cache, stats, mom2_weight=meta["lam"],
+                                                 edit_weight=meta["ew"], trace=trace)
+    assert hp["mom2_update_weight"] == meta["lam"] and hp["edit_weight"] == meta["ew"]
+    params = dict(pipe.unet.named_parameters())
+    for li, n in enumerate(meta["layer_names"]):
+        np.testing.assert_array_equal(trace[n]["K"].numpy(), z[f"K/{li}"])
+        np.testing.assert_array_equal(trace[n]["Zc"].numpy(), z[f"Zc/{li}"])
+        adj_k, resid = deltas[n + ".weight"]
+        np.testing.assert_allclose(adj_k.numpy(), z[f"adj_k/{li}"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(resid.numpy(), z[f"resid/{li}"], rtol=1e-13, atol=0)
+        np.testing.assert_array_equal(params[n + ".weight"].numpy(), z[f"w_final/{li}"])
