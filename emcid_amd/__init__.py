@@ -2,7 +2,8 @@
 
 Public surface mirrors the reference's (SilentView/EMCID) for this path:
     emcid_amd.emcid_main   apply_emcid_to_text_encoder, apply_emcid_to_sdxl_text_encoders, execute_*,
-                           get_cov_text_encoder, apply_emcid_to_model
+                           get_cov_text_encoder, apply_emcid_to_model,
+                           apply_emcid_to_cross_attn, execute_emcid_cross_attn (UNet cross-attention K/V)
     emcid_amd.layer_stats  layer_stats_text_encoder (Stage 0)
     emcid_amd.compute_ks / compute_z / runningstats / nethook / stat_dataset / causal_trace / emcid_hparams
 The compute is in csrc/ (hand-written HIP for gfx950) behind the C ABI declared in include/emcid_hip.h.
@@ -15,7 +16,8 @@ from .emcid_hparams import EMCIDHyperParams, EMCIDXLHyperParams  # noqa: F401
 def __getattr__(name):
     # lazy: importing the package must not require a built kernel library
     if name in ("apply_emcid_to_text_encoder", "apply_emcid_to_sdxl_text_encoders", "apply_emcid_to_model",
-                "execute_emcid_text_encoder", "execute_emcid_sd_xl_text_encoders", "get_cov_text_encoder"):
+                "execute_emcid_text_encoder", "execute_emcid_sd_xl_text_encoders", "get_cov_text_encoder",
+                "apply_emcid_to_cross_attn", "execute_emcid_cross_attn", "get_cov_cross_attn"):
         from . import emcid_main
         return getattr(emcid_main, name)
     raise AttributeError(name)

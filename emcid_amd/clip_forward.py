@@ -61,6 +61,7 @@ class ClipTextGraph:
     token_embedding: torch.nn.Embedding
     position_embedding: torch.nn.Embedding
     layers: List[ClipLayer]
+    final_layer_norm: Optional[torch.nn.LayerNorm] = None
 
 
 def discover(text_encoder, layer_module_tmp: str) -> ClipTextGraph:
@@ -90,7 +91,7 @@ def discover(text_encoder, layer_module_tmp: str) -> ClipTextGraph:
         for l in layers:
             if (l.q.bias is None) == (l.k.bias is None) == (l.v.bias is None) and l.q.weight.is_cuda:
                 l.fuse_qkv()
-        return ClipTextGraph(tok_e, pos_e, layers)
+        return ClipTextGraph(tok_e, pos_e, layers, getattr(root, "final_layer_norm", None))
     except (AttributeError, LookupError, TypeError) as e:
         raise UnsupportedEncoder(str(e))
 
@@ -285,3 +286,12 @@ def _run_layers(graph, trie, upto, on_fc2, last_rows_only):
                 return None
         hs = mid + out
     return hs
+
+
+def last_hidden_at_lookup(graph: ClipTextGraph, trie: TokenTrie) -> torch.Tensor:
+    """``text_encoder(**inputs)[0]`` (final LayerNorm applied) at every prompt's lookup token, (B, h), through the trie:
+    the whole encoder on the distinct prefixes, the last layer and the final norm on the lookup nodes only."""
+    if graph.final_layer_norm is None:
+        raise UnsupportedEncoder("no final_layer_norm")
+    hs = run_layers(graph, trie, len(graph.layers) - 1, None, last_rows_only=True)      # (R, h) query rows
+    return graph.final_layer_norm(hs).index_select(0, trie.lookup_in_query)

@@ -5,6 +5,8 @@ Mirrors the reference's entry points with the same names, argument meaning, side
     apply_emcid_to_text_encoder         :769-815      execute_emcid_text_encoder         :818-1082
     apply_emcid_to_sdxl_text_encoders   :38-106       execute_emcid_sd_xl_text_encoders  :1085-1425
     get_cov_text_encoder                :2239-2276    upd_matrix_match_shape             :2279-2298
+    apply_emcid_to_cross_attn           :511-548      execute_emcid_cross_attn           :314-508
+    get_cov_cross_attn                  :2203-2236
 plus ``apply_emcid_to_model`` (the name BASELINE.json uses; dispatches on the hparams type).
 
 What runs where: tokenizing, subject search, v*/C cache reads are host Python (once per call); everything
@@ -28,7 +30,8 @@ from .edit_engine import (ConceptShard, EncoderEditPlan, LayerEdit, check_info, 
                           run_encoder_edit)
 from .emcid_hparams import EMCIDHyperParams, EMCIDXLHyperParams
 from .globals import STATS_DIR, XL_STATS_DIR1, XL_STATS_DIR2
-from .layer_stats import layer_stats_text_encoder
+from .compute_ks import get_layers_input_output_at_words_cross_attn
+from .layer_stats import get_all_cross_attn_kv_layer_names, layer_stats_cross_attn_kv, layer_stats_text_encoder
 
 COV_CACHE: Dict[tuple, torch.Tensor] = {}          # key -> (d, d) fp32 on cpu, like the reference's (:36)
 _COV_DEVICE_CACHE: Dict[tuple, torch.Tensor] = {}  # (key, device) -> the same matrix resident in HBM
@@ -220,6 +223,158 @@ def apply_emcid_to_text_encoder(pipe, requests: List[Dict], hparams: EMCIDHyperP
     if verbose:
         print(f"New weights successfully inserted into {[e.weight_name for e in edits]}")
     return pipe, origin_text_encoder
+
+
+# ---- cross-attention K/V of the UNet (reference: :314-548) -------------------------------------------------------
+
+def get_cov_cross_attn(pipe, layer_name: str, mom2_dataset: str, sample_size: int, mom2_dtype: str, inv: bool = False,
+                       force_recompute: bool = False, verbose: bool = False, stats_dir=STATS_DIR) -> torch.Tensor:
+    """Second moment of a cross-attention projection's input (the text embedding), fp32 on the UNet's device
+    (reference: :2203-2236; its cache key ignores the statistics directory, this one includes it)."""
+    model_name = pipe.unet.config._name_or_path.replace("/", "_")
+    key = (model_name, layer_name, str(Path(stats_dir).resolve()), sample_size, mom2_dtype)
+    device = next(pipe.unet.parameters()).device
+    if verbose:
+        print(f"Retrieving covariance statistics for {model_name} @ {layer_name}.")
+    if key not in COV_CACHE or force_recompute:
+        stat = layer_stats_cross_attn_kv(pipe, layer_name, stats_dir, mom2_dataset, to_collect=["mom2"],
+                                         sample_size=sample_size, precision=mom2_dtype, force_recompute=force_recompute)
+        COV_CACHE[key] = stat.mom2.moment().float().to("cpu")
+        _COV_DEVICE_CACHE.pop((key, str(device)), None)
+    dkey = (key, str(device))
+    if dkey not in _COV_DEVICE_CACHE:
+        _COV_DEVICE_CACHE[dkey] = COV_CACHE[key].to(device)
+    c = _COV_DEVICE_CACHE[dkey]
+    return torch.inverse(c) if inv else c
+
+
+def load_v_stars_cross_attn(requests: Sequence[Dict], cache_name: Optional[str], layer_names: Sequence[str],
+                            stage1: Optional[Callable[[Dict], Dict[str, torch.Tensor]]] = None) -> Dict[str, torch.Tensor]:
+    """{layer_name: (N, out) fp32 on the host}.  Cache: one npz per request, ``source_{source}.npz``, whose entries are
+    pickled ``{"v_star": array}`` per layer name (reference: :373-391 read, :411-420 write)."""
+    rows = {n: [] for n in layer_names}
+    for idx, request in enumerate(requests):
+        f = Path(cache_name + f"source_{request['source']}.npz") if cache_name is not None else None
+        got = None
+        if f is not None and f.exists():
+            try:
+                data = np.load(f, allow_pickle=True)
+                got = {n: np.asarray(data[n].item()["v_star"], dtype=np.float32) for n in layer_names}
+            except Exception as e:   # unreadable cache -> recompute, as the reference (:392-393)
+                print(f"Error reading cache file due to {e}. Recomputing...")
+        if got is None:
+            if stage1 is None:
+                raise NotImplementedError(
+                    f"no cached cross-attention v* for request {idx} ([{request['source']}]) at {f}: Stage 1 "
+                    f"(compute_z_unet_x_kv, needs the SD UNet and its noise-prediction loss) is out of scope of this "
+                    f"build — pass cache_name pointing at the reference's npz files or a stage1= callable")
+            got = {n: v.detach().float().cpu().numpy() for n, v in stage1(request).items()}
+            if f is not None:
+                f.parent.mkdir(exist_ok=True, parents=True)
+                np.savez(f, **{n: {"v_star": got[n]} for n in layer_names})
+        for n in layer_names:
+            rows[n].append(got[n])
+    return {n: torch.from_numpy(np.stack(v, axis=0)) for n, v in rows.items()}
+
+
+def _edit_cross_attn(pipe, requests, hparams, cache_name, stats_dir, keep_factors, restore, verbose, stage1):
+    """Closed form for every cross-attention K/V projection.  Same keys for all of them (the text embedding at the last
+    subject token), own targets, own statistics, residual NOT split over layers (:473).  Each projection is one
+    ``emcid_edit_layer_f64`` call: d = text hidden size (768), N concepts, h = the block's channel count.
+
+    One reference behaviour is NOT reproduced: ``apply_emcid_to_cross_attn`` forms ``adj_k @ resid^T`` (hidden x out) and
+    relies on ``upd_matrix_match_shape`` to transpose it (:540-543); for a SQUARE projection the shape test passes
+    untransposed and the reference adds U^T.  No Stable Diffusion UNet has channels == text hidden size (768 vs
+    320/640/1280; 2048 vs 640/1280 for SDXL); here such a projection gets the intended U."""
+    names = get_all_cross_attn_kv_layer_names(pipe)
+    weights = {n: nethook.get_parameter(pipe.unet, f"{n}.weight") for n in names}
+    device = next(pipe.unet.parameters()).device
+    for n, w in weights.items():
+        if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
+            raise hip.EmcidHipError(f"{n}.weight must be a contiguous fp32 tensor in HBM (got {w.dtype} on {w.device})")
+    zs = load_v_stars_cross_attn(requests, cache_name, names, stage1)
+    covs = {n: get_cov_cross_attn(pipe, n, hparams.mom2_dataset, hparams.mom2_n_samples, hparams.mom2_dtype,
+                                  verbose=verbose, stats_dir=stats_dir) for n in names}
+    ks, cur = get_layers_input_output_at_words_cross_attn(pipe, requests, names,
+                                                          layer_module_tmp=getattr(hparams, "layer_module_tmp", None))
+    out, infos = {}, []
+    # The keys are the same for every projection, and so is the system matrix lam*C' + K K^T whenever two projections
+    # share their statistics (they all see the same text embeddings: the reference's files differ in name only).  Such
+    # projections share ONE assembly + factorization + solve (adj_k); each then costs its residual and one dW GEMM.
+    groups: List[Tuple[torch.Tensor, List[str]]] = []
+    for n in names:
+        for rep, members in groups:
+            if rep is covs[n] or (rep.shape == covs[n].shape and torch.equal(rep, covs[n])):
+                members.append(n)
+                break
+        else:
+            groups.append((covs[n], [n]))
+    s_ = (hparams.edit_weight / 0.5) ** 0.5
+    for cov, members in groups:
+        lead = members[0]
+        w = weights[lead]
+        K = ks[lead].contiguous()
+        w0 = w.detach().clone()
+        if verbose:
+            print(f"Writing {K.shape[0]} key/value pair(s) into layer {lead}")
+        res = hip.edit_layer(K, cur[lead].contiguous(), zs[lead].to(device).contiguous(), cov, hparams.mom2_update_weight,
+                             hparams.edit_weight, 1, W0=w0, W=w.data, want_factors=True, want_dw=False)
+        infos.append(res["ws"].info)
+        Xt = res["Xt"]                                             # (N, hidden) f64 = adj_k^T, shared by the group
+        adj_k_host = Xt.t().contiguous().cpu() if keep_factors else None
+        if keep_factors:
+            out[f"{lead}.weight"] = (adj_k_host, res["Rt"].t().contiguous().cpu())
+        if restore:
+            w.data.copy_(w0)
+        for n in members[1:]:
+            w = weights[n]
+            if verbose:
+                print(f"Writing {K.shape[0]} key/value pair(s) into layer {n}")
+            # resid^T = double(zs - Zc) * sqrt(e_w / 0.5)  (fp32 difference first, as :440 and :466)
+            Rt = ((zs[n].to(device) - cur[n]).double() * s_).contiguous()
+            if keep_factors:
+                out[f"{n}.weight"] = (adj_k_host, Rt.t().contiguous().cpu())
+            if not restore:
+                hip.delta_w_(Rt, Xt, w.detach().clone(), w.data)
+    out = {f"{n}.weight": out[f"{n}.weight"] for n in names if f"{n}.weight" in out}     # reference key order
+    code = int(torch.stack(infos).max().item()) if infos else 0
+    if code != 0:
+        raise FloatingPointError(f"lam*C + K K^T is not positive definite (non-positive pivot at column {code - 1})")
+    return names, out
+
+
+def execute_emcid_cross_attn(pipe, requests: List[Dict], hparams: EMCIDHyperParams, cache_name: Optional[str] = None,
+                             mom2_weight: Optional[int] = None, edit_weight: Optional[float] = None, verbose: bool = True,
+                             stats_dir=STATS_DIR, stage1=None) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
+    """{weight_name: (adj_k (hidden, N) f64 cpu, resid (out, N) f64 cpu)}; the UNet is unchanged on return (:314-508)."""
+    hparams.mom2_update_weight = mom2_weight if mom2_weight is not None else hparams.mom2_update_weight
+    hparams.edit_weight = edit_weight if edit_weight is not None else hparams.edit_weight
+    requests = deepcopy(requests)
+    if verbose:
+        for request in requests:
+            print(f"EMCID request sample: [{request['source']}] -> [{request['dest']}]" if "dest" in request
+                  else f"EMCID request sample: erasing [{request['source']}]")
+    names, deltas = _edit_cross_attn(pipe, requests, hparams, cache_name, stats_dir, True, True, verbose, stage1)
+    if verbose:
+        print(f"Deltas successfully computed for {[f'{n}.weight' for n in names]}")
+    return deltas
+
+
+def apply_emcid_to_cross_attn(pipe, requests: List[Dict], hparams: EMCIDHyperParams, device: str,
+                              mom2_weight: Optional[int] = None, edit_weight: Optional[float] = None,
+                              return_orig_text_model=False, cache_name: Optional[str] = None, stats_dir=STATS_DIR,
+                              verbose: bool = True, stage1=None):
+    """Returns (pipe with the edited UNet projections, the original UNet or None) (:511-548)."""
+    orig_unet = deepcopy(pipe.unet) if return_orig_text_model else None
+    hparams.mom2_update_weight = mom2_weight if mom2_weight is not None else hparams.mom2_update_weight
+    hparams.edit_weight = edit_weight if edit_weight is not None else hparams.edit_weight
+    requests = deepcopy(requests)
+    # each projection is left at W0 + float(U): what the reference reaches by restoring W0 and adding
+    # float(adj_k @ resid^T) (:538-545)
+    names, _ = _edit_cross_attn(pipe, requests, hparams, cache_name, stats_dir, False, False, verbose, stage1)
+    if verbose:
+        print(f"New weights successfully inserted into {[f'{n}.weight' for n in names]}")
+    return pipe, orig_unet
 
 
 # ---- SDXL ----------------------------------------------------------------------------------------------

@@ -33,3 +33,9 @@ RESULTS_DIR, DATA_DIR, STATS_DIR, HPARAMS_DIR, KV_DIR, CACHE_DIR, XL_STATS_DIR1,
 REMOTE_ROOT_URL = _d["REMOTE_ROOT_URL"]
 RESOLUTION = _d["RESOLUTION"]
 EDITING_PROMPTS_CNT = _d["EDITING_PROMPTS_CNT"]
+
+# module-name templates of the UNet projections the cross-attention edit rewrites (reference: util/globals.py:37-38)
+UNET_EDIT_TEMPLATES = {
+    "cross-k": "{}.{}.attentions.{}.transformer_blocks.0.attn2.to_k",
+    "cross-v": "{}.{}.attentions.{}.transformer_blocks.0.attn2.to_v",
+}

@@ -277,6 +277,22 @@ def cholesky_solve_(L, inv, Bt):
     return Bt
 
 
+def delta_w_(Rt, Xt, W0, W):
+    """W = W0 + float(Rt^T Xt): the dW contraction of emcid_main.py:1050,:1061 alone, for factors that are already
+    there (Rt (N, h) f64 residual rows, Xt (N, d) f64 rows of adj_k^T; both contiguous)."""
+    N, h = Rt.shape
+    d = Xt.shape[1]
+    assert Xt.shape[0] == N and W.shape == (h, d) and W0.shape == (h, d)
+    for t, nm in ((Rt, "Rt"), (Xt, "Xt"), (W0, "W0"), (W, "W")):
+        assert t.is_contiguous(), nm
+    if h % 2 or d % 2:
+        raise EmcidHipError("delta_w_: h and d must be even (16-byte aligned f64 rows)")
+    _check(load().emcid_delta_w_f64(_ptr(Rt, torch.float64, "Rt"), h, _ptr(Xt, torch.float64, "Xt"), d, N, h, d,
+                                    _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"), d, None, None, _stream(W)),
+           "emcid_delta_w_f64")
+    return W
+
+
 def profile_enable(classes=()):
     """Start (or, with no classes, stop) HIP-event timing of the named kernel classes (PROF_CLASSES)."""
     mask = 0

@@ -20,7 +20,7 @@ import torch
 from tqdm.auto import tqdm
 
 from .clip_attention import hip_attention
-from .globals import STATS_DIR
+from .globals import STATS_DIR, UNET_EDIT_TEMPLATES
 from .nethook import StopForward, get_module, set_requires_grad
 from .runningstats import (CombinedStat, SecondMoment, load_cached_state, make_loader, make_sampler,
                            save_cached_state, tally)
@@ -55,7 +55,8 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
                                    ds_name="ccs_filtered", to_collect=("mom2",), model_name="text_encoder",
                                    sample_size=None, precision="float32", batch_tokens=3 * 1024, progress=tqdm,
                                    force_recompute=False, data_path=CCS_PATH, shard=None, group=None,
-                                   num_workers=2, batch_size=100, device_batch_tokens=32768) -> Dict[str, CombinedStat]:
+                                   num_workers=2, batch_size=100, device_batch_tokens=32768, feature: str = "input",
+                                   files: Optional[Dict[str, Path]] = None) -> Dict[str, CombinedStat]:
     """All ``layer_names`` in ONE pass over the captions.  Returns {layer_name: CombinedStat} (on cpu).
 
     ``batch_tokens`` names the cache file like the reference (``_t3072_``) but the device batches are larger:
@@ -66,8 +67,10 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
     to_collect = list(to_collect)
     device = next(model.parameters()).device
     args = {} if sample_size is None else {"sample_size": sample_size}
-    files = {ln: stats_filename(stats_dir, model_name, ds_name, ln, precision, to_collect, batch_tokens, sample_size)
-             for ln in layer_names}
+    # ``feature``: "input" (the reference's retain_input, layer_stats.py:209) or "output" of the hooked module;
+    # ``files``: cache path per layer when it is not derived from the layer name (cross-attention statistics)
+    files = files or {ln: stats_filename(stats_dir, model_name, ds_name, ln, precision, to_collect, batch_tokens,
+                                         sample_size) for ln in layer_names}
     stats: Dict[str, CombinedStat] = {}
     todo: List[str] = []
     for ln in layer_names:
@@ -104,7 +107,7 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
     handles = []
     for ln in todo:
         def hook(mod, inputs, output, ln=ln):
-            grabbed[ln] = inputs[0]
+            grabbed[ln] = inputs[0] if feature == "input" else output
             if ln == deepest:
                 raise StopForward()
         handles.append(mods[ln].register_forward_hook(hook))
@@ -147,6 +150,91 @@ def layer_stats_text_encoder(model, tokenizer, layer_name, stats_dir="data/stats
     return layer_stats_text_encoder_multi(
         model, tokenizer, [layer_name], stats_dir, ds_name, to_collect, model_name, sample_size, precision,
         batch_tokens, progress, force_recompute, data_path, shard, group, num_workers)[layer_name]
+
+
+# ---- cross-attention K/V statistics (reference: layer_stats.py:333-427, :429-468, :470-495, :555-575) ------------
+
+def get_attr_through_name(obj, name):
+    """Recursive getattr for dotted names (reference: layer_stats.py:577-579)."""
+    for part in name.split("."):
+        obj = getattr(obj, part)
+    return obj
+
+
+def get_to_edit_layername_unet(template_key, block_type, block_idx, sub_idx) -> str:
+    """Module name of a UNet projection (reference: layer_stats.py:555-575, the attention templates)."""
+    name = UNET_EDIT_TEMPLATES[template_key].format(block_type, block_idx, sub_idx)
+    if "mid_block" in block_type:
+        name = name.replace(f"mid_block.{block_idx}.", "mid_block.")
+    return name
+
+
+def get_all_cross_attn_kv_layer_names(pipe) -> List[str]:
+    """Every ``attn2.to_k`` / ``to_v`` the UNet has, in the reference's order (layer_stats.py:470-495): down, up, mid;
+    inside a block all to_k then all to_v."""
+    names = []
+    for block_type, count in (("down_blocks", 4), ("up_blocks", 4), ("mid_block", 1)):
+        for idx in range(count):
+            for key in ("cross-k", "cross-v"):
+                for sub_idx in (0, 1, 2):
+                    name = get_to_edit_layername_unet(key, block_type, idx, sub_idx)
+                    try:
+                        get_attr_through_name(pipe.unet, name)
+                    except AttributeError:
+                        continue
+                    names.append(name)
+    return names
+
+
+def _final_norm_name(text_encoder) -> str:
+    for name, mod in text_encoder.named_modules():
+        if name.endswith("final_layer_norm"):
+            return name
+    raise LookupError("text encoder has no final_layer_norm")
+
+
+def layer_stats_cross_attn_kv(pipe, layer_name, stats_dir="data/stats", ds_name="ccs_filtered", to_collect=["mom2"],
+                              model_name="unet", sample_size=None, precision=None, batch_tokens=3 * 1024, download=False,
+                              progress=tqdm, force_recompute=False, data_path=CCS_PATH, also: Sequence[str] = ()):
+    """Load or compute the cached second moment of ``layer_name``'s input (reference: layer_stats.py:333-427).
+
+    The input of every cross-attention K/V projection is the text encoder's last hidden state — the reference runs the
+    UNet on dummy latents per caption batch only to hook it (:411-423).  Here the statistic is one pass of the text
+    encoder (tap: output of its final LayerNorm, attended tokens) and is written under ``layer_name`` and every name in
+    ``also`` (the reference computes all of them "in one go" too, :441-443), in the reference's path and npz format."""
+    if download:
+        raise NotImplementedError("Downloading stats from remote is not implemented yet.")   # as the reference (:368)
+    precision = _check_precision(precision)
+    to_collect = list(to_collect)
+    args = {} if sample_size is None else {"sample_size": sample_size}
+    names = [layer_name] + [n for n in also if n != layer_name]
+    files = {n: stats_filename(stats_dir, model_name, ds_name, n, precision, to_collect, batch_tokens, sample_size)
+             for n in names}
+    if not force_recompute:
+        cached = load_cached_state(files[layer_name], args, quiet=True)
+        if cached is not None:
+            st = CombinedStat(**{k: STAT_TYPES[k]() for k in to_collect})
+            st.load_state_dict(cached)
+            return st
+    tap = _final_norm_name(pipe.text_encoder)
+    scratch = files[layer_name].with_suffix(".tmp.npz")
+    st = layer_stats_text_encoder_multi(pipe.text_encoder, pipe.tokenizer, [tap], stats_dir, ds_name, to_collect,
+                                        model_name, sample_size, precision, batch_tokens, progress, True, data_path,
+                                        feature="output", files={tap: scratch})[tap]
+    scratch.unlink(missing_ok=True)
+    for n in names:
+        save_cached_state(files[n], st, args)
+    return st
+
+
+def compute_cross_attn_kv_stats(pipe, dataset="ccs_filtered", to_collect=["mom2"], sample_size=100000,
+                                batch_tokens=3 * 1024, precision="float32", stats_dir=STATS_DIR, force_recompute=False,
+                                data_path=CCS_PATH):
+    """Statistics files of ALL cross-attention K/V projections from one text-encoder pass (reference: :429-468)."""
+    names = get_all_cross_attn_kv_layer_names(pipe)
+    return layer_stats_cross_attn_kv(pipe, names[0], stats_dir, dataset, to_collect, sample_size=sample_size,
+                                     precision=precision, batch_tokens=batch_tokens, force_recompute=force_recompute,
+                                     data_path=data_path, also=names[1:])
 
 
 def main(argv=None):

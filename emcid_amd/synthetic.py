@@ -164,7 +164,7 @@ def build_pipe(kind: str = "toy", device: str = "cpu", sdxl: bool = False, seed:
 # ---- cross-attention K/V stand-in for the UNet -------------------------------------------------------------------
 # Channel widths of the 16 cross-attention blocks: SD-v1.4 [external: its UNet config], and a toy set.  The tree of
 # module NAMES is what the reference addresses (util/globals.py:37-38 through emcid/layer_stats.py:470-495).
-UNET_BLOCK_CHANNELS = {"sd-v1.4": (320, 640, 1280, 1280), "toy": (16, 32, 48, 48)}
+UNET_BLOCK_CHANNELS = {"sd-v1.4": (320, 640, 1280, 1280), "toy": (16, 24, 48, 48)}   # none equal to a text hidden size: see emcid_main._edit_cross_attn
 
 
 class _CrossAttention(torch.nn.Module):

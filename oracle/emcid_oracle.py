@@ -426,6 +426,41 @@ def layers_input_output_at_words_cross_attn(pipe, requests, module_names) -> Tup
     return {n: torch.stack(v, 0) for n, v in ins.items()}, {n: torch.stack(v, 0) for n, v in outs.items()}
 
 
+def layer_stats_cross_attn_kv(pipe, layer_name: str, captions: List[str], sample_size: Optional[int],
+                              batch_tokens: int = 3 * 1024, precision: str = "float32",
+                              batch_size: int = 4) -> SecondMomentOracle:
+    """layer_stats.py:333-427: fixed random caption subset -> groups of FOUR (:350) -> length-sorted sub-batches ->
+    text encoder -> UNet on dummy latents stopped at `layer_name` -> attended tokens of its INPUT -> mom2 += a^T a."""
+    dtype = getattr(torch, precision)
+    stat = SecondMomentOracle()
+    order = fixed_random_subset(len(captions), sample_size)
+    cap = {}
+
+    def hook(mod, args, out):
+        cap["in"] = args[0]
+        raise _Stop()
+
+    h = dict(pipe.unet.named_modules())[layer_name].register_forward_hook(hook)
+    latents = torch.zeros(batch_size, pipe.unet.config.in_channels, pipe.unet.config.sample_size, pipe.unet.config.sample_size)
+    timesteps = torch.zeros(batch_size, dtype=torch.long)
+    try:
+        with torch.no_grad():
+            for g in range(0, len(order), batch_size):
+                toks = [pipe.tokenizer.encode(captions[i], truncation=True, max_length=None) for i in order[g:g + batch_size]]
+                for rows in length_sorted_subbatches(toks, batch_tokens):
+                    batch = pad_batch(rows)
+                    rep = pipe.text_encoder(**batch).last_hidden_state
+                    try:
+                        pipe.unet(latents, timesteps, encoder_hidden_states=rep)
+                    except _Stop:
+                        pass
+                    feats = cap["in"].reshape(-1, cap["in"].shape[-1])[batch["attention_mask"].reshape(-1).nonzero()[:, 0]]
+                    stat.add(feats.to(dtype))
+    finally:
+        h.remove()
+    return stat
+
+
 def load_cov_cross_attn(stats_dir, layer_name, n_samples, precision="float32") -> torch.Tensor:
     """emcid_main.py:2217-2232 with the statistics already cached on disk (layer_stats.py:361: model_name "unet")."""
     with np.load(stats_path(stats_dir, layer_name, n_samples, precision, model_name="unet")) as z:

@@ -292,10 +292,18 @@ def golden_xattn(em, EMCIDHyperParams, scratch, tag="toy_xattn"):
         out[f"w_final/{li}"] = em.nethook.get_parameter(pipe2.unet, n + ".weight").numpy()
         assert torch.equal(em.nethook.get_parameter(orig_unet, n + ".weight"), w0[n])
     out.update(state_np(pipe.text_encoder, "te/"))
+    # Stage 0 of this path: the reference's layer_stats_cross_attn_kv on the captions golden_stage0 wrote
+    from tqdm import tqdm
+    import emcid.layer_stats as ls
+    stat = ls.layer_stats_cross_attn_kv(pipe, names[3], str(scratch / "xstats0"), "ccs_filtered", ["mom2"],
+                                        sample_size=300, precision="float32", batch_tokens=600, progress=tqdm)
+    out["stage0/mom2"] = stat.mom2.mom2.numpy()
+    out["stage0/count"] = np.array(stat.mom2.count)
     np.savez_compressed(OUT / f"{tag}.npz", **out)
     with open(OUT / f"{tag}.json", "w") as f:
         json.dump({"kind": "toy", "requests": reqs, "hparams": hp_d, "lam": lam, "ew": ew, "layer_names": names,
-                   "unet_seed": 11}, f, indent=1)
+                   "unet_seed": 11, "stage0": {"layer": names[3], "sample_size": 300, "batch_tokens": 600,
+                                               "captions_from": "toy_stage0.json"}}, f, indent=1)
     print(f"[golden] {tag}: wrote {len(out)} arrays, {len(names)} projections")
 
 

@@ -343,3 +343,109 @@ def test_eleven_layer_edit_vs_oracle(tmp_path):
         got = get_parameter(gpu.text_encoder, n + ".weight").cpu().double() - w0[n].double()
         err = (got - ref).abs().max().item()
         assert err < 1e-4 and err <= 1e-4 * ref.abs().max().item(), (n, err, ref.abs().max().item())
+
+
+# ---- cross-attention K/V of the UNet (reference emcid_main.py:314-548) ---------------------------------------------
+
+def test_toy_cross_attn_matches_reference_golden(tmp_path):
+    """execute_emcid_cross_attn / apply_emcid_to_cross_attn on the HIP path vs the REFERENCE's own outputs: keys and
+    current values of all 32 projections, adj_k, resid, final weights; the UNet is restored by execute_*."""
+    from conftest import xattn_from_golden
+    from emcid_amd.compute_ks import get_layers_input_output_at_words_cross_attn
+    z, meta = load_golden("toy_xattn")
+    pipe, cache, stats = xattn_from_golden(z, meta, tmp_path, DEV)
+    names = meta["layer_names"]
+    hp_d = dict(meta["hparams"], layer_module_tmp="encoder.layers.{}")
+    ks, cur = get_layers_input_output_at_words_cross_attn(pipe, meta["requests"], names,
+                                                          layer_module_tmp=hp_d["layer_module_tmp"])
+    for li, n in enumerate(names):
+        np.testing.assert_allclose(ks[n].cpu().numpy(), z[f"K/{li}"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(cur[n].cpu().numpy(), z[f"Zc/{li}"], rtol=2e-5, atol=5e-6)
+    hp = EMCIDHyperParams(**hp_d)
+    deltas = em.execute_emcid_cross_attn(pipe, meta["requests"], hp, cache_name=cache, mom2_weight=meta["lam"],
+                                         edit_weight=meta["ew"], verbose=False, stats_dir=stats)
+    assert hp.mom2_update_weight == meta["lam"] and hp.edit_weight == meta["ew"]     # mutated in place, like the reference
+    assert list(deltas) == [n + ".weight" for n in names]
+    for li, n in enumerate(names):
+        adj_k, resid = deltas[n + ".weight"]
+        assert adj_k.dtype == torch.float64 and adj_k.device.type == "cpu" and tuple(adj_k.shape) == z[f"adj_k/{li}"].shape
+        ref = z[f"adj_k/{li}"]
+        assert np.abs(adj_k.numpy() - ref).max() <= 2e-5 * np.abs(ref).max()       # fp32 keys in another summation order
+        np.testing.assert_allclose(resid.numpy(), z[f"resid/{li}"], rtol=0, atol=2e-5)
+        np.testing.assert_array_equal(get_parameter(pipe.unet, n + ".weight").cpu().numpy(), z[f"w_orig/{li}"])
+    hp2 = EMCIDHyperParams(**hp_d)
+    pipe2, orig_unet = em.apply_emcid_to_cross_attn(pipe, meta["requests"], hp2, DEV, mom2_weight=meta["lam"],
+                                                    edit_weight=meta["ew"], return_orig_text_model=True, cache_name=cache,
+                                                    stats_dir=stats, verbose=False)
+    assert pipe2 is pipe
+    for li, n in enumerate(names):
+        w = get_parameter(pipe.unet, n + ".weight").cpu().numpy()
+        dw_ref = z[f"w_final/{li}"].astype(np.float64) - z[f"w_orig/{li}"]
+        err = np.abs(w.astype(np.float64) - z[f"w_final/{li}"]).max()
+        assert err <= 1e-4 * max(np.abs(dw_ref).max(), 1e-3), (n, err)
+        np.testing.assert_array_equal(get_parameter(orig_unet, n + ".weight").cpu().numpy(), z[f"w_orig/{li}"])
+
+
+@pytest.mark.parametrize("shared_stats", [False, True])
+def test_cross_attn_real_dims_vs_oracle(tmp_path, shared_stats):
+    """SD-v1.4 shapes (text hidden 768; 320/640/1280-channel projections), N = 40 concepts, against the oracle — with
+    per-projection statistics, and with the same statistics under every name (what the reference's Stage 0 writes:
+    then all 32 projections share one factorization)."""
+    kind = "sd-v1.4"
+    pipe = syn.add_unet(syn.build_pipe(kind, DEV, syllables=True), kind)
+    cpu = syn.add_unet(syn.build_pipe(kind, "cpu", syllables=True), kind)
+    reqs = syn.make_requests(40, names="syllable")
+    names = orc.get_all_cross_attn_kv_layer_names(cpu.unet)
+    dims = {n: dict(cpu.unet.named_modules())[n].out_features for n in names}
+    cache = str(tmp_path / "cache") + "/"
+    syn.write_xattn_vstar_cache(cache, reqs, dims, seed=6, scale=0.5)
+    syn.write_stats_cache(tmp_path / "stats", names, 768, 100, seed=2, t=1536, model_name="unet")
+    if shared_stats:
+        import shutil
+        first = syn.stats_file(tmp_path / "stats", names[0], 100, model_name="unet")
+        for n in names[1:]:
+            shutil.copy(first, syn.stats_file(tmp_path / "stats", n, 100, model_name="unet"))
+    hp_d = syn.sd_hparams_dict(mom2_update_weight=4000, mom2_n_samples=100)
+    em.apply_emcid_to_cross_attn(pipe, reqs, EMCIDHyperParams(**hp_d), DEV, cache_name=cache,
+                                 stats_dir=str(tmp_path / "stats"), verbose=False)
+    w0 = {n: dict(cpu.unet.named_parameters())[n + ".weight"].clone() for n in names}
+    if shared_stats:      # execute_* returns the shared adj_k for every projection and leaves the UNet untouched
+        probe = syn.add_unet(syn.build_pipe(kind, DEV, syllables=True), kind)
+        deltas = em.execute_emcid_cross_attn(probe, reqs, EMCIDHyperParams(**hp_d), cache_name=cache, verbose=False,
+                                             stats_dir=str(tmp_path / "stats"))
+        assert list(deltas) == [n + ".weight" for n in names]
+        for n in names:
+            assert torch.equal(get_parameter(probe.unet, n + ".weight").cpu(), w0[n])
+    orc.apply_emcid_to_cross_attn(cpu, reqs, dict(hp_d), cache, tmp_path / "stats")
+    for n in names:
+        ref = dict(cpu.unet.named_parameters())[n + ".weight"]
+        got = get_parameter(pipe.unet, n + ".weight").cpu()
+        scale = (ref - w0[n]).abs().max().item()
+        assert (got - ref).abs().max().item() <= 1e-4 * max(scale, 1e-3), n
+
+
+def test_cross_attn_stage0_vs_reference_golden(tmp_path):
+    """Statistics of the projections' input: one text-encoder pass on the GPU (Gram kernel) vs the reference's
+    layer_stats_cross_attn_kv; written under every projection's name in the reference's npz format."""
+    import json
+    from emcid_amd import layer_stats as ls
+    z, meta = load_golden("toy_xattn")
+    z0, meta0 = load_golden("toy_stage0")
+    te = pipe_from_golden(z, meta["kind"], prefix="te/").to(DEV)
+    pipe = syn.add_unet(syn.SyntheticPipe(text_encoder=te, tokenizer=syn.build_tokenizer()), meta["kind"], seed=meta["unet_seed"])
+    data = tmp_path / "data" / "ccs_filtered.json"
+    data.parent.mkdir()
+    json.dump(meta0["captions"], open(data, "w"))
+    st0 = meta["stage0"]
+    names = meta["layer_names"]
+    stat = ls.layer_stats_cross_attn_kv(pipe, st0["layer"], tmp_path / "stats", sample_size=st0["sample_size"],
+                                        precision="float32", batch_tokens=st0["batch_tokens"], progress=None,
+                                        data_path=str(data), also=names)
+    assert stat.mom2.count == int(z["stage0/count"])
+    ref = z["stage0/mom2"].astype(np.float64)
+    assert np.abs(stat.mom2.mom2.numpy().astype(np.float64) - ref).max() <= 2e-5 * np.abs(ref).max()
+    for n in (names[0], names[-1]):          # served from the cache now, any projection name
+        again = ls.layer_stats_cross_attn_kv(pipe, n, tmp_path / "stats", sample_size=st0["sample_size"],
+                                             precision="float32", batch_tokens=st0["batch_tokens"], progress=None,
+                                             data_path=str(tmp_path / "absent.json"))
+        np.testing.assert_array_equal(again.mom2.mom2.numpy(), stat.mom2.mom2.numpy())

@@ -223,3 +223,34 @@ def test_export_and_load_edited_weights(tmp_path):
     assert not torch.equal(get_parameter(fresh, names[1]), w)
     assert em.load_edited_weights(fresh, tmp_path / "out" / "edit.safetensors") == names
     assert torch.equal(get_parameter(fresh, names[1]), w)
+
+
+def test_cross_attn_host_side(tmp_path):
+    """Layer enumeration order, v* cache format and error behaviour of the cross-attention path without a GPU."""
+    import numpy as np
+    from conftest import load_golden
+    from emcid_amd import emcid_main as em, layer_stats as ls, synthetic as syn
+    from emcid_amd.emcid_hparams import EMCIDHyperParams
+    from emcid_amd.hip import EmcidHipError
+    z, meta = load_golden("toy_xattn")
+    pipe = syn.add_unet(syn.build_pipe("toy", "cpu"), "toy")
+    names = ls.get_all_cross_attn_kv_layer_names(pipe)
+    assert names == meta["layer_names"] and len(names) == 32
+    assert ls.get_to_edit_layername_unet("cross-v", "mid_block", 0, 0) == "mid_block.attentions.0.transformer_blocks.0.attn2.to_v"
+    reqs = meta["requests"][:3]
+    cache = str(tmp_path / "c") + "/"
+    dims = {n: ls.get_attr_through_name(pipe.unet, n).out_features for n in names}
+    vs = syn.write_xattn_vstar_cache(cache, reqs, dims, seed=3)
+    got = em.load_v_stars_cross_attn(reqs, cache, names)
+    for n in names:
+        np.testing.assert_array_equal(got[n].numpy(), vs[n])
+    with pytest.raises(NotImplementedError):
+        em.load_v_stars_cross_attn(reqs + [{"source": "nobody", "prompts": ["{}"]}], cache, names)
+    # statistics are served from the reference-format cache file without touching the GPU
+    syn.write_stats_cache(tmp_path / "s", names[:1], 32, 1000, seed=2, t=64, model_name="unet")
+    st = ls.layer_stats_cross_attn_kv(pipe, names[0], tmp_path / "s", sample_size=1000, precision="float32")
+    assert st.mom2.moment().shape == (32, 32)
+    # the product never falls back to the CPU
+    hp = EMCIDHyperParams(**syn.sd_hparams_dict(mom2_n_samples=1000))
+    with pytest.raises(EmcidHipError):
+        em.apply_emcid_to_cross_attn(pipe, reqs, hp, "cpu", cache_name=cache, stats_dir=str(tmp_path / "s"), verbose=False)

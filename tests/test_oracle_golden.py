@@ -138,3 +138,17 @@ def test_toy_cross_attn_bit_level(tmp_path):
         np.testing.assert_allclose(adj_k.numpy(), z[f"adj_k/{li}"], rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(resid.numpy(), z[f"resid/{li}"], rtol=1e-13, atol=0)
         np.testing.assert_array_equal(params[n + ".weight"].numpy(), z[f"w_final/{li}"])
+
+
+def test_cross_attn_stage0_vs_reference_golden():
+    """Statistics of the cross-attention projections' input (reference layer_stats.py:333-427) on the toy captions."""
+    z, meta = load_golden("toy_xattn")
+    z0, meta0 = load_golden("toy_stage0")
+    te = pipe_from_golden(z, meta["kind"], prefix="te/")
+    pipe = syn.add_unet(syn.SyntheticPipe(text_encoder=te, tokenizer=syn.build_tokenizer()), meta["kind"],
+                        seed=meta["unet_seed"])
+    st0 = meta["stage0"]
+    stat = orc.layer_stats_cross_attn_kv(pipe, st0["layer"], [c["caption"] for c in meta0["captions"]], st0["sample_size"],
+                                         batch_tokens=st0["batch_tokens"])
+    assert stat.count == int(z["stage0/count"])
+    np.testing.assert_array_equal(stat.mom2.numpy(), z["stage0/mom2"])
