@@ -6,7 +6,7 @@ Mirrors the reference's entry points with the same names, argument meaning, side
     apply_emcid_to_sdxl_text_encoders   :38-106       execute_emcid_sd_xl_text_encoders  :1085-1425
     get_cov_text_encoder                :2239-2276    upd_matrix_match_shape             :2279-2298
     apply_emcid_to_cross_attn           :511-548      execute_emcid_cross_attn           :314-508
-    get_cov_cross_attn                  :2203-2236
+    get_cov_cross_attn                  :2203-2236    cal_insert_deltas                  :1969-2052
 plus ``apply_emcid_to_model`` (the name BASELINE.json uses; dispatches on the hparams type).
 
 What runs where: tokenizing, subject search, v*/C cache reads are host Python (once per call); everything
@@ -223,6 +223,28 @@ def apply_emcid_to_text_encoder(pipe, requests: List[Dict], hparams: EMCIDHyperP
     if verbose:
         print(f"New weights successfully inserted into {[e.weight_name for e in edits]}")
     return pipe, origin_text_encoder
+
+
+def cal_insert_deltas(pipe, weights: Dict[str, torch.Tensor], hparams: EMCIDHyperParams, requests: List[Dict],
+                      zs: torch.Tensor, verbose: bool = True, stat_dir=STATS_DIR, shard=None):
+    """The Stage-2 layer loop for targets the caller already has (reference: :1969-2052, used by the debias driver):
+    ``zs`` is (hidden, N), one column per request.  Returns {weight_name: (adj_k, resid)} and, like the reference, LEAVES
+    the edited weights in the model (its callers restore from their own copies); ``weights`` must be the live
+    ``rewrite_module_tmp`` parameters of ``pipe.text_encoder`` (it is what the reference indexes, :2031-2039)."""
+    for layer in hparams.layers:
+        name = f"{hparams.rewrite_module_tmp.format(layer)}.weight"
+        if weights[name] is not nethook.get_parameter(pipe.text_encoder, name):
+            raise ValueError(f"weights[{name!r}] is not the text encoder's live parameter")
+    zs_t = zs.detach().t().contiguous().float().cpu()
+    covs = {layer: get_cov_text_encoder(pipe.text_encoder, pipe.tokenizer, hparams.rewrite_module_tmp.format(layer),
+                                        hparams.mom2_dataset, hparams.mom2_n_samples, hparams.mom2_dtype,
+                                        stat_dir=stat_dir, verbose=verbose) for layer in hparams.layers}
+    plan = prepare_encoder_edit(pipe.text_encoder, pipe.tokenizer, requests, hparams.layers, hparams.rewrite_module_tmp,
+                                hparams.mom2_update_weight, hparams.edit_weight, zs_t, covs, _shard_from_env(shard),
+                                layer_module_tmp=getattr(hparams, "layer_module_tmp", None))
+    edits = run_encoder_edit(plan, keep_factors=True, restore=False)
+    check_info(plan)
+    return _deltas_to_host(edits)
 
 
 # ---- cross-attention K/V of the UNet (reference: :314-548) -------------------------------------------------------

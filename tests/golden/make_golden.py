@@ -242,6 +242,40 @@ def golden_stage0(ls, scratch, tag="toy_stage0"):
     print(f"[golden] {tag}: wrote {len(out)} arrays")
 
 
+def golden_cal_insert(em, EMCIDHyperParams, scratch, tag="toy_cal_insert"):
+    """Reference cal_insert_deltas (emcid_main.py:1969-2052): the layer loop for caller-supplied targets; it reads the
+    statistics from the module-level STATS_DIR and leaves the model edited."""
+    pipe = syn.build_pipe("toy", "cpu")
+    hidden, inter = syn.ENCODER_DIMS["toy"][:2]
+    reqs = syn.make_requests(5)
+    layers = (2, 3)
+    hp_d = syn.sd_hparams_dict(layers=layers, mom2_update_weight=35, edit_weight=0.7, mom2_n_samples=1000, prefix="")
+    names = [hp_d["rewrite_module_tmp"].format(l) for l in layers]
+    covs = syn.write_stats_cache(scratch / "data" / "stats", names, inter, 1000, seed=13, t=512)
+    em.COV_CACHE.clear()
+    g = torch.Generator().manual_seed(77)
+    zs = torch.randn(hidden, len(reqs), generator=g) * 0.5
+    hp = EMCIDHyperParams(**hp_d)
+    weights = {n + ".weight": em.nethook.get_parameter(pipe.text_encoder, n + ".weight") for n in names}
+    w0 = {k: v.clone() for k, v in weights.items()}
+    deltas = em.cal_insert_deltas(pipe, weights, hp, reqs, zs, verbose=False)
+    out = {"zs": zs.numpy()}
+    for li, n in enumerate(names):
+        adj_k, resid = deltas[n + ".weight"]
+        out[f"cov/{li}"] = covs[n].astype(np.float32)
+        out[f"adj_k/{li}"] = adj_k.numpy()
+        out[f"resid/{li}"] = resid.numpy()
+        out[f"w_orig/{li}"] = w0[n + ".weight"].numpy()
+        out[f"w_after/{li}"] = weights[n + ".weight"].detach().numpy().copy()    # NOT restored by the reference
+    for k, v in w0.items():
+        weights[k][...] = v
+    out.update(state_np(pipe.text_encoder))
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump({"kind": "toy", "requests": reqs, "hparams": hp_d, "layers": list(layers), "layer_names": names}, f, indent=1)
+    print(f"[golden] {tag}: wrote {len(out)} arrays")
+
+
 def golden_xattn(em, EMCIDHyperParams, scratch, tag="toy_xattn"):
     """Reference execute_emcid_cross_attn + apply_emcid_to_cross_attn (emcid_main.py:314-548) on a synthetic pipe whose
     `unet` is the module tree of cross-attention K/V projections (emcid_amd/synthetic.py: SyntheticUNet)."""
@@ -341,6 +375,7 @@ def main():
         golden_sdxl(em, XLHP, scratch)
         golden_stage0(ls, scratch)
         golden_xattn(em, HP, scratch)
+        golden_cal_insert(em, HP, scratch)
         if "--skip-real" not in sys.argv:
             golden_sd(em, HP, scratch, "real_sd_summary", "sd-v1.4", n_req=24, layers=(7, 8, 9, 10), lam=4000,
                       ew=0.5, ragged=False, full=False)

@@ -449,3 +449,27 @@ def test_cross_attn_stage0_vs_reference_golden(tmp_path):
                                              precision="float32", batch_tokens=st0["batch_tokens"], progress=None,
                                              data_path=str(tmp_path / "absent.json"))
         np.testing.assert_array_equal(again.mom2.mom2.numpy(), stat.mom2.mom2.numpy())
+
+
+def test_cal_insert_deltas_matches_reference_golden(tmp_path):
+    """cal_insert_deltas (reference :1969-2052): caller-supplied targets, factors returned, the model LEFT edited."""
+    z, meta = load_golden("toy_cal_insert")
+    te = pipe_from_golden(z, meta["kind"]).to(DEV)
+    pipe = syn.SyntheticPipe(text_encoder=te, tokenizer=syn.build_tokenizer())
+    for li, ln in enumerate(meta["layer_names"]):
+        write_cov_npz(tmp_path / "stats", ln, z[f"cov/{li}"], meta["hparams"]["mom2_n_samples"])
+    hp = EMCIDHyperParams(**meta["hparams"])
+    weights = {n + ".weight": get_parameter(pipe.text_encoder, n + ".weight") for n in meta["layer_names"]}
+    deltas = em.cal_insert_deltas(pipe, weights, hp, meta["requests"], torch.from_numpy(z["zs"]).to(DEV), verbose=False,
+                                  stat_dir=str(tmp_path / "stats"))
+    for li, n in enumerate(meta["layer_names"]):
+        adj_k, resid = deltas[n + ".weight"]
+        ref = z[f"adj_k/{li}"]
+        assert np.abs(adj_k.numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+        np.testing.assert_allclose(resid.numpy(), z[f"resid/{li}"], rtol=0, atol=2e-5)
+        dw = np.abs(z[f"w_after/{li}"].astype(np.float64) - z[f"w_orig/{li}"]).max()
+        err = np.abs(weights[n + ".weight"].detach().cpu().numpy().astype(np.float64) - z[f"w_after/{li}"]).max()
+        assert err <= 1e-4 * dw, (n, err, dw)
+    with pytest.raises(ValueError):
+        em.cal_insert_deltas(pipe, {k: v.clone() for k, v in weights.items()}, hp, meta["requests"],
+                             torch.from_numpy(z["zs"]).to(DEV), verbose=False, stat_dir=str(tmp_path / "stats"))

@@ -152,3 +152,20 @@ def test_cross_attn_stage0_vs_reference_golden():
                                          batch_tokens=st0["batch_tokens"])
     assert stat.count == int(z["stage0/count"])
     np.testing.assert_array_equal(stat.mom2.numpy(), z["stage0/mom2"])
+
+
+def test_cal_insert_deltas_golden():
+    """The layer loop for caller-supplied targets (reference emcid_main.py:1969-2052): factors and the weights it
+    leaves in the model."""
+    z, meta = load_golden("toy_cal_insert")
+    te = pipe_from_golden(z, meta["kind"])
+    hp = meta["hparams"]
+    covs = {l: torch.from_numpy(z[f"cov/{li}"]) for li, l in enumerate(meta["layers"])}
+    deltas = orc.execute_text_encoder(te, syn.build_tokenizer(), meta["requests"], meta["layers"], hp["rewrite_module_tmp"],
+                                      torch.from_numpy(z["zs"]), covs, hp["mom2_update_weight"], hp["edit_weight"],
+                                      restore=False)
+    for li, n in enumerate(meta["layer_names"]):
+        adj_k, resid = deltas[n + ".weight"]
+        np.testing.assert_allclose(adj_k.numpy(), z[f"adj_k/{li}"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(resid.numpy(), z[f"resid/{li}"], rtol=1e-13, atol=0)
+        np.testing.assert_array_equal(orc.get_parameter(te, n + ".weight").numpy(), z[f"w_after/{li}"])
