@@ -220,9 +220,21 @@ def main():
                  "inv_apply": "gemm_f64_kernel<KC,*,*,64,16,2,2,*> launched as GEMM against the explicit inverse factor "
                               "(Kt X^T, V X; triangular K range)",
                  "inv_build": "gemm_f64_kernel<KC,!KC,*,*,16,*> launched as recursive-halving build of X = inv(L)"}
+        # HBM-side bytes per launch of that kernel come from separate `rocprofv3 --pmc` runs (FETCH_SIZE and WRITE_SIZE
+        # cannot share a pass and neither can be collected from inside this process): scripts/pmc_inv_apply.py replays the
+        # class's larger launch (1024 x 3072 x 3072); the summary, with the gfx950 FETCH_SIZE correction, is committed
+        traffic, traffic_note = None, None
+        pmc = Path(__file__).resolve().parent / "profiles" / "r01_pmc_inv_apply.json"
+        if top == "inv_apply" and pmc.exists():
+            with open(pmc) as f:
+                rec = json.load(f)
+            traffic = rec["traffic_bytes_per_launch"]
+            traffic_note = (f"bytes per launch of the {rec['shape']['M']}x{rec['shape']['N']}x{rec['shape']['K']} launch, "
+                            f"rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, profiles/{pmc.name}; algorithmic "
+                            f"{rec['algorithmic_bytes_per_launch']} B")
         roofline = {"bound": "mfma", "kernel": names[top], "class": top, "achieved": achieved,
                     "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F64_MFMA_PEAK_TFLOPS,
-                    "traffic": None, "avg_launch_us": ms * 1e3 / launches, "launches": launches,
+                    "traffic": traffic, "traffic_note": traffic_note, "avg_launch_us": ms * 1e3 / launches, "launches": launches,
                     "flops_per_launch": per_step_flops[top] * args.steps / launches,
                     "solver": "dual" if dual else "direct"}
 
