@@ -93,6 +93,9 @@ def main():
             dist.init_process_group(backend)
     shard = ConceptShard(rank, world, None)
 
+    # the benchmark models a long-running editing service: the projection GEMM solutions are tuned once per shape (in
+    # prepare, untimed, reported as gemm_tuning_ms); a one-off library call only loads an existing results file
+    os.environ.setdefault("EMCID_TUNE_GEMM", "1")
     workdir = Path(tempfile.gettempdir()) / f"emcid_bench_{os.getuid()}"
     if rank == 0:
         workdir.mkdir(exist_ok=True)

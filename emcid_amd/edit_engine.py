@@ -122,8 +122,8 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
                     raise clip_forward.UnsupportedEncoder("rewrite_module_tmp is not the layer's mlp.fc2")
             plan.trie = clip_forward.build_trie(batch.inputs["input_ids"].tolist(), batch.lookup_host, device)
             plan.graph = graph
-            if os.environ.get("EMCID_TUNE_GEMM", "1") != "0":
-                plan.gemm_tuning_s = clip_forward.tune_projections(graph, plan.trie, max(plan.layers))
+            plan.gemm_tuning_s = clip_forward.tune_projections(graph, plan.trie, max(plan.layers),
+                                                               os.environ.get("EMCID_TUNE_GEMM", "auto"))
         except (clip_forward.UnsupportedEncoder, IndexError, LookupError):
             plan.graph = plan.trie = None
     return plan
