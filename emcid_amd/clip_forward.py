@@ -261,31 +261,43 @@ def embed(graph: ClipTextGraph, trie: TokenTrie) -> torch.Tensor:
     return graph.token_embedding(trie.token) + graph.position_embedding(trie.depth.long())
 
 
-def layer_attention_block(layer: ClipLayer, hs: torch.Tensor, trie: TokenTrie, rows: Optional[torch.Tensor]):
-    """hs (U, h) -> residual stream after the attention block, for every node (rows None) or the query rows only."""
-    x = layer.ln1(hs)
+def _fusable(ln) -> bool:
+    return isinstance(ln, torch.nn.LayerNorm) and ln.weight is not None and ln.bias is not None and \
+        ln.weight.is_cuda and ln.normalized_shape[0] % 4 == 0 and ln.normalized_shape[0] <= 8192
+
+
+def layer_attention_block(layer: ClipLayer, hs: torch.Tensor, trie: TokenTrie, rows: Optional[torch.Tensor],
+                          x_ln1: Optional[torch.Tensor] = None):
+    """hs (U, h) -> (residual stream after the attention block, LN2 of it), for every node (rows None) or the query
+    rows only.  ``x_ln1``: LN1(hs) when the previous layer's residual add already produced it."""
+    x = layer.ln1(hs) if x_ln1 is None else x_ln1
     if rows is None and layer.qkv_w is not None:
         hdim = layer.q.out_features
         qkv = F.linear(x, layer.qkv_w, layer.qkv_b)          # (U, 3h): q | k | v as strided row views
         ctx = hip.tree_attention(qkv[:, :hdim], qkv[:, hdim:2 * hdim], qkv[:, 2 * hdim:], trie.anc, trie.depth, layer.heads,
                                  layer.scale, None)
-        return hs + layer.out(ctx)
-    k = layer.k(x)
-    v = layer.v(x)
-    if rows is None:
-        q = layer.q(x)
         res = hs
     else:
-        idx = rows.long()
-        q = layer.q(x.index_select(0, idx))
-        res = hs.index_select(0, idx)
-    ctx = hip.tree_attention(q, k, v, trie.anc, trie.depth, layer.heads, layer.scale, rows)
-    return res + layer.out(ctx)
+        k = layer.k(x)
+        v = layer.v(x)
+        if rows is None:
+            q = layer.q(x)
+            res = hs
+        else:
+            idx = rows.long()
+            q = layer.q(x.index_select(0, idx))
+            res = hs.index_select(0, idx)
+        ctx = hip.tree_attention(q, k, v, trie.anc, trie.depth, layer.heads, layer.scale, rows)
+    o = layer.out(ctx)
+    if _fusable(layer.ln2):
+        return hip.add_layernorm(res, o, layer.ln2)          # residual add + LN2 in one pass
+    mid = res + o
+    return mid, layer.ln2(mid)
 
 
-def mlp_hidden(layer: ClipLayer, hs_mid: torch.Tensor) -> torch.Tensor:
+def mlp_hidden(layer: ClipLayer, ln2_mid: torch.Tensor) -> torch.Tensor:
     """fc2 INPUT (the "key" space): act(fc1(LN2(hs_mid)))."""
-    return layer.act(layer.fc1(layer.ln2(hs_mid)))
+    return layer.act(layer.fc1(ln2_mid))
 
 
 def run_layers(graph: ClipTextGraph, trie: TokenTrie, upto: int, on_fc2=None, last_rows_only: bool = True):
@@ -299,17 +311,22 @@ def run_layers(graph: ClipTextGraph, trie: TokenTrie, upto: int, on_fc2=None, la
 
 def _run_layers(graph, trie, upto, on_fc2, last_rows_only):
     hs = embed(graph, trie)
+    x_ln1 = None
     for i in range(upto + 1):
         layer = graph.layers[i]
         rows = trie.query_rows if (last_rows_only and i == upto) else None
-        mid = layer_attention_block(layer, hs, trie, rows)
-        x = mlp_hidden(layer, mid)
+        mid, ln2_mid = layer_attention_block(layer, hs, trie, rows, x_ln1)
+        x = mlp_hidden(layer, ln2_mid)
         out = layer.fc2(x)
         if on_fc2 is not None:
             out = on_fc2(i, x, out)
             if out is None:
                 return None
-        hs = mid + out
+        nxt = graph.layers[i + 1].ln1 if i < upto else None
+        if nxt is not None and _fusable(nxt):
+            hs, x_ln1 = hip.add_layernorm(mid, out, nxt)     # residual add + the next layer's LN1 in one pass
+        else:
+            hs, x_ln1 = mid + out, None
     return hs
 
 

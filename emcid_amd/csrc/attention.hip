@@ -212,6 +212,78 @@ extern "C" int emcid_tree_attention_f32(const float* q, int64_t ldq, const float
     return EMCID_OK;
 }
 
+// y = a + b ; z = LayerNorm(y) * gamma + beta   (one row per workgroup, the row lives in registers between the passes).
+// The residual add and the LayerNorm that follows it in every transformer block, as one pass over HBM instead of two
+// kernels (add: 2 reads + 1 write; layer norm: 1 read + 1 write).  Two-pass mean / variance like torch's.
+constexpr int LN_MAX_V4 = 8;    // float4 chunks per thread: rows up to 8 * 256 * 4 = 8192 columns
+__global__ __launch_bounds__(256) void add_layernorm_f32_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
+                                                                 int64_t ldb, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps, int cols,
+                                                                 float* __restrict__ y, float* __restrict__ z) {
+    const int64_t row = blockIdx.x;
+    const int nv = cols / 4;
+    const float4* pa = reinterpret_cast<const float4*>(a + row * lda);
+    const float4* pb = reinterpret_cast<const float4*>(b + row * ldb);
+    float4 v[LN_MAX_V4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < nv) {
+            const float4 x = pa[c], w = pb[c];
+            v[i] = make_float4(x.x + w.x, x.y + w.y, x.z + w.z, x.w + w.w);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    __shared__ float red[8];
+    auto block_sum = [&](float t) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    const float mean = block_sum(sum) / (float)cols;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < nv) {
+            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+            sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    }
+    const float rstd = rsqrtf(block_sum(sq) / (float)cols + eps);
+    float4* py = reinterpret_cast<float4*>(y + row * (int64_t)cols);
+    float4* pz = reinterpret_cast<float4*>(z + row * (int64_t)cols);
+    const float4* pg = reinterpret_cast<const float4*>(gamma);
+    const float4* pe = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i) {
+        const int c = threadIdx.x + i * 256;
+        if (c < nv) {
+            const float4 g = pg[c], e = pe[c];
+            py[c] = v[i];
+            pz[c] = make_float4((v[i].x - mean) * rstd * g.x + e.x, (v[i].y - mean) * rstd * g.y + e.y,
+                                (v[i].z - mean) * rstd * g.z + e.z, (v[i].w - mean) * rstd * g.w + e.w);
+        }
+    }
+}
+
+extern "C" int emcid_add_layernorm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gamma,
+                                       const float* beta, float eps, int64_t rows, int64_t cols, float* y, float* z,
+                                       void* stream) {
+    EMCID_CHECK_ARG(a && b && gamma && beta && y && z && rows > 0 && cols > 0 && rows < (1LL << 31));
+    EMCID_CHECK_ARG(cols % 4 == 0 && cols <= LN_MAX_V4 * 256 * 4 && lda % 4 == 0 && ldb % 4 == 0);
+    EMCID_CHECK_ARG(aligned16(a) && aligned16(b) && aligned16(gamma) && aligned16(beta) && aligned16(y) && aligned16(z));
+    ScopedProf sp(KC_MISC, (hipStream_t)stream);
+    hipLaunchKernelGGL(add_layernorm_f32_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, gamma,
+                       beta, eps, (int)cols, y, z);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
 extern "C" int emcid_quick_gelu_f32(const float* x, float* y, int64_t n, void* stream) {
     EMCID_CHECK_ARG(x && y && n > 0 && aligned16(x) && aligned16(y));
     const int64_t n4 = n / 4;

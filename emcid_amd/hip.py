@@ -20,7 +20,7 @@ EXPORTS = [
     "emcid_gather_mean_f32", "emcid_edit_workspace_bytes", "emcid_edit_layer_f64", "emcid_assemble_spd_f64",
     "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_dgemm_ex_f64", "emcid_axpy_f32",
     "emcid_profile_enable", "emcid_profile_collect", "emcid_attention_f32", "emcid_edit_layer_shard_f64",
-    "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32", "emcid_tree_attention_f32", "emcid_debug_leaf_stamps",
+    "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32", "emcid_add_layernorm_f32", "emcid_tree_attention_f32", "emcid_debug_leaf_stamps",
     "emcid_cov_factor_workspace_bytes", "emcid_factor_cov_f64", "emcid_cov_inverse_f64",
     "emcid_edit_dual_workspace_bytes",
     "emcid_edit_dual_stage1_f64", "emcid_edit_dual_pt", "emcid_edit_dual_stage2_f64",
@@ -83,6 +83,7 @@ def load():
         "emcid_dgemm_ex_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, i32, i32, i32, p]),
         "emcid_axpy_f32": (i32, [p, p, i64, p]),
         "emcid_quick_gelu_f32": (i32, [p, p, i64, p]),
+        "emcid_add_layernorm_f32": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p]),
         "emcid_tree_attention_f32": (i32, [p, i64, p, p, i64, p, i64, p, p, i64, i64, i64, f32, p, i64, p]),
         "emcid_profile_enable": (i32, [C.c_uint]),
         "emcid_profile_collect": (i32, [p, p, i32]),
@@ -345,6 +346,21 @@ def quick_gelu(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty_like(x)
     _check(load().emcid_quick_gelu_f32(_ptr(x, torch.float32, "x"), _ptr(y), x.numel(), _stream(x)), "emcid_quick_gelu_f32")
     return y
+
+
+def add_layernorm(a: torch.Tensor, b: torch.Tensor, ln: torch.nn.LayerNorm):
+    """(a + b, LayerNorm(a + b)) in one pass; a, b (rows, cols) fp32 with unit column stride."""
+    rows, cols = a.shape
+    if a.stride(1) != 1 or b.stride(1) != 1 or b.shape != a.shape:
+        raise EmcidHipError("add_layernorm: (rows, cols) operands with unit column stride")
+    if ln.weight is None or ln.bias is None or tuple(ln.normalized_shape) != (cols,):
+        raise EmcidHipError("add_layernorm: LayerNorm over the last dimension with affine parameters")
+    y = torch.empty(rows, cols, dtype=torch.float32, device=a.device)
+    z = torch.empty_like(y)
+    _check(load().emcid_add_layernorm_f32(_ptr(a, torch.float32, "a"), a.stride(0), _ptr(b, torch.float32, "b"), b.stride(0),
+                                          _ptr(ln.weight, torch.float32, "gamma"), _ptr(ln.bias, torch.float32, "beta"),
+                                          float(ln.eps), rows, cols, _ptr(y), _ptr(z), _stream(a)), "emcid_add_layernorm_f32")
+    return y, z
 
 
 def tree_attention(q, k, v, anc, depth, H: int, scale=None, rows=None):

@@ -92,6 +92,12 @@ int emcid_tree_attention_f32(const float* q, int64_t ldq, const float* k, const 
  * instead of the framework's three).  x may alias y. */
 int emcid_quick_gelu_f32(const float* x, float* y, int64_t n, void* stream);
 
+/* y = a + b ; z = LayerNorm(y) * gamma + beta over the last dimension (biased variance, eps inside the root, as
+ * torch.nn.LayerNorm) — the residual add and the LayerNorm after it of every block of the same hooked forward, one
+ * pass.  a/b: [rows, cols] with row strides lda/ldb (elements); y, z: [rows, cols] contiguous; cols % 4 == 0, <= 8192. */
+int emcid_add_layernorm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gamma, const float* beta,
+                            float eps, int64_t rows, int64_t cols, float* y, float* z, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Stage 2 — per-layer closed form (reference: emcid/emcid_main.py:1016-1061).
  *

@@ -302,3 +302,20 @@ def test_dual_solver_vs_oracle(N, d, h, lam, ew, left):
                                 want_dw=False)
             parts.append(ws2.Pt[lo:hi].clone())
         torch.testing.assert_close(torch.cat(parts), out["ws"].Pt[:N], rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("rows,cols", [(5, 32), (300, 768), (6400, 768), (77, 1280), (3, 8192)])
+def test_add_layernorm_vs_torch(rows, cols):
+    """Fused residual add + LayerNorm against torch's two kernels (fp32 reference of the same op)."""
+    g = torch.Generator().manual_seed(rows + cols)
+    a = torch.randn(rows, cols + 4, generator=g).to(DEV)[:, :cols]          # strided rows
+    b = (torch.randn(rows, cols, generator=g) * 3).to(DEV)
+    ln = torch.nn.LayerNorm(cols, eps=1e-5).to(DEV)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(cols, generator=g).to(DEV))
+        ln.bias.copy_(torch.randn(cols, generator=g).to(DEV))
+        y, z = hip.add_layernorm(a, b, ln)
+        ref_y = a + b
+        ref_z = ln(ref_y)
+    torch.testing.assert_close(y, ref_y, rtol=0, atol=0)
+    torch.testing.assert_close(z, ref_z, rtol=1e-5, atol=2e-5)
