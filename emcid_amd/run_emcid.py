@@ -1,0 +1,127 @@
+"""Instruction-file driver of the mass-edit path (counterpart of the reference's scripts/run_emcid.py:27-134).
+
+Same instruction JSON (reference: test_examples/*.json) — ``requests``, ``hparams`` (name of ``{hparams_dir}/{name}.json``),
+``model_ckpt`` ("sd-v1.4" | "sdxl-1.0"), ``mom2_weight``, ``edit_weight``, optional ``mom2_weight_2``; ``val_prompts``,
+``out_dir`` and ``sample_num`` are read and ignored: the reference generates pre/post images with the diffusion pipeline
+around the edit, this driver runs the edit only, reports its wall clock like experiments/emcid_test.py:1171-1180 and
+writes the edited fc2 matrices to a safetensors file.
+
+The pipeline: ``--pipe diffusers`` loads Stable Diffusion like the reference (needs the ``diffusers`` package and the
+checkpoints); ``--pipe synthetic`` builds the random-init encoders of the same dimensions with the in-memory tokenizer
+(emcid_amd/synthetic.py) — the configuration the parity fixtures and the benchmark use, v* and statistics caches
+included when ``--synthetic_caches`` is given.
+"""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+from .emcid_hparams import EMCIDHyperParams, EMCIDXLHyperParams
+from .globals import HPARAMS_DIR, STATS_DIR, XL_STATS_DIR1, XL_STATS_DIR2
+
+
+def set_weights(hparams, mom2_weight, edit_weight):
+    """reference: experiments/emcid_test.py:924-930"""
+    hparams.mom2_update_weight = hparams.mom2_update_weight if mom2_weight is None else mom2_weight
+    hparams.edit_weight = hparams.edit_weight if edit_weight is None else edit_weight
+    return hparams
+
+
+def load_instruction(path, hparams_dir=HPARAMS_DIR):
+    """(instructions dict, hparams object, cache_name) exactly as the reference derives them (:39-63)."""
+    with open(path, "r") as f:
+        ins = json.load(f)
+    ckpt = ins["model_ckpt"]
+    if ckpt == "sd-v1.4":
+        cls = EMCIDHyperParams
+    elif ckpt == "sdxl-1.0":
+        cls = EMCIDXLHyperParams
+    else:
+        raise ValueError("Invalid model_ckpt")
+    hparams = set_weights(cls.from_json(Path(hparams_dir) / f"{ins['hparams']}.json"), ins["mom2_weight"], ins["edit_weight"])
+    return ins, hparams, f"cache/{ins['hparams']}/"
+
+
+def build_pipe(kind: str, model_ckpt: str, device: str):
+    if kind == "diffusers":
+        try:
+            from diffusers import StableDiffusionPipeline, StableDiffusionXLPipeline
+        except ImportError as e:
+            raise SystemExit(f"--pipe diffusers needs the diffusers package ({e}); use --pipe synthetic") from e
+        if model_ckpt == "sd-v1.4":
+            return StableDiffusionPipeline.from_pretrained("CompVis/stable-diffusion-v1-4", torch_dtype=torch.float32,
+                                                           safety_checker=None, requires_safety_checker=False).to(device)
+        return StableDiffusionXLPipeline.from_pretrained("stabilityai/stable-diffusion-xl-base-1.0", torch_dtype=torch.float32,
+                                                         use_safetensors=True, variant="fp16").to(device)
+    from . import synthetic as syn
+    return syn.build_pipe("sd-v1.4", device, sdxl=(model_ckpt == "sdxl-1.0"))
+
+
+def run(instruction_path, device="cuda:0", pipe=None, pipe_kind="synthetic", hparams_dir=HPARAMS_DIR, cache_name: Optional[str] = None,
+        stats_dir=None, stats_dir_2=None, out: Optional[str] = None, verbose=True):
+    """Apply the instruction's edit; returns (pipe, hparams, seconds)."""
+    from . import emcid_main as em
+    ins, hparams, default_cache = load_instruction(instruction_path, hparams_dir)
+    cache_name = default_cache if cache_name is None else cache_name
+    pipe = build_pipe(pipe_kind, ins["model_ckpt"], device) if pipe is None else pipe
+    if device.startswith("cuda"):
+        torch.cuda.synchronize()
+    t0 = time.time()
+    if ins["model_ckpt"] == "sd-v1.4":
+        em.apply_emcid_to_text_encoder(pipe, ins["requests"], hparams, device, cache_name=cache_name,
+                                       stats_dir=STATS_DIR if stats_dir is None else stats_dir, verbose=verbose)
+    else:
+        em.apply_emcid_to_sdxl_text_encoders(pipe, ins["requests"], hparams, device, mom2_weight=ins["mom2_weight"],
+                                             mom2_weight_2=ins.get("mom2_weight_2", None), edit_weight=ins["edit_weight"],
+                                             cache_name=cache_name, stat_dir=XL_STATS_DIR1 if stats_dir is None else stats_dir,
+                                             stat_dir_2=XL_STATS_DIR2 if stats_dir_2 is None else stats_dir_2, verbose=verbose)
+    if device.startswith("cuda"):
+        torch.cuda.synchronize()
+    dt = time.time() - t0
+    if verbose:
+        print(f"apply_emcid takes {dt} seconds ({len(ins['requests']) / dt:.1f} concept-edits/s).")
+    if out:
+        em.export_edited_weights(pipe.text_encoder, hparams, out)
+        if ins["model_ckpt"] == "sdxl-1.0":
+            p = Path(out)
+            em.export_edited_weights(pipe.text_encoder_2, hparams, p.with_name(p.stem + "_2" + p.suffix), layers=hparams.layers_2)
+    return pipe, hparams, dt
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--instruction_path", type=str, required=True)
+    ap.add_argument("--device", type=str, default="cuda:0")
+    ap.add_argument("--pipe", choices=["synthetic", "diffusers"], default="synthetic")
+    ap.add_argument("--hparams_dir", default=str(HPARAMS_DIR))
+    ap.add_argument("--cache_name", default=None, help="v* cache prefix (default cache/{hparams}/ like the reference)")
+    ap.add_argument("--stats_dir", default=None)
+    ap.add_argument("--stats_dir_2", default=None)
+    ap.add_argument("--out", default=None, help="write the edited fc2 weights here (safetensors)")
+    ap.add_argument("--synthetic_caches", action="store_true",
+                    help="with --pipe synthetic: write synthetic v* / statistics caches for the instruction first")
+    a = ap.parse_args(argv)
+    if a.synthetic_caches:
+        if a.pipe != "synthetic":
+            raise SystemExit("--synthetic_caches only makes sense with --pipe synthetic")
+        from . import synthetic as syn
+        ins, hp, default_cache = load_instruction(a.instruction_path, a.hparams_dir)
+        cache = default_cache if a.cache_name is None else a.cache_name
+        sdxl = ins["model_ckpt"] == "sdxl-1.0"
+        syn.write_vstar_cache(cache, ins["requests"], 768, seed=1, scale=0.5)
+        s1 = a.stats_dir or str(XL_STATS_DIR1 if sdxl else STATS_DIR)
+        syn.write_stats_cache(s1, [hp.rewrite_module_tmp.format(l) for l in hp.layers], 3072, hp.mom2_n_samples, seed=2, t=6144)
+        if sdxl:
+            syn.write_vstar_cache(cache, ins["requests"], 1280, seed=5, scale=0.5, suffix="_2")
+            syn.write_stats_cache(a.stats_dir_2 or str(XL_STATS_DIR2), [hp.rewrite_module_tmp.format(l) for l in hp.layers_2],
+                                  5120, hp.mom2_n_samples, seed=7, t=10240)
+    run(a.instruction_path, a.device, None, a.pipe, a.hparams_dir, a.cache_name, a.stats_dir, a.stats_dir_2, a.out)
+    print("Done")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -242,6 +242,45 @@ def golden_stage0(ls, scratch, tag="toy_stage0"):
     print(f"[golden] {tag}: wrote {len(out)} arrays")
 
 
+def golden_instruction(em, EMCIDHyperParams, scratch, tag="config1_van_gogh"):
+    """BASELINE config 1: the reference's own instruction file test_examples/erasing_van_gogh_style.json with its shipped
+    hparams file, applied by the REAL reference to the synthetic SD-v1.4-dimension encoder (N = 1 request, 3 prompts).
+    The instruction and hparams JSON are stored verbatim in the fixture (they are data); summaries of dW as in
+    real_sd_summary."""
+    ins = json.load(open(REF / "test_examples" / "erasing_van_gogh_style.json"))
+    hp_file = json.load(open(REF / "hparams" / f"{ins['hparams']}.json"))
+    kind = "sd-v1.4"
+    pipe = syn.build_pipe(kind, "cpu")
+    hidden, inter = syn.ENCODER_DIMS[kind][:2]
+    hp_d = dict(hp_file)
+    for k in ("rewrite_module_tmp", "layer_module_tmp", "mlp_module_tmp", "attn_module_tmp", "ln_f_module"):
+        hp_d[k] = hp_d[k].replace("text_model.", "")          # shim 3 (transformers 5.x names), for the reference only
+    cache = str(scratch / "cache" / ins["hparams"]) + "/"
+    stats_dir = scratch / f"stats_{tag}"
+    vs = syn.write_vstar_cache(cache, ins["requests"], hidden, seed=1, scale=0.5)
+    names = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers"]]
+    syn.write_stats_cache(stats_dir, names, inter, hp_d["mom2_n_samples"], seed=2, t=2 * inter)
+    em.COV_CACHE.clear()
+    hp = EMCIDHyperParams(**hp_d)
+    hp.mom2_update_weight, hp.edit_weight = ins["mom2_weight"], ins["edit_weight"]          # set_weights, emcid_test.py:924-930
+    w0 = {n: em.nethook.get_parameter(pipe.text_encoder, n + ".weight").clone() for n in names}
+    em.apply_emcid_to_text_encoder(pipe, ins["requests"], hp, "cpu", cache_name=cache, stats_dir=str(stats_dir), verbose=False)
+    g = torch.Generator().manual_seed(123)
+    probe = torch.randn(inter, 8, generator=g, dtype=torch.float64)
+    out = {"vstar": vs}
+    for li, n in enumerate(names):
+        dw = em.nethook.get_parameter(pipe.text_encoder, n + ".weight").double() - w0[n].double()
+        out[f"dw_probe/{li}"] = (dw @ probe).numpy()
+        out[f"dw_fro/{li}"] = np.array(dw.norm().item())
+        out[f"dw_rownorm/{li}"] = dw.norm(dim=1).numpy()
+        out[f"dw_maxabs/{li}"] = np.array(dw.abs().max().item())
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump({"kind": kind, "instruction": ins, "hparams_file": hp_file, "layer_names": names,
+                   "stats": {"seed": 2, "t": 2 * inter}, "vstar": {"seed": 1, "scale": 0.5}}, f, indent=1)
+    print(f"[golden] {tag}: wrote {len(out)} arrays")
+
+
 def golden_cal_insert(em, EMCIDHyperParams, scratch, tag="toy_cal_insert"):
     """Reference cal_insert_deltas (emcid_main.py:1969-2052): the layer loop for caller-supplied targets; it reads the
     statistics from the module-level STATS_DIR and leaves the model edited."""
@@ -376,6 +415,7 @@ def main():
         golden_stage0(ls, scratch)
         golden_xattn(em, HP, scratch)
         golden_cal_insert(em, HP, scratch)
+        golden_instruction(em, HP, scratch)
         if "--skip-real" not in sys.argv:
             golden_sd(em, HP, scratch, "real_sd_summary", "sd-v1.4", n_req=24, layers=(7, 8, 9, 10), lam=4000,
                       ew=0.5, ragged=False, full=False)

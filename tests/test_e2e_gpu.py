@@ -473,3 +473,32 @@ def test_cal_insert_deltas_matches_reference_golden(tmp_path):
     with pytest.raises(ValueError):
         em.cal_insert_deltas(pipe, {k: v.clone() for k, v in weights.items()}, hp, meta["requests"],
                              torch.from_numpy(z["zs"]).to(DEV), verbose=False, stat_dir=str(tmp_path / "stats"))
+
+
+def test_config1_instruction_driver_matches_reference_golden(tmp_path, monkeypatch):
+    """BASELINE config 1 through the instruction-file driver (counterpart of scripts/run_emcid.py): the reference's own
+    erasing_van_gogh_style.json + shipped hparams file, N = 1, SD-v1.4 dims, on the HIP path vs the reference's dW."""
+    from test_oracle_golden import _config1_files
+    from emcid_amd import run_emcid
+    z, meta = load_golden("config1_van_gogh")
+    _config1_files(tmp_path, z, meta)
+    monkeypatch.chdir(tmp_path)                       # the driver's default v* cache is cache/{hparams}/ under the cwd
+    pipe = syn.build_pipe(meta["kind"], DEV)
+    names = meta["layer_names"]
+    w0 = {n: get_parameter(pipe.text_encoder, n + ".weight").detach().cpu().clone() for n in names}
+    out = tmp_path / "edited.safetensors"
+    pipe, hp, dt = run_emcid.run(str(tmp_path / "instruction.json"), DEV, pipe=pipe, hparams_dir=str(tmp_path / "hparams"),
+                                 stats_dir=str(tmp_path / "stats"), out=str(out), verbose=False)
+    assert hp.mom2_update_weight == meta["instruction"]["mom2_weight"] and dt > 0
+    g = torch.Generator().manual_seed(123)
+    probe = torch.randn(syn.ENCODER_DIMS[meta["kind"]][1], 8, generator=g, dtype=torch.float64)
+    from safetensors.torch import load_file
+    saved = load_file(str(out))
+    for li, n in enumerate(names):
+        w = get_parameter(pipe.text_encoder, n + ".weight").detach().cpu()
+        dw = w.double() - w0[n].double()
+        scale = float(z[f"dw_maxabs/{li}"])
+        assert np.abs((dw @ probe).numpy() - z[f"dw_probe/{li}"]).max() <= 1e-4 * scale * 60
+        assert np.abs(dw.norm(dim=1).numpy() - z[f"dw_rownorm/{li}"]).max() <= 1e-4 * z[f"dw_rownorm/{li}"].max()
+        key = [k for k in saved if k.endswith(n.split("encoder.")[-1] + ".weight")][0]
+        assert torch.equal(saved[key], w)

@@ -169,3 +169,41 @@ def test_cal_insert_deltas_golden():
         np.testing.assert_allclose(adj_k.numpy(), z[f"adj_k/{li}"], rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(resid.numpy(), z[f"resid/{li}"], rtol=1e-13, atol=0)
         np.testing.assert_array_equal(orc.get_parameter(te, n + ".weight").numpy(), z[f"w_after/{li}"])
+
+
+def _config1_files(tmp_path, z, meta):
+    """The instruction file, the hparams file (verbatim from the fixture) and the synthetic caches of BASELINE config 1."""
+    ins, hp_file = meta["instruction"], meta["hparams_file"]
+    (tmp_path / "hparams").mkdir()
+    json.dump(hp_file, open(tmp_path / "hparams" / f"{ins['hparams']}.json", "w"))
+    json.dump(ins, open(tmp_path / "instruction.json", "w"))
+    cache = str(tmp_path / "cache" / ins["hparams"]) + "/"
+    write_vstars(cache, ins["requests"], z["vstar"])
+    hidden, inter = syn.ENCODER_DIMS[meta["kind"]][:2]
+    # statistics files are named after the module names IN THE HPARAMS FILE (with the transformers-4.x "text_model."
+    # prefix, as shipped); the reference itself ran with the prefix stripped (shim 3) — same matrices, other file names
+    names = [hp_file["rewrite_module_tmp"].format(l) for l in hp_file["layers"]]
+    syn.write_stats_cache(tmp_path / "stats", names, inter, hp_file["mom2_n_samples"], seed=meta["stats"]["seed"],
+                          t=meta["stats"]["t"])
+    return cache
+
+
+def test_config1_van_gogh_instruction(tmp_path):
+    """BASELINE config 1 (the reference's own CPU-runnable case): test_examples/erasing_van_gogh_style.json with the
+    shipped ly-7-11 hparams, N = 1, SD-v1.4 dims — the oracle against the reference's dW summaries."""
+    z, meta = load_golden("config1_van_gogh")
+    cache = _config1_files(tmp_path, z, meta)
+    ins = meta["instruction"]
+    pipe = syn.build_pipe(meta["kind"], "cpu")
+    names = meta["layer_names"]
+    w0 = {n: orc.get_parameter(pipe.text_encoder, n + ".weight").clone() for n in names}
+    hp = dict(meta["hparams_file"])
+    orc.apply_emcid_to_text_encoder(pipe, ins["requests"], hp, mom2_weight=ins["mom2_weight"], edit_weight=ins["edit_weight"],
+                                    cache_name=cache, stats_dir=str(tmp_path / "stats"))
+    g = torch.Generator().manual_seed(123)
+    probe = torch.randn(syn.ENCODER_DIMS[meta["kind"]][1], 8, generator=g, dtype=torch.float64)
+    for li, n in enumerate(names):
+        dw = orc.get_parameter(pipe.text_encoder, n + ".weight").double() - w0[n].double()
+        np.testing.assert_allclose((dw @ probe).numpy(), z[f"dw_probe/{li}"], rtol=0, atol=1e-6 * float(z[f"dw_maxabs/{li}"]) * 60)
+        np.testing.assert_allclose(dw.norm(dim=1).numpy(), z[f"dw_rownorm/{li}"], rtol=1e-6, atol=1e-9)
+        assert abs(dw.abs().max().item() - float(z[f"dw_maxabs/{li}"])) <= 1e-6 * float(z[f"dw_maxabs/{li}"])
