@@ -67,8 +67,10 @@ def test_two_ranks_match_single_process(tmp_path, n_req, solver, monkeypatch):
     r0, r1 = np.load(f"{tmp}/rank0.npz"), np.load(f"{tmp}/rank1.npz")
     for n in names:
         single = get_parameter(pipe.text_encoder, n + ".weight").cpu().numpy()
-        np.testing.assert_array_equal(r0[n], r1[n])                      # ranks agree bit for bit
         dw = single.astype(np.float64) - w0[n]
+        # every rank finishes the layer from the same gathered rows: equal up to the summation order of the split-K
+        # f64 atomics (a last-bit fp32 flip at most)
+        assert np.abs(r0[n].astype(np.float64) - r1[n]).max() <= 1e-6 * np.abs(dw).max()
         err = np.abs(r0[n].astype(np.float64) - single).max()
         assert err <= 1e-5 * np.abs(dw).max(), (n, err)                  # different batch split in the fp32 forward
 
