@@ -703,7 +703,10 @@ static int build_full_inverse(const double* L, int64_t dp, int64_t lda, const do
     ScopedProf sp(KC_INV_BUILD, st);
     hipLaunchKernelGGL(copy_diag_inverse_kernel, dim3((unsigned)dp, (unsigned)nbatch), dim3(256), 0, st, invw, s_inv, X, lda, s_mat, dp);
     const int nob = (int)((dp + OB - 1) / OB);
-    static const int cfg_a = env_flag("EMCID_INV_CFG_A", -1), cfg_b = env_flag("EMCID_INV_CFG_B", -1);   // experiments
+    // 32x64 tiles in mirrored pairs: 1.06 ms for 4 x 3072^2 vs 1.30 ms with the launcher's own choice
+    // (scripts/inverse_alone.py sweeps these)
+    static const int cfg_a = env_flag("EMCID_INV_CFG_A", 2), cfg_b = env_flag("EMCID_INV_CFG_B", 2);
+    static const int pair_ = env_flag("EMCID_INV_PAIR", 1);
     struct Range { int b0, b1; };
     // post-order over the halving tree, iteratively (depth <= log2(64))
     Range stack[64];
@@ -725,9 +728,11 @@ static int build_full_inverse(const double* L, int64_t dp, int64_t lda, const do
         const int m = (int)(r1 - rm), n = (int)(rm - r0);
         GemmShape a{L + rm * lda + r0, lda, X + r0 * lda + r0, lda, m, n, n, 0, s_mat, s_mat, nbatch};
         a.tri = 2;   // B(k, n) = X11[k][n], zero for k < n
+        a.pair = pair_;
         launch_gemm_f64<true, false>(a, EpiAxpby{T, lda, 1.0, 0.0, s_mat}, st, cfg_a);
         GemmShape b{X + rm * lda + rm, lda, T, lda, m, n, m, 0, s_mat, s_mat, nbatch};
         b.tri = 4;   // A(m, k) = X22[m][k], zero for k > m
+        b.pair = pair_;
         launch_gemm_f64<true, false>(b, EpiAxpby{X + rm * lda + r0, lda, -1.0, 0.0, s_mat}, st, cfg_b);
     }
     return check_launch("build_full_inverse");
