@@ -300,16 +300,17 @@ def mlp_hidden(layer: ClipLayer, ln2_mid: torch.Tensor) -> torch.Tensor:
     return layer.act(layer.fc1(ln2_mid))
 
 
-def run_layers(graph: ClipTextGraph, trie: TokenTrie, upto: int, on_fc2=None, last_rows_only: bool = True):
+def run_layers(graph: ClipTextGraph, trie: TokenTrie, upto: int, on_fc2=None, last_rows_only: bool = True,
+               fc2_by_callback=()):
     """Layers 0..upto (inclusive).  ``on_fc2(i, x, out) -> out'`` is called with the fc2 input/output of every layer
     (rows = all nodes, or the query rows at layer ``upto`` when ``last_rows_only``); whatever it returns is used
     as fc2's output.  Returns the residual stream after layer ``upto`` (query rows only if ``last_rows_only``)."""
     _check_fp32(graph)
     with tuned_gemms():
-        return _run_layers(graph, trie, upto, on_fc2, last_rows_only)
+        return _run_layers(graph, trie, upto, on_fc2, last_rows_only, set(fc2_by_callback))
 
 
-def _run_layers(graph, trie, upto, on_fc2, last_rows_only):
+def _run_layers(graph, trie, upto, on_fc2, last_rows_only, fc2_by_callback=frozenset()):
     hs = embed(graph, trie)
     x_ln1 = None
     for i in range(upto + 1):
@@ -317,7 +318,9 @@ def _run_layers(graph, trie, upto, on_fc2, last_rows_only):
         rows = trie.query_rows if (last_rows_only and i == upto) else None
         mid, ln2_mid = layer_attention_block(layer, hs, trie, rows, x_ln1)
         x = mlp_hidden(layer, ln2_mid)
-        out = layer.fc2(x)
+        # layers in ``fc2_by_callback``: the callback produces fc2's output itself (out is passed as None), so an
+        # edited layer's projection is computed once, with the new weight, instead of twice
+        out = None if i in fc2_by_callback else layer.fc2(x)
         if on_fc2 is not None:
             out = on_fc2(i, x, out)
             if out is None:

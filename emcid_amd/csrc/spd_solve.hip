@@ -1322,9 +1322,26 @@ double* emcid_edit_dual_yt(void* workspace, int64_t N, int64_t d, int64_t h) {
     return (double*)workspace + DualWorkspace(N, d, h).off_Y;
 }
 
+/* The first part of stage 2 on its own: S = I + Yt Yt^T.  A caller that wants to start other work exactly when the
+ * latency-bound Cholesky of S begins (the engine builds the next layer's inverse factor on a second stream then) calls
+ * this, records its event, and passes assembled = 1 to stage 2. */
+int emcid_edit_dual_apply_assemble_f64(int64_t N, int64_t d, int64_t h, void* workspace, int64_t workspace_bytes, void* stream) {
+    EMCID_CHECK_ARG(N > 0 && d > 0 && h > 0 && workspace);
+    DualWorkspace ws(N, d, h);
+    if (workspace_bytes < ws.total * (int64_t)sizeof(double)) return fail(EMCID_ERR_WORKSPACE, __func__, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double* base = (double*)workspace;
+    double *Yt = base + ws.off_Y, *S = base + ws.off_S;
+    const int64_t dp = ws.dp, Np = ws.Np;
+    if (Np > N) hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, st, Yt + N * dp, (Np - N) * dp);
+    assemble_dual_system(Yt, Yt, dp, S, (int)Np, st);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
 int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void* cov_factor_ws, int64_t n_layers,
-                                     int64_t layer_index, int use_inverse, const float* W0, float* W, float* dW_out,
-                                     void* workspace, int64_t workspace_bytes, int* info_dev, void* stream) {
+                                     int64_t layer_index, int use_inverse, int assembled, const float* W0, float* W,
+                                     float* dW_out, void* workspace, int64_t workspace_bytes, int* info_dev, void* stream) {
     EMCID_CHECK_ARG(N > 0 && d > 0 && h > 0 && workspace && info_dev && cov_factor_ws && ((W == nullptr) || (W0 != nullptr)));
     EMCID_CHECK_ARG(0 <= layer_index && layer_index < n_layers && (W || dW_out));
     DualWorkspace ws(N, d, h);
@@ -1336,10 +1353,13 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
     const int64_t dp = ws.dp, Np = ws.Np, hp = ws.hp, s_mat = dp * dp;
     const double* Lb = (const double*)cov_factor_ws + n_layers * s_mat + layer_index * s_mat;
     const double* Ib = (const double*)cov_factor_ws + 2 * n_layers * s_mat + layer_index * inv_doubles(dp);
-    EMCID_TRY(with_graph(make_key(6, {Yt, R, S, LS, RT, V, U, info_dev}, {dp, Np, N, hp, (int64_t)(uintptr_t)Lb, use_inverse}), st,
+    EMCID_TRY(with_graph(make_key(6, {Yt, R, S, LS, RT, V, U, info_dev},
+                                  {dp, Np, N, hp, (int64_t)(uintptr_t)Lb, use_inverse + 2 * (assembled != 0)}), st,
                          [&](hipStream_t q) {
-        if (Np > N) hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, q, Yt + N * dp, (Np - N) * dp);
-        assemble_dual_system(Yt, Yt, dp, S, (int)Np, q);      // S = I + Yt Yt^T (lower tiles)
+        if (!assembled) {
+            if (Np > N) hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, q, Yt + N * dp, (Np - N) * dp);
+            assemble_dual_system(Yt, Yt, dp, S, (int)Np, q);      // S = I + Yt Yt^T (lower tiles)
+        }
         EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q));
         // RT[h, Np] = Rt^T ; Z^T = RT S^-1 (two solves with h rows)
         hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)((hp + 31) / 32), (unsigned)(Np / 32)), dim3(256), 0, q, R, hp, RT,

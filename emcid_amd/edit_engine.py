@@ -208,18 +208,25 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                 plan.cov_factors.info.zero_()
             plan.cov_factors = hip.factor_cov([plan.covs[l] for l in plan.layers], plan.lam, plan.edit_weight,
                                               plan.cov_factors, inverse=False)
-            fac_done = [torch.cuda.Event() for _ in range(L)]
-            fac_done[0].record(plan.side_stream)
-            # The first edited layer solves against M by block substitution with L as soon as the factorization is there;
-            # the explicit inverse factors X_l = inv(L_l) of the LATER layers (their two M-solves become two GEMMs) are
-            # built, batched, underneath that first solve.  EMCID_INVERSE_FROM: first layer index that uses X.
+            chol_done = torch.cuda.Event()
+            chol_done.record(plan.side_stream)
+            # The first edited layer solves against M by block substitution with L as soon as the factorization is there.
+            # The explicit inverse factors X_l = inv(L_l) of the LATER layers (their two M-solves become two GEMMs) are
+            # built one layer ahead, on the side stream, exactly while the previous layer's solve sits in the
+            # latency-bound Cholesky of its N x N system (the chip is idle there): see ``lazy_inverse`` in solve().
+            # EMCID_INVERSE_FROM: first layer index that uses X; EMCID_INVERSE_LAZY=0: build them all right after the
+            # factorization instead (batched, underneath the forward — costs the forward more than it hides).
             first_x = min(L, max(0, int(os.environ.get("EMCID_INVERSE_FROM", "1"))))
-            if first_x < L:
+            lazy = os.environ.get("EMCID_INVERSE_LAZY", "1") != "0" and keep_factors is False and first_x >= 1
+            fac_done = [chol_done] * L
+            if first_x < L and not lazy:
                 hip.cov_inverse(plan.cov_factors, first_x, L - first_x)
-            ev = torch.cuda.Event()
-            ev.record(plan.side_stream)
-            for i in range(L):
-                fac_done[i] = ev if i >= first_x else fac_done[0]
+                ev = torch.cuda.Event()
+                ev.record(plan.side_stream)
+                for i in range(first_x, L):
+                    fac_done[i] = ev
+        if first_x >= L:
+            lazy = False
     else:
         if plan.ws is None or plan.ws.key != (plan.n_total, d, h):
             plan.ws = hip.EditWorkspace(plan.n_total, d, h, dev)
@@ -233,10 +240,22 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
             torch.cuda.current_stream(dev).wait_event(fac_done[i])
             sharded = plan.shard.world > 1
             if not keep_factors:   # only the edited weights are wanted: the form that never builds adj_k
+                def lazy_inverse(nxt=i + 1):
+                    # stream position: S of layer i is assembled, its Cholesky starts now -> build X of the next layer
+                    start = torch.cuda.Event()
+                    start.record(torch.cuda.current_stream(dev))
+                    plan.side_stream.wait_event(start)
+                    with torch.cuda.stream(plan.side_stream):
+                        hip.cov_inverse(plan.cov_factors, nxt, 1)
+                        fac_done[nxt] = torch.cuda.Event()
+                        fac_done[nxt].record(plan.side_stream)
+
+                ahead = lazy and first_x <= i + 1 < L
                 res = hip.edit_layer_dual_apply(
                     K, Zc, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, backups[layer], weights[layer].data,
                     ws=plan.dual_ws, rows=plan.shard.bounds(plan.n_total) if sharded else None,
-                    gather_yt=(lambda rows_: _all_gather_rows(rows_.contiguous(), plan)) if sharded else None)
+                    gather_yt=(lambda rows_: _all_gather_rows(rows_.contiguous(), plan)) if sharded else None,
+                    on_factor_start=lazy_inverse if ahead else None)
                 edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], None, None,
                                        K if trace else None, Zc if trace else None))
                 return
@@ -272,18 +291,26 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
         def rows_at(x, idx):   # (rows, c) activations -> per-request means at each prompt's lookup row
             return hip.gather_mean(x.unsqueeze(0).expand(B, -1, -1), idx, plan.batch.seg)
 
+        zc_from_keys = os.environ.get("EMCID_ZC_FROM_KEYS", "1") != "0"      # 0: fc2 over every node + gather (A/B switch)
+
         def on_fc2(li, x, out):
             if li not in order:
                 return out
             idx = trie.lookup_in_query if li == last else trie.lookup_node
-            solve(order[li], li, rows_at(x, idx), rows_at(out, idx))
+            m = mods[li]
+            K_loc = rows_at(x, idx)
+            if not zc_from_keys:
+                solve(order[li], li, K_loc, rows_at(F.linear(x, m.weight, m.bias), idx))
+                return None if li == last else F.linear(x, m.weight, m.bias)
+            # fc2 is affine, so the mean over a request's prompts of its output at the lookup rows IS fc2 of the mean
+            # key: Zc = K W^T + b on N rows (to fp32 rounding) instead of fc2 over every node followed by a gather
+            solve(order[li], li, K_loc, F.linear(K_loc, m.weight, m.bias))
             if li == last:
                 return None
-            m = mods[li]
             return F.linear(x, m.weight, m.bias)
 
         with torch.no_grad():
-            clip_forward.run_layers(plan.graph, trie, last, on_fc2)
+            clip_forward.run_layers(plan.graph, trie, last, on_fc2, fc2_by_callback=order)
     else:
         def make_hook(i, layer):
             def hook(mod, inputs, output):

@@ -25,11 +25,12 @@ EXPORTS = [
     "emcid_edit_dual_workspace_bytes",
     "emcid_edit_dual_stage1_f64", "emcid_edit_dual_pt", "emcid_edit_dual_stage2_f64",
     "emcid_edit_dual_apply_stage1_f64", "emcid_edit_dual_yt", "emcid_edit_dual_apply_stage2_f64",
+    "emcid_edit_dual_apply_assemble_f64",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block"]
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NB = 128      # Cholesky block (csrc/common.h)
 NPAD = 64     # concept padding of the f64 stacks (csrc/common.h)
 
@@ -76,7 +77,8 @@ def load():
         "emcid_edit_dual_stage2_f64": (i32, [i64, i64, i64, p, p, p, p, p, p, i64, p, p]),
         "emcid_edit_dual_apply_stage1_f64": (i32, [p, p, p, i64, i64, i64, f64, i32, p, i64, i64, i64, i64, i32, p, i64, p]),
         "emcid_edit_dual_yt": (p, [p, i64, i64, i64]),
-        "emcid_edit_dual_apply_stage2_f64": (i32, [i64, i64, i64, p, i64, i64, i32, p, p, p, p, i64, p, p]),
+        "emcid_edit_dual_apply_stage2_f64": (i32, [i64, i64, i64, p, i64, i64, i32, i32, p, p, p, p, i64, p, p]),
+        "emcid_edit_dual_apply_assemble_f64": (i32, [i64, i64, i64, p, i64, p]),
         "emcid_cholesky_solve_f64": (i32, [p, i64, i64, p, p, p, i64, i64, p]),
         "emcid_delta_w_f64": (i32, [p, i64, p, i64, i64, i64, i64, p, p, i64, p, p, p]),
         "emcid_dgemm_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, p]),
@@ -489,8 +491,10 @@ def edit_layer_dual(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_wei
 
 def edit_layer_dual_apply(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_weight: float, layers_left: int,
                           W0, W, want_dw: bool = True, ws: Optional[DualWorkspace] = None, rows=None, gather_yt=None,
-                          use_inverse: Optional[bool] = None):
-    """Apply-only dual solver: W = W0 + float(U) without ever forming adj_k.  Returns dict(dW, ws)."""
+                          use_inverse: Optional[bool] = None, on_factor_start=None):
+    """Apply-only dual solver: W = W0 + float(U) without ever forming adj_k.  ``on_factor_start()``: called (host side)
+    right after S = I + Yt Yt^T has been enqueued, i.e. the stream position where the latency-bound Cholesky of S
+    begins.  Returns dict(dW, ws)."""
     if use_inverse is None:
         use_inverse = layer_index in factors.have_inverse
     N, d = K.shape
@@ -509,8 +513,13 @@ def edit_layer_dual_apply(K, Zc, zs_t, factors: CovFactors, layer_index: int, ed
     if gather_yt is not None:
         ws.Yt[:N].copy_(gather_yt(ws.Yt[lo:hi]))
     dW = torch.empty(h, d, dtype=torch.float32, device=K.device) if want_dw else None
+    if on_factor_start is not None:
+        _check(lib.emcid_edit_dual_apply_assemble_f64(N, d, h, _ptr(ws.buf), ws.nbytes, _stream(K)),
+               "emcid_edit_dual_apply_assemble_f64")
+        on_factor_start()
     _check(lib.emcid_edit_dual_apply_stage2_f64(N, d, h, _ptr(factors.buf), factors.n_layers, int(layer_index),
-                                                int(bool(use_inverse)), _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"), _ptr(dW),
+                                                int(bool(use_inverse)), int(on_factor_start is not None),
+                                                _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"), _ptr(dW),
                                                 _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32), _stream(K)),
            "emcid_edit_dual_apply_stage2_f64")
     return {"dW": dW, "ws": ws}

@@ -26,7 +26,7 @@ extern "C" {
 #define EMCID_ERR_HIP (-2)
 #define EMCID_ERR_WORKSPACE (-3)
 
-#define EMCID_ABI_VERSION 2
+#define EMCID_ABI_VERSION 3
 
 /* ABI version of the loaded library (host-only, no GPU needed). */
 int emcid_abi_version(void);
@@ -177,8 +177,11 @@ int emcid_edit_dual_apply_stage1_f64(const float* K, const float* Zc, const floa
                                      int64_t workspace_bytes, void* stream);
 double* emcid_edit_dual_yt(void* workspace, int64_t N, int64_t d, int64_t h);
 int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void* cov_factor_ws, int64_t n_layers,
-                                     int64_t layer_index, int use_inverse, const float* W0, float* W, float* dW_out,
-                                     void* workspace, int64_t workspace_bytes, int* info_dev, void* stream);
+                                     int64_t layer_index, int use_inverse, int assembled, const float* W0, float* W,
+                                     float* dW_out, void* workspace, int64_t workspace_bytes, int* info_dev, void* stream);
+/* S = I + Yt Yt^T alone (then pass assembled = 1 to stage 2): lets the caller hang other work on the moment the
+ * latency-bound Cholesky of S starts. */
+int emcid_edit_dual_apply_assemble_f64(int64_t N, int64_t d, int64_t h, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* The stages of emcid_edit_layer_f64 as separate calls (used by tests and micro-benchmarks). */
 
