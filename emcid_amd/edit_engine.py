@@ -217,8 +217,12 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
             # EMCID_INVERSE_FROM: first layer index that uses X; EMCID_INVERSE_LAZY=0: build them all right after the
             # factorization instead (batched, underneath the forward — costs the forward more than it hides).
             first_x = min(L, max(0, int(os.environ.get("EMCID_INVERSE_FROM", "1"))))
-            lazy = os.environ.get("EMCID_INVERSE_LAZY", "1") != "0" and keep_factors is False and first_x >= 1
+            lazy = os.environ.get("EMCID_INVERSE_LAZY", "1") != "0" and keep_factors is False
             fac_done = [chol_done] * L
+            if lazy and first_x == 0:      # the first layer's X right behind the factorization, the others one layer ahead
+                hip.cov_inverse(plan.cov_factors, 0, 1)
+                fac_done[0] = torch.cuda.Event()
+                fac_done[0].record(plan.side_stream)
             if first_x < L and not lazy:
                 hip.cov_inverse(plan.cov_factors, first_x, L - first_x)
                 ev = torch.cuda.Event()
@@ -227,6 +231,8 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                     fac_done[i] = ev
         if first_x >= L:
             lazy = False
+        if os.environ.get("EMCID_FACTOR_FIRST", "0") == "1":    # experiment: no overlap of the factorization with the forward
+            torch.cuda.current_stream(dev).wait_event(chol_done)
     else:
         if plan.ws is None or plan.ws.key != (plan.n_total, d, h):
             plan.ws = hip.EditWorkspace(plan.n_total, d, h, dev)
@@ -250,7 +256,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                         fac_done[nxt] = torch.cuda.Event()
                         fac_done[nxt].record(plan.side_stream)
 
-                ahead = lazy and first_x <= i + 1 < L
+                ahead = lazy and max(first_x, 1) <= i + 1 < L
                 res = hip.edit_layer_dual_apply(
                     K, Zc, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, backups[layer], weights[layer].data,
                     ws=plan.dual_ws, rows=plan.shard.bounds(plan.n_total) if sharded else None,
