@@ -216,12 +216,19 @@ def test_quick_gelu_vs_torch():
     torch.testing.assert_close(hip.quick_gelu(y), y * torch.sigmoid(1.702 * y), rtol=2e-6, atol=1e-6)
 
 
-def test_tree_attention_vs_dense_reference():
-    """Random trie: every node attends to its ancestor chain; compare with per-node dense softmax in torch."""
+@pytest.mark.parametrize("U,H,D,max_depth", [(300, 3, 16, None), (300, 12, 64, 9), (400, 20, 64, 15), (300, 5, 32, 16)])
+def test_tree_attention_vs_dense_reference(U, H, D, max_depth):
+    """Random trie: every node attends to its ancestor chain; compare with per-node dense softmax in torch.
+    ``max_depth`` < 16 exercises the short-chain kernel (chains in registers), None / 16 the general one."""
     import numpy as np
-    rng = np.random.default_rng(11)
-    U, H, D = 300, 3, 16
-    parent = [-1] + [int(rng.integers(max(0, u - 40), u)) for u in range(1, U)]
+    rng = np.random.default_rng(11 + U + H)
+    parent = [-1]
+    dep = [0]
+    for u in range(1, U):
+        cands = [c for c in range(max(0, u - 40), u) if max_depth is None or dep[c] < max_depth] or [0]
+        p_ = cands[int(rng.integers(0, len(cands)))]
+        parent.append(p_)
+        dep.append(dep[p_] + 1)
     depth, anc = [], []
     for u in range(U):
         chain = [u]
