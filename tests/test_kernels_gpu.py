@@ -219,7 +219,7 @@ def test_quick_gelu_vs_torch():
 @pytest.mark.parametrize("U,H,D,max_depth", [(300, 3, 16, None), (300, 12, 64, 9), (400, 20, 64, 15), (300, 5, 32, 16)])
 def test_tree_attention_vs_dense_reference(U, H, D, max_depth):
     """Random trie: every node attends to its ancestor chain; compare with per-node dense softmax in torch.
-    ``max_depth`` < 16 exercises the short-chain kernel (chains in registers), None / 16 the general one."""
+    Short chains (mass-edit prompts) and long ones, CLIP-L and bigG head shapes."""
     import numpy as np
     rng = np.random.default_rng(11 + U + H)
     parent = [-1]
