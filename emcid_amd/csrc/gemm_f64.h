@@ -116,6 +116,9 @@ struct GemmShape {
     int lower_only;  // skip output tiles that lie entirely above the diagonal (SYRK / Cholesky updates)
     int64_t sA = 0, sB = 0;  // element strides between the problems of a batch (blockIdx.z)
     int batch = 1;
+    // an outer batch dimension on top (e.g. matrices x diagonal blocks): problem (b1, b2), b1 < batch, b2 < batch2
+    int64_t sA2 = 0, sB2 = 0;
+    int batch2 = 1;
     // triangular operands (inverted diagonal blocks, explicit inverse factors), bit mask:
     //   1 = B(k, n) is zero for k > n,  2 = B(k, n) zero for k < n,  4 = A(m, k) zero for k > m,  8 = A(m, k) zero for k < m.
     // The K loop of an output tile then only covers the k range that can contribute; tiles are issued heaviest first.
@@ -223,9 +226,11 @@ __device__ __forceinline__ void gemm_f64_tile(const GemmShape& p, const Epi& epi
 template <bool KCA, bool KCB, int BM, int BN, int BK, int WGM, int WGN, class Epi>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Epi epi) {
     const int zb = blockIdx.z / p.ksplit, zs = blockIdx.z % p.ksplit;
-    p.A += (int64_t)zb * p.sA;
-    p.B += (int64_t)zb * p.sB;
-    epi.batch(zb);
+    const int z1 = zb % p.batch, z2 = zb / p.batch;
+    p.A += (int64_t)z1 * p.sA + (int64_t)z2 * p.sA2;
+    p.B += (int64_t)z1 * p.sB + (int64_t)z2 * p.sB2;
+    epi.batch(z1);
+    epi.batch2(z2);
     using TA = OpTile<KCA, BM, BK>;
     using TB = OpTile<KCB, BN, BK>;
     __shared__ __attribute__((aligned(16))) double smem[2 * (TA::SIZE + TB::SIZE)];
@@ -252,8 +257,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Ep
 
 // C = alpha * D + beta * C
 struct EpiAxpby {
-    double* C; int64_t ldc; double alpha, beta; int64_t sC = 0; int atomic = 0;
+    double* C; int64_t ldc; double alpha, beta; int64_t sC = 0; int atomic = 0; int64_t sC2 = 0;
     __device__ __forceinline__ void batch(int z) { C += (int64_t)z * sC; }
+    __device__ __forceinline__ void batch2(int z) { C += (int64_t)z * sC2; }
     __device__ __forceinline__ void operator()(int m, int n, double v) const {
         double* c = C + (int64_t)m * ldc + n;
         if (atomic) unsafeAtomicAdd(c, alpha * v);   // split-K partial of C += alpha * D (global_atomic_add_f64)
@@ -266,6 +272,7 @@ struct EpiAxpby {
 struct EpiAssemble {
     const float* Cf; int64_t ldcf; double lam; float cw; double* A; int64_t lda; int d;
     __device__ __forceinline__ void batch(int) {}
+    __device__ __forceinline__ void batch2(int) {}
     __device__ __forceinline__ void operator()(int m, int n, double v) const {
         double out;
         if (m < d && n < d) {
@@ -284,6 +291,7 @@ struct EpiAssemble {
 struct EpiDeltaW {
     const float* W0; float* W; int64_t ldw; float* dW; int64_t lddw; double* U; int64_t ldu;
     __device__ __forceinline__ void batch(int) {}
+    __device__ __forceinline__ void batch2(int) {}
     __device__ __forceinline__ void operator()(int m, int n, double v) const {
         const float f = (float)v;
         if (U) U[(int64_t)m * ldu + n] = v;
@@ -308,7 +316,7 @@ inline void launch_gemm_f64(GemmShape p, Epi epi, hipStream_t stream, int force_
         const int64_t tm = (p.M + bm - 1) / bm, tn = (p.N + bn - 1) / bn;
         const int64_t sq = tn * bn < tm * bm ? tn * bn : tm * bm;          // edge of the square part on the diagonal
         const int64_t skipped = p.lower_only ? (sq / bm) * (sq / bn) / 2 : 0;
-        return (tm * tn - skipped) * p.batch;
+        return (tm * tn - skipped) * p.batch * p.batch2;
     };
     const int64_t big_tiles = tiles(128, 128), mid_tiles = tiles(64, 64);
     // measured on the M ~ 1000 solve shapes (scripts/mb_shapes.py): 32x64 beats 64x64 whenever 128x128 cannot fill the chip
@@ -332,7 +340,7 @@ inline void launch_gemm_f64(GemmShape p, Epi epi, hipStream_t stream, int force_
         if (p.ksplit == 1) p.kchunk = 0;
     }
     if (p.ksplit > 1) epi_set_atomic(epi);
-    const unsigned gz = (unsigned)(p.batch * p.ksplit);
+    const unsigned gz = (unsigned)(p.batch * p.batch2 * p.ksplit);
     if (p.pair && (p.tri == 0 || p.lower_only)) p.pair = 0;
     const bool pair_n = p.pair && (p.tri & 3), pair_m = p.pair && !(p.tri & 3);
     auto half = [](unsigned n, bool h) { return h ? (n + 1) / 2 : n; };

@@ -508,14 +508,21 @@ static inline const double* inv_block(const double* invw, int64_t J) { return in
 
 // Completes inv(L_JJ) for every OB x OB diagonal block from the leaf's 128 x 128 inverses, two levels of
 //   inv([[A,0],[C,B]]) = [[A^-1, 0], [-B^-1 C A^-1, B^-1]]      (batched over the blocks)
-static void build_block_inverses(const double* L, int64_t dp, int64_t lda, double* invw, hipStream_t st) {
+static void build_block_inverses(const double* L, int64_t dp, int64_t lda, double* invw, hipStream_t st, int nmat = 1,
+                                 int64_t s_mat = 0, int64_t s_inv = 0) {
+    // nmat matrices (strides s_mat for L, s_inv for their inverse workspaces) share every launch: the products are
+    // batched over the diagonal blocks AND over the matrices (GemmShape.batch2)
     const int64_t nob = (dp + OB - 1) / OB, nfull = dp / OB, rem = dp % OB;
     double* tmp = invw + nob * (int64_t)OB * OB;
-    auto product = [&](const double* A, int64_t ldA, int64_t sA, bool b_lower, const double* B, int64_t ldB, int64_t sB,
-                       double* C, int64_t ldC, int64_t sC, int M, int N, int K, double alpha, int cnt) {
+    auto product = [&](const double* A, int64_t ldA, int64_t sA, int64_t sA2, bool b_lower, const double* B, int64_t ldB,
+                       int64_t sB, int64_t sB2, double* C, int64_t ldC, int64_t sC, int64_t sC2, int M, int N, int K,
+                       double alpha, int cnt) {
         GemmShape p{A, ldA, B, ldB, M, N, K, 0, sA, sB, cnt};
+        p.sA2 = sA2; p.sB2 = sB2; p.batch2 = nmat;
         p.tri = b_lower ? 2 : 0;   // B stored [k][n] and lower triangular: zero for k < n
-        launch_gemm_f64<true, false>(p, EpiAxpby{C, ldC, alpha, 0.0, sC}, st, 1);
+        EpiAxpby e{C, ldC, alpha, 0.0, sC};
+        e.sC2 = sC2;
+        launch_gemm_f64<true, false>(p, e, st, 1);
     };
     ScopedProf sp(KC_INV_BLOCK, st);
     const int64_t sI = (int64_t)OB * OB, sT = (int64_t)TB * TB, sL = (int64_t)OB * lda + OB;
@@ -527,8 +534,8 @@ static void build_block_inverses(const double* L, int64_t dp, int64_t lda, doubl
             double* Bi = inv_block(invw, J0) + ((2 * u + 1) * NB) * (int64_t)(OB + 1);
             double* X = inv_block(invw, J0) + ((2 * u + 1) * NB) * (int64_t)OB + 2 * u * NB;
             double* T = tmp + J0 * sT;
-            product(Cb, lda, sL, true, Ai, OB, sI, T, TB, sT, NB, NB, NB, 1.0, cnt);      // T = C A^-1
-            product(Bi, OB, sI, false, T, TB, sT, X, OB, sI, NB, NB, NB, -1.0, cnt);      // X = -B^-1 T
+            product(Cb, lda, sL, s_mat, true, Ai, OB, sI, s_inv, T, TB, sT, s_inv, NB, NB, NB, 1.0, cnt);      // T = C A^-1
+            product(Bi, OB, sI, s_inv, false, T, TB, sT, s_inv, X, OB, sI, s_inv, NB, NB, NB, -1.0, cnt);      // X = -B^-1 T
         };
         if (nfull > 0) level_a(0, (int)nfull);
         if (rem >= (u + 1) * 2 * NB) level_a(nfull, 1);
@@ -540,8 +547,8 @@ static void build_block_inverses(const double* L, int64_t dp, int64_t lda, doubl
         double* Bi = inv_block(invw, J0) + (2 * NB) * (int64_t)(OB + 1);
         double* X = inv_block(invw, J0) + (2 * NB) * (int64_t)OB;
         double* T = tmp + J0 * sT;
-        product(Cb, lda, sL, true, Ai, OB, sI, T, TB, sT, mrows, 2 * NB, 2 * NB, 1.0, cnt);
-        product(Bi, OB, sI, false, T, TB, sT, X, OB, sI, mrows, 2 * NB, mrows, -1.0, cnt);
+        product(Cb, lda, sL, s_mat, true, Ai, OB, sI, s_inv, T, TB, sT, s_inv, mrows, 2 * NB, 2 * NB, 1.0, cnt);
+        product(Bi, OB, sI, s_inv, false, T, TB, sT, s_inv, X, OB, sI, s_inv, mrows, 2 * NB, mrows, -1.0, cnt);
     };
     if (nfull > 0) level_b(0, (int)nfull, 2 * NB);
     if (rem > 2 * NB) level_b(nfull, 1, (int)(rem - 2 * NB));
@@ -608,7 +615,7 @@ static int cholesky_serial(double* A, double* L, int64_t dp, int64_t lda, double
             }
         }
     }
-    for (int b = 0; b < nbatch; ++b) build_block_inverses(L + b * s_mat, dp, lda, invw + b * s_inv, st);
+    build_block_inverses(L, dp, lda, invw, st, nbatch, s_mat, s_inv);
     return check_launch("emcid_cholesky_f64");
 }
 
