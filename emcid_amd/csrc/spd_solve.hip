@@ -5,6 +5,8 @@
 // Everything dense runs through gemm_f64.h (v_mfma_f64_16x16x4_f64).  The Cholesky is right-looking
 // with NB = 128: a single-workgroup LDS leaf factors the diagonal block and inverts it, so the panel
 // solve and every later triangular solve are MFMA GEMMs against the inverted diagonal blocks.
+#include <functional>
+
 #include "common.h"
 #include "gemm_f64.h"
 
@@ -714,34 +716,39 @@ static int build_full_inverse(const double* L, int64_t dp, int64_t lda, const do
     // (scripts/inverse_alone.py sweeps these)
     static const int cfg_a = env_flag("EMCID_INV_CFG_A", 2), cfg_b = env_flag("EMCID_INV_CFG_B", 2);
     static const int pair_ = env_flag("EMCID_INV_PAIR", 1);
-    struct Range { int b0, b1; };
-    // post-order over the halving tree, iteratively (depth <= log2(64))
-    Range stack[64];
-    bool expanded[64];
-    int sp_ = 0;
-    stack[sp_] = {0, nob}; expanded[sp_++] = false;
-    while (sp_ > 0) {
-        const Range r = stack[sp_ - 1];
-        if (r.b1 - r.b0 <= 1) { --sp_; continue; }
-        const int mid = r.b0 + (r.b1 - r.b0) / 2;
-        if (!expanded[sp_ - 1]) {
-            expanded[sp_ - 1] = true;
-            stack[sp_] = {r.b0, mid}; expanded[sp_++] = false;
-            stack[sp_] = {mid, r.b1}; expanded[sp_++] = false;
-            continue;
+    // Recursion over block ranges [b0, b1).  When the two halves of a range are the same problem (equal block counts, no
+    // short last block) they are solved ONCE with the copy count doubled: `reps` copies of the range sit `stride` blocks
+    // apart on the diagonal and share every launch through the GEMM's second batch dimension.
+    const bool regular = dp % OB == 0;
+    std::function<void(int, int, int, int)> rec = [&](int b0, int b1, int reps, int stride) {
+        const int n = b1 - b0;
+        if (n <= 1) return;
+        const int mid = b0 + n / 2, left = mid - b0, right = b1 - mid;
+        if (regular && left == right && (reps == 1 || stride == 2 * left)) {
+            rec(b0, mid, reps * 2, left);
+        } else {
+            rec(b0, mid, reps, stride);
+            rec(mid, b1, reps, stride);
         }
-        --sp_;
-        const int64_t r0 = (int64_t)r.b0 * OB, rm = (int64_t)mid * OB, r1 = (int64_t)r.b1 * OB < dp ? (int64_t)r.b1 * OB : dp;
-        const int m = (int)(r1 - rm), n = (int)(rm - r0);
-        GemmShape a{L + rm * lda + r0, lda, X + r0 * lda + r0, lda, m, n, n, 0, s_mat, s_mat, nbatch};
+        const int64_t r0 = (int64_t)b0 * OB, rm = (int64_t)mid * OB, r1 = (int64_t)b1 * OB < dp ? (int64_t)b1 * OB : dp;
+        const int m = (int)(r1 - rm), nn = (int)(rm - r0);
+        const int64_t hop = (int64_t)stride * OB * (lda + 1), thop = (int64_t)m * lda;      // between copies: diagonal / scratch
+        GemmShape a{L + rm * lda + r0, lda, X + r0 * lda + r0, lda, m, nn, nn, 0, s_mat, s_mat, nbatch};
+        a.sA2 = hop; a.sB2 = hop; a.batch2 = reps;
         a.tri = 2;   // B(k, n) = X11[k][n], zero for k < n
         a.pair = pair_;
-        launch_gemm_f64<true, false>(a, EpiAxpby{T, lda, 1.0, 0.0, s_mat}, st, cfg_a);
-        GemmShape b{X + rm * lda + rm, lda, T, lda, m, n, m, 0, s_mat, s_mat, nbatch};
+        EpiAxpby ea{T, lda, 1.0, 0.0, s_mat};
+        ea.sC2 = thop;
+        launch_gemm_f64<true, false>(a, ea, st, cfg_a);
+        GemmShape b{X + rm * lda + rm, lda, T, lda, m, nn, m, 0, s_mat, s_mat, nbatch};
+        b.sA2 = hop; b.sB2 = thop; b.batch2 = reps;
         b.tri = 4;   // A(m, k) = X22[m][k], zero for k > m
         b.pair = pair_;
-        launch_gemm_f64<true, false>(b, EpiAxpby{X + rm * lda + r0, lda, -1.0, 0.0, s_mat}, st, cfg_b);
-    }
+        EpiAxpby eb{X + rm * lda + r0, lda, -1.0, 0.0, s_mat};
+        eb.sC2 = hop;
+        launch_gemm_f64<true, false>(b, eb, st, cfg_b);
+    };
+    rec(0, nob, 1, 0);
     return check_launch("build_full_inverse");
 }
 
