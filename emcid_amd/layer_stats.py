@@ -89,13 +89,14 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
     # (layer_stats.py:196-206) — but the captions are tokenized with ONE batched tokenizer call up front instead of
     # one ``encode`` per item inside DataLoader workers (the pass was host-bound on that: 62k -> tokens/s).
     sample = list(make_sampler(ds, sample_size=sample_size, random_sample=1, shard=shard))
-    all_ids = tokenizer([ds.data[i] for i in sample], truncation=True, max_length=ds.maxlen)["input_ids"] if sample else []
-
     pool = max(batch_size, (device_batch_tokens // 16) // batch_size * batch_size)   # captions pooled per collation
 
     def groups():
-        for g in range(0, len(all_ids), pool):
-            yield collate_token_lists(all_ids[g:g + pool], max(batch_tokens, device_batch_tokens))
+        # tokenized pool by pool, inside the loop: the GPU works on pool i (launches are asynchronous) while the host
+        # tokenizes pool i+1 — tokenizing all captions up front kept the GPU idle for the first ~2.5 s of a 100k-caption job
+        for g in range(0, len(sample), pool):
+            ids = tokenizer([ds.data[i] for i in sample[g:g + pool]], truncation=True, max_length=ds.maxlen)["input_ids"]
+            yield collate_token_lists(ids, max(batch_tokens, device_batch_tokens))
 
     loader = groups()
     # forward order of the hooked modules decides which one is "deepest" (the one that stops the pass)
@@ -111,7 +112,7 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
             if ln == deepest:
                 raise StopForward()
         handles.append(mods[ln].register_forward_hook(hook))
-    n_groups = -(-len(all_ids) // pool)
+    n_groups = -(-len(sample) // pool)
     wrap = progress if progress is not None else (lambda it, total=None: it)
     try:
         with torch.no_grad(), hip_attention(model):
