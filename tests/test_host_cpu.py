@@ -254,3 +254,27 @@ def test_cross_attn_host_side(tmp_path):
     hp = EMCIDHyperParams(**syn.sd_hparams_dict(mom2_n_samples=1000))
     with pytest.raises(EmcidHipError):
         em.apply_emcid_to_cross_attn(pipe, reqs, hp, "cpu", cache_name=cache, stats_dir=str(tmp_path / "s"), verbose=False)
+
+
+def test_instruction_driver_host_side(tmp_path):
+    """run_emcid.load_instruction on the reference's own instruction + hparams files (config-1 fixture): hparams class,
+    set_weights overrides (emcid_test.py:924-930), cache prefix, rejection of an unknown checkpoint."""
+    from conftest import load_golden
+    from emcid_amd import run_emcid
+    z, meta = load_golden("config1_van_gogh")
+    ins, hp_file = meta["instruction"], meta["hparams_file"]
+    (tmp_path / "hparams").mkdir()
+    json.dump(hp_file, open(tmp_path / "hparams" / f"{ins['hparams']}.json", "w"))
+    json.dump(ins, open(tmp_path / "ins.json", "w"))
+    got, hp, cache = run_emcid.load_instruction(tmp_path / "ins.json", tmp_path / "hparams")
+    assert isinstance(hp, EMCIDHyperParams) and not isinstance(hp, EMCIDXLHyperParams)
+    assert hp.mom2_update_weight == ins["mom2_weight"] == 4000 and hp.edit_weight == ins["edit_weight"]
+    assert hp_file["mom2_update_weight"] == 10000                       # the file's own value is overridden
+    assert hp.layers == [7, 8, 9, 10] and cache == f"cache/{ins['hparams']}/"
+    assert got["requests"][0]["source"] == "Vincent van Gogh"
+    bad = dict(ins, model_ckpt="sd-v9")
+    json.dump(bad, open(tmp_path / "bad.json", "w"))
+    with pytest.raises(ValueError):
+        run_emcid.load_instruction(tmp_path / "bad.json", tmp_path / "hparams")
+    hp2 = run_emcid.set_weights(EMCIDHyperParams(**syn.sd_hparams_dict()), None, 0.7)
+    assert hp2.mom2_update_weight == 4000 and hp2.edit_weight == 0.7
