@@ -257,10 +257,14 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                         fac_done[nxt].record(plan.side_stream)
 
                 ahead = lazy and max(first_x, 1) <= i + 1 < L
+                # Sharded runs: every rank already holds all N key rows (the K all-gather above), and the M-solve of all
+                # of them is one 0.23 ms GEMM — cheaper than solving N/G rows and all-gathering Yt (N x d fp64, 25 MB)
+                # over xGMI, and one collective less per layer.  EMCID_SHARD_MSOLVE=1 restores the row-sharded solve.
+                split = sharded and os.environ.get("EMCID_SHARD_MSOLVE", "0") == "1"
                 res = hip.edit_layer_dual_apply(
                     K, Zc, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, backups[layer], weights[layer].data,
-                    ws=plan.dual_ws, rows=plan.shard.bounds(plan.n_total) if sharded else None,
-                    gather_yt=(lambda rows_: _all_gather_rows(rows_.contiguous(), plan)) if sharded else None,
+                    ws=plan.dual_ws, rows=plan.shard.bounds(plan.n_total) if split else None,
+                    gather_yt=(lambda rows_: _all_gather_rows(rows_.contiguous(), plan)) if split else None,
                     on_factor_start=lazy_inverse if ahead else None)
                 edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], None, None,
                                        K if trace else None, Zc if trace else None))
