@@ -239,9 +239,10 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
         plan.ws.info.zero_()
 
     def solve(i, layer, K_local, Zc_local):
-        """All-gather the shard's K/Zc rows, run the closed form, leave W0 + dW in the live weight."""
+        """All-gather the shard's K/Zc rows, run the closed form, leave W0 + dW in the live weight.  ``Zc_local`` may be
+        a callable K -> Zc (fc2 applied to the gathered keys): then only K crosses the links."""
         K = _all_gather_rows(K_local, plan)
-        Zc = _all_gather_rows(Zc_local, plan)
+        Zc = Zc_local(K) if callable(Zc_local) else _all_gather_rows(Zc_local, plan)
         if dual:
             torch.cuda.current_stream(dev).wait_event(fac_done[i])
             sharded = plan.shard.world > 1
@@ -314,7 +315,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                 return None if li == last else F.linear(x, m.weight, m.bias)
             # fc2 is affine, so the mean over a request's prompts of its output at the lookup rows IS fc2 of the mean
             # key: Zc = K W^T + b on N rows (to fp32 rounding) instead of fc2 over every node followed by a gather
-            solve(order[li], li, K_loc, F.linear(K_loc, m.weight, m.bias))
+            solve(order[li], li, K_loc, lambda K_all: F.linear(K_all, m.weight, m.bias))
             if li == last:
                 return None
             return F.linear(x, m.weight, m.bias)
