@@ -24,7 +24,6 @@ ALGORITHMIC flops per launch (SURVEY.md §8d counts); `kernel_classes` lists all
 import argparse
 import json
 import os
-import shutil
 import sys
 import tempfile
 import time
