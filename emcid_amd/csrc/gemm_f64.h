@@ -137,7 +137,8 @@ struct GemmShape {
 // WGM x WGN waves per workgroup; each wave owns a (BM/WGM) x (BN/WGN) sub-tile.
 // One output tile (bm, bn), K tiles restricted by `tri`, split zs of the K range.
 template <bool KCA, bool KCB, int BM, int BN, int BK, int WGM, int WGN, class Epi>
-__device__ __forceinline__ void gemm_f64_tile(const GemmShape& p, const Epi& epi, int bm, int bn, int zs, double* smem) {
+__device__ __forceinline__ void gemm_f64_tile(const GemmShape& p, const Epi& epi, int bm, int bn, int zs, double* smem,
+                                              int kt_begin = -1, int kt_end = -1) {
     constexpr int NT = WGM * WGN * 64;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 16, NI = WN / 16;
@@ -164,7 +165,11 @@ __device__ __forceinline__ void gemm_f64_tile(const GemmShape& p, const Epi& epi
     if (p.tri & 2) t0 = max(t0, min(n0, p.K) / BK);
     if (p.tri & 4) t1 = min(t1, (min(p.K, m0 + BM) + BK - 1) / BK);
     if (p.tri & 8) t0 = max(t0, min(m0, p.K) / BK);
-    if (p.kchunk > 0) {
+    if (kt_begin >= 0) {              // an explicit run [kt_begin, kt_end) of this tile's own K tiles (stream-K caller)
+        t1 = min(t1, t0 + kt_end);
+        t0 += kt_begin;
+        if (t0 >= t1) return;
+    } else if (p.kchunk > 0) {
         t0 += zs * p.kchunk;
         t1 = min(t1, t0 + p.kchunk);
         if (t0 >= t1) return;
@@ -299,6 +304,72 @@ struct EpiDeltaW {
         if (W) W[(int64_t)m * ldw + n] = W0[(int64_t)m * ldw + n] + f;
     }
 };
+
+// ---- stream-K for triangular contractions -------------------------------------------------------------------------
+// With a triangular operand the K depth of an output tile grows linearly along one tile dimension, so "one tile per
+// workgroup" leaves the chip waiting for the deepest tiles, and small tiles (for balance) give up the efficiency of the
+// 128x128 configuration.  Here the (tile, K-step) space is linearised — column tile major, 16-deep K steps — and cut into
+// equal runs, one per workgroup: a run covers the tail of one tile, some whole tiles, the head of another.  Whole tiles
+// are stored directly; the two partial ones are added with f64 atomics into C, which the caller zeroes first.  No
+// workgroup waits for another.  Only B-side triangles (tri = 1 or 2) and the f64 EpiAxpby epilogue.
+__device__ __forceinline__ int streamk_depth(const GemmShape& p, int bn, int BN, int BK) {
+    const int KT = (p.K + BK - 1) / BK;
+    if (p.tri & 1) return min(KT, (min(p.K, (bn + 1) * BN) + BK - 1) / BK);
+    if (p.tri & 2) return KT - min(bn * BN, p.K) / BK;
+    return KT;
+}
+
+template <bool KCA, bool KCB, int BM, int BN, int BK, int WGM, int WGN>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_streamk_kernel(GemmShape p, EpiAxpby epi, long long total_units,
+                                                                           long long units_per_wg) {
+    using TA = OpTile<KCA, BM, BK>;
+    using TB = OpTile<KCB, BN, BK>;
+    __shared__ __attribute__((aligned(16))) double smem[2 * (TA::SIZE + TB::SIZE)];
+    const int MT = (p.M + BM - 1) / BM, NTL = (p.N + BN - 1) / BN;
+    long long u = (long long)blockIdx.x * units_per_wg;
+    const long long u1 = min(total_units, u + units_per_wg);
+    // locate the column tile of unit u: prefix sums of MT * depth(bn)
+    int bn = 0;
+    long long base = 0;     // first unit of column tile bn
+    while (bn < NTL) {
+        const long long span = (long long)MT * streamk_depth(p, bn, BN, BK);
+        if (u < base + span) break;
+        base += span;
+        ++bn;
+    }
+    while (u < u1 && bn < NTL) {
+        const int depth = streamk_depth(p, bn, BN, BK);
+        const long long span = (long long)MT * depth;
+        if (depth == 0 || u >= base + span) { base += span; ++bn; continue; }
+        const int bm = (int)((u - base) / depth);
+        const int k_begin = (int)((u - base) % depth);
+        const int k_end = (int)min((long long)depth, k_begin + (u1 - u));
+        EpiAxpby e = epi;
+        e.atomic = (k_begin != 0 || k_end != depth) ? 1 : 0;
+        gemm_f64_tile<KCA, KCB, BM, BN, BK, WGM, WGN>(p, e, bm, bn, 0, smem, k_begin, k_end);
+        u += k_end - k_begin;
+    }
+}
+
+// C must be zero on entry (partial tiles accumulate atomically); alpha is applied, beta is ignored.
+template <bool KCA, bool KCB>
+inline void launch_gemm_f64_streamk(GemmShape p, EpiAxpby epi, hipStream_t stream, int wgs) {
+    constexpr int BM = 128, BN = 128, BK = 16;
+    const int MT = (p.M + BM - 1) / BM, NTL = (p.N + BN - 1) / BN, KT = (p.K + BK - 1) / BK;
+    long long total = 0;
+    for (int bn = 0; bn < NTL; ++bn) {
+        int depth = KT;
+        if (p.tri & 1) { const int ke = p.K < (bn + 1) * BN ? p.K : (bn + 1) * BN; depth = (ke + BK - 1) / BK; if (depth > KT) depth = KT; }
+        else if (p.tri & 2) { const int kb = bn * BN < p.K ? bn * BN : p.K; depth = KT - kb / BK; }
+        total += (long long)MT * depth;
+    }
+    if (total <= 0) return;
+    long long per = (total + wgs - 1) / wgs;
+    if (per < 8) per = 8;                                   // never less than half a 128-deep step per workgroup
+    const unsigned grid = (unsigned)((total + per - 1) / per);
+    epi.beta = 0.0;
+    hipLaunchKernelGGL((gemm_f64_streamk_kernel<KCA, KCB, BM, BN, BK, 2, 4>), dim3(grid), dim3(512), 0, stream, p, epi, total, per);
+}
 
 // ---- launcher ----------------------------------------------------------------------------------
 

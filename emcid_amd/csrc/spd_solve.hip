@@ -752,24 +752,29 @@ static int build_full_inverse(const double* L, int64_t dp, int64_t lda, const do
     return check_launch("build_full_inverse");
 }
 
+// Both GEMMs against X contract over a triangular K range; they run as stream-K over 128x128 tiles (gemm_f64.h): the
+// (tile, K-step) space cut into 256 equal runs, whole tiles stored, the two partial tiles of a run added atomically
+// into a zeroed output.  Measured for 1024 x 3072 x 3072: 218 us (zeroing included) against 253 us for mirrored 32x64
+// tile pairs and 306 us for plain 64x64 tiles; 768 rows: 188 / 238 / 299 us (scripts/mb_tri.py).
+static const int kStreamKWgs = 256;
+
 // Yt[rows, dp] = Kt[rows, dp] * X^T  (= Kt L^-T: the forward substitution as one GEMM)
 static void apply_inverse_forward(const double* X, int64_t dp, const double* Kt, double* Yt, int rows, hipStream_t st) {
     ScopedProf sp(KC_INV_APPLY, st);
     GemmShape g{Kt, dp, X, dp, rows, (int)dp, (int)dp, 0};
     g.tri = 1;       // B(k, n) = X[n][k], zero for k > n
-    g.pair = 1;      // column tile j and its mirror in one workgroup: equal contraction depth everywhere (measured
-                     // 230 us vs 278 us for 1024 x 3072 x 3072, scripts/mb_tri.py)
-    launch_gemm_f64<true, true>(g, EpiAxpby{Yt, dp, 1.0, 0.0}, st, 2);
+    hipLaunchKernelGGL(zero2d_f64_kernel, dim3((unsigned)rows, 1u), dim3(256), 0, st, Yt, dp, (int64_t)0, (int)dp);
+    launch_gemm_f64_streamk<true, true>(g, EpiAxpby{Yt, dp, 1.0, 0.0}, st, kStreamKWgs);
 }
 
-// C[rows, ncols] = V[rows, dp] * X  (= V L^-1: the backward substitution as one GEMM), through any epilogue
-template <class Epi>
-static void apply_inverse_backward(const double* X, int64_t dp, const double* V, int rows, int ncols, Epi epi, hipStream_t st) {
+// C[rows, ncols] (f64, leading dimension ldc) = V[rows, dp] * X  (= V L^-1: the backward substitution as one GEMM)
+static void apply_inverse_backward(const double* X, int64_t dp, const double* V, int rows, int ncols, double* C, int64_t ldc,
+                                   hipStream_t st) {
     ScopedProf sp(KC_INV_APPLY, st);
     GemmShape g{V, dp, X, dp, rows, ncols, (int)dp, 0};
     g.tri = 2;       // B(k, n) = X[k][n], zero for k < n
-    g.pair = 1;
-    launch_gemm_f64<true, false>(g, epi, st, 2);
+    hipLaunchKernelGGL(zero2d_f64_kernel, dim3((unsigned)rows, 1u), dim3(256), 0, st, C, ldc, (int64_t)0, ncols);
+    launch_gemm_f64_streamk<true, false>(g, EpiAxpby{C, ldc, 1.0, 0.0}, st, kStreamKWgs);
 }
 
 // layout of the covariance-factor workspace (emcid_factor_cov_f64): [M | L | 512-block inverses | X = inv(L)] x n_layers
@@ -1010,8 +1015,8 @@ int emcid_dgemm_ex_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double a
                        void* stream) {
     EMCID_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C);
     EMCID_CHECK_ARG(aligned16(A) && aligned16(B) && (lda % 2 == 0) && (ldb % 2 == 0));
-    EMCID_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30) && cfg >= -1 && cfg <= 2 && (flags & ~63) == 0);
-    EMCID_CHECK_ARG(ksplit == 0 || beta == 1.0);
+    EMCID_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30) && cfg >= -1 && cfg <= 4 && (flags & ~63) == 0);
+    EMCID_CHECK_ARG(ksplit == 0 || beta == 1.0 || cfg == 4);
     hipStream_t st = (hipStream_t)stream;
     GemmShape p{A, lda, B, ldb, (int)M, (int)N, (int)K, (flags >> 4) & 1};
     p.tri = flags & 15;
@@ -1020,6 +1025,14 @@ int emcid_dgemm_ex_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double a
     if (ksplit < 0) p.kchunk = -ksplit;
     EpiAxpby e{C, ldc, alpha, beta};
     ScopedProf sp(KC_DGEMM, st);
+    if (cfg == 4) {   // stream-K over a B-side triangle: ksplit = number of workgroups (0: 512); C is zeroed here
+        EMCID_CHECK_ARG(ta == 0 && (p.tri == 1 || p.tri == 2) && !p.lower_only);
+        hipLaunchKernelGGL(zero2d_f64_kernel, dim3((unsigned)M, 1u), dim3(256), 0, st, C, ldc, (int64_t)0, (int)N);
+        if (tb == 0) launch_gemm_f64_streamk<true, true>(p, e, st, ksplit > 0 ? ksplit : 512);
+        else launch_gemm_f64_streamk<true, false>(p, e, st, ksplit > 0 ? ksplit : 512);
+        EMCID_CHECK_LAUNCH();
+        return EMCID_OK;
+    }
     if (ta == 0 && tb == 0) launch_gemm_f64<true, true>(p, e, st, cfg);
     else if (ta == 0 && tb == 1) launch_gemm_f64<true, false>(p, e, st, cfg);
     else if (ta == 1 && tb == 0) launch_gemm_f64<false, true>(p, e, st, cfg);
@@ -1243,7 +1256,7 @@ int emcid_edit_dual_stage1_f64(const float* K, const float* Zc, const float* zs_
         // Pt = (Kt X^T) X : both triangular solves against M = L L^T are GEMMs against the explicit X = inv(L)
         const double* Xb = cov_inverse(cov_factor_ws, n_layers, dp, layer_index);
         apply_inverse_forward(Xb, dp, Kt + n_lo * dp, Y + n_lo * dp, (int)rows, st);
-        apply_inverse_backward(Xb, dp, Y + n_lo * dp, (int)rows, (int)dp, EpiAxpby{Pt + n_lo * dp, dp, 1.0, 0.0}, st);
+        apply_inverse_backward(Xb, dp, Y + n_lo * dp, (int)rows, (int)dp, Pt + n_lo * dp, dp, st);
         EMCID_CHECK_LAUNCH();
         return EMCID_OK;
     }
@@ -1387,11 +1400,9 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
         if (!use_inverse) trsm_backward(Lb, dp, dp, Ib, V, U, (int)h, dp, q);   // U L = V by block substitution
         return check_launch("emcid_edit_dual_apply_stage2_f64");
     }));
-    if (use_inverse)   // U = V inv(L), straight into W = W0 + float(U)  (V's padding columns are zero: Kt's are, X is I there)
-        apply_inverse_backward(cov_inverse(cov_factor_ws, n_layers, dp, layer_index), dp, V, (int)h, (int)d,
-                               EpiDeltaW{W0, W, d, dW_out, d, nullptr, d}, st);
-    else
-        hipLaunchKernelGGL(apply_u2d_kernel, dim3((unsigned)h), dim3(256), 0, st, U, dp, W0, W, dW_out, (int)d);
+    if (use_inverse)   // U = V inv(L)  (V's padding columns are zero: Kt's are, X is the identity there)
+        apply_inverse_backward(cov_inverse(cov_factor_ws, n_layers, dp, layer_index), dp, V, (int)h, (int)dp, U, dp, st);
+    hipLaunchKernelGGL(apply_u2d_kernel, dim3((unsigned)h), dim3(256), 0, st, U, dp, W0, W, dW_out, (int)d);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }

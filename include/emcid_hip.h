@@ -217,7 +217,8 @@ int emcid_dgemm_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alph
  * flags bits 0-3 = triangular operands (1: B(k,n)=0 for k>n, 2: B(k,n)=0 for k<n, 4: A(m,k)=0 for k>m, 8: A(m,k)=0 for
  * k<m), bit 4 = compute only output tiles that touch the lower triangle, bit 5 = pair mirrored tiles of the triangular
  * dimension in one workgroup; cfg: -1 auto, 0 = 128x128, 1 = 64x64,
- * 2 = 32x64 tiles; ksplit: 0 auto, n > 0 = even n-way split of K, n < 0 = fixed runs of |n| K-tiles (16 deep) per
+ * 2 = 32x64 tiles, 4 = stream-K over 128x128 tiles (B-side triangle only; C is zeroed by the call, ksplit = number of
+ * workgroups, 0 = 512); ksplit: 0 auto, n > 0 = even n-way split of K, n < 0 = fixed runs of |n| K-tiles (16 deep) per
  * workgroup; splits need beta == 1 (partials are added with f64 atomics). */
 int emcid_dgemm_ex_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
                        const double* A, int64_t lda, const double* B, int64_t ldb,

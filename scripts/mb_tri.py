@@ -16,20 +16,12 @@ shapes = [
 for name, ta, tb, M, B, tri, flops in shapes:
     A = torch.randn(M, d, dtype=torch.float64, device=dev)
     ref = A @ (B.t() if tb == 0 else B)
-    for cfg in (0, 1, 2):
-        for ks in (0, 100, -16, -32):
-            pair = ks == 100
-            if pair:
-                ks = 0
-            C = torch.zeros(M, d, dtype=torch.float64, device=dev)
-            beta = 0.0 if ks == 0 else 1.0
-            tri_ = tri | (32 if pair else 0)
-            hip.dgemm_ex(ta, tb, A, B, C, beta=beta, flags=tri_, cfg=cfg, ksplit=ks)
-            err = float((C - ref).abs().max() / ref.abs().max())
-            def run():
-                if ks != 0:
-                    C.zero_()
-                hip.dgemm_ex(ta, tb, A, B, C, beta=beta, flags=tri_, cfg=cfg, ksplit=ks)
-            dt = timeit(run, iters=20, warmup=3)
-            print(json.dumps({"shape": name, "cfg": cfg, "pair": pair, "ksplit": ks, "us": round(dt * 1e6, 1),
-                              "tflops_tri": round(flops / dt / 1e12, 1), "err": err}))
+    variants = [("cfg1", dict(flags=tri, cfg=1)), ("cfg2 pair", dict(flags=tri | 32, cfg=2)),
+                ("streamK 256", dict(flags=tri, cfg=4, ksplit=256)), ("streamK 512", dict(flags=tri, cfg=4, ksplit=512)),
+                ("streamK 384", dict(flags=tri, cfg=4, ksplit=384)), ("streamK 768", dict(flags=tri, cfg=4, ksplit=768))]
+    for label, kw in variants:
+        C = torch.zeros(M, d, dtype=torch.float64, device=dev)
+        hip.dgemm_ex(ta, tb, A, B, C, beta=0.0, **kw)
+        err = float((C - ref).abs().max() / ref.abs().max())
+        dt = timeit(lambda: hip.dgemm_ex(ta, tb, A, B, C, beta=0.0, **kw), iters=20, warmup=3)
+        print(json.dumps({"shape": name, "variant": label, "us": round(dt * 1e6, 1), "tflops_tri": round(flops / dt / 1e12, 1), "err": err}))
