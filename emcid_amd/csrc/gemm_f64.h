@@ -328,6 +328,27 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_streamk_kernel(GemmSha
     const int MT = (p.M + BM - 1) / BM, NTL = (p.N + BN - 1) / BN;
     long long u = (long long)blockIdx.x * units_per_wg;
     const long long u1 = min(total_units, u + units_per_wg);
+    if (p.lower_only) {
+        // SYRK-like: the lower tiles (bn <= bm) of a square output, every tile the full K deep, numbered row by row;
+        // C holds a start value (the caller's), so every run ADDS its part
+        const int KT = (p.K + BK - 1) / BK;
+        GemmShape q = p;
+        q.lower_only = 0;
+        while (u < u1) {
+            const long long t = u / KT;
+            int bm = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+            while ((long long)(bm + 1) * (bm + 2) / 2 <= t) ++bm;
+            while ((long long)bm * (bm + 1) / 2 > t) --bm;
+            const int bn = (int)(t - (long long)bm * (bm + 1) / 2);
+            const int k_begin = (int)(u - t * KT);
+            const int k_end = (int)min((long long)KT, k_begin + (u1 - u));
+            EpiAxpby e = epi;
+            e.atomic = 1;
+            gemm_f64_tile<KCA, KCB, BM, BN, BK, WGM, WGN>(q, e, bm, bn, 0, smem, k_begin, k_end);
+            u += k_end - k_begin;
+        }
+        return;
+    }
     // locate the column tile of unit u: prefix sums of MT * depth(bn)
     int bn = 0;
     long long base = 0;     // first unit of column tile bn
@@ -352,12 +373,14 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_streamk_kernel(GemmSha
 }
 
 // C must be zero on entry (partial tiles accumulate atomically); alpha is applied, beta is ignored.
+// lower_only (M == N): every run adds into C, whose content on entry is the start value (e.g. the identity).
 template <bool KCA, bool KCB>
 inline void launch_gemm_f64_streamk(GemmShape p, EpiAxpby epi, hipStream_t stream, int wgs) {
     constexpr int BM = 128, BN = 128, BK = 16;
     const int MT = (p.M + BM - 1) / BM, NTL = (p.N + BN - 1) / BN, KT = (p.K + BK - 1) / BK;
     long long total = 0;
-    for (int bn = 0; bn < NTL; ++bn) {
+    if (p.lower_only) total = (long long)MT * (MT + 1) / 2 * KT;      // square output, lower tiles, full K
+    else for (int bn = 0; bn < NTL; ++bn) {
         int depth = KT;
         if (p.tri & 1) { const int ke = p.K < (bn + 1) * BN ? p.K : (bn + 1) * BN; depth = (ke + BK - 1) / BK; if (depth > KT) depth = KT; }
         else if (p.tri & 2) { const int kb = bn * BN < p.K ? bn * BN : p.K; depth = KT - kb / BK; }

@@ -897,6 +897,11 @@ static void assemble_dual_system(const double* P, const double* Q, int64_t dp, d
     ScopedProf sp(KC_ASSEMBLE, st);
     hipLaunchKernelGGL(eye_f64_kernel, dim3((unsigned)Np), dim3(256), 0, st, S, Np);
     GemmShape g{P, dp, Q, dp, Np, Np, (int)dp, 1};
+    static const int streamk = env_flag("EMCID_SYRK_STREAMK", 1);
+    if (streamk && Np >= 512) {   // lower 128x128 tiles x K cut into 256 equal runs, added atomically into the identity
+        launch_gemm_f64_streamk<true, true>(g, EpiAxpby{S, Np, 1.0, 1.0}, st, 256);
+        return;
+    }
     const int kt = (int)(dp / 16);
     g.ksplit = kt >= 64 ? 4 : kt >= 32 ? 2 : 1;
     launch_gemm_f64<true, true>(g, EpiAxpby{S, Np, 1.0, 1.0}, st, Np >= 512 ? 1 : 2);
