@@ -219,8 +219,8 @@ def main():
                  "trsm_update": "gemm_f64_kernel<KC,*,*,*,16,EpiAxpby> launched as rank-512 TRSM update",
                  "trsm_diag": "gemm_f64_kernel<KC,*,32,64,16,2,2,EpiAxpby> launched as TRSM diagonal-block multiply",
                  "delta_w": "gemm_f64_kernel<!KC,*,64,64,16,2,2,EpiDeltaW> (dW = R^T X)",
-                 "inv_apply": "gemm_f64_kernel<KC,*,*,64,16,2,2,*> launched as GEMM against the explicit inverse factor "
-                              "(Kt X^T, V X; triangular K range)",
+                 "inv_apply": "gemm_f64_streamk_kernel<KC,*,128,128,16,2,4> (+ zero2d_f64_kernel of its output): GEMM against the "
+                              "explicit inverse factor (Kt X^T, V X; triangular K range cut into 256 equal runs)",
                  "inv_build": "gemm_f64_kernel<KC,!KC,*,*,16,*> launched as recursive-halving build of X = inv(L)"}
         # HBM-side bytes per launch of that kernel come from separate `rocprofv3 --pmc` runs (FETCH_SIZE and WRITE_SIZE
         # cannot share a pass and neither can be collected from inside this process): scripts/pmc_inv_apply.py replays the
@@ -236,7 +236,7 @@ def main():
                             f"{rec['algorithmic_bytes_per_launch']} B")
         roofline = {"bound": "mfma", "kernel": names[top], "class": top, "achieved": achieved,
                     "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / F64_MFMA_PEAK_TFLOPS,
-                    "traffic": traffic, "traffic_note": traffic_note, "avg_launch_us": ms * 1e3 / launches, "launches": launches,
+                    "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_note": traffic_note, "avg_launch_us": ms * 1e3 / launches, "launches": launches,
                     "flops_per_launch": per_step_flops[top] * args.steps / launches,
                     "solver": "dual" if dual else "direct"}
 
