@@ -13,6 +13,7 @@ MI355X-first differences:
   with one all-reduce per layer at the end (RCCL over xGMI on the GPU box).
 """
 import argparse
+import os
 from pathlib import Path
 from typing import Dict, List, Optional, Sequence
 
@@ -56,7 +57,7 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
                                    sample_size=None, precision="float32", batch_tokens=3 * 1024, progress=tqdm,
                                    force_recompute=False, data_path=CCS_PATH, shard=None, group=None,
                                    num_workers=2, batch_size=100, device_batch_tokens=32768, feature: str = "input",
-                                   files: Optional[Dict[str, Path]] = None) -> Dict[str, CombinedStat]:
+                                   files: Optional[Dict[str, Path]] = None, forward: str = "auto") -> Dict[str, CombinedStat]:
     """All ``layer_names`` in ONE pass over the captions.  Returns {layer_name: CombinedStat} (on cpu).
 
     ``batch_tokens`` names the cache file like the reference (``_t3072_``) but the device batches are larger:
@@ -98,6 +99,12 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
             ids = tokenizer([ds.data[i] for i in sample[g:g + pool]], truncation=True, max_length=ds.maxlen)["input_ids"]
             yield collate_token_lists(ids, max(batch_tokens, device_batch_tokens))
 
+    packed = _packed_plan(model, todo, mods_of=None) if (forward in ("auto", "trie") and feature == "input") else None
+    if forward == "trie" and packed is None:
+        raise ValueError("forward='trie' needs a HF CLIP text encoder and fc2 layer names")
+    if packed is not None:
+        return _collect_packed(model, tokenizer, ds, sample, pool, packed, todo, stats, files, args, shard, group, device,
+                               progress, device_batch_tokens)
     loader = groups()
     # forward order of the hooked modules decides which one is "deepest" (the one that stops the pass)
     order = {name: i for i, (name, _) in enumerate(model.named_modules())}
@@ -132,6 +139,73 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
     finally:
         for h in handles:
             h.remove()
+    for ln in todo:
+        if shard is not None and shard[1] > 1:
+            stats[ln].all_reduce_(group)
+        stats[ln].to_(device="cpu")
+        if shard is None or shard[0] == 0:
+            save_cached_state(files[ln], stats[ln], args)
+    return stats
+
+
+LAST_RUN = {}   # bookkeeping of the most recent Stage-0 pass (rows actually pushed through the Gram kernel vs tokens they stand for)
+
+
+def _packed_plan(model, layer_names, mods_of=None):
+    """(graph, {layer_name: encoder layer index}) when every requested module is the fc2 of a layer of a HF CLIP text
+    model (then Stage 0 can run on the packed prefix trie), else None."""
+    from . import clip_forward
+    for tmpl in ("text_model.encoder.layers.{}", "encoder.layers.{}"):
+        try:
+            graph = clip_forward.discover(model, tmpl)
+        except clip_forward.UnsupportedEncoder:
+            continue
+        index = {}
+        for ln in layer_names:
+            mod = get_module(model, ln)
+            hit = [i for i, l in enumerate(graph.layers) if l.fc2 is mod]
+            if not hit:
+                return None
+            index[ln] = hit[0]
+        return graph, index
+    return None
+
+
+def _collect_packed(model, tokenizer, ds, sample, pool, packed, todo, stats, files, args, shard, group, device, progress,
+                    device_batch_tokens):
+    """Stage 0 on the packed prefix trie: the captions of a pool share their common prefixes ("<bos> a photo of ...") and
+    carry no padding; every DISTINCT prefix is a row, computed once and entered into the Gram scaled by the square root
+    of the number of captions that pass through it — sum_tokens x x^T exactly as the reference's attended-token sum
+    (causal encoder: a token's state depends on its prefix only), in fp32 up to summation order.  Same fixed sample,
+    same caption pools as the hooked forward."""
+    from . import clip_forward
+    graph, index = packed
+    deepest = max(index.values())
+    wanted = {i: [ln for ln in todo if index[ln] == i] for i in set(index.values())}
+    wrap = progress if progress is not None else (lambda it, total=None: it)
+    # larger pools than the hooked forward's: more shared prefixes per trie and longer GEMMs (rows ~ 0.8 x tokens);
+    # EMCID_STAGE0_POOL captions per pool (default 4 x the hooked pool, i.e. ~110 k tokens, ~1.4 GB of fc2 inputs)
+    pool = int(os.environ.get("EMCID_STAGE0_POOL", 4 * pool))
+    pools = range(0, len(sample), pool)
+    LAST_RUN.clear()
+    LAST_RUN.update(forward="packed-trie", tokens=0, rows=0)
+    with torch.no_grad():
+        for g in wrap(pools, total=len(pools)):
+            ids = tokenizer([ds.data[i] for i in sample[g:g + pool]], truncation=True, max_length=ds.maxlen)["input_ids"]
+            trie, cnt = clip_forward.build_trie_packed(ids, device)
+            n_real, tokens = trie.n_nodes, int(sum(len(s) for s in ids))
+            LAST_RUN["tokens"] += tokens
+            LAST_RUN["rows"] += n_real
+            root = cnt.sqrt().unsqueeze(1)
+
+            def on_fc2(i, x, out):
+                if i in wanted:
+                    feats = x[:n_real] * root
+                    for ln in wanted[i]:
+                        stats[ln].add(feats, count=tokens)
+                return None if i == deepest else out
+
+            clip_forward.run_layers(graph, trie, deepest, on_fc2, last_rows_only=False, fc2_by_callback={deepest})
     for ln in todo:
         if shard is not None and shard[1] > 1:
             stats[ln].all_reduce_(group)

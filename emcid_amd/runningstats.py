@@ -75,7 +75,9 @@ class SecondMoment(Stat):
             super().__init__(state)
 
     # -- accumulation --------------------------------------------------------------------------------
-    def add(self, a: torch.Tensor):
+    def add(self, a: torch.Tensor, count: Optional[int] = None):
+        """mom2 += a^T a; ``count`` (default: the rows of ``a``) is what the rows stand for — the packed Stage-0 forward
+        hands in each distinct prefix once, scaled by the square root of its multiplicity."""
         a = self._normalize_add_shape(a)
         if len(a) == 0:
             return
@@ -90,7 +92,7 @@ class SecondMoment(Stat):
             else:
                 self._lower = torch.zeros(d, d, dtype=torch.float32, device=a.device)
         self._full = None
-        self.count += a.shape[0]
+        self.count += a.shape[0] if count is None else int(count)
         if a.shape[0] >= self.stage_tokens:
             self.flush()
             hip.gram_accumulate_(self._lower, a.contiguous(), self.ksplit)

@@ -7,6 +7,7 @@ from pathlib import Path
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 from emcid_amd import hip, synthetic as syn
+from emcid_amd import layer_stats as ls
 from emcid_amd.layer_stats import layer_stats_text_encoder_multi
 
 ap = argparse.ArgumentParser()
@@ -35,11 +36,15 @@ prof = hip.profile_collect()
 hip.profile_enable([])
 tokens = stats[names[0]].mom2.count
 gram_ms, gram_launches = prof.get("gram", (0.0, 0))
-syrk_flops = float(tokens) * d * d * a.layers          # T d^2 per layer
+syrk_flops = float(tokens) * d * d * a.layers          # T d^2 per layer (algorithmic: what the job is worth)
+rows = ls.LAST_RUN.get("rows", tokens)                  # distinct prefixes actually pushed through the kernel (packed forward)
+exec_flops = float(rows) * d * d * a.layers
 print(json.dumps({
     "stage": 0, "captions": a.captions, "layers": a.layers, "tokens": tokens, "wall_s": wall,
     "tokens_per_s": tokens / wall, "layer_tokens_per_s": tokens * a.layers / wall,
     "gram_ms": gram_ms, "gram_launches": gram_launches, "gram_share_of_wall": gram_ms * 1e-3 / wall,
-    "gram_tflops": syrk_flops / (gram_ms * 1e-3) / 1e12 if gram_ms else None,
-    "gram_frac_f32_mfma_peak": syrk_flops / (gram_ms * 1e-3) / 157.3e12 if gram_ms else None,
+    "forward": ls.LAST_RUN.get("forward", "hooked-hf"), "gram_rows": rows,
+    "gram_tflops_algorithmic": syrk_flops / (gram_ms * 1e-3) / 1e12 if gram_ms else None,
+    "gram_tflops_executed": exec_flops / (gram_ms * 1e-3) / 1e12 if gram_ms else None,
+    "gram_frac_f32_mfma_peak": exec_flops / (gram_ms * 1e-3) / 157.3e12 if gram_ms else None,
     "workers": a.workers}))
