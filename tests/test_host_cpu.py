@@ -278,3 +278,42 @@ def test_instruction_driver_host_side(tmp_path):
         run_emcid.load_instruction(tmp_path / "bad.json", tmp_path / "hparams")
     hp2 = run_emcid.set_weights(EMCIDHyperParams(**syn.sd_hparams_dict()), None, 0.7)
     assert hp2.mom2_update_weight == 4000 and hp2.edit_weight == 0.7
+
+
+def _trie_prefix_multiset(trie, count=None):
+    tok = trie.token.numpy()
+    anc = trie.anc.numpy()
+    dep = trie.depth.numpy()
+    out = {}
+    for u in range(trie.n_nodes):
+        key = tuple(int(tok[a]) for a in anc[u, :dep[u] + 1])
+        assert key not in out, "a prefix appears as two nodes"
+        out[key] = 1 if count is None else int(count[u])
+    return out
+
+
+def test_packed_trie_is_the_prefix_multiset_of_the_captions():
+    """Stage 0's numpy level-wise trie: one node per distinct prefix, count = captions through it; same node set as the
+    edit path's Python trie when every last token is the lookup. Padding rows attend to themselves only."""
+    from collections import Counter
+    from emcid_amd import clip_forward as cf
+    rng = np.random.default_rng(3)
+    seqs = []
+    for _ in range(300):
+        n = int(rng.integers(2, 12))
+        seqs.append([7] + [int(t) for t in rng.integers(0, 4, size=n - 1)])   # tiny vocabulary: many shared prefixes
+    seqs.append(list(seqs[0]))                                                # an exact duplicate caption
+    want = Counter(tuple(s[:i + 1]) for s in seqs for i in range(len(s)))
+    trie, count = cf.build_trie_packed(seqs, "cpu", bucket=16)
+    got = _trie_prefix_multiset(trie, count.numpy())
+    assert got == dict(want)
+    assert int(count.sum()) == sum(len(s) for s in seqs)
+    U = trie.token.shape[0]
+    assert U % 16 == 0 and U >= trie.n_nodes
+    anc = trie.anc.numpy()
+    assert (anc[trie.n_nodes:, 0] == np.arange(trie.n_nodes, U)).all() and (trie.depth.numpy()[trie.n_nodes:] == 0).all()
+    # the edit path's trie over the same sequences (padded to one length, lookup = last token) has the same prefixes
+    lmax = max(len(s) for s in seqs)
+    padded = [s + [0] * (lmax - len(s)) for s in seqs]
+    ref = cf.build_trie(padded, [len(s) - 1 for s in seqs], "cpu", bucket=16)
+    assert set(_trie_prefix_multiset(ref)) == set(got)
