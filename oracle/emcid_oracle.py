@@ -515,3 +515,138 @@ def apply_emcid_to_cross_attn(pipe, requests, hparams: Dict, cache_name, stats_d
     deltas = execute_cross_attn(pipe, requests, hparams, cache_name, stats_dir, mom2_weight, edit_weight, trace)
     insert_deltas(pipe.unet, deltas)
     return pipe, deltas
+
+
+# --------------------------------------------------------------------------------------
+# UCE closed form, the baseline the reference ships beside EMCID (emcid/uce_train.py:31-213 text-encoder fc2
+# variant, :216-416 cross-attention K/V variant).  W_new = (lam W + sum v k^T)(lam I + sum k k^T)^-1.
+# `dtype` = the arithmetic after the (always fp32) encoder forward: float32 restates the reference op for op
+# (incl. torch.inverse); float64 is the same algebra with the rounding of the fp32 inverse removed, which is what the
+# HIP path (fp64 Cholesky) is compared against.
+# --------------------------------------------------------------------------------------
+
+def _uce_texts(old_text_, new_text_, retain_text_):
+    """uce_train.py:52-66 / :268-282: '' as a new text becomes ' '; no retain list -> ['']."""
+    old_texts = list(old_text_)
+    new_texts = [(' ' if t == '' else t) for t in new_text_]
+    ret_texts = [''] if retain_text_ is None else list(retain_text_)
+    return old_texts, new_texts, ret_texts
+
+
+def _uce_tokens(tokenizer, texts):
+    return tokenizer(list(texts), padding="max_length", max_length=tokenizer.model_max_length, truncation=True,
+                     return_tensors="pt")
+
+
+def _uce_row_windows(attention_mask, n_rows: int):
+    """uce_train.py:109-127 / :304-316: rows from the last subject token to the end, the longer text's tail cut
+    so both have the same number of rows."""
+    f_old = int(attention_mask[0].sum().item()) - 2
+    f_new = int(attention_mask[1].sum().item()) - 2
+    far = max(f_old, f_new)
+    return (f_old, n_rows - max(0, far - f_old)), (f_new, n_rows - max(0, far - f_new))
+
+
+def _uce_value(layer_fn, old_rows, new_rows, technique):
+    """uce_train.py:155-169: 'tensor' removes from the new value its component along the (whole-matrix normalised)
+    old value; anything else takes the new value."""
+    if technique == 'tensor':
+        u = layer_fn(old_rows)
+        u = u / u.norm()
+        new_embs = layer_fn(new_rows)
+        return new_embs - (u * new_embs).sum() * u
+    return layer_fn(new_rows)
+
+
+def _uce_outer_sums(value, context):
+    """uce_train.py:170-174: sum_r v_r k_r^T and sum_r k_r k_r^T (batched outer products, summed)."""
+    return value.t() @ context, context.t() @ context
+
+
+def edit_text_encoder_uce(pipe, old_text_, new_text_, retain_text_, layer_to_edit=11, lamb=0.1, erase_scale=0.1,
+                          preserve_scale=0.1, technique='tensor', dtype=torch.float32) -> torch.Tensor:
+    """uce_train.py:31-213.  Quirks kept: the retain pass sits INSIDE the loop over edits (:178), so it is added once per
+    edit; values come from the whole fc2 module, bias included (:158, :163); only the weight is replaced."""
+    module = get_module(pipe.text_encoder, f"text_model.encoder.layers.{layer_to_edit}.mlp.fc2")
+    old_texts, new_texts, ret_texts = _uce_texts(old_text_, new_text_, retain_text_)
+    W = module.weight.detach().to(dtype)
+    b = module.bias.detach().to(dtype)
+    layer_fn = lambda x: x @ W.t() + b
+
+    def fc2_inputs(texts):
+        cap = {}
+        h = module.register_forward_hook(lambda m, a, o: cap.__setitem__("x", a[0].detach().clone()))
+        try:
+            ti = _uce_tokens(pipe.tokenizer, texts)
+            with torch.no_grad():
+                pipe.text_encoder(ti.input_ids.to(pipe.device))
+        finally:
+            h.remove()
+        return ti, cap["x"].to(dtype)
+
+    mat1 = lamb * W.clone()
+    mat2 = lamb * torch.eye(W.shape[1], dtype=dtype, device=W.device)
+    for old_text, new_text in zip(old_texts, new_texts):
+        ti, x = fc2_inputs([old_text, new_text])
+        (o0, o1), (n0, n1) = _uce_row_windows(ti.attention_mask, x.shape[1])
+        context, new_rows = x[0, o0:o1], x[1, n0:n1]
+        m1, m2 = _uce_outer_sums(_uce_value(layer_fn, context, new_rows, technique), context)
+        mat1 += erase_scale * m1
+        mat2 += erase_scale * m2
+        for t in ret_texts:
+            _, x = fc2_inputs([t, t])
+            m1, m2 = _uce_outer_sums(layer_fn(x[1]), x[0])
+            mat1 += preserve_scale * m1
+            mat2 += preserve_scale * m2
+    new_w = mat1 @ torch.inverse(mat2)
+    with torch.no_grad():
+        module.weight.copy_(new_w.to(module.weight.dtype))
+    return new_w
+
+
+def edit_model_uce(pipe, old_text_, new_text_, retain_text_, layers_to_edit=None, lamb=0.1, erase_scale=0.1,
+                   preserve_scale=0.1, with_to_k=True, technique='tensor', dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """uce_train.py:216-416.  context = final text embeddings (:298); the retain pass is outside the loop over edits
+    here (:392).  The reference's projection list (:232-247) is built from the K/V layer-name list with the
+    `.to_k`/`.to_v` suffix stripped, so every attention block appears in it TWICE: 2x16 to_v entries, then (with_to_k)
+    2x16 to_k entries, and `layers_to_edit` indexes that doubled list (:286).  Its "reset" loop (:254-260) re-attaches a
+    fresh copy per entry, which leaves the FIRST entry of each pair pointing at a detached module: only an edit through
+    the second entry reaches the UNet, and it starts from the original weight."""
+    blocks = [n.replace('.to_k', '').replace('.to_v', '') for n in get_all_cross_attn_kv_layer_names(pipe.unet)]
+    entries = [n + '.to_v' for n in blocks] + ([n + '.to_k' for n in blocks] if with_to_k else [])
+    attached = [pn not in entries[j + 1:len(blocks) * (1 + j // len(blocks))] for j, pn in enumerate(entries)]
+    proj_names = [pn if att else None for pn, att in zip(entries, attached)]
+    mods = dict(pipe.unet.named_modules())
+    old_texts, new_texts, ret_texts = _uce_texts(old_text_, new_text_, retain_text_)
+
+    def embed(texts):
+        ti = _uce_tokens(pipe.tokenizer, texts)
+        with torch.no_grad():
+            return ti, pipe.text_encoder(ti.input_ids.to(pipe.device))[0].to(dtype)
+
+    out = {}
+    for layer_num, pname in enumerate(proj_names):
+        if (layers_to_edit is not None and layer_num not in layers_to_edit) or pname is None:
+            continue
+        module = mods[pname]
+        W = module.weight.detach().to(dtype)
+        layer_fn = lambda x: x @ W.t()
+        mat1 = lamb * W.clone()
+        mat2 = lamb * torch.eye(W.shape[1], dtype=dtype, device=W.device)
+        for old_text, new_text in zip(old_texts, new_texts):
+            ti, emb = embed([old_text, new_text])
+            (o0, o1), (n0, n1) = _uce_row_windows(ti.attention_mask, emb.shape[1])
+            context, new_rows = emb[0, o0:o1], emb[1, n0:n1]
+            m1, m2 = _uce_outer_sums(_uce_value(layer_fn, context, new_rows, technique), context)
+            mat1 += erase_scale * m1
+            mat2 += erase_scale * m2
+        for t in ret_texts:
+            _, emb = embed([t, t])
+            m1, m2 = _uce_outer_sums(layer_fn(emb[1]), emb[0])
+            mat1 += preserve_scale * m1
+            mat2 += preserve_scale * m2
+        out[pname] = mat1 @ torch.inverse(mat2)
+    with torch.no_grad():
+        for pname, new_w in out.items():
+            mods[pname].weight.copy_(new_w.to(mods[pname].weight.dtype))
+    return out

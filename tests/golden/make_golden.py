@@ -16,6 +16,7 @@ four shims of SURVEY.md §8c:
 Only DATA is written to tests/golden/ (inputs + the reference's outputs).
 """
 import contextlib
+import io
 import json
 import os
 import shutil
@@ -380,6 +381,71 @@ def golden_xattn(em, EMCIDHyperParams, scratch, tag="toy_xattn"):
     print(f"[golden] {tag}: wrote {len(out)} arrays, {len(names)} projections")
 
 
+class _PrefixedEncoder(torch.nn.Module):
+    """transformers-4.x module names (`text_model.encoder...`, hard-coded at uce_train.py:45) for a 5.x CLIPTextModel
+    (SURVEY.md 8c shim 3: wrap the model; no arithmetic)."""
+
+    def __init__(self, te):
+        super().__init__()
+        self.text_model = te
+        self.config = te.config
+
+    def forward(self, *a, **k):
+        return self.text_model(*a, **k)
+
+
+UCE_CASES = {
+    # text-encoder fc2 variant (uce_train.py:31-213)
+    "te_tensor": dict(kind="te", layer_to_edit=3, technique="tensor", retain=["painting", "a photo of the artist"],
+                      lamb=0.1, erase_scale=0.1, preserve_scale=0.1),
+    "te_replace": dict(kind="te", layer_to_edit=4, technique="replace", retain=None, lamb=0.5, erase_scale=0.2,
+                       preserve_scale=0.3),
+    # cross-attention K/V variant (uce_train.py:216-416)
+    "ca_tensor": dict(kind="ca", layers_to_edit=None, with_to_k=True, technique="tensor",
+                      retain=["painting", "a photo of the artist"], lamb=0.1, erase_scale=0.1, preserve_scale=0.1),
+    "ca_replace_subset": dict(kind="ca", layers_to_edit=[0, 2, 3, 9, 17, 31], with_to_k=False, technique="replace",
+                              retain=None, lamb=0.5, erase_scale=1.0, preserve_scale=0.1),
+}
+UCE_OLD = ["tocife", "gefeti vonibo", "famous sketch", "bako"]
+UCE_NEW = ["a realist artist", "", "drawing", "landscape painting with a portrait"]
+
+
+def golden_uce(scratch, tag="toy_uce"):
+    """Reference edit_text_encoder_uce / edit_model_uce (emcid/uce_train.py) on the synthetic pipe + SyntheticUNet."""
+    import emcid.uce_train as uce
+    out, meta = {}, {"old": UCE_OLD, "new": UCE_NEW, "cases": UCE_CASES, "unet_seed": 11}
+    out.update(state_np(syn.build_pipe("toy", "cpu").text_encoder, "te/"))
+    for name, c in UCE_CASES.items():
+        pipe = syn.add_unet(syn.build_pipe("toy", "cpu"), "toy")
+        kw = dict(lamb=c["lamb"], erase_scale=c["erase_scale"], preserve_scale=c["preserve_scale"], technique=c["technique"])
+        with contextlib.redirect_stdout(io.StringIO()):
+            if c["kind"] == "te":
+                te = pipe.text_encoder
+                pipe.text_encoder = _PrefixedEncoder(te)
+                fc2 = te.encoder.layers[c["layer_to_edit"]].mlp.fc2
+                out[f"{name}/w_orig"] = fc2.weight.detach().numpy().copy()
+                uce.edit_text_encoder_uce(pipe, UCE_OLD, UCE_NEW, c["retain"], layer_to_edit=c["layer_to_edit"], **kw)
+                out[f"{name}/w_final"] = fc2.weight.detach().numpy().copy()
+            else:
+                names = [n for n, m in pipe.unet.named_modules() if n.endswith((".to_k", ".to_v"))]
+                w0 = {n: dict(pipe.unet.named_modules())[n].weight.detach().numpy().copy() for n in names}
+                uce.edit_model_uce(pipe, UCE_OLD, UCE_NEW, c["retain"], layers_to_edit=c["layers_to_edit"],
+                                   with_to_k=c["with_to_k"], **kw)
+                mods = dict(pipe.unet.named_modules())
+                changed = []
+                for n in names:
+                    w1 = mods[n].weight.detach().numpy()
+                    if not np.array_equal(w1, w0[n]):
+                        changed.append(n)
+                        out[f"{name}/w_final/{n}"] = w1.copy()
+                meta.setdefault("changed", {})[name] = changed
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump(meta, f, indent=1)
+    print(f"[golden] {tag}: wrote {len(out)} arrays; changed projections: " +
+          ", ".join(f"{k}={len(v)}" for k, v in meta.get("changed", {}).items()))
+
+
 def golden_token_ranges(find_token_range, tag="token_ranges"):
     tok = syn.build_tokenizer()
     cases = [
@@ -409,7 +475,11 @@ def main():
     try:
         em, ls, cz, HP, XLHP, ftr = import_reference(scratch)
         torch.set_num_threads(8)
+        if "--only-uce" in sys.argv:
+            golden_uce(scratch)
+            return
         golden_token_ranges(ftr)
+        golden_uce(scratch)
         golden_sd(em, HP, scratch, "toy_sd", "toy", n_req=8, layers=(1, 2, 3, 4), lam=50, ew=0.6, ragged=True, full=True)
         golden_sdxl(em, XLHP, scratch)
         golden_stage0(ls, scratch)
