@@ -559,8 +559,12 @@ def _uce_value(layer_fn, old_rows, new_rows, technique):
 
 
 def _uce_outer_sums(value, context):
-    """uce_train.py:170-174: sum_r v_r k_r^T and sum_r k_r k_r^T (batched outer products, summed)."""
-    return value.t() @ context, context.t() @ context
+    """uce_train.py:170-174: sum_r v_r k_r^T and sum_r k_r k_r^T — as the reference forms them, one outer product per
+    row and a sum over rows (a GEMM would round differently, and the fp32 inverse amplifies that)."""
+    cv = context.reshape(context.shape[0], context.shape[1], 1)
+    cvt = context.reshape(context.shape[0], 1, context.shape[1])
+    vv = value.reshape(value.shape[0], value.shape[1], 1)
+    return (vv @ cvt).sum(dim=0), (cv @ cvt).sum(dim=0)
 
 
 def edit_text_encoder_uce(pipe, old_text_, new_text_, retain_text_, layer_to_edit=11, lamb=0.1, erase_scale=0.1,
@@ -571,7 +575,7 @@ def edit_text_encoder_uce(pipe, old_text_, new_text_, retain_text_, layer_to_edi
     old_texts, new_texts, ret_texts = _uce_texts(old_text_, new_text_, retain_text_)
     W = module.weight.detach().to(dtype)
     b = module.bias.detach().to(dtype)
-    layer_fn = lambda x: x @ W.t() + b
+    layer_fn = lambda x: torch.nn.functional.linear(x, W, b)
 
     def fc2_inputs(texts):
         cap = {}
@@ -630,7 +634,7 @@ def edit_model_uce(pipe, old_text_, new_text_, retain_text_, layers_to_edit=None
             continue
         module = mods[pname]
         W = module.weight.detach().to(dtype)
-        layer_fn = lambda x: x @ W.t()
+        layer_fn = lambda x: torch.nn.functional.linear(x, W)
         mat1 = lamb * W.clone()
         mat2 = lamb * torch.eye(W.shape[1], dtype=dtype, device=W.device)
         for old_text, new_text in zip(old_texts, new_texts):

@@ -85,6 +85,17 @@ def xattn_from_golden(z, meta, tmp_path, device="cpu"):
     return pipe.to(device), cache, str(tmp_path / "xstats")
 
 
+def uce_pipe_from_golden(z, device="cpu"):
+    """Toy text encoder + SyntheticUNet of the UCE fixture, both from its stored state dicts."""
+    from emcid_amd import synthetic as syn
+
+    te = pipe_from_golden(z, "toy", prefix="te/")
+    pipe = syn.add_unet(syn.SyntheticPipe(text_encoder=te, tokenizer=syn.build_tokenizer()), "toy")
+    pipe.unet.load_state_dict({k[len("unet/"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("unet/")},
+                              strict=True)
+    return pipe.to(device)
+
+
 def write_vstars(cache_name, requests, vstar, suffix=""):
     from emcid_amd import synthetic as syn
 

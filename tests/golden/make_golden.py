@@ -415,6 +415,7 @@ def golden_uce(scratch, tag="toy_uce"):
     import emcid.uce_train as uce
     out, meta = {}, {"old": UCE_OLD, "new": UCE_NEW, "cases": UCE_CASES, "unet_seed": 11}
     out.update(state_np(syn.build_pipe("toy", "cpu").text_encoder, "te/"))
+    out.update(state_np(syn.add_unet(syn.build_pipe("toy", "cpu"), "toy").unet, "unet/"))
     for name, c in UCE_CASES.items():
         pipe = syn.add_unet(syn.build_pipe("toy", "cpu"), "toy")
         kw = dict(lamb=c["lamb"], erase_scale=c["erase_scale"], preserve_scale=c["preserve_scale"], technique=c["technique"])

@@ -317,3 +317,38 @@ def test_packed_trie_is_the_prefix_multiset_of_the_captions():
     padded = [s + [0] * (lmax - len(s)) for s in seqs]
     ref = cf.build_trie(padded, [len(s) - 1 for s in seqs], "cpu", bucket=16)
     assert set(_trie_prefix_multiset(ref)) == set(got)
+
+
+def test_uce_host_side():
+    """Row windows (uce_train.py:109-127), the doubled projection list and its detached first entries (:232-260), the
+    text formatting (:52-66) and the refusal to run on a CPU pipe."""
+    from conftest import load_golden, uce_pipe_from_golden
+    from emcid_amd import uce_train as uce
+    z, meta = load_golden("toy_uce")
+    pipe = uce_pipe_from_golden(z)
+    old, new, ret = uce._format_texts(meta["old"], meta["new"], None)
+    assert new[1] == " " and ret == [""] and old == meta["old"]
+    texts = [t for pr in zip(old, new) for t in pr]
+    ti = orc._uce_tokens(pipe.tokenizer, texts)
+    S = ti.input_ids.shape[1]
+    o_flat, n_flat, seg = uce.row_windows(ti.attention_mask.numpy(), len(old), S)
+    r0 = 0
+    for i in range(len(old)):
+        (o0, o1), (n0, n1) = orc._uce_row_windows(ti.attention_mask[2 * i:2 * i + 2], S)
+        m = o1 - o0
+        assert m == n1 - n0
+        assert (o_flat[r0:r0 + m] == 2 * i * S + np.arange(o0, o1)).all()
+        assert (n_flat[r0:r0 + m] == (2 * i + 1) * S + np.arange(n0, n1)).all()
+        assert (seg[r0:r0 + m] == i).all()
+        r0 += m
+    assert r0 == len(o_flat)
+    entries, attached = uce.projection_entries(pipe, with_to_k=True)
+    assert len(entries) == 64 and sum(attached) == 32 and len({e for e, a in zip(entries, attached) if a}) == 32
+    assert all(e.endswith(".to_v") for e in entries[:32]) and all(e.endswith(".to_k") for e in entries[32:])
+    want = meta["cases"]["ca_replace_subset"]
+    e_v, a_v = uce.projection_entries(pipe, with_to_k=False)
+    assert sorted(e_v[j] for j in want["layers_to_edit"] if a_v[j]) == sorted(meta["changed"]["ca_replace_subset"])
+    with pytest.raises(hip.EmcidHipError):
+        uce.edit_model_uce(pipe, meta["old"], meta["new"], None)
+    with pytest.raises(hip.EmcidHipError):
+        uce.edit_text_encoder_uce(pipe, meta["old"], meta["new"], None, layer_to_edit=2)

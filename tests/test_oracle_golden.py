@@ -207,3 +207,37 @@ def test_config1_van_gogh_instruction(tmp_path):
         np.testing.assert_allclose((dw @ probe).numpy(), z[f"dw_probe/{li}"], rtol=0, atol=1e-6 * float(z[f"dw_maxabs/{li}"]) * 60)
         np.testing.assert_allclose(dw.norm(dim=1).numpy(), z[f"dw_rownorm/{li}"], rtol=1e-6, atol=1e-9)
         assert abs(dw.abs().max().item() - float(z[f"dw_maxabs/{li}"])) <= 1e-6 * float(z[f"dw_maxabs/{li}"])
+
+
+@pytest.mark.parametrize("case", ["te_tensor", "te_replace", "ca_tensor", "ca_replace_subset"])
+def test_uce_closed_form_golden(case):
+    """The oracle's op-for-op fp32 restatement of uce_train.py against weights the reference itself produced; and its
+    fp64 mode (what the HIP path is checked against) within the fp32-inverse error of the reference."""
+    from conftest import uce_pipe_from_golden
+    z, meta = load_golden("toy_uce")
+    c = meta["cases"][case]
+    kw = dict(lamb=c["lamb"], erase_scale=c["erase_scale"], preserve_scale=c["preserve_scale"], technique=c["technique"])
+    # fp32 restatement: 0.0 measured here (same ops, same order); fp64 mode: 1.6e-4 .. 2.4e-4 = what the reference's own
+    # fp32 torch.inverse costs it at these condition numbers
+    for dtype, tol in ((torch.float32, 1e-6), (torch.float64, 1e-3)):
+        pipe = uce_pipe_from_golden(z)
+        if c["kind"] == "te":
+            new_w = orc.edit_text_encoder_uce(pipe, meta["old"], meta["new"], c["retain"], layer_to_edit=c["layer_to_edit"],
+                                              dtype=dtype, **kw)
+            want = torch.from_numpy(z[f"{case}/w_final"])
+            scale = want.abs().max().item()
+            assert (new_w.float() - want).abs().max().item() <= tol * scale
+            got = pipe.text_encoder.encoder.layers[c["layer_to_edit"]].mlp.fc2.weight
+            assert (got - want).abs().max().item() <= tol * scale
+        else:
+            w0 = {n: m.weight.detach().clone() for n, m in pipe.unet.named_modules() if n.endswith((".to_k", ".to_v"))}
+            out = orc.edit_model_uce(pipe, meta["old"], meta["new"], c["retain"], layers_to_edit=c["layers_to_edit"],
+                                     with_to_k=c["with_to_k"], dtype=dtype, **kw)
+            assert sorted(out) == sorted(meta["changed"][case])       # the doubled-list quirk: which entries reach the UNet
+            mods = dict(pipe.unet.named_modules())
+            for n in w0:
+                if n in out:
+                    want = torch.from_numpy(z[f"{case}/w_final/{n}"])
+                    assert (mods[n].weight - want).abs().max().item() <= tol * want.abs().max().item(), n
+                else:
+                    assert torch.equal(mods[n].weight, w0[n])

@@ -1,0 +1,137 @@
+"""UCE closed form on the HIP path (emcid_amd/uce_train.py) against the oracle and the reference-minted fixture."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, uce_pipe_from_golden
+from emcid_amd import uce_train as uce
+from oracle import emcid_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _closed_form_ref(Ko, Kn, Kr, seg, n, weights, biases, lamb, e, p, technique):
+    """fp64 torch restatement of the algebra on whatever device the inputs live on (the checker)."""
+    d = Ko.shape[1]
+    mat2 = lamb * torch.eye(d, dtype=torch.float64, device=Ko.device) + e * Ko.t() @ Ko + p * Kr.t() @ Kr
+    out = []
+    for W, b in zip(weights, biases):
+        W = W.double()
+        f = (lambda x: x @ W.t() + b.double()) if b is not None else (lambda x: x @ W.t())
+        mat1 = lamb * W.clone()
+        for i in range(n):
+            rows = seg == i
+            o, nw = f(Ko[rows]), f(Kn[rows])
+            if technique == "tensor":
+                u = o / o.norm()
+                nw = nw - (u * nw).sum() * u
+            mat1 += e * nw.t() @ Ko[rows]
+        mat1 += p * f(Kr).t() @ Kr
+        out.append(torch.linalg.solve(mat2, mat1.t()).t())
+    return out, mat2
+
+
+@pytest.mark.parametrize("technique", ["tensor", "replace"])
+@pytest.mark.parametrize("d,outs,bias", [(96, (16, 24, 48), False), (128, (32,), True), (320, (64, 130), False)])
+def test_closed_form_matches_fp64_torch(technique, d, outs, bias):
+    g = torch.Generator().manual_seed(d)
+    n = 5
+    lens = [7, 70, 33, 1, 64]
+    seg = torch.cat([torch.full((m,), i, dtype=torch.int64) for i, m in enumerate(lens)])
+    M = int(seg.numel())
+    Ko = torch.randn(M, d, generator=g, dtype=torch.float64)
+    Kn = torch.randn(M, d, generator=g, dtype=torch.float64)
+    Kr = torch.randn(154, d, generator=g, dtype=torch.float64)
+    ws = [torch.randn(o, d, generator=g) / d ** 0.5 for o in outs]
+    bs = [torch.randn(o, generator=g) if bias else None for o in outs]
+    want, _ = _closed_form_ref(Ko, Kn, Kr, seg, n, ws, bs, 0.1, 0.1, 0.3, technique)
+    got = uce.closed_form(Ko.to(DEV), Kn.to(DEV), Kr.to(DEV), seg.to(DEV), n, [w.to(DEV) for w in ws],
+                          [None if b is None else b.to(DEV) for b in bs], 0.1, 0.1, 0.3, technique)
+    for gw, ww in zip(got, want):
+        assert gw.dtype == torch.float32
+        torch.testing.assert_close(gw.cpu().double(), ww, rtol=0, atol=2e-7 * ww.abs().max().item())
+
+
+def test_closed_form_no_retain_and_no_edit_rows():
+    g = torch.Generator().manual_seed(1)
+    d = 128
+    W = torch.randn(24, d, generator=g)
+    Ko = torch.randn(40, d, generator=g, dtype=torch.float64)
+    seg = torch.zeros(40, dtype=torch.int64)
+    empty = torch.zeros(0, d, dtype=torch.float64)
+    want, _ = _closed_form_ref(Ko, Ko.flip(0), empty, seg, 1, [W], [None], 0.5, 1.0, 0.0, "replace")
+    (got,) = uce.closed_form(Ko.to(DEV), Ko.flip(0).contiguous().to(DEV), empty.to(DEV), seg.to(DEV), 1, [W.to(DEV)], [None],
+                             0.5, 1.0, 0.0, "replace")
+    torch.testing.assert_close(got.cpu().double(), want[0], rtol=0, atol=2e-7 * want[0].abs().max().item())
+    # no rows at all: (lam W)(lam I)^-1 = W
+    (same,) = uce.closed_form(empty.to(DEV), empty.to(DEV), empty.to(DEV), seg[:0].to(DEV), 0, [W.to(DEV)], [None], 0.5, 1.0, 0.1)
+    torch.testing.assert_close(same.cpu(), W, rtol=0, atol=1e-6)
+
+
+def test_closed_form_normal_equation_at_sd_dims():
+    """Size-independent property at the reference's real width (fc2 input 3072, 768 outputs, ~7 000 rows): the result
+    satisfies W_new mat2 = mat1 with both sides formed independently in fp64 torch on the GPU."""
+    g = torch.Generator().manual_seed(7)
+    d, out, n = 3072, 768, 96
+    lens = torch.randint(60, 76, (n,), generator=g)
+    seg = torch.repeat_interleave(torch.arange(n), lens).to(DEV)
+    M = int(seg.numel())
+    Ko = torch.randn(M, d, generator=g).double().to(DEV)
+    Kn = torch.randn(M, d, generator=g).double().to(DEV)
+    Kr = torch.randn(154, d, generator=g).double().to(DEV)
+    W = (torch.randn(out, d, generator=g) / d ** 0.5).to(DEV)
+    b = torch.randn(out, generator=g).to(DEV)
+    (got,) = uce.closed_form(Ko, Kn, Kr, seg, n, [W], [b], 0.1, 0.1, 0.1 * n, "tensor")
+    f = lambda x: x @ W.double().t() + b.double()
+    O, Nw = f(Ko), f(Kn)
+    dot = torch.zeros(n, dtype=torch.float64, device=DEV).index_add_(0, seg, (O * Nw).sum(1))
+    sq = torch.zeros(n, dtype=torch.float64, device=DEV).index_add_(0, seg, (O * O).sum(1))
+    S = Nw - (dot / sq)[seg][:, None] * O
+    mat1 = 0.1 * W.double() + 0.1 * S.t() @ Ko + 0.1 * n * f(Kr).t() @ Kr
+    mat2 = 0.1 * torch.eye(d, dtype=torch.float64, device=DEV) + 0.1 * Ko.t() @ Ko + 0.1 * n * Kr.t() @ Kr
+    resid = got.double() @ mat2 - mat1
+    # got is rounded to fp32: |dW| <= 6e-8 |W| per entry, times the row sums of mat2
+    bound = 6e-8 * got.abs().max().item() * mat2.abs().sum(0).max().item()
+    assert resid.abs().max().item() <= bound
+
+
+@pytest.mark.parametrize("case", ["te_tensor", "te_replace", "ca_tensor", "ca_replace_subset"])
+def test_uce_vs_oracle_and_reference_golden(case):
+    """Entry points on the GPU: (1) against the oracle's fp64 mode on the CPU (same algebra without the reference's fp32
+    inverse; what is left is the GPU-vs-CPU fp32 encoder forward), (2) against the weights the reference itself
+    produced, within the error of its fp32 inverse (2.4e-4 measured for the oracle's fp64 mode, tests/test_oracle_golden.py)."""
+    z, meta = load_golden("toy_uce")
+    c = meta["cases"][case]
+    kw = dict(lamb=c["lamb"], erase_scale=c["erase_scale"], preserve_scale=c["preserve_scale"], technique=c["technique"])
+    ref_pipe = uce_pipe_from_golden(z)
+    pipe = uce_pipe_from_golden(z, DEV)
+    if c["kind"] == "te":
+        want64 = orc.edit_text_encoder_uce(ref_pipe, meta["old"], meta["new"], c["retain"], layer_to_edit=c["layer_to_edit"],
+                                           dtype=torch.float64, **kw)
+        fc2 = pipe.text_encoder.encoder.layers[c["layer_to_edit"]].mlp.fc2
+        bias0 = fc2.bias.detach().clone()
+        ret = uce.edit_text_encoder_uce(pipe, meta["old"], meta["new"], c["retain"], layer_to_edit=c["layer_to_edit"], **kw)
+        assert ret is pipe
+        got = fc2.weight.detach().cpu()
+        assert torch.equal(fc2.bias, bias0)
+        pairs = [(got, want64, torch.from_numpy(z[f"{case}/w_final"]))]
+    else:
+        w0 = {n: m.weight.detach().clone() for n, m in pipe.unet.named_modules() if n.endswith((".to_k", ".to_v"))}
+        want64 = orc.edit_model_uce(ref_pipe, meta["old"], meta["new"], c["retain"], layers_to_edit=c["layers_to_edit"],
+                                    with_to_k=c["with_to_k"], dtype=torch.float64, **kw)
+        ret = uce.edit_model_uce(pipe, meta["old"], meta["new"], c["retain"], layers_to_edit=c["layers_to_edit"],
+                                 with_to_k=c["with_to_k"], **kw)
+        assert ret is pipe
+        mods = dict(pipe.unet.named_modules())
+        pairs = []
+        for n in w0:
+            if n in meta["changed"][case]:
+                pairs.append((mods[n].weight.detach().cpu(), want64[n], torch.from_numpy(z[f"{case}/w_final/{n}"])))
+            else:
+                assert torch.equal(mods[n].weight, w0[n]), n
+        assert len(pairs) == len(meta["changed"][case])
+    for got, w64, gold in pairs:
+        scale = gold.abs().max().item()
+        assert (got.double() - w64).abs().max().item() <= 2e-5 * scale
+        assert (got - gold).abs().max().item() <= 1e-3 * scale
