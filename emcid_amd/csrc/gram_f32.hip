@@ -5,8 +5,11 @@
 // X is [t][d] row-major, so both MFMA operands are d-contiguous slices of the same token rows: the LDS
 // image of a tile is a straight copy [BK tokens][128 features]; a fragment read is 32 consecutive floats
 // per token row (ds_read_b32, lanes 0-31 token k, lanes 32-63 token k+1) and is conflict-free.
-// The token dimension can be split over blockIdx.z (ksplit); partial tiles are then added with
+// The token dimension is split over blockIdx.z (ksplit); partial tiles are then added with
 // global_atomic_add_f32 (G is an accumulator anyway), otherwise with a plain read-modify-write.
+// Global loads are kept branch-free (see ALIGNED / FAST below): with per-element tails in the loop the compiler
+// serialised a stage's four loads behind `s_waitcnt vmcnt(0)` and the kernel sat at 50 % of the f32 MFMA peak; now
+// ~62 % (rocprofv3: matrix pipe busy 65 % of cycles at 2.26 GHz; without the global loads the same loop reaches 72 %).
 // Also here: the small byte-moving kernels of the K/Z assembly (gather + per-request mean) and the
 // lower->upper mirror used when the moment is read.
 #include "common.h"
@@ -19,86 +22,144 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int GB = 128;   // output tile edge
 constexpr int GBK = 16;   // tokens per stage
 
-__global__ __launch_bounds__(256) void gram_f32_kernel(const float* __restrict__ X, int t, int d, int64_t ldx,
+// MI = 32-row MFMA blocks per wave along m: the workgroup tile is (64*MI) x 128 (2 x 2 waves, each (32*MI) x 64).
+// MI = 2 (128 x 128, 4 workgroups per CU) is what is launched; MI = 4 (256 x 128: a third less data per flop through
+// L2/LDS, 2 workgroups per CU) measured 2-8 % slower at d = 3072 / 5120 — the kernel is not bound by that traffic.
+// ALIGNED (d % 4 == 0): a float4 of a row is entirely inside or entirely outside the matrix, so the global loads are
+// unconditional (clamped address + select) and the compiler can keep all of a stage's loads in flight; the general form
+// has per-element tails, whose branches serialise the loads behind `s_waitcnt vmcnt(0)`.
+template <int MI, bool ALIGNED, bool FAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void gram_f32_kernel(const float* __restrict__ X, int t, int d, int64_t ldx,
                                                         float* __restrict__ G, int64_t ldg, int kchunk, int use_atomic) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * GBK * GB];
+    constexpr int BMT = 64 * MI;                    // tile rows
+    constexpr int STAGE = GBK * (BMT + GB);         // floats per stage: A image [GBK][BMT], then B image [GBK][GB]
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
     const int bm = blockIdx.y, bn = blockIdx.x;
-    if (bn > bm) return;  // lower triangle of tiles only
-    const int m0 = bm * GB, n0 = bn * GB;
+    const int m0 = bm * BMT, n0 = bn * GB;
+    if (n0 >= m0 + BMT) return;  // tile entirely above the diagonal
     const int k_begin = blockIdx.z * kchunk;
     const int k_end = min(t, k_begin + kchunk);
     if (k_begin >= k_end) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int wm0 = (wave >> 1) * (32 * MI), wn0 = (wave & 1) * 64;
     const int l31 = lane & 31, l5 = lane >> 5;
 
-    v16f acc[2][2];
+    v16f acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // each thread stages 2 float4 of the A tile and 2 of the B tile per stage
-    v4f ra[2], rb[2];
-    auto load = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int v = tid + i * 256;          // 512 float4 per [16][128] tile
-            const int kr = k0 + v / (GB / 4);
-            const int c = 4 * (v % (GB / 4));
-            v4f a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    // per stage each thread moves MI float4 of the A image and 2 of the B image
+    v4f ra[MI], rb[2];
+    bool oka[MI], okb[2];                           // ALIGNED: the zeroing select is applied when the registers go to LDS,
+    auto fetch = [&](int kr, int col0, bool& ok) {  // after the MFMAs of the stage, so that nothing waits on the loads before
+        const v4f zero = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (ALIGNED) {
+            ok = kr < k_end && col0 < d;
+            const float* src = ok ? X + (int64_t)kr * ldx + col0 : X;
+            return *reinterpret_cast<const v4f*>(src);
+        } else {
+            ok = true;
+            v4f v = zero;
             if (kr < k_end) {
                 const float* row = X + (int64_t)kr * ldx;
-                if (m0 + c + 3 < d) a = *reinterpret_cast<const v4f*>(row + m0 + c);
+                if (col0 + 3 < d) v = *reinterpret_cast<const v4f*>(row + col0);
                 else
-                    for (int e = 0; e < 4; ++e) if (m0 + c + e < d) a[e] = row[m0 + c + e];
-                if (n0 + c + 3 < d) b = *reinterpret_cast<const v4f*>(row + n0 + c);
-                else
-                    for (int e = 0; e < 4; ++e) if (n0 + c + e < d) b[e] = row[n0 + c + e];
+                    for (int e = 0; e < 4; ++e) if (col0 + e < d) v[e] = row[col0 + e];
             }
-            ra[i] = a; rb[i] = b;
+            return v;
+        }
+    };
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int v = tid + i * 256;          // GBK * BMT / 4 float4 in the A image
+            ra[i] = fetch(k0 + v / (BMT / 4), m0 + 4 * (v % (BMT / 4)), oka[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = tid + i * 256;          // 512 float4 in the [16][128] B image
+            rb[i] = fetch(k0 + v / (GB / 4), n0 + 4 * (v % (GB / 4)), okb[i]);
         }
     };
     auto store = [&](float* stage) {
+        const v4f zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int v = tid + i * 256;
-            *reinterpret_cast<v4f*>(stage + 4 * v) = ra[i];
-            *reinterpret_cast<v4f*>(stage + GBK * GB + 4 * v) = rb[i];
-        }
+        for (int i = 0; i < MI; ++i) *reinterpret_cast<v4f*>(stage + 4 * (tid + i * 256)) = oka[i] ? ra[i] : zero;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<v4f*>(stage + GBK * BMT + 4 * (tid + i * 256)) = okb[i] ? rb[i] : zero;
     };
 
-    load(k_begin);
-    store(smem);
-    __syncthreads();
+    // FAST (every tile column inside the matrix): stages whose 16 rows all exist need no checks at all — one uniform base
+    // per stage plus a loop-invariant per-thread offset, raw registers to LDS; only the last, partial stage takes `load`.
+    int offa[MI], offb[2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int v = tid + i * 256;
+        offa[i] = (v / (BMT / 4)) * (int)ldx + m0 + 4 * (v % (BMT / 4));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = tid + i * 256;
+        offb[i] = (v / (GB / 4)) * (int)ldx + n0 + 4 * (v % (GB / 4));
+    }
+    auto load_fast = [&](int k0) {
+        const float* Xs = X + (int64_t)k0 * ldx;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) ra[i] = *reinterpret_cast<const v4f*>(Xs + offa[i]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rb[i] = *reinterpret_cast<const v4f*>(Xs + offb[i]);
+    };
+    auto store_fast = [&](float* stage) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) *reinterpret_cast<v4f*>(stage + 4 * (tid + i * 256)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<v4f*>(stage + GBK * BMT + 4 * (tid + i * 256)) = rb[i];
+    };
     const int T = (k_end - k_begin + GBK - 1) / GBK;
+    const int T_fast = FAST ? (k_end - k_begin) / GBK : 0;      // stages [0, T_fast) are complete
+
+    if (T_fast > 0) { load_fast(k_begin); store_fast(smem); }
+    else { load(k_begin); store(smem); }
+    __syncthreads();
     for (int it = 0; it < T; ++it) {
-        const float* As = smem + (it & 1) * (2 * GBK * GB);
-        const float* Bs = As + GBK * GB;
-        const bool more = it + 1 < T;
-        if (more) load(k_begin + (it + 1) * GBK);
+        const float* As = smem + (it & 1) * STAGE;
+        const float* Bs = As + GBK * BMT;
+        const int nx = it + 1;
+        if (nx < T_fast) load_fast(k_begin + nx * GBK);
+        else if (nx < T) load(k_begin + nx * GBK);
+        // fragments of step kk+1 are read from LDS before the MFMAs of step kk issue
+        float a[2][MI], b[2][2];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[0][i] = As[l5 * BMT + wm0 + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[0][j] = Bs[l5 * GB + wn0 + j * 32 + l31];
 #pragma unroll
         for (int kk = 0; kk < GBK / 2; ++kk) {
-            float a[2], b[2];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < GBK / 2) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[(kk * 2 + l5) * GB + wm0 + i * 32 + l31];
+                for (int i = 0; i < MI; ++i) a[nxt][i] = As[((kk + 1) * 2 + l5) * BMT + wm0 + i * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Bs[(kk * 2 + l5) * GB + wn0 + j * 32 + l31];
+                for (int j = 0; j < 2; ++j) b[nxt][j] = Bs[((kk + 1) * 2 + l5) * GB + wn0 + j * 32 + l31];
+            }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
         }
-        if (more) store(smem + ((it + 1) & 1) * (2 * GBK * GB));
+        if (nx < T_fast) store_fast(smem + (nx & 1) * STAGE);
+        else if (nx < T) store(smem + (nx & 1) * STAGE);
         __syncthreads();
     }
 
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -163,11 +224,13 @@ int emcid_gram_accumulate_f32(const float* X, int64_t t, int64_t d, int64_t ldx,
     EMCID_CHECK_ARG(aligned16(X) && (ldx % 4 == 0));
     if (t == 0) return EMCID_OK;  // empty batch: no-op, like SecondMoment.add (runningstats.py:485-486)
     const int tiles = (int)((d + GB - 1) / GB);
+    const int64_t lower = (int64_t)tiles * (tiles + 1) / 2;
     if (ksplit == 0) {
-        // auto: enough workgroups for ~4 per CU, but at least 256 tokens per chunk
-        const int64_t lower = (int64_t)tiles * (tiles + 1) / 2;
-        int64_t want = (1024 + lower - 1) / lower;
-        int64_t maxsplit = (t + 255) / 256;
+        // auto: ~6 rounds of the chip's 1024 workgroup slots (4 per CU), so the last, partly filled round costs little
+        // (measured at d 3072: 76 -> 94 SYRK-TF from 4 to 20 splits), but chunks of >= 1024 tokens, so the 64 KB of
+        // atomics a workgroup ends with stay small beside the 1 KB per token it streams; short inputs: >= 256 tokens.
+        const int64_t want = (6144 + lower - 1) / lower;
+        const int64_t maxsplit = t >= 4096 ? t / 1024 : (((t + 255) / 256) < 4 ? (t + 255) / 256 : 4);
         ksplit = (int)(want < maxsplit ? want : maxsplit);
         if (ksplit < 1) ksplit = 1;
     }
@@ -175,8 +238,16 @@ int emcid_gram_accumulate_f32(const float* X, int64_t t, int64_t d, int64_t ldx,
     ksplit = (int)((t + kchunk - 1) / kchunk);
     dim3 grid(tiles, tiles, ksplit);
     ScopedProf sp(KC_GRAM, (hipStream_t)stream);
-    hipLaunchKernelGGL(gram_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, (int)t, (int)d, ldx, G, ldg, (int)kchunk,
-                       ksplit > 1 ? 1 : 0);
+    const int atomic = ksplit > 1 ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    // FAST needs every tile column inside the matrix and 32-bit element offsets inside one 16-row stage
+    const bool fast = d % GB == 0 && ldx * GBK < (1LL << 30);
+#define EMCID_GRAM_LAUNCH(AL_, FA_) \
+    hipLaunchKernelGGL((gram_f32_kernel<2, AL_, FA_>), grid, dim3(256), 0, st, X, (int)t, (int)d, ldx, G, ldg, (int)kchunk, atomic)
+    if (d % 4 != 0) EMCID_GRAM_LAUNCH(false, false);
+    else if (!fast) EMCID_GRAM_LAUNCH(true, false);
+    else EMCID_GRAM_LAUNCH(true, true);
+#undef EMCID_GRAM_LAUNCH
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }
