@@ -4,6 +4,7 @@ Public surface mirrors the reference's (SilentView/EMCID) for this path:
     emcid_amd.emcid_main   apply_emcid_to_text_encoder, apply_emcid_to_sdxl_text_encoders, execute_*,
                            get_cov_text_encoder, apply_emcid_to_model,
                            apply_emcid_to_cross_attn, execute_emcid_cross_attn (UNet cross-attention K/V)
+    emcid_amd.uce_train    edit_text_encoder_uce, edit_model_uce (the UCE baseline's closed forms)
     emcid_amd.layer_stats  layer_stats_text_encoder (Stage 0)
     emcid_amd.compute_ks / compute_z / runningstats / nethook / stat_dataset / causal_trace / emcid_hparams
 The compute is in csrc/ (hand-written HIP for gfx950) behind the C ABI declared in include/emcid_hip.h.
@@ -20,4 +21,7 @@ def __getattr__(name):
                 "apply_emcid_to_cross_attn", "execute_emcid_cross_attn", "get_cov_cross_attn"):
         from . import emcid_main
         return getattr(emcid_main, name)
+    if name in ("edit_text_encoder_uce", "edit_model_uce"):
+        from . import uce_train
+        return getattr(uce_train, name)
     raise AttributeError(name)
