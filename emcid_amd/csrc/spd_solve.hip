@@ -1046,6 +1046,27 @@ int emcid_dgemm_ex_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double a
     return EMCID_OK;
 }
 
+int emcid_dgemm_batched_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                            int64_t sA, const double* B, int64_t ldb, int64_t sB, double beta, double* C, int64_t ldc, int64_t sC,
+                            int64_t batch, void* stream) {
+    EMCID_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C && batch > 0 && batch <= 65535);
+    EMCID_CHECK_ARG(aligned16(A) && aligned16(B) && (lda % 2 == 0) && (ldb % 2 == 0) && (sA % 2 == 0) && (sB % 2 == 0));
+    EMCID_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30) && sA >= 0 && sB >= 0 && sC >= 0);
+    hipStream_t st = (hipStream_t)stream;
+    GemmShape p{A, lda, B, ldb, (int)M, (int)N, (int)K, 0};
+    p.sA = sA; p.sB = sB; p.batch = (int)batch;
+    EpiAxpby e{C, ldc, alpha, beta};
+    e.sC = sC;
+    ScopedProf sp(KC_DGEMM, st);
+    // no K split here: with beta == 1 the launcher would add partials atomically, which is pointless for short K
+    if (ta == 0 && tb == 0) launch_gemm_f64<true, true>(p, e, st);
+    else if (ta == 0 && tb == 1) launch_gemm_f64<true, false>(p, e, st);
+    else if (ta == 1 && tb == 0) launch_gemm_f64<false, true>(p, e, st);
+    else launch_gemm_f64<false, false>(p, e, st);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
 int emcid_assemble_spd_f64(const float* C, int64_t ldc, const double* Kt64, int64_t Np, int64_t d, int64_t ldk, double lam,
                            float cw, double* A, int64_t lda, void* stream) {
     EMCID_CHECK_ARG(C && Kt64 && A && Np > 0 && d > 0);

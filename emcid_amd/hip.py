@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = [
     "emcid_abi_version", "emcid_last_error", "emcid_gram_accumulate_f32", "emcid_symmetrize_lower_f32",
     "emcid_gather_mean_f32", "emcid_edit_workspace_bytes", "emcid_edit_layer_f64", "emcid_assemble_spd_f64",
-    "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_dgemm_ex_f64", "emcid_axpy_f32",
+    "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_dgemm_ex_f64", "emcid_dgemm_batched_f64", "emcid_axpy_f32",
     "emcid_profile_enable", "emcid_profile_collect", "emcid_attention_f32", "emcid_edit_layer_shard_f64",
     "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32", "emcid_add_layernorm_f32", "emcid_tree_attention_f32", "emcid_debug_leaf_stamps",
     "emcid_cov_factor_workspace_bytes", "emcid_factor_cov_f64", "emcid_cov_inverse_f64",
@@ -30,7 +30,7 @@ EXPORTS = [
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block"]
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NB = 128      # Cholesky block (csrc/common.h)
 NPAD = 64     # concept padding of the f64 stacks (csrc/common.h)
 
@@ -83,6 +83,7 @@ def load():
         "emcid_delta_w_f64": (i32, [p, i64, p, i64, i64, i64, i64, p, p, i64, p, p, p]),
         "emcid_dgemm_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, p]),
         "emcid_dgemm_ex_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, i32, i32, i32, p]),
+        "emcid_dgemm_batched_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, i64, p, i64, i64, f64, p, i64, i64, i64, p]),
         "emcid_axpy_f32": (i32, [p, p, i64, p]),
         "emcid_quick_gelu_f32": (i32, [p, p, i64, p]),
         "emcid_add_layernorm_f32": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p]),
@@ -249,6 +250,25 @@ def dgemm_ex(ta: int, tb: int, A, B, Cm, alpha=1.0, beta=0.0, flags=0, cfg=-1, k
     _check(load().emcid_dgemm_ex_f64(ta, tb, M, N, K, float(alpha), _ptr(A, torch.float64), A.stride(0),
                                      _ptr(B, torch.float64), B.stride(0), float(beta), _ptr(Cm, torch.float64),
                                      Cm.stride(0), int(flags), int(cfg), int(ksplit), _stream(Cm)), "emcid_dgemm_ex_f64")
+    return Cm
+
+
+def dgemm_batched(ta: int, tb: int, A, B, Cm, alpha=1.0, beta=0.0):
+    """C[b] = alpha * opA(A[b]) opB(B[b]) + beta * C[b] for 3-D operands (batch, rows, cols) with unit inner stride;
+    ta/tb as in `dgemm`.  A batch stride of 0 (an expanded operand) shares that operand across the batch."""
+    nb = Cm.shape[0]
+    M = A.shape[1] if ta == 0 else A.shape[2]
+    K = A.shape[2] if ta == 0 else A.shape[1]
+    N = B.shape[1] if tb == 0 else B.shape[2]
+    for t_, nm in ((A, "A"), (B, "B"), (Cm, "C")):
+        if t_.dim() != 3 or t_.stride(2) != 1 or t_.shape[0] != nb:
+            raise EmcidHipError(f"dgemm_batched: {nm} must be (batch, rows, cols) with unit inner stride")
+    if Cm.shape[1] != M or Cm.shape[2] != N or (B.shape[2] if tb == 0 else B.shape[1]) != K:
+        raise EmcidHipError("dgemm_batched: shapes do not agree")
+    _check(load().emcid_dgemm_batched_f64(ta, tb, M, N, K, float(alpha), _ptr(A, torch.float64), A.stride(1), A.stride(0),
+                                          _ptr(B, torch.float64), B.stride(1), B.stride(0), float(beta),
+                                          _ptr(Cm, torch.float64), Cm.stride(1), Cm.stride(0), nb, _stream(Cm)),
+           "emcid_dgemm_batched_f64")
     return Cm
 
 

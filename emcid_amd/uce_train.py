@@ -25,6 +25,7 @@ tightly and to the reference-minted fixture within that error.  No CPU fallback:
 from __future__ import annotations
 
 import ast
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -34,7 +35,8 @@ from . import hip, nethook
 from .layer_stats import get_all_cross_attn_kv_layer_names
 
 FORWARD_CHUNK = 512          # texts per encoder forward (x model_max_length tokens each)
-MAX_VALUE_COLS = 8192        # projections are processed in groups of at most this many output columns (fp64 M x cols buffers)
+MAX_VALUE_COLS = 8192        # value rows: projections are processed in groups of at most this many output columns (fp64 M x cols buffers)
+EDIT_CHUNK = 1024            # per-edit Grams: edits per batch (2 x chunk x d x d fp64 buffers)
 LAST_RUN: Dict[str, float] = {}
 
 
@@ -180,13 +182,105 @@ def _solve_group(Ko, Kn, Kr, seg, n_edits, weights, biases, L, inv, lamb, e, p_e
     return out
 
 
-def closed_form(Ko, Kn, Kr, seg, n_edits, weights, biases, lamb, erase_scale, preserve_scale, technique="tensor"):
+def _pad_edits(K: torch.Tensor, seg: torch.Tensor, n_edits: int) -> torch.Tensor:
+    """(M, d) rows grouped by edit (seg sorted) -> (n_edits, S, d), each edit's rows followed by zero rows."""
+    lens = torch.bincount(seg, minlength=n_edits)
+    S = int(lens.max().item())
+    S += S % 2                                                      # even leading dimension for the f64 GEMM
+    start = torch.cumsum(lens, 0) - lens
+    pos = torch.arange(S, device=K.device)
+    idx = torch.where(pos[None, :] < lens[:, None], start[:, None] + pos[None, :], K.shape[0])
+    return torch.cat([K, torch.zeros(1, K.shape[1], dtype=K.dtype, device=K.device)], 0)[idx]
+
+
+def _solve_shared(Ko, Kn, Kr, seg, n_edits, weights, L, inv, lamb, e, p_eff, technique):
+    """Bias-free projections that share the context rows (the UNet variant), without ever forming a value row:
+    S_l^T Ko = W_l (Kn^T Ko - sum_i alpha_li Ko_i^T Ko_i) with alpha_li = <W_l^T W_l, Ko_i^T Kn_i> / <W_l^T W_l, Ko_i^T Ko_i>
+    (Frobenius products), so the per-edit d x d Grams are formed ONCE (batched GEMM) and every projection costs two
+    contractions against them instead of two (M x d x out) GEMMs: ~25x fewer flops at SD-v1.4 shapes.
+    mat1_l = W_l B_l,  B_l = lam I + e (Kn^T Ko - sum_i alpha_li G_i) + p Kr^T Kr;  W_new,l = mat1_l mat2^-1."""
+    dev = Ko.device
+    d = Ko.shape[1]
+    dp = L.shape[0]
+    P = len(weights)
+    f64 = dict(dtype=torch.float64, device=dev)
+    base = torch.zeros(d, d, **f64)
+    base.diagonal().fill_(lamb)
+    if Ko.shape[0]:
+        hip.dgemm(1, 1, Kn, Ko, base, alpha=e, beta=1.0)             # e Kn^T Ko
+    if Kr.shape[0]:
+        hip.dgemm(1, 1, Kr, Kr, base, alpha=p_eff, beta=1.0)         # p Kr^T Kr
+    W64 = [w.detach().double().contiguous() for w in weights]
+    Bl = base.reshape(1, d * d).repeat(P, 1)                         # (P, d*d): B_l, row-major d x d each
+    if technique == "tensor" and Ko.shape[0]:
+        A = torch.empty(P, d * d, **f64)                             # W_l^T W_l
+        for k, w in enumerate(W64):
+            hip.dgemm(1, 1, w, w, A[k].view(d, d))
+        Kop, Knp = _pad_edits(Ko, seg, n_edits), _pad_edits(Kn, seg, n_edits)
+        for c0 in range(0, n_edits, EDIT_CHUNK):
+            c1 = min(n_edits, c0 + EDIT_CHUNK)
+            c = c1 - c0
+            ce = c + c % 2                                           # even, the spare slot stays zero
+            Goo = torch.zeros(ce, d, d, **f64)
+            Gon = torch.zeros(ce, d, d, **f64)
+            hip.dgemm_batched(1, 1, Kop[c0:c1], Kop[c0:c1], Goo[:c])
+            hip.dgemm_batched(1, 1, Kop[c0:c1], Knp[c0:c1], Gon[:c])
+            dot = torch.zeros(P, ce, **f64)
+            sq = torch.zeros(P, ce, **f64)
+            hip.dgemm(0, 0, A, Gon.view(ce, d * d), dot, beta=1.0)   # beta 1: the d*d-long contraction is split over workgroups
+            hip.dgemm(0, 0, A, Goo.view(ce, d * d), sq, beta=1.0)
+            alpha = torch.where(sq != 0, dot / sq, torch.zeros_like(dot))
+            if c < ce:
+                alpha[:, c:] = 0
+            hip.dgemm(0, 1, alpha, Goo.view(ce, d * d), Bl, alpha=-e, beta=1.0)
+            del Goo, Gon
+    rhs = torch.zeros(sum(w.shape[0] for w in W64), dp, **f64)
+    r0 = 0
+    for k, w in enumerate(W64):
+        hip.dgemm(0, 1, w, Bl[k].view(d, d), rhs[r0:r0 + w.shape[0], :d])
+        r0 += w.shape[0]
+    hip.cholesky_solve_(L, inv, rhs)
+    out, r0 = [], 0
+    for w in weights:
+        out.append(rhs[r0:r0 + w.shape[0], :d].to(w.dtype).contiguous())
+        r0 += w.shape[0]
+    return out
+
+
+def closed_form(Ko, Kn, Kr, seg, n_edits, weights, biases, lamb, erase_scale, preserve_scale, technique="tensor",
+                method="auto"):
     """The whole device side for projections that share their context rows: Ko / Kn (M, d) f64 old / new rows, seg (M,)
-    edit index per row, Kr (Mr, d) retain rows (context and value source alike), weights [(out_k, d)], biases
-    [(out_k,) | None].  Returns the new weights, in the dtype of the old ones."""
+    edit index per row (sorted), Kr (Mr, d) retain rows (context and value source alike), weights [(out_k, d)], biases
+    [(out_k,) | None].  method: "rows" forms the value rows (any projection), "grams" contracts per-edit Grams
+    (bias-free projections), "auto" = grams when no projection has a bias.  Returns the new weights, in the dtype of the
+    old ones."""
+    weights, biases = list(weights), list(biases)
+    if method == "auto":
+        method = "grams" if all(b is None for b in biases) else "rows"
     L, inv = _normal_matrix(Ko, Kr, float(lamb), float(erase_scale), float(preserve_scale))
-    return _solve_group(Ko, Kn, Kr, seg, n_edits, list(weights), list(biases), L, inv, float(lamb), float(erase_scale),
-                        float(preserve_scale), technique)
+    if method == "grams":
+        if any(b is not None for b in biases):
+            raise ValueError("method='grams' needs bias-free projections")
+        return _solve_shared(Ko, Kn, Kr, seg, n_edits, weights, L, inv, float(lamb), float(erase_scale),
+                             float(preserve_scale), technique)
+    out = []
+    for group in _column_groups(weights):
+        out += _solve_group(Ko, Kn, Kr, seg, n_edits, [weights[k] for k in group], [biases[k] for k in group], L, inv,
+                            float(lamb), float(erase_scale), float(preserve_scale), technique)
+    return out
+
+
+def _column_groups(weights) -> List[List[int]]:
+    groups, group, cols = [], [], 0
+    for k, w in enumerate(weights):
+        if group and cols + w.shape[0] > MAX_VALUE_COLS:
+            groups.append(group)
+            group, cols = [], 0
+        group.append(k)
+        cols += w.shape[0]
+    if group:
+        groups.append(group)
+    return groups
 
 
 def _require_gpu(pipe):
@@ -269,24 +363,12 @@ def edit_model_uce(ldm_stable, old_text_, new_text_, retain_text_, add=False, la
     Ko, Kn, Kr = _encode_rows(ldm_stable, ti.input_ids, (old_flat, new_flat, ret_flat), None)
     seg_d = torch.from_numpy(seg).to(ldm_stable.device)
     t1 = time.perf_counter()
-    L, inv = _normal_matrix(Ko, Kr, float(lamb), float(erase_scale), float(preserve_scale))
     mods = dict(ldm_stable.unet.named_modules())
-    group, cols = [], 0
-    groups = []
-    for name in wanted:
-        w = mods[name].weight
-        if group and cols + w.shape[0] > MAX_VALUE_COLS:
-            groups.append(group)
-            group, cols = [], 0
-        group.append(name)
-        cols += w.shape[0]
-    groups.append(group)
-    for group in groups:
-        new_ws = _solve_group(Ko, Kn, Kr, seg_d, n, [mods[g].weight for g in group], [mods[g].bias for g in group], L, inv,
-                              float(lamb), float(erase_scale), float(preserve_scale), technique)
-        for g, w in zip(group, new_ws):
-            mods[g].weight = torch.nn.Parameter(w)
+    new_ws = closed_form(Ko, Kn, Kr, seg_d, n, [mods[g].weight for g in wanted], [mods[g].bias for g in wanted], lamb,
+                         erase_scale, preserve_scale, technique, method=os.environ.get("EMCID_UCE_METHOD", "auto"))
+    for g, w in zip(wanted, new_ws):
+        mods[g].weight = torch.nn.Parameter(w)
     torch.cuda.synchronize()
-    LAST_RUN.update(rows=int(Ko.shape[0]), retain_rows=int(Kr.shape[0]), projections=len(wanted), groups=len(groups),
+    LAST_RUN.update(rows=int(Ko.shape[0]), retain_rows=int(Kr.shape[0]), projections=len(wanted),
                     forward_s=t1 - t0, solve_s=time.perf_counter() - t1)
     return ldm_stable

@@ -26,7 +26,7 @@ extern "C" {
 #define EMCID_ERR_HIP (-2)
 #define EMCID_ERR_WORKSPACE (-3)
 
-#define EMCID_ABI_VERSION 3
+#define EMCID_ABI_VERSION 4
 
 /* ABI version of the loaded library (host-only, no GPU needed). */
 int emcid_abi_version(void);
@@ -223,6 +223,14 @@ int emcid_dgemm_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alph
 int emcid_dgemm_ex_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
                        const double* A, int64_t lda, const double* B, int64_t ldb,
                        double beta, double* C, int64_t ldc, int flags, int cfg, int ksplit, void* stream);
+
+/* `batch` independent problems of one shape: C_b = alpha * opA(A_b) opB(B_b) + beta * C_b with A_b = A + b*sA etc.
+ * (element strides).  Used for the per-edit Grams sum_r k_r k_r^T of the UCE closed form (reference
+ * emcid/uce_train.py:170-176, :378-404, kept per edit there as well: one batch-2 forward and one outer-product sum per
+ * (edit, projection)). */
+int emcid_dgemm_batched_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
+                            const double* A, int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB,
+                            double beta, double* C, int64_t ldc, int64_t sC, int64_t batch, void* stream);
 
 /* W[h,d] += dW[h,d]  (final insert, reference: emcid_main.py:802-809 `w[...] += upd_matrix.float()`). */
 int emcid_axpy_f32(float* W, const float* dW, int64_t n, void* stream);

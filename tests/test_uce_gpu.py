@@ -33,8 +33,11 @@ def _closed_form_ref(Ko, Kn, Kr, seg, n, weights, biases, lamb, e, p, technique)
 
 
 @pytest.mark.parametrize("technique", ["tensor", "replace"])
-@pytest.mark.parametrize("d,outs,bias", [(96, (16, 24, 48), False), (128, (32,), True), (320, (64, 130), False)])
-def test_closed_form_matches_fp64_torch(technique, d, outs, bias):
+@pytest.mark.parametrize("d,outs,bias,method", [(96, (16, 24, 48), False, "rows"), (96, (16, 24, 48), False, "grams"),
+                                                (128, (32,), True, "rows"), (320, (64, 130), False, "rows"),
+                                                (320, (64, 130), False, "grams"), (128, (32, 32, 48), False, "auto")])
+def test_closed_form_matches_fp64_torch(technique, d, outs, bias, method):
+    """Both device-side forms of the same algebra (value rows; per-edit Grams) against fp64 torch on the CPU."""
     g = torch.Generator().manual_seed(d)
     n = 5
     lens = [7, 70, 33, 1, 64]
@@ -47,10 +50,33 @@ def test_closed_form_matches_fp64_torch(technique, d, outs, bias):
     bs = [torch.randn(o, generator=g) if bias else None for o in outs]
     want, _ = _closed_form_ref(Ko, Kn, Kr, seg, n, ws, bs, 0.1, 0.1, 0.3, technique)
     got = uce.closed_form(Ko.to(DEV), Kn.to(DEV), Kr.to(DEV), seg.to(DEV), n, [w.to(DEV) for w in ws],
-                          [None if b is None else b.to(DEV) for b in bs], 0.1, 0.1, 0.3, technique)
+                          [None if b is None else b.to(DEV) for b in bs], 0.1, 0.1, 0.3, technique, method=method)
     for gw, ww in zip(got, want):
         assert gw.dtype == torch.float32
         torch.testing.assert_close(gw.cpu().double(), ww, rtol=0, atol=2e-7 * ww.abs().max().item())
+
+
+def test_closed_form_grams_equals_rows_at_unet_width():
+    """SD-v1.4 cross-attention width (768 -> 320 / 640 / 1280), 40 edits of 60-76 rows, odd edit count, an edit chunk
+    smaller than the batch: the two device-side forms agree to fp32 rounding of the result."""
+    g = torch.Generator().manual_seed(11)
+    d, n = 768, 41
+    lens = torch.randint(60, 77, (n,), generator=g)
+    seg = torch.repeat_interleave(torch.arange(n), lens).to(DEV)
+    M = int(seg.numel())
+    Ko = torch.randn(M, d, generator=g).double().to(DEV)
+    Kn = torch.randn(M, d, generator=g).double().to(DEV)
+    Kr = torch.randn(154, d, generator=g).double().to(DEV)
+    ws = [(torch.randn(o, d, generator=g) / d ** 0.5).to(DEV) for o in (320, 640, 1280)]
+    rows = uce.closed_form(Ko, Kn, Kr, seg, n, ws, [None] * 3, 0.1, 0.1, 0.1, "tensor", method="rows")
+    old_chunk = uce.EDIT_CHUNK
+    uce.EDIT_CHUNK = 16
+    try:
+        grams = uce.closed_form(Ko, Kn, Kr, seg, n, ws, [None] * 3, 0.1, 0.1, 0.1, "tensor", method="grams")
+    finally:
+        uce.EDIT_CHUNK = old_chunk
+    for a, b in zip(rows, grams):
+        assert (a - b).abs().max().item() <= 3e-7 * a.abs().max().item()
 
 
 def test_closed_form_no_retain_and_no_edit_rows():
@@ -67,6 +93,23 @@ def test_closed_form_no_retain_and_no_edit_rows():
     # no rows at all: (lam W)(lam I)^-1 = W
     (same,) = uce.closed_form(empty.to(DEV), empty.to(DEV), empty.to(DEV), seg[:0].to(DEV), 0, [W.to(DEV)], [None], 0.5, 1.0, 0.1)
     torch.testing.assert_close(same.cpu(), W, rtol=0, atol=1e-6)
+
+
+def test_batched_dgemm():
+    from emcid_amd import hip
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(7, 20, 36, generator=g, dtype=torch.float64)
+    B = torch.randn(7, 20, 50, generator=g, dtype=torch.float64)
+    C0 = torch.randn(7, 36, 50, generator=g, dtype=torch.float64)
+    C = C0.clone().to(DEV)
+    hip.dgemm_batched(1, 1, A.to(DEV), B.to(DEV), C, alpha=0.5, beta=-1.0)           # A_b^T B_b
+    torch.testing.assert_close(C.cpu(), 0.5 * A.transpose(1, 2) @ B - C0, rtol=1e-12, atol=1e-12)
+    Bs = torch.randn(1, 50, 36, generator=g, dtype=torch.float64)
+    C = torch.zeros(7, 20, 50, dtype=torch.float64, device=DEV)
+    hip.dgemm_batched(0, 0, A.to(DEV), Bs.to(DEV).expand(7, 50, 36), C)              # shared B (batch stride 0): A_b Bs^T
+    torch.testing.assert_close(C.cpu(), A @ Bs[0].t(), rtol=1e-12, atol=1e-12)
+    with pytest.raises(hip.EmcidHipError):
+        hip.dgemm_batched(0, 0, A.to(DEV), B.to(DEV), C)
 
 
 def test_closed_form_normal_equation_at_sd_dims():
