@@ -30,14 +30,25 @@ constexpr int GBK = 16;   // tokens per stage
 // has per-element tails, whose branches serialise the loads behind `s_waitcnt vmcnt(0)`.
 template <int MI, bool ALIGNED, bool FAST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void gram_f32_kernel(const float* __restrict__ X, int t, int d, int64_t ldx,
-                                                        float* __restrict__ G, int64_t ldg, int kchunk, int use_atomic) {
+                                                        float* __restrict__ G, int64_t ldg, int kchunk, int use_atomic,
+                                                        int ksplit) {
     constexpr int BMT = 64 * MI;                    // tile rows
     constexpr int STAGE = GBK * (BMT + GB);         // floats per stage: A image [GBK][BMT], then B image [GBK][GB]
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
-    const int bm = blockIdx.y, bn = blockIdx.x;
+    // 1-D grid over (lower tile, token slab), slab fastest.  Workgroups go to the 8 XCDs round-robin by linear id: with a
+    // (bn, bm, z) grid of 24 x 24 tiles the XCD was bn % 8 and XCD 0 owned 48 of the 300 lower tiles, XCD 7 only 27 — the
+    // launch lasted as long as XCD 0 (78 % balance).  Here consecutive ids are the slabs of ONE tile, so with the slab
+    // count a multiple of 8 every XCD gets the same number of (tile, slab) pairs and only ever reads its own eighth of
+    // the token rows (each XCD's L2 then holds 1/8 of X instead of all of it).
+    static_assert(BMT == GB, "the triangular tile numbering assumes square tiles");
+    const int z = blockIdx.x % ksplit;
+    const int L = blockIdx.x / ksplit;
+    int bm = (int)((__builtin_sqrt(8.0 * L + 1.0) - 1.0) * 0.5);
+    while ((bm + 1) * (bm + 2) / 2 <= L) ++bm;      // guard the rounding of the square root
+    while (bm * (bm + 1) / 2 > L) --bm;
+    const int bn = L - bm * (bm + 1) / 2;
     const int m0 = bm * BMT, n0 = bn * GB;
-    if (n0 >= m0 + BMT) return;  // tile entirely above the diagonal
-    const int k_begin = blockIdx.z * kchunk;
+    const int k_begin = z * kchunk;
     const int k_end = min(t, k_begin + kchunk);
     if (k_begin >= k_end) return;
 
@@ -232,18 +243,20 @@ int emcid_gram_accumulate_f32(const float* X, int64_t t, int64_t d, int64_t ldx,
         const int64_t want = (6144 + lower - 1) / lower;
         const int64_t maxsplit = t >= 4096 ? t / 1024 : (((t + 255) / 256) < 4 ? (t + 255) / 256 : 4);
         ksplit = (int)(want < maxsplit ? want : maxsplit);
+        if (ksplit >= 8) ksplit = (ksplit + 4) / 8 * 8;      // a multiple of the XCD count: see the kernel's grid comment
         if (ksplit < 1) ksplit = 1;
     }
     int64_t kchunk = round_up((t + ksplit - 1) / ksplit, GBK);
     ksplit = (int)((t + kchunk - 1) / kchunk);
-    dim3 grid(tiles, tiles, ksplit);
+    EMCID_CHECK_ARG(lower * ksplit < (1LL << 31));
+    dim3 grid((unsigned)(lower * ksplit));
     ScopedProf sp(KC_GRAM, (hipStream_t)stream);
     const int atomic = ksplit > 1 ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     // FAST needs every tile column inside the matrix and 32-bit element offsets inside one 16-row stage
     const bool fast = d % GB == 0 && ldx * GBK < (1LL << 30);
 #define EMCID_GRAM_LAUNCH(AL_, FA_) \
-    hipLaunchKernelGGL((gram_f32_kernel<2, AL_, FA_>), grid, dim3(256), 0, st, X, (int)t, (int)d, ldx, G, ldg, (int)kchunk, atomic)
+    hipLaunchKernelGGL((gram_f32_kernel<2, AL_, FA_>), grid, dim3(256), 0, st, X, (int)t, (int)d, ldx, G, ldg, (int)kchunk, atomic, ksplit)
     if (d % 4 != 0) EMCID_GRAM_LAUNCH(false, false);
     else if (!fast) EMCID_GRAM_LAUNCH(true, false);
     else EMCID_GRAM_LAUNCH(true, true);
