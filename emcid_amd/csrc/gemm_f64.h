@@ -132,6 +132,7 @@ struct GemmShape {
     // pair = 1 (with a triangular operand): one workgroup computes tile j and tile ntiles-1-j of the triangular
     // dimension, so all workgroups do equal work; the grid is halved along that dimension
     int pair = 0;
+    int xcd_rows = 0;   // number tile rows fastest (set by the launcher for B-side triangles; see gemm_f64_kernel)
 };
 
 // WGM x WGN waves per workgroup; each wave owns a (BM/WGM) x (BN/WGN) sub-tile.
@@ -252,9 +253,19 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Ep
             gemm_f64_tile<KCA, KCB, BM, BN, BK, WGM, WGN>(p, epi, by_n ? (int)blockIdx.y : second, by_n ? second : (int)blockIdx.x, zs, smem);
         return;
     }
+    // Workgroups go to the 8 XCDs round-robin by linear id (x fastest).  When the K range depends on the tile COLUMN
+    // (B-side triangle) and the column count is a multiple of 8, XCD = column % 8 and one XCD owns all the long columns
+    // (8 columns of a 512-block: 8x the work of the XCD with the short ones) — number the tile ROWS fastest instead, so
+    // that every XCD sees every column.  `xcd_rows` (set by the launcher, env EMCID_GEMM_XCD_ROWS=0 disables) selects it.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_rows) {
+        const int lin = bx + gridDim.x * by;
+        by = lin % gridDim.y;
+        bx = lin / gridDim.y;
+    }
     // tiles whose K range grows with n (tri & 1) or m (tri & 4) are numbered from the far end: long ranges start first
-    const int bm = (p.tri & 4) ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
-    const int bn = (p.tri & 1) ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const int bm = (p.tri & 4) ? gridDim.y - 1 - by : by;
+    const int bn = (p.tri & 1) ? gridDim.x - 1 - bx : bx;
     gemm_f64_tile<KCA, KCB, BM, BN, BK, WGM, WGN>(p, epi, bm, bn, zs, smem);
 }
 
@@ -436,6 +447,8 @@ inline void launch_gemm_f64(GemmShape p, Epi epi, hipStream_t stream, int force_
     if (p.ksplit > 1) epi_set_atomic(epi);
     const unsigned gz = (unsigned)(p.batch * p.batch2 * p.ksplit);
     if (p.pair && (p.tri == 0 || p.lower_only)) p.pair = 0;
+    static const int env_xcd_rows = [] { const char* v = getenv("EMCID_GEMM_XCD_ROWS"); return v ? atoi(v) : 1; }();
+    p.xcd_rows = (env_xcd_rows && (p.tri & 3) && !(p.tri & 12) && !p.lower_only && !p.pair) ? 1 : 0;
     const bool pair_n = p.pair && (p.tri & 3), pair_m = p.pair && !(p.tri & 3);
     auto half = [](unsigned n, bool h) { return h ? (n + 1) / 2 : n; };
     if (cfg == 0) {
