@@ -133,9 +133,49 @@ struct GemmShape {
     // dimension, so all workgroups do equal work; the grid is halved along that dimension
     int pair = 0;
     int xcd_rows = 0;   // number tile rows fastest (set by the launcher for B-side triangles; see gemm_f64_kernel)
+    int pf = 0;         // small tiles: keep PF K-tiles of global loads in flight (set by the launcher; see gemm_f64_tile)
 };
 
 // WGM x WGN waves per workgroup; each wave owns a (BM/WGM) x (BN/WGN) sub-tile.
+// The same share of a tile WITHOUT branches: every 16-byte vector is either wholly inside or wholly outside the operand
+// (the caller guarantees an even extent along the contiguous dimension), so the load is unconditional from a clamped
+// address and `ok` says whether it counts.  The zeroing select is applied by store_tile_masked, i.e. after the MFMAs of
+// the stage, so that nothing waits on the loads where they are issued and several K tiles can be in flight.
+// `tile_valid` = false turns the whole call into dummy loads of g[0]: the ring issues the SAME number of loads on every
+// path (a load skipped under a branch makes the compiler's s_waitcnt for an older set fall back to vmcnt(0)).
+template <bool KC, int ROWS, int BK, int NT>
+__device__ __forceinline__ void load_tile_nobranch(v2d (&reg)[ROWS * BK / 2 / NT], bool (&ok)[ROWS * BK / 2 / NT],
+                                                   const double* __restrict__ g, int64_t ld, int row0, int rows_total, int k0,
+                                                   int K, int tid, bool tile_valid) {
+    constexpr int NV = ROWS * BK / 2 / NT;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * NT;
+        int r, k;
+        if (KC) { r = row0 + v / (BK / 2); k = k0 + 2 * (v % (BK / 2)); }
+        else    { k = k0 + v / (ROWS / 2); r = row0 + 2 * (v % (ROWS / 2)); }
+        ok[i] = tile_valid && r < rows_total && k < K;
+        const double* p = ok[i] ? (KC ? g + (int64_t)r * ld + k : g + (int64_t)k * ld + r) : g;
+        reg[i] = *reinterpret_cast<const v2d*>(p);
+    }
+}
+
+template <bool KC, int ROWS, int BK, int NT>
+__device__ __forceinline__ void store_tile_masked(const v2d (&reg)[ROWS * BK / 2 / NT], const bool (&ok)[ROWS * BK / 2 / NT],
+                                                  double* lds, int tid) {
+    constexpr int NV = ROWS * BK / 2 / NT;
+    using T = OpTile<KC, ROWS, BK>;
+    const v2d zero = {0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * NT;
+        int o;
+        if (KC) o = (v / (BK / 2)) * T::LD + 2 * (v % (BK / 2));
+        else    o = (v / (ROWS / 2)) * T::LD + 2 * (v % (ROWS / 2));
+        *reinterpret_cast<v2d*>(lds + o) = ok[i] ? reg[i] : zero;
+    }
+}
+
 // One output tile (bm, bn), K tiles restricted by `tri`, split zs of the K range.
 template <bool KCA, bool KCB, int BM, int BN, int BK, int WGM, int WGN, class Epi>
 __device__ __forceinline__ void gemm_f64_tile(const GemmShape& p, const Epi& epi, int bm, int bn, int zs, double* smem,
@@ -179,6 +219,76 @@ __device__ __forceinline__ void gemm_f64_tile(const GemmShape& p, const Epi& epi
         t0 += zs * per;
         t1 = min(t1, t0 + per);
         if (t0 >= t1) return;
+    }
+
+    auto mfma_stage = [&](const double* As, const double* Bs) {
+#pragma unroll
+        for (int k8 = 0; k8 < BK / 8; ++k8) {
+            double a[2][MI], b[2][NI];
+            TA::template frags<MI>(As, wm0, k8, l15, l4, a);
+            TB::template frags<NI>(Bs, wn0, k8, l15, l4, b);
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e][i], b[e][j], acc[i][j], 0, 0, 0);
+        }
+    };
+    auto epilogue = [&]() {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm0 + TA::index_of(i, l4 + 4 * r);
+                    const int n = n0 + wn0 + TB::index_of(j, l15);
+                    if (m < p.M && n < p.N) epi(m, n, acc[i][j][r]);
+                }
+    };
+
+    // Small tiles (a wave has 8-16 MFMAs per K tile, ~0.2-0.4 us) at one workgroup per CU are bound by the global-load
+    // latency when only the next K tile is in flight: a 32 x 64 tile took 0.9 us per K tile.  Here PF K tiles are in
+    // flight in PF register sets (3-6 vectors each at these sizes); LDS stays double-buffered.  The loads are
+    // branch-free (load_tile_nobranch), so the compiler can wait for the oldest set only (counted vmcnt).
+    if constexpr (BM * BN <= 64 * 64) {
+        if (p.pf) {
+            constexpr int PF = 4, NA = TA::NVEC / NT, NB = TB::NVEC / NT;
+            v2d qa[PF][NA], qb[PF][NB];
+            bool oa[PF][NA], ob[PF][NB];
+#pragma unroll
+            for (int s = 0; s < PF; ++s) {
+                load_tile_nobranch<KCA, BM, BK, NT>(qa[s], oa[s], p.A, p.lda, m0, p.M, (t0 + s) * BK, p.K, tid, t0 + s < t1);
+                load_tile_nobranch<KCB, BN, BK, NT>(qb[s], ob[s], p.B, p.ldb, n0, p.N, (t0 + s) * BK, p.K, tid, t0 + s < t1);
+            }
+            store_tile_masked<KCA, BM, BK, NT>(qa[0], oa[0], smem, tid);
+            store_tile_masked<KCB, BN, BK, NT>(qb[0], ob[0], smem + TA::SIZE, tid);
+            __syncthreads();
+            for (int base = t0; base < t1; base += PF) {
+#pragma unroll
+                for (int s = 0; s < PF; ++s) {
+                    const int t = base + s;          // tile t is in LDS stage s & 1 (base - t0 is a multiple of PF)
+                    if (t < t1) {
+                        const double* As = smem + (s & 1) * STAGE;
+                        // set s is free (its tile went to LDS one step ago); past the end these are dummy loads
+                        load_tile_nobranch<KCA, BM, BK, NT>(qa[s], oa[s], p.A, p.lda, m0, p.M, (t + PF) * BK, p.K, tid, t + PF < t1);
+                        load_tile_nobranch<KCB, BN, BK, NT>(qb[s], ob[s], p.B, p.ldb, n0, p.N, (t + PF) * BK, p.K, tid, t + PF < t1);
+                        mfma_stage(As, As + TA::SIZE);
+                        {   // tile t+1 (zeros past the end: never read) into the other LDS stage
+                            const int sn = (s + 1) % PF;   // a constant once the s loop is unrolled
+                            double* An = smem + (sn & 1) * STAGE;
+                            store_tile_masked<KCA, BM, BK, NT>(qa[sn], oa[sn], An, tid);
+                            store_tile_masked<KCB, BN, BK, NT>(qb[sn], ob[sn], An + TA::SIZE, tid);
+                        }
+                        __syncthreads();
+                    }
+                }
+            }
+            epilogue();
+            return;
+        }
     }
 
     v2d ra[TA::NVEC / NT], rb[TB::NVEC / NT];
@@ -449,6 +559,9 @@ inline void launch_gemm_f64(GemmShape p, Epi epi, hipStream_t stream, int force_
     if (p.pair && (p.tri == 0 || p.lower_only)) p.pair = 0;
     static const int env_xcd_rows = [] { const char* v = getenv("EMCID_GEMM_XCD_ROWS"); return v ? atoi(v) : 1; }();
     p.xcd_rows = (env_xcd_rows && (p.tri & 3) && !(p.tri & 12) && !p.lower_only && !p.pair) ? 1 : 0;
+    // prefetch ring for the small-tile configurations: needs an even extent along each operand's contiguous dimension
+    static const int env_pf = [] { const char* v = getenv("EMCID_GEMM_PF"); return v ? atoi(v) : 1; }();
+    p.pf = (env_pf && cfg != 0 && ((KCA ? p.K : p.M) % 2 == 0) && ((KCB ? p.K : p.N) % 2 == 0)) ? 1 : 0;
     const bool pair_n = p.pair && (p.tri & 3), pair_m = p.pair && !(p.tri & 3);
     auto half = [](unsigned n, bool h) { return h ? (n + 1) / 2 : n; };
     if (cfg == 0) {
