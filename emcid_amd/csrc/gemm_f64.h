@@ -535,7 +535,10 @@ inline void launch_gemm_f64(GemmShape p, Epi epi, hipStream_t stream, int force_
     };
     const int64_t big_tiles = tiles(128, 128), mid_tiles = tiles(64, 64);
     // measured on the M ~ 1000 solve shapes (scripts/mb_shapes.py): 32x64 beats 64x64 whenever 128x128 cannot fill the chip
-    int cfg = (big_tiles >= 224) ? 0 : (KCA ? 2 : 1);
+    // (re-measured with the prefetch ring in the small-tile kernels: 32x64 also wins between 224 and 512 big tiles, e.g.
+    // the batched Cholesky trailing updates: chol_trail 0.93 -> 0.86 ms per step)
+    static const int big_min = [] { const char* v = getenv("EMCID_GEMM_BIG"); return v ? atoi(v) : 512; }();      // experiments
+    int cfg = (big_tiles >= big_min) ? 0 : (KCA ? 2 : 1);
     if (force_cfg >= 0) cfg = force_cfg;
     static const int env_cfg = [] { const char* v = getenv("EMCID_GEMM_CFG"); return v ? atoi(v) : -1; }();      // experiments
     static const int env_split = [] { const char* v = getenv("EMCID_GEMM_KSPLIT"); return v ? atoi(v) : -1; }();

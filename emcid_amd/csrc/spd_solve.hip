@@ -524,7 +524,7 @@ static void build_block_inverses(const double* L, int64_t dp, int64_t lda, doubl
         p.tri = b_lower ? 2 : 0;   // B stored [k][n] and lower triangular: zero for k < n
         EpiAxpby e{C, ldC, alpha, 0.0, sC};
         e.sC2 = sC2;
-        launch_gemm_f64<true, false>(p, e, st, 1);
+        launch_gemm_f64<true, false>(p, e, st, 2);
     };
     ScopedProf sp(KC_INV_BLOCK, st);
     const int64_t sI = (int64_t)OB * OB, sT = (int64_t)TB * TB, sL = (int64_t)OB * lda + OB;
