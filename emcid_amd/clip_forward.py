@@ -251,13 +251,14 @@ def tune_projections(graph: ClipTextGraph, trie: TokenTrie, upto: int, mode: str
     return time.perf_counter() - t0
 
 
-def build_trie_packed(seqs: Sequence[Sequence[int]], device, bucket: int = ROW_BUCKET):
+def build_trie_packed(seqs: Sequence[Sequence[int]], device, bucket: int = ROW_BUCKET, return_nodes: bool = False):
     """Trie over WHOLE token sequences (Stage 0: every attended token of every caption is a lookup), built level by level
     with numpy — the Python loop of ``build_trie`` costs ~1 us per token, too slow for millions of caption tokens.
 
     Returns (TokenTrie, count): ``count[u]`` = number of sequences that pass through node u, i.e. how many (caption,
     position) pairs the node's row stands for; the rows are a multiset of size ``count.sum()`` = total tokens.
-    ``lookup_node`` / ``query_rows`` / ``lookup_in_query`` are empty: every node is wanted."""
+    ``lookup_node`` / ``query_rows`` / ``lookup_in_query`` are empty: every node is wanted.
+    ``return_nodes``: also return the (n, lmax) int64 array of the node of every (sequence, position), -1 past the end."""
     n = len(seqs)
     lens = np.fromiter((len(s) for s in seqs), dtype=np.int64, count=n)
     lmax = int(lens.max())
@@ -268,6 +269,7 @@ def build_trie_packed(seqs: Sequence[Sequence[int]], device, bucket: int = ROW_B
         tok[i, :len(s)] = s
     vocab = int(tok.max()) + 1
     node_of = np.full(n, -1, dtype=np.int64)          # node of each sequence at the previous level
+    nodes = np.full((n, lmax), -1, dtype=np.int64) if return_nodes else None
     tokens, parents, depths, counts, level_nodes = [], [], [], [], []
     total = 0
     for p in range(lmax):
@@ -278,6 +280,8 @@ def build_trie_packed(seqs: Sequence[Sequence[int]], device, bucket: int = ROW_B
         uniq, inverse, cnt = np.unique(key, return_inverse=True, return_counts=True)
         ids = total + np.arange(uniq.size)
         node_of[alive] = ids[inverse]
+        if return_nodes:
+            nodes[alive, p] = node_of[alive]
         tokens.append(uniq % vocab)
         parents.append(uniq // vocab - 1)
         depths.append(np.full(uniq.size, p, dtype=np.int32))
@@ -304,7 +308,8 @@ def build_trie_packed(seqs: Sequence[Sequence[int]], device, bucket: int = ROW_B
     trie = TokenTrie(torch.from_numpy(token).to(device), torch.from_numpy(depth.astype(np.int32)).to(device),
                      torch.from_numpy(anc).to(device), empty64, torch.zeros(0, dtype=torch.int32, device=device), empty64,
                      n_real, n * lmax)
-    return trie, torch.from_numpy(count.astype(np.float32)).to(device)
+    count_t = torch.from_numpy(count.astype(np.float32)).to(device)
+    return (trie, count_t, nodes) if return_nodes else (trie, count_t)
 
 
 def _check_fp32(graph: ClipTextGraph):

@@ -31,7 +31,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import hip, nethook
+from . import clip_forward, hip, nethook
 from .layer_stats import get_all_cross_attn_kv_layer_names
 
 FORWARD_CHUNK = 512          # texts per encoder forward (x model_max_length tokens each)
@@ -75,7 +75,54 @@ def row_windows(attention_mask: np.ndarray, n_edits: int, n_rows: int):
     return np.concatenate(old_flat), np.concatenate(new_flat), np.concatenate(seg)
 
 
+def _encode_rows_packed(pipe, ids: torch.Tensor, flat_sets: Sequence[np.ndarray], tap_module: Optional[str]):
+    """The same rows through the explicit CLIP forward over the prefix trie of the padded token rows (the encoder is
+    called with input_ids only, so padding positions are ordinary causal tokens): identical texts — the usual case for
+    the new / anchor concept — and shared beginnings are computed once.  Raises UnsupportedEncoder for anything that is
+    not an HF CLIP text model in fp32; the caller then takes the hooked forward."""
+    dev = pipe.device
+    te = pipe.text_encoder
+    names = [n for n, _ in te.named_modules() if n.endswith("encoder.layers.0")]
+    if not names:
+        raise clip_forward.UnsupportedEncoder("no encoder.layers")
+    graph = clip_forward.discover(te, names[0][:-1] + "{}")
+    trie, _, nodes = clip_forward.build_trie_packed(ids.tolist(), dev, return_nodes=True)
+    if tap_module is None:
+        if graph.final_layer_norm is None:
+            raise clip_forward.UnsupportedEncoder("no final_layer_norm")
+        hs = clip_forward.run_layers(graph, trie, len(graph.layers) - 1, None, last_rows_only=False)
+        feats = graph.final_layer_norm(hs)
+    else:
+        mods = dict(te.named_modules())
+        layer = next(i for i, l in enumerate(graph.layers) if l.fc2 is mods[tap_module])
+        box = {}
+
+        def on_fc2(i, x, out):
+            if i == layer:
+                box["x"] = x
+                return None                      # stop: nothing after the tapped fc2 input is needed
+            return out
+        clip_forward.run_layers(graph, trie, layer, on_fc2, last_rows_only=False, fc2_by_callback={layer})
+        feats = box["x"]
+    flat_nodes = torch.from_numpy(nodes.reshape(-1)).to(dev)
+    return [feats.index_select(0, flat_nodes.index_select(0, torch.from_numpy(np.asarray(f, dtype=np.int64)).to(dev))).double()
+            for f in flat_sets]
+
+
 def _encode_rows(pipe, ids: torch.Tensor, flat_sets: Sequence[np.ndarray], tap_module: Optional[str]):
+    """Context / value-source rows: the packed explicit forward when the encoder allows it, else the hooked HF forward."""
+    if os.environ.get("EMCID_UCE_FORWARD", "packed") == "packed":
+        try:
+            out = _encode_rows_packed(pipe, ids, flat_sets, tap_module)
+            LAST_RUN["forward"] = "packed-trie"
+            return out
+        except clip_forward.UnsupportedEncoder:
+            pass
+    LAST_RUN["forward"] = "hooked"
+    return _encode_rows_hooked(pipe, ids, flat_sets, tap_module)
+
+
+def _encode_rows_hooked(pipe, ids: torch.Tensor, flat_sets: Sequence[np.ndarray], tap_module: Optional[str]):
     """Run the encoder over the token rows `ids` in chunks and return, per index set, the fp64 rows at those flat
     (text*S + pos) positions of either the tapped module's INPUT (fc2 variant) or the encoder's output [0] (cross-attention
     variant).  input_ids only, as the reference calls it (uce_train.py:105, :298)."""

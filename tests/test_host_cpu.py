@@ -304,7 +304,13 @@ def test_packed_trie_is_the_prefix_multiset_of_the_captions():
         seqs.append([7] + [int(t) for t in rng.integers(0, 4, size=n - 1)])   # tiny vocabulary: many shared prefixes
     seqs.append(list(seqs[0]))                                                # an exact duplicate caption
     want = Counter(tuple(s[:i + 1]) for s in seqs for i in range(len(s)))
-    trie, count = cf.build_trie_packed(seqs, "cpu", bucket=16)
+    trie, count, nodes = cf.build_trie_packed(seqs, "cpu", bucket=16, return_nodes=True)
+    tok_np, anc_np = trie.token.numpy(), trie.anc.numpy()
+    for i, sq in enumerate(seqs):          # the node of (sequence, position) spells exactly that prefix
+        for pos in (0, len(sq) // 2, len(sq) - 1):
+            u = nodes[i, pos]
+            assert [int(tok_np[a]) for a in anc_np[u, :pos + 1]] == sq[:pos + 1]
+        assert (nodes[i, len(sq):] == -1).all()
     got = _trie_prefix_multiset(trie, count.numpy())
     assert got == dict(want)
     assert int(count.sum()) == sum(len(s) for s in seqs)

@@ -198,3 +198,22 @@ def test_uce_text_encoder_variant_at_sd_dims_vs_oracle():
     # amplifies that (the closed form itself agrees with fp64 torch to 2e-7 on shared inputs, tests above)
     err = (got - want).abs().max().item() / want.abs().max().item()
     assert err <= 2e-4, err
+
+
+@pytest.mark.parametrize("tap", [None, "encoder.layers.3.mlp.fc2"])
+def test_uce_packed_forward_rows_equal_hooked_forward_rows(tap):
+    """The rows the closed form consumes, through the explicit prefix-trie forward and through the hooked HF forward
+    (final text embeddings for the UNet variant, fc2 inputs for the text-encoder variant), duplicates included."""
+    z, meta = load_golden("toy_uce")
+    pipe = uce_pipe_from_golden(z, DEV)
+    texts = [t for pr in zip(meta["old"], [(" " if t == "" else t) for t in meta["new"]]) for t in pr] + ["painting", "painting", ""]
+    ti = uce._tokenize(pipe.tokenizer, texts)
+    S = ti.input_ids.shape[1]
+    o_flat, n_flat, _ = uce.row_windows(ti.attention_mask.numpy(), len(meta["old"]), S)
+    r_flat = 2 * len(meta["old"]) * S + np.arange(3 * S)
+    a = uce._encode_rows_packed(pipe, ti.input_ids, (o_flat, n_flat, r_flat), tap)
+    b = uce._encode_rows_hooked(pipe, ti.input_ids, (o_flat, n_flat, r_flat), tap)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and x.dtype == torch.float64
+        assert (x - y).abs().max().item() <= 2e-5 * y.abs().max().item()
+    assert torch.equal(a[2][:S], a[2][S:2 * S])          # the duplicated text is one set of trie nodes
