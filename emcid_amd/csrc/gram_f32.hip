@@ -242,7 +242,11 @@ int emcid_gram_accumulate_f32(const float* X, int64_t t, int64_t d, int64_t ldx,
         // (measured at d 3072: 76 -> 94 SYRK-TF from 4 to 20 splits), but chunks of >= 1024 tokens, so the 64 KB of
         // atomics a workgroup ends with stay small beside the 1 KB per token it streams; short inputs: >= 256 tokens.
         const int64_t want = (6144 + lower - 1) / lower;
-        const int64_t maxsplit = t >= 4096 ? t / 1024 : (((t + 255) / 256) < 4 ? (t + 255) / 256 : 4);
+        int64_t maxsplit = t >= 4096 ? t / 1024 : (((t + 255) / 256) < 4 ? (t + 255) / 256 : 4);
+        // few tiles (d = 768: 21): 1024-token slabs cannot even give every CU a workgroup — go down to 256-token slabs
+        // until the chip has ~4 workgroups per CU; the atomics of 21 tiles are small at any split
+        const int64_t fill = (1024 + lower - 1) / lower, fine = (t + 255) / 256;
+        if (maxsplit < fill) maxsplit = fill < fine ? fill : fine;
         ksplit = (int)(want < maxsplit ? want : maxsplit);
         if (ksplit >= 8) ksplit = (ksplit + 4) / 8 * 8;      // a multiple of the XCD count: see the kernel's grid comment
         if (ksplit < 1) ksplit = 1;
