@@ -134,6 +134,8 @@ struct GemmShape {
     int pair = 0;
     int xcd_rows = 0;   // number tile rows fastest (set by the launcher for B-side triangles; see gemm_f64_kernel)
     int pf = 0;         // small tiles: keep PF K-tiles of global loads in flight (set by the launcher; see gemm_f64_tile)
+    int lo_total = 0;   // lower-only square outputs: number of tiles that touch the lower triangle (> 0: the kernel
+                        // enumerates exactly those, row by row, from the linear workgroup id; see gemm_f64_kernel)
 };
 
 // WGM x WGN waves per workgroup; each wave owns a (BM/WGM) x (BN/WGN) sub-tile.
@@ -367,6 +369,21 @@ __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Ep
     // (B-side triangle) and the column count is a multiple of 8, XCD = column % 8 and one XCD owns all the long columns
     // (8 columns of a 512-block: 8x the work of the XCD with the short ones) — number the tile ROWS fastest instead, so
     // that every XCD sees every column.  `xcd_rows` (set by the launcher, env EMCID_GEMM_XCD_ROWS=0 disables) selects it.
+    if (p.lo_total > 0) {
+        // Lower-only square output: with the (bn, bm) grid the XCD (= linear id % 8 = bn % 8 when the column count is a
+        // multiple of 8) that owns tile column 0 gets 17 % more tiles than the average (80 x 40 tiles of 32 x 64) and the
+        // launch lasts as long as that XCD.  Number only the tiles that exist, row by row: consecutive ids alternate
+        // over the XCDs and share their A rows.  Row bm has bm / r + 1 tiles (r = BN / BM).
+        constexpr int r = BN / BM;
+        const int L = blockIdx.x + gridDim.x * blockIdx.y;
+        if (L >= p.lo_total) return;
+        int q = (int)((__builtin_sqrt(8.0 * L / r + 1.0) - 1.0) * 0.5);
+        while (r * (q + 1) * (q + 2) / 2 <= L) ++q;      // guard the rounding of the square root
+        while (r * q * (q + 1) / 2 > L) --q;
+        const int rem = L - r * q * (q + 1) / 2;
+        gemm_f64_tile<KCA, KCB, BM, BN, BK, WGM, WGN>(p, epi, r * q + rem / (q + 1), rem % (q + 1), zs, smem);
+        return;
+    }
     int bx = blockIdx.x, by = blockIdx.y;
     if (p.xcd_rows) {
         const int lin = bx + gridDim.x * by;
@@ -565,6 +582,12 @@ inline void launch_gemm_f64(GemmShape p, Epi epi, hipStream_t stream, int force_
     // prefetch ring for the small-tile configurations: needs an even extent along each operand's contiguous dimension
     static const int env_pf = [] { const char* v = getenv("EMCID_GEMM_PF"); return v ? atoi(v) : 1; }();
     p.pf = (env_pf && cfg != 0 && ((KCA ? p.K : p.M) % 2 == 0) && ((KCB ? p.K : p.N) % 2 == 0)) ? 1 : 0;
+    static const int env_lo = [] { const char* v = getenv("EMCID_GEMM_LO_ENUM"); return v ? atoi(v) : 1; }();
+    if (env_lo && p.lower_only && !p.pair && p.tri == 0 && p.M == p.N) {
+        const int bm_ = cfg == 0 ? 128 : cfg == 1 ? 64 : 32, r_ = (cfg == 0 ? 128 : 64) / bm_;
+        const int gy_ = (p.M + bm_ - 1) / bm_, q_ = gy_ / r_, s_ = gy_ % r_;
+        p.lo_total = r_ * q_ * (q_ + 1) / 2 + s_ * (q_ + 1);
+    }
     const bool pair_n = p.pair && (p.tri & 3), pair_m = p.pair && !(p.tri & 3);
     auto half = [](unsigned n, bool h) { return h ? (n + 1) / 2 : n; };
     if (cfg == 0) {
