@@ -10,7 +10,9 @@ strings are memoised per tokenizer, so the walk costs one dict lookup per token 
 ``tokenizer.decode`` call.
 """
 import unicodedata
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
 
 
 def decode_tokens(tokenizer, token_array):
@@ -23,6 +25,9 @@ class TokenRangeFinder:
     def __init__(self, tokenizer):
         self.tokenizer = tokenizer
         self._piece: Dict[int, str] = {}
+        self._plen: Optional[np.ndarray] = None      # len(decode([t])) per token id, -1 = not decoded yet
+        self._piece_ns: List[Optional[str]] = []     # decode([t]) without spaces ("\ufffd" if it holds a replacement char)
+        self._suffix = False                         # see _compositional (False = not probed yet)
 
     def _pieces(self, ids: Sequence[int]) -> List[str]:
         out = []
@@ -33,12 +38,121 @@ class TokenRangeFinder:
             out.append(s)
         return out
 
+    def _decode_whole(self):
+        """Whole-prompt decoder: ``tokenizer.decode(ids)`` — for a tokenizers-backed HF tokenizer the backend call that
+        ``decode`` wraps (transformers ``TokenizersBackend._decode``: backend decode, then ``clean_up_tokenization``, which
+        only ever deletes SPACES; the walk below strips every space first, so the two are interchangeable here)."""
+        bt = getattr(self.tokenizer, "_tokenizer", None)
+        if bt is not None and type(self.tokenizer).__mro__[1].__name__ == "TokenizersBackend" and hasattr(bt, "decode"):
+            dec = bt.decode
+            return lambda ids: dec(ids, skip_special_tokens=False)
+        return self.tokenizer.decode
+
+    def _compositional(self) -> Optional[str]:
+        """The end-of-word suffix if this is a byte-level BPE tokenizer, whose ``decode`` is compositional: the text is
+        the UTF-8 decoding of the concatenated token bytes (tokenizers' ByteLevel decoder), then — CLIP — every
+        end-of-word suffix becomes a space.  Whenever each token's own bytes are valid UTF-8 (its single-token decode has
+        no U+FFFD), decode(ids) equals the concatenation of the single-token decodes up to SPACES, which the search
+        strips anyway.  ``batch`` then never decodes a whole row; rows with a U+FFFD piece, or whose concatenation still
+        shows the suffix (formed across a token boundary), take the whole-row decode.  None: not such a tokenizer."""
+        if self._suffix is not False:
+            return self._suffix
+        self._suffix = None
+        bt = getattr(self.tokenizer, "_tokenizer", None)
+        try:
+            if bt is not None and type(bt.model).__name__ == "BPE" and type(bt.decoder).__name__ == "ByteLevel":
+                self._suffix = bt.model.end_of_word_suffix or ""
+        except Exception:
+            self._suffix = None
+        return self._suffix
+
+    def _row_strings(self, ids: np.ndarray, rows, need) -> List[Optional[str]]:
+        """Space-free decoded string of every row in ``need`` (a boolean list), None elsewhere."""
+        suffix = self._compositional()
+        dec = self._decode_whole()
+        if suffix is None:
+            return [dec(r).replace(" ", "") if n else None for r, n in zip(rows, need)]
+        top = int(ids.max()) + 1
+        while len(self._piece_ns) < top:
+            self._piece_ns.append(None)
+        table = self._piece_ns
+        for t in np.unique(ids).tolist():
+            if table[t] is None:
+                piece = self._pieces([t])[0]
+                table[t] = "\ufffd" if "\ufffd" in piece else piece.replace(" ", "")
+        out = []
+        get = table.__getitem__
+        for r, n in zip(rows, need):
+            if not n:
+                out.append(None)
+                continue
+            cat = "".join(map(get, r))
+            if "\ufffd" in cat or (suffix and suffix in cat):
+                cat = dec(r).replace(" ", "")
+            out.append(cat)
+        return out
+
+    def _piece_lengths(self, ids: np.ndarray) -> np.ndarray:
+        """len(decode([t])) for every id of the (B, S) array, from a lazily filled per-token table."""
+        top = int(ids.max()) + 1
+        if self._plen is None or self._plen.size < top:
+            grown = np.full(top, -1, dtype=np.int64)
+            if self._plen is not None:
+                grown[:self._plen.size] = self._plen
+            self._plen = grown
+        missing = np.unique(ids[self._plen[ids] < 0])
+        for t in missing.tolist():
+            self._plen[t] = len(self._pieces([t])[0])
+        return self._plen[ids]
+
     def batch(self, token_arrays, substrings) -> List[Tuple[int, int]]:
-        """All prompts of a request list at once: ONE ``batch_decode`` for the whole-prompt strings (the same text
-        ``decode`` gives per prompt) instead of one tokenizer call per prompt."""
-        rows = [[int(t) for t in ids] for ids in token_arrays]
-        wholes = self.tokenizer.batch_decode(rows)
-        return [self(ids, sub, whole) for ids, sub, whole in zip(rows, substrings, wholes)]
+        """All prompts of a request list at once (rows of equal length, as the padded tokenizer output): the whole-prompt
+        strings come from one decode per row, the character-offset walk is a cumulative sum over a per-token length
+        table for the whole batch.  Rows that touch a special case of the scalar walk (``[CLS]``, ``[EOS]``/empty subject,
+        the two-token n-acute, a subject that is never covered) go through ``__call__``, so every result is the scalar one."""
+        try:
+            ids = np.asarray(token_arrays, dtype=np.int64)
+        except ValueError:          # ragged rows
+            ids = np.zeros(0, dtype=np.int64)
+        if ids.ndim != 2 or ids.size == 0:
+            return [self(row, sub) for row, sub in zip(token_arrays, substrings)]
+        B, S = ids.shape
+        rows = ids.tolist()
+        at = np.zeros(B, dtype=np.int64)
+        stop = np.zeros(B, dtype=np.int64)
+        scalar = []
+        special = ("[CLS]", "[EOS]", "", " ")
+        wholes = self._row_strings(ids, rows, [sub0 not in special for sub0 in substrings])
+        for i, sub0 in enumerate(substrings):
+            if sub0 in special:
+                scalar.append(i)
+                continue
+            sub = sub0.replace(" ", "").lower()
+            whole = wholes[i]
+            if "’" in sub:
+                whole = whole.replace("'", "’")
+            if not whole.isascii():
+                whole = unicodedata.normalize("NFKC", whole)
+            if not sub.isascii():
+                sub = unicodedata.normalize("NFKC", sub)
+                if "ń" in sub:
+                    scalar.append(i)
+                    continue
+            a = whole.find(sub)
+            if a < 0:
+                raise ValueError(f"subject {sub0!r} not found in tokens: {whole!r}")
+            at[i], stop[i] = a, a + len(sub)
+            if not sub:
+                scalar.append(i)
+        cum = np.cumsum(self._piece_lengths(ids), axis=1)
+        started = cum > at[:, None]
+        covered = cum >= stop[:, None]
+        first, last = started.argmax(axis=1), covered.argmax(axis=1) + 1
+        ok = started[np.arange(B), first] & covered[np.arange(B), last - 1]
+        out = list(zip(first.tolist(), last.tolist()))
+        for i in set(scalar) | set(np.nonzero(~ok)[0].tolist()):
+            out[i] = self(rows[i], substrings[i])
+        return out
 
     def __call__(self, token_array, substring_orig: str, whole_decoded: str = None) -> Tuple[int, int]:
         ids = [int(t) for t in token_array]

@@ -17,6 +17,7 @@ Same arithmetic as the HF module tree (its own weights, LayerNorm eps, activatio
 match the hooked HF forward to fp32 rounding (tests/test_e2e_gpu.py).  Encoders that do not look like HF's
 CLIPTextModel raise ``UnsupportedEncoder`` and the engine falls back to the hooked HF forward.
 """
+import weakref
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
@@ -96,6 +97,38 @@ def discover(text_encoder, layer_module_tmp: str) -> ClipTextGraph:
         raise UnsupportedEncoder(str(e))
 
 
+_GRAPHS = weakref.WeakKeyDictionary()      # text_encoder -> (layer_module_tmp, signature, ClipTextGraph)
+
+
+def _graph_signature(graph: ClipTextGraph) -> tuple:
+    """Identity + in-place version of the tensors the stacked q|k|v snapshots were cut from."""
+    sig = []
+    for l in graph.layers:
+        for m in (l.q, l.k, l.v):
+            sig.append((id(m.weight), m.weight._version, m.weight.data_ptr()))
+            if m.bias is not None:
+                sig.append((id(m.bias), m.bias._version, m.bias.data_ptr()))
+    return tuple(sig)
+
+
+def discover_cached(text_encoder, layer_module_tmp: str) -> ClipTextGraph:
+    """``discover`` once per encoder object: the module walk and the stacked q|k|v copies are reused by later edits as long
+    as the q/k/v parameters are the same tensors and have not been written in place (their version counters)."""
+    try:
+        hit = _GRAPHS.get(text_encoder)
+    except TypeError:
+        return discover(text_encoder, layer_module_tmp)
+    if hit is not None and hit[0] == layer_module_tmp:
+        try:
+            if _graph_signature(hit[2]) == hit[1]:
+                return hit[2]
+        except AttributeError:
+            pass
+    graph = discover(text_encoder, layer_module_tmp)
+    _GRAPHS[text_encoder] = (layer_module_tmp, _graph_signature(graph), graph)
+    return graph
+
+
 @dataclass
 class TokenTrie:
     """Unique causal prefixes of a prompt batch (host-built, device-resident index arrays)."""
@@ -112,50 +145,53 @@ class TokenTrie:
 ROW_BUCKET = 256   # node / query-row counts are padded to a multiple of this: a few GEMM shapes per encoder, not one per batch
 
 
-def build_trie(input_ids: Sequence[Sequence[int]], lookup: Sequence[int], device, bucket: int = ROW_BUCKET) -> TokenTrie:
-    index: Dict[tuple, int] = {}
-    token, parent, depth = [], [], []
-    lookup_node = []
-    for ids, lk in zip(input_ids, lookup):
-        p = -1
-        for pos in range(lk + 1):
-            key = (p, ids[pos])
-            u = index.get(key)
-            if u is None:
-                u = index[key] = len(token)
-                token.append(ids[pos])
-                parent.append(p)
-                depth.append(pos)
-            p = u
-        lookup_node.append(p)
-    n_real = len(token)
-    dmax = max(depth) + 1
+def build_trie(input_ids, lookup: Sequence[int], device, bucket: int = ROW_BUCKET) -> TokenTrie:
+    """Trie of the prompts' prefixes up to each lookup token.  ``input_ids``: (B, S) array (or equal-length rows).
+    Built level by level with numpy (one ``np.unique`` over (parent, token) keys per position): nodes are numbered by
+    depth, then by (parent, token)."""
+    tok = np.asarray(input_ids, dtype=np.int64)
+    if tok.ndim != 2:
+        raise UnsupportedEncoder("prompt rows of unequal length")
+    lk = np.asarray(lookup, dtype=np.int64)
+    B = tok.shape[0]
+    dmax = int(lk.max()) + 1
     if dmax > 128:
         raise UnsupportedEncoder("prompt longer than 128 tokens")
-    # padding nodes: copies of the root token at depth 0 that attend to themselves; nothing ever looks them up
+    vocab = int(tok[:, :dmax].max()) + 1
+    node_of = np.full(B, -1, dtype=np.int64)
+    tokens, parents, levels = [], [], []
+    total = 0
+    for p in range(dmax):
+        alive = np.nonzero(lk >= p)[0] if p else np.arange(B)
+        key = (node_of[alive] + 1) * vocab + tok[alive, p]
+        uniq, inverse = np.unique(key, return_inverse=True)
+        node_of[alive] = total + inverse
+        tokens.append(uniq % vocab)
+        parents.append(uniq // vocab - 1)
+        levels.append(np.arange(total, total + uniq.size))
+        total += uniq.size
+    n_real = total
     pad = (-n_real) % bucket if bucket > 1 else 0
-    token += [token[0]] * pad
-    parent += [-1] * pad
-    depth += [0] * pad
-    U = len(token)
+    U = n_real + pad
+    token = np.concatenate(tokens + [np.full(pad, tokens[0][0], dtype=np.int64)])
+    parent = np.concatenate(parents)
+    depth = np.zeros(U, dtype=np.int32)
     anc = np.zeros((U, dmax), dtype=np.int32)
-    par = np.asarray(parent)
-    dep = np.asarray(depth)
-    for u in range(U):          # parents precede children, so their rows are complete
-        d = dep[u]
-        if d:
-            anc[u, :d] = anc[par[u], :d]
-        anc[u, d] = u
-    ln = np.asarray(lookup_node)
+    for p, ids in enumerate(levels):          # parents of level p are complete: copy their chains, append self
+        depth[ids] = p
+        if p:
+            anc[ids, :p] = anc[parent[ids], :p]
+        anc[ids, p] = ids
+    # padding nodes: copies of the root token at depth 0 that attend to themselves; nothing ever looks them up
+    anc[n_real:, 0] = np.arange(n_real, U)
+    ln = node_of                                   # node of each prompt's lookup token (its last alive level)
     q_rows, inverse = np.unique(ln, return_inverse=True)
     if bucket > 1 and len(q_rows) % bucket:       # query rows of the last layer: repeat the first one as padding
         q_rows = np.concatenate([q_rows, np.full((-len(q_rows)) % bucket, q_rows[0], dtype=q_rows.dtype)])
-    return TokenTrie(torch.tensor(token, dtype=torch.int64, device=device),
-                     torch.tensor(dep, dtype=torch.int32, device=device),
+    return TokenTrie(torch.from_numpy(token).to(device), torch.from_numpy(depth).to(device),
                      torch.from_numpy(anc).to(device), torch.from_numpy(ln).to(device),
                      torch.from_numpy(q_rows.astype(np.int32)).to(device),
-                     torch.from_numpy(inverse.astype(np.int64)).to(device), n_real,
-                     len(input_ids) * len(input_ids[0]))
+                     torch.from_numpy(inverse.astype(np.int64)).to(device), n_real, B * tok.shape[1])
 
 
 class tuned_gemms:
@@ -181,11 +217,25 @@ _TUNED = {"done": False, "shapes": set()}
 
 
 def _tunable_file(dev) -> str:
+    """TunableOp results file: per user (0700 directory under ~/.cache, or $EMCID_CACHE_DIR), per device and rank —
+    processes of a multi-GPU job must not write the same file at exit, and nobody else can plant one."""
     import os
-    import tempfile
-    # one results file per device and rank: processes of a multi-GPU job must not write the same file at exit
-    return os.path.join(tempfile.gettempdir(),
-                        f"emcid_tunableop_{os.getuid()}_gpu{dev.index or 0}_r{os.environ.get('RANK', '0')}.csv")
+    root = os.environ.get("EMCID_CACHE_DIR") or os.path.join(os.path.expanduser("~"), ".cache", "emcid_amd")
+    os.makedirs(root, mode=0o700, exist_ok=True)
+    return os.path.join(root, f"tunableop_gpu{dev.index or 0}_r{os.environ.get('RANK', '0')}.csv")
+
+
+def _own_regular_file(path: str) -> bool:
+    import os
+    import stat
+    try:
+        st = os.lstat(path)
+    except OSError:
+        return False
+    return stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & 0o022)
+
+
+TUNING_SECONDS_TOTAL = 0.0     # seconds this process has spent inside TunableOp tuning (bench.py reports it)
 
 
 def tune_projections(graph: ClipTextGraph, trie: TokenTrie, upto: int, mode: str = "auto") -> float:
@@ -194,7 +244,7 @@ def tune_projections(graph: ClipTextGraph, trie: TokenTrie, upto: int, mode: str
     10-35 % on the table for (rows x 768) @ (768 x {768, 2304, 3072}).
 
     ``mode``: "1" tunes shapes not seen yet (seconds per encoder, once; results also go to TunableOp's file under the
-    temp dir) — what a long-running editing service or the benchmark wants; "auto" (the library default) only LOADS
+    user's cache directory) — what a long-running editing service or the benchmark wants; "auto" (the library default) only LOADS
     that file if an earlier process left one, so a one-off call never pays for tuning; "0" leaves torch alone.
     Returns the seconds spent."""
     import os
@@ -207,14 +257,15 @@ def tune_projections(graph: ClipTextGraph, trie: TokenTrie, upto: int, mode: str
     fname = _tunable_file(dev)
     t0 = time.perf_counter()
     if mode != "1":
-        if not _TUNED["done"] and os.path.exists(fname):
-            prev = (t.is_enabled(), t.tuning_is_enabled())
+        if not _TUNED["done"] and _own_regular_file(fname):
+            prev = (t.is_enabled(), t.tuning_is_enabled(), t.get_filename())
             try:
                 t.enable(True)
                 t.tuning_enable(False)
                 t.set_filename(fname)
                 _TUNED["done"] = bool(t.read_file(fname))
             finally:
+                t.set_filename(prev[2])
                 t.tuning_enable(prev[1])
                 t.enable(prev[0])
         return time.perf_counter() - t0
@@ -229,6 +280,7 @@ def tune_projections(graph: ClipTextGraph, trie: TokenTrie, upto: int, mode: str
     todo = [s for s in dict.fromkeys(todo) if s not in _TUNED["shapes"]]
     if not todo:
         return 0.0
+    global TUNING_SECONDS_TOTAL
     prev = (t.is_enabled(), t.tuning_is_enabled())
     try:
         t.enable(True)
@@ -248,6 +300,7 @@ def tune_projections(graph: ClipTextGraph, trie: TokenTrie, upto: int, mode: str
     finally:
         t.tuning_enable(prev[1])
         t.enable(prev[0])
+    TUNING_SECONDS_TOTAL += time.perf_counter() - t0
     return time.perf_counter() - t0
 
 

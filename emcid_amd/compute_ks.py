@@ -24,7 +24,7 @@ def text_embedding_at_lookup(pipe, batch: PromptBatch, layer_module_tmp: Optiona
     if layer_module_tmp is not None and batch.lookup.is_cuda:
         try:
             graph = clip_forward.discover(te, layer_module_tmp)
-            trie = clip_forward.build_trie(batch.inputs["input_ids"].tolist(), batch.lookup_host, batch.lookup.device)
+            trie = clip_forward.build_trie(batch.ids_host, batch.lookup_host, batch.lookup.device)
             with torch.no_grad():
                 return clip_forward.last_hidden_at_lookup(graph, trie)
         except (clip_forward.UnsupportedEncoder, IndexError, LookupError):

@@ -13,6 +13,7 @@ MI355X-first differences, results identical:
   torch-CPU's ``.mean(0)``;
 * the forward stops at the hooked module (the reference runs the remaining layers and discards them).
 """
+import weakref
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -58,41 +59,81 @@ class PromptBatch:
     seg: torch.Tensor                    # (N+1,) int64: prompt offsets per request
     n_requests: int
     lookup_host: List[int]
+    ids_host: Optional[np.ndarray] = None   # (B, S) int64 copy of input_ids on the host (the trie is built from it)
 
     @property
     def n_prompts(self):
         return int(self.lookup.numel())
 
 
+def tokenize_lists(tokenizer, prompts: Sequence[str]) -> Dict[str, np.ndarray]:
+    """``tokenizer(prompts, padding=True, truncation=True)`` as (B, S) int64 arrays (reference: compute_z.py:65).
+
+    For a tokenizers-backed HF tokenizer the public call spends most of its time assembling a ``BatchEncoding`` and
+    tracking character offsets nobody reads.  Here a ONE-prompt public call configures the backend's truncation and
+    padding exactly as transformers does for these arguments (``set_truncation_and_padding``), then the backend encodes
+    the batch without offsets (``encode_batch_fast``; same ids and masks by construction) — and the one-prompt public
+    result is checked against the corresponding row.  Anything unexpected falls back to the public call."""
+    bt = getattr(tokenizer, "_tokenizer", None)
+    if bt is not None and hasattr(bt, "encode_batch_fast") and len(prompts) > 8:
+        try:
+            longest = max(range(len(prompts)), key=lambda i: len(prompts[i]))
+            probe = tokenizer([prompts[longest]], padding=True, truncation=True)
+            encs = bt.encode_batch_fast(list(prompts), add_special_tokens=True)
+            ids = np.array([e.ids for e in encs], dtype=np.int64)
+            mask = np.array([e.attention_mask for e in encs], dtype=np.int64)
+            want = probe["input_ids"][0]
+            if ids.ndim == 2 and ids.shape[1] >= len(want) and ids[longest, :len(want)].tolist() == want \
+                    and int(mask[longest].sum()) == int(sum(probe["attention_mask"][0])) \
+                    and set(probe.keys()) == {"input_ids", "attention_mask"}:
+                return {"input_ids": ids, "attention_mask": mask}
+        except Exception:
+            pass
+    enc = tokenizer(list(prompts), padding=True, truncation=True)
+    return {k: np.asarray(v, dtype=np.int64) for k, v in enc.items()}
+
+
+_FINDERS = weakref.WeakKeyDictionary()     # tokenizer -> TokenRangeFinder (its per-token decode table is a pure function of the tokenizer)
+
+
+def finder_for(tokenizer) -> TokenRangeFinder:
+    try:
+        f = _FINDERS.get(tokenizer)
+        if f is None:
+            f = _FINDERS[tokenizer] = TokenRangeFinder(tokenizer)
+        return f
+    except TypeError:       # not weak-referenceable
+        return TokenRangeFinder(tokenizer)
+
+
 def build_prompt_batch(tokenizer, requests: Sequence[Dict], device, finder: Optional[TokenRangeFinder] = None,
                        truncate: bool = True) -> PromptBatch:
     prompts, subjects, counts = expand_request_prompts(requests)
-    # plain lists from the tokenizer, tensors built here: `return_tensors="pt"` walks every id in Python (a third of
-    # the host time of this function at 3 000 prompts) and the lists are needed for the subject search anyway
-    enc_lists = tokenizer(prompts, padding=True, truncation=True)
-    enc = {k: torch.tensor(v, dtype=torch.int64) for k, v in enc_lists.items()}
-    finder = finder or TokenRangeFinder(tokenizer)
-    ids_host = enc_lists["input_ids"]
+    enc = tokenize_lists(tokenizer, prompts)
+    finder = finder or finder_for(tokenizer)
+    ids_host = enc["input_ids"]
     lookup = [r[-1] - 1 for r in finder.batch(ids_host, subjects)]
     if len(ids_host) != len(lookup):
         raise ValueError("The number of prompts and lookup indices should be the same.")
-    S = enc["input_ids"].shape[1]
-    for i, j in enumerate(lookup):
-        if not 0 <= j < S:
-            raise ValueError(f"lookup index {j} outside the padded prompt (S={S}) for prompt {prompts[i]!r}")
+    S = ids_host.shape[1]
+    lk = np.asarray(lookup, dtype=np.int64)
+    bad = np.nonzero((lk < 0) | (lk >= S))[0]
+    if bad.size:
+        i = int(bad[0])
+        raise ValueError(f"lookup index {lookup[i]} outside the padded prompt (S={S}) for prompt {prompts[i]!r}")
     seg = np.cumsum([0] + counts)
     if seg[-1] != len(prompts):
         raise ValueError(f"request prompt counts ({seg[-1]}) do not cover the {len(prompts)} prompts")
     if truncate:
         # CLIP text attention is causal: nothing at or before a lookup token depends on later positions, so
         # the columns after the last lookup index (EOS, padding) are never needed by the K/Z gather.
-        keep = max(lookup) + 1
-        enc = {k: v[:, :keep] for k, v in enc.items()}
+        keep = int(lk.max()) + 1
+        enc = {k: np.ascontiguousarray(v[:, :keep]) for k, v in enc.items()}
     return PromptBatch(
-        inputs={k: v.to(device) for k, v in enc.items()},
-        lookup=torch.tensor(lookup, dtype=torch.int64, device=device),
-        seg=torch.tensor(seg, dtype=torch.int64, device=device),
-        n_requests=len(requests), lookup_host=lookup)
+        inputs={k: torch.from_numpy(v).to(device) for k, v in enc.items()},
+        lookup=torch.from_numpy(lk).to(device),
+        seg=torch.from_numpy(seg.astype(np.int64)).to(device),
+        n_requests=len(requests), lookup_host=lookup, ids_host=enc["input_ids"])
 
 
 def gather_request_means(act: torch.Tensor, batch: PromptBatch) -> torch.Tensor:

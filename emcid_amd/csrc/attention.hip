@@ -311,12 +311,14 @@ extern "C" int emcid_attention_f32(const float* q, const float* k, const float* 
         hipLaunchKernelGGL(attention_f32_kernel<4>, dim3((unsigned)((pairs + 3) / 4)), dim3(256), per_wave * 4, st, a);
     } else {
         if (per_wave > 160 * 1024) return fail(EMCID_ERR_BAD_ARG, __func__, "S x D too large for one wave's LDS image");
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_set[64] = {};      // a function attribute is per device
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_f32_kernel<1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return fail(EMCID_ERR_HIP, __func__, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)");
-            attr_set = true;
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
         hipLaunchKernelGGL(attention_f32_kernel<1>, dim3((unsigned)pairs), dim3(64), per_wave, st, a);
     }

@@ -6,6 +6,7 @@
 // with NB = 128: a single-workgroup LDS leaf factors the diagonal block and inverts it, so the panel
 // solve and every later triangular solve are MFMA GEMMs against the inverted diagonal blocks.
 #include <functional>
+#include <mutex>
 
 #include "common.h"
 #include "gemm_f64.h"
@@ -558,11 +559,19 @@ static void build_block_inverses(const double* L, int64_t dp, int64_t lda, doubl
 
 // Graphs are captured on an internal stream: the caller's stream may be the legacy default stream, which cannot capture.
 namespace {
-hipStream_t g_capture_stream = nullptr;
-int capture_stream_init() {
-    if (g_capture_stream) return EMCID_OK;
-    if (hipStreamCreateWithFlags(&g_capture_stream, hipStreamNonBlocking) != hipSuccess)
-        return fail(EMCID_ERR_HIP, "emcid_edit_layer_f64", "hipStreamCreateWithFlags");
+constexpr int MAX_DEVICES = 64;
+hipStream_t g_capture_stream[MAX_DEVICES] = {};      // one per device: a stream belongs to the device current at its creation
+std::mutex g_state_mutex;                           // graph cache + capture streams (entry points may be called from threads)
+int current_device() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev;
+}
+int capture_stream_init(int dev, hipStream_t* out) {
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(EMCID_ERR_BAD_ARG, "emcid graph", "device ordinal out of range");
+    if (!g_capture_stream[dev] && hipStreamCreateWithFlags(&g_capture_stream[dev], hipStreamNonBlocking) != hipSuccess)
+        return fail(EMCID_ERR_HIP, "emcid graph", "hipStreamCreateWithFlags");
+    *out = g_capture_stream[dev];
     return EMCID_OK;
 }
 }  // namespace
@@ -791,6 +800,7 @@ namespace {
 struct GraphKey {
     const void* ptr[8];
     int64_t num[6];
+    int64_t dev;          // device the launches were captured for (filled in by with_graph)
     bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
 };
 struct GraphSlot { GraphKey key; hipGraphExec_t exec; hipGraph_t graph; uint64_t used; };
@@ -813,15 +823,18 @@ GraphKey make_key(int tag, std::initializer_list<const void*> ptrs, std::initial
 
 // Runs `body(stream)` — a chain of launches whose arguments are fully determined by `key` — as a cached hipGraph.
 template <class F>
-static int with_graph(const GraphKey& key, hipStream_t st, F&& body) {
+static int with_graph(const GraphKey& key_in, hipStream_t st, F&& body) {
     static const int use_graph = env_flag("EMCID_GRAPH", 1);
     if (!use_graph || g_prof_mask != 0) return body(st);
+    std::lock_guard<std::mutex> lock(g_state_mutex);
+    GraphKey key = key_in;
+    key.dev = current_device();     // the caller made the buffers' device current (emcid_amd/hip.py does; see emcid_hip.h)
     GraphSlot* slot = nullptr;
     for (int i = 0; i < g_graph_n; ++i)
         if (g_graphs[i].key == key) { slot = &g_graphs[i]; break; }
     if (!slot) {
-        EMCID_TRY(capture_stream_init());
-        hipStream_t cap = g_capture_stream;
+        hipStream_t cap = nullptr;
+        EMCID_TRY(capture_stream_init((int)key.dev, &cap));
         if (hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) != hipSuccess)
             return fail(EMCID_ERR_HIP, "emcid graph", "hipStreamBeginCapture");
         const int rc = body(cap);

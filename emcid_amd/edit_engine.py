@@ -19,6 +19,9 @@ Same K, Zc, A, X, R, dW as the reference's loop (same inputs to every step), 1 p
 touches only HBM-resident inputs — that is the region bench.py times.
 """
 import os
+import threading
+import time
+from collections import OrderedDict
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
 
@@ -77,9 +80,66 @@ class EncoderEditPlan:
     graph: Optional[clip_forward.ClipTextGraph] = None   # set -> prefix-deduplicated forward (clip_forward.py)
     trie: Optional[clip_forward.TokenTrie] = None
     gemm_tuning_s: float = 0.0           # one-off TunableOp time spent in prepare (first plan with these GEMM shapes)
+    backups: Optional[Dict[int, torch.Tensor]] = None    # W0 of the edited layers of the last run (failure recovery)
+    factor_key: Optional[tuple] = None   # set by a run that factored lam*C' itself: check_info caches the factors if sound
+    factors_from_cache: bool = False
 
     def weight_name(self, layer):
         return f"{self.rewrite_module_tmp.format(layer)}.weight"
+
+
+# ---- state kept across calls (all guarded by ENGINE_LOCK: the engine serialises edits per process) ------------------
+ENGINE_LOCK = threading.RLock()
+_WS_CACHE: "OrderedDict[tuple, object]" = OrderedDict()        # (kind, device, N, d, h) -> reusable f64 workspace
+_FACTOR_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()     # see factor_cache_key -> (CovFactors, cov tensors)
+WS_CACHE_SIZE = 4
+
+
+def _factor_cache_size() -> int:
+    return int(os.environ.get("EMCID_FACTOR_CACHE", "4"))
+
+
+def _workspace(kind: str, N: int, d: int, h: int, dev):
+    key = (kind, str(dev), N, d, h)
+    ws = _WS_CACHE.get(key)
+    if ws is None:
+        ws = (hip.DualWorkspace if kind == "dual" else hip.EditWorkspace)(N, d, h, dev)
+        _WS_CACHE[key] = ws
+        while len(_WS_CACHE) > WS_CACHE_SIZE:
+            _WS_CACHE.popitem(last=False)
+    else:
+        _WS_CACHE.move_to_end(key)
+    return ws
+
+
+def factor_cache_key(covs: Sequence[torch.Tensor], lam: float, edit_weight: float) -> tuple:
+    """lam*C'_l and its Cholesky factor / explicit inverse factor are pure functions of (the statistics, lam, edit_weight):
+    keyed by the identity and version counter of the HBM-resident C tensors (the entries of emcid_main's covariance
+    cache), so a second edit with the same statistics and weights factors only its own N x N systems."""
+    return (tuple((c.device.index, c.data_ptr(), c._version, tuple(c.shape)) for c in covs), float(lam), float(edit_weight))
+
+
+def clear_engine_caches():
+    with ENGINE_LOCK:
+        _WS_CACHE.clear()
+        _FACTOR_CACHE.clear()
+
+
+TIMING: Dict[str, float] = {}      # host seconds per phase of the last prepare/run (diagnostic; scripts/host_profile.py)
+
+
+class phase:
+    """with phase("name"): ... accumulates host wall-clock into TIMING[name]."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.t = time.perf_counter()
+
+    def __exit__(self, *exc):
+        TIMING[self.name] = TIMING.get(self.name, 0.0) + time.perf_counter() - self.t
+        return False
 
 
 FORWARD_MODE = "trie"   # "trie": prefix-deduplicated forward when the encoder is a HF CLIP text model; "hf": hooked HF forward
@@ -104,26 +164,33 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
     shard = shard or ConceptShard()
     device = next(text_encoder.parameters()).device
     lo, hi = shard.bounds(len(requests))
-    if hi <= lo:
-        raise ValueError(f"rank {shard.rank}/{shard.world} has no requests (N={len(requests)} < world size)")
-    batch = build_prompt_batch(tokenizer, list(requests[lo:hi]), device)
-    zs_t = zs_t.to(device=device, dtype=torch.float32).contiguous()
-    if zs_t.shape[0] != len(requests):
-        raise ValueError(f"v* stack has {zs_t.shape[0]} rows for {len(requests)} requests")
-    covs = {l: c.to(device=device, dtype=torch.float32).contiguous() for l, c in covs.items()}
+    if len(requests) < shard.world:     # the same verdict on every rank, before any collective can be entered
+        raise ValueError(f"{len(requests)} request(s) cannot be sharded over {shard.world} ranks (every rank needs one)")
+    with phase("tokenize+lookup"):
+        batch = build_prompt_batch(tokenizer, list(requests[lo:hi]), device)
+    with phase("h2d"):
+        if hasattr(zs_t, "result"):         # a concurrent.futures.Future from the caller's reader thread
+            zs_t = zs_t.result()
+        zs_t = zs_t.to(device=device, dtype=torch.float32).contiguous()
+        if zs_t.shape[0] != len(requests):
+            raise ValueError(f"v* stack has {zs_t.shape[0]} rows for {len(requests)} requests")
+        covs = {l: c.to(device=device, dtype=torch.float32).contiguous() for l, c in covs.items()}
     plan = EncoderEditPlan(text_encoder, list(layers), rewrite_module_tmp, float(lam), float(edit_weight), batch,
                            zs_t, covs, len(requests), shard)
     mode = forward_mode or FORWARD_MODE
     if mode == "trie" and layer_module_tmp is not None and device.type == "cuda":
         try:
-            graph = clip_forward.discover(text_encoder, layer_module_tmp)
-            for l in plan.layers:   # the edited weights must be the very tensors the explicit forward multiplies with
-                if graph.layers[l].fc2.weight is not get_parameter(text_encoder, plan.weight_name(l)):
-                    raise clip_forward.UnsupportedEncoder("rewrite_module_tmp is not the layer's mlp.fc2")
-            plan.trie = clip_forward.build_trie(batch.inputs["input_ids"].tolist(), batch.lookup_host, device)
+            with phase("graph"):
+                graph = clip_forward.discover_cached(text_encoder, layer_module_tmp)
+                for l in plan.layers:   # the edited weights must be the very tensors the explicit forward multiplies with
+                    if graph.layers[l].fc2.weight is not get_parameter(text_encoder, plan.weight_name(l)):
+                        raise clip_forward.UnsupportedEncoder("rewrite_module_tmp is not the layer's mlp.fc2")
+            with phase("trie"):
+                plan.trie = clip_forward.build_trie(batch.ids_host, batch.lookup_host, device)
             plan.graph = graph
-            plan.gemm_tuning_s = clip_forward.tune_projections(graph, plan.trie, max(plan.layers),
-                                                               os.environ.get("EMCID_TUNE_GEMM", "auto"))
+            with phase("gemm_tuning"):
+                plan.gemm_tuning_s = clip_forward.tune_projections(graph, plan.trie, max(plan.layers),
+                                                                   os.environ.get("EMCID_TUNE_GEMM", "auto"))
         except (clip_forward.UnsupportedEncoder, IndexError, LookupError):
             plan.graph = plan.trie = None
     return plan
@@ -185,6 +252,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
             raise hip.EmcidHipError(f"{plan.weight_name(l)} must be a contiguous fp32 tensor in HBM "
                                     f"(got {w.dtype} on {w.device})")
     backups = {l: w.detach().clone() for l, w in weights.items()}
+    plan.backups = backups
     d, h = weights[plan.layers[0]].shape[1], weights[plan.layers[0]].shape[0]
     dev = weights[plan.layers[0]].device
     dual = _use_dual(plan, d)
@@ -192,50 +260,64 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
     last = plan.layers[-1]
     handles = []
     fac_done = None
+    lazy, first_x = False, 0
+    plan.factor_key, plan.factors_from_cache = None, False
     if dual:
-        # lam * C'_l does not depend on the concepts: factor it for ALL edited layers in one batched pass on a side
-        # stream, underneath the encoder forward that produces the first layer's keys
-        if plan.dual_ws is None or plan.dual_ws.key != (plan.n_total, d, h):
-            plan.dual_ws = hip.DualWorkspace(plan.n_total, d, h, dev)
+        plan.dual_ws = _workspace("dual", plan.n_total, d, h, dev)
         plan.dual_ws.info.zero_()
-        if plan.side_stream is None:
-            # high priority: the factorization is a long chain of small dependent kernels; each must get the next
-            # free CU ahead of the forward's wide GEMMs or the chain stretches to several times its own length
-            plan.side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("EMCID_SIDE_PRIORITY", "-1")))
-        plan.side_stream.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(plan.side_stream):
-            if plan.cov_factors is not None:
-                plan.cov_factors.info.zero_()
-            plan.cov_factors = hip.factor_cov([plan.covs[l] for l in plan.layers], plan.lam, plan.edit_weight,
-                                              plan.cov_factors, inverse=False)
-            chol_done = torch.cuda.Event()
-            chol_done.record(plan.side_stream)
-            # The first edited layer solves against M by block substitution with L as soon as the factorization is there.
-            # The explicit inverse factors X_l = inv(L_l) of the LATER layers (their two M-solves become two GEMMs) are
-            # built one layer ahead, on the side stream, exactly while the previous layer's solve sits in the
-            # latency-bound Cholesky of its N x N system (the chip is idle there): see ``lazy_inverse`` in solve().
-            # EMCID_INVERSE_FROM: first layer index that uses X; EMCID_INVERSE_LAZY=0: build them all right after the
-            # factorization instead (batched, underneath the forward — costs the forward more than it hides).
-            first_x = min(L, max(0, int(os.environ.get("EMCID_INVERSE_FROM", "1"))))
-            lazy = os.environ.get("EMCID_INVERSE_LAZY", "1") != "0" and keep_factors is False
-            fac_done = [chol_done] * L
-            if lazy and first_x == 0:      # the first layer's X right behind the factorization, the others one layer ahead
-                hip.cov_inverse(plan.cov_factors, 0, 1)
-                fac_done[0] = torch.cuda.Event()
-                fac_done[0].record(plan.side_stream)
-            if first_x < L and not lazy:
-                hip.cov_inverse(plan.cov_factors, first_x, L - first_x)
-                ev = torch.cuda.Event()
-                ev.record(plan.side_stream)
-                for i in range(first_x, L):
-                    fac_done[i] = ev
-        if first_x >= L:
-            lazy = False
-        if os.environ.get("EMCID_FACTOR_FIRST", "0") == "1":    # experiment: no overlap of the factorization with the forward
-            torch.cuda.current_stream(dev).wait_event(chol_done)
+        fkey = factor_cache_key([plan.covs[l] for l in plan.layers], plan.lam, plan.edit_weight)
+        hit = _FACTOR_CACHE.get(fkey) if _factor_cache_size() > 0 else None
+        if hit is not None:
+            # lam * C'_l = L L^T and X = inv(L) of every edited layer are already in HBM from an earlier edit with the
+            # same statistics, lam and edit_weight: every M-solve of this pass is a GEMM against X, nothing is factored
+            # but the N x N systems
+            _FACTOR_CACHE.move_to_end(fkey)
+            plan.cov_factors, plan.factors_from_cache = hit[0], True
+            if plan.cov_factors.ready is not None:
+                torch.cuda.current_stream(dev).wait_event(plan.cov_factors.ready)
+        else:
+            # lam * C'_l does not depend on the concepts: factor it for ALL edited layers in one batched pass on a side
+            # stream, underneath the encoder forward that produces the first layer's keys
+            if plan.side_stream is None:
+                # high priority: the factorization is a long chain of small dependent kernels; each must get the next
+                # free CU ahead of the forward's wide GEMMs or the chain stretches to several times its own length
+                plan.side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("EMCID_SIDE_PRIORITY", "-1")))
+            plan.side_stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(plan.side_stream):
+                if plan.cov_factors is not None and plan.cov_factors.cached:
+                    plan.cov_factors = None        # never refactor into a workspace the cache hands to other edits
+                if plan.cov_factors is not None:
+                    plan.cov_factors.info.zero_()
+                plan.cov_factors = hip.factor_cov([plan.covs[l] for l in plan.layers], plan.lam, plan.edit_weight,
+                                                  plan.cov_factors, inverse=False)
+                plan.factor_key = fkey
+                chol_done = torch.cuda.Event()
+                chol_done.record(plan.side_stream)
+                # The first edited layer solves against M by block substitution with L as soon as the factorization is there.
+                # The explicit inverse factors X_l = inv(L_l) of the LATER layers (their two M-solves become two GEMMs) are
+                # built one layer ahead, on the side stream, exactly while the previous layer's solve sits in the
+                # latency-bound Cholesky of its N x N system (the chip is idle there): see ``lazy_inverse`` in solve().
+                # EMCID_INVERSE_FROM: first layer index that uses X; EMCID_INVERSE_LAZY=0: build them all right after the
+                # factorization instead (batched, underneath the forward — costs the forward more than it hides).
+                first_x = min(L, max(0, int(os.environ.get("EMCID_INVERSE_FROM", "1"))))
+                lazy = os.environ.get("EMCID_INVERSE_LAZY", "1") != "0" and keep_factors is False
+                fac_done = [chol_done] * L
+                if lazy and first_x == 0:      # the first layer's X right behind the factorization, the others one layer ahead
+                    hip.cov_inverse(plan.cov_factors, 0, 1)
+                    fac_done[0] = torch.cuda.Event()
+                    fac_done[0].record(plan.side_stream)
+                if first_x < L and not lazy:
+                    hip.cov_inverse(plan.cov_factors, first_x, L - first_x)
+                    ev = torch.cuda.Event()
+                    ev.record(plan.side_stream)
+                    for i in range(first_x, L):
+                        fac_done[i] = ev
+            if first_x >= L:
+                lazy = False
+            if os.environ.get("EMCID_FACTOR_FIRST", "0") == "1":    # experiment: no overlap of the factorization with the forward
+                torch.cuda.current_stream(dev).wait_event(chol_done)
     else:
-        if plan.ws is None or plan.ws.key != (plan.n_total, d, h):
-            plan.ws = hip.EditWorkspace(plan.n_total, d, h, dev)
+        plan.ws = _workspace("direct", plan.n_total, d, h, dev)
         plan.ws.info.zero_()
 
     def solve(i, layer, K_local, Zc_local):
@@ -244,7 +326,8 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
         K = _all_gather_rows(K_local, plan)
         Zc = Zc_local(K) if callable(Zc_local) else _all_gather_rows(Zc_local, plan)
         if dual:
-            torch.cuda.current_stream(dev).wait_event(fac_done[i])
+            if fac_done is not None:
+                torch.cuda.current_stream(dev).wait_event(fac_done[i])
             sharded = plan.shard.world > 1
             if not keep_factors:   # only the edited weights are wanted: the form that never builds adj_k
                 def lazy_inverse(nxt=i + 1):
@@ -346,6 +429,17 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
     if len(edits) != L:
         raise RuntimeError(f"only {len(edits)} of {L} edited layers were reached by the forward pass "
                            f"(hparams.layers must be in forward order)")
+    if dual and plan.factor_key is not None and _factor_cache_size() > 0:
+        # this pass factored lam*C' itself: finish the explicit inverse factors it did not need (off the critical path,
+        # on the side stream) so that check_info can hand the complete set to later edits
+        missing = [i for i in range(L) if i not in plan.cov_factors.have_inverse]
+        if missing:
+            plan.side_stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(plan.side_stream):
+                for i in missing:
+                    hip.cov_inverse(plan.cov_factors, i, 1)
+                plan.cov_factors.ready = torch.cuda.Event()
+                plan.cov_factors.ready.record(plan.side_stream)
     if restore:
         with torch.no_grad():
             for l, w in weights.items():
@@ -353,14 +447,37 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
     return edits
 
 
-def check_info(plan: EncoderEditPlan):
-    """One host sync at the very end: did any factorization meet a non-positive pivot?"""
+def solver_info(plan: EncoderEditPlan) -> int:
+    """One host sync: 0, or 1 + the column of the first non-positive pivot any factorization of the last run met."""
     code = 0
     for holder in (plan.ws, plan.dual_ws, plan.cov_factors):
         if holder is not None and code == 0:
             code = int(holder.info.item())
-    if code != 0:
-        raise FloatingPointError(
-            f"lam*C + K K^T is not positive definite (non-positive pivot at column {code - 1}); the reference's LU "
-            f"(torch.linalg.solve, emcid_main.py:1045) would have returned numbers for an indefinite system — "
-            f"check the statistics file / mom2_update_weight")
+    return code
+
+
+def check_info(plan: EncoderEditPlan, restore_on_failure: bool = True):
+    """One host sync at the very end: did any factorization meet a non-positive pivot?  If so the edited weights hold
+    garbage: they are put back to the values they had before the run, then FloatingPointError is raised (callers that can
+    retry — emcid_main — catch it and rerun with the pivoted-LU solver, the reference's own semantics)."""
+    code = solver_info(plan)
+    if code == 0:
+        if plan.factor_key is not None and plan.cov_factors is not None and _factor_cache_size() > 0:
+            with ENGINE_LOCK:
+                plan.cov_factors.cached = True
+                _FACTOR_CACHE[plan.factor_key] = (plan.cov_factors, [plan.covs[l] for l in plan.layers])
+                while len(_FACTOR_CACHE) > _factor_cache_size():
+                    _FACTOR_CACHE.popitem(last=False)
+            plan.factor_key = None
+        return
+    if plan.factor_key is not None:
+        plan.factor_key = None
+        plan.cov_factors = None
+    if restore_on_failure and plan.backups is not None:
+        with torch.no_grad():
+            for l, w0 in plan.backups.items():
+                get_parameter(plan.text_encoder, plan.weight_name(l)).copy_(w0)
+    raise FloatingPointError(
+        f"lam*C + K K^T is not positive definite (non-positive pivot at column {code - 1}); the reference's LU "
+        f"(torch.linalg.solve, emcid_main.py:1045) returns numbers for an indefinite system — the edited weights have been "
+        f"restored; rerun with solver='lu' (emcid_main does so by itself) or check the statistics file / mom2_update_weight")

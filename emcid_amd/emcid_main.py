@@ -12,12 +12,13 @@ plus ``apply_emcid_to_model`` (the name BASELINE.json uses; dispatches on the hp
 What runs where: tokenizing, subject search, v*/C cache reads are host Python (once per call); everything
 between "inputs are in HBM" and "fc2 weights are edited" is edit_engine.run_encoder_edit -> HIP kernels.
 Kept reference behaviours: ``hparams`` is mutated in place by the mom2/edit weight overrides (:846-847);
-``requests`` is deep-copied (:850); ``execute_*`` leaves TE1 weights untouched (:1076-1078); the SDXL path
+``requests`` is never written (the reference deep-copies it for that, :850); ``execute_*`` leaves TE1 weights untouched (:1076-1078); the SDXL path
 leaves TE2 edited and ``apply_*`` then adds the deltas again, so TE2 ends at W + 2*dW (:1410 vs :93-99) —
 reproduced by default (``SDXL_TE2_DOUBLE_APPLY``).  Deliberate differences: ``COV_CACHE`` is keyed by the
 statistics directory too (the reference's key ignores it and silently reuses a stale C, SURVEY.md §5);
 per-request progress prints obey ``verbose``; a v* cache miss raises (Stage 1 needs the SD UNet, out of scope).
 """
+import os
 from copy import deepcopy
 from pathlib import Path
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -26,7 +27,7 @@ import numpy as np
 import torch
 
 from . import hip, nethook
-from .edit_engine import (ConceptShard, EncoderEditPlan, LayerEdit, check_info, prepare_encoder_edit,
+from .edit_engine import (ConceptShard, EncoderEditPlan, LayerEdit, check_info, phase, prepare_encoder_edit,
                           run_encoder_edit)
 from .emcid_hparams import EMCIDHyperParams, EMCIDXLHyperParams
 from .globals import STATS_DIR, XL_STATS_DIR1, XL_STATS_DIR2
@@ -88,24 +89,71 @@ def upd_matrix_match_shape(matrix: torch.Tensor, shape: torch.Size) -> torch.Ten
 
 # ---- v* cache -----------------------------------------------------------------------------------------
 
-def vstar_cache_file(cache_name: Optional[str], request: Dict, hparams, idx: int, suffix: str = "") -> Optional[Path]:
+def vstar_cache_name(cache_name: Optional[str], request: Dict, hparams, idx: int, suffix: str = "") -> Optional[str]:
     """Cache path of one request's v* (reference :873-890 SD; :1157-1166 SDXL with suffix ``_2``)."""
     if cache_name is None:
         return None
     if "esd" in hparams.objective:
-        return Path(cache_name + f"source_{request['source']}{suffix}.npz")
+        return f"{cache_name}source_{request['source']}{suffix}.npz"
     if getattr(hparams, "sld_supervision", False):
-        return Path(cache_name + f"source_{request['source_cat']}_{idx}{suffix}.npz")
-    return Path(cache_name + f"source_{request['source']}_dest_{request['dest']}{suffix}.npz")
+        return f"{cache_name}source_{request['source_cat']}_{idx}{suffix}.npz"
+    return f"{cache_name}source_{request['source']}_dest_{request['dest']}{suffix}.npz"
 
 
-def _read_vstar(path: Path) -> np.ndarray:
-    st = path.stat()
-    key = (str(path), st.st_mtime_ns, st.st_size)
+def vstar_cache_file(cache_name: Optional[str], request: Dict, hparams, idx: int, suffix: str = "") -> Optional[Path]:
+    name = vstar_cache_name(cache_name, request, hparams, idx, suffix)
+    return None if name is None else Path(name)
+
+
+def _npz_single_array(blob: bytes, key: str) -> Optional[np.ndarray]:
+    """The array of an npz whose FIRST member is ``{key}.npy``, stored uncompressed, little-endian f4/f8, C order — the
+    file ``np.savez(f, v_star=...)`` writes (reference :951-968) — parsed straight from the bytes: the zip local header,
+    then the npy header, then the data.  ``zipfile`` + ``np.load`` cost ~130 us per file, 1 000 files per mass edit.
+    Returns None for anything else (the caller then uses ``np.load``)."""
+    try:
+        if blob[:4] != b"PK\x03\x04" or blob[8:10] != b"\x00\x00":          # local file header, method 0 = stored
+            return None
+        n_name, n_extra = int.from_bytes(blob[26:28], "little"), int.from_bytes(blob[28:30], "little")
+        if blob[30:30 + n_name] != (key + ".npy").encode():
+            return None
+        o = 30 + n_name + n_extra
+        if blob[o:o + 6] != b"\x93NUMPY":
+            return None
+        major = blob[o + 6]
+        if major == 1:
+            hlen, o = int.from_bytes(blob[o + 8:o + 10], "little"), o + 10
+        elif major in (2, 3):
+            hlen, o = int.from_bytes(blob[o + 8:o + 12], "little"), o + 12
+        else:
+            return None
+        header = blob[o:o + hlen].decode("latin1")
+        o += hlen
+        import ast
+        meta = ast.literal_eval(header)
+        descr, shape = meta["descr"], tuple(meta["shape"])
+        if meta["fortran_order"] and len(shape) > 1 or descr not in ("<f4", "<f8"):
+            return None
+        n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        dt = np.dtype(descr)
+        if o + n * dt.itemsize > len(blob):
+            return None
+        return np.frombuffer(blob, dtype=dt, count=n, offset=o).reshape(shape).copy()
+    except Exception:
+        return None
+
+
+def _read_vstar(path: str) -> np.ndarray:
+    """``np.load(path)["v_star"]``, memoised on (path, mtime, size): an unchanged cache file is read once per process."""
+    st = os.stat(path)
+    key = (path, st.st_mtime_ns, st.st_size)
     v = _VSTAR_CACHE.get(key)
     if v is None:
-        with np.load(path) as z:
-            v = np.asarray(z["v_star"])
+        with open(path, "rb") as f:
+            blob = f.read()
+        v = _npz_single_array(blob, "v_star")
+        if v is None:
+            with np.load(path) as z:
+                v = np.asarray(z["v_star"])
         _VSTAR_CACHE[key] = v
     return v
 
@@ -114,31 +162,29 @@ def load_v_stars(requests: Sequence[Dict], hparams, cache_name: Optional[str], s
                  stage1: Optional[Stage1Fn] = None) -> torch.Tensor:
     """(N, hidden) fp32 on the host: one row per request, the transpose of the reference's ``zs`` (:977)."""
     rows = []
-    files = [vstar_cache_file(cache_name, request, hparams, idx, suffix) for idx, request in enumerate(requests)]
-
-    def read(f):
-        if f is None or not f.exists():
-            return None
-        try:
-            return _read_vstar(f)
-        except Exception as e:  # unreadable cache -> recompute, as the reference (:903-904)
-            print(f"Error reading cache file due to {e}. Recomputing...")
-            return None
-
-    loaded = [read(f) for f in files]   # (a thread pool was measured 6x SLOWER here: np.load of tiny files is GIL-bound)
     for idx, request in enumerate(requests):
-        f, v = files[idx], loaded[idx]
+        f = vstar_cache_name(cache_name, request, hparams, idx, suffix)
+        v = None
+        if f is not None:
+            try:
+                v = _read_vstar(f)
+            except FileNotFoundError:
+                v = None
+            except Exception as e:  # unreadable cache -> recompute, as the reference (:903-904)
+                print(f"Error reading cache file due to {e}. Recomputing...")
+                v = None
         if v is None:
             if stage1 is None:
                 raise NotImplementedError(
                     f"no cached v* for request {idx} ([{request['source']}] -> [{request['dest']}]) at {f}: "
-                    f"Stage 1 (compute_z_*, Adam through the SD UNet; reference emcid/compute_z.py:315-649) is out "
-                    f"of scope of this build — pass cache_name pointing at v_star npz files or a stage1= callable")
+                    f"pass cache_name pointing at v_star npz files (reference emcid_main.py:873-890) or a stage1= "
+                    f"callable (emcid_amd.compute_z.compute_z_text_encoder is the reference's Stage 1)")
             v = stage1(request, suffix).detach().float().cpu().numpy()
             if f is not None:
-                f.parent.mkdir(exist_ok=True, parents=True)
+                Path(f).parent.mkdir(exist_ok=True, parents=True)
                 np.savez(f, v_star=v)
-        v = np.asarray(v, dtype=np.float32)
+        if v.dtype != np.float32:
+            v = v.astype(np.float32)
         if v.ndim == 2:   # use_new_compute_z layout (num_edit_tokens, hidden) with num_edit_tokens == 1
             if v.shape[0] != 1:
                 raise NotImplementedError("num_edit_tokens > 1 is not built (unused by shipped hparams)")
@@ -158,10 +204,27 @@ def _shard_from_env(shard: Optional[ConceptShard]) -> ConceptShard:
     return ConceptShard()
 
 
+_IO_POOL = None
+
+
+def _io_pool():
+    global _IO_POOL
+    if _IO_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _IO_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="emcid-io")
+    return _IO_POOL
+
+
 def prepare_text_encoder_edit(text_encoder, tokenizer, requests, hparams, layers, lam, stat_dir, cache_name,
                               suffix="", verbose=True, shard=None, stage1=None) -> EncoderEditPlan:
     """Host side of one encoder's edit: v* rows, C per layer (HBM-resident), tokenized prompts + lookup."""
-    zs_t = load_v_stars(requests, hparams, cache_name, suffix, stage1)
+    # the v* cache reads are file-system calls (they release the GIL): they run on a helper thread underneath the
+    # tokenizer, which is native code that releases it too.  A Stage-1 callable stays on this thread.
+    if stage1 is None and cache_name is not None and len(requests) >= 64:
+        zs_future = _io_pool().submit(load_v_stars, requests, hparams, cache_name, suffix, None)
+    else:
+        with phase("vstar"):
+            zs_future = load_v_stars(requests, hparams, cache_name, suffix, stage1)
     covs = {layer: get_cov_text_encoder(text_encoder, tokenizer, hparams.rewrite_module_tmp.format(layer),
                                         hparams.mom2_dataset, hparams.mom2_n_samples, hparams.mom2_dtype,
                                         stat_dir=stat_dir, verbose=verbose)
@@ -169,7 +232,7 @@ def prepare_text_encoder_edit(text_encoder, tokenizer, requests, hparams, layers
     for layer in layers:   # resolve every edited weight now: LookupError before any GPU work, like the reference (:858-863)
         nethook.get_parameter(text_encoder, f"{hparams.rewrite_module_tmp.format(layer)}.weight")
     return prepare_encoder_edit(text_encoder, tokenizer, requests, layers, hparams.rewrite_module_tmp, lam,
-                                hparams.edit_weight, zs_t, covs, _shard_from_env(shard),
+                                hparams.edit_weight, zs_future, covs, _shard_from_env(shard),
                                 layer_module_tmp=getattr(hparams, "layer_module_tmp", None))
 
 
@@ -193,7 +256,6 @@ def execute_emcid_text_encoder(pipe, requests: List[Dict], hparams: EMCIDHyperPa
     """Computes the per-layer factors; the model is unchanged on return (invariant of the reference)."""
     hparams.mom2_update_weight = mom2_weight if mom2_weight is not None else hparams.mom2_update_weight
     hparams.edit_weight = edit_weight if edit_weight is not None else hparams.edit_weight
-    requests = deepcopy(requests)
     _announce(requests, verbose)
     plan = prepare_text_encoder_edit(pipe.text_encoder, pipe.tokenizer, requests, hparams, hparams.layers,
                                      hparams.mom2_update_weight, stat_dir, cache_name, "", verbose, shard, stage1)
@@ -212,14 +274,15 @@ def apply_emcid_to_text_encoder(pipe, requests: List[Dict], hparams: EMCIDHyperP
     origin_text_encoder = deepcopy(pipe.text_encoder) if return_orig_text_encoder else None
     hparams.mom2_update_weight = mom2_weight if mom2_weight is not None else hparams.mom2_update_weight
     hparams.edit_weight = edit_weight if edit_weight is not None else hparams.edit_weight
-    requests = deepcopy(requests)
     _announce(requests, verbose)
     plan = prepare_text_encoder_edit(pipe.text_encoder, pipe.tokenizer, requests, hparams, hparams.layers,
                                      hparams.mom2_update_weight, stats_dir, cache_name, "", verbose, shard, stage1)
     # The engine leaves each fc2 at W0 + float(U): the value the reference reaches by restoring W0 (:1076-1078)
     # and adding float(adj_k @ resid^T) again (:802-809).
-    edits = run_encoder_edit(plan, keep_factors=False, restore=False)
-    check_info(plan)
+    with phase("run(host launches)"):
+        edits = run_encoder_edit(plan, keep_factors=False, restore=False)
+    with phase("final sync"):
+        check_info(plan)
     if verbose:
         print(f"New weights successfully inserted into {[e.weight_name for e in edits]}")
     return pipe, origin_text_encoder
@@ -424,7 +487,6 @@ def execute_emcid_sd_xl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
                                       stat_dir_2="data/stats/sdxl/text2", shard=None, stage1=None):
     """(deltas, deltas_2).  TE1 is restored; TE2 is left at W + dW exactly as the reference leaves it (:1410)."""
     _sdxl_overrides(hparams, mom2_weight, mom2_weight_2, edit_weight)
-    requests = deepcopy(requests)
     _announce(requests, verbose)
     p1, p2 = _sdxl_plans(pipe, requests, hparams, cache_name, stat_dir, stat_dir_2, verbose, shard, stage1)
     e1 = run_encoder_edit(p1, keep_factors=True, restore=True)
@@ -443,7 +505,6 @@ def apply_emcid_to_sdxl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
     o1 = deepcopy(pipe.text_encoder) if return_orig_text_encoder else None
     o2 = deepcopy(pipe.text_encoder_2) if return_orig_text_encoder else None
     _sdxl_overrides(hparams, mom2_weight, mom2_weight_2, edit_weight)
-    requests = deepcopy(requests)
     _announce(requests, verbose)
     p1, p2 = _sdxl_plans(pipe, requests, hparams, cache_name, stat_dir, stat_dir_2, verbose, shard, stage1)
     # The two encoders are independent models (:1233 vs :1333): run them on two HIP streams.

@@ -101,7 +101,12 @@ def load():
     return lib
 
 
+_restore_device = []      # device ordinals to go back to after the call in flight (see _stream)
+
+
 def _check(rc: int, what: str):
+    if _restore_device:
+        torch.cuda.set_device(_restore_device.pop())
     if rc != 0:
         raise EmcidHipError(f"{what} failed (rc={rc}): {load().emcid_last_error().decode()}")
 
@@ -117,6 +122,15 @@ def _ptr(t: Optional[torch.Tensor], dtype=None, what="tensor"):
 
 
 def _stream(t: torch.Tensor):
+    """The current HIP stream of the tensor's device — and that device made current for the duration of the call
+    (include/emcid_hip.h: the library keys its capture streams, cached graphs and launches by the current device; a model
+    on cuda:1 while cuda:0 is current must still run on cuda:1).  Every call site is ``_check(lib.fn(..., _stream(t)), name)``:
+    ``_check`` switches back."""
+    idx = t.device.index
+    cur = torch.cuda.current_device()
+    if idx is not None and idx != cur:
+        _restore_device.append(cur)
+        torch.cuda.set_device(idx)
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
@@ -421,6 +435,8 @@ class CovFactors:
         self.dp = (d + NB - 1) // NB * NB
         self._inv = ((self.dp + 511) // 512) * (512 * 512 + 256 * 256)   # csrc/common.h inv_doubles
         self.have_inverse = set()                                        # layers whose X = inv(L) has been built
+        self.ready = None       # HIP event after the last kernel that wrote this workspace on another stream (or None)
+        self.cached = False     # True once the edit engine shares it between edits (then it is read-only)
 
     def L(self, layer: int) -> torch.Tensor:
         """(dp, dp) view of the Cholesky factor of lam*C'_layer (lower triangle valid)."""

@@ -10,7 +10,9 @@
  * with explicit leading dimensions in ELEMENTS; `stream` is a hipStream_t passed as void*; every
  * call is asynchronous on `stream` and returns 0 (EMCID_OK) or a negative error code — no
  * exceptions cross the ABI; the caller owns every buffer.  f64 buffers and leading dimensions must
- * be 16-byte aligned / even (checked: EMCID_ERR_BAD_ARG).
+ * be 16-byte aligned / even (checked: EMCID_ERR_BAD_ARG).  The device that owns the buffers and `stream`
+ * must be the CURRENT device of the calling thread (hipSetDevice) — emcid_amd/hip.py makes it so around every
+ * call; internal per-device state (capture streams, cached graphs, function attributes) is keyed by it.
  */
 #ifndef EMCID_HIP_H
 #define EMCID_HIP_H

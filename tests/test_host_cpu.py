@@ -59,6 +59,68 @@ def test_token_ranges_golden_and_memo():
                 assert list(fn(r["ids"], r["subject"])) == r["range"]
 
 
+def test_token_range_batch_equals_scalar_walk():
+    """The vectorised batch walk (cumulative piece lengths) returns what the scalar walk returns, row for row, including
+    the rows it must hand to the scalar path ([CLS], [EOS], '', ' ', all-space subjects) and a missing subject."""
+    tok = syn.build_tokenizer(*syn.synthetic_vocab(syllables=True))
+    names = syn.syllable_names(40) + ["Vincent van Gogh", "c0042", "by", "[CLS]", "[EOS]", "", " ", "o'keeffe", "painting"]
+    prompts = [t.format(n) for n in names for t in syn.ARTIST_TEMPLATES]
+    subjects = [n for n in names for _ in syn.ARTIST_TEMPLATES]
+    ids = tok(prompts, padding=True, truncation=True)["input_ids"]
+    scalar = TokenRangeFinder(tok)
+    want = [scalar(r, s) for r, s in zip(ids, subjects)]
+    got = TokenRangeFinder(tok).batch(ids, subjects)
+    assert [tuple(g) for g in got] == [tuple(w) for w in want]
+    orc_want = [orc.find_token_range(tok, torch.tensor(r), s) for r, s in zip(ids, subjects)]
+    assert [tuple(g) for g in got] == [tuple(w) for w in orc_want]
+    with pytest.raises(ValueError):
+        TokenRangeFinder(tok).batch(ids[:3], ["zzzz", subjects[1], subjects[2]])
+    # a row with a piece that is not valid UTF-8 on its own (U+FFFD) takes the whole-row decode: same answer
+    poisoned = TokenRangeFinder(tok)
+    poisoned.batch(ids[:4], subjects[:4])
+    poisoned._piece_ns[ids[0][3]] = "\ufffd"
+    assert [tuple(g) for g in poisoned.batch(ids, subjects)] == [tuple(w) for w in want]
+    assert TokenRangeFinder(tok)._compositional() == "</w>"
+    # ragged rows (no common length): the scalar path row by row
+    ragged = [r[:len(r) - (i % 2)] for i, r in enumerate(ids[:6])]
+    assert TokenRangeFinder(tok).batch(ragged, subjects[:6]) == [scalar(r, s) for r, s in zip(ragged, subjects[:6])]
+
+
+def test_fast_tokenize_equals_public_call():
+    from emcid_amd.compute_z import tokenize_lists
+    tok = syn.build_tokenizer(*syn.synthetic_vocab(syllables=True))
+    prompts = [t.format(n) for n in syn.syllable_names(30) + ["a " * 90 + "b"] for t in syn.ARTIST_TEMPLATES]   # one over 77 tokens
+    pub = tok(prompts, padding=True, truncation=True)
+    got = tokenize_lists(tok, prompts)
+    assert got["input_ids"].tolist() == pub["input_ids"] and got["attention_mask"].tolist() == pub["attention_mask"]
+    assert got["input_ids"].shape[1] == 77
+    few = tokenize_lists(tok, prompts[:3])          # small batches take the public call
+    assert few["input_ids"].tolist() == tok(prompts[:3], padding=True, truncation=True)["input_ids"]
+
+
+def test_vectorised_trie_is_the_prefix_set_up_to_the_lookup_tokens():
+    from emcid_amd import clip_forward as cf
+    rng = np.random.default_rng(5)
+    B, S = 200, 9
+    ids = rng.integers(0, 3, size=(B, S))
+    ids[:, 0] = 7
+    lookup = rng.integers(0, S, size=B)
+    trie = cf.build_trie(ids, lookup.tolist(), "cpu", bucket=16)
+    tok_np, anc_np, dep = trie.token.numpy(), trie.anc.numpy(), trie.depth.numpy()
+    want = {tuple(ids[b, :p + 1]) for b in range(B) for p in range(lookup[b] + 1)}
+    got = {tuple(int(tok_np[a]) for a in anc_np[u, :dep[u] + 1]) for u in range(trie.n_nodes)}
+    assert got == want and trie.n_nodes == len(want)
+    for b in range(B):          # every prompt's lookup node spells the prompt up to its lookup token
+        u = int(trie.lookup_node[b])
+        assert dep[u] == lookup[b] and [int(tok_np[a]) for a in anc_np[u, :dep[u] + 1]] == ids[b, :lookup[b] + 1].tolist()
+        assert int(trie.query_rows[int(trie.lookup_in_query[b])]) == u
+    U = trie.token.shape[0]
+    assert U % 16 == 0 and trie.query_rows.numel() % 16 == 0
+    assert (anc_np[trie.n_nodes:, 0] == np.arange(trie.n_nodes, U)).all() and (dep[trie.n_nodes:] == 0).all()
+    for u in range(trie.n_nodes):       # parents precede children (the forward relies on nothing else about the order)
+        assert (anc_np[u, :dep[u]] < u).all() and anc_np[u, dep[u]] == u
+
+
 def test_prompt_batch_matches_oracle_lookup():
     tok = syn.build_tokenizer()
     reqs = syn.make_requests(9, ragged=True)
@@ -198,6 +260,23 @@ def test_vstar_paths_and_loading(tmp_path):
         em.load_v_stars(syn.make_requests(5), hp, cache)
     filled = em.load_v_stars(syn.make_requests(5), hp, cache, stage1=lambda req, sfx: torch.ones(32))
     assert filled.shape == (5, 32) and (Path(cache) / "source_c0004_dest_a realist artist.npz").exists()
+    # the direct npz parser: only the file np.savez(f, v_star=...) writes; everything else goes through np.load
+    f0 = str(syn.vstar_cache_path(cache, reqs[0]))
+    assert np.array_equal(em._npz_single_array(open(f0, "rb").read(), "v_star"), vs[0])
+    np.savez_compressed(tmp_path / "c.npz", v_star=vs[1])
+    assert em._npz_single_array(open(tmp_path / "c.npz", "rb").read(), "v_star") is None
+    assert np.array_equal(em._read_vstar(str(tmp_path / "c.npz")), vs[1])
+    np.savez(tmp_path / "d.npz", other=vs[2], v_star=vs[3])
+    assert em._npz_single_array(open(tmp_path / "d.npz", "rb").read(), "v_star") is None
+    assert np.array_equal(em._read_vstar(str(tmp_path / "d.npz")), vs[3])
+    # a rewritten file is re-read (the in-process copy is keyed by mtime and size)
+    import os, time as _t
+    np.savez(f0, v_star=vs[0] + 1)
+    os.utime(f0, ns=(_t.time_ns(), _t.time_ns() + 10_000_000))
+    assert np.array_equal(em.load_v_stars(reqs, hp, cache).numpy()[0], vs[0] + 1)
+    (tmp_path / "e.npz").write_bytes(b"PK\x03\x04 not a zip")
+    hp2 = EMCIDHyperParams(**syn.sd_hparams_dict())
+    assert em._npz_single_array((tmp_path / "e.npz").read_bytes(), "v_star") is None
 
 
 def test_upd_matrix_match_shape():
