@@ -341,6 +341,91 @@ __device__ __forceinline__ void gemm_f64_tile(const GemmShape& p, const Epi& epi
             }
 }
 
+
+// The K loop of one output tile over its K tiles [kt_begin, kt_end) (relative to the tile's own first contributing K
+// tile under `tri`), result left in the caller's accumulators: the building block of the two-phase stream-K kernel.
+// PF K tiles of global loads are in flight in PF register sets (LDS stays double-buffered).  The stream-K shapes read
+// operands that the XCD's L2 rarely holds (1024 x 3072 x 3072 against a triangle: ~90 % of the tile bytes come from the
+// Infinity Cache); with one K tile ahead a workgroup has 32 KB in flight and needs it back within one K tile of MFMAs
+// (1.7 us) — the loaded Infinity-Cache latency is above that (MI355X_MICROARCH.md, gather table: 72 KB in flight per CU for
+// 33 GB/s).  Loads are branch-free (clamped address + zeroing select at the LDS store), so the waits are counted.
+// Needs even extents along each operand's contiguous dimension.
+template <bool KCA, bool KCB, int BM, int BN, int BK, int WGM, int WGN, int PF>
+__device__ __forceinline__ void gemm_f64_tile_acc(const GemmShape& p, int bm, int bn, double* smem, int kt_begin, int kt_end,
+                                                  v4d (&acc)[BM / WGM / 16][BN / WGN / 16]) {
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int MI = WM / 16, NI = WN / 16;
+    using TA = OpTile<KCA, BM, BK>;
+    using TB = OpTile<KCB, BN, BK>;
+    constexpr int STAGE = TA::SIZE + TB::SIZE;
+    constexpr int NA = TA::NVEC / NT, NB = TB::NVEC / NT;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    int t0 = 0, t1 = (p.K + BK - 1) / BK;
+    if (p.tri & 1) t1 = min(t1, (min(p.K, n0 + BN) + BK - 1) / BK);
+    if (p.tri & 2) t0 = max(t0, min(n0, p.K) / BK);
+    if (p.tri & 4) t1 = min(t1, (min(p.K, m0 + BM) + BK - 1) / BK);
+    if (p.tri & 8) t0 = max(t0, min(m0, p.K) / BK);
+    t1 = min(t1, t0 + kt_end);
+    t0 += kt_begin;
+    if (t0 >= t1) return;
+    v2d qa[PF][NA], qb[PF][NB];
+    bool oa[PF][NA], ob[PF][NB];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+        load_tile_nobranch<KCA, BM, BK, NT>(qa[s], oa[s], p.A, p.lda, m0, p.M, (t0 + s) * BK, p.K, tid, t0 + s < t1);
+        load_tile_nobranch<KCB, BN, BK, NT>(qb[s], ob[s], p.B, p.ldb, n0, p.N, (t0 + s) * BK, p.K, tid, t0 + s < t1);
+    }
+    __syncthreads();          // the previous segment's last MFMA stage may still be reading LDS
+    store_tile_masked<KCA, BM, BK, NT>(qa[0], oa[0], smem, tid);
+    store_tile_masked<KCB, BN, BK, NT>(qb[0], ob[0], smem + TA::SIZE, tid);
+    __syncthreads();
+    for (int base = t0; base < t1; base += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int t = base + s;          // tile t sits in LDS stage (t - t0) & 1; its register set s is free again
+            if (t < t1) {
+                const double* As = smem + ((t - t0) & 1) * STAGE;
+                const double* Bs = As + TA::SIZE;
+                load_tile_nobranch<KCA, BM, BK, NT>(qa[s], oa[s], p.A, p.lda, m0, p.M, (t + PF) * BK, p.K, tid, t + PF < t1);
+                load_tile_nobranch<KCB, BN, BK, NT>(qb[s], ob[s], p.B, p.ldb, n0, p.N, (t + PF) * BK, p.K, tid, t + PF < t1);
+                // keep the loads HERE: left alone, hipcc sinks them below the MFMAs into the registers the LDS store of
+                // this step frees, which puts them back to one K tile ahead of their use
+                if (PF > 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k8 = 0; k8 < BK / 8; ++k8) {
+                    double a[2][MI], b[2][NI];
+                    TA::template frags<MI>(As, wm0, k8, l15, l4, a);
+                    TB::template frags<NI>(Bs, wn0, k8, l15, l4, b);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+#pragma unroll
+                            for (int j = 0; j < NI; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e][i], b[e][j], acc[i][j], 0, 0, 0);
+                }
+                if (PF > 1) __builtin_amdgcn_sched_barrier(0);   // ... and the zeroing selects of the set stored next BELOW them
+                {   // tile t+1 (zeros past the end: never read) into the other LDS stage
+                    const int sn = (s + 1) % PF;
+                    double* An = smem + ((t + 1 - t0) & 1) * STAGE;
+                    store_tile_masked<KCA, BM, BK, NT>(qa[sn], oa[sn], An, tid);
+                    store_tile_masked<KCB, BN, BK, NT>(qb[sn], ob[sn], An + TA::SIZE, tid);
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
 template <bool KCA, bool KCB, int BM, int BN, int BK, int WGM, int WGN, class Epi>
 __global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_kernel(GemmShape p, Epi epi) {
     const int zb = blockIdx.z / p.ksplit, zs = blockIdx.z % p.ksplit;
@@ -530,6 +615,242 @@ inline void launch_gemm_f64_streamk(GemmShape p, EpiAxpby epi, hipStream_t strea
     const unsigned grid = (unsigned)((total + per - 1) / per);
     epi.beta = 0.0;
     hipLaunchKernelGGL((gemm_f64_streamk_kernel<KCA, KCB, BM, BN, BK, 2, 4>), dim3(grid), dim3(512), 0, stream, p, epi, total, per);
+}
+
+
+// ---- stream-K, second form: no atomics, no zero fill, bit-reproducible ---------------------------------------------------
+// Same partition as above (the (tile, K-step) space cut into equal runs), but a run's partial tiles go to a workspace slot
+// (lane-linear image of the accumulators, 16-byte write-through stores) instead of being added into C with f64 atomics:
+//   * a run holds at most two partial segments: its first (the tail of a tile an earlier run started) and its last (the
+//     head of a tile a later run continues) -> slots 2r and 2r+1 of `partials` (BM*BN doubles each);
+//   * every contributor of a tile publishes its slot, then takes a ticket on the tile's counter; the one whose ticket is
+//     the last re-reads ALL slots of the tile in run order — its own included, so the sum order never depends on who came
+//     last — applies the epilogue and puts the counter back to zero (the workspace is ready for the next launch);
+//   * nobody waits for anybody: no spinning, no co-residency assumption.
+// Atomics execute at the memory side at ~1.3 TB/s chip-wide (MI355X_MICROARCH.md): the 256 runs of the first form all end at
+// the same time and leave ~33 MB of them behind as a tail; write-through stores move the same bytes at ~6 TB/s, and the
+// output needs no zero-filling launch.  Cross-CU hand-off follows cdna_hip_programming.md Guideline 16 (R1), write-through form: sc1 stores ->
+// every wave's s_waitcnt vmcnt(0) -> barrier -> lane 0 relaxed agent-scope ticket; the last arriver: ticket -> lane 0
+// acquire fence (agent) -> s_waitcnt -> barrier -> plain loads.
+// Runs are dealt to workgroups so that the 32 workgroups of an XCD (blockIdx % 8) hold 32 CONSECUTIVE runs: they work
+// on the same one or two column tiles at the same time, whose B panel (<= 3 MB) then stays in that XCD's 4 MB L2.
+struct StreamKWork {
+    double* partials;        // [2 * runs][BM * BN]
+    unsigned* counters;      // [tiles], zero on entry, zero again on exit
+    double diag_add;         // added to C(i, i) by the epilogue (the identity of S = I + Yt Yt^T); 0 otherwise
+    long long* stamps;       // diagnostic (usually null): 8 shader-clock values per workgroup, see scripts/streamk_stamps.py
+};
+
+template <int MI, int NI>
+__device__ __forceinline__ void streamk_store_partial(double* slot, const v4d (&acc)[MI][NI], int tid, int nthreads) {
+    // lane-linear: vector v = (i * NI + j) * 2 + half holds registers {2 half, 2 half + 1} of tile (i, j)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                v2d x = {acc[i][j][2 * hf], acc[i][j][2 * hf + 1]};
+                double* q = slot + ((int64_t)((i * NI + j) * 2 + hf) * nthreads + tid) * 2;
+                // write-through (sc1): the bytes leave the XCD's L2 as they are stored, so publishing them needs no
+                // agent-scope release (an L2 write-back of everything the workgroup's XCD has dirtied: 2-6 us)
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(q), "v"(x) : "memory");
+            }
+}
+
+template <int MI, int NI>
+__device__ __forceinline__ void streamk_add_partial(const double* slot, v4d (&acc)[MI][NI], int tid, int nthreads) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const v2d x = *reinterpret_cast<const v2d*>(slot + ((int64_t)((i * NI + j) * 2 + hf) * nthreads + tid) * 2);
+                acc[i][j][2 * hf] += x[0];
+                acc[i][j][2 * hf + 1] += x[1];
+            }
+}
+
+template <bool KCA, bool KCB, int BM, int BN, int BK, int WGM, int WGN, int PF>
+__global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_streamk2_kernel(GemmShape p, EpiAxpby epi, StreamKWork w, long long total_units,
+                                                                            long long units_per_wg, int xcd_map) {
+    using TA = OpTile<KCA, BM, BK>;
+    using TB = OpTile<KCB, BN, BK>;
+    constexpr int NT = WGM * WGN * 64;
+    constexpr int MI = BM / WGM / 16, NI = BN / WGN / 16;
+    __shared__ __attribute__((aligned(16))) double smem[2 * (TA::SIZE + TB::SIZE) + (KCB ? 0 : 2)];
+    // "I took the last ticket" flag: with a K-contiguous B image the last double of the array is row padding nobody reads
+    // (a separate __shared__ word would push 2 x 80 KB over the CU's 160 KB); otherwise two spare doubles behind it
+    volatile int& s_last = *reinterpret_cast<volatile int*>(smem + (KCB ? 2 * (TA::SIZE + TB::SIZE) - 1 : 2 * (TA::SIZE + TB::SIZE)));
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WGN) * (BM / WGM), wn0 = (wave % WGN) * (BN / WGN);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int MT = (p.M + BM - 1) / BM, NTL = (p.N + BN - 1) / BN;
+    const int KT = (p.K + BK - 1) / BK;
+    const int G = gridDim.x;
+    long long run = blockIdx.x;
+    if (xcd_map && G % 8 == 0) run = (long long)(blockIdx.x % 8) * (G / 8) + blockIdx.x / 8;
+    long long u = run * units_per_wg;
+    const long long u0 = u;
+    const long long u1 = min(total_units, u + units_per_wg);
+    GemmShape q = p;
+    q.lower_only = 0;
+    int bn = 0, bm = 0;
+    long long base = 0;      // first unit of the current tile (lower_only) or column tile (triangular)
+    long long st_begin = 0, st_loop = 0, st_publish = 0, st_reduce = 0, st_epi = 0, st_segments = 0, st_mark = 0;
+    if (w.stamps) st_begin = st_mark = __builtin_amdgcn_s_memtime();
+#define EMCID_SK_LAP(acc_var)                                                \
+    if (w.stamps) {                                                          \
+        const long long now_ = __builtin_amdgcn_s_memtime();                 \
+        acc_var += now_ - st_mark;                                           \
+        st_mark = now_;                                                      \
+    }
+    if (!p.lower_only) {
+        while (bn < NTL) {
+            const long long span = (long long)MT * streamk_depth(p, bn, BN, BK);
+            if (u < base + span) break;
+            base += span;
+            ++bn;
+        }
+    }
+    while (u < u1) {
+        int depth, tile_id;
+        long long tile_begin;
+        if (p.lower_only) {
+            // SYRK-like: the lower tiles (bn <= bm) of a square output, every tile KT deep, numbered row by row
+            const long long t = u / KT;
+            bm = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+            while ((long long)(bm + 1) * (bm + 2) / 2 <= t) ++bm;
+            while ((long long)bm * (bm + 1) / 2 > t) --bm;
+            bn = (int)(t - (long long)bm * (bm + 1) / 2);
+            depth = KT;
+            tile_begin = t * KT;
+            tile_id = (int)t;
+        } else {
+            if (bn >= NTL) break;
+            depth = streamk_depth(p, bn, BN, BK);
+            const long long span = (long long)MT * depth;
+            if (depth == 0 || u >= base + span) { base += span; ++bn; continue; }
+            bm = (int)((u - base) / depth);
+            tile_begin = base + (long long)bm * depth;
+            tile_id = bn * MT + bm;
+        }
+        const int k_begin = (int)(u - tile_begin);
+        const int k_end = (int)min((long long)depth, k_begin + (u1 - u));
+        v4d acc[MI][NI];
+        gemm_f64_tile_acc<KCA, KCB, BM, BN, BK, WGM, WGN, PF>(q, bm, bn, smem, k_begin, k_end, acc);
+        EMCID_SK_LAP(st_loop)
+        ++st_segments;
+        bool finish = (k_begin == 0 && k_end == depth);
+        if (!finish) {
+            const long long r_first = tile_begin / units_per_wg, r_last = (tile_begin + depth - 1) / units_per_wg;
+            const int slot = (int)(2 * run + (u == u0 ? 0 : 1));
+            streamk_store_partial<MI, NI>(w.partials + (int64_t)slot * BM * BN, acc, tid, NT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned old = __hip_atomic_fetch_add(w.counters + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = (old == (unsigned)(r_last - r_first)) ? 1 : 0;
+            }
+            __syncthreads();
+            EMCID_SK_LAP(st_publish)
+            if (s_last) {
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+                for (long long r = r_first; r <= r_last; ++r) {
+                    // run r's segment of this tile starts at the run's own start unless the tile begins inside the run
+                    const int sl = (int)(2 * r + ((r == r_first && tile_begin != r * units_per_wg) ? 1 : 0));
+                    streamk_add_partial<MI, NI>(w.partials + (int64_t)sl * BM * BN, acc, tid, NT);
+                }
+                if (tid == 0) w.counters[tile_id] = 0;
+                finish = true;
+            }
+            __syncthreads();       // s_last is rewritten by the next segment
+            EMCID_SK_LAP(st_reduce)
+        }
+        if (finish) {
+            const int m0 = bm * BM, n0 = bn * BN;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + wm0 + TA::index_of(i, l4 + 4 * r);
+                        const int n = n0 + wn0 + TB::index_of(j, l15);
+                        if (m < p.M && n < p.N) {
+                            double v = epi.alpha * acc[i][j][r];
+                            if (m == n) v += w.diag_add;
+                            epi.C[(int64_t)m * epi.ldc + n] = v;
+                        }
+                    }
+            EMCID_SK_LAP(st_epi)
+        }
+        u += k_end - k_begin;
+    }
+    if (w.stamps && tid == 0) {
+        long long* o = w.stamps + (int64_t)blockIdx.x * 8;
+        o[0] = st_begin; o[1] = __builtin_amdgcn_s_memtime(); o[2] = st_loop; o[3] = st_publish; o[4] = st_reduce; o[5] = st_epi;
+        o[6] = st_segments; o[7] = (long long)run;
+    }
+#undef EMCID_SK_LAP
+}
+
+inline long long* g_streamk_stamps = nullptr;      // diagnostic target, set by emcid_debug_streamk_stamps
+
+inline int64_t streamk_workspace_doubles(int wgs) { return (int64_t)2 * wgs * 128 * 128 + 8192; }   // slots + counters (as doubles)
+
+// C = alpha * A B (+ diag_add on the diagonal); C needs no initial value.  `work`: streamk_workspace_doubles(wgs) doubles whose
+// counter part (the last 8192 doubles) is zero (it is left zero).
+template <bool KCA, bool KCB, int BK>
+inline void launch_gemm_f64_streamk2_bk(GemmShape p, EpiAxpby epi, hipStream_t stream, int wgs, double* work, double diag_add) {
+    constexpr int BM = 128, BN = 128;
+    const int MT = (p.M + BM - 1) / BM, NTL = (p.N + BN - 1) / BN, KT = (p.K + BK - 1) / BK;
+    long long total = 0;
+    if (p.lower_only) total = (long long)MT * (MT + 1) / 2 * KT;
+    else for (int bn = 0; bn < NTL; ++bn) {
+        int depth = KT;
+        if (p.tri & 1) { const int ke = p.K < (bn + 1) * BN ? p.K : (bn + 1) * BN; depth = (ke + BK - 1) / BK; if (depth > KT) depth = KT; }
+        else if (p.tri & 2) { const int kb = bn * BN < p.K ? bn * BN : p.K; depth = KT - kb / BK; }
+        total += (long long)MT * depth;
+    }
+    if (total <= 0) return;
+    long long per = (total + wgs - 1) / wgs;
+    if (per < 128 / BK) per = 128 / BK;                      // never less than a 128-deep run per workgroup
+    unsigned grid = (unsigned)((total + per - 1) / per);
+    static const int xcd_map = [] { const char* v = getenv("EMCID_STREAMK_XCD"); return v ? atoi(v) : 1; }();
+    int map = xcd_map;
+    if (grid % 8) {                    // keep the XCD dealing exact: round the grid up (trailing runs are empty)
+        const unsigned g8 = (grid + 7) / 8 * 8;
+        if ((int)g8 <= wgs) grid = g8; else map = 0;
+    }
+    StreamKWork w{work, reinterpret_cast<unsigned*>(work + (int64_t)2 * wgs * BM * BN), diag_add, g_streamk_stamps};
+    static const int pf = [] { const char* v = getenv("EMCID_STREAMK_PF"); return v ? atoi(v) : 1; }();
+    if (pf <= 1) hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, 2, 4, 1>), dim3(grid), dim3(512), 0, stream, p, epi, w, total, per, map);
+    else hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, 2, 4, 2>), dim3(grid), dim3(512), 0, stream, p, epi, w, total, per, map);
+}
+
+// C = alpha * A B (+ diag_add on the diagonal); C needs no initial value.  `work`: streamk_workspace_doubles(wgs) doubles whose
+// counter part (the last 8192 doubles) is zero (it is left zero).
+template <bool KCA, bool KCB>
+inline void launch_gemm_f64_streamk2(GemmShape p, EpiAxpby epi, hipStream_t stream, int wgs, double* work, double diag_add = 0.0) {
+    const int MT = (p.M + 127) / 128, NTL = (p.N + 127) / 128;
+    if ((long long)MT * NTL > 16384) {      // more tiles than ticket counters: the atomic form (needs C zeroed / preset by the caller)
+        launch_gemm_f64_streamk<KCA, KCB>(p, epi, stream, wgs);
+        return;
+    }
+    static const int bk = [] { const char* v = getenv("EMCID_STREAMK_BK"); return v ? atoi(v) : 16; }();
+    if (bk == 32) launch_gemm_f64_streamk2_bk<KCA, KCB, 32>(p, epi, stream, wgs, work, diag_add);
+    else launch_gemm_f64_streamk2_bk<KCA, KCB, 16>(p, epi, stream, wgs, work, diag_add);
 }
 
 // ---- launcher ----------------------------------------------------------------------------------

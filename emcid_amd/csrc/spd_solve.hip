@@ -766,22 +766,32 @@ static int build_full_inverse(const double* L, int64_t dp, int64_t lda, const do
 // into a zeroed output.  Measured for 1024 x 3072 x 3072: 218 us (zeroing included) against 253 us for mirrored 32x64
 // tile pairs and 306 us for plain 64x64 tiles; 768 rows: 188 / 238 / 299 us (scripts/mb_tri.py).
 static const int kStreamKWgs = 256;
+static const int kStreamKForm = env_flag("EMCID_STREAMK_V", 2);      // 2: two-phase, reproducible; 1: f64 atomics into a zeroed C
 
 // Yt[rows, dp] = Kt[rows, dp] * X^T  (= Kt L^-T: the forward substitution as one GEMM)
-static void apply_inverse_forward(const double* X, int64_t dp, const double* Kt, double* Yt, int rows, hipStream_t st) {
+static void apply_inverse_forward(const double* X, int64_t dp, const double* Kt, double* Yt, int rows, hipStream_t st,
+                                  double* sk_work = nullptr) {
     ScopedProf sp(KC_INV_APPLY, st);
     GemmShape g{Kt, dp, X, dp, rows, (int)dp, (int)dp, 0};
     g.tri = 1;       // B(k, n) = X[n][k], zero for k > n
+    if (sk_work && kStreamKForm == 2) {
+        launch_gemm_f64_streamk2<true, true>(g, EpiAxpby{Yt, dp, 1.0, 0.0}, st, kStreamKWgs, sk_work);
+        return;
+    }
     hipLaunchKernelGGL(zero2d_f64_kernel, dim3((unsigned)rows, 1u), dim3(256), 0, st, Yt, dp, (int64_t)0, (int)dp);
     launch_gemm_f64_streamk<true, true>(g, EpiAxpby{Yt, dp, 1.0, 0.0}, st, kStreamKWgs);
 }
 
 // C[rows, ncols] (f64, leading dimension ldc) = V[rows, dp] * X  (= V L^-1: the backward substitution as one GEMM)
 static void apply_inverse_backward(const double* X, int64_t dp, const double* V, int rows, int ncols, double* C, int64_t ldc,
-                                   hipStream_t st) {
+                                   hipStream_t st, double* sk_work = nullptr) {
     ScopedProf sp(KC_INV_APPLY, st);
     GemmShape g{V, dp, X, dp, rows, ncols, (int)dp, 0};
     g.tri = 2;       // B(k, n) = X[k][n], zero for k < n
+    if (sk_work && kStreamKForm == 2) {
+        launch_gemm_f64_streamk2<true, false>(g, EpiAxpby{C, ldc, 1.0, 0.0}, st, kStreamKWgs, sk_work);
+        return;
+    }
     hipLaunchKernelGGL(zero2d_f64_kernel, dim3((unsigned)rows, 1u), dim3(256), 0, st, C, ldc, (int64_t)0, ncols);
     launch_gemm_f64_streamk<true, false>(g, EpiAxpby{C, ldc, 1.0, 0.0}, st, kStreamKWgs);
 }
@@ -906,11 +916,16 @@ __global__ __launch_bounds__(256) void eye_f64_kernel(double* __restrict__ S, in
 
 // S[Np, Np] = I + P Q^T on the lower tiles, K = dp deep.  Np x Np is too few output tiles for the chip, so the
 // contraction is split over workgroups that add their partials into the identity with f64 atomics.
-static void assemble_dual_system(const double* P, const double* Q, int64_t dp, double* S, int Np, hipStream_t st) {
+static void assemble_dual_system(const double* P, const double* Q, int64_t dp, double* S, int Np, hipStream_t st,
+                                 double* sk_work = nullptr) {
     ScopedProf sp(KC_ASSEMBLE, st);
-    hipLaunchKernelGGL(eye_f64_kernel, dim3((unsigned)Np), dim3(256), 0, st, S, Np);
     GemmShape g{P, dp, Q, dp, Np, Np, (int)dp, 1};
     static const int streamk = env_flag("EMCID_SYRK_STREAMK", 1);
+    if (streamk && Np >= 512 && sk_work && kStreamKForm == 2) {    // S = I + P Q^T written once per tile, no identity pass
+        launch_gemm_f64_streamk2<true, true>(g, EpiAxpby{S, Np, 1.0, 0.0}, st, kStreamKWgs, sk_work, 1.0);
+        return;
+    }
+    hipLaunchKernelGGL(eye_f64_kernel, dim3((unsigned)Np), dim3(256), 0, st, S, Np);
     if (streamk && Np >= 512) {   // lower 128x128 tiles x K cut into 256 equal runs, added atomically into the identity
         launch_gemm_f64_streamk<true, true>(g, EpiAxpby{S, Np, 1.0, 1.0}, st, 256);
         return;
@@ -934,7 +949,7 @@ __global__ __launch_bounds__(256) void transpose_f64_kernel(const double* __rest
 
 struct DualWorkspace {
     int64_t Np, dp, hp;
-    int64_t off_K, off_P, off_Y, off_R, off_S, off_LS, off_invS, off_PT, off_Y2, off_V, off_U, total;   // doubles
+    int64_t off_K, off_P, off_Y, off_R, off_S, off_LS, off_invS, off_PT, off_Y2, off_V, off_U, off_SK, total;   // doubles
     DualWorkspace(int64_t N, int64_t d, int64_t h) {
         Np = round_up(N, NB);
         dp = round_up(d, NB);
@@ -951,6 +966,7 @@ struct DualWorkspace {
         off_Y2 = o; o += dp * Np;
         off_V = o; o += hp * dp;
         off_U = o; o += hp * dp;
+        off_SK = o; o += streamk_workspace_doubles(kStreamKWgs);      // partial-tile slots + ticket counters (zero between launches)
         total = o;
     }
 };
@@ -1056,6 +1072,35 @@ int emcid_dgemm_ex_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double a
     else if (ta == 1 && tb == 0) launch_gemm_f64<false, true>(p, e, st, cfg);
     else launch_gemm_f64<false, false>(p, e, st, cfg);
     EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+int64_t emcid_streamk_workspace_bytes(int wgs) { return wgs > 0 ? streamk_workspace_doubles(wgs) * (int64_t)sizeof(double) : 0; }
+
+int emcid_dgemm_streamk_f64(int tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda, const double* B,
+                            int64_t ldb, double* C, int64_t ldc, int flags, int wgs, double diag_add, void* workspace,
+                            int64_t workspace_bytes, void* stream) {
+    EMCID_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C && workspace && wgs > 0 && wgs <= 4096);
+    EMCID_CHECK_ARG(aligned16(A) && aligned16(B) && aligned16(workspace) && (lda % 2 == 0) && (ldb % 2 == 0));
+    EMCID_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30) && (flags & ~19) == 0);
+    const int tri = flags & 3, lower = (flags >> 4) & 1;
+    EMCID_CHECK_ARG((lower && M == N && tri == 0) || (!lower && (tri == 1 || tri == 2)));
+    if (workspace_bytes < emcid_streamk_workspace_bytes(wgs)) return fail(EMCID_ERR_WORKSPACE, __func__, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    GemmShape p{A, lda, B, ldb, (int)M, (int)N, (int)K, lower};
+    p.tri = tri;
+    ScopedProf sp(KC_DGEMM, st);
+    if (tb == 0) launch_gemm_f64_streamk2<true, true>(p, EpiAxpby{C, ldc, alpha, 0.0}, st, wgs, (double*)workspace, diag_add);
+    else launch_gemm_f64_streamk2<true, false>(p, EpiAxpby{C, ldc, alpha, 0.0}, st, wgs, (double*)workspace, diag_add);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+/* diagnostic: later two-phase stream-K launches write 8 shader-clock values per workgroup to stamps_dev (NULL: stop) —
+ * [0] start, [1] end, cycles in [2] K loops, [3] partial-tile publishes, [4] last-ticket reductions, [5] epilogues,
+ * [6] segments, [7] run index */
+int emcid_debug_streamk_stamps(long long* stamps_dev) {
+    g_streamk_stamps = stamps_dev;
     return EMCID_OK;
 }
 
@@ -1294,8 +1339,8 @@ int emcid_edit_dual_stage1_f64(const float* K, const float* Zc, const float* zs_
     if (use_inverse) {
         // Pt = (Kt X^T) X : both triangular solves against M = L L^T are GEMMs against the explicit X = inv(L)
         const double* Xb = cov_inverse(cov_factor_ws, n_layers, dp, layer_index);
-        apply_inverse_forward(Xb, dp, Kt + n_lo * dp, Y + n_lo * dp, (int)rows, st);
-        apply_inverse_backward(Xb, dp, Y + n_lo * dp, (int)rows, (int)dp, Pt + n_lo * dp, dp, st);
+        apply_inverse_forward(Xb, dp, Kt + n_lo * dp, Y + n_lo * dp, (int)rows, st, base + ws.off_SK);
+        apply_inverse_backward(Xb, dp, Y + n_lo * dp, (int)rows, (int)dp, Pt + n_lo * dp, dp, st, base + ws.off_SK);
         EMCID_CHECK_LAUNCH();
         return EMCID_OK;
     }
@@ -1326,7 +1371,7 @@ int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, const float* W0,
     EMCID_TRY(with_graph(make_key(4, {Kt, Pt, S, LS, invS, PT, Y2, info_dev}, {dp, Np, N}), st, [&](hipStream_t q) {
         if (Np > N)   // rows of the padding concepts: zero (their Kt rows are zero, so S gets identity rows there)
             hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, q, Pt + N * dp, (Np - N) * dp);
-        assemble_dual_system(Pt, Kt, dp, S, (int)Np, q);
+        assemble_dual_system(Pt, Kt, dp, S, (int)Np, q, base + ws.off_SK);
         EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q));
         hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)(dp / 32), (unsigned)(Np / 32)), dim3(256), 0, q, Pt, dp, PT, Np,
                            (int)Np, (int)dp);
@@ -1370,7 +1415,7 @@ int emcid_edit_dual_apply_stage1_f64(const float* K, const float* Zc, const floa
     const int64_t rows = n_hi - n_lo;
     if (use_inverse) {
         apply_inverse_forward(cov_inverse(cov_factor_ws, n_layers, dp, layer_index), dp, Kt + n_lo * dp, Yt + n_lo * dp, (int)rows,
-                              st);
+                              st, base + ws.off_SK);
         EMCID_CHECK_LAUNCH();
         return EMCID_OK;
     }
@@ -1400,7 +1445,7 @@ int emcid_edit_dual_apply_assemble_f64(int64_t N, int64_t d, int64_t h, void* wo
     double *Yt = base + ws.off_Y, *S = base + ws.off_S;
     const int64_t dp = ws.dp, Np = ws.Np;
     if (Np > N) hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, st, Yt + N * dp, (Np - N) * dp);
-    assemble_dual_system(Yt, Yt, dp, S, (int)Np, st);
+    assemble_dual_system(Yt, Yt, dp, S, (int)Np, st, base + ws.off_SK);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }
@@ -1424,7 +1469,7 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
                          [&](hipStream_t q) {
         if (!assembled) {
             if (Np > N) hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, q, Yt + N * dp, (Np - N) * dp);
-            assemble_dual_system(Yt, Yt, dp, S, (int)Np, q);      // S = I + Yt Yt^T (lower tiles)
+            assemble_dual_system(Yt, Yt, dp, S, (int)Np, q, base + ws.off_SK);      // S = I + Yt Yt^T (lower tiles)
         }
         EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q));
         // RT[h, Np] = Rt^T ; Z^T = RT S^-1 (two solves with h rows)
@@ -1440,7 +1485,7 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
         return check_launch("emcid_edit_dual_apply_stage2_f64");
     }));
     if (use_inverse)   // U = V inv(L)  (V's padding columns are zero: Kt's are, X is the identity there)
-        apply_inverse_backward(cov_inverse(cov_factor_ws, n_layers, dp, layer_index), dp, V, (int)h, (int)dp, U, dp, st);
+        apply_inverse_backward(cov_inverse(cov_factor_ws, n_layers, dp, layer_index), dp, V, (int)h, (int)dp, U, dp, st, base + ws.off_SK);
     hipLaunchKernelGGL(apply_u2d_kernel, dim3((unsigned)h), dim3(256), 0, st, U, dp, W0, W, dW_out, (int)d);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;

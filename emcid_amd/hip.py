@@ -18,7 +18,7 @@ _lib = None
 EXPORTS = [
     "emcid_abi_version", "emcid_last_error", "emcid_gram_accumulate_f32", "emcid_symmetrize_lower_f32",
     "emcid_gather_mean_f32", "emcid_edit_workspace_bytes", "emcid_edit_layer_f64", "emcid_assemble_spd_f64",
-    "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_dgemm_ex_f64", "emcid_dgemm_batched_f64", "emcid_axpy_f32",
+    "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_dgemm_ex_f64", "emcid_dgemm_batched_f64", "emcid_streamk_workspace_bytes", "emcid_dgemm_streamk_f64", "emcid_debug_streamk_stamps", "emcid_axpy_f32",
     "emcid_profile_enable", "emcid_profile_collect", "emcid_attention_f32", "emcid_edit_layer_shard_f64",
     "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32", "emcid_add_layernorm_f32", "emcid_tree_attention_f32", "emcid_debug_leaf_stamps",
     "emcid_cov_factor_workspace_bytes", "emcid_factor_cov_f64", "emcid_cov_inverse_f64",
@@ -30,7 +30,7 @@ EXPORTS = [
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block"]
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NB = 128      # Cholesky block (csrc/common.h)
 NPAD = 64     # concept padding of the f64 stacks (csrc/common.h)
 
@@ -84,6 +84,9 @@ def load():
         "emcid_dgemm_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, p]),
         "emcid_dgemm_ex_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, i32, i32, i32, p]),
         "emcid_dgemm_batched_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, i64, p, i64, i64, f64, p, i64, i64, i64, p]),
+        "emcid_streamk_workspace_bytes": (i64, [i32]),
+        "emcid_debug_streamk_stamps": (i32, [p]),
+        "emcid_dgemm_streamk_f64": (i32, [i32, i64, i64, i64, f64, p, i64, p, i64, p, i64, i32, i32, f64, p, i64, p]),
         "emcid_axpy_f32": (i32, [p, p, i64, p]),
         "emcid_quick_gelu_f32": (i32, [p, p, i64, p]),
         "emcid_add_layernorm_f32": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p]),
@@ -264,6 +267,23 @@ def dgemm_ex(ta: int, tb: int, A, B, Cm, alpha=1.0, beta=0.0, flags=0, cfg=-1, k
     _check(load().emcid_dgemm_ex_f64(ta, tb, M, N, K, float(alpha), _ptr(A, torch.float64), A.stride(0),
                                      _ptr(B, torch.float64), B.stride(0), float(beta), _ptr(Cm, torch.float64),
                                      Cm.stride(0), int(flags), int(cfg), int(ksplit), _stream(Cm)), "emcid_dgemm_ex_f64")
+    return Cm
+
+
+_streamk_ws = {}
+
+
+def dgemm_streamk(tb: int, A, B, Cm, alpha=1.0, flags=1, wgs=256, diag_add=0.0):
+    """Test hook: the two-phase (atomic-free, reproducible) stream-K GEMM; flags 1/2: triangular B, 16: lower-only square."""
+    M, K = A.shape
+    N = B.shape[0] if tb == 0 else B.shape[1]
+    key = (str(A.device), wgs)
+    ws = _streamk_ws.get(key)
+    if ws is None:
+        ws = _streamk_ws[key] = torch.zeros(int(load().emcid_streamk_workspace_bytes(wgs)) // 8, dtype=torch.float64, device=A.device)
+    _check(load().emcid_dgemm_streamk_f64(tb, M, N, K, float(alpha), _ptr(A, torch.float64), A.stride(0), _ptr(B, torch.float64),
+                                          B.stride(0), _ptr(Cm, torch.float64), Cm.stride(0), int(flags), int(wgs), float(diag_add),
+                                          _ptr(ws), ws.numel() * 8, _stream(Cm)), "emcid_dgemm_streamk_f64")
     return Cm
 
 
@@ -479,7 +499,7 @@ class DualWorkspace:
     def __init__(self, N: int, d: int, h: int, device):
         self.key = (N, d, h)
         self.nbytes = int(load().emcid_edit_dual_workspace_bytes(N, d, h))
-        self.buf = torch.empty(self.nbytes // 8, dtype=torch.float64, device=device)
+        self.buf = torch.zeros(self.nbytes // 8, dtype=torch.float64, device=device)     # zero: the stream-K ticket counters
         self.info = torch.zeros(1, dtype=torch.int32, device=device)
         self.Np, self.dp = (N + NB - 1) // NB * NB, (d + NB - 1) // NB * NB
         pt = load().emcid_edit_dual_pt(_ptr(self.buf), N, d, h)

@@ -28,7 +28,7 @@ extern "C" {
 #define EMCID_ERR_HIP (-2)
 #define EMCID_ERR_WORKSPACE (-3)
 
-#define EMCID_ABI_VERSION 4
+#define EMCID_ABI_VERSION 5
 
 /* ABI version of the loaded library (host-only, no GPU needed). */
 int emcid_abi_version(void);
@@ -225,6 +225,22 @@ int emcid_dgemm_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alph
 int emcid_dgemm_ex_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
                        const double* A, int64_t lda, const double* B, int64_t ldb,
                        double beta, double* C, int64_t ldc, int flags, int cfg, int ksplit, void* stream);
+
+/* Stream-K form of the same GEMM for the two shapes whose work per output tile is uneven or too scarce for the chip —
+ * a triangular B operand (flags bit 0 or 1 as above) or a lower-only square output (flags bit 4: SYRK-like, M == N) —
+ * WITHOUT atomics: the (tile, K-step) space is cut into `wgs` equal runs; a run's partial tiles go to `workspace`, the
+ * contributor of a tile that takes the last ticket sums them in run order (bit-reproducible) and writes
+ * C = alpha * A op(B) (+ diag_add on the diagonal).  C needs no initial value.  A is [M][K]; tb as in emcid_dgemm_f64.
+ * workspace: emcid_streamk_workspace_bytes(wgs) bytes whose LAST 65536 bytes (the ticket counters) are zero on entry;
+ * they are zero again on exit, so one zero-filled allocation serves any number of stream-ordered calls. */
+int64_t emcid_streamk_workspace_bytes(int wgs);
+int emcid_dgemm_streamk_f64(int tb, int64_t M, int64_t N, int64_t K, double alpha, const double* A, int64_t lda,
+                            const double* B, int64_t ldb, double* C, int64_t ldc, int flags, int wgs, double diag_add,
+                            void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Diagnostic: until called again with NULL, every two-phase stream-K launch writes 8 int64 shader-clock values per workgroup
+ * to stamps_dev (start, end, cycles in K loops / partial publishes / last-ticket reductions / epilogues, segments, run). */
+int emcid_debug_streamk_stamps(long long* stamps_dev);
 
 /* `batch` independent problems of one shape: C_b = alpha * opA(A_b) opB(B_b) + beta * C_b with A_b = A + b*sA etc.
  * (element strides).  Used for the per-edit Grams sum_r k_r k_r^T of the UCE closed form (reference

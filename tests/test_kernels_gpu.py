@@ -341,3 +341,39 @@ def test_streamk_triangular_gemm(M, N, K, tri, tb, wgs):
     C = torch.full((M, N), float("nan"), dtype=torch.float64, device=DEV)            # the call zeroes its output itself
     hip.dgemm_ex(0, tb, A, T, C, alpha=1.0, beta=0.0, flags=tri, cfg=4, ksplit=wgs)
     assert (C - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M,N,K,tri,tb,wgs", [(1024, 3072, 3072, 1, 0, 256), (768, 3072, 3072, 2, 1, 256), (100, 384, 384, 1, 0, 7),
+                                               (130, 500, 500, 2, 1, 512), (1000, 1408, 1408, 1, 0, 64), (37, 128, 128, 2, 1, 3),
+                                               (1024, 5120, 5120, 1, 0, 256), (1280, 5120, 5120, 2, 1, 256)])
+def test_streamk_two_phase_triangular_gemm(M, N, K, tri, tb, wgs):
+    """The atomic-free stream-K form (partial tiles to a workspace, the last ticket holder sums them in run order):
+    against a plain fp64 matmul on the same shapes as the atomic form, the output never pre-initialised, and
+    BIT-IDENTICAL from call to call (the atomic form is not)."""
+    g = torch.Generator().manual_seed(M + N + wgs)
+    A = torch.randn(M, K, generator=g, dtype=torch.float64).to(DEV)
+    T = torch.tril(torch.randn(N, K, generator=g, dtype=torch.float64)).to(DEV)
+    ref = A @ (T.t() if tb == 0 else T)
+    outs = []
+    for rep in range(3):
+        C = torch.full((M, N), float("nan"), dtype=torch.float64, device=DEV)
+        hip.dgemm_streamk(tb, A, T, C, flags=tri, wgs=wgs)
+        assert (C - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("n,k,wgs", [(1024, 3072, 256), (512, 3072, 256), (640, 5120, 256), (1000, 200, 16), (128, 64, 256)])
+def test_streamk_two_phase_syrk_plus_identity(n, k, wgs):
+    """S = I + Y Y^T on the lower 128-tiles (the N x N system of the dual solver), identity added by the epilogue."""
+    g = torch.Generator().manual_seed(n + k)
+    Y = torch.randn(n, k, generator=g, dtype=torch.float64).to(DEV)
+    ref = torch.eye(n, dtype=torch.float64, device=DEV) + Y @ Y.t()
+    outs = []
+    for rep in range(2):
+        S = torch.full((n, n), float("nan"), dtype=torch.float64, device=DEV)
+        hip.dgemm_streamk(0, Y, Y, S, flags=16, wgs=wgs, diag_add=1.0)
+        low = torch.tril(torch.ones(n, n, dtype=torch.bool, device=DEV))
+        assert ((S - ref)[low]).abs().max().item() <= 1e-12 * ref.abs().max().item()
+        outs.append(S[low])
+    assert torch.equal(outs[0], outs[1])
