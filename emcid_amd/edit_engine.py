@@ -103,7 +103,7 @@ def _workspace(kind: str, N: int, d: int, h: int, dev):
     key = (kind, str(dev), N, d, h)
     ws = _WS_CACHE.get(key)
     if ws is None:
-        ws = (hip.DualWorkspace if kind == "dual" else hip.EditWorkspace)(N, d, h, dev)
+        ws = {"dual": hip.DualWorkspace, "lu": hip.LuWorkspace}.get(kind, hip.EditWorkspace)(N, d, h, dev)
         _WS_CACHE[key] = ws
         while len(_WS_CACHE) > WS_CACHE_SIZE:
             _WS_CACHE.popitem(last=False)
@@ -146,12 +146,17 @@ FORWARD_MODE = "trie"   # "trie": prefix-deduplicated forward when the encoder i
 SOLVER = None           # None: plan.solver decides; "direct" / "dual" force it (tests, experiments; env EMCID_SOLVER too)
 
 
+def _solver_mode(plan) -> str:
+    if plan.solver == "lu":          # the fallback after a failed Cholesky overrides every preference
+        return "lu"
+    return SOLVER or os.environ.get("EMCID_SOLVER") or plan.solver
+
+
 def _use_dual(plan, d: int) -> bool:
-    import os
-    mode = SOLVER or os.environ.get("EMCID_SOLVER") or plan.solver
+    mode = _solver_mode(plan)
     if mode == "dual":
         return True
-    if mode == "direct":
+    if mode in ("direct", "lu"):
         return False
     np_, dp = -(-plan.n_total // hip.NB) * hip.NB, -(-d // hip.NB) * hip.NB
     return np_ * 5 <= dp * 3      # N x N system + two extra solves pay off when N is well below d
@@ -316,6 +321,10 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                 lazy = False
             if os.environ.get("EMCID_FACTOR_FIRST", "0") == "1":    # experiment: no overlap of the factorization with the forward
                 torch.cuda.current_stream(dev).wait_event(chol_done)
+    elif _solver_mode(plan) == "lu":
+        plan.ws = _workspace("lu", plan.n_total, d, h, dev)
+        plan.ws.info.zero_()
+        plan.dual_ws = None
     else:
         plan.ws = _workspace("direct", plan.n_total, d, h, dev)
         plan.ws.info.zero_()
@@ -358,6 +367,15 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                 want_factors=keep_factors, ws=plan.dual_ws,
                 rows=plan.shard.bounds(plan.n_total) if sharded else None,
                 gather_pt=(lambda rows_: _all_gather_rows(rows_.contiguous(), plan)) if sharded else None)
+            xt = res["adj_k"].t() if res["adj_k"] is not None else None
+            edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], xt, res["Rt"],
+                                   K if trace else None, Zc if trace else None))
+            return
+        if _solver_mode(plan) == "lu":
+            # the reference's own algorithm (LU with partial pivoting) for a system the Cholesky paths rejected; every
+            # rank holds all N key rows here and solves the whole layer itself (rare path, never sharded)
+            res = hip.edit_layer_lu(K, Zc, plan.zs_t, plan.covs[layer], plan.lam, plan.edit_weight, L - i,
+                                    W0=backups[layer], W=weights[layer].data, want_factors=keep_factors, ws=plan.ws)
             xt = res["adj_k"].t() if res["adj_k"] is not None else None
             edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], xt, res["Rt"],
                                    K if trace else None, Zc if trace else None))
@@ -456,11 +474,37 @@ def solver_info(plan: EncoderEditPlan) -> int:
     return code
 
 
+def run_checked(plan: EncoderEditPlan, keep_factors: bool = False, restore: bool = False) -> List[LayerEdit]:
+    """run_encoder_edit + check_info with the reference's fallback semantics: if a Cholesky factorization met a
+    non-positive pivot (lam*C' + K K^T not positive definite, e.g. statistics that lost definiteness in fp32), the
+    weights are put back and the whole pass is rerun with LU + partial pivoting — torch.linalg.solve's algorithm
+    (reference emcid_main.py:1045), which returns numbers for any nonsingular system.  EMCID_LU_FALLBACK=0 raises instead."""
+    edits = run_encoder_edit(plan, keep_factors=keep_factors, restore=restore)
+    try:
+        check_info(plan)
+    except FloatingPointError:
+        if os.environ.get("EMCID_LU_FALLBACK", "1") == "0" or plan.solver == "lu":
+            raise
+        plan.solver = "lu"
+        plan.cov_factors = None
+        edits = run_encoder_edit(plan, keep_factors=keep_factors, restore=restore)
+        check_info(plan)
+    return edits
+
+
 def check_info(plan: EncoderEditPlan, restore_on_failure: bool = True):
     """One host sync at the very end: did any factorization meet a non-positive pivot?  If so the edited weights hold
     garbage: they are put back to the values they had before the run, then FloatingPointError is raised (callers that can
     retry — emcid_main — catch it and rerun with the pivoted-LU solver, the reference's own semantics)."""
     code = solver_info(plan)
+    if code != 0 and plan.solver == "lu":
+        if restore_on_failure and plan.backups is not None:
+            with torch.no_grad():
+                for l, w0 in plan.backups.items():
+                    get_parameter(plan.text_encoder, plan.weight_name(l)).copy_(w0)
+        raise torch.linalg.LinAlgError(
+            f"lam*C + K K^T is singular to working precision (zero pivot at column {code - 1} of the pivoted LU): "
+            f"torch.linalg.solve (reference emcid_main.py:1045) raises for this system too; the edited weights have been restored")
     if code == 0:
         if plan.factor_key is not None and plan.cov_factors is not None and _factor_cache_size() > 0:
             with ENGINE_LOCK:

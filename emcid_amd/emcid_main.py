@@ -28,7 +28,7 @@ import torch
 
 from . import hip, nethook
 from .edit_engine import (ConceptShard, EncoderEditPlan, LayerEdit, check_info, phase, prepare_encoder_edit,
-                          run_encoder_edit)
+                          run_checked, run_encoder_edit)
 from .emcid_hparams import EMCIDHyperParams, EMCIDXLHyperParams
 from .globals import STATS_DIR, XL_STATS_DIR1, XL_STATS_DIR2
 from .compute_ks import get_layers_input_output_at_words_cross_attn
@@ -259,8 +259,7 @@ def execute_emcid_text_encoder(pipe, requests: List[Dict], hparams: EMCIDHyperPa
     _announce(requests, verbose)
     plan = prepare_text_encoder_edit(pipe.text_encoder, pipe.tokenizer, requests, hparams, hparams.layers,
                                      hparams.mom2_update_weight, stat_dir, cache_name, "", verbose, shard, stage1)
-    edits = run_encoder_edit(plan, keep_factors=True, restore=True)
-    check_info(plan)
+    edits = run_checked(plan, keep_factors=True, restore=True)
     if verbose:
         print(f"Deltas successfully computed for {[e.weight_name for e in edits]}")
     return _deltas_to_host(edits)
@@ -279,10 +278,8 @@ def apply_emcid_to_text_encoder(pipe, requests: List[Dict], hparams: EMCIDHyperP
                                      hparams.mom2_update_weight, stats_dir, cache_name, "", verbose, shard, stage1)
     # The engine leaves each fc2 at W0 + float(U): the value the reference reaches by restoring W0 (:1076-1078)
     # and adding float(adj_k @ resid^T) again (:802-809).
-    with phase("run(host launches)"):
-        edits = run_encoder_edit(plan, keep_factors=False, restore=False)
-    with phase("final sync"):
-        check_info(plan)
+    with phase("run + final sync"):
+        edits = run_checked(plan, keep_factors=False, restore=False)
     if verbose:
         print(f"New weights successfully inserted into {[e.weight_name for e in edits]}")
     return pipe, origin_text_encoder
@@ -305,8 +302,7 @@ def cal_insert_deltas(pipe, weights: Dict[str, torch.Tensor], hparams: EMCIDHype
     plan = prepare_encoder_edit(pipe.text_encoder, pipe.tokenizer, requests, hparams.layers, hparams.rewrite_module_tmp,
                                 hparams.mom2_update_weight, hparams.edit_weight, zs_t, covs, _shard_from_env(shard),
                                 layer_module_tmp=getattr(hparams, "layer_module_tmp", None))
-    edits = run_encoder_edit(plan, keep_factors=True, restore=False)
-    check_info(plan)
+    edits = run_checked(plan, keep_factors=True, restore=False)
     return _deltas_to_host(edits)
 
 
@@ -489,10 +485,8 @@ def execute_emcid_sd_xl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
     _sdxl_overrides(hparams, mom2_weight, mom2_weight_2, edit_weight)
     _announce(requests, verbose)
     p1, p2 = _sdxl_plans(pipe, requests, hparams, cache_name, stat_dir, stat_dir_2, verbose, shard, stage1)
-    e1 = run_encoder_edit(p1, keep_factors=True, restore=True)
-    e2 = run_encoder_edit(p2, keep_factors=True, restore=not SDXL_TE2_DOUBLE_APPLY)
-    check_info(p1)
-    check_info(p2)
+    e1 = run_checked(p1, keep_factors=True, restore=True)
+    e2 = run_checked(p2, keep_factors=True, restore=not SDXL_TE2_DOUBLE_APPLY)
     return _deltas_to_host(e1), _deltas_to_host(e2)
 
 
@@ -517,8 +511,22 @@ def apply_emcid_to_sdxl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
             for e in e2:
                 hip.axpy_(nethook.get_parameter(pipe.text_encoder_2, e.weight_name).data, e.dW)
     torch.cuda.current_stream(p2.zs_t.device).wait_stream(s2)
-    check_info(p1)
-    check_info(p2)
+
+    def double_apply(edits):
+        for e in edits:
+            hip.axpy_(nethook.get_parameter(pipe.text_encoder_2, e.weight_name).data, e.dW)
+
+    for plan, redo in ((p1, None), (p2, double_apply if SDXL_TE2_DOUBLE_APPLY else None)):
+        try:
+            check_info(plan)                       # restores the encoder's weights if a factorization failed
+        except FloatingPointError:
+            if os.environ.get("EMCID_LU_FALLBACK", "1") == "0":
+                raise
+            plan.solver, plan.cov_factors = "lu", None          # the reference's own solver semantics (edit_engine.run_checked)
+            again = run_encoder_edit(plan, keep_factors=False, restore=False)
+            check_info(plan)
+            if redo is not None:
+                redo(again)
     if verbose:
         print(f"New weights successfully inserted into {[e.weight_name for e in e1 + e2]}")
     return pipe, o1, o2

@@ -26,6 +26,7 @@ EXPORTS = [
     "emcid_edit_dual_stage1_f64", "emcid_edit_dual_pt", "emcid_edit_dual_stage2_f64",
     "emcid_edit_dual_apply_stage1_f64", "emcid_edit_dual_yt", "emcid_edit_dual_apply_stage2_f64",
     "emcid_edit_dual_apply_assemble_f64",
+    "emcid_edit_lu_workspace_bytes", "emcid_edit_layer_lu_f64", "emcid_lu_solve_f64",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block"]
@@ -80,6 +81,9 @@ def load():
         "emcid_edit_dual_apply_stage2_f64": (i32, [i64, i64, i64, p, i64, i64, i32, i32, p, p, p, p, i64, p, p]),
         "emcid_edit_dual_apply_assemble_f64": (i32, [i64, i64, i64, p, i64, p]),
         "emcid_cholesky_solve_f64": (i32, [p, i64, i64, p, p, p, i64, i64, p]),
+        "emcid_edit_lu_workspace_bytes": (i64, [i64, i64, i64]),
+        "emcid_edit_layer_lu_f64": (i32, [p, p, p, p, i64, i64, i64, f64, f64, i32, p, p, p, p, p, p, i64, p, p]),
+        "emcid_lu_solve_f64": (i32, [p, i64, i64, p, i64, i64, p, p, p]),
         "emcid_delta_w_f64": (i32, [p, i64, p, i64, i64, i64, i64, p, p, i64, p, p, p]),
         "emcid_dgemm_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, p]),
         "emcid_dgemm_ex_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, p, i64, f64, p, i64, i32, i32, i32, p]),
@@ -212,6 +216,52 @@ def edit_layer(K, Zc, zs_t, Cov, lam: float, edit_weight: float, layers_left: in
         _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"), _ptr(Xt), _ptr(Rt), _ptr(dW),
         _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32, "info"), _stream(K)), "emcid_edit_layer_f64")
     return {"Xt": Xt, "Rt": Rt, "dW": dW, "ws": ws}
+
+
+class LuWorkspace:
+    """Workspace of the pivoted-LU fallback (emcid_edit_layer_lu_f64)."""
+
+    def __init__(self, N: int, d: int, h: int, device):
+        self.key = (N, d, h)
+        self.nbytes = int(load().emcid_edit_lu_workspace_bytes(N, d, h))
+        self.buf = torch.empty(self.nbytes // 8, dtype=torch.float64, device=device)
+        self.info = torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def edit_layer_lu(K, Zc, zs_t, Cov, lam: float, edit_weight: float, layers_left: int, W0=None, W=None,
+                  want_factors: bool = False, want_dw: bool = True, ws: Optional[LuWorkspace] = None):
+    """One edited layer solved like the reference does (LU with partial pivoting, torch.linalg.solve's algorithm): works for
+    any nonsingular lam*C' + K K^T.  Returns dict(adj_k (d, N) | None, Rt (N, h) | None, dW, ws)."""
+    N, d = K.shape
+    h = Zc.shape[1]
+    assert Cov.shape == (d, d) and zs_t.shape == (N, h) and Zc.shape == (N, h)
+    for t, nm in ((K, "K"), (Zc, "Zc"), (zs_t, "zs_t"), (Cov, "C")):
+        assert t.is_contiguous(), nm
+    if ws is None or ws.key != (N, d, h):
+        ws = LuWorkspace(N, d, h, K.device)
+    dev = K.device
+    adj_k = torch.empty(d, N, dtype=torch.float64, device=dev) if want_factors else None
+    Rt = torch.empty(N, h, dtype=torch.float64, device=dev) if want_factors else None
+    dW = torch.empty(h, d, dtype=torch.float32, device=dev) if want_dw else None
+    if W is not None:
+        assert W.is_contiguous() and W.shape == (h, d) and W0 is not None and W0.is_contiguous()
+    _check(load().emcid_edit_layer_lu_f64(
+        _ptr(K, torch.float32, "K"), _ptr(Zc, torch.float32, "Zc"), _ptr(zs_t, torch.float32, "zs_t"),
+        _ptr(Cov, torch.float32, "C"), N, d, h, float(lam), float(edit_weight), int(layers_left),
+        _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"), _ptr(adj_k), _ptr(Rt), _ptr(dW),
+        _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32, "info"), _stream(K)), "emcid_edit_layer_lu_f64")
+    return {"adj_k": adj_k, "Rt": Rt, "dW": dW, "ws": ws}
+
+
+def lu_solve_(A: torch.Tensor, B: torch.Tensor):
+    """Test hook: solves A X = B in place (A (n, n) f64 becomes P L U, B (n, nrhs) f64 becomes X) by LU with partial
+    pivoting; returns (pivots int32 (n,), info int32 (1,))."""
+    n = A.shape[0]
+    piv = torch.zeros(n, dtype=torch.int32, device=A.device)
+    info = torch.zeros(1, dtype=torch.int32, device=A.device)
+    _check(load().emcid_lu_solve_f64(_ptr(A, torch.float64, "A"), A.stride(0), n, _ptr(B, torch.float64, "B"), B.stride(0),
+                                     B.shape[1], _ptr(piv), _ptr(info), _stream(A)), "emcid_lu_solve_f64")
+    return piv, info
 
 
 def edit_layer_shard(K, Zc, zs_t, Cov, lam: float, edit_weight: float, layers_left: int, rows, want_factors=False,

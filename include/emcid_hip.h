@@ -185,6 +185,25 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
  * latency-bound Cholesky of S starts. */
 int emcid_edit_dual_apply_assemble_f64(int64_t N, int64_t d, int64_t h, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fallback with the reference's own solver semantics.  torch.linalg.solve (reference: emcid/emcid_main.py:1045-1048) is
+ * LAPACK getrf + getrs: LU with partial pivoting, which returns numbers for ANY nonsingular system, whereas the Cholesky
+ * paths above stop at a non-positive pivot (info_dev).  emcid_edit_layer_lu_f64 runs one edited layer through a blocked
+ * right-looking LU with row pivoting (largest magnitude in the column, lowest row on ties) and two substitutions for
+ * all N right-hand sides — same inputs, scaling rules and outputs as emcid_edit_layer_f64, except that adj_k is
+ * returned in the reference's orientation: adjk_out [d][N].  info_dev: 1 + column of an exactly-zero pivot (singular
+ * matrix: torch raises there), else left untouched.  Built for being rare, not fast (~50 ms at d = 3072).
+ * emcid_lu_solve_f64: the factor + solve alone (test hook): A [n][lda] is overwritten by P L U, B [n][ldb] by the
+ * solution; piv_dev: n device ints.
+ * ------------------------------------------------------------------------------------------- */
+int64_t emcid_edit_lu_workspace_bytes(int64_t N, int64_t d, int64_t h);
+int emcid_edit_layer_lu_f64(const float* K, const float* Zc, const float* zs_t, const float* C,
+                            int64_t N, int64_t d, int64_t h, double lam, double edit_weight, int layers_left,
+                            const float* W0, float* W, double* adjk_out, double* Rt_out, float* dW_out,
+                            void* workspace, int64_t workspace_bytes, int* info_dev, void* stream);
+int emcid_lu_solve_f64(double* A, int64_t lda, int64_t n, double* B, int64_t ldb, int64_t nrhs, int* piv_dev,
+                       int* info_dev, void* stream);
+
 /* The stages of emcid_edit_layer_f64 as separate calls (used by tests and micro-benchmarks). */
 
 /* A[d,d] (f64, ld lda, LOWER triangle valid) = lam_c * double(fl32(fl32(C*cw)/0.5f)) + Kt64^T Kt64,

@@ -113,11 +113,14 @@ def unrecord_kz(em, orig, cks):
     cks.get_module_input_output_at_words = orig
 
 
-def golden_sd(em, EMCIDHyperParams, scratch, tag, kind, n_req, layers, lam, ew, ragged, full):
-    """Reference execute_emcid_text_encoder + apply_emcid_to_text_encoder on a synthetic pipe."""
-    pipe = syn.build_pipe(kind, "cpu")
+def golden_sd(em, EMCIDHyperParams, scratch, tag, kind, n_req, layers, lam, ew, ragged, full, syllables=False,
+              store_vstar=True):
+    """Reference execute_emcid_text_encoder + apply_emcid_to_text_encoder on a synthetic pipe.  ``syllables``: bench.py's
+    workload (syllable vocabulary, 3-syllable names); ``store_vstar=False``: the v* rows are a seeded function of the
+    request list (syn.write_vstar_cache(seed=1, scale=0.5)), only their checksum goes into the fixture."""
+    pipe = syn.build_pipe(kind, "cpu", syllables=syllables)
     hidden, inter = syn.ENCODER_DIMS[kind][:2]
-    reqs = syn.make_requests(n_req, ragged=ragged)
+    reqs = syn.make_requests(n_req, ragged=ragged, names="syllable" if syllables else "index")
     hp_d = syn.sd_hparams_dict(layers=layers, mom2_update_weight=lam + 1, edit_weight=0.5, mom2_n_samples=1000, prefix="")
     cache = str(scratch / f"cache_{tag}") + "/"
     stats_dir = scratch / f"stats_{tag}"
@@ -141,9 +144,11 @@ def golden_sd(em, EMCIDHyperParams, scratch, tag, kind, n_req, layers, lam, ew, 
                                                     return_orig_text_encoder=True, cache_name=cache,
                                                     stats_dir=str(stats_dir), verbose=False)
     assert hp2.mom2_update_weight == lam  # in-place mutation quirk
-    out = {"vstar": vs}
-    meta = {"kind": kind, "requests": reqs, "hparams": hp_d, "layers": list(layers), "lam": lam, "ew": ew,
-            "layer_names": layer_names}
+    out = {"vstar": vs} if store_vstar else {"vstar_sum": np.array(vs.astype(np.float64).sum()),
+                                             "vstar_row0": vs[0]}
+    meta = {"kind": kind, "requests": reqs if store_vstar else None, "n_requests": n_req, "syllables": syllables,
+            "hparams": hp_d, "layers": list(layers), "lam": lam, "ew": ew, "layer_names": layer_names,
+            "stats": {"seed": 2, "t": max(2 * inter, 512), "n_samples": 1000}, "vstar": {"seed": 1, "scale": 0.5}}
     g = torch.Generator().manual_seed(123)
     probe = torch.randn(inter, 8, generator=g, dtype=torch.float64)
     for li, n in enumerate(layer_names):
@@ -216,6 +221,80 @@ def golden_sdxl(em, EMCIDXLHyperParams, scratch, tag="toy_sdxl"):
         json.dump({"requests": reqs, "hparams": hp_d, "layers": layers, "layers_2": layers_2,
                    "mom2_weight": 50, "mom2_weight_2": 100, "edit_weight": 0.6,
                    "layer_names": n1, "layer_names_2": n2}, f, indent=1)
+    print(f"[golden] {tag}: wrote {len(out)} arrays")
+
+
+def golden_sdxl_real(em, EMCIDXLHyperParams, scratch, tag="real_sdxl_summary", n_req=300):
+    """BASELINE config 4 at real dimensions: apply_emcid_to_sdxl_text_encoders of the REAL reference on the synthetic
+    SDXL pair (TE1 768/3072/12L layers 8-10, TE2 1280/5120/32L layers 26-30), bench vocabulary, N concepts; summaries of
+    the final dW of both encoders (TE2 carries the reference's double apply)."""
+    pipe = syn.build_pipe("sdxl", "cpu", sdxl=True, syllables=True)
+    reqs = syn.make_requests(n_req, names="syllable")
+    layers, layers_2 = (8, 9, 10), (26, 27, 28, 29, 30)
+    hp_d = syn.sdxl_hparams_dict(layers=layers, layers_2=layers_2, mom2_update_weight=4000, mom2_update_weight_2=10000,
+                                 mom2_n_samples=1000, prefix="")
+    cache = str(scratch / f"cache_{tag}") + "/"
+    sd1, sd2 = scratch / f"stats1_{tag}", scratch / f"stats2_{tag}"
+    h1, i1 = syn.ENCODER_DIMS["sdxl-te1"][:2]
+    h2, i2 = syn.ENCODER_DIMS["sdxl-te2"][:2]
+    vs1 = syn.write_vstar_cache(cache, reqs, h1, seed=1, scale=0.5)
+    vs2 = syn.write_vstar_cache(cache, reqs, h2, seed=5, scale=0.5, suffix="_2")
+    n1 = [hp_d["rewrite_module_tmp"].format(l) for l in layers]
+    n2 = [hp_d["rewrite_module_tmp"].format(l) for l in layers_2]
+    syn.write_stats_cache(sd1, n1, i1, 1000, seed=2, t=2 * i1)
+    syn.write_stats_cache(sd2, n2, i2, 1000, seed=7, t=2 * i2)
+    em.COV_CACHE.clear()
+    w0_1 = {n: em.nethook.get_parameter(pipe.text_encoder, n + ".weight").clone() for n in n1}
+    w0_2 = {n: em.nethook.get_parameter(pipe.text_encoder_2, n + ".weight").clone() for n in n2}
+    hp = EMCIDXLHyperParams(**hp_d)
+    pipe, _, _ = em.apply_emcid_to_sdxl_text_encoders(pipe, reqs, hp, "cpu", cache_name=cache, stat_dir=str(sd1),
+                                                      stat_dir_2=str(sd2), verbose=False)
+    out = {"vstar_sum": np.array(vs1.astype(np.float64).sum()), "vstar_2_sum": np.array(vs2.astype(np.float64).sum())}
+    g = torch.Generator().manual_seed(123)
+    for sfx, names, w0, te, inter in (("", n1, w0_1, pipe.text_encoder, i1), ("_2", n2, w0_2, pipe.text_encoder_2, i2)):
+        probe = torch.randn(inter, 8, generator=g, dtype=torch.float64)
+        out[f"probe{sfx}"] = probe.numpy()
+        for li, n in enumerate(names):
+            dw = em.nethook.get_parameter(te, n + ".weight").double() - w0[n].double()
+            out[f"dw_probe{sfx}/{li}"] = (dw @ probe).numpy()
+            out[f"dw_fro{sfx}/{li}"] = np.array(dw.norm().item())
+            out[f"dw_rownorm{sfx}/{li}"] = dw.norm(dim=1).numpy()
+            out[f"dw_maxabs{sfx}/{li}"] = np.array(dw.abs().max().item())
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump({"n_requests": n_req, "hparams": hp_d, "layers": layers, "layers_2": layers_2, "layer_names": n1,
+                   "layer_names_2": n2, "stats": {"seed": 2, "seed_2": 7, "n_samples": 1000},
+                   "vstar": {"seed": 1, "seed_2": 5, "scale": 0.5}}, f, indent=1)
+    print(f"[golden] {tag}: wrote {len(out)} arrays")
+
+
+def golden_stage0_real(ls, scratch, tag="real_stage0_summary", n_captions=20000, layers=(2, 7)):
+    """BASELINE config 5 at real dimensions: the REAL reference's layer_stats_text_encoder over n_captions synthetic
+    captions (SD-v1.4 dims, d = 3072), two layers; summaries of C = mom2 / count."""
+    from tqdm import tqdm
+    syn.write_captions(scratch / "data" / "ccs_filtered.json", n_captions, seed=2)
+    pipe = syn.build_pipe("sd-v1.4", "cpu")
+    d = syn.ENCODER_DIMS["sd-v1.4"][1]
+    g = torch.Generator().manual_seed(321)
+    probe = torch.randn(d, 8, generator=g, dtype=torch.float64)
+    out = {"probe": probe.numpy()}
+    names = [f"encoder.layers.{l}.mlp.fc2" for l in layers]
+    for li, ln in enumerate(names):
+        stat = ls.layer_stats_text_encoder(pipe.text_encoder, pipe.tokenizer, ln, str(scratch / "stats0_real"),
+                                           "ccs_filtered", ["mom2"], sample_size=n_captions, precision="float32",
+                                           batch_tokens=3 * 1024, progress=tqdm)
+        mom2 = stat.mom2.mom2.double()
+        cnt = int(stat.mom2.count)
+        C = mom2 / cnt
+        out[f"count/{li}"] = np.array(cnt)
+        out[f"trace/{li}"] = np.array(C.diagonal().sum().item())
+        out[f"fro/{li}"] = np.array(C.norm().item())
+        out[f"diag/{li}"] = C.diagonal().numpy()
+        out[f"C_probe/{li}"] = (C @ probe).numpy()
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump({"kind": "sd-v1.4", "n_captions": n_captions, "captions": {"seed": 2}, "layer_names": names,
+                   "sample_size": n_captions, "batch_tokens": 3 * 1024}, f, indent=1)
     print(f"[golden] {tag}: wrote {len(out)} arrays")
 
 
@@ -478,6 +557,18 @@ def main():
         torch.set_num_threads(8)
         if "--only-uce" in sys.argv:
             golden_uce(scratch)
+            return
+        if "--only" in sys.argv:       # the heavy real-dimension summaries, one at a time (minutes each on 8 cores)
+            which = sys.argv[sys.argv.index("--only") + 1]
+            if which == "real_sd_n1000_summary":
+                golden_sd(em, HP, scratch, which, "sd-v1.4", n_req=1000, layers=(7, 8, 9, 10), lam=4000, ew=0.5,
+                          ragged=False, full=False, syllables=True, store_vstar=False)
+            elif which == "real_sdxl_summary":
+                golden_sdxl_real(em, XLHP, scratch)
+            elif which == "real_stage0_summary":
+                golden_stage0_real(ls, scratch)
+            else:
+                raise SystemExit(f"unknown fixture {which}")
             return
         golden_token_ranges(ftr)
         golden_uce(scratch)

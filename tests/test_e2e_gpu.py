@@ -502,3 +502,88 @@ def test_config1_instruction_driver_matches_reference_golden(tmp_path, monkeypat
         assert np.abs(dw.norm(dim=1).numpy() - z[f"dw_rownorm/{li}"]).max() <= 1e-4 * z[f"dw_rownorm/{li}"].max()
         key = [k for k in saved if k.endswith(n.split("encoder.")[-1] + ".weight")][0]
         assert torch.equal(saved[key], w)
+
+
+def test_apply_falls_back_to_pivoted_lu_when_statistics_are_not_positive_definite(tmp_path, monkeypatch):
+    """Statistics with negative eigenvalues: the reference's torch.linalg.solve (LU) returns numbers; the Cholesky
+    solvers report a pivot.  apply_* must then restore the weights and rerun with the pivoted-LU kernels, ending at the
+    oracle's (= the reference's) result; with the fallback switched off it must raise and leave the model untouched."""
+    from test_kernels_gpu import _indefinite_cov
+    reqs = syn.make_requests(6, ragged=True)
+    hp_d = syn.sd_hparams_dict(layers=(1, 2, 3), mom2_update_weight=30, edit_weight=0.5, mom2_n_samples=1000)
+    names = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers"]]
+    cache = str(tmp_path / "cache") + "/"
+    syn.write_vstar_cache(cache, reqs, 32, seed=1, scale=0.5)
+    for i, ln in enumerate(names):
+        write_cov_npz(tmp_path / "stats", ln, _indefinite_cov(128, seed=20 + i).numpy(), 1000)
+    cpu = syn.build_pipe("toy", "cpu")
+    w0 = {n: orc.get_parameter(cpu.text_encoder, n + ".weight").clone() for n in names}
+    orc.apply_emcid_to_text_encoder(cpu, reqs, copy.deepcopy(hp_d), cache_name=cache, stats_dir=str(tmp_path / "stats"))
+    gpu = syn.build_pipe("toy", DEV)
+    monkeypatch.setenv("EMCID_LU_FALLBACK", "0")
+    with pytest.raises(FloatingPointError):
+        em.apply_emcid_to_text_encoder(gpu, reqs, EMCIDHyperParams(**hp_d), DEV, cache_name=cache,
+                                       stats_dir=str(tmp_path / "stats"), verbose=False)
+    for n in names:       # restored, not left at W0 + garbage
+        assert torch.equal(get_parameter(gpu.text_encoder, n + ".weight").cpu(), w0[n])
+    monkeypatch.setenv("EMCID_LU_FALLBACK", "1")
+    em.apply_emcid_to_text_encoder(gpu, reqs, EMCIDHyperParams(**hp_d), DEV, cache_name=cache,
+                                   stats_dir=str(tmp_path / "stats"), verbose=False)
+    for n in names:
+        ref = orc.get_parameter(cpu.text_encoder, n + ".weight").double() - w0[n].double()
+        got = get_parameter(gpu.text_encoder, n + ".weight").cpu().double() - w0[n].double()
+        err = (got - ref).abs().max().item()
+        assert err <= 1e-4 * ref.abs().max().item(), (n, err, ref.abs().max().item())
+    # execute_* returns the reference's factors through the same fallback, model unchanged
+    gpu2 = syn.build_pipe("toy", DEV)
+    deltas = em.execute_emcid_text_encoder(gpu2, reqs, EMCIDHyperParams(**hp_d), cache_name=cache,
+                                           stat_dir=str(tmp_path / "stats"), verbose=False)
+    assert list(deltas) == [n + ".weight" for n in names] and deltas[names[0] + ".weight"][0].shape == (128, 6)
+    for n in names:
+        assert torch.equal(get_parameter(gpu2.text_encoder, n + ".weight").cpu(), w0[n])
+
+
+def _summary_close(dw, z, li, sfx, probe, bar=1e-4):
+    """dW (h, d) f64 on the host against the reference's summaries of the same matrix."""
+    ref_p = z[f"dw_probe{sfx}/{li}"]
+    scale = float(z[f"dw_maxabs{sfx}/{li}"])
+    # |dW probe - ref| <= ||dW - dW_ref||_rowwise * ||probe column||: hold the probe to the bar times the probe norm
+    pn = np.linalg.norm(probe.numpy(), axis=0).max()
+    assert np.abs((dw @ probe).numpy() - ref_p).max() <= bar * scale * pn, (li, sfx)
+    np.testing.assert_allclose(dw.norm().item(), float(z[f"dw_fro{sfx}/{li}"]), rtol=bar)
+    np.testing.assert_allclose(dw.norm(dim=1).numpy(), z[f"dw_rownorm{sfx}/{li}"], rtol=0, atol=bar * z[f"dw_rownorm{sfx}/{li}"].max())
+    np.testing.assert_allclose(dw.abs().max().item(), scale, rtol=bar)
+
+
+def test_headline_n1000_edit_matches_reference_summary(tmp_path):
+    """BASELINE configs 2/3 at the headline size, no oracle run needed on the GPU box: bench.py's very workload (1 000
+    syllable-named concepts x 3 prompts, SD-v1.4 dims, layers 7-10, lambda 4000) through execute_* and apply_* against
+    summaries the REAL reference produced for it in the build container (tests/golden/make_golden.py --only
+    real_sd_n1000_summary: ~4 min on 8 cores)."""
+    z, meta = load_golden("real_sd_n1000_summary")
+    kind = meta["kind"]
+    hidden, inter = syn.ENCODER_DIMS[kind][:2]
+    reqs = syn.make_requests(meta["n_requests"], names="syllable")
+    cache = str(tmp_path / "cache") + "/"
+    vs = syn.write_vstar_cache(cache, reqs, hidden, seed=meta["vstar"]["seed"], scale=meta["vstar"]["scale"])
+    np.testing.assert_array_equal(vs[0], z["vstar_row0"])
+    assert float(vs.astype(np.float64).sum()) == float(z["vstar_sum"])
+    st = meta["stats"]
+    syn.write_stats_cache(tmp_path / "stats", meta["layer_names"], inter, st["n_samples"], seed=st["seed"], t=st["t"])
+    probe = torch.randn(inter, 8, generator=torch.Generator().manual_seed(123), dtype=torch.float64)
+    pipe = syn.build_pipe(kind, DEV, syllables=True)
+    w0 = {ln: get_parameter(pipe.text_encoder, ln + ".weight").detach().cpu().clone() for ln in meta["layer_names"]}
+    deltas = em.execute_emcid_text_encoder(pipe, reqs, EMCIDHyperParams(**meta["hparams"]), cache_name=cache,
+                                           mom2_weight=meta["lam"], edit_weight=meta["ew"], verbose=False,
+                                           stat_dir=str(tmp_path / "stats"))
+    for li, ln in enumerate(meta["layer_names"]):
+        adj_k, resid = deltas[ln + ".weight"]
+        ref = z[f"adjk_probe/{li}"]
+        assert np.abs((probe.t() @ adj_k).numpy() - ref).max() <= 2e-4 * np.abs(ref).max(), li
+        np.testing.assert_allclose(resid.norm().item(), float(z[f"resid_fro/{li}"]), rtol=1e-5)
+        assert torch.equal(get_parameter(pipe.text_encoder, ln + ".weight").cpu(), w0[ln])
+    em.apply_emcid_to_text_encoder(pipe, reqs, EMCIDHyperParams(**meta["hparams"]), DEV, mom2_weight=meta["lam"],
+                                   edit_weight=meta["ew"], cache_name=cache, stats_dir=str(tmp_path / "stats"), verbose=False)
+    for li, ln in enumerate(meta["layer_names"]):
+        dw = get_parameter(pipe.text_encoder, ln + ".weight").cpu().double() - w0[ln].double()
+        _summary_close(dw, z, li, "", probe)

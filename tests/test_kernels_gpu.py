@@ -377,3 +377,104 @@ def test_streamk_two_phase_syrk_plus_identity(n, k, wgs):
         assert ((S - ref)[low]).abs().max().item() <= 1e-12 * ref.abs().max().item()
         outs.append(S[low])
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("n,nrhs,kind", [(64, 5, "general"), (200, 130, "general"), (1000, 64, "indefinite"),
+                                         (1536, 300, "indefinite"), (96, 2, "spd")])
+def test_lu_solve_matches_lapack(n, nrhs, kind):
+    """Blocked LU with partial pivoting + two substitutions (the reference's torch.linalg.solve = getrf + getrs) against
+    LAPACK on the same matrix: same pivot rows (no ties in random data), solution to fp64 rounding."""
+    g = torch.Generator().manual_seed(n + nrhs)
+    A = torch.randn(n, n, generator=g, dtype=torch.float64)
+    if kind == "indefinite":       # symmetric, eigenvalues of both signs
+        q, _ = torch.linalg.qr(A)
+        ev = torch.linspace(-2.0, 3.0, n, dtype=torch.float64)
+        ev[ev.abs() < 0.05] = 0.05
+        A = (q * ev) @ q.t()
+        A = (A + A.t()) / 2
+    elif kind == "spd":
+        A = A @ A.t() + n * torch.eye(n, dtype=torch.float64)
+    B = torch.randn(n, nrhs + (nrhs % 2), generator=g, dtype=torch.float64)
+    ref = torch.linalg.solve(A, B)
+    _, ipiv = torch.linalg.lu_factor(A)
+    Ad, Bd = A.clone().to(DEV), B.clone().to(DEV)
+    piv, info = hip.lu_solve_(Ad, Bd)
+    assert int(info.item()) == 0
+    assert torch.equal(piv.cpu() + 1, ipiv.to(torch.int32))
+    err = (Bd.cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 1e-9 * max(1.0, float(torch.linalg.cond(A))) * 1e-3 + 1e-11, err
+
+
+def test_lu_reports_singular_matrix():
+    n = 128
+    A = torch.randn(n, n, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+    A[:, 40] = 0.0                                  # an exactly zero column: pivot 40 is zero whatever the row order
+    piv, info = hip.lu_solve_(A.to(DEV), torch.ones(n, 2, dtype=torch.float64, device=DEV))
+    assert int(info.item()) == 41
+
+
+def _indefinite_cov(d, seed, neg=3):
+    """A symmetric fp32 'second moment' with a few NEGATIVE eigenvalues: lam*C' + K K^T is then not positive definite
+    (the Cholesky paths report a pivot) but perfectly nonsingular, which is all torch.linalg.solve needs."""
+    g = torch.Generator().manual_seed(seed)
+    q, _ = torch.linalg.qr(torch.randn(d, d, generator=g, dtype=torch.float64))
+    ev = torch.logspace(0, -3, d, dtype=torch.float64)
+    ev[-neg:] = -0.05
+    C = ((q * ev) @ q.t())
+    return ((C + C.t()) / 2).float().contiguous()
+
+
+@pytest.mark.parametrize("N,d,h", [(12, 256, 64), (200, 3072, 768)])
+def test_edit_layer_lu_on_indefinite_system_vs_oracle(N, d, h):
+    """Where the reference's LU returns numbers and Cholesky cannot: the LU fallback against the oracle's
+    torch.linalg.solve on the same indefinite system; the Cholesky entry points flag the same input."""
+    K, Zc, zs, _, W0 = _edit_inputs(N, d, h, seed=11)
+    Cov = _indefinite_cov(d, seed=5)
+    lam, ew, left = 40.0, 0.5, 2
+    adj_k, resid, upd = orc.closed_form_layer(K, Zc, zs, Cov, lam, ew, left)
+    args = (K.to(DEV), Zc.to(DEV), zs.t().contiguous().to(DEV), Cov.to(DEV), lam, ew, left)
+    chol = hip.edit_layer(*args, W0=W0.to(DEV), W=torch.empty(h, d, device=DEV))
+    assert int(chol["ws"].info.item()) > 0                      # not positive definite
+    Wd = torch.empty(h, d, dtype=torch.float32, device=DEV)
+    out = hip.edit_layer_lu(*args, W0=W0.to(DEV), W=Wd, want_factors=True)
+    assert int(out["ws"].info.item()) == 0
+    assert out["adj_k"].shape == (d, N)
+    assert (out["adj_k"].cpu() - adj_k).abs().max().item() <= 1e-8 * adj_k.abs().max().item()
+    torch.testing.assert_close(out["Rt"].cpu(), resid.t().contiguous(), rtol=1e-14, atol=0)
+    scale = upd.abs().max().item()
+    assert (out["dW"].cpu().double() - upd).abs().max().item() <= 1e-6 * scale
+    assert (Wd.cpu() - (W0 + upd.float())).abs().max().item() <= 1e-6 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("decades", [2, 4, 6, 8])
+@pytest.mark.parametrize("form", ["dual_inverse", "dual_substitution", "direct"])
+def test_ill_conditioned_statistics(decades, form):
+    """Statistics with a log-uniform spectrum over `decades` decades (cond(C) = 1e2 ... 1e8), d = 3072: dW of every solver
+    form against an fp64 LU of the full system lam*C' + K K^T on identical inputs (the reference's computation,
+    emcid_main.py:1040-1050).  Bar: 1e-4 relative (BASELINE.json); the dual forms factor lam*C' alone, the matrix
+    whose conditioning is worst."""
+    N, d, h, lam, ew = 200, 3072, 768, 4000.0, 0.5
+    g = torch.Generator().manual_seed(decades)
+    Q, _ = torch.linalg.qr(torch.randn(d, d, dtype=torch.float64, generator=g))
+    sp = torch.logspace(0, -decades, d, dtype=torch.float64)
+    C = ((Q * sp) @ Q.t())
+    C = ((C + C.t()) * 0.5).float().contiguous()
+    K = (torch.randn(N, d, generator=g) * 0.3)
+    Zc = torch.randn(N, h, generator=g)
+    zs_t = torch.randn(N, h, generator=g)
+    W0 = torch.randn(h, d, generator=g)
+    _, _, upd = orc.closed_form_layer(K, Zc, zs_t.t().contiguous(), C, lam, ew, 1)
+    Kd, Zd, zd, Cd, W0d = K.to(DEV), Zc.to(DEV), zs_t.to(DEV), C.to(DEV), W0.to(DEV)
+    W = torch.empty(h, d, device=DEV)
+    if form == "direct":
+        res = hip.edit_layer(Kd, Zd, zd, Cd, lam, ew, 1, W0=W0d, W=W)
+        info = int(res["ws"].info.item())
+    else:
+        use_inv = form == "dual_inverse"
+        fac = hip.factor_cov([Cd], lam, ew, inverse=use_inv)
+        res = hip.edit_layer_dual_apply(Kd, Zd, zd, fac, 0, ew, 1, W0d, W, use_inverse=use_inv)
+        info = max(int(fac.info.item()), int(res["ws"].info.item()))
+    assert info == 0
+    err = (res["dW"].cpu().double() - upd).abs().max().item() / upd.abs().max().item()
+    assert err <= 1e-4, err
+    assert err <= 2e-6, err           # observed: the fp32 rounding of dW itself (3-4e-8) at every condition number

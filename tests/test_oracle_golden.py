@@ -119,6 +119,22 @@ def test_real_dims_summary(tmp_path):
         np.testing.assert_allclose(dw.norm().item(), float(z[f"dw_fro/{li}"]), rtol=1e-6)
 
 
+def test_headline_workload_keys_at_first_edited_layer():
+    """bench.py's workload itself (1 000 syllable-named concepts, 3 000 prompts, SD-v1.4 dims): the oracle's keys at the
+    first edited layer against the REAL reference's (fixture real_sd_n1000_summary; one 12-layer forward, ~15 s).  Pins
+    tokenization, subject lookup and the per-request means at the headline size; the full 1 000-concept edit through
+    the oracle takes ~4 min and is left to the fixture + the GPU test."""
+    z, meta = load_golden("real_sd_n1000_summary")
+    assert meta["n_requests"] == 1000 and meta["syllables"]
+    pipe = syn.build_pipe(meta["kind"], "cpu", syllables=True)
+    reqs = syn.make_requests(1000, names="syllable")
+    K, Zc = orc.module_input_output_at_words(pipe.text_encoder, pipe.tokenizer, reqs, meta["layer_names"][0])
+    inter = syn.ENCODER_DIMS[meta["kind"]][1]
+    probe = torch.randn(inter, 8, generator=torch.Generator().manual_seed(123), dtype=torch.float64)
+    np.testing.assert_allclose((K.double() @ probe).numpy(), z["K_probe/0"], rtol=0, atol=1e-9 * np.abs(z["K_probe/0"]).max())
+    np.testing.assert_allclose(Zc.double().norm(dim=1).numpy(), z["Zc_rownorm/0"], rtol=1e-9)
+
+
 def test_toy_cross_attn_bit_level(tmp_path):
     """Cross-attention K/V edit (reference emcid_main.py:314-548): layer names and order, keys, current values,
     adj_k, resid and the 32 final projection matrices against the reference's own outputs."""
