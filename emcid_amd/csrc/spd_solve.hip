@@ -1491,4 +1491,117 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
     return EMCID_OK;
 }
 
+/* ---- dual solver, apply-only form, COLUMN-SHARDED over ranks (multi-GPU) -----------------------------------
+ * The d columns of Yt = Kt64 X^T are dealt to the ranks in 128-wide tiles (`tiles`: this rank's tile indices, ascending).
+ * With Yc = the rank's columns of Yt:
+ *     S = I + sum_ranks Yc Yc^T        (one all-reduce of the N x N partial sums — the only coupling of the concepts)
+ *     V[:, mine] = Z^T Yc,  Z = S^-1 Rt (every rank factors S itself: d^3-free, latency-bound, 0.5 ms)
+ *     U = V X = sum_ranks V[:, mine] X[mine, :]      (one all-reduce of the h x d partial sums)
+ * so a rank's GEMM work is 1/world of the layer's and nothing but S and U crosses the links.  Needs X = inv(L) of the layer
+ * (emcid_cov_inverse_f64).  stage 1 leaves the partial S (no identity) at emcid_edit_dual_s(); stage 2 expects the SUMMED S
+ * there and leaves the partial U (leading dimension dp = d rounded up to 128) at emcid_edit_dual_u(). */
+__global__ __launch_bounds__(256) void add_identity_f64_kernel(double* __restrict__ S, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) S[(int64_t)i * n + i] += 1.0;
+}
+
+static int check_tiles(const int* tiles, int n_tiles, int64_t dp) {
+    if (!tiles || n_tiles <= 0 || n_tiles > 256) return 0;
+    for (int i = 0; i < n_tiles; ++i)
+        if (tiles[i] < 0 || (int64_t)tiles[i] * NB >= dp || (i > 0 && tiles[i] <= tiles[i - 1])) return 0;
+    return 1;
+}
+
+int emcid_edit_dual_cols_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
+                                    double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
+                                    int64_t layer_index, const int* tiles_host, int n_tiles, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+    EMCID_CHECK_ARG(K && Zc && zs_t && N > 0 && d > 0 && h > 0 && layers_left > 0 && cov_factor_ws && workspace);
+    EMCID_CHECK_ARG(0 <= layer_index && layer_index < n_layers);
+    DualWorkspace ws(N, d, h);
+    EMCID_CHECK_ARG(check_tiles(tiles_host, n_tiles, ws.dp));
+    if (workspace_bytes < ws.total * (int64_t)sizeof(double)) return fail(EMCID_ERR_WORKSPACE, __func__, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double* base = (double*)workspace;
+    double *Kt = base + ws.off_K, *Yc = base + ws.off_Y, *R = base + ws.off_R, *S = base + ws.off_S, *sk = base + ws.off_SK;
+    const int64_t dp = ws.dp, Np = ws.Np;
+    const double* X = cov_inverse(cov_factor_ws, n_layers, dp, layer_index);
+    const double s = sqrt(edit_weight / 0.5);
+    {
+        ScopedProf sp(KC_PREP, st);
+        hipLaunchKernelGGL(prep_kr_kernel, dim3((unsigned)Np), dim3(256), 0, st, K, Zc, zs_t, (int)N, (int)d, (int)h, s,
+                           (double)layers_left, Kt, (int)Np, (int)dp, R, (int)ws.hp);
+    }
+    for (int i = 0; i < n_tiles; ++i) {        // Yc[:, 128 i : 128 i + 128] = Kt[:, 0 : kd] X[128 t : 128 t + 128, 0 : kd]^T,  kd = 128 (t + 1)
+        const int64_t t = tiles_host[i], kd = (t + 1) * NB;
+        ScopedProf sp(KC_INV_APPLY, st);
+        GemmShape g{Kt, dp, X + t * NB * dp, dp, (int)Np, NB, (int)kd, 0};
+        launch_gemm_f64_streamk2<true, true>(g, EpiAxpby{Yc + (int64_t)i * NB, dp, 1.0, 0.0}, st, kStreamKWgs, sk);
+    }
+    {   // partial S = Yc Yc^T on the lower 128-tiles, K = 128 n_tiles deep
+        ScopedProf sp(KC_ASSEMBLE, st);
+        GemmShape g{Yc, dp, Yc, dp, (int)Np, (int)Np, n_tiles * NB, 1};
+        launch_gemm_f64_streamk2<true, true>(g, EpiAxpby{S, Np, 1.0, 0.0}, st, kStreamKWgs, sk, 0.0);
+    }
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+double* emcid_edit_dual_s(void* workspace, int64_t N, int64_t d, int64_t h) {
+    if (!workspace || N <= 0 || d <= 0 || h <= 0) return nullptr;
+    return (double*)workspace + DualWorkspace(N, d, h).off_S;
+}
+
+double* emcid_edit_dual_u(void* workspace, int64_t N, int64_t d, int64_t h) {
+    if (!workspace || N <= 0 || d <= 0 || h <= 0) return nullptr;
+    return (double*)workspace + DualWorkspace(N, d, h).off_U;
+}
+
+int emcid_edit_dual_cols_stage2_f64(int64_t N, int64_t d, int64_t h, const void* cov_factor_ws, int64_t n_layers,
+                                    int64_t layer_index, const int* tiles_host, int n_tiles, void* workspace,
+                                    int64_t workspace_bytes, int* info_dev, void* stream) {
+    EMCID_CHECK_ARG(N > 0 && d > 0 && h > 0 && workspace && info_dev && cov_factor_ws);
+    EMCID_CHECK_ARG(0 <= layer_index && layer_index < n_layers);
+    DualWorkspace ws(N, d, h);
+    EMCID_CHECK_ARG(check_tiles(tiles_host, n_tiles, ws.dp));
+    if (workspace_bytes < ws.total * (int64_t)sizeof(double)) return fail(EMCID_ERR_WORKSPACE, __func__, "workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    double* base = (double*)workspace;
+    double *Yc = base + ws.off_Y, *R = base + ws.off_R, *S = base + ws.off_S, *LS = base + ws.off_LS, *invS = base + ws.off_invS;
+    double *RT = base + ws.off_PT, *Y2 = base + ws.off_Y2, *V = base + ws.off_V, *U = base + ws.off_U;
+    const int64_t dp = ws.dp, Np = ws.Np, hp = ws.hp;
+    const double* X = cov_inverse(cov_factor_ws, n_layers, dp, layer_index);
+    const int w = n_tiles * NB;
+    EMCID_TRY(with_graph(make_key(8, {Yc, R, S, LS, RT, V, U, info_dev}, {dp, Np, N, hp, (int64_t)w}), st, [&](hipStream_t q) {
+        hipLaunchKernelGGL(add_identity_f64_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, q, S, (int)Np);
+        EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q));
+        hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)((hp + 31) / 32), (unsigned)(Np / 32)), dim3(256), 0, q, R, hp, RT,
+                           Np, (int)Np, (int)hp);
+        EMCID_TRY(cholesky_solve_impl(LS, Np, Np, invS, RT, Y2, h, Np, q));      // RT := Z^T
+        {
+            ScopedProf sp(KC_DELTA_W, q);       // V[h, w] = Z^T Yc
+            GemmShape g{RT, Np, Yc, dp, (int)h, w, (int)Np, 0};
+            launch_gemm_f64<true, false>(g, EpiAxpby{V, dp, 1.0, 0.0}, q);
+        }
+        hipLaunchKernelGGL(zero2d_f64_kernel, dim3((unsigned)h, 1u), dim3(256), 0, q, U, dp, (int64_t)0, (int)dp);
+        return check_launch("emcid_edit_dual_cols_stage2_f64");
+    }));
+    for (int i = 0; i < n_tiles; ++i) {        // U[:, 0 : kd] += V[:, 128 i : 128 i + 128] X[128 t : 128 t + 128, 0 : kd]
+        const int64_t t = tiles_host[i], kd = (t + 1) * NB;
+        ScopedProf sp(KC_INV_APPLY, st);
+        GemmShape g{V + (int64_t)i * NB, dp, X + t * NB * dp, dp, (int)h, (int)kd, NB, 0};
+        launch_gemm_f64<true, false>(g, EpiAxpby{U, dp, 1.0, 1.0}, st);
+    }
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+/* W = W0 + float(U) (optional), dW = float(U) (optional) for U [h][ldu] f64 with ldu >= d (the padded partial sums above) */
+int emcid_apply_update2d_f32(const double* U, int64_t ldu, const float* W0, float* W, float* dW, int64_t h, int64_t d, void* stream) {
+    EMCID_CHECK_ARG(U && h > 0 && d > 0 && ldu >= d && (W || dW) && ((W == nullptr) || (W0 != nullptr)));
+    hipLaunchKernelGGL(apply_u2d_kernel, dim3((unsigned)h), dim3(256), 0, (hipStream_t)stream, U, ldu, W0, W, dW, (int)d);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
 }  // extern "C"

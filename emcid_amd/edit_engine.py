@@ -306,6 +306,8 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                 # factorization instead (batched, underneath the forward — costs the forward more than it hides).
                 first_x = min(L, max(0, int(os.environ.get("EMCID_INVERSE_FROM", "1"))))
                 lazy = os.environ.get("EMCID_INVERSE_LAZY", "1") != "0" and keep_factors is False
+                if plan.shard.world > 1 and not keep_factors and -(-d // hip.NB) >= plan.shard.world:
+                    first_x, lazy = 0, False      # the column-sharded solve multiplies by X in every layer
                 fac_done = [chol_done] * L
                 if lazy and first_x == 0:      # the first layer's X right behind the factorization, the others one layer ahead
                     hip.cov_inverse(plan.cov_factors, 0, 1)
@@ -350,9 +352,21 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                         fac_done[nxt].record(plan.side_stream)
 
                 ahead = lazy and max(first_x, 1) <= i + 1 < L
-                # Sharded runs: every rank already holds all N key rows (the K all-gather above), and the M-solve of all
-                # of them is one 0.23 ms GEMM — cheaper than solving N/G rows and all-gathering Yt (N x d fp64, 25 MB)
-                # over xGMI, and one collective less per layer.  EMCID_SHARD_MSOLVE=1 restores the row-sharded solve.
+                if sharded and -(-d // hip.NB) >= plan.shard.world and os.environ.get("EMCID_SHARD_SOLVE", "cols") != "replicate":
+                    # Every rank holds all N key rows (the K all-gather above).  The layer's GEMMs are split by 128-wide
+                    # column tiles of d: a rank forms its columns of Yt = Kt X^T and its share of S = I + Yt Yt^T and of
+                    # U = (Z^T Yt) X; S (N x N) and U (h x d) are summed over the ranks (two all-reduces over xGMI), the
+                    # N x N Cholesky and the h-row solves are repeated by everyone (latency-bound, no d^2 work in them).
+                    n_tiles = -(-d // hip.NB)
+                    res = hip.edit_layer_dual_cols(
+                        K, Zc, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, backups[layer], weights[layer].data,
+                        hip.column_tiles(plan.shard.rank, plan.shard.world, n_tiles),
+                        lambda t: _all_reduce_sum(t, plan.shard.group), ws=plan.dual_ws)
+                    edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], None, None,
+                                           K if trace else None, Zc if trace else None))
+                    return
+                # EMCID_SHARD_SOLVE=replicate: every rank runs the whole layer itself (the round-1 form; one collective
+                # less per layer, no scaling of the solve).  EMCID_SHARD_MSOLVE=1 additionally row-shards the M-solve.
                 split = sharded and os.environ.get("EMCID_SHARD_MSOLVE", "0") == "1"
                 res = hip.edit_layer_dual_apply(
                     K, Zc, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, backups[layer], weights[layer].data,

@@ -466,6 +466,43 @@ def _sdxl_overrides(hparams, mom2_weight, mom2_weight_2, edit_weight):
     hparams.edit_weight = edit_weight if edit_weight is not None else hparams.edit_weight
 
 
+SDXL_TE1_COST_SHARE = 0.14     # TE1 alone 16 ms, TE2 alone 102 ms per 1 000 concepts on one MI355X: share of the ranks TE1 gets
+_SDXL_GROUPS: Dict[tuple, tuple] = {}
+
+
+def sdxl_rank_split(rank: int, world: int):
+    """(encoder this rank edits, its rank inside that encoder's group, group sizes (g1, g2)).  The two SDXL text encoders
+    are independent models (reference :1233-1320 vs :1333-1422): TE1 goes to the first g1 ranks, TE2 to the rest, in
+    proportion to their cost (at least one rank each)."""
+    g1 = max(1, min(world - 1, int(round(world * SDXL_TE1_COST_SHARE))))
+    return (1, rank, (g1, world - g1)) if rank < g1 else (2, rank - g1, (g1, world - g1))
+
+
+def _sdxl_split(shard: ConceptShard):
+    """Process groups of the TE1 / TE2 rank split, or None when the split does not apply (one rank, a caller-supplied
+    group, or EMCID_SDXL_SPLIT=0: then both encoders are edited on every rank, concept-sharded, on two streams)."""
+    import torch.distributed as dist
+    if shard.world < 2 or shard.group is not None or os.environ.get("EMCID_SDXL_SPLIT", "1") == "0":
+        return None
+    which, sub_rank, (g1, g2) = sdxl_rank_split(shard.rank, shard.world)
+    key = (shard.world, g1)
+    if key not in _SDXL_GROUPS:       # collective: every rank creates both groups, in the same order
+        _SDXL_GROUPS[key] = (dist.new_group(list(range(g1))), dist.new_group(list(range(g1, shard.world))))
+    grp = _SDXL_GROUPS[key][which - 1]
+    return {"which": which, "shard": ConceptShard(sub_rank, g1 if which == 1 else g2, grp), "roots": (0, g1)}
+
+
+def _broadcast_(t: torch.Tensor, src: int):
+    """In-place broadcast over the default group (RCCL on device buffers; gloo stages HBM tensors through the host)."""
+    import torch.distributed as dist
+    if t.is_cuda and dist.get_backend() == "gloo":
+        host = t.detach().cpu()
+        dist.broadcast(host, src=src)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src=src)
+
+
 def _sdxl_plans(pipe, requests, hparams, cache_name, stat_dir, stat_dir_2, verbose, shard, stage1):
     if hparams.num_edit_tokens != 1:
         raise AssertionError("num_edit_tokens should be 1")   # reference :1246
@@ -500,6 +537,33 @@ def apply_emcid_to_sdxl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
     o2 = deepcopy(pipe.text_encoder_2) if return_orig_text_encoder else None
     _sdxl_overrides(hparams, mom2_weight, mom2_weight_2, edit_weight)
     _announce(requests, verbose)
+    split = _sdxl_split(_shard_from_env(shard))
+    if split is not None:
+        # TE1 || TE2 on disjoint GPU groups (BASELINE config 4): this rank edits ONE encoder, concept-sharded
+        # inside its group, then the groups' roots broadcast the edited fc2 weights so every rank ends with the whole pipe
+        if hparams.num_edit_tokens != 1:
+            raise AssertionError("num_edit_tokens should be 1")   # reference :1246
+        if split["which"] == 1:
+            plan = prepare_text_encoder_edit(pipe.text_encoder, pipe.tokenizer, requests, hparams, hparams.layers,
+                                             hparams.mom2_update_weight, stat_dir, cache_name, "", verbose, split["shard"], stage1)
+            run_checked(plan, keep_factors=False, restore=False)
+        else:
+            plan = prepare_text_encoder_edit(pipe.text_encoder_2, pipe.tokenizer_2, requests, hparams, hparams.layers_2,
+                                             hparams.mom2_update_weight_2, stat_dir_2, cache_name, "_2", verbose, split["shard"], stage1)
+            edits = run_checked(plan, keep_factors=False, restore=False)
+            if SDXL_TE2_DOUBLE_APPLY:   # execute left TE2 edited, apply adds the update once more (:93-99)
+                for e in edits:
+                    hip.axpy_(nethook.get_parameter(pipe.text_encoder_2, e.weight_name).data, e.dW)
+        names = []
+        for enc, layers, root in ((pipe.text_encoder, hparams.layers, split["roots"][0]),
+                                  (pipe.text_encoder_2, hparams.layers_2, split["roots"][1])):
+            for layer in layers:
+                name = f"{hparams.rewrite_module_tmp.format(layer)}.weight"
+                _broadcast_(nethook.get_parameter(enc, name).data, root)
+                names.append(name)
+        if verbose:
+            print(f"New weights successfully inserted into {names}")
+        return pipe, o1, o2
     p1, p2 = _sdxl_plans(pipe, requests, hparams, cache_name, stat_dir, stat_dir_2, verbose, shard, stage1)
     # The two encoders are independent models (:1233 vs :1333): run them on two HIP streams.
     s2 = torch.cuda.Stream(device=p2.zs_t.device)

@@ -27,11 +27,13 @@ EXPORTS = [
     "emcid_edit_dual_apply_stage1_f64", "emcid_edit_dual_yt", "emcid_edit_dual_apply_stage2_f64",
     "emcid_edit_dual_apply_assemble_f64",
     "emcid_edit_lu_workspace_bytes", "emcid_edit_layer_lu_f64", "emcid_lu_solve_f64",
+    "emcid_edit_dual_cols_stage1_f64", "emcid_edit_dual_s", "emcid_edit_dual_u", "emcid_edit_dual_cols_stage2_f64",
+    "emcid_apply_update2d_f32",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block"]
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 NB = 128      # Cholesky block (csrc/common.h)
 NPAD = 64     # concept padding of the f64 stacks (csrc/common.h)
 
@@ -81,6 +83,11 @@ def load():
         "emcid_edit_dual_apply_stage2_f64": (i32, [i64, i64, i64, p, i64, i64, i32, i32, p, p, p, p, i64, p, p]),
         "emcid_edit_dual_apply_assemble_f64": (i32, [i64, i64, i64, p, i64, p]),
         "emcid_cholesky_solve_f64": (i32, [p, i64, i64, p, p, p, i64, i64, p]),
+        "emcid_edit_dual_cols_stage1_f64": (i32, [p, p, p, i64, i64, i64, f64, i32, p, i64, i64, p, i32, p, i64, p]),
+        "emcid_edit_dual_s": (p, [p, i64, i64, i64]),
+        "emcid_edit_dual_u": (p, [p, i64, i64, i64]),
+        "emcid_edit_dual_cols_stage2_f64": (i32, [i64, i64, i64, p, i64, i64, p, i32, p, i64, p, p]),
+        "emcid_apply_update2d_f32": (i32, [p, i64, p, p, p, i64, i64, p]),
         "emcid_edit_lu_workspace_bytes": (i64, [i64, i64, i64]),
         "emcid_edit_layer_lu_f64": (i32, [p, p, p, p, i64, i64, i64, f64, f64, i32, p, p, p, p, p, p, i64, p, p]),
         "emcid_lu_solve_f64": (i32, [p, i64, i64, p, i64, i64, p, p, p]),
@@ -558,6 +565,11 @@ class DualWorkspace:
         yt = load().emcid_edit_dual_yt(_ptr(self.buf), N, d, h)
         off = (yt - self.buf.data_ptr()) // 8
         self.Yt = self.buf[off:off + self.Np * self.dp].view(self.Np, self.dp)   # the Yt stack of the apply-only form
+        hp = h + (h % 2)
+        off = (load().emcid_edit_dual_s(_ptr(self.buf), N, d, h) - self.buf.data_ptr()) // 8
+        self.S = self.buf[off:off + self.Np * self.Np].view(self.Np, self.Np)    # N x N system (column-sharded form: partial sums)
+        off = (load().emcid_edit_dual_u(_ptr(self.buf), N, d, h) - self.buf.data_ptr()) // 8
+        self.U = self.buf[off:off + hp * self.dp].view(hp, self.dp)[:h]          # U (h, dp) f64 partial sums of the same form
 
 
 def edit_layer_dual(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_weight: float, layers_left: int,
@@ -593,6 +605,83 @@ def edit_layer_dual(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_wei
                                           _ptr(Rt), _ptr(dW), _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32),
                                           _stream(K)), "emcid_edit_dual_stage2_f64")
     return {"adj_k": adj_k, "Rt": Rt, "dW": dW, "ws": ws}
+
+
+def column_tiles(rank: int, world: int, n_tiles: int):
+    """This rank's 128-wide column tiles of the d dimension for the column-sharded solve.  Tile t of the triangular factor
+    costs ~(t + 1) (its contraction depth), so the tiles are dealt heaviest first, each to the least loaded rank so far
+    (ties: lowest rank) — the same table on every rank, per-rank cost within a few percent of the mean (24 tiles over 8
+    ranks: 36..39 of a mean 37.5)."""
+    load_ = [0] * world
+    owner = {}
+    for t in range(n_tiles - 1, -1, -1):
+        r = min(range(world), key=lambda i: (load_[i], i))
+        owner[t] = r
+        load_[r] += t + 1
+    return [t for t in range(n_tiles) if owner[t] == rank]
+
+
+class _HipColsBackend:
+    """The two stages of the column-sharded solve on the C library (include/emcid_hip.h)."""
+
+    def __init__(self, K, Zc, zs_t, factors, layer_index, edit_weight, layers_left, ws):
+        self.a = (K, Zc, zs_t, factors, layer_index, edit_weight, layers_left, ws)
+
+    def stage1(self, tiles):
+        K, Zc, zs_t, factors, layer_index, edit_weight, layers_left, ws = self.a
+        N, d = K.shape
+        arr = (C.c_int * len(tiles))(*tiles)
+        _check(load().emcid_edit_dual_cols_stage1_f64(
+            _ptr(K, torch.float32, "K"), _ptr(Zc, torch.float32, "Zc"), _ptr(zs_t, torch.float32, "zs_t"), N, d, Zc.shape[1],
+            float(edit_weight), int(layers_left), _ptr(factors.buf), factors.n_layers, int(layer_index), arr, len(tiles),
+            _ptr(ws.buf), ws.nbytes, _stream(K)), "emcid_edit_dual_cols_stage1_f64")
+        return ws.S
+
+    def stage2(self, tiles):
+        K, Zc, zs_t, factors, layer_index, edit_weight, layers_left, ws = self.a
+        N, d = K.shape
+        arr = (C.c_int * len(tiles))(*tiles)
+        _check(load().emcid_edit_dual_cols_stage2_f64(N, d, Zc.shape[1], _ptr(factors.buf), factors.n_layers, int(layer_index), arr,
+                                                      len(tiles), _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32), _stream(K)),
+               "emcid_edit_dual_cols_stage2_f64")
+        return ws.U
+
+    def apply(self, U, W0, W, want_dw):
+        K, Zc = self.a[0], self.a[1]
+        h, d = Zc.shape[1], K.shape[1]
+        dW = torch.empty(h, d, dtype=torch.float32, device=K.device) if want_dw else None
+        _check(load().emcid_apply_update2d_f32(_ptr(U), U.stride(0), _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"),
+                                               _ptr(dW), h, d, _stream(K)), "emcid_apply_update2d_f32")
+        return dW
+
+
+def edit_layer_dual_cols(K, Zc, zs_t, factors, layer_index: int, edit_weight: float, layers_left: int, W0, W,
+                         tiles, all_reduce, want_dw: bool = True, ws: Optional["DualWorkspace"] = None, backend=None):
+    """Apply-only dual solver with the layer's GEMMs split over ranks by column tiles of d (include/emcid_hip.h,
+    "COLUMN-SHARDED").  ``tiles``: this rank's tile indices (column_tiles); ``all_reduce(t)``: sums a tensor over the
+    ranks in place (two calls: the N x N partial S, the h x dp partial U).  Needs the layer's explicit inverse factor.
+    ``backend``: object with stage1/stage2/apply (default: the C library; tests/test_dist_cpu.py passes a torch-CPU
+    restatement of the two stages to run this very skeleton under gloo)."""
+    N, d = K.shape
+    h = Zc.shape[1]
+    tiles = sorted(int(t) for t in tiles)
+    if not tiles:
+        raise EmcidHipError("a rank without a column tile: world size exceeds d / 128")
+    if backend is None:
+        for t, nm in ((K, "K"), (Zc, "Zc"), (zs_t, "zs_t"), (W, "W"), (W0, "W0")):
+            assert t.is_contiguous(), nm
+        assert zs_t.shape == (N, h) and factors.d == d and W.shape == (h, d)
+        if layer_index not in factors.have_inverse:
+            raise EmcidHipError("edit_layer_dual_cols needs the explicit inverse factor of the layer (cov_inverse)")
+        if ws is None or ws.key != (N, d, h):
+            ws = DualWorkspace(N, d, h, K.device)
+        backend = _HipColsBackend(K, Zc, zs_t, factors, layer_index, edit_weight, layers_left, ws)
+    S = backend.stage1(tiles)            # partial S_r = Yc Yc^T (no identity)
+    all_reduce(S)
+    U = backend.stage2(tiles)            # partial U_r = (Z^T Yc) X[tiles, :]
+    all_reduce(U)
+    dW = backend.apply(U, W0, W, want_dw)
+    return {"dW": dW, "ws": ws}
 
 
 def edit_layer_dual_apply(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_weight: float, layers_left: int,

@@ -28,7 +28,7 @@ extern "C" {
 #define EMCID_ERR_HIP (-2)
 #define EMCID_ERR_WORKSPACE (-3)
 
-#define EMCID_ABI_VERSION 5
+#define EMCID_ABI_VERSION 6
 
 /* ABI version of the loaded library (host-only, no GPU needed). */
 int emcid_abi_version(void);
@@ -203,6 +203,29 @@ int emcid_edit_layer_lu_f64(const float* K, const float* Zc, const float* zs_t, 
                             void* workspace, int64_t workspace_bytes, int* info_dev, void* stream);
 int emcid_lu_solve_f64(double* A, int64_t lda, int64_t n, double* B, int64_t ldb, int64_t nrhs, int* piv_dev,
                        int* info_dev, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Apply-only dual solver, COLUMN-SHARDED over ranks (multi-GPU; SURVEY.md §8e: concept stacks are all-gathered, the
+ * solve itself is split so that no rank repeats another's GEMMs).  The d columns of Yt = Kt64 X^T (X = inv(L), needs
+ * emcid_cov_inverse_f64 for the layer) are dealt to the ranks in 128-wide tiles; `tiles_host`: this rank's tile indices,
+ * ascending, HOST array.  With Yc = this rank's columns:
+ *     stage 1:  Kt64, Rt, Yc, partial S_r = Yc Yc^T (lower 128-tiles)          -> emcid_edit_dual_s()  [Np][Np] f64
+ *     caller :  all-reduce (sum) of S over the ranks                            (RCCL over xGMI: 8 MB at N = 1000)
+ *     stage 2:  S + I = L_S L_S^T, Z = S^-1 Rt, V = Z^T Yc, partial U_r = V X[tiles, :] -> emcid_edit_dual_u() [hp][dp] f64
+ *     caller :  all-reduce (sum) of U, then emcid_apply_update2d_f32 (W = W0 + float(U), ldu = dp)
+ * Summed over the ranks this is exactly emcid_edit_dual_apply_stage1/2 (same algebra, sums in another order).
+ * ------------------------------------------------------------------------------------------- */
+int emcid_edit_dual_cols_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
+                                    double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
+                                    int64_t layer_index, const int* tiles_host, int n_tiles, void* workspace,
+                                    int64_t workspace_bytes, void* stream);
+double* emcid_edit_dual_s(void* workspace, int64_t N, int64_t d, int64_t h);
+double* emcid_edit_dual_u(void* workspace, int64_t N, int64_t d, int64_t h);
+int emcid_edit_dual_cols_stage2_f64(int64_t N, int64_t d, int64_t h, const void* cov_factor_ws, int64_t n_layers,
+                                    int64_t layer_index, const int* tiles_host, int n_tiles, void* workspace,
+                                    int64_t workspace_bytes, int* info_dev, void* stream);
+int emcid_apply_update2d_f32(const double* U, int64_t ldu, const float* W0, float* W, float* dW, int64_t h, int64_t d,
+                             void* stream);
 
 /* The stages of emcid_edit_layer_f64 as separate calls (used by tests and micro-benchmarks). */
 

@@ -587,3 +587,53 @@ def test_headline_n1000_edit_matches_reference_summary(tmp_path):
     for li, ln in enumerate(meta["layer_names"]):
         dw = get_parameter(pipe.text_encoder, ln + ".weight").cpu().double() - w0[ln].double()
         _summary_close(dw, z, li, "", probe)
+
+
+def test_sdxl_n300_edit_matches_reference_summary(tmp_path):
+    """BASELINE config 4 at real dimensions and N = 300 against the REAL reference's summaries (fixture real_sdxl_summary):
+    TE1 768/3072 layers 8-10 (lambda 4000), TE2 1280/5120/32L layers 26-30 (lambda 10000), incl. the TE2 double apply."""
+    z, meta = load_golden("real_sdxl_summary")
+    reqs = syn.make_requests(meta["n_requests"], names="syllable")
+    hp_d = meta["hparams"]
+    n1, n2 = meta["layer_names"], meta["layer_names_2"]
+    cache = str(tmp_path / "cache") + "/"
+    v1 = syn.write_vstar_cache(cache, reqs, 768, seed=meta["vstar"]["seed"], scale=meta["vstar"]["scale"])
+    v2 = syn.write_vstar_cache(cache, reqs, 1280, seed=meta["vstar"]["seed_2"], scale=meta["vstar"]["scale"], suffix="_2")
+    assert float(v1.astype(np.float64).sum()) == float(z["vstar_sum"]) and float(v2.astype(np.float64).sum()) == float(z["vstar_2_sum"])
+    ns = meta["stats"]["n_samples"]
+    syn.write_stats_cache(tmp_path / "s1", n1, 3072, ns, seed=meta["stats"]["seed"], t=6144)
+    syn.write_stats_cache(tmp_path / "s2", n2, 5120, ns, seed=meta["stats"]["seed_2"], t=10240)
+    gpu = syn.build_pipe("sdxl", DEV, sdxl=True, syllables=True)
+    w0 = {("", n): get_parameter(gpu.text_encoder, n + ".weight").detach().cpu().clone() for n in n1}
+    w0.update({("_2", n): get_parameter(gpu.text_encoder_2, n + ".weight").detach().cpu().clone() for n in n2})
+    em.apply_emcid_to_sdxl_text_encoders(gpu, reqs, EMCIDXLHyperParams(**hp_d), DEV, cache_name=cache,
+                                         stat_dir=str(tmp_path / "s1"), stat_dir_2=str(tmp_path / "s2"), verbose=False)
+    for sfx, names, enc in (("", n1, gpu.text_encoder), ("_2", n2, gpu.text_encoder_2)):
+        probe = torch.from_numpy(z[f"probe{sfx}"])
+        for li, n in enumerate(names):
+            dw = get_parameter(enc, n + ".weight").cpu().double() - w0[(sfx, n)].double()
+            _summary_close(dw, z, li, sfx, probe)
+
+
+def test_stage0_real_dims_matches_reference_summary(tmp_path):
+    """BASELINE config 5 at real dimensions (d = 3072): the single-pass packed-trie Stage 0 over 20 000 captions against
+    summaries of the REAL reference's layer_stats_text_encoder on the same captions (fixture real_stage0_summary)."""
+    from emcid_amd.layer_stats import layer_stats_text_encoder_multi
+    z, meta = load_golden("real_stage0_summary")
+    data = tmp_path / "data" / "ccs_filtered.json"
+    syn.write_captions(data, meta["n_captions"], seed=meta["captions"]["seed"])
+    pipe = syn.build_pipe(meta["kind"], DEV)
+    stats = layer_stats_text_encoder_multi(pipe.text_encoder, pipe.tokenizer, meta["layer_names"], tmp_path / "stats",
+                                           sample_size=meta["sample_size"], batch_tokens=meta["batch_tokens"],
+                                           data_path=str(data), progress=None, num_workers=0)
+    probe = torch.from_numpy(z["probe"])
+    for li, ln in enumerate(meta["layer_names"]):
+        st = stats[ln].mom2
+        assert st.count == int(z[f"count/{li}"])
+        C = st.mom2.double() / st.count
+        # both sides sum ~230 000 rank-1 terms in fp32, in different orders
+        np.testing.assert_allclose(C.diagonal().sum().item(), float(z[f"trace/{li}"]), rtol=5e-5)
+        np.testing.assert_allclose(C.norm().item(), float(z[f"fro/{li}"]), rtol=5e-5)
+        np.testing.assert_allclose(C.diagonal().numpy(), z[f"diag/{li}"], rtol=0, atol=5e-5 * z[f"diag/{li}"].max())
+        ref = z[f"C_probe/{li}"]
+        assert np.abs((C @ probe).numpy() - ref).max() <= 5e-5 * np.abs(ref).max(), li
