@@ -1,9 +1,9 @@
 """K/Z assembly: fc2 input ("key") and fc2 output at each concept's last subject token.
 
 Host-side counterpart of the slice of the reference's emcid/compute_z.py that Stage 2 calls:
-``tokenize_prompts`` (:56-74) and ``get_module_input_output_at_words`` (:2252-2384).  Stage 1
-(``compute_z_text_encoder*``, Adam through the UNet) is out of scope: its OUTPUT, the cached ``v_star``
-npz, is an input here.
+``tokenize_prompts`` (:56-74) and ``get_module_input_output_at_words`` (:2252-2384) — and Stage 1 itself,
+``compute_z_text_encoder`` (:315-649, the per-concept Adam optimisation of v* through the UNet),
+which emcid_main calls on a v* cache miss when the pipeline carries a UNet and a VAE.
 
 MI355X-first differences, results identical:
 * the prompt batch (ids, mask, lookup index per prompt, request segment offsets) is built once on the host
@@ -19,6 +19,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from . import hip
 from .causal_trace import TokenRangeFinder
@@ -149,10 +150,10 @@ def get_module_input_output_at_words(text_encoder, tok, requests: List[Dict], mo
                                      num_fact_token: int = 1, batch: Optional[PromptBatch] = None
                                      ) -> Tuple[torch.Tensor, torch.Tensor]:
     """(input_ret (N, d), output_ret (N, h)) of ``module_name`` at the last subject token, mean over each
-    request's prompts (reference: compute_z.py:2252-2325, the ``num_fact_token == 1`` branch)."""
+    request's prompts (reference: compute_z.py:2252-2325); with ``num_fact_token = k > 1`` the rows [last subject token,
+    EOS, k - 2 padding positions] of prompts padded to (longest + k - 2) tokens: (N, k, d), (N, k, h) (:2329-2382)."""
     if num_fact_token != 1:
-        raise NotImplementedError("num_fact_token > 1 (compute_z.py:2329-2382) is unused by every shipped hparams "
-                                  "file and is not built")
+        return _module_input_output_multi(text_encoder, tok, requests, module_name, int(num_fact_token))
     device = next(text_encoder.parameters()).device
     if batch is None:
         batch = build_prompt_batch(tok, requests, device)
@@ -172,3 +173,254 @@ def get_module_input_output_at_words(text_encoder, tok, requests: List[Dict], mo
     finally:
         handle.remove()
     return gather_request_means(grabbed["in"], batch), gather_request_means(grabbed["out"], batch)
+
+
+def _module_input_output_multi(text_encoder, tok, requests: List[Dict], module_name: str, k: int):
+    """The ``num_fact_token > 1`` branch (reference: compute_z.py:2329-2382).  No token truncation here: the rows wanted
+    lie at and behind each prompt's EOS."""
+    if k < 2:
+        raise ValueError(f"num_fact_token must be >= 1, got {k}")
+    device = next(text_encoder.parameters()).device
+    prompts, subjects, counts = expand_request_prompts(requests)
+    first = tok(prompts, padding=True, truncation=True)
+    n_pad = k - 2
+    enc = tok(prompts, padding="max_length", truncation=True, max_length=len(first["input_ids"][0]) + n_pad)
+    ids = np.asarray(enc["input_ids"], dtype=np.int64)
+    mask = np.asarray(enc["attention_mask"], dtype=np.int64)
+    last_subject = np.asarray([r[-1] - 1 for r in finder_for(tok).batch(ids, subjects)], dtype=np.int64)
+    eos = mask.sum(axis=1) - 1
+    idx = np.concatenate([last_subject[:, None], eos[:, None] + np.arange(n_pad + 1)[None, :]], axis=1)      # (B, k)
+    if idx.max() >= ids.shape[1] or idx.min() < 0:
+        raise ValueError("lookup index outside the padded prompt")
+    seg = torch.from_numpy(np.cumsum([0] + counts).astype(np.int64)).to(device)
+    grabbed = {}
+
+    def hook(mod, inputs, output):
+        grabbed["in"], grabbed["out"] = inputs[0], output
+        raise StopForward()
+
+    handle = get_module(text_encoder, module_name).register_forward_hook(hook)
+    try:
+        with torch.no_grad(), hip_attention(text_encoder):
+            try:
+                text_encoder(input_ids=torch.from_numpy(ids).to(device), attention_mask=torch.from_numpy(mask).to(device))
+            except StopForward:
+                pass
+    finally:
+        handle.remove()
+    ins, outs = [], []
+    for j in range(k):          # one gather + per-request mean per looked-up position (bit-compatible with torch's mean)
+        col = torch.from_numpy(np.ascontiguousarray(idx[:, j])).to(device)
+        for act, acc in ((grabbed["in"], ins), (grabbed["out"], outs)):
+            if act.dtype != torch.float32:
+                raise hip.EmcidHipError(f"K/Z assembly is fp32; got {act.dtype}")
+            acc.append(hip.gather_mean(act if act.stride(-1) == 1 else act.contiguous(), col, seg))
+    return torch.stack(ins, dim=1), torch.stack(outs, dim=1)
+
+
+# ---- Stage 1: v* by Adam through the UNet (reference: emcid/compute_z.py:34-53, :315-649) ----------------------------------
+
+def preprocess_img(images, resolution: int = 512) -> torch.Tensor:
+    """Resize(bilinear) -> CenterCrop -> RandomHorizontalFlip -> ToTensor -> Normalize(0.5, 0.5) of PIL images, (n, 3, R, R)
+    fp32 on the host (reference :34-53, whose torchvision transforms are restated on PIL + torch: torchvision is not a
+    dependency here).  One ``torch.rand(1)`` per image decides the flip, as torchvision's RandomHorizontalFlip does."""
+    from PIL import Image
+    out = []
+    for im in images:
+        im = im.convert("RGB")
+        w, h = im.size
+        if not ((w <= h and w == resolution) or (h <= w and h == resolution)):
+            im = im.resize((resolution, int(resolution * h / w)) if w < h else (int(resolution * w / h), resolution), Image.BILINEAR)
+            w, h = im.size
+        left, top = int(round((w - resolution) / 2.0)), int(round((h - resolution) / 2.0))
+        im = im.crop((left, top, left + resolution, top + resolution))
+        if torch.rand(1) < 0.5:
+            im = im.transpose(Image.FLIP_LEFT_RIGHT)
+        x = torch.from_numpy(np.asarray(im, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255.0)
+        out.append((x - 0.5) / 0.5)
+    return torch.stack(out)
+
+
+def default_noise_scheduler():
+    """The DDPM training schedule of Stable Diffusion v1.x (reference :378 loads it from the hub): diffusers' own class
+    when that package and its files are reachable, else the same schedule from its published constants."""
+    try:
+        from diffusers import DDPMScheduler
+        return DDPMScheduler.from_pretrained("CompVis/stable-diffusion-v1-4", subfolder="scheduler")
+    except Exception:
+        from .synthetic import DDPMNoiseSchedule
+        return DDPMNoiseSchedule()
+
+
+def compute_z_text_encoder(pipe, request: Dict, hparams, layer: int, device=None, noise_scheduler=None,
+                           resolution: int = 512, rng_device=None) -> torch.Tensor:
+    """v* of one concept: the hidden state of ``layer_module_tmp.format(layer)`` at the last subject token of the first
+    prompt plus a vector ``delta`` found by ``v_num_grad_steps`` Adam steps on the denoising objective (MSE between the
+    UNet's predictions under the edited source embedding and under the destination embedding, or the sampled noise),
+    a weight decay and a text-alignment term, projected onto an L2 ball (reference: emcid/compute_z.py:315-649;
+    same arguments, same return).  Runs wherever the pipeline lives (PyTorch-ROCm autograd through ``pipe.unet``).
+
+    Results-identical restructuring: the text encoder is hooked in place instead of deep-copied per concept (it is frozen:
+    both see the same weights); the clean text-encoder forwards, which the reference repeats every step, run once; the
+    VAE's posterior of a training batch is computed once per distinct batch and SAMPLED every step like the reference's
+    ``encode(...).latent_dist.sample()``.  Random draws happen in the reference's order (image flips, per step: sample
+    indices, VAE posterior noise, latent noise, timesteps).  ``rng_device``: where they are drawn — default: like the
+    reference on this device (the global generator of the model's device; sample indices and flips always on the host);
+    "cpu": everything from the host generator, then moved (reproduces a CPU run on the GPU to fp32 rounding)."""
+    from PIL import Image
+    hp = hparams
+    if getattr(hp, "use_ewc", False):
+        raise NotImplementedError("use_ewc needs the Fisher statistics of emcid/fim_cal.py (Stage-1 option outside the shipped hparams)")
+    te = pipe.text_encoder
+    dev = next(te.parameters()).device
+    rdev = torch.device(rng_device) if rng_device is not None else dev
+    tok = pipe.tokenizer
+    sched = noise_scheduler if noise_scheduler is not None else default_noise_scheduler()
+    objective = hp.objective
+    if objective not in ("ablate-source", "ablate-dest", "esd"):
+        raise ValueError(f"Objective {objective} can not be used for compute_z.")
+    source_prompts = [p.format(request["source"]) for p in request["prompts"]]
+    dest_prompts = ["" for _ in request["prompts"]] if objective == "esd" else [p.format(request["dest"]) for p in request["prompts"]]
+    spp = hp.samples_per_prompt
+    if "training_img_paths" in request and objective != "esd":
+        images = [Image.open(path) for path in request["training_img_paths"]]
+    elif "images" in request and objective != "esd":
+        images = request["images"]
+    else:       # the reference samples the training images from the pipeline itself (:383-412)
+        gen = torch.Generator(dev).manual_seed(int(request["seed_train"])) if request.get("seed_train") is not None else None
+        images = []
+        for _ in range(spp):
+            images.extend(pipe(source_prompts, guidance_scale=7.5, generator=gen).images)
+    pixels = preprocess_img(images, resolution)
+    bsz = len(source_prompts)
+    pixels = pixels.reshape(spp, bsz, *pixels.shape[1:]).transpose(0, 1)              # "(s b) c h w -> b s c h w"
+    if len(pixels) % bsz:
+        raise AssertionError(f"len(img_batch) {len(pixels)} should be n times of batch size {bsz}")
+    src_inp, dst_inp = tokenize_prompts(source_prompts, tok, dev), tokenize_prompts(dest_prompts, tok, dev)
+    finder = finder_for(tok)
+    src_lookup = [finder(ids, request["source"])[-1] - 1 for ids in src_inp["input_ids"].tolist()]
+    dst_lookup = [finder(ids, request["dest"])[-1] - 1 for ids in dst_inp["input_ids"].tolist()]
+    if not (len(src_inp["input_ids"]) == len(dst_inp["input_ids"]) == len(pixels)):
+        raise AssertionError("The number of prompts and images should be the same.")
+    ar = torch.arange(bsz, device=dev)
+    src_idx, dst_idx = torch.tensor(src_lookup, device=dev), torch.tensor(dst_lookup, device=dev)
+    frozen = [prm for m in (te, pipe.vae, pipe.unet) for prm in m.parameters() if prm.requires_grad]
+    for prm in frozen:
+        prm.requires_grad_(False)
+    delta = torch.zeros((te.config.hidden_size,), requires_grad=True, device=dev)
+    opt = torch.optim.Adam([delta], lr=hp.v_lr)
+    state = {"edit": False, "source_init": None}
+
+    def hook(mod, args, out):
+        if not state["edit"]:
+            return out
+        h = out[0] if isinstance(out, tuple) else out          # transformers 4.x layers return a tuple, 5.x the tensor
+        if state["source_init"] is None:
+            state["source_init"] = h[0, src_lookup[0]].detach().clone()
+        h = h.clone()
+        if hp.replace_repr:
+            h[ar, src_idx, :] = delta
+        else:
+            h[ar, src_idx, :] = h[ar, src_idx, :] + delta
+        return (h,) + tuple(out[1:]) if isinstance(out, tuple) else h
+
+    def edited(inp):
+        state["edit"] = True
+        try:
+            return te(**inp)[0:2]
+        finally:
+            state["edit"] = False
+
+    handle = get_module(te, hp.layer_module_tmp.format(layer)).register_forward_hook(hook)
+    try:
+        with torch.no_grad():        # loop invariants (the reference recomputes them every step from the same frozen encoder)
+            dest_repr, dest_pool = te(**dst_inp)[0:2]
+            source_repr = te(**src_inp)[0] if (objective == "esd" or hp.cal_text_repr_loss) else None
+            if hp.contrastive_text_loss:
+                neg_pool = te(**tokenize_prompts(request["negative_prompts"], tok, dev))[1]
+                single_pool = te(**tokenize_prompts([request["dest"]], tok, dev))[1]
+            if hp.align_obj_eos_pad:
+                full = lambda ps: {k: v.to(dev) for k, v in tok(ps, max_length=tok.model_max_length, return_tensors="pt",
+                                                                padding="max_length", truncation=True).items()}
+                src_full, dst_full = full(source_prompts), full(dest_prompts)
+                src_eos = [int(m.sum()) - 1 for m in src_full["attention_mask"]]
+                dst_eos = [int(m.sum()) - 1 for m in dst_full["attention_mask"]]
+                far = max(src_eos + dst_eos)
+                src_slices = [list(range(e, tok.model_max_length - max(0, far - e))) for e in src_eos]
+                dst_slices = [list(range(e, tok.model_max_length - max(0, far - e))) for e in dst_eos]
+                dest_full = te(**dst_full)[0]
+                d_pad = torch.stack([dest_full[i, sl, :] for i, sl in enumerate(dst_slices)], dim=0)
+        posteriors = {}
+        host_draw = rdev.type == "cpu" and dev.type != "cpu"
+        for it in range(hp.v_num_grad_steps):
+            opt.zero_grad()
+            sample_indices = torch.randint(0, spp, (bsz,))
+            key = tuple(sample_indices.tolist())
+            if key not in posteriors:
+                with torch.no_grad():
+                    posteriors[key] = pipe.vae.encode(pixels[torch.arange(bsz), sample_indices].to(dev)).latent_dist
+            with torch.no_grad():
+                latents = posteriors[key].sample(torch.default_generator) if host_draw else posteriors[key].sample()
+                latents = latents * pipe.vae.config.scaling_factor
+            if host_draw:
+                noise = torch.randn(latents.shape, dtype=latents.dtype).to(dev)
+                timesteps = torch.randint(0, sched.config.num_train_timesteps, (bsz,)).long().to(dev)
+            else:
+                noise = torch.randn_like(latents, device=dev)
+                timesteps = torch.randint(0, sched.config.num_train_timesteps, (bsz,), device=dev).long()
+            noisy = sched.add_noise(latents, noise, timesteps)
+            edit_repr, edit_pool = edited(src_inp)
+            source_init = state["source_init"]
+            if not hp.no_noise_loss:
+                edit_pred = pipe.unet(noisy, timesteps, edit_repr).sample
+                with torch.no_grad():
+                    pred_dest = pipe.unet(noisy, timesteps, dest_repr).sample
+            reg = hp.v_weight_decay * (torch.norm(delta) / torch.norm(source_init) ** 2)
+            if "ablate" in objective:
+                if getattr(hp, "use_sampled_noise", False) or request.get("use_real_noise", False):
+                    loss = F.mse_loss(noise, edit_pred, reduction="mean") + reg
+                elif hp.no_noise_loss:
+                    loss = reg
+                else:
+                    loss = F.mse_loss(edit_pred, pred_dest, reduction="mean") + reg
+            else:
+                with torch.no_grad():
+                    pred_source = pipe.unet(noisy, timesteps, source_repr).sample
+                loss = F.mse_loss(edit_pred, pred_dest - hp.esd_mu * (pred_source - pred_dest), reduction="mean") + reg
+            if hp.cal_text_repr_loss and request.get("txt_align", True):
+                scale = hp.text_repr_loss_scale_factor
+                if hp.contrastive_text_loss:
+                    emb = torch.cat([single_pool, neg_pool], dim=0)
+                    scores = torch.squeeze(-torch.cdist(edit_pool.unsqueeze(0), emb.unsqueeze(0)))
+                    loss = loss + scale * (-torch.log_softmax(scores, dim=1)[:, 0].mean(dim=0))
+                elif hp.align_object_token:
+                    loss = loss + scale * F.mse_loss(edit_repr[ar, src_idx, :], dest_repr[ar, dst_idx, :], reduction="mean")
+                elif hp.align_obj_eos_pad:
+                    e_full = edited(src_full)[0]
+                    e_pad = torch.stack([e_full[i, sl, :] for i, sl in enumerate(src_slices)], dim=0)
+                    loss = loss + scale * F.mse_loss(torch.cat([edit_repr[ar, src_idx, :].unsqueeze(1), e_pad], dim=1),
+                                                     torch.cat([dest_repr[ar, dst_idx, :].unsqueeze(1), d_pad], dim=1),
+                                                     reduction="mean")
+                else:
+                    loss = loss + scale * F.mse_loss(edit_pool, dest_pool, reduction="mean")
+            loss.backward()
+            opt.step()
+            max_norm = hp.clamp_norm_factor * source_init.norm()
+            if delta.norm() > max_norm:
+                with torch.no_grad():
+                    delta[...] = delta * max_norm / delta.norm()
+    finally:
+        handle.remove()
+        for prm in frozen:
+            prm.requires_grad_(True)
+    return (state["source_init"] + delta).detach()
+
+
+def stage1_for(pipe, hparams, layer: int, **kw):
+    """The ``stage1=`` callable emcid_main's v* cache expects (``stage1(request, suffix) -> v*``) for a pipeline that carries
+    a UNet and a VAE: Stage 1 on a cache miss, like the reference (emcid_main.py:905-969)."""
+    def stage1(request, suffix=""):
+        if suffix:
+            raise NotImplementedError("the SDXL pair optimisation compute_z_sdxl_text_encoders (compute_z.py:651-1037) is not built")
+        return compute_z_text_encoder(pipe, request, hparams, layer, **kw)
+    return stage1

@@ -16,7 +16,8 @@ Kept reference behaviours: ``hparams`` is mutated in place by the mom2/edit weig
 leaves TE2 edited and ``apply_*`` then adds the deltas again, so TE2 ends at W + 2*dW (:1410 vs :93-99) —
 reproduced by default (``SDXL_TE2_DOUBLE_APPLY``).  Deliberate differences: ``COV_CACHE`` is keyed by the
 statistics directory too (the reference's key ignores it and silently reuses a stale C, SURVEY.md §5);
-per-request progress prints obey ``verbose``; a v* cache miss raises (Stage 1 needs the SD UNet, out of scope).
+per-request progress prints obey ``verbose``; a v* cache miss runs Stage 1 (compute_z.compute_z_text_encoder) when the
+pipeline carries a UNet and a VAE, and raises otherwise.
 """
 import os
 from copy import deepcopy
@@ -215,13 +216,30 @@ def _io_pool():
     return _IO_POOL
 
 
+class _VstarFuture:
+    """Result of the reader thread; if a cache file was missing and the caller has a Stage-1 function, the load is
+    repeated on the calling thread with it (files that were found stay in the in-process copy)."""
+
+    def __init__(self, fut, args):
+        self.fut, self.args = fut, args
+
+    def result(self):
+        try:
+            return self.fut.result()
+        except NotImplementedError:
+            if self.args[-1] is None:
+                raise
+            return load_v_stars(*self.args)
+
+
 def prepare_text_encoder_edit(text_encoder, tokenizer, requests, hparams, layers, lam, stat_dir, cache_name,
                               suffix="", verbose=True, shard=None, stage1=None) -> EncoderEditPlan:
     """Host side of one encoder's edit: v* rows, C per layer (HBM-resident), tokenized prompts + lookup."""
     # the v* cache reads are file-system calls (they release the GIL): they run on a helper thread underneath the
-    # tokenizer, which is native code that releases it too.  A Stage-1 callable stays on this thread.
-    if stage1 is None and cache_name is not None and len(requests) >= 64:
-        zs_future = _io_pool().submit(load_v_stars, requests, hparams, cache_name, suffix, None)
+    # tokenizer, which is native code that releases it too.  A cache miss is served afterwards on this thread (Stage 1).
+    if cache_name is not None and len(requests) >= 64:
+        zs_future = _VstarFuture(_io_pool().submit(load_v_stars, requests, hparams, cache_name, suffix, None),
+                                 (requests, hparams, cache_name, suffix, stage1))
     else:
         with phase("vstar"):
             zs_future = load_v_stars(requests, hparams, cache_name, suffix, stage1)
@@ -234,6 +252,20 @@ def prepare_text_encoder_edit(text_encoder, tokenizer, requests, hparams, layers
     return prepare_encoder_edit(text_encoder, tokenizer, requests, layers, hparams.rewrite_module_tmp, lam,
                                 hparams.edit_weight, zs_future, covs, _shard_from_env(shard),
                                 layer_module_tmp=getattr(hparams, "layer_module_tmp", None))
+
+
+def _default_stage1(pipe, hparams, stage1):
+    """Stage 1 on a v* cache miss, like the reference (:905-969): when the caller gave no ``stage1=`` and the pipeline
+    carries a UNet and a VAE, the missing v* is optimised by compute_z.compute_z_text_encoder at z_layer =
+    hparams.layers[-1] (:868) and written to the cache.  The reference's other Stage-1 variants (sld_supervision,
+    txt_img_align_scale_factor != 0, use_new_compute_z) are not built."""
+    if stage1 is not None or getattr(pipe, "unet", None) is None or getattr(pipe, "vae", None) is None:
+        return stage1
+    if getattr(hparams, "sld_supervision", False) or getattr(hparams, "txt_img_align_scale_factor", 0) != 0 \
+            or getattr(hparams, "use_new_compute_z", False):
+        return None
+    from .compute_z import stage1_for
+    return stage1_for(pipe, hparams, hparams.layers[-1])
 
 
 def _deltas_to_host(edits: List[LayerEdit]) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
@@ -258,7 +290,8 @@ def execute_emcid_text_encoder(pipe, requests: List[Dict], hparams: EMCIDHyperPa
     hparams.edit_weight = edit_weight if edit_weight is not None else hparams.edit_weight
     _announce(requests, verbose)
     plan = prepare_text_encoder_edit(pipe.text_encoder, pipe.tokenizer, requests, hparams, hparams.layers,
-                                     hparams.mom2_update_weight, stat_dir, cache_name, "", verbose, shard, stage1)
+                                     hparams.mom2_update_weight, stat_dir, cache_name, "", verbose, shard,
+                                     _default_stage1(pipe, hparams, stage1))
     edits = run_checked(plan, keep_factors=True, restore=True)
     if verbose:
         print(f"Deltas successfully computed for {[e.weight_name for e in edits]}")
@@ -275,7 +308,8 @@ def apply_emcid_to_text_encoder(pipe, requests: List[Dict], hparams: EMCIDHyperP
     hparams.edit_weight = edit_weight if edit_weight is not None else hparams.edit_weight
     _announce(requests, verbose)
     plan = prepare_text_encoder_edit(pipe.text_encoder, pipe.tokenizer, requests, hparams, hparams.layers,
-                                     hparams.mom2_update_weight, stats_dir, cache_name, "", verbose, shard, stage1)
+                                     hparams.mom2_update_weight, stats_dir, cache_name, "", verbose, shard,
+                                     _default_stage1(pipe, hparams, stage1))
     # The engine leaves each fc2 at W0 + float(U): the value the reference reaches by restoring W0 (:1076-1078)
     # and adding float(adj_k @ resid^T) again (:802-809).
     with phase("run + final sync"):

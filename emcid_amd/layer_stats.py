@@ -45,10 +45,10 @@ def stats_filename(stats_dir, model_name, ds_name, layer_name, precision, to_col
 def _check_precision(precision):
     if precision is None:
         precision = "float64"   # the reference's default when unset (layer_stats.py:161-162)
-    if precision != "float32":
+    if precision not in ("float32", "float64"):
         raise NotImplementedError(
-            f"precision={precision!r}: the MI355X SYRK kernel accumulates fp32 (the reference's CLI default, "
-            f"layer_stats.py:51, and every shipped hparams file); other precisions are not built")
+            f"precision={precision!r}: the statistics are accumulated by the fp32 (reference CLI default, layer_stats.py:51) "
+            f"or the fp64 MFMA SYRK; float16 sums are not built")
     return precision
 
 
@@ -104,8 +104,9 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
         raise ValueError("forward='trie' needs a HF CLIP text encoder and fc2 layer names")
     if packed is not None:
         return _collect_packed(model, tokenizer, ds, sample, pool, packed, todo, stats, files, args, shard, group, device,
-                               progress, device_batch_tokens)
+                               progress, device_batch_tokens, getattr(torch, precision))
     loader = groups()
+    stat_dtype = getattr(torch, precision)
     # forward order of the hooked modules decides which one is "deepest" (the one that stops the pass)
     order = {name: i for i, (name, _) in enumerate(model.named_modules())}
     mods = {ln: get_module(model, ln) for ln in todo}
@@ -134,7 +135,7 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
                     for ln in todo:
                         x = grabbed[ln]
                         feats = x.reshape(-1, x.size(-1)).index_select(0, attended)  # == flatten_masked_batch(x, mask)
-                        stats[ln].add(feats.to(dtype=torch.float32))
+                        stats[ln].add(feats.to(dtype=stat_dtype))        # reference: feats.to(dtype=dtype) (:218)
                     grabbed.clear()
     finally:
         for h in handles:
@@ -172,7 +173,7 @@ def _packed_plan(model, layer_names, mods_of=None):
 
 
 def _collect_packed(model, tokenizer, ds, sample, pool, packed, todo, stats, files, args, shard, group, device, progress,
-                    device_batch_tokens):
+                    device_batch_tokens, stat_dtype=torch.float32):
     """Stage 0 on the packed prefix trie: the captions of a pool share their common prefixes ("<bos> a photo of ...") and
     carry no padding; every DISTINCT prefix is a row, computed once and entered into the Gram scaled by the square root
     of the number of captions that pass through it — sum_tokens x x^T exactly as the reference's attended-token sum
@@ -196,11 +197,11 @@ def _collect_packed(model, tokenizer, ds, sample, pool, packed, todo, stats, fil
             n_real, tokens = trie.n_nodes, int(sum(len(s) for s in ids))
             LAST_RUN["tokens"] += tokens
             LAST_RUN["rows"] += n_real
-            root = cnt.sqrt().unsqueeze(1)
+            root = cnt.to(stat_dtype).sqrt().unsqueeze(1)
 
             def on_fc2(i, x, out):
                 if i in wanted:
-                    feats = x[:n_real] * root
+                    feats = x[:n_real].to(stat_dtype) * root
                     for ln in wanted[i]:
                         stats[ln].add(feats, count=tokens)
                 return None if i == deepest else out

@@ -83,30 +83,43 @@ class SecondMoment(Stat):
             return
         if not a.is_cuda:
             raise hip.EmcidHipError("SecondMoment.add needs a tensor in HBM (no CPU path in emcid_amd)")
-        if a.dtype != torch.float32:
-            raise hip.EmcidHipError(f"SecondMoment.add accumulates fp32 (reference default precision); got {a.dtype}")
+        if a.dtype not in (torch.float32, torch.float64):
+            raise hip.EmcidHipError(f"SecondMoment.add accumulates fp32 (the reference's CLI default, fp32 MFMA SYRK) or fp64 "
+                                    f"(its --precision float64, fp64 MFMA SYRK); got {a.dtype}")
         d = a.shape[1]
         if self._lower is None:
             if self._full is not None:   # resumed from a loaded state
-                self._lower = self._full.to(a.device, torch.float32).contiguous().clone()
+                self._lower = self._full.to(a.device, a.dtype).contiguous().clone()
             else:
-                self._lower = torch.zeros(d, d, dtype=torch.float32, device=a.device)
+                self._lower = torch.zeros(d, d, dtype=a.dtype, device=a.device)
+        if a.dtype != self._lower.dtype:
+            raise hip.EmcidHipError(f"SecondMoment holds {self._lower.dtype} sums; got a {a.dtype} batch")
+        if a.dtype == torch.float64 and d % 2:
+            raise hip.EmcidHipError("fp64 statistics need an even feature width (16-byte aligned f64 rows)")
         self._full = None
         self.count += a.shape[0] if count is None else int(count)
         if a.shape[0] >= self.stage_tokens:
             self.flush()
-            hip.gram_accumulate_(self._lower, a.contiguous(), self.ksplit)
+            self._accumulate(a.contiguous())
             return
         if self._stage is None:
-            self._stage = torch.empty(self.stage_tokens, d, dtype=torch.float32, device=a.device)
+            self._stage = torch.empty(self.stage_tokens, d, dtype=a.dtype, device=a.device)
         if self._staged + a.shape[0] > self.stage_tokens:
             self.flush()
         self._stage[self._staged:self._staged + a.shape[0]].copy_(a)
         self._staged += a.shape[0]
 
+    def _accumulate(self, x: torch.Tensor):
+        """lower(mom2) += x^T x on the matrix cores: fp32 SYRK (csrc/gram_f32.hip) or the fp64 MFMA GEMM restricted to the
+        lower tiles (csrc/gemm_f64.h: A = x stored [K = tokens][rows = d] for both operands)."""
+        if x.dtype == torch.float32:
+            hip.gram_accumulate_(self._lower, x, self.ksplit)
+        else:
+            hip.dgemm_ex(1, 1, x, x, self._lower, alpha=1.0, beta=1.0, flags=16, ksplit=1 if self.ksplit == 1 else 0)
+
     def flush(self):
         if self._staged:
-            hip.gram_accumulate_(self._lower, self._stage[:self._staged], self.ksplit)
+            self._accumulate(self._stage[:self._staged])
             self._staged = 0
 
     # -- readout -------------------------------------------------------------------------------------
@@ -114,7 +127,10 @@ class SecondMoment(Stat):
     def mom2(self) -> Optional[torch.Tensor]:
         if self._full is None and self._lower is not None:
             self.flush()
-            self._full = hip.symmetrize_lower_(self._lower.clone())
+            if self._lower.dtype == torch.float32:
+                self._full = hip.symmetrize_lower_(self._lower.clone())
+            else:
+                self._full = torch.tril(self._lower) + torch.tril(self._lower, -1).t()
         return self._full
 
     def moment(self):

@@ -144,6 +144,8 @@ class SyntheticPipe(SimpleNamespace):
             self.text_encoder_2.to(device)
         if getattr(self, "unet", None) is not None:
             self.unet.to(device)
+        if getattr(self, "vae", None) is not None:
+            self.vae.to(device)
         return self
 
 
@@ -213,11 +215,92 @@ class SyntheticUNet(torch.nn.Module):
         self.config = SimpleNamespace(_name_or_path=f"synthetic/unet-{kind}", in_channels=4, sample_size=8)
 
     def forward(self, sample, timestep, encoder_hidden_states=None, **kw):
+        # every projection sees the text embedding (what the reference's hooks record); the returned "noise prediction"
+        # depends smoothly on the projections' outputs and on the timestep, so Stage 1 has something to differentiate
+        s = 0.0
         for m in self.modules():
             if isinstance(m, _CrossAttention):
-                m.to_k(encoder_hidden_states)
-                m.to_v(encoder_hidden_states)
+                k = m.to_k(encoder_hidden_states)
+                v = m.to_v(encoder_hidden_states)
+                s = s + (k.mean(dim=(1, 2)) * v.mean(dim=(1, 2)))
+        if torch.is_tensor(s):
+            t = torch.as_tensor(timestep, dtype=sample.dtype, device=sample.device).reshape(-1)
+            g = (1.0 + 0.5 * torch.tanh(8.0 * s) + 0.1 * torch.sin(t / 160.0)).reshape(-1, *([1] * (sample.dim() - 1)))
+            sample = sample * g + 3.0 * s.reshape(-1, *([1] * (sample.dim() - 1)))
         return SimpleNamespace(sample=sample)
+
+
+class _LatentDist:
+    def __init__(self, mean, logvar):
+        self.mean, self.std = mean, torch.exp(0.5 * logvar)
+
+    def sample(self, generator=None):
+        # like diffusers' DiagonalGaussianDistribution.sample (randn_tensor): one draw from the global generator of the
+        # mean's device, or from `generator` on ITS device (a CPU generator serves a device tensor) moved over afterwards
+        dev = self.mean.device if generator is None else generator.device
+        eps = torch.randn(self.mean.shape, generator=generator, device=dev, dtype=self.mean.dtype)
+        return self.mean + self.std * eps.to(self.mean.device)
+
+
+class SyntheticVAE(torch.nn.Module):
+    """The part of a diffusers AutoencoderKL Stage 1 touches: ``encode(x).latent_dist.sample()`` and
+    ``config.scaling_factor``; an 8x-downsampling conv to 2 x 4 latent channels (mean | log-variance)."""
+
+    def __init__(self, seed: int = 21):
+        super().__init__()
+        st = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        self.conv = torch.nn.Conv2d(3, 8, kernel_size=8, stride=8)
+        torch.random.set_rng_state(st)
+        for p in self.parameters():
+            p.requires_grad_(False)
+        self.config = SimpleNamespace(scaling_factor=0.18215)
+
+    def encode(self, x):
+        mom = self.conv(x)
+        return SimpleNamespace(latent_dist=_LatentDist(mom[:, :4], mom[:, 4:].clamp(-30.0, 20.0) - 4.0))
+
+
+class DDPMNoiseSchedule:
+    """``add_noise`` of the DDPM training schedule Stable Diffusion v1.x ships in its ``scheduler`` folder [external:
+    CompVis/stable-diffusion-v1-4 scheduler_config.json: 1000 steps, scaled_linear betas 0.00085 .. 0.012] — all Stage 1
+    uses of ``DDPMScheduler`` (reference: emcid/compute_z.py:378, :521-524):  x_t = sqrt(acp_t) x_0 + sqrt(1 - acp_t) eps."""
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012):
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps)
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+
+    @classmethod
+    def from_pretrained(cls, *args, **kwargs):
+        return cls()
+
+    def add_noise(self, original_samples, noise, timesteps):
+        acp = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)
+        t = timesteps.to(original_samples.device)
+        a = acp[t].sqrt().reshape(-1, *([1] * (original_samples.dim() - 1)))
+        b = (1.0 - acp[t]).sqrt().reshape(-1, *([1] * (original_samples.dim() - 1)))
+        return a * original_samples + b * noise
+
+
+def make_images(n: int, resolution: int, seed: int = 31):
+    """n deterministic RGB PIL images (smooth random fields) of ``resolution`` x ``resolution``."""
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    imgs = []
+    for _ in range(n):
+        low = rng.random((4, 4, 3))
+        arr = np.kron(low, np.ones((resolution // 4, resolution // 4, 1)))
+        imgs.append(Image.fromarray((arr * 255).astype(np.uint8), "RGB"))
+    return imgs
+
+
+def add_diffusion(pipe: "SyntheticPipe", kind: str = "toy") -> "SyntheticPipe":
+    """UNet stand-in (cross-attention projections under their real names, differentiable output), VAE stand-in and the
+    scheduler attribute: everything Stage 1 (compute_z_text_encoder) reads from a pipeline besides the text encoder."""
+    add_unet(pipe, kind)
+    pipe.vae = SyntheticVAE().to(pipe.device)
+    return pipe
 
 
 def add_unet(pipe: "SyntheticPipe", kind: str = "toy", seed: int = 11) -> "SyntheticPipe":

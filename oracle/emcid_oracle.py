@@ -106,6 +106,39 @@ def expand_requests(requests: Sequence[Dict]) -> Tuple[List[str], List[str], Lis
     return prompts, subjects, counts
 
 
+def module_input_output_at_words_multi(text_encoder, tokenizer, requests, module_name, num_fact_token):
+    """The num_fact_token > 1 branch (compute_z.py:2329-2382): prompts padded to (longest + num_fact_token - 2) tokens
+    with padding="max_length"; per prompt the rows [last subject token, EOS, the num_fact_token - 2 positions after it];
+    returns (N, num_fact_token, d) and (N, num_fact_token, h) means over each request's prompts."""
+    device = next(text_encoder.parameters()).device
+    prompts, subjects, counts = expand_requests(requests)
+    first = tokenize_prompts(prompts, tokenizer, device)
+    n_pad = num_fact_token - 2
+    enc = tokenizer(prompts, return_tensors="pt", padding="max_length", truncation=True,
+                    max_length=len(first["input_ids"][0]) + n_pad)
+    inp = {k: v.to(device) for k, v in enc.items()}
+    lookup = [[find_token_range(tokenizer, ids, w)[-1] - 1] for ids, w in zip(inp["input_ids"], subjects)]
+    eos = [int(m.sum()) - 1 for m in inp["attention_mask"]]
+    lookup = [lk + list(range(e, e + n_pad + 1)) for lk, e in zip(lookup, eos)]
+    cap = {}
+
+    def hook(mod, args, out):
+        cap["in"], cap["out"] = args[0], out
+
+    h = get_module(text_encoder, module_name).register_forward_hook(hook)
+    try:
+        with torch.no_grad():
+            text_encoder(**inp)
+    finally:
+        h.remove()
+    rows_in = torch.stack([cap["in"][i, idx, :] for i, idx in enumerate(lookup)], 0).detach().clone()
+    rows_out = torch.stack([cap["out"][i, idx, :] for i, idx in enumerate(lookup)], 0).detach().clone()
+    edges = np.cumsum([0] + counts).tolist()
+    k = torch.stack([rows_in[edges[i]:edges[i + 1]].mean(0) for i in range(len(requests))], 0)
+    z = torch.stack([rows_out[edges[i]:edges[i + 1]].mean(0) for i in range(len(requests))], 0)
+    return k, z
+
+
 def module_input_output_at_words(text_encoder, tokenizer, requests, module_name) -> Tuple[torch.Tensor, torch.Tensor]:
     """One full encoder forward on all N*P prompts; fc2 input/output at the last subject
     token of each prompt; mean over each request's prompts (num_fact_token == 1 branch)."""
@@ -130,6 +163,175 @@ def module_input_output_at_words(text_encoder, tokenizer, requests, module_name)
     k = torch.stack([rows_in[edges[i]:edges[i + 1]].mean(0) for i in range(len(requests))], 0)
     z = torch.stack([rows_out[edges[i]:edges[i + 1]].mean(0) for i in range(len(requests))], 0)
     return k, z
+
+
+# --------------------------------------------------------------------------------------
+# Stage 1 (reference: emcid/compute_z.py:34-53 preprocess_img, :315-649 compute_z_text_encoder)
+# --------------------------------------------------------------------------------------
+
+def preprocess_img(images, resolution: int) -> torch.Tensor:
+    """Resize(bilinear) -> CenterCrop -> RandomHorizontalFlip -> ToTensor -> Normalize(0.5, 0.5) on PIL images
+    (compute_z.py:34-53; torchvision's transforms restated with PIL + torch: one ``torch.rand(1)`` per image for the flip)."""
+    from PIL import Image
+    out = []
+    for im in images:
+        im = im.convert("RGB")
+        w, h = im.size
+        if min(w, h) != resolution:                       # Resize(int): the shorter side becomes `resolution`
+            if w <= h:
+                im = im.resize((resolution, int(resolution * h / w)), Image.BILINEAR)
+            else:
+                im = im.resize((int(resolution * w / h), resolution), Image.BILINEAR)
+            w, h = im.size
+        left, top = int(round((w - resolution) / 2.0)), int(round((h - resolution) / 2.0))
+        im = im.crop((left, top, left + resolution, top + resolution))
+        if torch.rand(1) < 0.5:
+            im = im.transpose(Image.FLIP_LEFT_RIGHT)
+        x = torch.from_numpy(np.asarray(im, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255.0)
+        out.append((x - 0.5) / 0.5)
+    return torch.stack(out)
+
+
+def _hidden(out):
+    return out[0] if isinstance(out, tuple) else out      # transformers 4.x layers return a tuple, 5.x the tensor
+
+
+def compute_z_text_encoder(pipe, request: Dict, hparams: Dict, layer: int, noise_scheduler, resolution: int = 512) -> torch.Tensor:
+    """Per-concept Adam optimisation of v* through the UNet (compute_z.py:315-649), op for op: deep copy of the encoder
+    with a hook that adds ``delta`` at each prompt's last subject token in ``layer_module_tmp.format(layer)``'s output,
+    per step one VAE encode, the clean text-encoder forwards, two (esd: three) UNet forwards, MSE + weight decay (+ the
+    text-alignment term), Adam step, projection onto the L2 ball.  ``hparams``: the JSON fields (missing flags = the
+    dataclass defaults of emcid_hparams.py:55-163).  Randomness: the global torch generators, consumed in the
+    reference's order."""
+    from copy import deepcopy
+    import torch.nn.functional as F
+    hp = lambda k, d=None: hparams.get(k, d)
+    if hp("use_ewc", False):
+        raise NotImplementedError("use_ewc needs the Fisher statistics file (Stage-1 option outside the shipped hparams)")
+    device = next(pipe.text_encoder.parameters()).device
+    te_edit = deepcopy(pipe.text_encoder).to(device)
+    source_prompts = [p.format(request["source"]) for p in request["prompts"]]
+    objective = hp("objective")
+    dest_prompts = ["" for _ in request["prompts"]] if objective == "esd" else [p.format(request["dest"]) for p in request["prompts"]]
+    delta = torch.zeros((te_edit.config.hidden_size,), requires_grad=True, device=device)
+    state = {"source_init": None}
+    opt = torch.optim.Adam([delta], lr=hp("v_lr"))
+    for m in (te_edit, pipe.vae, pipe.unet, pipe.text_encoder):
+        for prm in m.parameters():
+            prm.requires_grad = False
+    spp = hp("samples_per_prompt", 1)
+    if objective not in ("ablate-source", "ablate-dest", "esd"):
+        raise ValueError(f"Objective {objective} can not be used for compute_z.")
+    if "training_img_paths" in request and objective != "esd":
+        from PIL import Image
+        all_imgs = [Image.open(path) for path in request["training_img_paths"]]
+    elif "images" in request and objective != "esd":
+        all_imgs = request["images"]
+    else:
+        generator = torch.Generator(device).manual_seed(int(request["seed_train"])) if request["seed_train"] is not None else None
+        all_imgs = []
+        for _ in range(spp):
+            all_imgs.extend(pipe(source_prompts, guidance_scale=7.5, generator=generator).images)
+    all_imgs = preprocess_img(all_imgs, resolution)
+    bsz = len(source_prompts)
+    all_imgs = all_imgs.reshape(spp, bsz, *all_imgs.shape[1:]).transpose(0, 1)       # "(s b) c h w -> b s c h w"
+    assert len(all_imgs) % bsz == 0
+    src_inp = tokenize_prompts(source_prompts, pipe.tokenizer, device)
+    dst_inp = tokenize_prompts(dest_prompts, pipe.tokenizer, device)
+    tok = pipe.tokenizer
+    if hp("align_obj_eos_pad", False):
+        full = lambda ps: {k: v.to(device) for k, v in tok(ps, max_length=tok.model_max_length, return_tensors="pt",
+                                                           padding="max_length", truncation=True).items()}
+        src_full, dst_full = full(source_prompts), full(dest_prompts)
+        src_eos = [int(m.sum()) - 1 for m in src_full["attention_mask"]]
+        dst_eos = [int(m.sum()) - 1 for m in dst_full["attention_mask"]]
+        far = max(src_eos + dst_eos)
+        src_slices = [list(range(e, tok.model_max_length - max(0, far - e))) for e in src_eos]
+        dst_slices = [list(range(e, tok.model_max_length - max(0, far - e))) for e in dst_eos]
+        with torch.no_grad():
+            dest_full = pipe.text_encoder(**dst_full)[0]
+    if hp("contrastive_text_loss", False):
+        neg_inp = tokenize_prompts(request["negative_prompts"], tok, device)
+    src_lookup = [find_token_range(tok, ids, request["source"])[-1] - 1 for ids in src_inp["input_ids"]]
+    dst_lookup = [find_token_range(tok, ids, request["dest"])[-1] - 1 for ids in dst_inp["input_ids"]]
+    assert len(src_inp["input_ids"]) == len(dst_inp["input_ids"]) == len(all_imgs)
+    layer_mod = get_module(te_edit, hparams["layer_module_tmp"].format(layer))
+
+    def hook(mod, args, out):
+        h = _hidden(out)
+        if state["source_init"] is None:
+            state["source_init"] = h[0, src_lookup[0]].detach().clone()
+        for i, idx in enumerate(src_lookup):
+            if hp("replace_repr", False):
+                h[i, idx, :] = delta
+            else:
+                h[i, idx, :] += delta
+        return out
+
+    handle = layer_mod.register_forward_hook(hook)
+    try:
+        for it in range(hp("v_num_grad_steps")):
+            opt.zero_grad()
+            sample_indices = torch.randint(0, spp, (bsz,))
+            img_batch = all_imgs[torch.arange(bsz), sample_indices].to(device)
+            with torch.no_grad():
+                latents = pipe.vae.encode(img_batch).latent_dist.sample() * pipe.vae.config.scaling_factor
+                dest_repr, dest_pool = pipe.text_encoder(**dst_inp)[0:2]
+                if objective == "esd" or hp("cal_text_repr_loss", False):
+                    source_repr = pipe.text_encoder(**src_inp)[0]
+                    if hp("contrastive_text_loss", False):
+                        neg_repr, neg_pool = pipe.text_encoder(**neg_inp)[0:2]
+            noise = torch.randn_like(latents, device=device)
+            timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (bsz,), device=device).long()
+            noisy = noise_scheduler.add_noise(latents, noise, timesteps)
+            edit_repr, edit_pool = te_edit(**src_inp)[0:2]
+            with torch.no_grad():
+                if objective == "esd":
+                    pred_source = pipe.unet(noisy, timesteps, source_repr).sample
+            if not hp("no_noise_loss", False):
+                edit_pred = pipe.unet(noisy, timesteps, edit_repr).sample
+                pred_dest = pipe.unet(noisy, timesteps, dest_repr).sample
+            source_init = state["source_init"]
+            reg = hp("v_weight_decay") * (torch.norm(delta) / torch.norm(source_init) ** 2)
+            if "ablate" in objective:
+                if hp("use_sampled_noise", False) or request.get("use_real_noise", False):
+                    mse = F.mse_loss(noise, edit_pred, reduction="mean")
+                elif hp("no_noise_loss", False):
+                    mse = None
+                else:
+                    mse = F.mse_loss(edit_pred, pred_dest, reduction="mean")
+                loss = reg if hp("no_noise_loss", False) else mse + reg
+            else:
+                tmp = pred_dest - hp("esd_mu") * (pred_source - pred_dest)
+                loss = F.mse_loss(edit_pred, tmp, reduction="mean") + reg
+            if hp("cal_text_repr_loss", False) and request.get("txt_align", True):
+                scale = hp("text_repr_loss_scale_factor")
+                ar = torch.arange(bsz)
+                if hp("contrastive_text_loss", False):
+                    single = pipe.text_encoder(**tokenize_prompts([request["dest"]], tok, device))[1]
+                    emb = torch.cat([single, neg_pool], dim=0)
+                    scores = torch.squeeze(-torch.cdist(edit_pool.unsqueeze(0), emb.unsqueeze(0)))
+                    loss = loss + scale * (-torch.log_softmax(scores, dim=1)[:, 0].mean(dim=0))
+                elif hp("align_object_token", False):
+                    loss = loss + scale * F.mse_loss(edit_repr[ar, src_lookup, :], dest_repr[ar, dst_lookup, :], reduction="mean")
+                elif hp("align_obj_eos_pad", False):
+                    e_full = te_edit(**src_full)[0]
+                    e_pad = torch.stack([e_full[i, sl, :] for i, sl in enumerate(src_slices)], dim=0)
+                    d_pad = torch.stack([dest_full[i, sl, :] for i, sl in enumerate(dst_slices)], dim=0)
+                    loss = loss + scale * F.mse_loss(torch.cat([edit_repr[ar, src_lookup, :].unsqueeze(1), e_pad], dim=1),
+                                                     torch.cat([dest_repr[ar, dst_lookup, :].unsqueeze(1), d_pad], dim=1),
+                                                     reduction="mean")
+                else:
+                    loss = loss + scale * F.mse_loss(edit_pool, dest_pool, reduction="mean")
+            loss.backward()
+            opt.step()
+            max_norm = hp("clamp_norm_factor") * source_init.norm()
+            if delta.norm() > max_norm:
+                with torch.no_grad():
+                    delta[...] = delta * max_norm / delta.norm()
+    finally:
+        handle.remove()
+    return (state["source_init"] + delta).detach()
 
 
 # --------------------------------------------------------------------------------------

@@ -57,9 +57,62 @@ def _install_stubs():
     d.models = mod("diffusers.models", UNet2DConditionModel=_Dummy)
     d.utils = mod("diffusers.utils")
     d.utils.logging = mod("diffusers.utils.logging", disable_progress_bar=lambda: None)
+    d.DDPMScheduler = syn.DDPMNoiseSchedule       # Stage 1 only calls from_pretrained(...), .config.num_train_timesteps, .add_noise
     tv = mod("torchvision")
-    tv.transforms = mod("torchvision.transforms", Compose=_Dummy, Resize=_Dummy, CenterCrop=_Dummy,
-                        RandomHorizontalFlip=_Dummy, ToTensor=_Dummy, Normalize=_Dummy,
+    # Stage 1's preprocess_img (compute_z.py:34-53) runs these on PIL images: stand-ins with torchvision's documented
+    # behaviour for PIL inputs (torchvision is not installed in this image)
+    from PIL import Image as _Image
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class Resize:
+        def __init__(self, size, interpolation=None):
+            self.size = size
+
+        def __call__(self, im):
+            w, h = im.size
+            if (w <= h and w == self.size) or (h <= w and h == self.size):
+                return im
+            if w < h:
+                return im.resize((self.size, int(self.size * h / w)), _Image.BILINEAR)
+            return im.resize((int(self.size * w / h), self.size), _Image.BILINEAR)
+
+    class CenterCrop:
+        def __init__(self, size):
+            self.size = size
+
+        def __call__(self, im):
+            w, h = im.size
+            left, top = int(round((w - self.size) / 2.0)), int(round((h - self.size) / 2.0))
+            return im.crop((left, top, left + self.size, top + self.size))
+
+    class RandomHorizontalFlip:
+        def __init__(self, p=0.5):
+            self.p = p
+
+        def __call__(self, im):
+            return im.transpose(_Image.FLIP_LEFT_RIGHT) if torch.rand(1) < self.p else im
+
+    class ToTensor:
+        def __call__(self, im):
+            return torch.from_numpy(np.asarray(im, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255.0)
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = mean[0], std[0]
+
+        def __call__(self, x):
+            return (x - self.mean) / self.std
+
+    tv.transforms = mod("torchvision.transforms", Compose=Compose, Resize=Resize, CenterCrop=CenterCrop,
+                        RandomHorizontalFlip=RandomHorizontalFlip, ToTensor=ToTensor, Normalize=Normalize,
                         InterpolationMode=types.SimpleNamespace(BILINEAR=0, BICUBIC=1))
     tv.datasets = mod("torchvision.datasets", ImageNet=_Dummy)
     tv.utils = mod("torchvision.utils", save_image=lambda *a, **k: None, make_grid=lambda *a, **k: None)
@@ -75,7 +128,8 @@ class _NullCudaDevice(contextlib.AbstractContextManager):
 
 def import_reference(scratch: Path):
     _install_stubs()
-    shutil.copy(REF / "globals.yml", scratch / "globals.yml")
+    # the scratch copy of globals.yml (configuration, read relative to the cwd at import) with small Stage-1 images
+    (scratch / "globals.yml").write_text((REF / "globals.yml").read_text().replace("RESOLUTION: 512", f"RESOLUTION: {STAGE1_RESOLUTION}"))
     (scratch / "data").mkdir(exist_ok=True)
     os.chdir(scratch)
     sys.path.insert(0, str(REF))
@@ -87,6 +141,80 @@ def import_reference(scratch: Path):
     from emcid.emcid_hparams import EMCIDHyperParams, EMCIDXLHyperParams
     from experiments.causal_trace import find_token_range
     return em, ls, cz, EMCIDHyperParams, EMCIDXLHyperParams, find_token_range
+
+
+STAGE1_RESOLUTION = 32
+
+
+class Layer427(torch.nn.Module):
+    """transformers-4.27 encoder layers return a TUPLE (hidden_states,); the reference's Stage-1 hook indexes it
+    (compute_z.py:353-373: cur_out[0][i, idx, :] += delta).  transformers 5.x layers return the tensor; this wrapper and
+    the encoder subclass below restore the 4.27 calling convention around the unchanged layer (no arithmetic)."""
+
+    def __init__(self, inner):
+        super().__init__()
+        self.inner = inner
+
+    def forward(self, *a, **k):
+        return (self.inner(*a, **k),)
+
+
+def as_transformers_427(te):
+    from transformers.models.clip.modeling_clip import CLIPEncoder
+    from transformers.modeling_outputs import BaseModelOutput
+
+    class CLIPEncoder427(CLIPEncoder):
+        def forward(self, inputs_embeds, attention_mask=None, **kwargs):
+            hidden = inputs_embeds
+            for layer in self.layers:
+                hidden = layer(hidden, attention_mask, **kwargs)[0]
+            return BaseModelOutput(last_hidden_state=hidden)
+
+    enc = te.encoder if hasattr(te, "encoder") else te.text_model.encoder
+    enc.layers = torch.nn.ModuleList([Layer427(l) for l in enc.layers])
+    enc.__class__ = CLIPEncoder427
+    return te
+
+
+STAGE1_CASES = {
+    # the shipped SD hparams' Stage-1 settings (hparams/dest_s-200_c-1.5_ly-7-11...json), fewer steps
+    "shipped": dict(hp=dict(objective="ablate-dest", cal_text_repr_loss=True, text_repr_loss_scale_factor=0.01, v_lr=0.2,
+                            v_weight_decay=5e-4, clamp_norm_factor=1.5, v_num_grad_steps=10), layer=3, seed=1234, req={}),
+    "ablate_source_object_token": dict(hp=dict(objective="ablate-source", cal_text_repr_loss=True, align_object_token=True,
+                                               text_repr_loss_scale_factor=0.05, v_lr=0.1, v_weight_decay=1e-3,
+                                               clamp_norm_factor=0.6, v_num_grad_steps=8, samples_per_prompt=2),
+                                       layer=2, seed=77, req={"use_real_noise": True}),
+    "eos_pad_replace": dict(hp=dict(objective="ablate-dest", cal_text_repr_loss=True, align_obj_eos_pad=True, replace_repr=True,
+                                    text_repr_loss_scale_factor=0.02, v_lr=0.05, v_weight_decay=5e-4, clamp_norm_factor=1.2,
+                                    v_num_grad_steps=6), layer=4, seed=5, req={}),
+}
+
+
+def golden_stage1(cz, EMCIDHyperParams, scratch, tag="toy_stage1"):
+    """Stage 1: the REAL reference's compute_z_text_encoder (compute_z.py:315-649) on the synthetic pipe with the UNet / VAE
+    stand-ins of emcid_amd/synthetic.py, the DDPM schedule stub and caller-supplied training images."""
+    out, meta = {}, {"cases": {}, "resolution": STAGE1_RESOLUTION}
+    for name, c in STAGE1_CASES.items():
+        pipe = syn.add_diffusion(syn.build_pipe("toy", "cpu"))
+        as_transformers_427(pipe.text_encoder)
+        hp_d = syn.sd_hparams_dict(layers=(1, 2, 3, 4), prefix="")
+        hp_d.update(c["hp"])
+        hp = EMCIDHyperParams(**hp_d)
+        spp = hp.samples_per_prompt
+        request = {"source": "tocife" if name != "shipped" else "c0042", "dest": "a realist artist",
+                   "prompts": list(syn.ARTIST_TEMPLATES), "seed_train": 2024}
+        request.update(c["req"])
+        imgs = syn.make_images(len(request["prompts"]) * spp, STAGE1_RESOLUTION, seed=31 + c["seed"])
+        torch.manual_seed(c["seed"])
+        with contextlib.redirect_stdout(io.StringIO()):
+            v = cz.compute_z_text_encoder(pipe, dict(request, images=imgs), hp, c["layer"], device="cpu")
+        out[f"{name}/v_star"] = v.detach().numpy()
+        out[f"{name}/images"] = np.stack([np.asarray(im) for im in imgs])
+        meta["cases"][name] = {"hparams": hp_d, "layer": c["layer"], "seed": c["seed"], "request": request}
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump(meta, f, indent=1)
+    print(f"[golden] {tag}: wrote {len(out)} arrays: " + ", ".join(f"{k}: |v*| {np.linalg.norm(out[k + '/v_star']):.4f}" for k in STAGE1_CASES))
 
 
 def state_np(model, prefix="w/"):
@@ -296,6 +424,34 @@ def golden_stage0_real(ls, scratch, tag="real_stage0_summary", n_captions=20000,
         json.dump({"kind": "sd-v1.4", "n_captions": n_captions, "captions": {"seed": 2}, "layer_names": names,
                    "sample_size": n_captions, "batch_tokens": 3 * 1024}, f, indent=1)
     print(f"[golden] {tag}: wrote {len(out)} arrays")
+
+
+def golden_toy_extras(cz, ls, scratch, tag="toy_extras"):
+    """Two reference behaviours no shipped hparams file exercises: get_module_input_output_at_words with
+    num_fact_token = 3 (compute_z.py:2329-2382) and layer_stats_text_encoder with precision = float64 (layer_stats.py:161,218)."""
+    from tqdm import tqdm
+    pipe = syn.build_pipe("toy", "cpu")
+    reqs = syn.make_requests(7, ragged=True)
+    mod = "encoder.layers.3.mlp.fc2"
+    out = {}
+    for k in (2, 3):
+        i, o = cz.get_module_input_output_at_words(pipe.text_encoder, pipe.tokenizer, reqs, mod, num_fact_token=k)
+        out[f"K{k}"], out[f"Z{k}"] = i.detach().numpy(), o.detach().numpy()
+    caps = syn.write_captions(scratch / "data" / "ccs_filtered.json", 300, seed=6)
+    ln = "encoder.layers.2.mlp.fc2"
+    stat = ls.layer_stats_text_encoder(pipe.text_encoder, pipe.tokenizer, ln, str(scratch / "stats64"), "ccs_filtered",
+                                       ["mom2"], sample_size=200, precision="float64", batch_tokens=600, progress=tqdm)
+    out["mom2_f64"] = stat.mom2.mom2.numpy()
+    out["count_f64"] = np.array(stat.mom2.count)
+    assert out["mom2_f64"].dtype == np.float64
+    f = syn.stats_file(scratch / "stats64", ln, 200, precision="float64", batch_tokens=600)
+    with np.load(f) as z:
+        assert z["mom2.mom2"].dtype == np.float64
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as fh:
+        json.dump({"kind": "toy", "requests": reqs, "module": mod, "captions": caps, "stats_layer": ln, "sample_size": 200,
+                   "batch_tokens": 600}, fh)
+    print(f"[golden] {tag}: wrote {len(out)} arrays; K3 {out['K3'].shape}")
 
 
 def golden_stage0(ls, scratch, tag="toy_stage0"):
@@ -567,6 +723,10 @@ def main():
                 golden_sdxl_real(em, XLHP, scratch)
             elif which == "real_stage0_summary":
                 golden_stage0_real(ls, scratch)
+            elif which == "toy_extras":
+                golden_toy_extras(cz, ls, scratch)
+            elif which == "toy_stage1":
+                golden_stage1(cz, HP, scratch)
             else:
                 raise SystemExit(f"unknown fixture {which}")
             return
@@ -578,6 +738,8 @@ def main():
         golden_xattn(em, HP, scratch)
         golden_cal_insert(em, HP, scratch)
         golden_instruction(em, HP, scratch)
+        golden_toy_extras(cz, ls, scratch)
+        golden_stage1(cz, HP, scratch)
         if "--skip-real" not in sys.argv:
             golden_sd(em, HP, scratch, "real_sd_summary", "sd-v1.4", n_req=24, layers=(7, 8, 9, 10), lam=4000,
                       ew=0.5, ragged=False, full=False)

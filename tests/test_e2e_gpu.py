@@ -637,3 +637,89 @@ def test_stage0_real_dims_matches_reference_summary(tmp_path):
         np.testing.assert_allclose(C.diagonal().numpy(), z[f"diag/{li}"], rtol=0, atol=5e-5 * z[f"diag/{li}"].max())
         ref = z[f"C_probe/{li}"]
         assert np.abs((C @ probe).numpy() - ref).max() <= 5e-5 * np.abs(ref).max(), li
+
+
+def test_fact_tokens_and_float64_statistics_match_reference_golden(tmp_path):
+    """num_fact_token > 1 (rows [last subject token, EOS, padding...], (N, k, d) / (N, k, h)) and fp64 statistics (the fp64
+    MFMA SYRK behind SecondMoment, npz in float64) on the HIP path against the reference's outputs (fixture toy_extras)."""
+    import json
+    from emcid_amd.compute_z import get_module_input_output_at_words
+    from emcid_amd.layer_stats import layer_stats_text_encoder, stats_filename
+    z, meta = load_golden("toy_extras")
+    pipe = syn.build_pipe(meta["kind"], DEV)
+    for k in (2, 3):
+        K, Z = get_module_input_output_at_words(pipe.text_encoder, pipe.tokenizer, meta["requests"], meta["module"], num_fact_token=k)
+        assert K.shape == z[f"K{k}"].shape and Z.shape == z[f"Z{k}"].shape
+        np.testing.assert_allclose(K.cpu().numpy(), z[f"K{k}"], rtol=0, atol=2e-5 * np.abs(z[f"K{k}"]).max())
+        np.testing.assert_allclose(Z.cpu().numpy(), z[f"Z{k}"], rtol=0, atol=2e-5 * np.abs(z[f"Z{k}"]).max())
+    data = tmp_path / "data" / "ccs_filtered.json"
+    data.parent.mkdir()
+    json.dump(meta["captions"], open(data, "w"))
+    for forward in ("auto", "hf"):
+        stats_dir = tmp_path / f"stats_{forward}"
+        from emcid_amd.layer_stats import layer_stats_text_encoder_multi
+        st = layer_stats_text_encoder_multi(pipe.text_encoder, pipe.tokenizer, [meta["stats_layer"]], stats_dir,
+                                            sample_size=meta["sample_size"], precision="float64",
+                                            batch_tokens=meta["batch_tokens"], data_path=str(data), progress=None,
+                                            num_workers=0, forward=forward)[meta["stats_layer"]]
+        assert st.mom2.count == int(z["count_f64"]) and st.mom2.mom2.dtype == torch.float64
+        ref = z["mom2_f64"]
+        # fp64 sums of fp32 features computed on another device: the forward's fp32 rounding is what remains
+        assert np.abs(st.mom2.mom2.numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+        f = stats_filename(stats_dir, "text_encoder", "ccs_filtered", meta["stats_layer"], "float64", ["mom2"],
+                           meta["batch_tokens"], meta["sample_size"])
+        with np.load(f) as npz:
+            assert npz["mom2.mom2"].dtype == np.float64 and int(npz["mom2.count"]) == st.mom2.count
+
+
+@pytest.mark.parametrize("name", ["shipped", "ablate_source_object_token", "eos_pad_replace"])
+def test_stage1_on_gpu_matches_reference_golden(name):
+    """Stage 1 on the MI355X (PyTorch-ROCm autograd through the UNet stand-in) with the random draws taken from the host
+    generator in the reference's order: the REAL reference's v* (minted on CPU) to fp32 rounding."""
+    from PIL import Image
+    from emcid_amd.compute_z import compute_z_text_encoder
+    z, meta = load_golden("toy_stage1")
+    c = meta["cases"][name]
+    pipe = syn.add_diffusion(syn.build_pipe("toy", DEV))
+    imgs = [Image.fromarray(a, "RGB") for a in z[f"{name}/images"]]
+    torch.manual_seed(c["seed"])
+    v = compute_z_text_encoder(pipe, dict(c["request"], images=imgs), EMCIDHyperParams(**c["hparams"]), c["layer"],
+                               noise_scheduler=syn.DDPMNoiseSchedule(), resolution=meta["resolution"], rng_device="cpu")
+    ref = z[f"{name}/v_star"]
+    assert v.is_cuda and np.abs(v.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
+def test_vstar_cache_miss_runs_stage1_then_edits(tmp_path):
+    """A v* cache miss on a pipeline that carries a UNet and a VAE runs Stage 1 and writes the npz (reference
+    emcid_main.py:905-969); the edit that follows equals an edit from that cache."""
+    reqs = [dict(r, images=syn.make_images(len(r["prompts"]), 32, seed=40 + i)) for i, r in enumerate(syn.make_requests(3))]
+    hp_d = syn.sd_hparams_dict(layers=(1, 2, 3), mom2_update_weight=50, edit_weight=0.5, mom2_n_samples=1000)
+    hp_d.update(v_num_grad_steps=4, cal_text_repr_loss=True)
+    names = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers"]]
+    syn.write_stats_cache(tmp_path / "stats", names, 128, 1000, seed=2, t=512)
+    cache = str(tmp_path / "cache") + "/"
+    import emcid_amd.compute_z as cz
+    real = cz.compute_z_text_encoder
+    calls = []
+
+    def small(pipe, request, hparams, layer, **kw):
+        calls.append(request["source"])
+        return real(pipe, request, hparams, layer, noise_scheduler=syn.DDPMNoiseSchedule(), resolution=32, **kw)
+
+    cz.compute_z_text_encoder = small
+    try:
+        pipe = syn.add_diffusion(syn.build_pipe("toy", DEV))
+        torch.manual_seed(3)
+        em.apply_emcid_to_text_encoder(pipe, reqs, EMCIDHyperParams(**hp_d), DEV, cache_name=cache,
+                                       stats_dir=str(tmp_path / "stats"), verbose=False)
+    finally:
+        cz.compute_z_text_encoder = real
+    assert calls == [r["source"] for r in reqs]
+    files = sorted((tmp_path / "cache").glob("*.npz"))
+    assert len(files) == 3 and np.load(files[0])["v_star"].shape == (32,)
+    w1 = {n: get_parameter(pipe.text_encoder, n + ".weight").cpu().clone() for n in names}
+    pipe2 = syn.add_diffusion(syn.build_pipe("toy", DEV))
+    em.apply_emcid_to_text_encoder(pipe2, reqs, EMCIDHyperParams(**hp_d), DEV, cache_name=cache,
+                                   stats_dir=str(tmp_path / "stats"), verbose=False, stage1=lambda *a: 1 / 0)   # served from the cache
+    for n in names:
+        assert torch.equal(get_parameter(pipe2.text_encoder, n + ".weight").cpu(), w1[n])

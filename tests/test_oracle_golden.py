@@ -9,6 +9,7 @@ import torch
 
 from conftest import GOLDEN, load_golden, pipe_from_golden, write_cov_npz, write_vstars, xattn_from_golden
 from emcid_amd import synthetic as syn
+from emcid_amd.emcid_hparams import EMCIDHyperParams
 from oracle import emcid_oracle as orc
 
 
@@ -117,6 +118,51 @@ def test_real_dims_summary(tmp_path):
         ref = z[f"dw_probe/{li}"]
         np.testing.assert_allclose((dw @ probe).numpy(), ref, rtol=0, atol=1e-6 * np.abs(ref).max())
         np.testing.assert_allclose(dw.norm().item(), float(z[f"dw_fro/{li}"]), rtol=1e-6)
+
+
+def test_fact_tokens_and_float64_statistics_match_reference():
+    """Two reference behaviours outside the shipped hparams: num_fact_token > 1 (compute_z.py:2329-2382) and
+    --precision float64 statistics (layer_stats.py:161, :218) — the oracle's restatements against the reference's outputs."""
+    z, meta = load_golden("toy_extras")
+    pipe = syn.build_pipe(meta["kind"], "cpu")
+    for k in (2, 3):
+        K, Z = orc.module_input_output_at_words_multi(pipe.text_encoder, pipe.tokenizer, meta["requests"], meta["module"], k)
+        assert K.shape == z[f"K{k}"].shape == (len(meta["requests"]), k, 128)
+        np.testing.assert_array_equal(K.numpy(), z[f"K{k}"])
+        np.testing.assert_array_equal(Z.numpy(), z[f"Z{k}"])
+    caps = [c["caption"] for c in meta["captions"]]
+    stat = orc.layer_stats_text_encoder(pipe.text_encoder, pipe.tokenizer, meta["stats_layer"], caps, meta["sample_size"],
+                                        batch_tokens=meta["batch_tokens"], precision="float64")
+    assert stat.count == int(z["count_f64"]) and stat.mom2.dtype == torch.float64
+    np.testing.assert_array_equal(stat.mom2.numpy(), z["mom2_f64"])
+
+
+def _stage1_case(z, meta, name, device="cpu"):
+    from PIL import Image
+    c = meta["cases"][name]
+    pipe = syn.add_diffusion(syn.build_pipe("toy", device))
+    imgs = [Image.fromarray(a, "RGB") for a in z[f"{name}/images"]]
+    return c, pipe, dict(c["request"], images=imgs)
+
+
+@pytest.mark.parametrize("name", ["shipped", "ablate_source_object_token", "eos_pad_replace"])
+def test_stage1_v_star_matches_reference(name):
+    """Stage 1 (compute_z_text_encoder, compute_z.py:315-649): the oracle's op-for-op restatement reproduces the REAL
+    reference's v* bit for bit (fixture toy_stage1: UNet / VAE stand-ins, DDPM schedule, caller-supplied images); the
+    product's restructured loop (hooked in place, invariant forwards hoisted) agrees to fp32 rounding on the same device."""
+    from emcid_amd.compute_z import compute_z_text_encoder
+    z, meta = load_golden("toy_stage1")
+    ref = z[f"{name}/v_star"]
+    c, pipe, request = _stage1_case(z, meta, name)
+    torch.manual_seed(c["seed"])
+    v = orc.compute_z_text_encoder(pipe, request, c["hparams"], c["layer"], syn.DDPMNoiseSchedule(), meta["resolution"])
+    np.testing.assert_array_equal(v.numpy(), ref)
+    c, pipe, request = _stage1_case(z, meta, name)
+    torch.manual_seed(c["seed"])
+    v = compute_z_text_encoder(pipe, request, EMCIDHyperParams(**c["hparams"]), c["layer"],
+                               noise_scheduler=syn.DDPMNoiseSchedule(), resolution=meta["resolution"])
+    assert np.abs(v.numpy() - ref).max() <= 2e-6 * np.abs(ref).max()
+    assert all(p.requires_grad is False for p in pipe.text_encoder.parameters())      # synthetic encoders are frozen: left as found
 
 
 def test_headline_workload_keys_at_first_edited_layer():
