@@ -343,10 +343,9 @@ def main():
         "config": {"workload": f"{args.concepts}-concept edit, SD-v1.4 text-encoder dims (768/3072/12L), layers 7-10, "
                                f"lambda 4000, 3 prompts/concept; one step = one apply_emcid_to_text_encoder call, timer "
                                f"around the call (v* npz on disk, C_l in the covariance cache, model in HBM)",
-                   "concepts": args.concepts, "prompts_per_rank": plan.batch.n_prompts,
-                   "seq_len": int(plan.batch.inputs["input_ids"].shape[1]),
-                   "forward": ("prefix-trie: %d unique rows of %d tokens" % (plan.trie.n_nodes, plan.trie.n_tokens_dense))
-                   if plan.trie is not None else "hooked HF forward",
+                   "concepts": args.concepts, "prompts_per_rank": plan.n_prompts,
+                   "forward": ("prefix-trie: %d unique rows of %d tokens in %d slice(s)" % (*plan.trie_rows, len(plan.chunks)))
+                   if plan.chunks is not None else "hooked HF forward",
                    "caches": {"covariance_in_hbm": True, "cov_factor_cache": "warm" if plan.factors_from_cache else "off",
                               "vstar_files": "in-process copy validated by (path, mtime, size) per call",
                               "gemm_selection": "TunableOp table built in the first call"},

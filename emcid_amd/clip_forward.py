@@ -419,32 +419,70 @@ def run_layers(graph: ClipTextGraph, trie: TokenTrie, upto: int, on_fc2=None, la
     """Layers 0..upto (inclusive).  ``on_fc2(i, x, out) -> out'`` is called with the fc2 input/output of every layer
     (rows = all nodes, or the query rows at layer ``upto`` when ``last_rows_only``); whatever it returns is used
     as fc2's output.  Returns the residual stream after layer ``upto`` (query rows only if ``last_rows_only``)."""
+    cb = None
+    if on_fc2 is not None:
+        def cb(i, xs, outs):
+            out = on_fc2(i, xs[0], outs[0])
+            return None if out is None else [out]
+    res = run_layers_multi(graph, [trie], None, 0, upto, cb, last_rows_only, fc2_by_callback)
+    return None if res is None else res[0][0]
+
+
+def run_prefix(graph: ClipTextGraph, trie: TokenTrie, stop: int):
+    """Layers 0..stop-1 on every node: the state (residual stream, LN1 of it or None) that enters layer ``stop``."""
     _check_fp32(graph)
     with tuned_gemms():
-        return _run_layers(graph, trie, upto, on_fc2, last_rows_only, set(fc2_by_callback))
+        hs, x_ln1 = embed(graph, trie), None
+        for i in range(stop):
+            hs, x_ln1 = _layer_full(graph, i, trie, hs, x_ln1, stop)
+    return hs, x_ln1
 
 
-def _run_layers(graph, trie, upto, on_fc2, last_rows_only, fc2_by_callback=frozenset()):
-    hs = embed(graph, trie)
-    x_ln1 = None
-    for i in range(upto + 1):
-        layer = graph.layers[i]
-        rows = trie.query_rows if (last_rows_only and i == upto) else None
-        mid, ln2_mid = layer_attention_block(layer, hs, trie, rows, x_ln1)
-        x = mlp_hidden(layer, ln2_mid)
-        # layers in ``fc2_by_callback``: the callback produces fc2's output itself (out is passed as None), so an
-        # edited layer's projection is computed once, with the new weight, instead of twice
-        out = None if i in fc2_by_callback else layer.fc2(x)
-        if on_fc2 is not None:
-            out = on_fc2(i, x, out)
-            if out is None:
-                return None
-        nxt = graph.layers[i + 1].ln1 if i < upto else None
-        if nxt is not None and _fusable(nxt):
-            hs, x_ln1 = hip.add_layernorm(mid, out, nxt)     # residual add + the next layer's LN1 in one pass
-        else:
-            hs, x_ln1 = mid + out, None
-    return hs
+def _layer_full(graph, i, trie, hs, x_ln1, n_layers_needed):
+    layer = graph.layers[i]
+    mid, ln2_mid = layer_attention_block(layer, hs, trie, None, x_ln1)
+    out = layer.fc2(mlp_hidden(layer, ln2_mid))
+    nxt = graph.layers[i + 1].ln1 if i + 1 < len(graph.layers) and i + 1 <= n_layers_needed else None
+    if nxt is not None and _fusable(nxt):
+        return hip.add_layernorm(mid, out, nxt)          # residual add + the next layer's LN1 in one pass
+    return mid + out, None
+
+
+def run_layers_multi(graph: ClipTextGraph, tries: Sequence[TokenTrie], states, start: int, upto: int, on_fc2=None,
+                     last_rows_only: bool = True, fc2_by_callback=()):
+    """Layers start..upto (inclusive) for several tries at once, layer by layer: the prompt list of an edit may arrive in
+    slices (compute_z.iter_prompt_chunks), each with its own trie; rows of different slices never attend to each other,
+    but an edited layer's solve needs the keys of all of them before any slice can go on.  ``states[c]``: (residual
+    stream, LN1 of it | None) of slice c entering layer ``start`` (None: start from the embeddings, start == 0).
+    ``on_fc2(i, xs, outs) -> outs'``: lists over the slices.  Returns the list of final states, or None if the callback
+    ended the pass."""
+    _check_fp32(graph)
+    by_cb = set(fc2_by_callback)
+    with tuned_gemms():
+        if states is None:
+            states = [(embed(graph, t), None) for t in tries]
+        states = list(states)
+        for i in range(start, upto + 1):
+            layer = graph.layers[i]
+            xs, mids = [], []
+            for trie, (hs, x_ln1) in zip(tries, states):
+                rows = trie.query_rows if (last_rows_only and i == upto) else None
+                mid, ln2_mid = layer_attention_block(layer, hs, trie, rows, x_ln1)
+                xs.append(mlp_hidden(layer, ln2_mid))
+                mids.append(mid)
+            # layers in ``fc2_by_callback``: the callback produces fc2's output itself (out is passed as None), so an
+            # edited layer's projection is computed once, with the new weight, instead of twice
+            outs = [None if i in by_cb else layer.fc2(x) for x in xs]
+            if on_fc2 is not None:
+                outs = on_fc2(i, xs, outs)
+                if outs is None:
+                    return None
+            nxt = graph.layers[i + 1].ln1 if i < upto else None
+            if nxt is not None and _fusable(nxt):
+                states = [hip.add_layernorm(mid, out, nxt) for mid, out in zip(mids, outs)]
+            else:
+                states = [(mid + out, None) for mid, out in zip(mids, outs)]
+    return states
 
 
 def last_hidden_at_lookup(graph: ClipTextGraph, trie: TokenTrie) -> torch.Tensor:

@@ -35,12 +35,12 @@ def tokenize_prompts(prompts, tokenizer, device, padding_length=None):
     return {k: v.to(device) for k, v in enc.items()}
 
 
-def expand_request_prompts(requests: Sequence[Dict]) -> Tuple[List[str], List[str], List[int]]:
+def expand_request_prompts(requests: Sequence[Dict], first: Optional[Dict] = None) -> Tuple[List[str], List[str], List[int]]:
     """Flattened prompt strings, the subject of each, and prompts-per-request.
     ``source_prompts`` (pre-formatted) wins over ``prompts`` when the FIRST request carries it, and the
     per-request count is taken from ``prompts`` when the first request has that key — both as the reference
-    does (compute_z.py:2270-2283, :2318-2320)."""
-    first = requests[0]
+    does (compute_z.py:2270-2283, :2318-2320).  ``first``: the first request of the WHOLE list when ``requests`` is a slice."""
+    first = requests[0] if first is None else first
     use_pre = "source_prompts" in first
     count_key = "prompts" if "prompts" in first else "source_prompts"
     prompts, subjects, counts = [], [], []
@@ -135,6 +135,38 @@ def build_prompt_batch(tokenizer, requests: Sequence[Dict], device, finder: Opti
         lookup=torch.from_numpy(lk).to(device),
         seg=torch.from_numpy(seg.astype(np.int64)).to(device),
         n_requests=len(requests), lookup_host=lookup, ids_host=enc["input_ids"])
+
+
+@dataclass
+class PromptChunk:
+    """Host-side tokenization of a contiguous slice of the request list (prompts truncated behind the last lookup token)."""
+    ids: np.ndarray          # (B_c, S_c) int64
+    lookup: List[int]        # position of the last subject token per prompt
+    counts: List[int]        # prompts per request
+    n_requests: int
+
+
+def iter_prompt_chunks(tokenizer, requests: Sequence[Dict], n_chunks: int):
+    """The request list in ``n_chunks`` contiguous slices, each tokenized, searched and truncated on its own, lazily: the
+    caller builds a slice's prefix trie and launches its share of the encoder forward before asking for the next slice,
+    so the GPU works on slice i while the host tokenizes slice i+1 (no helper thread: the launches are asynchronous)."""
+    n = len(requests)
+    n_chunks = max(1, min(n_chunks, n))
+    first = requests[0]
+    finder = finder_for(tokenizer)
+    for i in range(n_chunks):
+        lo, hi = (n * i) // n_chunks, (n * (i + 1)) // n_chunks
+        prompts, subjects, counts = expand_request_prompts(requests[lo:hi], first)
+        ids = tokenize_lists(tokenizer, prompts)["input_ids"]
+        lookup = [r[-1] - 1 for r in finder.batch(ids, subjects)]
+        lk = np.asarray(lookup, dtype=np.int64)
+        bad = np.nonzero((lk < 0) | (lk >= ids.shape[1]))[0]
+        if bad.size:
+            j = int(bad[0])
+            raise ValueError(f"lookup index {lookup[j]} outside the padded prompt (S={ids.shape[1]}) for prompt {prompts[j]!r}")
+        if sum(counts) != len(prompts):
+            raise ValueError(f"request prompt counts ({sum(counts)}) do not cover the {len(prompts)} prompts")
+        yield PromptChunk(np.ascontiguousarray(ids[:, :int(lk.max()) + 1]), lookup, counts, hi - lo)
 
 
 def gather_request_means(act: torch.Tensor, batch: PromptBatch) -> torch.Tensor:

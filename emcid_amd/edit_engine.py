@@ -26,13 +26,14 @@ from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
 
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
 from . import hip
 from . import clip_forward
 from .clip_attention import hip_attention
-from .compute_z import PromptBatch, build_prompt_batch, gather_request_means
+from .compute_z import PromptBatch, build_prompt_batch, gather_request_means, iter_prompt_chunks
 from .nethook import StopForward, get_module, get_parameter
 
 
@@ -60,6 +61,17 @@ class LayerEdit:
 
 
 @dataclass
+class TrieChunk:
+    """One slice of this rank's requests on the prefix-trie forward: its trie, its request -> prompt offsets and, when
+    prepare already ran the unedited leading layers for it, the state that enters the first edited layer."""
+    trie: clip_forward.TokenTrie
+    seg: torch.Tensor                      # (n_requests + 1,) int64 prompt offsets
+    n_requests: int
+    n_prompts: int
+    state: Optional[tuple] = None          # (layer index, residual stream, LN1 of it | None)
+
+
+@dataclass
 class EncoderEditPlan:
     """Everything one encoder's Stage-2 pass needs, resident in HBM."""
     text_encoder: torch.nn.Module
@@ -67,7 +79,7 @@ class EncoderEditPlan:
     rewrite_module_tmp: str
     lam: float
     edit_weight: float
-    batch: PromptBatch                     # this rank's prompts
+    batch: Optional[PromptBatch]           # this rank's prompts as one padded batch (hooked-HF forward; built on demand)
     zs_t: torch.Tensor                     # (N, h) fp32: v* of ALL requests, row per request
     covs: Dict[int, torch.Tensor]          # layer -> (d, d) fp32 second moment C
     n_total: int                           # N over all ranks
@@ -78,7 +90,10 @@ class EncoderEditPlan:
     side_stream: Optional[torch.cuda.Stream] = None
     solver: str = "auto"                                 # "direct" | "dual" | "auto" (dual when N is well below d)
     graph: Optional[clip_forward.ClipTextGraph] = None   # set -> prefix-deduplicated forward (clip_forward.py)
-    trie: Optional[clip_forward.TokenTrie] = None
+    chunks: Optional[List[TrieChunk]] = None             # the slices of the trie forward (None: hooked-HF forward)
+    tokenizer: object = None
+    local_requests: Optional[List[Dict]] = None
+    zs_pending: object = None
     gemm_tuning_s: float = 0.0           # one-off TunableOp time spent in prepare (first plan with these GEMM shapes)
     backups: Optional[Dict[int, torch.Tensor]] = None    # W0 of the edited layers of the last run (failure recovery)
     factor_key: Optional[tuple] = None   # set by a run that factored lam*C' itself: check_info caches the factors if sound
@@ -86,6 +101,48 @@ class EncoderEditPlan:
 
     def weight_name(self, layer):
         return f"{self.rewrite_module_tmp.format(layer)}.weight"
+
+    @property
+    def trie(self):                        # the (first) trie of the prefix-deduplicated forward, None on the hooked-HF path
+        return self.chunks[0].trie if self.chunks and self.graph is not None else None
+
+    @trie.setter
+    def trie(self, value):                 # ``plan.graph = plan.trie = None`` switches a plan to the hooked-HF forward
+        if value is not None:
+            raise AttributeError("assign plan.chunks instead")
+        self.chunks = None
+
+    @property
+    def n_prompts(self) -> int:
+        return sum(c.n_prompts for c in self.chunks) if self.chunks else self.ensure_batch().n_prompts
+
+    @property
+    def trie_rows(self):
+        return (sum(c.trie.n_nodes for c in self.chunks), sum(c.trie.n_tokens_dense for c in self.chunks)) if self.chunks else None
+
+    def resolve_targets(self) -> torch.Tensor:
+        """(N, h) fp32 v* rows in HBM.  When prepare was handed the reader thread's future, this is where it is joined:
+        at the first solve, i.e. after the forward up to the first edited layer has been launched."""
+        if self.zs_pending is not None:
+            with phase("vstar join + h2d"):
+                zs = self.zs_pending.result() if hasattr(self.zs_pending, "result") else self.zs_pending
+                dev = next(self.text_encoder.parameters()).device
+                if dev.type == "cuda" and not zs.is_cuda:
+                    # through a page-locked staging buffer, asynchronously: a pageable copy would make the host wait for
+                    # everything already queued on the stream (the encoder forward this call is meant to run underneath)
+                    zs = _pinned_like(zs.to(torch.float32)).to(dev, non_blocking=True)
+                else:
+                    zs = zs.to(device=dev, dtype=torch.float32).contiguous()
+                if zs.shape[0] != self.n_total:
+                    raise ValueError(f"v* stack has {zs.shape[0]} rows for {self.n_total} requests")
+                self.zs_t, self.zs_pending = zs, None
+        return self.zs_t
+
+    def ensure_batch(self) -> PromptBatch:
+        if self.batch is None:
+            dev = next(self.text_encoder.parameters()).device
+            self.batch = build_prompt_batch(self.tokenizer, self.local_requests, dev)
+        return self.batch
 
 
 # ---- state kept across calls (all guarded by ENGINE_LOCK: the engine serialises edits per process) ------------------
@@ -110,6 +167,22 @@ def _workspace(kind: str, N: int, d: int, h: int, dev):
     else:
         _WS_CACHE.move_to_end(key)
     return ws
+
+
+_PINNED: Dict[tuple, torch.Tensor] = {}
+
+
+def _pinned_like(t: torch.Tensor) -> torch.Tensor:
+    """``t`` copied into a cached page-locked buffer of its shape (reused by later calls: every edit ends with a host
+    synchronisation, so the previous asynchronous copy out of the buffer has completed)."""
+    key = (tuple(t.shape), t.dtype)
+    buf = _PINNED.get(key)
+    if buf is None:
+        if len(_PINNED) > 8:
+            _PINNED.clear()
+        buf = _PINNED[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    buf.copy_(t)
+    return buf
 
 
 def factor_cache_key(covs: Sequence[torch.Tensor], lam: float, edit_weight: float) -> tuple:
@@ -171,33 +244,57 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
     lo, hi = shard.bounds(len(requests))
     if len(requests) < shard.world:     # the same verdict on every rank, before any collective can be entered
         raise ValueError(f"{len(requests)} request(s) cannot be sharded over {shard.world} ranks (every rank needs one)")
-    with phase("tokenize+lookup"):
-        batch = build_prompt_batch(tokenizer, list(requests[lo:hi]), device)
-    with phase("h2d"):
-        if hasattr(zs_t, "result"):         # a concurrent.futures.Future from the caller's reader thread
-            zs_t = zs_t.result()
-        zs_t = zs_t.to(device=device, dtype=torch.float32).contiguous()
-        if zs_t.shape[0] != len(requests):
-            raise ValueError(f"v* stack has {zs_t.shape[0]} rows for {len(requests)} requests")
-        covs = {l: c.to(device=device, dtype=torch.float32).contiguous() for l, c in covs.items()}
-    plan = EncoderEditPlan(text_encoder, list(layers), rewrite_module_tmp, float(lam), float(edit_weight), batch,
-                           zs_t, covs, len(requests), shard)
+    local = list(requests[lo:hi])
     mode = forward_mode or FORWARD_MODE
+    graph = None
     if mode == "trie" and layer_module_tmp is not None and device.type == "cuda":
         try:
             with phase("graph"):
                 graph = clip_forward.discover_cached(text_encoder, layer_module_tmp)
-                for l in plan.layers:   # the edited weights must be the very tensors the explicit forward multiplies with
-                    if graph.layers[l].fc2.weight is not get_parameter(text_encoder, plan.weight_name(l)):
+                for l in layers:   # the edited weights must be the very tensors the explicit forward multiplies with
+                    if graph.layers[l].fc2.weight is not get_parameter(text_encoder, f"{rewrite_module_tmp.format(l)}.weight"):
                         raise clip_forward.UnsupportedEncoder("rewrite_module_tmp is not the layer's mlp.fc2")
-            with phase("trie"):
-                plan.trie = clip_forward.build_trie(batch.ids_host, batch.lookup_host, device)
-            plan.graph = graph
-            with phase("gemm_tuning"):
-                plan.gemm_tuning_s = clip_forward.tune_projections(graph, plan.trie, max(plan.layers),
-                                                                   os.environ.get("EMCID_TUNE_GEMM", "auto"))
+                if sorted(layers) != list(layers):
+                    raise clip_forward.UnsupportedEncoder("layers not in forward order")
         except (clip_forward.UnsupportedEncoder, IndexError, LookupError):
-            plan.graph = plan.trie = None
+            graph = None
+    plan = EncoderEditPlan(text_encoder, list(layers), rewrite_module_tmp, float(lam), float(edit_weight), None,
+                           None, covs, len(requests), shard, tokenizer=tokenizer, local_requests=local)
+    if graph is not None:
+        # As soon as the prompts are tokenized their prefix trie is built and the unedited leading layers are LAUNCHED here,
+        # so the GPU runs them underneath the rest of the host preparation (v* reads, statistics lookups).  The prompt list
+        # can also be cut into EMCID_PREP_CHUNKS slices, each launched before the next is tokenized; measured on 2 x EPYC
+        # 9575F (scripts/host_profile.py, configurations interleaved) every extra tokenizer call costs 3-4 ms of fixed
+        # overhead (waking the backend's thread pool), more than the 2.9 ms of GPU time a second slice hides: default 1.
+        n_chunks = int(os.environ.get("EMCID_PREP_CHUNKS", "0")) or 1
+        first_edit = plan.layers[0]
+        chunks: List[TrieChunk] = []
+        tune_mode = os.environ.get("EMCID_TUNE_GEMM", "auto")
+        try:
+            it = iter_prompt_chunks(tokenizer, local, n_chunks)
+            while True:
+                with phase("tokenize+lookup"):
+                    pc = next(it, None)
+                if pc is None:
+                    break
+                with phase("trie"):
+                    trie = clip_forward.build_trie(pc.ids, pc.lookup, device)
+                    seg = torch.from_numpy(np.cumsum([0] + pc.counts).astype(np.int64)).to(device)
+                with phase("gemm_tuning"):
+                    plan.gemm_tuning_s += clip_forward.tune_projections(graph, trie, max(plan.layers), tune_mode)
+                with phase("prefix launches"), torch.no_grad():
+                    hs, x_ln1 = clip_forward.run_prefix(graph, trie, first_edit)
+                chunks.append(TrieChunk(trie, seg, pc.n_requests, len(pc.lookup), (first_edit, hs, x_ln1)))
+            plan.graph, plan.chunks = graph, chunks
+        except (clip_forward.UnsupportedEncoder, IndexError):
+            plan.graph = plan.chunks = None
+    if plan.chunks is None:
+        with phase("tokenize+lookup"):
+            plan.ensure_batch()
+    plan.covs = {l: c.to(device=device, dtype=torch.float32).contiguous() for l, c in covs.items()}
+    plan.zs_pending = zs_t          # a tensor, or the caller's reader-thread future: resolved where the first solve needs it
+    if not hasattr(zs_t, "result"):
+        plan.resolve_targets()
     return plan
 
 
@@ -336,6 +433,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
         a callable K -> Zc (fc2 applied to the gathered keys): then only K crosses the links."""
         K = _all_gather_rows(K_local, plan)
         Zc = Zc_local(K) if callable(Zc_local) else _all_gather_rows(Zc_local, plan)
+        plan.resolve_targets()
         if dual:
             if fac_done is not None:
                 torch.cuda.current_stream(dev).wait_event(fac_done[i])
@@ -408,40 +506,52 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
         edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], res["Xt"], res["Rt"],
                                K if trace else None, Zc if trace else None))
 
-    if plan.trie is not None:
-        trie, order = plan.trie, {l: i for i, l in enumerate(plan.layers)}
+    if plan.chunks is not None and plan.graph is not None:
+        chunks, order = plan.chunks, {l: i for i, l in enumerate(plan.layers)}
         if sorted(plan.layers) != plan.layers:
             raise RuntimeError("hparams.layers must be in forward order")
-        B = trie.lookup_node.numel()
+        first_edit = plan.layers[0]
 
-        def rows_at(x, idx):   # (rows, c) activations -> per-request means at each prompt's lookup row
-            return hip.gather_mean(x.unsqueeze(0).expand(B, -1, -1), idx, plan.batch.seg)
+        def rows_at(x, idx, ch):   # (rows, c) activations -> per-request means at each prompt's lookup row
+            return hip.gather_mean(x.unsqueeze(0).expand(idx.numel(), -1, -1), idx, ch.seg)
+
+        def keys(li, xs):          # this rank's (N_local, d) key rows, slices concatenated in request order
+            parts = [rows_at(x, ch.trie.lookup_in_query if li == last else ch.trie.lookup_node, ch) for x, ch in zip(xs, chunks)]
+            return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
 
         zc_from_keys = os.environ.get("EMCID_ZC_FROM_KEYS", "1") != "0"      # 0: fc2 over every node + gather (A/B switch)
 
-        def on_fc2(li, x, out):
+        def on_fc2(li, xs, outs):
             if li not in order:
-                return out
-            idx = trie.lookup_in_query if li == last else trie.lookup_node
+                return outs
             m = mods[li]
-            K_loc = rows_at(x, idx)
+            K_loc = keys(li, xs)
             if not zc_from_keys:
-                solve(order[li], li, K_loc, rows_at(F.linear(x, m.weight, m.bias), idx))
-                return None if li == last else F.linear(x, m.weight, m.bias)
+                solve(order[li], li, K_loc, keys(li, [F.linear(x, m.weight, m.bias) for x in xs]))
+                return None if li == last else [F.linear(x, m.weight, m.bias) for x in xs]
             # fc2 is affine, so the mean over a request's prompts of its output at the lookup rows IS fc2 of the mean
             # key: Zc = K W^T + b on N rows (to fp32 rounding) instead of fc2 over every node followed by a gather
             solve(order[li], li, K_loc, lambda K_all: F.linear(K_all, m.weight, m.bias))
             if li == last:
                 return None
-            return F.linear(x, m.weight, m.bias)
+            return [F.linear(x, m.weight, m.bias) for x in xs]
 
         with torch.no_grad():
-            clip_forward.run_layers(plan.graph, trie, last, on_fc2, fc2_by_callback=order)
+            # the unedited leading layers: already launched by prepare (underneath the host's tokenization), else here
+            states = []
+            for ch in chunks:
+                if ch.state is not None and ch.state[0] == first_edit:
+                    states.append((ch.state[1], ch.state[2]))
+                else:
+                    states.append(clip_forward.run_prefix(plan.graph, ch.trie, first_edit))
+                ch.state = None         # single use: the residual stream below belongs to the weights of this very call
+            clip_forward.run_layers_multi(plan.graph, [ch.trie for ch in chunks], states, first_edit, last, on_fc2,
+                                          fc2_by_callback=order)
     else:
         def make_hook(i, layer):
             def hook(mod, inputs, output):
                 x = inputs[0]
-                solve(i, layer, gather_request_means(x, plan.batch), gather_request_means(output, plan.batch))
+                solve(i, layer, gather_request_means(x, plan.ensure_batch()), gather_request_means(output, plan.ensure_batch()))
                 if layer == last:
                     raise StopForward()
                 return F.linear(x, mod.weight, mod.bias)
@@ -452,7 +562,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
         try:
             with torch.no_grad(), hip_attention(te):
                 try:
-                    te(**plan.batch.inputs)
+                    te(**plan.ensure_batch().inputs)
                 except StopForward:
                     pass
         finally:

@@ -205,44 +205,22 @@ def _shard_from_env(shard: Optional[ConceptShard]) -> ConceptShard:
     return ConceptShard()
 
 
-_IO_POOL = None
+class _LazyVstars:
+    """The v* rows of a request list, read when first asked for.  prepare hands this to the engine, which asks at the first
+    edited layer's solve — by then the encoder forward up to that layer is queued on the GPU, so the file-system calls of
+    the cache reads (and Stage 1 on a miss) cost no wall-clock of their own."""
 
-
-def _io_pool():
-    global _IO_POOL
-    if _IO_POOL is None:
-        from concurrent.futures import ThreadPoolExecutor
-        _IO_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="emcid-io")
-    return _IO_POOL
-
-
-class _VstarFuture:
-    """Result of the reader thread; if a cache file was missing and the caller has a Stage-1 function, the load is
-    repeated on the calling thread with it (files that were found stay in the in-process copy)."""
-
-    def __init__(self, fut, args):
-        self.fut, self.args = fut, args
+    def __init__(self, *args):
+        self.args = args
 
     def result(self):
-        try:
-            return self.fut.result()
-        except NotImplementedError:
-            if self.args[-1] is None:
-                raise
-            return load_v_stars(*self.args)
+        return load_v_stars(*self.args)
 
 
 def prepare_text_encoder_edit(text_encoder, tokenizer, requests, hparams, layers, lam, stat_dir, cache_name,
                               suffix="", verbose=True, shard=None, stage1=None) -> EncoderEditPlan:
     """Host side of one encoder's edit: v* rows, C per layer (HBM-resident), tokenized prompts + lookup."""
-    # the v* cache reads are file-system calls (they release the GIL): they run on a helper thread underneath the
-    # tokenizer, which is native code that releases it too.  A cache miss is served afterwards on this thread (Stage 1).
-    if cache_name is not None and len(requests) >= 64:
-        zs_future = _VstarFuture(_io_pool().submit(load_v_stars, requests, hparams, cache_name, suffix, None),
-                                 (requests, hparams, cache_name, suffix, stage1))
-    else:
-        with phase("vstar"):
-            zs_future = load_v_stars(requests, hparams, cache_name, suffix, stage1)
+    zs_future = _LazyVstars(requests, hparams, cache_name, suffix, stage1)
     covs = {layer: get_cov_text_encoder(text_encoder, tokenizer, hparams.rewrite_module_tmp.format(layer),
                                         hparams.mom2_dataset, hparams.mom2_n_samples, hparams.mom2_dtype,
                                         stat_dir=stat_dir, verbose=verbose)

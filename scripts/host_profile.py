@@ -28,16 +28,22 @@ def call():
 
 t0 = time.perf_counter(); call(); torch.cuda.synchronize(); first = time.perf_counter() - t0
 call(); call()
-walls, phases = [], {}
-for _ in range(n_calls):
-    edit_engine.TIMING.clear()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    call()
-    torch.cuda.synchronize()
-    walls.append((time.perf_counter() - t0) * 1e3)
-    for k, v in edit_engine.TIMING.items():
-        phases.setdefault(k, []).append(v * 1e3)
-print(json.dumps({"first_call_ms": first * 1e3, "wall_ms_median": statistics.median(walls), "wall_ms_min": min(walls),
-                  "phases_ms_median": {k: round(statistics.median(v), 3) for k, v in phases.items()},
-                  "cpu": bench.cpu_model(), "concepts": N}))
+configs = [c for c in os.environ.get("EMCID_PROFILE_CHUNKS", os.environ.get("EMCID_PREP_CHUNKS", "0")).split(",")]
+walls = {c: [] for c in configs}
+phases = {c: {} for c in configs}
+for rnd in range(n_calls):              # configurations interleaved call by call: box and clock drift hit all of them alike
+    for c in configs:
+        os.environ["EMCID_PREP_CHUNKS"] = c
+        edit_engine.TIMING.clear()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        call()
+        torch.cuda.synchronize()
+        walls[c].append((time.perf_counter() - t0) * 1e3)
+        for k, v in edit_engine.TIMING.items():
+            phases[c].setdefault(k, []).append(v * 1e3)
+for c in configs:
+    print(json.dumps({"prep_chunks": c, "first_call_ms": round(first * 1e3, 1), "wall_ms_median": round(statistics.median(walls[c]), 2),
+                      "wall_ms_min": round(min(walls[c]), 2),
+                      "phases_ms_median": {k: round(statistics.median(v), 3) for k, v in phases[c].items()},
+                      "cpu": bench.cpu_model(), "concepts": N}))
