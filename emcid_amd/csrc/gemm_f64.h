@@ -136,6 +136,8 @@ struct GemmShape {
     int pf = 0;         // small tiles: keep PF K-tiles of global loads in flight (set by the launcher; see gemm_f64_tile)
     int lo_total = 0;   // lower-only square outputs: number of tiles that touch the lower triangle (> 0: the kernel
                         // enumerates exactly those, row by row, from the linear workgroup id; see gemm_f64_kernel)
+    int lower_shift = 0;  // lower_only on a trapezoid: output row m stands for matrix row m + lower_shift (the rows of the
+                          // output start lower_shift below its first column's diagonal element)
 };
 
 // WGM x WGN waves per workgroup; each wave owns a (BM/WGM) x (BN/WGN) sub-tile.
@@ -189,7 +191,7 @@ __device__ __forceinline__ void gemm_f64_tile(const GemmShape& p, const Epi& epi
     using TB = OpTile<KCB, BN, BK>;
     constexpr int STAGE = TA::SIZE + TB::SIZE;
     const int m0 = bm * BM, n0 = bn * BN;
-    if (p.lower_only && n0 > m0 + BM - 1) return;
+    if (p.lower_only && n0 > m0 + p.lower_shift + BM - 1) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -904,7 +906,7 @@ inline void launch_gemm_f64(GemmShape p, Epi epi, hipStream_t stream, int force_
     static const int env_pf = [] { const char* v = getenv("EMCID_GEMM_PF"); return v ? atoi(v) : 1; }();
     p.pf = (env_pf && cfg != 0 && ((KCA ? p.K : p.M) % 2 == 0) && ((KCB ? p.K : p.N) % 2 == 0)) ? 1 : 0;
     static const int env_lo = [] { const char* v = getenv("EMCID_GEMM_LO_ENUM"); return v ? atoi(v) : 1; }();
-    if (env_lo && p.lower_only && !p.pair && p.tri == 0 && p.M == p.N) {
+    if (env_lo && p.lower_only && !p.pair && p.tri == 0 && p.M == p.N && p.lower_shift == 0) {
         const int bm_ = cfg == 0 ? 128 : cfg == 1 ? 64 : 32, r_ = (cfg == 0 ? 128 : 64) / bm_;
         const int gy_ = (p.M + bm_ - 1) / bm_, q_ = gy_ / r_, s_ = gy_ % r_;
         p.lo_total = r_ * q_ * (q_ + 1) / 2 + s_ * (q_ + 1);

@@ -503,6 +503,103 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
     stamp();
 }
 
+
+// ---- the step between two leaves of a small Cholesky: L[j+1, j] and the next diagonal block -------------------------------------
+// After leaf j the next leaf needs exactly one 128 x 128 block: D = A[j+1, j+1] - P P^T with P = L[j+1, j] = A[j+1, j] inv(L_jj)^T.
+// As two launches of the tile GEMM this costs ~17 us of latency on the serial spine of the factorization; here it is one
+// launch of 36 workgroups, one per lower 16 x 16 tile (bi, bj) of D: the workgroup forms the two 16-row strips P_i and P_j it
+// needs itself (redundantly — no workgroup waits for another), updates its tile, and the bj == 0 column also stores its P_i
+// strip into L.  Operands through LDS with the leaf's row stride; the triangular inverse is staged in two 64-row halves.
+constexpr int SP_T = 256;
+constexpr int SP_R = 16;                    // strip height
+constexpr int SP_LDS = (64 + 4 * SP_R) * SLD;
+
+template <class FA, class FB>
+__device__ __forceinline__ v4d leaf_tile_k(const double* lds, FA fa, FB fb, int l15, int l4, int K) {
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int kk = 0; kk < K / 4; kk += 2) {
+        const double a0 = lds[fa(l15, kk * 4 + l4)];
+        const double b0 = lds[fb(kk * 4 + l4, l15)];
+        const double a1 = lds[fa(l15, kk * 4 + 4 + l4)];
+        const double b1 = lds[fb(kk * 4 + 4 + l4, l15)];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+    }
+    return acc0 + acc1;
+}
+
+__global__ __launch_bounds__(SP_T) void chol_spine_kernel(const double* __restrict__ Ablk, int64_t lda, const double* __restrict__ inv,
+                                                           int64_t ldi, double* __restrict__ Lout, int64_t ldl, double* __restrict__ D) {
+    __shared__ __attribute__((aligned(16))) double lds[SP_LDS];
+    double* sInv = lds;                     // [64][SLD]   half of inv(L_jj): rows n of the half, columns k
+    double* sAi = lds + 64 * SLD;           // [16][SLD]   A strips, overwritten by nothing (P goes to sPi / sPj)
+    double* sAj = sAi + SP_R * SLD;
+    double* sPi = sAj + SP_R * SLD;
+    double* sPj = sPi + SP_R * SLD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // lower tile (bi, bj) of the 8 x 8 tiles of D from the linear block index
+    int bi = 0, rem = blockIdx.x;
+    while (rem > bi) { rem -= bi + 1; ++bi; }
+    const int bj = rem;
+    // ---- strips of A[j+1, j]: 16 rows x 128 columns, 16-byte vectors
+    for (int v = tid; v < 2 * SP_R * (NB / 2); v += SP_T) {
+        const int which = v / (SP_R * (NB / 2)), w = v % (SP_R * (NB / 2));
+        const int r = w / (NB / 2), c = 2 * (w % (NB / 2));
+        const int row = (which ? bj : bi) * SP_R + r;
+        const v2d x = *reinterpret_cast<const v2d*>(Ablk + (int64_t)row * lda + c);
+        *reinterpret_cast<v2d*>((which ? sAj : sAi) + r * SLD + c) = x;
+    }
+    for (int half = 0; half < 2; ++half) {
+        // rows n = 64 half .. of the inverse; row n has non-zeros for k <= n only: 64 (half 0) or 128 (half 1) columns
+        const int kcols = half ? NB : 64;
+        __syncthreads();                    // previous half's reads done (and, for half 0, nothing to wait for)
+        for (int v = tid; v < 64 * (kcols / 2); v += SP_T) {
+            const int r = v / (kcols / 2), c = 2 * (v % (kcols / 2));
+            *reinterpret_cast<v2d*>(sInv + r * SLD + c) = *reinterpret_cast<const v2d*>(inv + (int64_t)(64 * half + r) * ldi + c);
+        }
+        __syncthreads();
+        // P[:, 16 t .. 16 t + 16] = A[:, 0 : K] inv[16 t .., 0 : K]^T with K = 16 (t + 1): four column tiles per half, one per
+        // wave — the deeper tiles of the second half go to the waves that had the shallow ones in the first
+        const int tl = half ? 3 - wave : wave;          // tile inside the half
+        const int t = 4 * half + tl, K = SP_R * (t + 1);
+        const v4d pi = leaf_tile_k(lds, [&](int i, int k) { return (int)(sAi - lds) + i * SLD + k; },
+                                   [&](int k, int j) { return (tl * SP_R + j) * SLD + k; }, l15, l4, K);
+        const v4d pj = leaf_tile_k(lds, [&](int i, int k) { return (int)(sAj - lds) + i * SLD + k; },
+                                   [&](int k, int j) { return (tl * SP_R + j) * SLD + k; }, l15, l4, K);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sPi[(l4 + 4 * q) * SLD + t * SP_R + l15] = pi[q];
+            sPj[(l4 + 4 * q) * SLD + t * SP_R + l15] = pj[q];
+        }
+    }
+    __syncthreads();
+    // ---- D tile -= P_i P_j^T, the 128-deep contraction cut over the four waves and summed through LDS (sInv is free now)
+    {
+        const int k0 = 32 * wave;
+        const v4d part = leaf_tile_k(lds, [&](int i, int k) { return (int)(sPi - lds) + i * SLD + k0 + k; },
+                                     [&](int k, int j) { return (int)(sPj - lds) + j * SLD + k0 + k; }, l15, l4, 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sInv[(wave * SP_R + l4 + 4 * q) * SLD + l15] = part[q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = l4 + 4 * q;
+            const double sum = (sInv[r * SLD + l15] + sInv[(SP_R + r) * SLD + l15]) + (sInv[(2 * SP_R + r) * SLD + l15] + sInv[(3 * SP_R + r) * SLD + l15]);
+            double* d = D + (int64_t)(bi * SP_R + r) * lda + bj * SP_R + l15;
+            *d -= sum;
+        }
+    }
+    if (bj == 0) {      // this column of workgroups covers every strip once: P_i -> L[j+1, j]
+        for (int v = tid; v < SP_R * (NB / 2); v += SP_T) {
+            const int r = v / (NB / 2), c = 2 * (v % (NB / 2));
+            *reinterpret_cast<v2d*>(Lout + (int64_t)(bi * SP_R + r) * ldl + c) = *reinterpret_cast<const v2d*>(sPi + r * SLD + c);
+        }
+    }
+}
+
 // ---- host orchestration -------------------------------------------------------------------------------
 
 // invw: [ceil(dp/OB)] x (OB*OB inverse block, ld OB) followed by ceil(dp/OB) x (TB*TB scratch)
@@ -630,10 +727,121 @@ static int cholesky_serial(double* A, double* L, int64_t dp, int64_t lda, double
     return check_launch("emcid_cholesky_f64");
 }
 
+
+// ---- small Cholesky with look-ahead (n <= 2048: the N x N system of the dual solver) -----------------------------------------------
+// The serial spine of a right-looking factorization is leaf -> (panel block + diagonal update of the NEXT block) -> leaf; everything
+// else of step j — the rest of the panel, the rest of the trailing update, the 512-block inverses the triangular solves want —
+// only has to be done before step j+2 reads it.  Here the spine runs on the caller's stream (leaf + chol_spine_kernel, ~45 us per
+// 128 columns) and the rest on a second stream, ordered by events; inside a captured graph the two become parallel branches.
+// (For the d x d statistics matrices this schedule lost: their bulk GEMMs fill the chip and the leaf, which wants a whole CU's
+// LDS, cannot start underneath them — see the note at cholesky_impl.  At n = 1024 the bulk is a handful of workgroups.)
+namespace {
+hipStream_t g_side_stream[MAX_DEVICES] = {};
+constexpr int EV_POOL = 96;
+hipEvent_t g_events[MAX_DEVICES][EV_POOL] = {};
+int side_stream_init(int dev, hipStream_t* out) {
+    if (dev < 0 || dev >= MAX_DEVICES) return fail(EMCID_ERR_BAD_ARG, "emcid side stream", "device ordinal out of range");
+    if (!g_side_stream[dev] && hipStreamCreateWithFlags(&g_side_stream[dev], hipStreamNonBlocking) != hipSuccess)
+        return fail(EMCID_ERR_HIP, "emcid side stream", "hipStreamCreateWithFlags");
+    for (int i = 0; i < EV_POOL; ++i)
+        if (!g_events[dev][i] && hipEventCreateWithFlags(&g_events[dev][i], hipEventDisableTiming) != hipSuccess)
+            return fail(EMCID_ERR_HIP, "emcid side stream", "hipEventCreateWithFlags");
+    *out = g_side_stream[dev];
+    return EMCID_OK;
+}
+}  // namespace
+
+static int cholesky_lookahead(double* A, double* L, int64_t n, int64_t lda, double* invw, int* info, hipStream_t st) {
+    const int nb = (int)(n / NB);
+    const int dev = current_device();
+    hipStream_t side = nullptr;
+    EMCID_TRY(side_stream_init(dev, &side));
+    int next_ev = 0;
+    auto signal = [&](hipStream_t from, hipStream_t to) {        // everything queued on `from` so far happens before what `to` gets next
+        hipEvent_t e = g_events[dev][next_ev++ % EV_POOL];
+        (void)hipEventRecord(e, from);
+        (void)hipStreamWaitEvent(to, e, 0);
+    };
+    hipLaunchKernelGGL(zero_f64_kernel, dim3(1024), dim3(256), 0, st, invw, inv_doubles(n));
+    signal(st, side);
+    double* tmp = invw + ((n + OB - 1) / OB) * (int64_t)OB * OB;
+    auto product = [&](const double* Am, int64_t ldA, bool b_lower, const double* Bm, int64_t ldB, double* Cm, int64_t ldC, int M,
+                       int N, int K, double alpha, hipStream_t q) {
+        GemmShape p{Am, ldA, Bm, ldB, M, N, K, 0};
+        p.tri = b_lower ? 2 : 0;
+        ScopedProf sp(KC_INV_BLOCK, q);
+        launch_gemm_f64<true, false>(p, EpiAxpby{Cm, ldC, alpha, 0.0}, q, 2);
+    };
+    auto level_a = [&](int J, int u, hipStream_t q) {         // the 256-block inverse from the pair (4J + 2u, 4J + 2u + 1) of 128-inverses
+        const double* Cb = L + ((int64_t)(J * 4 + 2 * u + 1) * NB) * lda + (int64_t)(J * 4 + 2 * u) * NB;
+        double* Ai = inv_block(invw, J) + (2 * u * NB) * (int64_t)(OB + 1);
+        double* Bi = inv_block(invw, J) + ((2 * u + 1) * NB) * (int64_t)(OB + 1);
+        double* X = inv_block(invw, J) + ((2 * u + 1) * NB) * (int64_t)OB + 2 * u * NB;
+        double* T = tmp + (int64_t)J * TB * TB;
+        product(Cb, lda, true, Ai, OB, T, TB, NB, NB, NB, 1.0, q);
+        product(Bi, OB, false, T, TB, X, OB, NB, NB, NB, -1.0, q);
+    };
+    auto level_b = [&](int J, int mrows, hipStream_t q) {     // the 512-block inverse from its two 256-halves (the lower may be short)
+        const double* Cb = L + ((int64_t)(J * 4 + 2) * NB) * lda + (int64_t)(J * 4) * NB;
+        double* Ai = inv_block(invw, J);
+        double* Bi = inv_block(invw, J) + (2 * NB) * (int64_t)(OB + 1);
+        double* X = inv_block(invw, J) + (2 * NB) * (int64_t)OB;
+        double* T = tmp + (int64_t)J * TB * TB;
+        product(Cb, lda, true, Ai, OB, T, TB, mrows, 2 * NB, 2 * NB, 1.0, q);
+        product(Bi, OB, false, T, TB, X, OB, mrows, 2 * NB, mrows, -1.0, q);
+    };
+    auto inverses_ready_after_block = [&](int j, hipStream_t q) {   // j: a block whose leaf and whose row of L are complete
+        const int J = j / 4, r = j % 4;
+        if (r == 1 || r == 3) level_a(J, r / 2, q);
+        const int last_in_J = (4 * J + 3 < nb) ? 4 * J + 3 : nb - 1;
+        if (j == last_in_J && last_in_J - 4 * J >= 2) level_b(J, (last_in_J - 4 * J - 1) * NB, q);
+    };
+    for (int j = 0; j < nb; ++j) {
+        const int64_t o = (int64_t)j * NB;
+        double* inv = inv_block(invw, j / 4) + ((j % 4) * NB) * (int64_t)(OB + 1);
+        {
+            ScopedProf sp(KC_CHOL_LEAF, st);
+            hipLaunchKernelGGL(chol_leaf_kernel, dim3(1), dim3(LEAF_T), 0, st, A + o * lda + o, lda, L + o * lda + o, lda, inv,
+                               (int64_t)OB, info, (int)o, (long long*)nullptr, (int64_t)0, (int64_t)0);
+        }
+        if (j == nb - 1) break;
+        if (j > 0) signal(side, st);            // bulk j-1 has brought block column j+1 up to date through column j-1
+        {
+            ScopedProf sp(KC_CHOL_PANEL, st);
+            hipLaunchKernelGGL(chol_spine_kernel, dim3(36), dim3(SP_T), 0, st, A + (o + NB) * lda + o, lda, inv, (int64_t)OB,
+                               L + (o + NB) * lda + o, lda, A + (o + NB) * lda + o + NB);
+        }
+        signal(st, side);                       // leaf j and L[j+1, j] are there
+        inverses_ready_after_block(j, side);    // block j's own row of L was finished by step j-1
+        const int m2 = (int)(n - o - 2 * NB);
+        if (m2 > 0) {
+            GemmShape ps{A + (o + 2 * NB) * lda + o, lda, inv, OB, m2, NB, NB, 0};
+            ps.tri = 1;
+            {
+                ScopedProf sp(KC_CHOL_PANEL, side);
+                launch_gemm_f64<true, true>(ps, EpiAxpby{L + (o + 2 * NB) * lda + o, lda, 1.0, 0.0}, side);
+            }
+            // A[r, c] -= L[r, j] L[c, j]^T for rows r >= j+2, columns j+1 <= c <= r (block (j+1, j+1) was the spine's)
+            GemmShape ts{L + (o + 2 * NB) * lda + o, lda, L + (o + NB) * lda + o, lda, m2, m2 + NB, NB, 1};
+            ts.lower_shift = NB;
+            ScopedProf sp(KC_CHOL_INNER, side);
+            launch_gemm_f64<true, true>(ts, EpiAxpby{A + (o + 2 * NB) * lda + o + NB, lda, -1.0, 1.0}, side);
+        }
+    }
+    signal(side, st);
+    inverses_ready_after_block(nb - 1, st);
+    return check_launch("emcid_cholesky_f64");
+}
+
 // (A two-stream look-ahead schedule — spine leaf -> one panel block -> diagonal update on the caller's stream, bulk
 // panel/trailing on a side stream — was built and measured 6-11 % SLOWER, eager and as a graph: the leaf needs a
 // whole CU's LDS, so it cannot start while the bulk GEMM keeps every CU populated.  Kept serial.)
 static int cholesky_impl(double* A, double* L, int64_t dp, int64_t lda, double* invw, int* info, hipStream_t st) {
+    // Off by default: measured on MI355X / ROCm 7.2 (bench.py device step, 4 layers, N = 1000): 13.3 ms serial -> 22.3 ms with the
+    // look-ahead schedule inside the captured graph — every fork/join between the two capture streams costs ~70 us of graph
+    // execution — and 14.2 ms with both run eagerly (host-launch bound).  Kept for the day parallel graph branches are cheap.
+    static const int lookahead = env_flag("EMCID_CHOL_LOOKAHEAD", 0);
+    if (lookahead && dp <= 2048 && dp >= 2 * NB) return cholesky_lookahead(A, L, dp, lda, invw, info, st);
     return cholesky_serial(A, L, dp, lda, invw, info, st);
 }
 
