@@ -27,6 +27,54 @@ def __getattr__(name):
     raise AttributeError(name)
 
 
+def effective_cpu_count() -> int:
+    """CPUs this process may actually use: the scheduler affinity mask AND the container's CPU bandwidth quota (cgroup v2
+    ``cpu.max`` / v1 ``cpu.cfs_quota_us``), which ``os.cpu_count()`` and PyTorch's default thread count both ignore."""
+    import math
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota|max> <period>"
+            q, period = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, period = int(f.read()), int(g.read())
+                if q > 0 and period > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, math.floor(quota)))
+    return max(1, n)
+
+
+def _respect_cpu_quota():
+    """PyTorch sizes its intra-op (OpenMP) pool by the machine's cores; inside a container with a CPU quota (the MI355X
+    boxes here: 256 hardware threads visible, quota 16) the 128 OpenMP workers spin after every small CPU tensor op of the
+    edit's host side, use up the quota within the scheduler's 100 ms period, and the whole process — the thread feeding the
+    GPU included — is frozen for the rest of it: every third 19 ms edit took 62 ms (scripts/call_jitter.py,
+    scripts/cgroup_probe.sh: 62 s throttled in a 15 s run).  The pool is therefore LOWERED to the CPUs the process can
+    actually use, never raised; EMCID_TORCH_THREADS=0 leaves PyTorch alone, any other value is used instead."""
+    import os
+    want = os.environ.get("EMCID_TORCH_THREADS", "")
+    if want == "0" or "OMP_NUM_THREADS" in os.environ:
+        return
+    try:
+        import torch
+        n = int(want) if want else effective_cpu_count()
+        if n >= 1 and torch.get_num_threads() > n:
+            torch.set_num_threads(n)
+    except Exception:       # never fail an import over a tuning default
+        pass
+
+
 def _cap_tokenizer_threads():
     """The HF `tokenizers` backend (Rust, rayon) starts one worker per hardware thread; on a 128-core editing host a
     3 000-prompt batch then spends more time waking 128 workers than encoding (measured on 2 x EPYC 9575F:
@@ -34,9 +82,13 @@ def _cap_tokenizer_threads():
     rayon reads RAYON_NUM_THREADS when its pool is first used, so a DEFAULT is set here, at import, if the process has
     none (EMCID_RAYON_THREADS=0 leaves the environment alone, any other value is used instead of 32)."""
     import os
-    want = os.environ.get("EMCID_RAYON_THREADS", "32")
-    if want != "0" and "RAYON_NUM_THREADS" not in os.environ and (os.cpu_count() or 1) > int(want):
-        os.environ["RAYON_NUM_THREADS"] = want
+    want = os.environ.get("EMCID_RAYON_THREADS", "")
+    if want == "0" or "RAYON_NUM_THREADS" in os.environ:
+        return
+    n = int(want) if want else min(32, effective_cpu_count())
+    if (os.cpu_count() or 1) > n:
+        os.environ["RAYON_NUM_THREADS"] = str(n)
 
 
 _cap_tokenizer_threads()
+_respect_cpu_quota()

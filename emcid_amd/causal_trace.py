@@ -14,6 +14,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
+from . import host_text
+
 
 def decode_tokens(tokenizer, token_array):
     if hasattr(token_array, "shape") and len(token_array.shape) > 1:
@@ -28,6 +30,7 @@ class TokenRangeFinder:
         self._plen: Optional[np.ndarray] = None      # len(decode([t])) per token id, -1 = not decoded yet
         self._piece_ns: List[Optional[str]] = []     # decode([t]) without spaces ("\ufffd" if it holds a replacement char)
         self._suffix = False                         # see _compositional (False = not probed yet)
+        self._native = None                          # (piece bytes per id, packed blob, offsets, lengths) for libemcid_host
 
     def _pieces(self, ids: Sequence[int]) -> List[str]:
         out = []
@@ -117,6 +120,8 @@ class TokenRangeFinder:
         if ids.ndim != 2 or ids.size == 0:
             return [self(row, sub) for row, sub in zip(token_arrays, substrings)]
         B, S = ids.shape
+        if self._compositional() is not None and host_text.available() and int(ids.min()) >= 0:
+            return self._batch_native(ids, substrings)
         rows = ids.tolist()
         at = np.zeros(B, dtype=np.int64)
         stop = np.zeros(B, dtype=np.int64)
@@ -152,6 +157,51 @@ class TokenRangeFinder:
         out = list(zip(first.tolist(), last.tolist()))
         for i in set(scalar) | set(np.nonzero(~ok)[0].tolist()):
             out[i] = self(rows[i], substrings[i])
+        return out
+
+    def _native_tables(self, ids: np.ndarray):
+        """Per-token tables for ``emcid_find_token_ranges``, grown when the batch shows token ids not decoded before."""
+        top = int(ids.max()) + 1
+        if self._native is None:
+            self._native = [[], b"", np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=bool)]
+        pieces, blob, off, plen, known = self._native
+        if known.size < top:
+            pieces.extend([b""] * (top - len(pieces)))
+            plen = np.concatenate([plen, np.full(top - plen.size, -1, dtype=np.int32)])
+            known = np.concatenate([known, np.zeros(top - known.size, dtype=bool)])
+            blob = None
+        present = np.zeros(known.size, dtype=bool)
+        present[ids.ravel()] = True
+        new = np.nonzero(present & ~known)[0]
+        if new.size:
+            for t, piece in zip(new.tolist(), self._pieces(new.tolist())):
+                ns = piece.replace(" ", "")
+                if ns.isascii():
+                    pieces[t], plen[t] = ns.encode("ascii"), len(piece)
+            known[new] = True
+            blob = None
+        if blob is None:
+            off = np.zeros(len(pieces) + 1, dtype=np.int64)
+            np.cumsum(np.fromiter(map(len, pieces), dtype=np.int64, count=len(pieces)), out=off[1:])
+            blob = b"".join(pieces)
+            self._native = [pieces, blob, off, plen, known]
+        return blob, off, plen
+
+    def _batch_native(self, ids: np.ndarray, substrings) -> List[Tuple[int, int]]:
+        """``batch`` through libemcid_host (``emcid_find_token_ranges``): the same walk over the same per-token pieces; the
+        rows it hands back (special subjects, non-ASCII, a subject it does not find) take the scalar path, errors included."""
+        blob, off, plen = self._native_tables(ids)
+        special = ("[CLS]", "[EOS]", "", " ")
+        subs = []
+        for sub0 in substrings:
+            sub = "" if sub0 in special else sub0.replace(" ", "").lower()
+            subs.append(sub if sub.isascii() else "")
+        first, last, status = host_text.find_token_ranges(ids, blob, off, plen, subs, forbid=self._compositional() or "")
+        out = list(zip(first.tolist(), last.tolist()))
+        todo = np.nonzero(status)[0]
+        if todo.size:
+            for i in todo.tolist():
+                out[i] = self(ids[i].tolist(), substrings[i])
         return out
 
     def __call__(self, token_array, substring_orig: str, whole_decoded: str = None) -> Tuple[int, int]:

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import hip
+from . import hip, host_text
 from .causal_trace import TokenRangeFinder
 from .clip_attention import hip_attention
 from .nethook import StopForward, get_module
@@ -70,26 +70,41 @@ class PromptBatch:
 def tokenize_lists(tokenizer, prompts: Sequence[str]) -> Dict[str, np.ndarray]:
     """``tokenizer(prompts, padding=True, truncation=True)`` as (B, S) int64 arrays (reference: compute_z.py:65).
 
-    For a tokenizers-backed HF tokenizer the public call spends most of its time assembling a ``BatchEncoding`` and
-    tracking character offsets nobody reads.  Here a ONE-prompt public call configures the backend's truncation and
-    padding exactly as transformers does for these arguments (``set_truncation_and_padding``), then the backend encodes
-    the batch without offsets (``encode_batch_fast``; same ids and masks by construction) — and the one-prompt public
-    result is checked against the corresponding row.  Anything unexpected falls back to the public call."""
+    Three routes, all returning what the public call returns:
+    1. ``host_text.NativeClipBpe`` — the C++ restatement of the CLIP pipeline in ``libemcid_host.so``, built from this
+       tokenizer's own vocabulary and merges and checked against it on a probe set when first seen; prompts it does not
+       serve (non-ASCII, special-token syntax) go through the HF tokenizer row by row.  The longest prompt is also encoded
+       with the public call and compared, every time.
+    2. For a tokenizers-backed HF tokenizer without a native twin, a ONE-prompt public call configures the backend's
+       truncation and padding exactly as transformers does for these arguments (``set_truncation_and_padding``), then the
+       backend encodes the batch without offsets (``encode_batch_fast``), checked against the one-prompt result.
+    3. The public call."""
     bt = getattr(tokenizer, "_tokenizer", None)
-    if bt is not None and hasattr(bt, "encode_batch_fast") and len(prompts) > 8:
-        try:
-            longest = max(range(len(prompts)), key=lambda i: len(prompts[i]))
+    if bt is not None and len(prompts) > 8:
+        longest = max(range(len(prompts)), key=lambda i: len(prompts[i]))
+        twin = host_text.NativeClipBpe.for_tokenizer(tokenizer)
+        if twin is not None:
+            out = twin.tokenize(tokenizer, prompts)
             probe = tokenizer([prompts[longest]], padding=True, truncation=True)
-            encs = bt.encode_batch_fast(list(prompts), add_special_tokens=True)
-            ids = np.array([e.ids for e in encs], dtype=np.int64)
-            mask = np.array([e.attention_mask for e in encs], dtype=np.int64)
             want = probe["input_ids"][0]
-            if ids.ndim == 2 and ids.shape[1] >= len(want) and ids[longest, :len(want)].tolist() == want \
-                    and int(mask[longest].sum()) == int(sum(probe["attention_mask"][0])) \
-                    and set(probe.keys()) == {"input_ids", "attention_mask"}:
-                return {"input_ids": ids, "attention_mask": mask}
-        except Exception:
-            pass
+            ids, mask = out["input_ids"], out["attention_mask"]
+            if ids.shape[1] >= len(want) and ids[longest, :len(want)].tolist() == want \
+                    and int(mask[longest].sum()) == int(sum(probe["attention_mask"][0])):
+                return out
+            host_text.NativeClipBpe.disable(tokenizer)      # never trust a twin that disagreed once
+        if hasattr(bt, "encode_batch_fast"):
+            try:
+                probe = tokenizer([prompts[longest]], padding=True, truncation=True)
+                encs = bt.encode_batch_fast(list(prompts), add_special_tokens=True)
+                ids = np.array([e.ids for e in encs], dtype=np.int64)
+                mask = np.array([e.attention_mask for e in encs], dtype=np.int64)
+                want = probe["input_ids"][0]
+                if ids.ndim == 2 and ids.shape[1] >= len(want) and ids[longest, :len(want)].tolist() == want \
+                        and int(mask[longest].sum()) == int(sum(probe["attention_mask"][0])) \
+                        and set(probe.keys()) == {"input_ids", "attention_mask"}:
+                    return {"input_ids": ids, "attention_mask": mask}
+            except Exception:
+                pass
     enc = tokenizer(list(prompts), padding=True, truncation=True)
     return {k: np.asarray(v, dtype=np.int64) for k, v in enc.items()}
 

@@ -352,9 +352,11 @@ __device__ __forceinline__ void gemm_f64_tile(const GemmShape& p, const Epi& epi
 // (1.7 us) — the loaded Infinity-Cache latency is above that (MI355X_MICROARCH.md, gather table: 72 KB in flight per CU for
 // 33 GB/s).  Loads are branch-free (clamped address + zeroing select at the LDS store), so the waits are counted.
 // Needs even extents along each operand's contiguous dimension.
-template <bool KCA, bool KCB, int BM, int BN, int BK, int WGM, int WGN, int PF>
+template <bool KCA, bool KCB, int BM, int BN, int BK, int WGM, int WGN, int PFX>
 __device__ __forceinline__ void gemm_f64_tile_acc(const GemmShape& p, int bm, int bn, double* smem, int kt_begin, int kt_end,
                                                   v4d (&acc)[BM / WGM / 16][BN / WGN / 16]) {
+    constexpr int PF = PFX % 10;                  // K tiles of global loads in flight
+    constexpr bool kFragPrefetch = PFX >= 10;     // LDS fragments of the next k8 step fetched ahead of the MFMAs
     constexpr int NT = WGM * WGN * 64;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MI = WM / 16, NI = WN / 16;
@@ -402,6 +404,30 @@ __device__ __forceinline__ void gemm_f64_tile_acc(const GemmShape& p, int bm, in
                 // keep the loads HERE: left alone, hipcc sinks them below the MFMAs into the registers the LDS store of
                 // this step frees, which puts them back to one K tile ahead of their use
                 if (PF > 1) __builtin_amdgcn_sched_barrier(0);
+                if (kFragPrefetch) {
+                    // fragments of k8 + 1 are fetched from LDS BEFORE the MFMAs of k8 (a second register set): the two
+                    // waves of a SIMD leave the barrier together, so an LDS read that both wait for is a hole in the
+                    // matrix pipe; only the first read of a K tile stays exposed
+                    double a[2][2][MI], b[2][2][NI];
+                    TA::template frags<MI>(As, wm0, 0, l15, l4, a[0]);
+                    TB::template frags<NI>(Bs, wn0, 0, l15, l4, b[0]);
+#pragma unroll
+                    for (int k8 = 0; k8 < BK / 8; ++k8) {
+                        if (k8 + 1 < BK / 8) {
+                            TA::template frags<MI>(As, wm0, k8 + 1, l15, l4, a[(k8 + 1) & 1]);
+                            TB::template frags<NI>(Bs, wn0, k8 + 1, l15, l4, b[(k8 + 1) & 1]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e)
+#pragma unroll
+                            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                                for (int j = 0; j < NI; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[k8 & 1][e][i], b[k8 & 1][e][j], acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
 #pragma unroll
                 for (int k8 = 0; k8 < BK / 8; ++k8) {
                     double a[2][MI], b[2][NI];
@@ -414,6 +440,7 @@ __device__ __forceinline__ void gemm_f64_tile_acc(const GemmShape& p, int bm, in
 #pragma unroll
                             for (int j = 0; j < NI; ++j)
                                 acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e][i], b[e][j], acc[i][j], 0, 0, 0);
+                }
                 }
                 if (PF > 1) __builtin_amdgcn_sched_barrier(0);   // ... and the zeroing selects of the set stored next BELOW them
                 {   // tile t+1 (zeros past the end: never read) into the other LDS stage
@@ -837,7 +864,8 @@ inline void launch_gemm_f64_streamk2_bk(GemmShape p, EpiAxpby epi, hipStream_t s
     }
     StreamKWork w{work, reinterpret_cast<unsigned*>(work + (int64_t)2 * wgs * BM * BN), diag_add, g_streamk_stamps};
     static const int pf = [] { const char* v = getenv("EMCID_STREAMK_PF"); return v ? atoi(v) : 1; }();
-    if (pf <= 1) hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, 2, 4, 1>), dim3(grid), dim3(512), 0, stream, p, epi, w, total, per, map);
+    if (pf == 11) hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, 2, 4, 11>), dim3(grid), dim3(512), 0, stream, p, epi, w, total, per, map);
+    else if (pf <= 1) hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, 2, 4, 1>), dim3(grid), dim3(512), 0, stream, p, epi, w, total, per, map);
     else hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, 2, 4, 2>), dim3(grid), dim3(512), 0, stream, p, epi, w, total, per, map);
 }
 

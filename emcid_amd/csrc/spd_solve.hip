@@ -346,15 +346,11 @@ __device__ __forceinline__ void flush_diag_block(const double* stage, int c0, do
     }
 }
 
-__global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restrict__ A, int64_t lda, double* __restrict__ L,
-                                                            int64_t ldl, double* __restrict__ inv, int64_t ldinv, int* info,
-                                                            int col0, long long* dbg = nullptr, int64_t s_mat = 0,
-                                                            int64_t s_inv = 0) {
-    // blockIdx.x = which matrix of a batch (independent factorizations share the launch: their serial spines overlap)
-    A += blockIdx.x * s_mat;
-    L += blockIdx.x * s_mat;
-    inv += blockIdx.x * s_inv;
-    __shared__ __attribute__((aligned(16))) double lds[NB * SLD + 2 * SB * ZLD];
+constexpr int LEAF_LDS = NB * SLD + 2 * SB * ZLD;      // doubles
+
+__device__ __forceinline__ void chol_leaf_body(const double* __restrict__ A, int64_t lda, double* __restrict__ L, int64_t ldl,
+                                               double* __restrict__ inv, int64_t ldinv, int* info, int col0, long long* dbg,
+                                               double* lds) {
     double* S = lds;
     constexpr int ZOFF = NB * SLD;          // two [32][48] temporaries behind S
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -503,6 +499,32 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
     stamp();
 }
 
+__global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restrict__ A, int64_t lda, double* __restrict__ L,
+                                                            int64_t ldl, double* __restrict__ inv, int64_t ldinv, int* info,
+                                                            int col0, long long* dbg = nullptr, int64_t s_mat = 0,
+                                                            int64_t s_inv = 0) {
+    // blockIdx.x = which matrix of a batch (independent factorizations share the launch: their serial spines overlap)
+    __shared__ __attribute__((aligned(16))) double lds[LEAF_LDS];
+    chol_leaf_body(A + blockIdx.x * s_mat, lda, L + blockIdx.x * s_mat, ldl, inv + blockIdx.x * s_inv, ldinv, info, col0, dbg, lds);
+}
+
+// One launch = the leaf of block j (workgroup 0) AND the trailing update of step j-1 that the leaf does not depend on (the other
+// workgroups, one 128 x 128 tile each): on one in-order stream a leaf and the previous step's bulk cannot overlap as two kernels,
+// and as parallel graph branches they cost more than they save (see cholesky_lookahead) — as one grid they simply run side by side.
+__global__ __launch_bounds__(LEAF_T) void chol_step_leaf_kernel(const double* __restrict__ A, int64_t lda, double* __restrict__ L,
+                                                                 int64_t ldl, double* __restrict__ inv, int64_t ldinv, int* info,
+                                                                 int col0, GemmShape trail, EpiAxpby trail_epi) {
+    __shared__ __attribute__((aligned(16))) double lds[LEAF_LDS];
+    if (blockIdx.x == 0) {
+        chol_leaf_body(A, lda, L, ldl, inv, ldinv, info, col0, nullptr, lds);
+        return;
+    }
+    // lower-trapezoid tile (bm, bn), bn <= bm + 1, from the linear index: row bm holds bm + 2 tiles
+    int bm = 0, rem = (int)blockIdx.x - 1;
+    while (rem >= bm + 2) { rem -= bm + 2; ++bm; }
+    gemm_f64_tile<true, true, 128, 128, 16, 2, 4, EpiAxpby>(trail, trail_epi, bm, rem, 0, lds);
+}
+
 
 // ---- the step between two leaves of a small Cholesky: L[j+1, j] and the next diagonal block -------------------------------------
 // After leaf j the next leaf needs exactly one 128 x 128 block: D = A[j+1, j+1] - P P^T with P = L[j+1, j] = A[j+1, j] inv(L_jj)^T.
@@ -528,35 +550,59 @@ __device__ __forceinline__ v4d leaf_tile_k(const double* lds, FA fa, FB fb, int 
     return acc0 + acc1;
 }
 
-__global__ __launch_bounds__(SP_T) void chol_spine_kernel(const double* __restrict__ Ablk, int64_t lda, const double* __restrict__ inv,
-                                                           int64_t ldi, double* __restrict__ Lout, int64_t ldl, double* __restrict__ D) {
-    __shared__ __attribute__((aligned(16))) double lds[SP_LDS];
+__device__ __forceinline__ void chol_spine_body(const double* __restrict__ Ablk, int64_t lda, const double* __restrict__ inv, int64_t ldi,
+                                                double* __restrict__ Lout, int64_t ldl, double* __restrict__ D, int tile, double* lds) {
     double* sInv = lds;                     // [64][SLD]   half of inv(L_jj): rows n of the half, columns k
-    double* sAi = lds + 64 * SLD;           // [16][SLD]   A strips, overwritten by nothing (P goes to sPi / sPj)
+    double* sAi = lds + 64 * SLD;           // [16][SLD]   A strips
     double* sAj = sAi + SP_R * SLD;
     double* sPi = sAj + SP_R * SLD;
     double* sPj = sPi + SP_R * SLD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    // lower tile (bi, bj) of the 8 x 8 tiles of D from the linear block index
-    int bi = 0, rem = blockIdx.x;
+    // lower tile (bi, bj) of the 8 x 8 tiles of D from the linear tile index
+    int bi = 0, rem = tile;
     while (rem > bi) { rem -= bi + 1; ++bi; }
     const int bj = rem;
-    // ---- strips of A[j+1, j]: 16 rows x 128 columns, 16-byte vectors
-    for (int v = tid; v < 2 * SP_R * (NB / 2); v += SP_T) {
+    // every global vector this thread will stage, fetched up front (32 independent 16-byte loads: the two A strips, the
+    // 64 x 64 and the 64 x 128 halves of the triangular inverse), so the kernel pays ONE memory latency, not one per vector
+    v2d ra[8], r0[8], r1[16];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int v = tid + u * SP_T;                               // 2 strips x 16 rows x 64 vectors
         const int which = v / (SP_R * (NB / 2)), w = v % (SP_R * (NB / 2));
         const int r = w / (NB / 2), c = 2 * (w % (NB / 2));
-        const int row = (which ? bj : bi) * SP_R + r;
-        const v2d x = *reinterpret_cast<const v2d*>(Ablk + (int64_t)row * lda + c);
-        *reinterpret_cast<v2d*>((which ? sAj : sAi) + r * SLD + c) = x;
+        ra[u] = *reinterpret_cast<const v2d*>(Ablk + (int64_t)((which ? bj : bi) * SP_R + r) * lda + c);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int v = tid + u * SP_T;                               // 64 rows x 32 vectors
+        r0[u] = *reinterpret_cast<const v2d*>(inv + (int64_t)(v / 32) * ldi + 2 * (v % 32));
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int v = tid + u * SP_T;                               // 64 rows x 64 vectors
+        r1[u] = *reinterpret_cast<const v2d*>(inv + (int64_t)(64 + v / 64) * ldi + 2 * (v % 64));
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int v = tid + u * SP_T;
+        const int which = v / (SP_R * (NB / 2)), w = v % (SP_R * (NB / 2));
+        *reinterpret_cast<v2d*>((which ? sAj : sAi) + (w / (NB / 2)) * SLD + 2 * (w % (NB / 2))) = ra[u];
     }
     for (int half = 0; half < 2; ++half) {
-        // rows n = 64 half .. of the inverse; row n has non-zeros for k <= n only: 64 (half 0) or 128 (half 1) columns
-        const int kcols = half ? NB : 64;
-        __syncthreads();                    // previous half's reads done (and, for half 0, nothing to wait for)
-        for (int v = tid; v < 64 * (kcols / 2); v += SP_T) {
-            const int r = v / (kcols / 2), c = 2 * (v % (kcols / 2));
-            *reinterpret_cast<v2d*>(sInv + r * SLD + c) = *reinterpret_cast<const v2d*>(inv + (int64_t)(64 * half + r) * ldi + c);
+        __syncthreads();                    // previous half's reads done
+        if (half == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int v = tid + u * SP_T;
+                *reinterpret_cast<v2d*>(sInv + (v / 32) * SLD + 2 * (v % 32)) = r0[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int v = tid + u * SP_T;
+                *reinterpret_cast<v2d*>(sInv + (v / 64) * SLD + 2 * (v % 64)) = r1[u];
+            }
         }
         __syncthreads();
         // P[:, 16 t .. 16 t + 16] = A[:, 0 : K] inv[16 t .., 0 : K]^T with K = 16 (t + 1): four column tiles per half, one per
@@ -598,6 +644,26 @@ __global__ __launch_bounds__(SP_T) void chol_spine_kernel(const double* __restri
             *reinterpret_cast<v2d*>(Lout + (int64_t)(bi * SP_R + r) * ldl + c) = *reinterpret_cast<const v2d*>(sPi + r * SLD + c);
         }
     }
+}
+
+__global__ __launch_bounds__(SP_T) void chol_spine_kernel(const double* __restrict__ Ablk, int64_t lda, const double* __restrict__ inv,
+                                                           int64_t ldi, double* __restrict__ Lout, int64_t ldl, double* __restrict__ D) {
+    __shared__ __attribute__((aligned(16))) double lds[SP_LDS];
+    chol_spine_body(Ablk, lda, inv, ldi, Lout, ldl, D, (int)blockIdx.x, lds);
+}
+
+// One launch = the spine step of block j (workgroups 0..35) AND the rest of panel j (32 x 64 tiles of L[j+2.., j] = A[j+2.., j]
+// inv(L_jj)^T): both need leaf j only, neither needs the other.
+__global__ __launch_bounds__(SP_T) void chol_step_spine_kernel(const double* __restrict__ Ablk, int64_t lda, const double* __restrict__ inv,
+                                                                int64_t ldi, double* __restrict__ Lout, int64_t ldl, double* __restrict__ D,
+                                                                GemmShape panel, EpiAxpby panel_epi) {
+    __shared__ __attribute__((aligned(16))) double lds[SP_LDS];
+    if (blockIdx.x < 36) {
+        chol_spine_body(Ablk, lda, inv, ldi, Lout, ldl, D, (int)blockIdx.x, lds);
+        return;
+    }
+    const int t = (int)blockIdx.x - 36;
+    gemm_f64_tile<true, true, 32, 64, 16, 2, 2, EpiAxpby>(panel, panel_epi, t / 2, t % 2, 0, lds);
 }
 
 // ---- host orchestration -------------------------------------------------------------------------------
@@ -833,6 +899,56 @@ static int cholesky_lookahead(double* A, double* L, int64_t n, int64_t lda, doub
     return check_launch("emcid_cholesky_f64");
 }
 
+// ---- small Cholesky, two heterogeneous launches per 128 columns (n <= 2048) -------------------------------------------------------
+// Step j:   launch A_j = { leaf j }  +  { trailing update of step j-1 minus the block the leaf needs }
+//           launch B_j = { spine step j: L[j+1, j] and the next diagonal block }  +  { the rest of panel j }
+// Everything a launch contains depends on earlier LAUNCHES only, so the parts run side by side on the chip and the serial chain
+// per step is leaf + spine step + two kernel boundaries (~48 us) instead of leaf + panel + trailing update + three (~65 us) — with
+// one stream, i.e. without the parallel graph branches that sank cholesky_lookahead.
+static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, double* invw, int* info, hipStream_t st) {
+    const int nb = (int)(n / NB);
+    hipLaunchKernelGGL(zero_f64_kernel, dim3(1024), dim3(256), 0, st, invw, inv_doubles(n));
+    for (int j = 0; j < nb; ++j) {
+        const int64_t o = (int64_t)j * NB;
+        double* inv = inv_block(invw, j / 4) + ((j % 4) * NB) * (int64_t)(OB + 1);
+        {   // A_j
+            const int M = (j >= 1) ? (int)(n - o - NB) : 0;           // rows j+1.. still to be updated by column j-1
+            GemmShape tr{L, lda, L, lda, 0, 0, NB, 1};
+            EpiAxpby te{A, lda, -1.0, 1.0};
+            int ntiles = 0;
+            if (M > 0) {
+                tr = GemmShape{L + (o + NB) * lda + (o - NB), lda, L + o * lda + (o - NB), lda, M, M + NB, NB, 1};
+                tr.lower_shift = NB;
+                te.C = A + (o + NB) * lda + o;
+                const int Mb = M / NB;
+                ntiles = Mb * (Mb + 3) / 2;
+            }
+            ScopedProf sp(KC_CHOL_LEAF, st);
+            hipLaunchKernelGGL(chol_step_leaf_kernel, dim3(1 + ntiles), dim3(LEAF_T), 0, st, A + o * lda + o, lda, L + o * lda + o, lda,
+                               inv, (int64_t)OB, info, (int)o, tr, te);
+        }
+        if (j == nb - 1) break;
+        {   // B_j
+            const int m2 = (int)(n - o - 2 * NB);
+            GemmShape ps{A, lda, inv, OB, 0, NB, NB, 0};
+            EpiAxpby pe{L, lda, 1.0, 0.0};
+            int npanel = 0;
+            if (m2 > 0) {
+                ps = GemmShape{A + (o + 2 * NB) * lda + o, lda, inv, OB, m2, NB, NB, 0};
+                ps.tri = 1;
+                ps.pf = 1;
+                pe.C = L + (o + 2 * NB) * lda + o;
+                npanel = (m2 / 32) * 2;
+            }
+            ScopedProf sp(KC_CHOL_PANEL, st);
+            hipLaunchKernelGGL(chol_step_spine_kernel, dim3(36 + npanel), dim3(SP_T), 0, st, A + (o + NB) * lda + o, lda, inv,
+                               (int64_t)OB, L + (o + NB) * lda + o, lda, A + (o + NB) * lda + o + NB, ps, pe);
+        }
+    }
+    build_block_inverses(L, n, lda, invw, st);
+    return check_launch("emcid_cholesky_f64");
+}
+
 // (A two-stream look-ahead schedule — spine leaf -> one panel block -> diagonal update on the caller's stream, bulk
 // panel/trailing on a side stream — was built and measured 6-11 % SLOWER, eager and as a graph: the leaf needs a
 // whole CU's LDS, so it cannot start while the bulk GEMM keeps every CU populated.  Kept serial.)
@@ -842,6 +958,8 @@ static int cholesky_impl(double* A, double* L, int64_t dp, int64_t lda, double* 
     // execution — and 14.2 ms with both run eagerly (host-launch bound).  Kept for the day parallel graph branches are cheap.
     static const int lookahead = env_flag("EMCID_CHOL_LOOKAHEAD", 0);
     if (lookahead && dp <= 2048 && dp >= 2 * NB) return cholesky_lookahead(A, L, dp, lda, invw, info, st);
+    static const int fused = env_flag("EMCID_CHOL_FUSED", 1);
+    if (fused && dp <= 2048 && dp >= 2 * NB) return cholesky_fused_steps(A, L, dp, lda, invw, info, st);
     return cholesky_serial(A, L, dp, lda, invw, info, st);
 }
 
@@ -1051,6 +1169,8 @@ static int with_graph(const GraphKey& key_in, hipStream_t st, F&& body) {
     for (int i = 0; i < g_graph_n; ++i)
         if (g_graphs[i].key == key) { slot = &g_graphs[i]; break; }
     if (!slot) {
+        static const int trace = env_flag("EMCID_GRAPH_TRACE", 0);
+        if (trace) fprintf(stderr, "[emcid graph] capture tag %lld (cached %d of %d)\n", (long long)key.num[5], g_graph_n, GRAPH_SLOTS);
         hipStream_t cap = nullptr;
         EMCID_TRY(capture_stream_init((int)key.dev, &cap));
         if (hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) != hipSuccess)

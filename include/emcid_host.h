@@ -1,0 +1,58 @@
+/* emcid_host.h — C ABI of libemcid_host.so: the host-side text work on the edit path (no GPU, no HIP).
+ *
+ * The reference tokenizes every prompt of an edit with the pipeline's own Hugging Face CLIP tokenizer
+ * (`tokenize_prompts`, emcid/compute_z.py:65: `tokenizer(prompts, return_tensors="pt", padding=True, truncation=True)`, called
+ * from get_module_input_output_at_words, compute_z.py:2284) and finds each subject's last token by decoding the ids
+ * (`find_token_range`, experiments/causal_trace.py:1057, called per prompt at compute_z.py:2287-2290).  On a 1 000-concept edit that is 3 000 prompts: 9-17 ms in the HF
+ * tokenizer and 3-4 ms in the search, more than the whole GPU solve.  These two entry points restate exactly that work for
+ * the common case (ASCII prompts, a CLIP byte-level BPE vocabulary) and REPORT, per prompt, when a prompt is outside that
+ * case — the caller then sends just those prompts through the HF tokenizer.  `emcid_amd/host_text.py` is the binding; it
+ * checks the tokenizer's configuration and a probe set against the HF tokenizer before it trusts this library.
+ */
+#ifndef EMCID_HOST_H
+#define EMCID_HOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct emcid_bpe emcid_bpe;
+
+int emcid_host_abi_version(void);
+
+/* A CLIP byte-level BPE model (tokenizers' `BPE` with `end_of_word_suffix`, behind the CLIP normalizer / pre-tokenizer:
+ * NFC, \s+ -> ' ', lowercase; split on  's|'t|'re|'ve|'m|'ll|'d|\p{L}+|\p{N}|[^\s\p{L}\p{N}]+ ; ByteLevel).
+ * vocab: token i is the UTF-8 string vocab_bytes[vocab_off[i] .. vocab_off[i+1]) with id vocab_ids[i].
+ * merges: n_merges (left id, right id) pairs in rank order; the merged token (left + right) must be in the vocabulary.
+ * Returns NULL (and sets emcid_host_last_error) on an inconsistent model. */
+emcid_bpe* emcid_bpe_create(const char* vocab_bytes, const int64_t* vocab_off, const int32_t* vocab_ids, int64_t n_vocab,
+                            const int32_t* merges, int64_t n_merges, const char* end_of_word_suffix);
+void emcid_bpe_destroy(emcid_bpe* m);
+
+/* Encode n texts; text i is text[off[i] .. off[i+1]).  Row i of ids (n x max_len, int64) becomes
+ * bos, tokens (at most max_len - 2), eos, then `pad` up to max_len; lengths[i] = tokens written including bos/eos.
+ * fallback[i] = 1 and the row is left as pad when text i is outside what this library restates exactly: a byte outside
+ * printable ASCII / ASCII white space, the sequence "<|" (special-token syntax), or a character missing from the vocabulary.
+ * Returns the number of fallback rows, or -1 on a bad argument.  Thread-safe (one lock per model). */
+int64_t emcid_bpe_encode_batch(emcid_bpe* m, const char* text, const int64_t* off, int64_t n, int32_t bos, int32_t eos,
+                               int32_t pad, int32_t max_len, int64_t* ids, int32_t* lengths, uint8_t* fallback);
+
+/* The token range of a subject inside a tokenized prompt, as the reference's find_token_range walks it, for n rows at once.
+ * ids: n x S int64.  Per token id t < n_pieces: piece_ns[piece_off[t] .. piece_off[t+1]) = decode([t]) without spaces
+ * (ASCII), piece_len[t] = len(decode([t])) WITH spaces (what the reference's walk counts); piece_len[t] < 0 marks a token
+ * this table cannot serve (non-ASCII piece).  subj: the subjects, already lower-cased and stripped of spaces,
+ * subj[subj_off[i] .. subj_off[i+1]).  forbid (may be NULL or empty): a string whose presence in a row's concatenated pieces
+ * means the tokenizer's own decode would differ from the concatenation (CLIP's end-of-word suffix formed across tokens).
+ * first[i], last[i] = the [first, last) token range; status[i] = 0 found, 1 = take the scalar path (unservable token, empty
+ * subject, forbidden string, subject not found or never covered).
+ * Returns the number of rows with status != 0, or -1 on a bad argument. */
+int64_t emcid_find_token_ranges(const int64_t* ids, int64_t n, int64_t S, const char* piece_ns, const int64_t* piece_off,
+                                const int32_t* piece_len, int64_t n_pieces, const char* subj, const int64_t* subj_off,
+                                const char* forbid, int32_t* first, int32_t* last, uint8_t* status);
+
+const char* emcid_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

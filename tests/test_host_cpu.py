@@ -59,7 +59,7 @@ def test_token_ranges_golden_and_memo():
                 assert list(fn(r["ids"], r["subject"])) == r["range"]
 
 
-def test_token_range_batch_equals_scalar_walk():
+def test_token_range_batch_equals_scalar_walk(monkeypatch):
     """The vectorised batch walk (cumulative piece lengths) returns what the scalar walk returns, row for row, including
     the rows it must hand to the scalar path ([CLS], [EOS], '', ' ', all-space subjects) and a missing subject."""
     tok = syn.build_tokenizer(*syn.synthetic_vocab(syllables=True))
@@ -69,21 +69,51 @@ def test_token_range_batch_equals_scalar_walk():
     ids = tok(prompts, padding=True, truncation=True)["input_ids"]
     scalar = TokenRangeFinder(tok)
     want = [scalar(r, s) for r, s in zip(ids, subjects)]
-    got = TokenRangeFinder(tok).batch(ids, subjects)
-    assert [tuple(g) for g in got] == [tuple(w) for w in want]
     orc_want = [orc.find_token_range(tok, torch.tensor(r), s) for r, s in zip(ids, subjects)]
-    assert [tuple(g) for g in got] == [tuple(w) for w in orc_want]
-    with pytest.raises(ValueError):
-        TokenRangeFinder(tok).batch(ids[:3], ["zzzz", subjects[1], subjects[2]])
-    # a row with a piece that is not valid UTF-8 on its own (U+FFFD) takes the whole-row decode: same answer
-    poisoned = TokenRangeFinder(tok)
-    poisoned.batch(ids[:4], subjects[:4])
-    poisoned._piece_ns[ids[0][3]] = "\ufffd"
-    assert [tuple(g) for g in poisoned.batch(ids, subjects)] == [tuple(w) for w in want]
+    assert [tuple(w) for w in want] == [tuple(w) for w in orc_want]
+    from emcid_amd import host_text
+    for native in (True, False):        # libemcid_host's walk, and the numpy walk it replaces
+        monkeypatch.setattr(host_text, "available", lambda native=native: native)
+        got = TokenRangeFinder(tok).batch(ids, subjects)
+        assert [tuple(g) for g in got] == [tuple(w) for w in want]
+        with pytest.raises(ValueError):
+            TokenRangeFinder(tok).batch(ids[:3], ["zzzz", subjects[1], subjects[2]])
+        # a row with a piece that is not valid UTF-8 on its own (U+FFFD) takes the whole-row decode: same answer
+        poisoned = TokenRangeFinder(tok)
+        poisoned.batch(ids[:4], subjects[:4])
+        if native:
+            assert poisoned._native is not None
+            poisoned._native[3][ids[0][3]] = -1
+        else:
+            assert poisoned._native is None
+            poisoned._piece_ns[ids[0][3]] = "\ufffd"
+        assert [tuple(g) for g in poisoned.batch(ids, subjects)] == [tuple(w) for w in want]
+        # ragged rows (no common length): the scalar path row by row
+        ragged = [r[:len(r) - (i % 2)] for i, r in enumerate(ids[:6])]
+        assert TokenRangeFinder(tok).batch(ragged, subjects[:6]) == [scalar(r, s) for r, s in zip(ragged, subjects[:6])]
     assert TokenRangeFinder(tok)._compositional() == "</w>"
-    # ragged rows (no common length): the scalar path row by row
-    ragged = [r[:len(r) - (i % 2)] for i, r in enumerate(ids[:6])]
-    assert TokenRangeFinder(tok).batch(ragged, subjects[:6]) == [scalar(r, s) for r, s in zip(ragged, subjects[:6])]
+
+
+def test_native_token_ranges_hand_back_what_they_cannot_serve():
+    """The suffix formed across tokens ('<', '/', 'w', '>'), non-ASCII subjects and pieces, and subjects that appear only
+    partially: the native walk flags them and the scalar walk answers, so the batch equals the scalar walk everywhere."""
+    tok, _ = _rich_pair(0)
+    prompts = ["a photo of </w> thing", "a photo of café", "the thing and the thing", "an image of the-thing!", "thing"]
+    subjects = ["thing", "café", "thing", "the-thing", "thing"]
+    ids = np.asarray(tok(prompts, padding=True, truncation=True)["input_ids"])
+    f = TokenRangeFinder(tok)
+    want = []
+    for r, s_ in zip(ids.tolist(), subjects):
+        try:
+            want.append(tuple(TokenRangeFinder(tok)(r, s_)))
+        except ValueError:
+            want.append("ValueError")
+    assert want[1] == "ValueError" and want.count("ValueError") == 1     # 'é' is outside this vocabulary: the reference raises too
+    keep = [0, 2, 3, 4]
+    assert [tuple(g) for g in f.batch(ids[keep], [subjects[i] for i in keep])] == [want[i] for i in keep]
+    assert f._native is not None
+    with pytest.raises(ValueError):
+        f.batch(ids, subjects)
 
 
 def test_fast_tokenize_equals_public_call():
@@ -437,3 +467,137 @@ def test_uce_host_side():
         uce.edit_model_uce(pipe, meta["old"], meta["new"], None)
     with pytest.raises(hip.EmcidHipError):
         uce.edit_text_encoder_uce(pipe, meta["old"], meta["new"], None, layer_to_edit=2)
+
+
+# ---- libemcid_host.so: native CLIP BPE + token ranges (include/emcid_host.h) ---------------------------------------------------
+def _native_pair():
+    from emcid_amd import host_text
+    tok = syn.build_tokenizer(*syn.synthetic_vocab(syllables=True))
+    twin = host_text.NativeClipBpe.for_tokenizer(tok)
+    assert twin is not None, "the synthetic CLIP tokenizer must get a native twin"
+    return tok, twin
+
+
+def _rich_pair(seed=0, n_merges=3000):
+    """A CLIP tokenizer over ALL printable ASCII with random merges (short tokens favoured, so that chains of competing
+    merges of different rank occur inside ordinary words) and its native twin."""
+    from emcid_amd import host_text
+    rng = np.random.default_rng(seed)
+    chars = [chr(c) for c in range(0x21, 0x7f)]
+    vocab = {}
+    for c in chars:
+        vocab[c] = len(vocab)
+    for c in chars:
+        vocab[c + "</w>"] = len(vocab)
+    open_toks, all_toks, merges, seen = list(chars), list(vocab), [], set()
+    common = list("etaoinshrdlu'.,!")
+    while len(merges) < n_merges:
+        pool_a = open_toks if rng.random() < 0.5 else common
+        a = pool_a[rng.integers(len(pool_a))]
+        b = all_toks[rng.integers(len(all_toks))] if rng.random() < 0.6 else common[rng.integers(len(common))] + \
+            ("</w>" if rng.random() < 0.3 else "")
+        if (a, b) in seen or len(a + b) > 9 or a.endswith("</w>"):
+            continue
+        seen.add((a, b))
+        merges.append((a, b))
+        if a + b not in vocab:
+            vocab[a + b] = len(vocab)
+            all_toks.append(a + b)
+            if not b.endswith("</w>"):
+                open_toks.append(a + b)
+    vocab["<|startoftext|>"] = len(vocab)
+    vocab["<|endoftext|>"] = len(vocab)
+    tok = syn.build_tokenizer(vocab, merges)
+    twin = host_text.NativeClipBpe.for_tokenizer(tok)
+    assert twin is not None
+    return tok, twin
+
+
+def test_host_library_exports_every_declared_symbol():
+    import ctypes
+    import re
+    from emcid_amd import host_text
+    header = (Path(__file__).resolve().parents[1] / "include" / "emcid_host.h").read_text()
+    names = set(re.findall(r"\b(emcid_[a-z0-9_]+)\s*\(", header))
+    assert {"emcid_bpe_create", "emcid_bpe_encode_batch", "emcid_find_token_ranges", "emcid_host_abi_version"} <= names
+    lib = ctypes.CDLL(str(host_text.lib_path()))
+    for n in names:
+        assert hasattr(lib, n), n
+    assert host_text.load().emcid_host_abi_version() == host_text.ABI_VERSION
+
+
+def test_native_bpe_matches_hf_on_request_prompts():
+    from emcid_amd.compute_z import expand_request_prompts
+    tok, twin = _native_pair()
+    for names in ("syllable", None):
+        reqs = syn.make_requests(300, names=names) if names else syn.make_requests(64, ragged=True)
+        prompts, _, _ = expand_request_prompts(reqs)
+        want = tok(prompts, padding=True, truncation=True)
+        got = twin.tokenize(tok, prompts)
+        assert np.array_equal(np.asarray(want["input_ids"]), got["input_ids"])
+        assert np.array_equal(np.asarray(want["attention_mask"]), got["attention_mask"])
+
+
+def test_native_bpe_matches_hf_on_arbitrary_text():
+    """Property test: printable ASCII soup (contractions, digits, punctuation runs, odd white space), long rows that get
+    truncated, and rows the library must hand back (non-ASCII, control bytes, special-token syntax)."""
+    from hypothesis import given, settings, strategies as st
+    pairs = [_native_pair(), _rich_pair(0), _rich_pair(1, 800)]
+    alphabet = st.sampled_from(list("abcdefgopqrstuvwxyzABCTZ '\t\n0123456789.,!?-_()[]'\"<|>#") + ["'s", "'re", " 'll", "n't", "'D"])
+    text = st.lists(alphabet, max_size=60).map("".join)
+    odd = st.sampled_from(["café au lait", "naïve", "á", "你好", "x\x00y", "x\x1fy", "a\x7fb", "<|endoftext|> hi",
+                           "pre <|startoftext|>", "emoji \U0001f600", "nbsp here", "’s"])
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(st.one_of(text, text, text, odd), min_size=1, max_size=12), st.integers(0, 3))
+    def check(rows, long_rows):
+        rows = rows + ["the quick brown fox " * 30 + r for r in rows[:long_rows]]
+        for tok, twin in pairs:
+            want = tok(rows, padding=True, truncation=True)
+            got = twin.tokenize(tok, rows)
+            assert np.array_equal(np.asarray(want["input_ids"]), got["input_ids"]), rows
+            assert np.array_equal(np.asarray(want["attention_mask"]), got["attention_mask"]), rows
+    check()
+    # and the flags themselves: served rows are not flagged, foreign rows are
+    tok, twin = pairs[1]
+    _, _, fb = twin.encode(["every printable: !\"#$%&'()*+,-./:;<=>?@[\\]^_`{}~ 0123456789 The End"])
+    assert not fb.any()
+    _, _, fb = twin.encode(["plain ascii", "café", "<|endoftext|>", "x\x00y", "tab\tok"])
+    assert fb.tolist() == [False, True, True, True, False]
+
+
+def test_native_bpe_rejects_a_foreign_pipeline():
+    """A tokenizer whose serialized pipeline is not exactly CLIP's gets no twin (the HF path is used)."""
+    import json
+    from emcid_amd import host_text
+    tok = syn.build_tokenizer(*syn.synthetic_vocab(syllables=True))
+    cfg = json.loads(tok._tokenizer.to_str())
+    assert host_text._clip_pipeline(cfg) is None
+    for mutate in (lambda c: c["normalizer"]["normalizers"].pop(),
+                   lambda c: c["pre_tokenizer"]["pretokenizers"][0]["pattern"].update(Regex=r"\w+"),
+                   lambda c: c["model"].update(dropout=0.1),
+                   lambda c: c["model"].update(end_of_word_suffix=""),
+                   lambda c: c["post_processor"].update(type="TemplateProcessing"),
+                   lambda c: c["added_tokens"].append({"id": 1, "content": "photo"})):
+        c = json.loads(json.dumps(cfg))
+        mutate(c)
+        assert host_text._clip_pipeline(c) is not None
+
+
+def test_tokenize_lists_uses_the_native_twin_and_agrees():
+    from emcid_amd import host_text
+    from emcid_amd.compute_z import expand_request_prompts, tokenize_lists
+    tok, twin = _native_pair()
+    prompts, _, _ = expand_request_prompts(syn.make_requests(40, names="syllable"))
+    prompts[3] = "a photo of café " + prompts[3]
+    calls = []
+    orig = host_text.NativeClipBpe.tokenize
+    try:
+        host_text.NativeClipBpe.tokenize = lambda self, t, p: (calls.append(len(p)), orig(self, t, p))[1]
+        got = tokenize_lists(tok, prompts)
+    finally:
+        host_text.NativeClipBpe.tokenize = orig
+    assert calls == [len(prompts)]
+    want = tok(prompts, padding=True, truncation=True)
+    assert np.array_equal(np.asarray(want["input_ids"]), got["input_ids"])
+    assert np.array_equal(np.asarray(want["attention_mask"]), got["attention_mask"])
