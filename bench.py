@@ -128,9 +128,21 @@ def step_flops(N, n_rows, d, h, L, dual, apply_only, factors_cached, first_x):
     add(chol_flops(Np), L)                               # the N x N system S = I + Yt Yt^T
     f["assemble"] += L * N * N * d                       # SYRK count of S
     if apply_only:
-        add(trsm_flops(h, Np, 2), L)                     # Z = S^-1 Rt: h right-hand sides
+        if os.environ.get("EMCID_S_INVERSE", "1") != "0" and Np <= 4096:
+            # Z^T = (Rt^T XS^T) XS with XS = inv(LS) explicit: two triangular GEMMs on h rows + the halving level(s) above 512
+            f["trsm_diag"] += L * 2 * h * Np * Np
+            f["inv_build"] += L * (Np ** 3 // 3 - (Np // 512) * 512 ** 3 // 3)
+        else:
+            add(trsm_flops(h, Np, 2), L)                 # Z = S^-1 Rt by block substitution: h right-hand sides
         f["delta_w"] += L * 2 * h * N * d                # V = Z^T Yt
-        f["inv_apply"] += n_x * (n_rows + h) * d * d     # Yt = Kt X^T on the concept rows, U = V X on h rows
+        shadow = (os.environ.get("EMCID_SHADOW_P", "1") != "0" and os.environ.get("EMCID_CHOL_FUSED", "1") != "0"
+                  and 256 <= Np <= 2048)
+        if shadow:
+            # P = Yt X rides in the Cholesky's leaf launches (csrc/spd_solve.hip ShadowJob); U = Z^T P is the delta_w GEMM
+            f["inv_apply"] += n_x * n_rows * d * d       # Yt = Kt X^T on the concept rows
+            f["chol_leaf"] += n_x * N * d * d            # P = Yt X: N x d x d against a triangle
+        else:
+            f["inv_apply"] += n_x * (n_rows + h) * d * d     # Yt = Kt X^T on the concept rows, U = V X on h rows
         add(trsm_flops(n_rows, d, 1), L - n_x)
         add(trsm_flops(h, d, 1), L - n_x)
     else:
@@ -143,7 +155,8 @@ def step_flops(N, n_rows, d, h, L, dual, apply_only, factors_cached, first_x):
 
 KERNEL_OF_CLASS = {
     "assemble": "gemm_f64_streamk_kernel / gemm_f64_kernel launched as SYRK (S = I + Yt Yt^T, or K^T K in the direct solver)",
-    "chol_leaf": "chol_leaf_kernel (128 x 128 diagonal block: factor + inverse, one workgroup, matrix-pipe pivots)",
+    "chol_leaf": "chol_step_leaf_kernel: workgroup 0 = 128 x 128 diagonal block (factor + inverse, matrix-pipe pivots), the others = "
+                 "the previous step's trailing tiles and one K slice of the shadow product P = Yt X (64 x 128 tiles)",
     "chol_trail": "gemm_f64_kernel<KC,KC,*,*,16,EpiAxpby> launched as left-looking Cholesky block-column update",
     "chol_inner": "gemm_f64_kernel<KC,KC,*,64,16,2,2,EpiAxpby> launched as in-block Cholesky trailing update",
     "chol_panel": "gemm_f64_kernel<KC,KC,32,64,16,2,2,EpiAxpby> launched as Cholesky panel solve",
@@ -353,6 +366,7 @@ def main():
                    "parallelism": f"concept-shard x{world}"},
         "ms_per_call_median": statistics.median(per_call) * 1e3,
         "ms_per_call_min": min(per_call) * 1e3,
+        "ms_per_call": [round(t * 1e3, 3) for t in per_call],
         "first_call_ms": first_s * 1e3,
         "untuned_ms_per_step": untuned_ms,
         "host_prepare_ms": statistics.median(prep_ms),

@@ -187,22 +187,44 @@ class TokenRangeFinder:
             self._native = [pieces, blob, off, plen, known]
         return blob, off, plen
 
-    def _batch_native(self, ids: np.ndarray, substrings) -> List[Tuple[int, int]]:
+    def _batch_native(self, ids: np.ndarray, substrings, index: Optional[np.ndarray] = None) -> List[Tuple[int, int]]:
         """``batch`` through libemcid_host (``emcid_find_token_ranges``): the same walk over the same per-token pieces; the
-        rows it hands back (special subjects, non-ASCII, a subject it does not find) take the scalar path, errors included."""
+        rows it hands back (special subjects, non-ASCII, a subject it does not find) take the scalar path, errors included.
+        ``index``: row i searches ``substrings[index[i]]`` (the subjects of a mass edit repeat once per template)."""
         blob, off, plen = self._native_tables(ids)
         special = ("[CLS]", "[EOS]", "", " ")
         subs = []
         for sub0 in substrings:
             sub = "" if sub0 in special else sub0.replace(" ", "").lower()
             subs.append(sub if sub.isascii() else "")
-        first, last, status = host_text.find_token_ranges(ids, blob, off, plen, subs, forbid=self._compositional() or "")
+        first, last, status = host_text.find_token_ranges(ids, blob, off, plen, subs, forbid=self._compositional() or "",
+                                                          subject_idx=index)
         out = list(zip(first.tolist(), last.tolist()))
         todo = np.nonzero(status)[0]
         if todo.size:
             for i in todo.tolist():
-                out[i] = self(ids[i].tolist(), substrings[i])
+                out[i] = self(ids[i].tolist(), substrings[i if index is None else int(index[i])])
         return out
+
+    def last_tokens(self, ids: np.ndarray, subjects: Sequence[str], index: np.ndarray, packed=None) -> np.ndarray:
+        """Lookup position (``find_token_range(...)[1] - 1``, compute_z.py:2287-2290) of every row of ``ids`` (B, S) for the
+        subject ``subjects[index[i]]``, as an int64 array.  ``packed``: ``host_text.pack_strings(subjects)`` if the caller
+        has it already.  The native walk lower-cases and strips the subjects itself; special subjects, non-ASCII ones and
+        rows it cannot serve take the scalar walk (its errors included)."""
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        index = np.asarray(index)
+        if self._compositional() is not None and host_text.available() and ids.size and int(ids.min()) >= 0:
+            blob, off, plen = self._native_tables(ids)
+            if packed is None:
+                packed = host_text.pack_strings(subjects)
+            _, last, status = host_text.find_token_ranges(ids, blob, off, plen, packed, forbid=self._compositional() or "",
+                                                          subject_idx=index, normalize=True)
+            out = last.astype(np.int64) - 1
+            for i in np.nonzero(status)[0].tolist():
+                out[i] = self(ids[i].tolist(), subjects[int(index[i])])[1] - 1
+            return out
+        rng = self.batch(ids, [subjects[int(k)] for k in index])
+        return np.fromiter((r[1] - 1 for r in rng), dtype=np.int64, count=len(rng))
 
     def __call__(self, token_array, substring_orig: str, whole_decoded: str = None) -> Tuple[int, int]:
         ids = [int(t) for t in token_array]

@@ -105,9 +105,11 @@ def _graph_signature(graph: ClipTextGraph) -> tuple:
     sig = []
     for l in graph.layers:
         for m in (l.q, l.k, l.v):
-            sig.append((id(m.weight), m.weight._version, m.weight.data_ptr()))
-            if m.bias is not None:
-                sig.append((id(m.bias), m.bias._version, m.bias.data_ptr()))
+            params = m._parameters          # (nn.Module.__getattr__ costs ~1 us per access; this runs on every edit call)
+            w, b = params["weight"], params.get("bias")
+            sig.append((id(w), w._version, w.data_ptr()))
+            if b is not None:
+                sig.append((id(b), b._version, b.data_ptr()))
     return tuple(sig)
 
 
@@ -147,8 +149,9 @@ ROW_BUCKET = 256   # node / query-row counts are padded to a multiple of this: a
 
 def build_trie(input_ids, lookup: Sequence[int], device, bucket: int = ROW_BUCKET) -> TokenTrie:
     """Trie of the prompts' prefixes up to each lookup token.  ``input_ids``: (B, S) array (or equal-length rows).
-    Built level by level with numpy (one ``np.unique`` over (parent, token) keys per position): nodes are numbered by
-    depth, then by (parent, token)."""
+    Nodes are numbered by depth, then by (parent, token).  Built by ``libemcid_host.so`` (``emcid_trie_build``: one packed image
+    in pinned memory, ONE asynchronous upload) when that library is there, else level by level with numpy
+    (``build_trie_numpy``: six pageable uploads) — same arrays either way (tests/test_host_cpu.py)."""
     tok = np.asarray(input_ids, dtype=np.int64)
     if tok.ndim != 2:
         raise UnsupportedEncoder("prompt rows of unequal length")
@@ -157,6 +160,29 @@ def build_trie(input_ids, lookup: Sequence[int], device, bucket: int = ROW_BUCKE
     dmax = int(lk.max()) + 1
     if dmax > 128:
         raise UnsupportedEncoder("prompt longer than 128 tokens")
+    from . import host_text
+    if host_text.available() and B > 0 and int(lk.min()) >= 0 and dmax <= tok.shape[1] and int(tok[:, :dmax].min()) >= 0:
+        dev = torch.device(device)
+
+        def alloc(nbytes):
+            buf = torch.empty(nbytes, dtype=torch.uint8, pin_memory=(dev.type == "cuda"))
+            return buf, buf.data_ptr()
+
+        host, z = host_text.build_trie_packed(tok, lk, bucket, alloc)
+        img = host.to(dev, non_blocking=True)
+        U, n, R, D = z["U"], z["n"], z["R_pad"], z["dmax"]
+        o32 = 8 * (U + 2 * n)
+        return TokenTrie(img[:8 * U].view(torch.int64), img[o32:o32 + 4 * U].view(torch.int32),
+                         img[o32 + 4 * (U + R):o32 + 4 * (U + R + U * D)].view(torch.int32).view(U, D),
+                         img[8 * U:8 * (U + n)].view(torch.int64), img[o32 + 4 * U:o32 + 4 * (U + R)].view(torch.int32),
+                         img[8 * (U + n):o32].view(torch.int64), z["n_real"], B * tok.shape[1])
+    return build_trie_numpy(tok, lk, device, bucket)
+
+
+def build_trie_numpy(tok: np.ndarray, lk: np.ndarray, device, bucket: int = ROW_BUCKET) -> TokenTrie:
+    """``build_trie`` with numpy: one ``np.unique`` over (parent, token) keys per position."""
+    B = tok.shape[0]
+    dmax = int(lk.max()) + 1
     vocab = int(tok[:, :dmax].max()) + 1
     node_of = np.full(B, -1, dtype=np.int64)
     tokens, parents, levels = [], [], []

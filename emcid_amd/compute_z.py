@@ -13,6 +13,7 @@ MI355X-first differences, results identical:
   torch-CPU's ``.mean(0)``;
 * the forward stops at the hooked module (the reference runs the remaining layers and discards them).
 """
+import os
 import weakref
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -156,9 +157,90 @@ def build_prompt_batch(tokenizer, requests: Sequence[Dict], device, finder: Opti
 class PromptChunk:
     """Host-side tokenization of a contiguous slice of the request list (prompts truncated behind the last lookup token)."""
     ids: np.ndarray          # (B_c, S_c) int64
-    lookup: List[int]        # position of the last subject token per prompt
+    lookup: Sequence[int]    # position of the last subject token per prompt (list or int64 array)
     counts: List[int]        # prompts per request
     n_requests: int
+
+
+def templated_prompt_chunk(tokenizer, requests: Sequence[Dict], first: Dict) -> Optional[PromptChunk]:
+    """The (few templates) x (many names) shape of a mass edit WITHOUT building, joining and re-splitting the prompt strings:
+    ``p.format(source)`` (reference compute_z.py:2278-2283) for templates with exactly one ``{}`` and no other brace is
+    ``prefix + source + suffix``, so ``libemcid_host`` encodes every distinct prefix, suffix and source once
+    (``emcid_bpe_encode_templated``) and walks each row for its subject with the subjects passed once
+    (``emcid_find_token_ranges_idx``).  Same ids and lookup positions as the generic path (tests/test_host_cpu.py); returns
+    None whenever the request list is outside that shape (pre-formatted ``source_prompts``, other format fields, a
+    tokenizer without a native twin, a non-string source) and the caller takes the generic path."""
+    if "source_prompts" in first or "prompts" not in first or len(requests) < 3 or getattr(tokenizer, "_tokenizer", None) is None:
+        return None
+    twin = host_text.NativeClipBpe.for_tokenizer(tokenizer)
+    if twin is None:
+        return None
+    try:
+        names = [r["source"] for r in requests]
+        keys = [tuple(r["prompts"]) for r in requests]
+        distinct = dict.fromkeys(keys)                   # the distinct template tuples, in order of first appearance
+    except TypeError:                                    # unhashable prompt entries
+        return None
+    if set(map(type, names)) != {str}:                   # format() would str() anything else
+        return None
+    tmpl: Dict[str, int] = {}
+    pre, suf, set_tmpl = [], [], []
+    for k, key in enumerate(distinct):
+        idxs = []
+        for p in key:
+            t = tmpl.get(p)
+            if t is None:
+                if type(p) is not str or p.count("{}") != 1 or p.count("{") != 1 or p.count("}") != 1:
+                    return None
+                a, b = p.split("{}")
+                t = tmpl[p] = len(pre)
+                pre.append(a)
+                suf.append(b)
+            idxs.append(t)
+        distinct[key] = k
+        set_tmpl.append(np.asarray(idxs, dtype=np.int32))
+    n = len(names)
+    if len(set_tmpl) == 1:
+        per = int(set_tmpl[0].size)
+        counts = [per] * n
+        tmpl_idx = np.tile(set_tmpl[0], n)
+        name_idx = np.repeat(np.arange(n, dtype=np.int32), per)
+    else:
+        req_set = [distinct[key] for key in keys]
+        counts = [int(set_tmpl[k].size) for k in req_set]
+        tmpl_idx = np.concatenate([set_tmpl[k] for k in req_set])
+        name_idx = np.repeat(np.arange(n, dtype=np.int32), counts)
+    if tmpl_idx.size == 0:
+        return None
+
+    def prompt(i):
+        t = int(tmpl_idx[i])
+        return pre[t] + names[int(name_idx[i])] + suf[t]
+
+    packed_names = host_text.pack_strings(names)
+    ids, lengths, fb = twin.encode_templated(pre, suf, packed_names, tmpl_idx, name_idx)
+    if fb.any():                # rows outside the native library (non-ASCII, special-token syntax): the HF tokenizer
+        rows = np.nonzero(fb)[0].tolist()
+        enc = tokenizer([prompt(i) for i in rows], padding=False, truncation=True)["input_ids"]
+        for i, r in zip(rows, enc):
+            ids[i, :len(r)] = r
+            lengths[i] = len(r)
+    S = int(lengths.max())
+    # as tokenize_lists does on every call: the longest row against the public tokenizer call
+    j = int(lengths.argmax())
+    probe = tokenizer([prompt(j)], padding=True, truncation=True)
+    want = probe["input_ids"][0]
+    if S < len(want) or ids[j, :len(want)].tolist() != want or int(lengths[j]) != int(sum(probe["attention_mask"][0])) \
+            or set(probe.keys()) != {"input_ids", "attention_mask"}:
+        host_text.NativeClipBpe.disable(tokenizer)
+        return None
+    ids = ids[:, :S]
+    lk = finder_for(tokenizer).last_tokens(ids, names, name_idx, packed=packed_names)
+    bad = np.nonzero((lk < 0) | (lk >= S))[0]
+    if bad.size:
+        j = int(bad[0])
+        raise ValueError(f"lookup index {int(lk[j])} outside the padded prompt (S={S}) for prompt {prompt(j)!r}")
+    return PromptChunk(np.ascontiguousarray(ids[:, :int(lk.max()) + 1]), lk, counts, n)
 
 
 def iter_prompt_chunks(tokenizer, requests: Sequence[Dict], n_chunks: int):
@@ -171,6 +253,11 @@ def iter_prompt_chunks(tokenizer, requests: Sequence[Dict], n_chunks: int):
     finder = finder_for(tokenizer)
     for i in range(n_chunks):
         lo, hi = (n * i) // n_chunks, (n * (i + 1)) // n_chunks
+        if os.environ.get("EMCID_TEMPLATED", "1") != "0":
+            fast = templated_prompt_chunk(tokenizer, requests[lo:hi], first)
+            if fast is not None:
+                yield fast
+                continue
         prompts, subjects, counts = expand_request_prompts(requests[lo:hi], first)
         ids = tokenize_lists(tokenizer, prompts)["input_ids"]
         lookup = [r[-1] - 1 for r in finder.batch(ids, subjects)]

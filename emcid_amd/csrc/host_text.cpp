@@ -4,6 +4,7 @@
 // flagged back to the caller, prompt by prompt.
 #include "../../include/emcid_host.h"
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -80,7 +81,7 @@ struct emcid_bpe {
 
 extern "C" {
 
-int emcid_host_abi_version(void) { return 1; }
+int emcid_host_abi_version(void) { return 3; }
 
 const char* emcid_host_last_error(void) { return g_error.c_str(); }
 
@@ -136,6 +137,53 @@ emcid_bpe* emcid_bpe_create(const char* vocab_bytes, const int64_t* vocab_off, c
 
 void emcid_bpe_destroy(emcid_bpe* m) { delete m; }
 
+// One text -> the ids of its pre-tokens appended to `row` (no bos/eos), stopping once `budget` ids are there (truncation keeps
+// a prefix: later pieces cannot matter).  false: the text is outside what this library restates (see emcid_host.h).
+// Caller holds m->lock.
+static bool encode_text(emcid_bpe* m, const char* s, size_t len, std::string& low, std::vector<int32_t>& row, int32_t budget) {
+    low.assign(s, len);
+    for (size_t p = 0; p < len; ++p) {
+        const unsigned char c = (unsigned char)low[p];
+        if (c >= 0x80 || !servable(c) || (c == '<' && p + 1 < len && low[p + 1] == '|')) return false;
+        if (c >= 'A' && c <= 'Z') low[p] = (char)(c + 32);
+    }
+    size_t p = 0;
+    while (p < len) {
+        const unsigned char c = (unsigned char)low[p];
+        if (is_space(c)) {
+            ++p;
+            continue;
+        }
+        size_t q = p + contraction(low, p, len);    // 's|'t|'re|'ve|'m|'ll|'d come first in the alternation
+        if (q == p) {
+            q = p + 1;
+            if (is_letter(c)) {                         // \p{L}+
+                while (q < len && is_letter((unsigned char)low[q])) ++q;
+            } else if (!is_digit(c)) {                  // [^\s\p{L}\p{N}]+   (a digit is a piece of its own: \p{N})
+                while (q < len && !is_space((unsigned char)low[q]) && !is_letter((unsigned char)low[q]) &&
+                       !is_digit((unsigned char)low[q]))
+                    ++q;
+            }
+        }
+        const std::vector<int32_t>* w = nullptr;
+        if (!m->word(low.data() + p, q - p, &w)) return false;
+        row.insert(row.end(), w->begin(), w->end());
+        p = q;
+        if ((int32_t)row.size() >= budget) break;
+    }
+    return true;
+}
+
+static inline void write_row(int64_t* out, const std::vector<int32_t>& row, int32_t bos, int32_t eos, int32_t max_len,
+                             int32_t* length) {
+    const int32_t budget = max_len - 2;
+    const int32_t keep = (int32_t)row.size() < budget ? (int32_t)row.size() : budget;
+    out[0] = bos;
+    for (int32_t j = 0; j < keep; ++j) out[1 + j] = row[j];
+    out[1 + keep] = eos;
+    *length = keep + 2;
+}
+
 int64_t emcid_bpe_encode_batch(emcid_bpe* m, const char* text, const int64_t* off, int64_t n, int32_t bos, int32_t eos,
                                int32_t pad, int32_t max_len, int64_t* ids, int32_t* lengths, uint8_t* fallback) {
     if (!m || !text || !off || n < 0 || max_len < 2 || !ids || !lengths || !fallback) {
@@ -155,65 +203,129 @@ int64_t emcid_bpe_encode_batch(emcid_bpe* m, const char* text, const int64_t* of
             g_error = "emcid_bpe_encode_batch: text offsets are not monotone";
             return -1;
         }
-        const char* s = text + off[i];
-        const size_t len = (size_t)(off[i + 1] - off[i]);
-        bool ok = true;
-        low.assign(s, len);
-        for (size_t p = 0; p < len && ok; ++p) {
-            const unsigned char c = (unsigned char)low[p];
-            if (c >= 0x80 || !servable(c) || (c == '<' && p + 1 < len && low[p + 1] == '|')) ok = false;
-            if (c >= 'A' && c <= 'Z') low[p] = (char)(c + 32);
+        row.clear();
+        if (!encode_text(m, text + off[i], (size_t)(off[i + 1] - off[i]), low, row, max_len - 2)) {
+            fallback[i] = 1;
+            ++n_fallback;
+            continue;
+        }
+        write_row(out, row, bos, eos, max_len, lengths + i);
+    }
+    return n_fallback;
+}
+
+int64_t emcid_bpe_encode_templated(emcid_bpe* m, const char* pre, const int64_t* pre_off, const char* suf, const int64_t* suf_off,
+                                   int64_t n_templates, const char* names, const int64_t* name_off, int64_t n_names,
+                                   const int32_t* tmpl_idx, const int32_t* name_idx, int64_t n, int32_t bos, int32_t eos,
+                                   int32_t pad, int32_t max_len, int64_t* ids, int32_t* lengths, uint8_t* fallback) {
+    if (!m || !pre || !pre_off || !suf || !suf_off || n_templates <= 0 || !names || !name_off || n_names <= 0 || !tmpl_idx ||
+        !name_idx || n < 0 || max_len < 2 || !ids || !lengths || !fallback) {
+        g_error = "emcid_bpe_encode_templated: bad argument";
+        return -1;
+    }
+    std::lock_guard<std::mutex> guard(m->lock);
+    const int32_t budget = max_len - 2;
+    std::string low;
+    // every distinct piece is encoded once: 0 = not yet, 1 = ids there, 2 = outside the library
+    struct Piece { std::vector<int32_t> ids; uint8_t state = 0; };
+    std::vector<Piece> P((size_t)n_templates), Sx((size_t)n_templates), Nm((size_t)n_names);
+    auto piece = [&](Piece& pc, const char* blob, const int64_t* off, int64_t k) -> bool {
+        if (pc.state == 0) pc.state = encode_text(m, blob + off[k], (size_t)(off[k + 1] - off[k]), low, pc.ids, budget) ? 1 : 2;
+        return pc.state == 1;
+    };
+    auto joins = [&](const char* a, const int64_t* aoff, int64_t ka, const char* b, const int64_t* boff, int64_t kb) {
+        // the boundary between two pieces falls between pre-tokens iff one side is empty or white space touches it
+        const int64_t la = aoff[ka + 1] - aoff[ka], lb = boff[kb + 1] - boff[kb];
+        return la == 0 || lb == 0 || is_space((unsigned char)a[aoff[ka + 1] - 1]) || is_space((unsigned char)b[boff[kb]]);
+    };
+    int64_t n_fallback = 0;
+    std::vector<int32_t> row;
+    std::string whole;
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t* out = ids + i * (int64_t)max_len;
+        for (int32_t j = 0; j < max_len; ++j) out[j] = pad;
+        lengths[i] = 0;
+        fallback[i] = 0;
+        const int64_t t = tmpl_idx[i], k = name_idx[i];
+        if (t < 0 || t >= n_templates || k < 0 || k >= n_names || pre_off[t + 1] < pre_off[t] || suf_off[t + 1] < suf_off[t] ||
+            name_off[k + 1] < name_off[k]) {
+            g_error = "emcid_bpe_encode_templated: index or offsets out of range";
+            return -1;
         }
         row.clear();
-        size_t p = 0;
-        const int32_t budget = max_len - 2;
-        while (ok && p < len) {
-            const unsigned char c = (unsigned char)low[p];
-            if (is_space(c)) {
-                ++p;
-                continue;
+        bool ok;
+        if (name_off[k + 1] > name_off[k] && joins(pre, pre_off, t, names, name_off, k) && joins(names, name_off, k, suf, suf_off, t)) {
+            ok = piece(P[(size_t)t], pre, pre_off, t) && piece(Nm[(size_t)k], names, name_off, k) && piece(Sx[(size_t)t], suf, suf_off, t);
+            if (ok) {
+                row = P[(size_t)t].ids;
+                row.insert(row.end(), Nm[(size_t)k].ids.begin(), Nm[(size_t)k].ids.end());
+                row.insert(row.end(), Sx[(size_t)t].ids.begin(), Sx[(size_t)t].ids.end());
             }
-            size_t q = p + contraction(low, p, len);    // 's|'t|'re|'ve|'m|'ll|'d come first in the alternation
-            if (q == p) {
-                q = p + 1;
-                if (is_letter(c)) {                         // \p{L}+
-                    while (q < len && is_letter((unsigned char)low[q])) ++q;
-                } else if (!is_digit(c)) {                  // [^\s\p{L}\p{N}]+   (a digit is a piece of its own: \p{N})
-                    while (q < len && !is_space((unsigned char)low[q]) && !is_letter((unsigned char)low[q]) &&
-                           !is_digit((unsigned char)low[q]))
-                        ++q;
-                }
-            }
-            const std::vector<int32_t>* w = nullptr;
-            if (!m->word(low.data() + p, q - p, &w)) {
-                ok = false;
-                break;
-            }
-            row.insert(row.end(), w->begin(), w->end());
-            p = q;
-            if ((int32_t)row.size() >= budget) break;    // truncation keeps a prefix: later pieces cannot matter
+        } else {                                   // pre-tokens may span a boundary: encode the formatted text as a whole
+            whole.assign(pre + pre_off[t], (size_t)(pre_off[t + 1] - pre_off[t]));
+            whole.append(names + name_off[k], (size_t)(name_off[k + 1] - name_off[k]));
+            whole.append(suf + suf_off[t], (size_t)(suf_off[t + 1] - suf_off[t]));
+            ok = encode_text(m, whole.data(), whole.size(), low, row, budget);
         }
         if (!ok) {
             fallback[i] = 1;
             ++n_fallback;
             continue;
         }
-        const int32_t keep = (int32_t)row.size() < budget ? (int32_t)row.size() : budget;
-        out[0] = bos;
-        for (int32_t j = 0; j < keep; ++j) out[1 + j] = row[j];
-        out[1 + keep] = eos;
-        lengths[i] = keep + 2;
+        write_row(out, row, bos, eos, max_len, lengths + i);
     }
     return n_fallback;
 }
 
+int64_t emcid_find_token_ranges_idx(const int64_t* ids, int64_t n, int64_t S, const char* piece_ns, const int64_t* piece_off,
+                                    const int32_t* piece_len, int64_t n_pieces, const char* subj, const int64_t* subj_off,
+                                    const int32_t* subj_idx, int64_t n_subj, int normalize, const char* forbid, int32_t* first,
+                                    int32_t* last, uint8_t* status);
+
 int64_t emcid_find_token_ranges(const int64_t* ids, int64_t n, int64_t S, const char* piece_ns, const int64_t* piece_off,
                                 const int32_t* piece_len, int64_t n_pieces, const char* subj, const int64_t* subj_off,
                                 const char* forbid, int32_t* first, int32_t* last, uint8_t* status) {
+    return emcid_find_token_ranges_idx(ids, n, S, piece_ns, piece_off, piece_len, n_pieces, subj, subj_off, nullptr, n, 0, forbid,
+                                       first, last, status);
+}
+
+int64_t emcid_find_token_ranges_idx(const int64_t* ids, int64_t n, int64_t S, const char* piece_ns, const int64_t* piece_off,
+                                    const int32_t* piece_len, int64_t n_pieces, const char* subj, const int64_t* subj_off,
+                                    const int32_t* subj_idx, int64_t n_subj, int normalize, const char* forbid, int32_t* first,
+                                    int32_t* last, uint8_t* status) {
     if (!ids || n < 0 || S <= 0 || !piece_ns || !piece_off || !piece_len || n_pieces <= 0 || !subj || !subj_off || !first ||
-        !last || !status) {
+        !last || !status || n_subj < 0) {
         g_error = "emcid_find_token_ranges: bad argument";
         return -1;
+    }
+    if (subj_idx)
+        for (int64_t i = 0; i < n; ++i)
+            if (subj_idx[i] < 0 || subj_idx[i] >= n_subj) {
+                g_error = "emcid_find_token_ranges: subject index out of range";
+                return -1;
+            }
+    // normalize: the subjects arrive as the caller's raw strings; what the reference's walk searches for is
+    // `sub.replace(" ", "").lower()` (causal_trace.py:1066); "[CLS]" / "[EOS]" / "" / " " are its special cases and anything
+    // outside ASCII is left to the scalar walk — all of those become empty here, i.e. status 1
+    std::string norm_blob;
+    std::vector<int64_t> norm_off;
+    if (normalize) {
+        norm_off.assign((size_t)n_subj + 1, 0);
+        for (int64_t k = 0; k < n_subj; ++k) {
+            const char* b = subj + subj_off[k];
+            const int64_t len = subj_off[k + 1] - subj_off[k];
+            const size_t start = norm_blob.size();
+            bool keep = len > 0 && !(len == 5 && (!std::memcmp(b, "[CLS]", 5) || !std::memcmp(b, "[EOS]", 5)));
+            for (int64_t j = 0; j < len && keep; ++j) {
+                const unsigned char c = (unsigned char)b[j];
+                if (c >= 0x80) keep = false;
+                else if (c != ' ') norm_blob.push_back((char)((c >= 'A' && c <= 'Z') ? c + 32 : c));
+            }
+            if (!keep) norm_blob.resize(start);
+            norm_off[(size_t)k + 1] = (int64_t)norm_blob.size();
+        }
+        subj = norm_blob.data();
+        subj_off = norm_off.data();
     }
     int64_t n_scalar = 0;
     std::string whole;
@@ -221,8 +333,9 @@ int64_t emcid_find_token_ranges(const int64_t* ids, int64_t n, int64_t S, const 
         const int64_t* row = ids + i * S;
         first[i] = last[i] = 0;
         status[i] = 1;
-        const size_t sl = (size_t)(subj_off[i + 1] - subj_off[i]);
-        bool ok = sl > 0 && subj_off[i + 1] >= subj_off[i];
+        const int64_t si = subj_idx ? subj_idx[i] : i;
+        const size_t sl = (size_t)(subj_off[si + 1] - subj_off[si]);
+        bool ok = sl > 0 && subj_off[si + 1] >= subj_off[si];
         whole.clear();
         for (int64_t j = 0; j < S && ok; ++j) {
             const int64_t t = row[j];
@@ -231,7 +344,7 @@ int64_t emcid_find_token_ranges(const int64_t* ids, int64_t n, int64_t S, const 
         }
         if (ok && forbid && *forbid && whole.find(forbid) != std::string::npos) ok = false;
         if (ok) {
-            const size_t at = whole.find(subj + subj_off[i], 0, sl);
+            const size_t at = whole.find(subj + subj_off[si], 0, sl);
             if (at == std::string::npos) ok = false;
             else {
                 // the reference's walk: `seen` counts len(decode([t])) (spaces included) against offsets in the space-free
@@ -255,5 +368,151 @@ int64_t emcid_find_token_ranges(const int64_t* ids, int64_t n, int64_t S, const 
     }
     return n_scalar;
 }
+
+// ---- prefix trie of a tokenized prompt batch ------------------------------------------------------------------------------------
+// Same construction and the same node numbering as emcid_amd/clip_forward.py build_trie (level by level; nodes numbered by depth,
+// then by (parent, token)): the forward's row order, and with it every GEMM's operand layout, does not depend on which of the
+// two built the trie.
+struct emcid_trie {
+    int64_t n = 0, U = 0, n_real = 0, R = 0, R_pad = 0;
+    int32_t dmax = 0;
+    std::vector<int64_t> token, lookup_node, inverse;
+    std::vector<int32_t> depth, parent, q_rows;
+    std::vector<int64_t> level_begin;      // first node of each level (dmax + 1 entries)
+};
+
+emcid_trie* emcid_trie_build(const int64_t* ids, int64_t n, int64_t S, const int64_t* lookup, int64_t bucket) {
+    if (!ids || !lookup || n <= 0 || S <= 0 || bucket < 1) {
+        g_error = "emcid_trie_build: bad argument";
+        return nullptr;
+    }
+    int64_t lmax = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (lookup[i] < 0 || lookup[i] >= S) {
+            g_error = "emcid_trie_build: lookup index outside the row";
+            return nullptr;
+        }
+        if (lookup[i] > lmax) lmax = lookup[i];
+    }
+    auto* t = new emcid_trie();
+    t->n = n;
+    t->dmax = (int32_t)(lmax + 1);
+    t->lookup_node.assign((size_t)n, -1);
+    t->level_begin.push_back(0);
+    // keys (parent + 1) * vocab + token, sorted per level by an LSD radix sort (11-bit digits): a comparison sort of the ~n
+    // entries of every level was most of the build's time
+    int64_t vocab = 1;
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t p = 0; p <= lookup[i]; ++p) {
+            const int64_t tk = ids[i * S + p];
+            if (tk < 0) {
+                delete t;
+                g_error = "emcid_trie_build: negative token id";
+                return nullptr;
+            }
+            if (tk >= vocab) vocab = tk + 1;
+        }
+    struct Entry { uint64_t key; int64_t row; };
+    std::vector<Entry> cur, tmp;
+    cur.reserve((size_t)n);
+    tmp.reserve((size_t)n);
+    std::vector<int64_t>& node_of = t->lookup_node;     // node of each prompt at the level just built (its last alive level stays)
+    int64_t total = 0;
+    for (int32_t p = 0; p < t->dmax; ++p) {
+        cur.clear();
+        uint64_t kmax = 0;
+        for (int64_t i = 0; i < n; ++i)
+            if (lookup[i] >= p) {
+                const uint64_t key = (uint64_t)(node_of[(size_t)i] + 1) * (uint64_t)vocab + (uint64_t)ids[i * S + p];
+                if (key > kmax) kmax = key;
+                cur.push_back({key, i});
+            }
+        for (int shift = 0; shift < 64 && (kmax >> shift) != 0; shift += 11) {
+            size_t count[2049] = {0};
+            for (const Entry& e : cur) ++count[((e.key >> shift) & 2047) + 1];
+            for (int b = 0; b < 2048; ++b) count[b + 1] += count[b];
+            tmp.resize(cur.size());
+            for (const Entry& e : cur) tmp[count[(e.key >> shift) & 2047]++] = e;
+            cur.swap(tmp);
+        }
+        int64_t id = total - 1;
+        for (size_t k = 0; k < cur.size(); ++k) {
+            if (k == 0 || cur[k].key != cur[k - 1].key) {
+                ++id;
+                t->token.push_back((int64_t)(cur[k].key % (uint64_t)vocab));
+                t->parent.push_back((int32_t)((int64_t)(cur[k].key / (uint64_t)vocab) - 1));
+                t->depth.push_back(p);
+            }
+            node_of[(size_t)cur[k].row] = id;
+        }
+        total = id + 1;
+        t->level_begin.push_back(total);
+    }
+    t->n_real = total;
+    const int64_t pad = bucket > 1 ? (bucket - total % bucket) % bucket : 0;
+    t->U = total + pad;
+    for (int64_t k = 0; k < pad; ++k) {       // padding nodes: copies of the first root token at depth 0, attending to themselves
+        t->token.push_back(t->token[0]);
+        t->depth.push_back(0);
+        t->parent.push_back(-1);
+    }
+    // distinct lookup nodes, sorted, and each prompt's index among them: mark the nodes, then one scan in node order
+    std::vector<int32_t> rank((size_t)total, -1);
+    for (int64_t i = 0; i < n; ++i) rank[(size_t)t->lookup_node[(size_t)i]] = 0;
+    t->q_rows.clear();
+    for (int64_t u = 0; u < total; ++u)
+        if (rank[(size_t)u] == 0) {
+            rank[(size_t)u] = (int32_t)t->q_rows.size();
+            t->q_rows.push_back((int32_t)u);
+        }
+    t->R = (int64_t)t->q_rows.size();
+    t->inverse.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) t->inverse[(size_t)i] = rank[(size_t)t->lookup_node[(size_t)i]];
+    if (bucket > 1 && t->R % bucket) {
+        const int32_t q0 = t->q_rows[0];
+        t->q_rows.resize((size_t)(t->R + (bucket - t->R % bucket)), q0);
+    }
+    t->R_pad = (int64_t)t->q_rows.size();
+    return t;
+}
+
+void emcid_trie_sizes(const emcid_trie* t, int64_t* U, int64_t* n_real, int64_t* dmax, int64_t* R_pad) {
+    if (!t) return;
+    if (U) *U = t->U;
+    if (n_real) *n_real = t->n_real;
+    if (dmax) *dmax = t->dmax;
+    if (R_pad) *R_pad = t->R_pad;
+}
+
+int64_t emcid_trie_packed_bytes(const emcid_trie* t) {
+    if (!t) return -1;
+    const int64_t i32s = t->U + t->R_pad + t->U * t->dmax;
+    return 8 * (t->U + 2 * t->n) + 4 * (i32s + (i32s & 1));
+}
+
+int emcid_trie_export(const emcid_trie* t, void* out, int64_t out_bytes) {
+    if (!t || !out || out_bytes < emcid_trie_packed_bytes(t)) {
+        g_error = "emcid_trie_export: bad argument";
+        return -1;
+    }
+    int64_t* p64 = (int64_t*)out;
+    std::memcpy(p64, t->token.data(), (size_t)t->U * 8);
+    std::memcpy(p64 + t->U, t->lookup_node.data(), (size_t)t->n * 8);
+    std::memcpy(p64 + t->U + t->n, t->inverse.data(), (size_t)t->n * 8);
+    int32_t* p32 = (int32_t*)(p64 + t->U + 2 * t->n);
+    std::memcpy(p32, t->depth.data(), (size_t)t->U * 4);
+    std::memcpy(p32 + t->U, t->q_rows.data(), (size_t)t->R_pad * 4);
+    int32_t* anc = p32 + t->U + t->R_pad;
+    const int32_t D = t->dmax;
+    std::memset(anc, 0, (size_t)t->U * D * 4);
+    for (int64_t u = 0; u < t->U; ++u) {            // parents precede their children: copy the parent's chain, append self
+        const int32_t d = t->depth[(size_t)u], par = t->parent[(size_t)u];
+        if (d > 0) std::memcpy(anc + u * D, anc + (int64_t)par * D, (size_t)d * 4);
+        anc[u * D + d] = (int32_t)u;
+    }
+    return 0;
+}
+
+void emcid_trie_destroy(emcid_trie* t) { delete t; }
 
 }  // extern "C"

@@ -508,21 +508,79 @@ __global__ __launch_bounds__(LEAF_T) void chol_leaf_kernel(const double* __restr
     chol_leaf_body(A + blockIdx.x * s_mat, lda, L + blockIdx.x * s_mat, ldl, inv + blockIdx.x * s_inv, ldinv, info, col0, dbg, lds);
 }
 
+// A product that does NOT depend on the matrix being factored, cut into `nslices` K slices, one per leaf launch: the leaf
+// occupies ONE compute unit for ~36 us while the rest of the chip has (almost) nothing to do, so an independent GEMM of the
+// caller's rides along in the launches' other workgroups ("shadow").  Used by the dual solver for P = Yt X (X = inv(L) of
+// lam*C', lower triangular, stored [k][n]), which turns U = (Z^T Yt) X — a GEMM against the triangle AFTER the N x N solve, on
+// the critical path — into U = Z^T P.  C = A B with B(k, n) = 0 for k < n; 64 x 128 output tiles; a workgroup takes column tile
+// j and its mirror image NT-1-j (equal total depth for every workgroup) and contracts slice `slice` of each tile's own K range;
+// slice 0 stores, later slices add — launches of one stream are ordered and a tile belongs to one workgroup per launch, so the
+// sum order is fixed (bit-reproducible) and nothing is atomic.
+struct ShadowJob {
+    const double* A; int64_t lda;     // [M][K], K contiguous
+    const double* B; int64_t ldb;     // [K][N], N contiguous, zero for k < n
+    double* C; int64_t ldc;           // [M][N]
+    int M, N, K;
+    int wgs;                          // workgroups per launch: ceil(M / 64) * ceil(ceil(N / 128) / 2); 0 = no job
+};
+constexpr int SH_BM = 64, SH_BN = 128, SH_BK = 16, SH_PF = 3;
+
+__device__ __forceinline__ void shadow_tile(const ShadowJob& sh, int bm, int bn, int slice, int nslices, double* smem) {
+    using TA = OpTile<true, SH_BM, SH_BK>;
+    using TB = OpTile<false, SH_BN, SH_BK>;
+    GemmShape q{sh.A, sh.lda, sh.B, sh.ldb, sh.M, sh.N, sh.K, 0};
+    q.tri = 2;
+    const int depth = streamk_depth(q, bn, SH_BN, SH_BK);
+    const int per = (depth + nslices - 1) / nslices;
+    const int kb = slice * per, ke = min(depth, kb + per);
+    if (kb >= ke) return;
+    v4d acc[SH_BM / 2 / 16][SH_BN / 4 / 16];
+    gemm_f64_tile_acc<true, false, SH_BM, SH_BN, SH_BK, 2, 4, SH_PF>(q, bm, bn, smem, kb, ke, acc);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / 4) * (SH_BM / 2), wn0 = (wave % 4) * (SH_BN / 4);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int m0 = bm * SH_BM, n0 = bn * SH_BN;
+#pragma unroll
+    for (int i = 0; i < SH_BM / 2 / 16; ++i)
+#pragma unroll
+        for (int j = 0; j < SH_BN / 4 / 16; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm0 + TA::index_of(i, l4 + 4 * r);
+                const int n = n0 + wn0 + TB::index_of(j, l15);
+                if (m < sh.M && n < sh.N) {
+                    double* c = sh.C + (int64_t)m * sh.ldc + n;
+                    *c = slice ? *c + acc[i][j][r] : acc[i][j][r];
+                }
+            }
+    __syncthreads();      // the next tile's first LDS store must not overtake this tile's last MFMA stage
+}
+
 // One launch = the leaf of block j (workgroup 0) AND the trailing update of step j-1 that the leaf does not depend on (the other
 // workgroups, one 128 x 128 tile each): on one in-order stream a leaf and the previous step's bulk cannot overlap as two kernels,
 // and as parallel graph branches they cost more than they save (see cholesky_lookahead) — as one grid they simply run side by side.
+// Behind those, sh.wgs workgroups of the caller's shadow product (slice `slice` of `nslices`).
 __global__ __launch_bounds__(LEAF_T) void chol_step_leaf_kernel(const double* __restrict__ A, int64_t lda, double* __restrict__ L,
                                                                  int64_t ldl, double* __restrict__ inv, int64_t ldinv, int* info,
-                                                                 int col0, GemmShape trail, EpiAxpby trail_epi) {
+                                                                 int col0, GemmShape trail, EpiAxpby trail_epi, int ntrail,
+                                                                 ShadowJob sh, int slice, int nslices) {
     __shared__ __attribute__((aligned(16))) double lds[LEAF_LDS];
     if (blockIdx.x == 0) {
         chol_leaf_body(A, lda, L, ldl, inv, ldinv, info, col0, nullptr, lds);
         return;
     }
-    // lower-trapezoid tile (bm, bn), bn <= bm + 1, from the linear index: row bm holds bm + 2 tiles
-    int bm = 0, rem = (int)blockIdx.x - 1;
-    while (rem >= bm + 2) { rem -= bm + 2; ++bm; }
-    gemm_f64_tile<true, true, 128, 128, 16, 2, 4, EpiAxpby>(trail, trail_epi, bm, rem, 0, lds);
+    if ((int)blockIdx.x <= ntrail) {
+        // lower-trapezoid tile (bm, bn), bn <= bm + 1, from the linear index: row bm holds bm + 2 tiles
+        int bm = 0, rem = (int)blockIdx.x - 1;
+        while (rem >= bm + 2) { rem -= bm + 2; ++bm; }
+        gemm_f64_tile<true, true, 128, 128, 16, 2, 4, EpiAxpby>(trail, trail_epi, bm, rem, 0, lds);
+        return;
+    }
+    const int s_ = (int)blockIdx.x - 1 - ntrail;
+    const int ntl = (sh.N + SH_BN - 1) / SH_BN, npairs = (ntl + 1) / 2;
+    const int bm = s_ / npairs, pr = s_ % npairs;
+    shadow_tile(sh, bm, pr, slice, nslices, lds);                            // the long K range first
+    if (ntl - 1 - pr != pr) shadow_tile(sh, bm, ntl - 1 - pr, slice, nslices, lds);
 }
 
 
@@ -905,7 +963,8 @@ static int cholesky_lookahead(double* A, double* L, int64_t n, int64_t lda, doub
 // Everything a launch contains depends on earlier LAUNCHES only, so the parts run side by side on the chip and the serial chain
 // per step is leaf + spine step + two kernel boundaries (~48 us) instead of leaf + panel + trailing update + three (~65 us) — with
 // one stream, i.e. without the parallel graph branches that sank cholesky_lookahead.
-static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, double* invw, int* info, hipStream_t st) {
+static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, double* invw, int* info, hipStream_t st,
+                                const ShadowJob* shadow = nullptr) {
     const int nb = (int)(n / NB);
     hipLaunchKernelGGL(zero_f64_kernel, dim3(1024), dim3(256), 0, st, invw, inv_doubles(n));
     for (int j = 0; j < nb; ++j) {
@@ -923,9 +982,11 @@ static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, do
                 const int Mb = M / NB;
                 ntiles = Mb * (Mb + 3) / 2;
             }
+            ShadowJob sh{};
+            if (shadow) sh = *shadow;
             ScopedProf sp(KC_CHOL_LEAF, st);
-            hipLaunchKernelGGL(chol_step_leaf_kernel, dim3(1 + ntiles), dim3(LEAF_T), 0, st, A + o * lda + o, lda, L + o * lda + o, lda,
-                               inv, (int64_t)OB, info, (int)o, tr, te);
+            hipLaunchKernelGGL(chol_step_leaf_kernel, dim3(1 + ntiles + sh.wgs), dim3(LEAF_T), 0, st, A + o * lda + o, lda,
+                               L + o * lda + o, lda, inv, (int64_t)OB, info, (int)o, tr, te, ntiles, sh, j, nb);
         }
         if (j == nb - 1) break;
         {   // B_j
@@ -952,14 +1013,21 @@ static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, do
 // (A two-stream look-ahead schedule — spine leaf -> one panel block -> diagonal update on the caller's stream, bulk
 // panel/trailing on a side stream — was built and measured 6-11 % SLOWER, eager and as a graph: the leaf needs a
 // whole CU's LDS, so it cannot start while the bulk GEMM keeps every CU populated.  Kept serial.)
-static int cholesky_impl(double* A, double* L, int64_t dp, int64_t lda, double* invw, int* info, hipStream_t st) {
+static inline bool cholesky_takes_shadow(int64_t dp) {      // the schedule whose leaf launches can carry a ShadowJob
+    static const int lookahead = env_flag("EMCID_CHOL_LOOKAHEAD", 0), fused = env_flag("EMCID_CHOL_FUSED", 1);
+    return !lookahead && fused && dp <= 2048 && dp >= 2 * NB;
+}
+
+static int cholesky_impl(double* A, double* L, int64_t dp, int64_t lda, double* invw, int* info, hipStream_t st,
+                         const ShadowJob* shadow = nullptr) {
     // Off by default: measured on MI355X / ROCm 7.2 (bench.py device step, 4 layers, N = 1000): 13.3 ms serial -> 22.3 ms with the
     // look-ahead schedule inside the captured graph — every fork/join between the two capture streams costs ~70 us of graph
     // execution — and 14.2 ms with both run eagerly (host-launch bound).  Kept for the day parallel graph branches are cheap.
     static const int lookahead = env_flag("EMCID_CHOL_LOOKAHEAD", 0);
     if (lookahead && dp <= 2048 && dp >= 2 * NB) return cholesky_lookahead(A, L, dp, lda, invw, info, st);
     static const int fused = env_flag("EMCID_CHOL_FUSED", 1);
-    if (fused && dp <= 2048 && dp >= 2 * NB) return cholesky_fused_steps(A, L, dp, lda, invw, info, st);
+    if (fused && dp <= 2048 && dp >= 2 * NB) return cholesky_fused_steps(A, L, dp, lda, invw, info, st, shadow);
+    if (shadow) return fail(EMCID_ERR_BAD_ARG, "cholesky_impl", "shadow job without the fused schedule");
     return cholesky_serial(A, L, dp, lda, invw, info, st);
 }
 
@@ -1792,28 +1860,53 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
     const int64_t dp = ws.dp, Np = ws.Np, hp = ws.hp, s_mat = dp * dp;
     const double* Lb = (const double*)cov_factor_ws + n_layers * s_mat + layer_index * s_mat;
     const double* Ib = (const double*)cov_factor_ws + 2 * n_layers * s_mat + layer_index * inv_doubles(dp);
+    // P = Yt X rides in the Cholesky's leaf launches (ShadowJob) when X is explicit and the fused schedule runs: then
+    // U = Z^T P is one GEMM and the GEMM against the triangle after the N x N solve (U = (Z^T Yt) X) disappears from the chain
+    static const int shadow_env = env_flag("EMCID_SHADOW_P", 1);
+    const bool shadow = shadow_env && use_inverse && cholesky_takes_shadow(Np);
+    double* P = base + ws.off_P;
+    const double* X = use_inverse ? cov_inverse(cov_factor_ws, n_layers, dp, layer_index) : nullptr;
     EMCID_TRY(with_graph(make_key(6, {Yt, R, S, LS, RT, V, U, info_dev},
-                                  {dp, Np, N, hp, (int64_t)(uintptr_t)Lb, use_inverse + 2 * (assembled != 0)}), st,
+                                  {dp, Np, N, hp, (int64_t)(uintptr_t)Lb, use_inverse + 2 * (assembled != 0) + 4 * (int)shadow}), st,
                          [&](hipStream_t q) {
         if (!assembled) {
             if (Np > N) hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, q, Yt + N * dp, (Np - N) * dp);
             assemble_dual_system(Yt, Yt, dp, S, (int)Np, q, base + ws.off_SK);      // S = I + Yt Yt^T (lower tiles)
         }
-        EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q));
+        ShadowJob job{Yt, dp, X, dp, P, dp, (int)Np, (int)dp, (int)dp, 0};
+        job.wgs = (int)((Np + SH_BM - 1) / SH_BM) * (int)(((dp + SH_BN - 1) / SH_BN + 1) / 2);
+        EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q, shadow ? &job : nullptr));
         // RT[h, Np] = Rt^T ; Z^T = RT S^-1 (two solves with h rows)
         hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)((hp + 31) / 32), (unsigned)(Np / 32)), dim3(256), 0, q, R, hp, RT,
                            Np, (int)Np, (int)hp);
-        EMCID_TRY(cholesky_solve_impl(LS, Np, Np, invS, RT, Y2, h, Np, q));
+        // Z^T = RT S^-1.  As block substitution this is 6 dependent launches on h rows (~140 us at N = 1000, latency-bound); with
+        // XS = inv(LS) made explicit (one more halving level on top of the 512-block inverses, into S, which the factorization has
+        // consumed) it is two GEMMs against a triangle:  Z^T = (RT XS^T) XS.   EMCID_S_INVERSE=0 keeps the substitution.
+        static const int s_inverse = env_flag("EMCID_S_INVERSE", 1);
+        if (s_inverse && Np <= 4096) {
+            EMCID_TRY(build_full_inverse(LS, Np, Np, invS, S, Y2, 1, 0, 0, q));
+            ScopedProf sp(KC_TRSM_DIAG, q);
+            GemmShape f{RT, Np, S, Np, (int)h, (int)Np, (int)Np, 0};
+            f.tri = 1;       // B(k, n) = XS[n][k], zero for k > n
+            f.pair = 1;
+            launch_gemm_f64<true, true>(f, EpiAxpby{Y2, Np, 1.0, 0.0}, q);
+            GemmShape b{Y2, Np, S, Np, (int)h, (int)Np, (int)Np, 0};
+            b.tri = 2;       // B(k, n) = XS[k][n], zero for k < n
+            b.pair = 1;
+            launch_gemm_f64<true, false>(b, EpiAxpby{RT, Np, 1.0, 0.0}, q);
+        } else {
+            EMCID_TRY(cholesky_solve_impl(LS, Np, Np, invS, RT, Y2, h, Np, q));
+        }
         {
-            ScopedProf sp(KC_DELTA_W, q);       // V[h, dp] = Z^T Yt
-            GemmShape g{RT, Np, Yt, dp, (int)h, (int)dp, (int)Np, 0};
-            launch_gemm_f64<true, false>(g, EpiAxpby{V, dp, 1.0, 0.0}, q);
+            ScopedProf sp(KC_DELTA_W, q);       // U[h, dp] = Z^T P  (shadow)  or  V[h, dp] = Z^T Yt
+            GemmShape g{RT, Np, shadow ? P : Yt, dp, (int)h, (int)dp, (int)Np, 0};
+            launch_gemm_f64<true, false>(g, EpiAxpby{shadow ? U : V, dp, 1.0, 0.0}, q);
         }
         if (!use_inverse) trsm_backward(Lb, dp, dp, Ib, V, U, (int)h, dp, q);   // U L = V by block substitution
         return check_launch("emcid_edit_dual_apply_stage2_f64");
     }));
-    if (use_inverse)   // U = V inv(L)  (V's padding columns are zero: Kt's are, X is the identity there)
-        apply_inverse_backward(cov_inverse(cov_factor_ws, n_layers, dp, layer_index), dp, V, (int)h, (int)dp, U, dp, st, base + ws.off_SK);
+    if (use_inverse && !shadow)   // U = V inv(L)  (V's padding columns are zero: Kt's are, X is the identity there)
+        apply_inverse_backward(X, dp, V, (int)h, (int)dp, U, dp, st, base + ws.off_SK);
     hipLaunchKernelGGL(apply_u2d_kernel, dim3((unsigned)h), dim3(256), 0, st, U, dp, W0, W, dW_out, (int)d);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;

@@ -180,7 +180,8 @@ def load_v_stars(requests: Sequence[Dict], hparams, cache_name: Optional[str], s
                     f"no cached v* for request {idx} ([{request['source']}] -> [{request['dest']}]) at {f}: "
                     f"pass cache_name pointing at v_star npz files (reference emcid_main.py:873-890) or a stage1= "
                     f"callable (emcid_amd.compute_z.compute_z_text_encoder is the reference's Stage 1)")
-            v = stage1(request, suffix).detach().float().cpu().numpy()
+            with torch.enable_grad():      # Stage 1 is an optimisation through the UNet, whatever mode the caller is in
+                v = stage1(request, suffix).detach().float().cpu().numpy()
             if f is not None:
                 Path(f).parent.mkdir(exist_ok=True, parents=True)
                 np.savez(f, v_star=v)
@@ -205,6 +206,32 @@ def _shard_from_env(shard: Optional[ConceptShard]) -> ConceptShard:
     return ConceptShard()
 
 
+def _any_vstar_missing(requests: Sequence[Dict], hparams, cache_name: Optional[str], suffix: str) -> bool:
+    """True when some request has no v* file: one directory listing per cache directory instead of a stat per request
+    (the per-file validation by mtime/size happens later, underneath the GPU's forward)."""
+    listing: Dict[str, set] = {}
+    pre = cache_name if isinstance(cache_name, str) else None
+    pre_dir, pre_base = os.path.split(pre) if pre is not None else ("", "")
+    for idx, request in enumerate(requests):
+        f = vstar_cache_name(cache_name, request, hparams, idx, suffix)
+        if f is None:
+            return True
+        if pre is not None and f.startswith(pre) and "/" not in f[len(pre):]:
+            d, base = pre_dir, pre_base + f[len(pre):]        # the usual case: every file sits in cache_name's directory
+        else:
+            d, base = os.path.split(f)
+        names = listing.get(d)
+        if names is None:
+            try:
+                names = set(os.listdir(d or "."))
+            except OSError:
+                return True
+            listing[d] = names
+        if base not in names:
+            return True
+    return False
+
+
 class _LazyVstars:
     """The v* rows of a request list, read when first asked for.  prepare hands this to the engine, which asks at the first
     edited layer's solve — by then the encoder forward up to that layer is queued on the GPU, so the file-system calls of
@@ -221,6 +248,10 @@ def prepare_text_encoder_edit(text_encoder, tokenizer, requests, hparams, layers
                               suffix="", verbose=True, shard=None, stage1=None) -> EncoderEditPlan:
     """Host side of one encoder's edit: v* rows, C per layer (HBM-resident), tokenized prompts + lookup."""
     zs_future = _LazyVstars(requests, hparams, cache_name, suffix, stage1)
+    if _any_vstar_missing(requests, hparams, cache_name, suffix):
+        # a cache miss is handled FIRST, as the reference does (:873-969 come before the layer loop's covariance reads): Stage 1
+        # runs (or the miss is reported) before statistics are read or computed and before anything is launched
+        zs_future = load_v_stars(requests, hparams, cache_name, suffix, stage1)
     covs = {layer: get_cov_text_encoder(text_encoder, tokenizer, hparams.rewrite_module_tmp.format(layer),
                                         hparams.mom2_dataset, hparams.mom2_n_samples, hparams.mom2_dtype,
                                         stat_dir=stat_dir, verbose=verbose)
@@ -578,15 +609,16 @@ def apply_emcid_to_sdxl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
         return pipe, o1, o2
     p1, p2 = _sdxl_plans(pipe, requests, hparams, cache_name, stat_dir, stat_dir_2, verbose, shard, stage1)
     # The two encoders are independent models (:1233 vs :1333): run them on two HIP streams.
-    s2 = torch.cuda.Stream(device=p2.zs_t.device)
-    s2.wait_stream(torch.cuda.current_stream(p2.zs_t.device))
+    dev2 = next(pipe.text_encoder_2.parameters()).device      # (v* may still be a pending upload: plan.zs_t is set lazily)
+    s2 = torch.cuda.Stream(device=dev2)
+    s2.wait_stream(torch.cuda.current_stream(dev2))
     e1 = run_encoder_edit(p1, keep_factors=False, restore=False)
     with torch.cuda.stream(s2):
         e2 = run_encoder_edit(p2, keep_factors=False, restore=False)
         if SDXL_TE2_DOUBLE_APPLY:   # execute left TE2 edited, apply adds the update once more (:93-99)
             for e in e2:
                 hip.axpy_(nethook.get_parameter(pipe.text_encoder_2, e.weight_name).data, e.dW)
-    torch.cuda.current_stream(p2.zs_t.device).wait_stream(s2)
+    torch.cuda.current_stream(dev2).wait_stream(s2)
 
     def double_apply(edits):
         for e in edits:

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 3
 _LIB = None
 _LOCK = threading.Lock()
 
@@ -48,6 +48,20 @@ def load():
         lib.emcid_bpe_encode_batch.argtypes = [P, P, P, I64, I32, I32, I32, I32, P, P, P]
         lib.emcid_find_token_ranges.restype = I64
         lib.emcid_find_token_ranges.argtypes = [P, I64, I64, P, P, P, I64, P, P, ctypes.c_char_p, P, P, P]
+        lib.emcid_bpe_encode_templated.restype = I64
+        lib.emcid_bpe_encode_templated.argtypes = [P, P, P, P, P, I64, P, P, I64, P, P, I64, I32, I32, I32, I32, P, P, P]
+        lib.emcid_find_token_ranges_idx.restype = I64
+        lib.emcid_find_token_ranges_idx.argtypes = [P, I64, I64, P, P, P, I64, P, P, P, I64, ctypes.c_int, ctypes.c_char_p, P, P, P]
+        lib.emcid_trie_build.restype = P
+        lib.emcid_trie_build.argtypes = [P, I64, I64, P, I64]
+        lib.emcid_trie_sizes.restype = None
+        lib.emcid_trie_sizes.argtypes = [P, P, P, P, P]
+        lib.emcid_trie_packed_bytes.restype = I64
+        lib.emcid_trie_packed_bytes.argtypes = [P]
+        lib.emcid_trie_export.restype = ctypes.c_int
+        lib.emcid_trie_export.argtypes = [P, P, I64]
+        lib.emcid_trie_destroy.restype = None
+        lib.emcid_trie_destroy.argtypes = [P]
         if lib.emcid_host_abi_version() != ABI_VERSION:
             raise RuntimeError(f"{path}: ABI {lib.emcid_host_abi_version()}, this package needs {ABI_VERSION}; rebuild")
         _LIB = lib
@@ -165,6 +179,26 @@ class NativeClipBpe:
             raise RuntimeError((self._lib.emcid_host_last_error() or b"").decode())
         return ids, lengths, fb.astype(bool)
 
+    def encode_templated(self, pre: Sequence[str], suf: Sequence[str], names: Sequence[str], tmpl_idx: np.ndarray,
+                         name_idx: np.ndarray):
+        """``encode`` of the prompts ``pre[t] + names[k] + suf[t]`` for (t, k) = (tmpl_idx[i], name_idx[i]) without building
+        the strings: (ids (B, max_len), lengths, fallback) exactly as ``encode`` gives for them."""
+        n = len(tmpl_idx)
+        pb, po = pack_strings(pre)
+        sb, so = pack_strings(suf)
+        nb, no = names if isinstance(names, tuple) else pack_strings(names)      # (bytes, offsets) from pack_strings, or strings
+        tmpl_idx = np.ascontiguousarray(tmpl_idx, dtype=np.int32)
+        name_idx = np.ascontiguousarray(name_idx, dtype=np.int32)
+        ids = np.empty((n, self.max_len), dtype=np.int64)
+        lengths = np.empty(n, dtype=np.int32)
+        fb = np.empty(n, dtype=np.uint8)
+        rc = self._lib.emcid_bpe_encode_templated(self._h, pb, _ptr(po), sb, _ptr(so), len(pre), nb, _ptr(no), len(no) - 1,
+                                                  _ptr(tmpl_idx), _ptr(name_idx), n, self.bos, self.eos, self.pad, self.max_len,
+                                                  _ptr(ids), _ptr(lengths), _ptr(fb))
+        if rc < 0:
+            raise RuntimeError((self._lib.emcid_host_last_error() or b"").decode())
+        return ids, lengths, fb.astype(bool)
+
     def tokenize(self, tokenizer, prompts: Sequence[str]) -> Dict[str, np.ndarray]:
         """``tokenizer(prompts, padding=True, truncation=True)`` as (B, S) int64 arrays; flagged rows through ``tokenizer``."""
         ids, lengths, fb = self.encode(prompts)
@@ -231,18 +265,51 @@ class NativeClipBpe:
             and set(want.keys()) == {"input_ids", "attention_mask"}
 
 
-def find_token_ranges(ids: np.ndarray, piece_ns: bytes, piece_off: np.ndarray, piece_len: np.ndarray, subjects: Sequence[str],
-                      forbid: str = ""):
-    """``emcid_find_token_ranges``: (first, last, status) arrays for the rows of ``ids`` (B, S) int64."""
+def find_token_ranges(ids: np.ndarray, piece_ns: bytes, piece_off: np.ndarray, piece_len: np.ndarray, subjects,
+                      forbid: str = "", subject_idx: Optional[np.ndarray] = None, normalize: bool = False):
+    """``emcid_find_token_ranges[_idx]``: (first, last, status) arrays for the rows of ``ids`` (B, S) int64; with
+    ``subject_idx`` row i searches ``subjects[subject_idx[i]]``, else ``subjects[i]``.  ``subjects``: strings, or what
+    ``pack_strings`` made of them.  ``normalize``: the subjects are raw (the library lower-cases and strips spaces)."""
     lib = load()
     ids = np.ascontiguousarray(ids, dtype=np.int64)
     B, S = ids.shape
-    sb, soff = pack_strings(subjects)
+    sb, soff = subjects if isinstance(subjects, tuple) else pack_strings(subjects)
+    n_subjects = len(soff) - 1
     first = np.empty(B, dtype=np.int32)
     last = np.empty(B, dtype=np.int32)
     status = np.empty(B, dtype=np.uint8)
-    rc = lib.emcid_find_token_ranges(_ptr(ids), B, S, piece_ns, _ptr(piece_off), _ptr(piece_len), len(piece_len), sb,
-                                     _ptr(soff), forbid.encode(), _ptr(first), _ptr(last), _ptr(status))
+    if subject_idx is not None:
+        subject_idx = np.ascontiguousarray(subject_idx, dtype=np.int32)
+        if subject_idx.shape != (B,):
+            raise ValueError("subject_idx must have one entry per row")
+    elif n_subjects != B:
+        raise ValueError("one subject per row")
+    rc = lib.emcid_find_token_ranges_idx(_ptr(ids), B, S, piece_ns, _ptr(piece_off), _ptr(piece_len), len(piece_len), sb,
+                                         _ptr(soff), _ptr(subject_idx) if subject_idx is not None else None, n_subjects,
+                                         int(bool(normalize)), forbid.encode(), _ptr(first), _ptr(last), _ptr(status))
     if rc < 0:
         raise RuntimeError((lib.emcid_host_last_error() or b"").decode())
     return first, last, status
+
+
+def build_trie_packed(ids: np.ndarray, lookup: np.ndarray, bucket: int, alloc):
+    """``emcid_trie_build`` + ``emcid_trie_export``: ``alloc(nbytes)`` returns (object, address) of a host buffer (pinned, for an
+    asynchronous upload); returns (object, dict(U, n_real, dmax, R_pad, n)).  Layout: include/emcid_host.h."""
+    lib = load()
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    lookup = np.ascontiguousarray(lookup, dtype=np.int64)
+    n, S = ids.shape
+    h = lib.emcid_trie_build(_ptr(ids), n, S, _ptr(lookup), int(bucket))
+    if not h:
+        raise RuntimeError((lib.emcid_host_last_error() or b"").decode())
+    try:
+        sz = (ctypes.c_int64 * 4)()
+        base = ctypes.addressof(sz)
+        lib.emcid_trie_sizes(h, base, base + 8, base + 16, base + 24)
+        nbytes = lib.emcid_trie_packed_bytes(h)
+        buf, addr = alloc(nbytes)
+        if lib.emcid_trie_export(h, addr, nbytes) != 0:
+            raise RuntimeError((lib.emcid_host_last_error() or b"").decode())
+    finally:
+        lib.emcid_trie_destroy(h)
+    return buf, dict(U=int(sz[0]), n_real=int(sz[1]), dmax=int(sz[2]), R_pad=int(sz[3]), n=n)

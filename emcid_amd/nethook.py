@@ -23,7 +23,29 @@ def _candidates(name):
         yield "text_model." + name
 
 
+def _walk(model, name):
+    """The sub-module at dotted path ``name`` by walking ``_modules`` (O(depth)); None when the path does not exist or
+    the object is not built from ``torch.nn.Module``s (duck-typed encoders take the ``named_*`` tables below)."""
+    obj = model
+    if name:
+        for part in name.split("."):
+            mods = getattr(obj, "_modules", None)
+            if mods is None:
+                return None
+            obj = mods.get(part)
+            if obj is None:
+                return None
+    return obj
+
+
 def get_module(model, name):
+    """``dict(model.named_modules())[name]`` (reference util/nethook.py:375-383), tolerant of the ``text_model.`` prefix.
+    The path is walked directly first: building the name table costs ~0.2 ms on a CLIP text encoder and an edit call
+    resolves a dozen names."""
+    for cand in _candidates(name):
+        m = _walk(model, cand)
+        if m is not None:
+            return m
     table = dict(model.named_modules())
     for cand in _candidates(name):
         if cand in table:
@@ -32,6 +54,14 @@ def get_module(model, name):
 
 
 def get_parameter(model, name):
+    """``dict(model.named_parameters())[name]`` (reference util/nethook.py:385-392), same prefix tolerance, same fast path."""
+    for cand in _candidates(name):
+        owner, _, leaf = cand.rpartition(".")
+        m = _walk(model, owner)
+        if m is not None:
+            p = getattr(m, "_parameters", {}).get(leaf)
+            if p is not None:
+                return p
     table = dict(model.named_parameters())
     for cand in _candidates(name):
         if cand in table:

@@ -50,6 +50,40 @@ int64_t emcid_find_token_ranges(const int64_t* ids, int64_t n, int64_t S, const 
                                 const int32_t* piece_len, int64_t n_pieces, const char* subj, const int64_t* subj_off,
                                 const char* forbid, int32_t* first, int32_t* last, uint8_t* status);
 
+/* emcid_bpe_encode_batch for prompts that are `template.format(name)` with ONE "{}" per template (the mass-edit case: a few
+ * templates x many names; reference compute_z.py:2278-2283 formats every prompt, :65 tokenizes every string): prompt i is
+ * pre[tmpl_idx[i]] + names[name_idx[i]] + suf[tmpl_idx[i]].  Every distinct piece is encoded once and rows are concatenations
+ * whenever white space (or an empty piece) separates the pieces — pre-tokens never span white space — else the formatted text is
+ * encoded as a whole; same ids, lengths and fallback flags as emcid_bpe_encode_batch on the formatted strings. */
+int64_t emcid_bpe_encode_templated(emcid_bpe* m, const char* pre, const int64_t* pre_off, const char* suf, const int64_t* suf_off,
+                                   int64_t n_templates, const char* names, const int64_t* name_off, int64_t n_names,
+                                   const int32_t* tmpl_idx, const int32_t* name_idx, int64_t n, int32_t bos, int32_t eos,
+                                   int32_t pad, int32_t max_len, int64_t* ids, int32_t* lengths, uint8_t* fallback);
+
+/* emcid_find_token_ranges with the subjects given once: row i searches subject subj_idx[i] of n_subj (subj_idx NULL: row i
+ * searches subject i).  normalize != 0: the subjects are the caller's raw strings and are lower-cased and stripped of ' '
+ * here, as find_token_range does (causal_trace.py:1066); its special subjects ("[CLS]", "[EOS]", "", " ") and anything
+ * outside ASCII come back with status 1. */
+int64_t emcid_find_token_ranges_idx(const int64_t* ids, int64_t n, int64_t S, const char* piece_ns, const int64_t* piece_off,
+                                    const int32_t* piece_len, int64_t n_pieces, const char* subj, const int64_t* subj_off,
+                                    const int32_t* subj_idx, int64_t n_subj, int normalize, const char* forbid, int32_t* first,
+                                    int32_t* last, uint8_t* status);
+
+/* The prefix trie of n tokenized prompts, each cut behind its lookup token (the edit's forward runs once per DISTINCT causal
+ * prefix: emcid_amd/clip_forward.py).  Replaces nothing in the reference (which runs the dense batch, compute_z.py:2308); it is
+ * the host-side index build of this implementation's forward, moved out of numpy.  ids: n x S int64 (>= 0), lookup[i] in [0, S).
+ * Nodes are numbered level by level, inside a level by (parent node, token); node and query-row counts are padded to a multiple
+ * of `bucket` (padding nodes: the first root token at depth 0, each attending to itself; padding query rows: the first one).
+ * emcid_trie_export writes ONE packed image (a single host-to-device copy), 8-byte aligned, in this order:
+ *   int64 token[U] | int64 lookup_node[n] | int64 lookup_in_query[n] | int32 depth[U] | int32 query_rows[R_pad] |
+ *   int32 anc[U][dmax]   (ancestor chain root..node, zero padded) */
+typedef struct emcid_trie emcid_trie;
+emcid_trie* emcid_trie_build(const int64_t* ids, int64_t n, int64_t S, const int64_t* lookup, int64_t bucket);
+void emcid_trie_sizes(const emcid_trie* t, int64_t* U, int64_t* n_real, int64_t* dmax, int64_t* R_pad);
+int64_t emcid_trie_packed_bytes(const emcid_trie* t);
+int emcid_trie_export(const emcid_trie* t, void* out, int64_t out_bytes);
+void emcid_trie_destroy(emcid_trie* t);
+
 const char* emcid_host_last_error(void);
 
 #ifdef __cplusplus

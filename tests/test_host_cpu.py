@@ -151,6 +151,27 @@ def test_vectorised_trie_is_the_prefix_set_up_to_the_lookup_tokens():
         assert (anc_np[u, :dep[u]] < u).all() and anc_np[u, dep[u]] == u
 
 
+@pytest.mark.parametrize("B,S,vocab,bucket,seed", [(200, 9, 3, 16, 5), (3000, 7, 50, 256, 6), (17, 1, 4, 1, 7), (64, 77, 2, 256, 8)])
+def test_native_trie_equals_numpy_trie(B, S, vocab, bucket, seed):
+    """libemcid_host's emcid_trie_build (what the edit path runs) and the numpy construction give the same arrays: node
+    numbering, ancestor chains, padding, query rows."""
+    from emcid_amd import clip_forward as cf, host_text
+    if not host_text.available():
+        pytest.skip("libemcid_host.so not built")
+    rng = np.random.default_rng(seed)
+    ids = rng.integers(0, vocab, size=(B, S)).astype(np.int64)
+    ids[:, 0] = 7
+    lookup = rng.integers(0, S, size=B).astype(np.int64)
+    a = cf.build_trie(ids, lookup, "cpu", bucket=bucket)
+    b = cf.build_trie_numpy(ids, lookup, "cpu", bucket=bucket)
+    assert a.n_nodes == b.n_nodes and a.n_tokens_dense == b.n_tokens_dense
+    for f in ("token", "depth", "anc", "lookup_node", "query_rows", "lookup_in_query"):
+        x, y = getattr(a, f), getattr(b, f)
+        assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y), f
+    with pytest.raises(RuntimeError):
+        host_text.build_trie_packed(ids, np.full(B, S, dtype=np.int64), bucket, lambda n: (None, 0))      # lookup outside the row
+
+
 def test_prompt_batch_matches_oracle_lookup():
     tok = syn.build_tokenizer()
     reqs = syn.make_requests(9, ragged=True)
@@ -601,3 +622,61 @@ def test_tokenize_lists_uses_the_native_twin_and_agrees():
     want = tok(prompts, padding=True, truncation=True)
     assert np.array_equal(np.asarray(want["input_ids"]), got["input_ids"])
     assert np.array_equal(np.asarray(want["attention_mask"]), got["attention_mask"])
+
+
+def _chunks_equal(a, b):
+    assert a.n_requests == b.n_requests and list(a.counts) == list(b.counts)
+    assert np.array_equal(np.asarray(a.ids), np.asarray(b.ids)) and np.asarray(a.lookup).tolist() == np.asarray(b.lookup).tolist()
+
+
+def test_templated_prompt_path_equals_generic_path(monkeypatch):
+    """templated_prompt_chunk (prefix/name/suffix encoded once, subjects passed once) against the generic path (every prompt
+    formatted, tokenized and searched as a string): same ids, lookup positions, counts — mass-edit shape, ragged template
+    sets, names with spaces / apostrophes / capitals, a name that also occurs inside a template, glued templates (no white
+    space next to the braces), non-ASCII names (row-wise fallback to the HF tokenizer), 1-prompt requests."""
+    from emcid_amd import compute_z as cz, host_text
+    if not host_text.available():
+        pytest.skip("libemcid_host.so not built")
+    tok = syn.build_tokenizer(*syn.synthetic_vocab(syllables=True))
+    if host_text.NativeClipBpe.for_tokenizer(tok) is None:
+        pytest.skip("no native twin for the synthetic tokenizer")
+
+    def both(reqs, n_chunks=1):
+        monkeypatch.setenv("EMCID_TEMPLATED", "1")
+        fast = list(cz.iter_prompt_chunks(tok, reqs, n_chunks))
+        monkeypatch.setenv("EMCID_TEMPLATED", "0")
+        slow = list(cz.iter_prompt_chunks(tok, reqs, n_chunks))
+        assert len(fast) == len(slow)
+        for a, b in zip(fast, slow):
+            _chunks_equal(a, b)
+        return fast
+
+    reqs = syn.make_requests(300, names="syllable")
+    assert cz.templated_prompt_chunk(tok, reqs, reqs[0]) is not None        # the fast path really serves the bench shape
+    both(reqs)
+    both(reqs, n_chunks=3)
+    names = syn.syllable_names(12)
+    odd = []
+    for i, nm in enumerate(names):
+        src = [nm, nm.upper(), f"{nm} {names[(i + 1) % 12]}", f"{nm}'s", f" {nm}", f"{nm} "][i % 6]
+        tmpls = [["painting by {}", "{} style", "a{}b", "in the style of {} , oil"], ["{}"], ["art by {}", "{}, {}"[:2] + " art"],
+                 [f"{nm} and {{}}"]][i % 4]
+        odd.append({"source": src, "dest": "x", "prompts": tmpls, "seed_train": 1})
+    both(odd)
+    uni = [dict(r) for r in reqs[:9]]
+    uni[4]["prompts"] = ["caf\u00e9 by {}", "{} caf\u00e9"]      # outside ASCII: those rows go through the HF tokenizer
+    both(uni)
+    uni[4]["source"] = "caf\u00e9 " + uni[4]["source"]          # a subject the synthetic vocabulary cannot spell: same error
+    for flag in ("1", "0"):
+        monkeypatch.setenv("EMCID_TEMPLATED", flag)
+        with pytest.raises(ValueError, match="not found in tokens"):
+            list(cz.iter_prompt_chunks(tok, uni, 1))
+    # outside the templated shape: the generic path must serve these (and the fast one must decline)
+    for bad in ([{"source": "ka", "dest": "x", "prompts": ["{0} art", "by {}"], "seed_train": 1}] * 4,
+                [{"source": "ka", "dest": "x", "prompts": ["{{}} {}"], "seed_train": 1}] * 4,
+                [{"source": "ka", "dest": "x", "source_prompts": ["art by ka"], "prompts": ["art by {}"], "seed_train": 1}] * 4):
+        assert cz.templated_prompt_chunk(tok, bad, bad[0]) is None
+        both(bad)
+    with pytest.raises(ValueError):                              # subject not in the prompt: the scalar walk's error
+        monkeypatch.setenv("EMCID_TEMPLATED", "1")
+        list(cz.iter_prompt_chunks(tok, [{"source": "zu", "dest": "x", "prompts": ["art by ka {}"[:9]], "seed_train": 1}] * 4, 1))
