@@ -522,9 +522,15 @@ struct ShadowJob {
     double* C; int64_t ldc;           // [M][N]
     int M, N, K;
     int wgs;                          // workgroups per launch: ceil(M / 64) * ceil(ceil(N / 128) / 2); 0 = no job
+    int skip_xcd0;                    // keep the shadow workgroups off the XCD the leaf runs on
+    int variant;                      // tile pipeline variant (see chol_step_leaf_kernel)
+    long long* stamps;                // diagnostic (usually null): per launch slice and workgroup [start, mid, end, kind]
+    int xcd_gx;                       // > 0: XCD-blocked tile assignment, the 8 XCDs as a xcd_gx x (8 / xcd_gx) grid (set by the launcher)
 };
-constexpr int SH_BM = 64, SH_BN = 128, SH_BK = 16, SH_PF = 3;
+inline long long* g_step_stamps = nullptr;      // set by emcid_debug_step_stamps
+constexpr int SH_BM = 64, SH_BN = 128;
 
+template <int SH_BK, int SH_PF>
 __device__ __forceinline__ void shadow_tile(const ShadowJob& sh, int bm, int bn, int slice, int nslices, double* smem) {
     using TA = OpTile<true, SH_BM, SH_BK>;
     using TB = OpTile<false, SH_BN, SH_BK>;
@@ -534,26 +540,57 @@ __device__ __forceinline__ void shadow_tile(const ShadowJob& sh, int bm, int bn,
     const int per = (depth + nslices - 1) / nslices;
     const int kb = slice * per, ke = min(depth, kb + per);
     if (kb >= ke) return;
-    v4d acc[SH_BM / 2 / 16][SH_BN / 4 / 16];
-    gemm_f64_tile_acc<true, false, SH_BM, SH_BN, SH_BK, 2, 4, SH_PF>(q, bm, bn, smem, kb, ke, acc);
+    constexpr int MI = SH_BM / 2 / 16, NI = SH_BN / 4 / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave / 4) * (SH_BM / 2), wn0 = (wave % 4) * (SH_BN / 4);
     const int l15 = lane & 15, l4 = lane >> 4;
     const int m0 = bm * SH_BM, n0 = bn * SH_BN;
+    // The earlier slices' sum is fetched BEFORE the K loop (the launch before this one wrote it from another compute unit: a
+    // cold read costs ~2.7 us here, scripts/step_stamps.py) and added after it; clamped addresses, so the loads are unconditional
+    v4d prev[MI][NI];
 #pragma unroll
-    for (int i = 0; i < SH_BM / 2 / 16; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < SH_BN / 4 / 16; ++j)
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = min(m0 + wm0 + TA::index_of(i, l4 + 4 * r), sh.M - 1);
+                const int n = min(n0 + wn0 + TB::index_of(j, l15), sh.N - 1);
+                prev[i][j][r] = slice ? sh.C[(int64_t)m * sh.ldc + n] : 0.0;
+            }
+    __builtin_amdgcn_sched_barrier(0);      // keep those loads up here
+    v4d acc[MI][NI];
+    gemm_f64_tile_acc<true, false, SH_BM, SH_BN, SH_BK, 2, 4, SH_PF>(q, bm, bn, smem, kb, ke, acc);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm0 + TA::index_of(i, l4 + 4 * r);
                 const int n = n0 + wn0 + TB::index_of(j, l15);
-                if (m < sh.M && n < sh.N) {
-                    double* c = sh.C + (int64_t)m * sh.ldc + n;
-                    *c = slice ? *c + acc[i][j][r] : acc[i][j][r];
-                }
+                if (m < sh.M && n < sh.N) sh.C[(int64_t)m * sh.ldc + n] = prev[i][j][r] + acc[i][j][r];
             }
     __syncthreads();      // the next tile's first LDS store must not overtake this tile's last MFMA stage
+}
+
+template <int SH_BK, int SH_PF>
+__device__ __forceinline__ void shadow_pair(const ShadowJob& sh, int s_, int slice, int nslices, double* lds) {
+    const int ntl = (sh.N + SH_BN - 1) / SH_BN, npairs = (ntl + 1) / 2;
+    int bm = s_ / npairs, pr = s_ % npairs;
+    if (sh.xcd_gx > 0) {
+        // The workgroups of a launch go to the 8 XCDs round-robin by id, so shadow workgroups s_ = g (mod 8) share an L2.  Give
+        // each XCD a compact gx x gy block of the (row tile, column pair) grid: its 24 workgroups then re-read each other's A and
+        // B tiles out of their own L2 (B: half of the X slice, 2.4 MB at d = 3072) instead of all 192 streaming everything from
+        // the Infinity Cache — the K loop here is bound by that traffic, not by the matrix pipe (scripts/step_stamps.py).
+        const int mb = (sh.M + SH_BM - 1) / SH_BM;
+        const int g = s_ & 7, r = s_ >> 3;
+        const int gy = 8 / sh.xcd_gx, rows = mb / sh.xcd_gx, cols = npairs / gy;
+        bm = (g / gy) * rows + r / cols;
+        pr = (g % gy) * cols + r % cols;
+    }
+    shadow_tile<SH_BK, SH_PF>(sh, bm, pr, slice, nslices, lds);                            // the long K range first
+    if (ntl - 1 - pr != pr) shadow_tile<SH_BK, SH_PF>(sh, bm, ntl - 1 - pr, slice, nslices, lds);
 }
 
 // One launch = the leaf of block j (workgroup 0) AND the trailing update of step j-1 that the leaf does not depend on (the other
@@ -565,8 +602,11 @@ __global__ __launch_bounds__(LEAF_T) void chol_step_leaf_kernel(const double* __
                                                                  int col0, GemmShape trail, EpiAxpby trail_epi, int ntrail,
                                                                  ShadowJob sh, int slice, int nslices) {
     __shared__ __attribute__((aligned(16))) double lds[LEAF_LDS];
+    long long* stamp = (sh.stamps && blockIdx.x < 512) ? sh.stamps + ((int64_t)slice * 512 + blockIdx.x) * 4 : nullptr;
+    if (stamp && threadIdx.x == 0) stamp[0] = (long long)__builtin_amdgcn_s_memrealtime();
     if (blockIdx.x == 0) {
         chol_leaf_body(A, lda, L, ldl, inv, ldinv, info, col0, nullptr, lds);
+        if (stamp && threadIdx.x == 0) { stamp[2] = (long long)__builtin_amdgcn_s_memrealtime(); stamp[3] = 1; }
         return;
     }
     if ((int)blockIdx.x <= ntrail) {
@@ -574,13 +614,25 @@ __global__ __launch_bounds__(LEAF_T) void chol_step_leaf_kernel(const double* __
         int bm = 0, rem = (int)blockIdx.x - 1;
         while (rem >= bm + 2) { rem -= bm + 2; ++bm; }
         gemm_f64_tile<true, true, 128, 128, 16, 2, 4, EpiAxpby>(trail, trail_epi, bm, rem, 0, lds);
+        if (stamp && threadIdx.x == 0) { stamp[2] = (long long)__builtin_amdgcn_s_memrealtime(); stamp[3] = 2; }
         return;
     }
-    const int s_ = (int)blockIdx.x - 1 - ntrail;
-    const int ntl = (sh.N + SH_BN - 1) / SH_BN, npairs = (ntl + 1) / 2;
-    const int bm = s_ / npairs, pr = s_ % npairs;
-    shadow_tile(sh, bm, pr, slice, nslices, lds);                            // the long K range first
-    if (ntl - 1 - pr != pr) shadow_tile(sh, bm, ntl - 1 - pr, slice, nslices, lds);
+    int s_ = (int)blockIdx.x - 1 - ntrail;
+    if (sh.skip_xcd0) {
+        // workgroups go to the 8 XCDs round-robin by linear id: those that would land on the leaf's XCD (id % 8 == 0) leave at
+        // once, so that XCD runs the leaf (and a few trailing tiles) alone, at its own clock, while the other seven carry the
+        // shadow product (the grid is enlarged by 8/7 accordingly)
+        if ((blockIdx.x & 7) == 0) return;
+        s_ -= (int)((blockIdx.x + 7) / 8) - (1 + ntrail + 7) / 8;
+        if (s_ >= sh.wgs) return;
+    }
+    switch (sh.variant) {          // experiments (EMCID_SHADOW_VARIANT): K-tile depth / loads in flight / LDS fragment prefetch
+        case 1: shadow_pair<32, 2>(sh, s_, slice, nslices, lds); break;
+        case 2: shadow_pair<16, 13>(sh, s_, slice, nslices, lds); break;
+        case 3: shadow_pair<32, 12>(sh, s_, slice, nslices, lds); break;
+        default: shadow_pair<16, 3>(sh, s_, slice, nslices, lds); break;
+    }
+    if (stamp && threadIdx.x == 0) { stamp[2] = (long long)__builtin_amdgcn_s_memrealtime(); stamp[3] = 3; }
 }
 
 
@@ -984,9 +1036,25 @@ static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, do
             }
             ShadowJob sh{};
             if (shadow) sh = *shadow;
+            static const int skip0 = env_flag("EMCID_SHADOW_SKIP_XCD0", 0);
+            static const int dbg_scale = env_flag("EMCID_SHADOW_DEBUG_SCALE", 1);   // timing experiments only (> 1: part of P is never computed)
+            sh.skip_xcd0 = skip0;
+            static const int variant = env_flag("EMCID_SHADOW_VARIANT", 0);
+            sh.variant = variant;
+            sh.stamps = g_step_stamps;
+            sh.xcd_gx = 0;
+            static const int xcd_block = env_flag("EMCID_SHADOW_XCD_BLOCK", 1);
+            if (xcd_block && sh.wgs && !skip0 && sh.wgs % 8 == 0) {
+                const int mb = (sh.M + SH_BM - 1) / SH_BM, np_ = ((sh.N + SH_BN - 1) / SH_BN + 1) / 2;
+                // (shadow ids with the same s_ % 8 land on the same XCD whatever the id of the first one is)
+                for (int gx : {4, 2, 8, 1})
+                    if (mb % gx == 0 && np_ % (8 / gx) == 0) { sh.xcd_gx = gx; break; }
+            }
+            // with skip_xcd0 one id in eight is a no-op: enough ids that sh.wgs of them are not multiples of 8
+            const int shadow_ids = (sh.wgs && skip0) ? (sh.wgs * 8 + 6) / 7 + 8 : sh.wgs;
             ScopedProf sp(KC_CHOL_LEAF, st);
-            hipLaunchKernelGGL(chol_step_leaf_kernel, dim3(1 + ntiles + sh.wgs), dim3(LEAF_T), 0, st, A + o * lda + o, lda,
-                               L + o * lda + o, lda, inv, (int64_t)OB, info, (int)o, tr, te, ntiles, sh, j, nb);
+            hipLaunchKernelGGL(chol_step_leaf_kernel, dim3(1 + ntiles + shadow_ids), dim3(LEAF_T), 0, st, A + o * lda + o, lda,
+                               L + o * lda + o, lda, inv, (int64_t)OB, info, (int)o, tr, te, ntiles, sh, j, nb * dbg_scale);
         }
         if (j == nb - 1) break;
         {   // B_j
@@ -1495,6 +1563,14 @@ int emcid_dgemm_streamk_f64(int tb, int64_t M, int64_t N, int64_t K, double alph
 /* diagnostic: later two-phase stream-K launches write 8 shader-clock values per workgroup to stamps_dev (NULL: stop) —
  * [0] start, [1] end, cycles in [2] K loops, [3] partial-tile publishes, [4] last-ticket reductions, [5] epilogues,
  * [6] segments, [7] run index */
+/* diagnostic: chol_step_leaf_kernel writes, per launch slice s < 16 and workgroup b < 512, [start, -, end, kind] (constant
+ * 100 MHz clock; kind 1 leaf, 2 trailing tile, 3 shadow tile pair) at stamps_dev[(s * 512 + b) * 4]; null switches it off.
+ * Set it before the first edit of the process (captured graphs keep the pointer they were captured with). */
+int emcid_debug_step_stamps(long long* stamps_dev) {
+    g_step_stamps = stamps_dev;
+    return EMCID_OK;
+}
+
 int emcid_debug_streamk_stamps(long long* stamps_dev) {
     g_streamk_stamps = stamps_dev;
     return EMCID_OK;
@@ -1873,7 +1949,7 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
             if (Np > N) hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, q, Yt + N * dp, (Np - N) * dp);
             assemble_dual_system(Yt, Yt, dp, S, (int)Np, q, base + ws.off_SK);      // S = I + Yt Yt^T (lower tiles)
         }
-        ShadowJob job{Yt, dp, X, dp, P, dp, (int)Np, (int)dp, (int)dp, 0};
+        ShadowJob job{Yt, dp, X, dp, P, dp, (int)Np, (int)dp, (int)dp, 0, 0, 0, nullptr, 0};
         job.wgs = (int)((Np + SH_BM - 1) / SH_BM) * (int)(((dp + SH_BN - 1) / SH_BN + 1) / 2);
         EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q, shadow ? &job : nullptr));
         // RT[h, Np] = Rt^T ; Z^T = RT S^-1 (two solves with h rows)

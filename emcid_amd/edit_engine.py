@@ -43,6 +43,12 @@ class ConceptShard:
     rank: int = 0
     world: int = 1
     group: object = None
+    force_collectives: bool = False      # run the multi-rank code path (collectives, column-sharded solve) even at world size 1:
+                                         # lets ONE GPU exercise the RCCL calls on HBM buffers (tests/test_dist_gpu.py)
+
+    @property
+    def collective(self) -> bool:
+        return self.world > 1 or self.force_collectives
 
     def bounds(self, n: int, r: Optional[int] = None):
         r = self.rank if r is None else r
@@ -319,7 +325,7 @@ def _all_reduce_sum(t: torch.Tensor, group):
 def _all_gather_rows(local: torch.Tensor, plan: EncoderEditPlan) -> torch.Tensor:
     """Concatenate per-rank row blocks (uneven shards allowed) in rank order == request order."""
     sh = plan.shard
-    if sh.world == 1:
+    if not sh.collective:
         return local
     import torch.distributed as dist
 
@@ -403,7 +409,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                 # factorization instead (batched, underneath the forward — costs the forward more than it hides).
                 first_x = min(L, max(0, int(os.environ.get("EMCID_INVERSE_FROM", "1"))))
                 lazy = os.environ.get("EMCID_INVERSE_LAZY", "1") != "0" and keep_factors is False
-                if plan.shard.world > 1 and not keep_factors and -(-d // hip.NB) >= plan.shard.world:
+                if plan.shard.collective and not keep_factors and -(-d // hip.NB) >= plan.shard.world:
                     first_x, lazy = 0, False      # the column-sharded solve multiplies by X in every layer
                 fac_done = [chol_done] * L
                 if lazy and first_x == 0:      # the first layer's X right behind the factorization, the others one layer ahead
@@ -437,7 +443,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
         if dual:
             if fac_done is not None:
                 torch.cuda.current_stream(dev).wait_event(fac_done[i])
-            sharded = plan.shard.world > 1
+            sharded = plan.shard.collective
             if not keep_factors:   # only the edited weights are wanted: the form that never builds adj_k
                 def lazy_inverse(nxt=i + 1):
                     # stream position: S of layer i is assembled, its Cholesky starts now -> build X of the next layer
@@ -492,7 +498,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
             edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], xt, res["Rt"],
                                    K if trace else None, Zc if trace else None))
             return
-        if plan.shard.world > 1 and not keep_factors:
+        if plan.shard.collective and not keep_factors:
             # every rank assembles and factors A from all N concepts; the triangular solves and the dW
             # contraction are split by concept rows and the partial U summed over xGMI (fp64, h*d*8 bytes)
             res = hip.edit_layer_shard(K, Zc, plan.zs_t, plan.covs[layer], plan.lam, plan.edit_weight, L - i,

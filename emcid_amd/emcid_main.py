@@ -201,35 +201,54 @@ def _shard_from_env(shard: Optional[ConceptShard]) -> ConceptShard:
     if shard is not None:
         return shard
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        return ConceptShard(dist.get_rank(), dist.get_world_size(), None)
+    if dist.is_available() and dist.is_initialized():
+        force = os.environ.get("EMCID_FORCE_COLLECTIVES", "0") == "1"
+        if dist.get_world_size() > 1 or force:
+            return ConceptShard(dist.get_rank(), dist.get_world_size(), None, force_collectives=force)
     return ConceptShard()
 
 
+_DIR_LISTINGS: Dict[str, Tuple[int, frozenset]] = {}      # directory -> (its st_mtime_ns, its entries): a listing is re-read only
+                                                           # when the directory changed (a file added or removed bumps mtime)
+
+
+def _dir_entries(d: str) -> Optional[frozenset]:
+    try:
+        m = os.stat(d or ".").st_mtime_ns
+        hit = _DIR_LISTINGS.get(d)
+        if hit is None or hit[0] != m:
+            hit = _DIR_LISTINGS[d] = (m, frozenset(os.listdir(d or ".")))
+            if len(_DIR_LISTINGS) > 64:
+                _DIR_LISTINGS.pop(next(iter(_DIR_LISTINGS)))
+        return hit[1]
+    except OSError:
+        return None
+
+
 def _any_vstar_missing(requests: Sequence[Dict], hparams, cache_name: Optional[str], suffix: str) -> bool:
-    """True when some request has no v* file: one directory listing per cache directory instead of a stat per request
-    (the per-file validation by mtime/size happens later, underneath the GPU's forward)."""
-    listing: Dict[str, set] = {}
-    pre = cache_name if isinstance(cache_name, str) else None
-    pre_dir, pre_base = os.path.split(pre) if pre is not None else ("", "")
-    for idx, request in enumerate(requests):
-        f = vstar_cache_name(cache_name, request, hparams, idx, suffix)
-        if f is None:
-            return True
-        if pre is not None and f.startswith(pre) and "/" not in f[len(pre):]:
-            d, base = pre_dir, pre_base + f[len(pre):]        # the usual case: every file sits in cache_name's directory
+    """True when some request has no v* file: one directory listing per cache directory (re-read only when the directory's
+    mtime moved) instead of a stat per request; the per-file validation by mtime/size happens later, underneath the GPU's
+    forward.  A stale answer is harmless either way: "missing" takes the eager path, which opens the files; "present" takes
+    the lazy one, which handles a file that is gone exactly like the eager one, just later."""
+    if cache_name is None:
+        return True
+    pre = str(cache_name)
+    try:
+        if "esd" in hparams.objective:
+            tails = [f"source_{r['source']}{suffix}.npz" for r in requests]
+        elif getattr(hparams, "sld_supervision", False):
+            tails = [f"source_{r['source_cat']}_{i}{suffix}.npz" for i, r in enumerate(requests)]
         else:
-            d, base = os.path.split(f)
-        names = listing.get(d)
-        if names is None:
-            try:
-                names = set(os.listdir(d or "."))
-            except OSError:
-                return True
-            listing[d] = names
-        if base not in names:
-            return True
-    return False
+            tails = [f"source_{r['source']}_dest_{r['dest']}{suffix}.npz" for r in requests]
+    except KeyError:
+        return True                                        # the eager path raises the reference's KeyError
+    if any("/" in t for t in tails):                       # a source with a path separator: per-file check
+        return not all(os.path.exists(pre + t) for t in tails)
+    pre_dir, pre_base = os.path.split(pre)
+    names = _dir_entries(pre_dir)
+    if names is None:
+        return True
+    return not names.issuperset(pre_base + t for t in tails) if pre_base else not names.issuperset(tails)
 
 
 class _LazyVstars:

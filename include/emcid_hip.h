@@ -28,7 +28,7 @@ extern "C" {
 #define EMCID_ERR_HIP (-2)
 #define EMCID_ERR_WORKSPACE (-3)
 
-#define EMCID_ABI_VERSION 6
+#define EMCID_ABI_VERSION 7
 
 /* ABI version of the loaded library (host-only, no GPU needed). */
 int emcid_abi_version(void);
@@ -283,6 +283,9 @@ int emcid_dgemm_streamk_f64(int tb, int64_t M, int64_t N, int64_t K, double alph
 /* Diagnostic: until called again with NULL, every two-phase stream-K launch writes 8 int64 shader-clock values per workgroup
  * to stamps_dev (start, end, cycles in K loops / partial publishes / last-ticket reductions / epilogues, segments, run). */
 int emcid_debug_streamk_stamps(long long* stamps_dev);
+/* diagnostic: per-workgroup start/end stamps of the fused Cholesky step launches (leaf + trailing tiles + shadow product);
+ * layout in csrc/spd_solve.hip; scripts/step_stamps.py reads it. */
+int emcid_debug_step_stamps(long long* stamps_dev);
 
 /* `batch` independent problems of one shape: C_b = alpha * opA(A_b) opB(B_b) + beta * C_b with A_b = A + b*sA etc.
  * (element strides).  Used for the per-edit Grams sum_r k_r k_r^T of the UCE closed form (reference

@@ -57,3 +57,17 @@ for seg in calls[-n_calls:]:
             before = max((r for r in seg if r[1] <= a), key=lambda r: r[1])
             after = min((r for r in seg if r[0] >= b), key=lambda r: r[0])
             print(f"   gap {(b - a) / 1e3:7.1f} us at +{(a - t0) / 1e3:8.0f} us   after [{short(before[2])}]  before [{short(after[2])}]")
+
+# per-kernel totals over the last n_calls segments (steady state: the first call's tuning launches are far behind)
+from collections import defaultdict
+tot = defaultdict(lambda: [0, 0])
+nseg = 0
+for seg in calls[-n_calls:]:
+    nseg += 1
+    for s_, e_, n_ in seg:
+        k = short(n_)
+        tot[k][0] += e_ - s_
+        tot[k][1] += 1
+print(f"--- kernel totals per segment (mean over {nseg} segments), us: name, launches, total, mean")
+for k, (t, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:40]:
+    print(f"   {k:72s} {c / nseg:7.1f} {t / nseg / 1e3:9.1f} {t / c / 1e3:8.2f}")

@@ -217,3 +217,101 @@ def test_two_ranks_sdxl_matches_reference_golden(tmp_path, split):
             dw_ref = z[f"w_final{sfx}/{li}"].astype(np.float64) - w0
             err = np.abs((r0[f"{tag}/{ln}"].astype(np.float64) - w0) - dw_ref).max()
             assert err < 1e-4 and err <= 1e-4 * np.abs(dw_ref).max(), (tag, li, err)
+
+
+# ---- RCCL itself, on the one GPU of the test box ---------------------------------------------------------------------------------
+# The two-rank tests above share one GPU, which RCCL refuses ("duplicate GPU"), so they run under gloo with the collectives
+# staged through the host.  What they cannot show is the production path: backend "nccl" (= RCCL on ROCm) working directly on
+# HBM buffers.  These tests run that path in a ONE-rank RCCL process group with EMCID_FORCE_COLLECTIVES=1, which sends a world
+# of one through the multi-rank code (K all-gather, column-sharded solve with its two fp64 all-reduces, Stage-0 all-reduce,
+# weight broadcast): same calls, same dtypes, same buffers as at 8 ranks — only the peers are missing.
+
+def _rccl_worker(rank, world, port, tmp, n_req, kind):
+    import json
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", EMCID_FORCE_COLLECTIVES="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        assert dist.get_backend() == "nccl"
+        from emcid_amd import emcid_main as em, edit_engine, synthetic as syn
+        from emcid_amd.emcid_hparams import EMCIDHyperParams
+        from emcid_amd.nethook import get_parameter
+        assert em._shard_from_env(None).collective and not edit_engine._staged(None)
+        if kind == "toy":
+            reqs, hp_d, names, cache = _setup(tmp, n_req)
+            pipe = syn.build_pipe("toy", "cuda:0")
+            hp, kw, stats = EMCIDHyperParams(**hp_d), {}, tmp + "/stats"
+        else:
+            meta = json.load(open(tmp + "/meta.json"))
+            reqs = syn.make_requests(meta["n_requests"], names="syllable")
+            pipe = syn.build_pipe(meta["kind"], "cuda:0", syllables=True)
+            names, cache, stats = meta["layer_names"], tmp + "/cache/", tmp + "/stats"
+            hp, kw = EMCIDHyperParams(**meta["hparams"]), dict(mom2_weight=meta["lam"], edit_weight=meta["ew"])
+        w0 = {n: get_parameter(pipe.text_encoder, n + ".weight").detach().cpu().double() for n in names}
+        for call in range(2):        # the second call runs on the cached covariance factors
+            with torch.no_grad():
+                for n in names:
+                    get_parameter(pipe.text_encoder, n + ".weight").copy_(w0[n].float())
+            em.apply_emcid_to_text_encoder(pipe, reqs, hp, "cuda:0", cache_name=cache, stats_dir=stats, verbose=False, **kw)
+        np.savez(f"{tmp}/rccl.npz", **{n: (get_parameter(pipe.text_encoder, n + ".weight").cpu().double() - w0[n]).numpy()
+                                       for n in names})
+        # the weight broadcast of the SDXL group split and the Stage-0 all-reduce, on HBM tensors
+        t = torch.arange(12, dtype=torch.float32, device="cuda:0").reshape(3, 4)
+        em._broadcast_(t, 0)
+        assert t.is_cuda and float(t.sum()) == 66.0
+        from emcid_amd import runningstats as rs
+        sm = rs.SecondMoment()
+        x = torch.randn(300, 64, device="cuda:0")
+        sm.add(x)
+        sm.all_reduce_()
+        assert sm.count == 300
+        assert (sm.moment().cpu() - (x.t() @ x / 300).cpu()).abs().max().item() < 1e-4
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("solver", ["dual", "direct"])
+def test_rccl_collectives_on_hbm_buffers_toy(tmp_path, solver, monkeypatch):
+    """One-rank RCCL group, multi-rank code path forced, toy dims, both solvers: same weights as the plain single-process edit."""
+    from emcid_amd import emcid_main as em, synthetic as syn
+    from emcid_amd.emcid_hparams import EMCIDHyperParams
+    from emcid_amd.nethook import get_parameter
+    tmp = str(tmp_path)
+    reqs, hp_d, names, cache = _setup(tmp, 9)
+    monkeypatch.setenv("EMCID_SOLVER", solver)
+    mp.spawn(_rccl_worker, args=(1, _free_port(), tmp, 9, "toy"), nprocs=1, join=True)
+    em.clear_caches()
+    pipe = syn.build_pipe("toy", "cuda:0")
+    w0 = {n: get_parameter(pipe.text_encoder, n + ".weight").cpu().double() for n in names}
+    em.apply_emcid_to_text_encoder(pipe, reqs, EMCIDHyperParams(**hp_d), "cuda:0", cache_name=cache,
+                                   stats_dir=tmp + "/stats", verbose=False)
+    got = np.load(f"{tmp}/rccl.npz")
+    for n in names:
+        dw = (get_parameter(pipe.text_encoder, n + ".weight").cpu().double() - w0[n]).numpy()
+        assert np.abs(got[n] - dw).max() <= 1e-5 * np.abs(dw).max(), n
+
+
+def test_rccl_column_sharded_solve_at_headline_size(tmp_path):
+    """The 1 000-concept SD-v1.4 edit through the column-sharded solve with its all-gather / all-reduces executed by RCCL on
+    HBM buffers (one rank), against the reference-minted summary (real_sd_n1000_summary), cached-factor call."""
+    import json
+    from conftest import load_golden
+    from emcid_amd import synthetic as syn
+    z, meta = load_golden("real_sd_n1000_summary")
+    tmp = str(tmp_path)
+    hidden, inter = syn.ENCODER_DIMS[meta["kind"]][:2]
+    reqs = syn.make_requests(meta["n_requests"], names="syllable")
+    syn.write_vstar_cache(tmp + "/cache/", reqs, hidden, seed=meta["vstar"]["seed"], scale=meta["vstar"]["scale"])
+    st = meta["stats"]
+    syn.write_stats_cache(tmp + "/stats", meta["layer_names"], inter, st["n_samples"], seed=st["seed"], t=st["t"])
+    json.dump(meta, open(tmp + "/meta.json", "w"))
+    mp.spawn(_rccl_worker, args=(1, _free_port(), tmp, meta["n_requests"], "real"), nprocs=1, join=True)
+    got = np.load(f"{tmp}/rccl.npz")
+    probe = torch.randn(inter, 8, generator=torch.Generator().manual_seed(123), dtype=torch.float64).numpy()
+    for li, n in enumerate(meta["layer_names"]):
+        scale = float(z[f"dw_maxabs/{li}"])
+        assert np.abs(got[n] @ probe - z[f"dw_probe/{li}"]).max() <= 1e-4 * scale * np.linalg.norm(probe, axis=0).max(), li
+        np.testing.assert_allclose(np.linalg.norm(got[n]), float(z[f"dw_fro/{li}"]), rtol=1e-4)
+        np.testing.assert_allclose(np.abs(got[n]).max(), scale, rtol=1e-4)
