@@ -137,6 +137,11 @@ def step_flops(N, n_rows, d, h, L, dual, apply_only, factors_cached, first_x):
         f["delta_w"] += L * 2 * h * N * d                # V = Z^T Yt
         shadow = (os.environ.get("EMCID_SHADOW_P", "1") != "0" and os.environ.get("EMCID_CHOL_FUSED", "1") != "0"
                   and 256 <= Np <= 2048)
+        if shadow and os.environ.get("EMCID_SHADOW_P", "1") == "1":      # the library's own fit estimate (emcid_edit_dual_apply_stage2_f64)
+            ntl, nb = -(-d // 128), Np // 128
+            steps = -(-(ntl + 1) * 8 // nb)
+            rounds = -(-(Np // 64) * ((ntl + 1) // 2) // 240)
+            shadow = rounds * (9.0 + 1.5 * steps) <= 50.0
         if shadow:
             # P = Yt X rides in the Cholesky's leaf launches (csrc/spd_solve.hip ShadowJob); U = Z^T P is the delta_w GEMM
             f["inv_apply"] += n_x * n_rows * d * d       # Yt = Kt X^T on the concept rows

@@ -1938,8 +1938,17 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
     const double* Ib = (const double*)cov_factor_ws + 2 * n_layers * s_mat + layer_index * inv_doubles(dp);
     // P = Yt X rides in the Cholesky's leaf launches (ShadowJob) when X is explicit and the fused schedule runs: then
     // U = Z^T P is one GEMM and the GEMM against the triangle after the N x N solve (U = (Z^T Yt) X) disappears from the chain
-    static const int shadow_env = env_flag("EMCID_SHADOW_P", 1);
-    const bool shadow = shadow_env && use_inverse && cholesky_takes_shadow(Np);
+    static const int shadow_env = env_flag("EMCID_SHADOW_P", 1);      // 0: never, 1: when it fits under the leaves, 2: always
+    bool shadow = shadow_env && use_inverse && cholesky_takes_shadow(Np);
+    if (shadow && shadow_env == 1) {
+        // The product only pays while a launch's shadow tiles finish about when its leaf does (~36 us).  Measured on MI355X
+        // (scripts/step_stamps.py): a tile pair's slice costs ~9 us + 1.5 us per 16-deep K step, one workgroup per compute unit.
+        // SD dims, N = 1000: 25 steps, 192 workgroups -> 46 us; SDXL TE2 (d = 5120) at N = 1000: 41 steps in two rounds -> no.
+        const int64_t ntl = (dp + SH_BN - 1) / SH_BN, nb = Np / NB;
+        const int64_t steps = ((ntl + 1) * (SH_BN / 16) + nb - 1) / nb;
+        const int64_t wgs = ((Np + SH_BM - 1) / SH_BM) * ((ntl + 1) / 2), rounds = (wgs + 239) / 240;
+        shadow = rounds * (9.0 + 1.5 * (double)steps) <= 50.0;
+    }
     double* P = base + ws.off_P;
     const double* X = use_inverse ? cov_inverse(cov_factor_ws, n_layers, dp, layer_index) : nullptr;
     EMCID_TRY(with_graph(make_key(6, {Yt, R, S, LS, RT, V, U, info_dev},

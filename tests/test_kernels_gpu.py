@@ -478,3 +478,37 @@ def test_ill_conditioned_statistics(decades, form):
     err = (res["dW"].cpu().double() - upd).abs().max().item() / upd.abs().max().item()
     assert err <= 1e-4, err
     assert err <= 2e-6, err           # observed: the fp32 rounding of dW itself (3-4e-8) at every condition number
+
+
+_SHADOW_SCRIPT = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from emcid_amd import hip
+from oracle import emcid_oracle as orc
+from test_kernels_gpu import _edit_inputs
+worst = 0.0
+for N, d, h, lam in ((200, 3072, 768, 4000.0), (300, 5120, 1280, 10000.0), (260, 1400, 96, 300.0), (640, 1152, 64, 500.0),
+                     (1000, 3072, 768, 4000.0)):
+    K, Zc, zs, Cov, W0 = _edit_inputs(N, d, h, seed=N + d)
+    _, _, upd = orc.closed_form_layer(K, Zc, zs, Cov, lam, 0.5, 2)
+    fac = hip.factor_cov([Cov.cuda()], lam, 0.5)
+    W = torch.empty(h, d, device="cuda")
+    out = hip.edit_layer_dual_apply(K.cuda(), Zc.cuda(), zs.t().contiguous().cuda(), fac, 0, 0.5, 2, W0.cuda(), W)
+    assert int(fac.info.item()) == 0 and int(out["ws"].info.item()) == 0
+    err = (out["dW"].cpu().double() - upd).abs().max().item() / upd.abs().max().item()
+    worst = max(worst, err)
+    assert err <= 2e-6, (N, d, err)
+print("SHADOW_OK", worst)
+'''
+
+
+@pytest.mark.parametrize("mode", ["2", "0"])
+def test_shadow_product_forced_and_off(mode):
+    """The product P = Yt X riding in the Cholesky leaf launches (EMCID_SHADOW_P=2: forced for every shape, i.e. 2 / 3 / 5 / 8
+    leaf launches, an odd number of column tiles, every XCD-block grid) and the path without it (=0) against the oracle; the
+    switch is read once per process, hence the child process."""
+    import os, subprocess, sys
+    from conftest import REPO
+    env = dict(os.environ, EMCID_SHADOW_P=mode)
+    r = subprocess.run([sys.executable, "-c", _SHADOW_SCRIPT, str(REPO)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SHADOW_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
