@@ -61,7 +61,26 @@ def alone(p, ws, te):
     for _ in range(K): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t) / K
 t1, t2 = alone(p1, w1, pipe.text_encoder), alone(p2, w2, pipe.text_encoder_2)
+# the metric of bench.py for this config: wall of apply_emcid_to_sdxl_text_encoders (timer around the call, warm caches)
+import os, statistics
+def apply_call():
+    with torch.no_grad():
+        for l, w in w1.items(): get_parameter(pipe.text_encoder, p1.weight_name(l)).copy_(w)
+        for l, w in w2.items(): get_parameter(pipe.text_encoder_2, p2.weight_name(l)).copy_(w)
+    em.apply_emcid_to_sdxl_text_encoders(pipe, reqs, hp, dev, cache_name=cache, stat_dir=str(tmp / "s1"), stat_dir_2=str(tmp / "s2"),
+                                         verbose=False)
+calls = {}
+for streams in ("1", "2"):
+    os.environ["EMCID_SDXL_STREAMS"] = streams
+    for _ in range(2): apply_call()
+    ts = []
+    for _ in range(7):
+        torch.cuda.synchronize(); t = time.perf_counter(); apply_call(); torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t) * 1e3)
+    calls[streams] = statistics.median(ts)
 print(json.dumps({"config": "sdxl dual text-encoder edit, 1 GPU", "concepts": N, "ms_per_step": dt * 1e3,
+                  "apply_call_ms_sequential": calls["1"], "apply_call_ms_two_streams": calls["2"],
+                  "concept_edits_per_s_apply_call": N / (min(calls.values()) * 1e-3),
                   "concept_edits_per_s": N / dt, "te1_alone_ms": t1 * 1e3, "te2_alone_ms": t2 * 1e3,
                   "host_prepare_ms": prep_ms, "trie_rows": [p1.trie.n_nodes, p2.trie.n_nodes],
                   "algorithmic_solve_flops": 8.1e11}))
