@@ -630,6 +630,8 @@ __global__ __launch_bounds__(LEAF_T) void chol_step_leaf_kernel(const double* __
         case 1: shadow_pair<32, 2>(sh, s_, slice, nslices, lds); break;
         case 2: shadow_pair<16, 13>(sh, s_, slice, nslices, lds); break;
         case 3: shadow_pair<32, 12>(sh, s_, slice, nslices, lds); break;
+        case 4: shadow_pair<16, 6>(sh, s_, slice, nslices, lds); break;
+        case 5: shadow_pair<16, 8>(sh, s_, slice, nslices, lds); break;
         default: shadow_pair<16, 3>(sh, s_, slice, nslices, lds); break;
     }
     if (stamp && threadIdx.x == 0) { stamp[2] = (long long)__builtin_amdgcn_s_memrealtime(); stamp[3] = 3; }
