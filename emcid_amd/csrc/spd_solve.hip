@@ -526,6 +526,7 @@ struct ShadowJob {
     int variant;                      // tile pipeline variant (see chol_step_leaf_kernel)
     long long* stamps;                // diagnostic (usually null): per launch slice and workgroup [start, mid, end, kind]
     int xcd_gx;                       // > 0: XCD-blocked tile assignment, the 8 XCDs as a xcd_gx x (8 / xcd_gx) grid (set by the launcher)
+    int nofast;                       // GemmShape.nofast for the shadow tiles (EMCID_GEMM_FAST=0)
 };
 inline long long* g_step_stamps = nullptr;      // set by emcid_debug_step_stamps
 constexpr int SH_BM = 64, SH_BN = 128;
@@ -536,6 +537,7 @@ __device__ __forceinline__ void shadow_tile(const ShadowJob& sh, int bm, int bn,
     using TB = OpTile<false, SH_BN, SH_BK>;
     GemmShape q{sh.A, sh.lda, sh.B, sh.ldb, sh.M, sh.N, sh.K, 0};
     q.tri = 2;
+    q.nofast = sh.nofast;
     const int depth = streamk_depth(q, bn, SH_BN, SH_BK);
     const int per = (depth + nslices - 1) / nslices;
     const int kb = slice * per, ke = min(depth, kb + per);
@@ -1045,6 +1047,8 @@ static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, do
             sh.variant = variant;
             sh.stamps = g_step_stamps;
             sh.xcd_gx = 0;
+            static const int gemm_fast = env_flag("EMCID_GEMM_FAST", 1);
+            sh.nofast = !gemm_fast;
             static const int xcd_block = env_flag("EMCID_SHADOW_XCD_BLOCK", 1);
             if (xcd_block && sh.wgs && !skip0 && sh.wgs % 8 == 0) {
                 const int mb = (sh.M + SH_BM - 1) / SH_BM, np_ = ((sh.N + SH_BN - 1) / SH_BN + 1) / 2;
@@ -1960,7 +1964,7 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
             if (Np > N) hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, q, Yt + N * dp, (Np - N) * dp);
             assemble_dual_system(Yt, Yt, dp, S, (int)Np, q, base + ws.off_SK);      // S = I + Yt Yt^T (lower tiles)
         }
-        ShadowJob job{Yt, dp, X, dp, P, dp, (int)Np, (int)dp, (int)dp, 0, 0, 0, nullptr, 0};
+        ShadowJob job{Yt, dp, X, dp, P, dp, (int)Np, (int)dp, (int)dp, 0, 0, 0, nullptr, 0, 0};
         job.wgs = (int)((Np + SH_BM - 1) / SH_BM) * (int)(((dp + SH_BN - 1) / SH_BN + 1) / 2);
         EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q, shadow ? &job : nullptr));
         // RT[h, Np] = Rt^T ; Z^T = RT S^-1 (two solves with h rows)
