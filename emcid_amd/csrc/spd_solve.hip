@@ -527,6 +527,7 @@ struct ShadowJob {
     long long* stamps;                // diagnostic (usually null): per launch slice and workgroup [start, mid, end, kind]
     int xcd_gx;                       // > 0: XCD-blocked tile assignment, the 8 XCDs as a xcd_gx x (8 / xcd_gx) grid (set by the launcher)
     int nofast;                       // GemmShape.nofast for the shadow tiles (EMCID_GEMM_FAST=0)
+    int fuse_pair;                    // both tiles of a pair through one software pipeline (EMCID_SHADOW_FUSE, default 1)
 };
 inline long long* g_step_stamps = nullptr;      // set by emcid_debug_step_stamps
 constexpr int SH_BM = 64, SH_BN = 128;
@@ -576,6 +577,134 @@ __device__ __forceinline__ void shadow_tile(const ShadowJob& sh, int bm, int bn,
     __syncthreads();      // the next tile's first LDS store must not overtake this tile's last MFMA stage
 }
 
+// Both tiles of a pair in ONE software pipeline (interior shapes: M % 64 == N % 128 == K % 16 == 0): the K tiles of tile bn0's
+// slice, then those of bn1's, flow through the same register ring and LDS double buffer; at the seam tile bn0's sum goes out
+// while bn1's first K tiles are already in flight, so the second tile pays no load-latency prologue (~2.5 us of a 38 us launch).
+__device__ __forceinline__ void shadow_pair_fused(const ShadowJob& sh, int bm, int bn0, int bn1, int slice, int nslices, double* smem) {
+    constexpr int BK = 16, PF = 3, NT = LEAF_T;
+    using TA = OpTile<true, SH_BM, BK>;
+    using TB = OpTile<false, SH_BN, BK>;
+    constexpr int STAGE = TA::SIZE + TB::SIZE;
+    constexpr int MI = SH_BM / 2 / 16, NI = SH_BN / 4 / 16;
+    constexpr int NA = TA::NVEC / NT, NB = TB::NVEC / NT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / 4) * (SH_BM / 2), wn0 = (wave % 4) * (SH_BN / 4);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int m0 = bm * SH_BM;
+    const int KT = sh.K / BK;
+    // segment g: column tile bn[g], absolute K tiles [kb[g], ke[g])  (B(k, n) = 0 for k < n: the tile's own range starts at its column)
+    int bn[2] = {bn0, bn1}, kb[2], ke[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int first = bn[g] * SH_BN / BK, depth = KT - first;
+        const int per = (depth + nslices - 1) / nslices;
+        kb[g] = first + min(depth, slice * per);
+        ke[g] = first + min(depth, slice * per + per);
+    }
+    const int n0len = ke[0] - kb[0], total = n0len + (ke[1] - kb[1]);
+    if (total <= 0) return;
+    const double* pa[NA];
+    const double* pb[NB];
+    int la[NA], lb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int v = tid + i * NT;
+        pa[i] = sh.A + (int64_t)(m0 + v / (BK / 2)) * sh.lda + 2 * (v % (BK / 2));
+        la[i] = (v / (BK / 2)) * TA::LD + 2 * (v % (BK / 2));
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int v = tid + i * NT;
+        pb[i] = sh.B + (int64_t)(v / (SH_BN / 2)) * sh.ldb + 2 * (v % (SH_BN / 2));
+        lb[i] = (v / (SH_BN / 2)) * TB::LD + 2 * (v % (SH_BN / 2));
+    }
+    v2d fa[PF][NA], fb[PF][NB];
+    auto fetch = [&](int s, int u) {            // unified step u -> (segment, absolute K tile); past the end: the last one again
+        const int uu = u < total ? u : total - 1;
+        const int g = uu < n0len ? 0 : 1;
+        const int64_t kt = g ? kb[1] + (uu - n0len) : kb[0] + uu;
+        const int64_t ncol = (int64_t)bn[g] * SH_BN;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) fa[s][i] = *reinterpret_cast<const v2d*>(pa[i] + kt * BK);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) fb[s][i] = *reinterpret_cast<const v2d*>(pb[i] + kt * BK * sh.ldb + ncol);
+    };
+    auto stash = [&](int s, double* stage) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<v2d*>(stage + la[i]) = fa[s][i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<v2d*>(stage + TA::SIZE + lb[i]) = fb[s][i];
+    };
+    v4d prev[MI][NI], acc[MI][NI];
+    auto c_ptr = [&](int g, int i, int j, int r) {
+        return sh.C + (int64_t)(m0 + wm0 + TA::index_of(i, l4 + 4 * r)) * sh.ldc + bn[g] * SH_BN + wn0 + TB::index_of(j, l15);
+    };
+    auto load_prev = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) prev[i][j][r] = slice ? *c_ptr(g, i, j, r) : 0.0;
+    };
+    auto flush = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    *c_ptr(g, i, j, r) = prev[i][j][r] + acc[i][j][r];
+                    acc[i][j][r] = 0.0;
+                }
+    };
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    load_prev(n0len > 0 ? 0 : 1);
+#pragma unroll
+    for (int s = 0; s < PF; ++s) fetch(s, s);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    stash(0, smem);
+    __syncthreads();
+    for (int base = 0; base < total; base += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int u = base + s;
+            if (u < total) {
+                const double* As = smem + (u & 1) * STAGE;
+                const double* Bs = As + TA::SIZE;
+                fetch(s, u + PF);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k8 = 0; k8 < BK / 8; ++k8) {
+                    double a[2][MI], b[2][NI];
+                    TA::template frags<MI>(As, wm0, k8, l15, l4, a);
+                    TB::template frags<NI>(Bs, wn0, k8, l15, l4, b);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e)
+#pragma unroll
+                        for (int i = 0; i < MI; ++i)
+#pragma unroll
+                            for (int j = 0; j < NI; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e][i], b[e][j], acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 1 < total) stash((s + 1) % PF, smem + ((u + 1) & 1) * STAGE);
+                if (u + 1 == n0len && n0len < total) {       // the seam: tile bn0 is complete, bn1's K tiles are already in flight
+                    flush(0);
+                    load_prev(1);
+                }
+                __syncthreads();
+            }
+        }
+    }
+    flush(n0len < total ? 1 : 0);
+    __syncthreads();
+}
+
 template <int SH_BK, int SH_PF>
 __device__ __forceinline__ void shadow_pair(const ShadowJob& sh, int s_, int slice, int nslices, double* lds) {
     const int ntl = (sh.N + SH_BN - 1) / SH_BN, npairs = (ntl + 1) / 2;
@@ -590,6 +719,11 @@ __device__ __forceinline__ void shadow_pair(const ShadowJob& sh, int s_, int sli
         const int gy = 8 / sh.xcd_gx, rows = mb / sh.xcd_gx, cols = npairs / gy;
         bm = (g / gy) * rows + r / cols;
         pr = (g % gy) * cols + r % cols;
+    }
+    if (SH_BK == 16 && SH_PF == 3 && sh.fuse_pair && ntl - 1 - pr != pr && sh.M % SH_BM == 0 && sh.N % SH_BN == 0 &&
+        sh.K % SH_BK == 0) {
+        shadow_pair_fused(sh, bm, pr, ntl - 1 - pr, slice, nslices, lds);
+        return;
     }
     shadow_tile<SH_BK, SH_PF>(sh, bm, pr, slice, nslices, lds);                            // the long K range first
     if (ntl - 1 - pr != pr) shadow_tile<SH_BK, SH_PF>(sh, bm, ntl - 1 - pr, slice, nslices, lds);
@@ -628,14 +762,9 @@ __global__ __launch_bounds__(LEAF_T) void chol_step_leaf_kernel(const double* __
         s_ -= (int)((blockIdx.x + 7) / 8) - (1 + ntrail + 7) / 8;
         if (s_ >= sh.wgs) return;
     }
-    switch (sh.variant) {          // experiments (EMCID_SHADOW_VARIANT): K-tile depth / loads in flight / LDS fragment prefetch
-        case 1: shadow_pair<32, 2>(sh, s_, slice, nslices, lds); break;
-        case 2: shadow_pair<16, 13>(sh, s_, slice, nslices, lds); break;
-        case 3: shadow_pair<32, 12>(sh, s_, slice, nslices, lds); break;
-        case 4: shadow_pair<16, 6>(sh, s_, slice, nslices, lds); break;
-        case 5: shadow_pair<16, 8>(sh, s_, slice, nslices, lds); break;
-        default: shadow_pair<16, 3>(sh, s_, slice, nslices, lds); break;
-    }
+    // (K-tile depth 32, 6 or 8 K tiles of loads in flight and LDS fragment prefetch were measured here as template variants:
+    //  none moved the launch time by more than 1 us)
+    shadow_pair<16, 3>(sh, s_, slice, nslices, lds);
     if (stamp && threadIdx.x == 0) { stamp[2] = (long long)__builtin_amdgcn_s_memrealtime(); stamp[3] = 3; }
 }
 
@@ -1049,6 +1178,8 @@ static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, do
             sh.xcd_gx = 0;
             static const int gemm_fast = env_flag("EMCID_GEMM_FAST", 1);
             sh.nofast = !gemm_fast;
+            static const int fuse_pair = env_flag("EMCID_SHADOW_FUSE", 1);
+            sh.fuse_pair = fuse_pair;
             static const int xcd_block = env_flag("EMCID_SHADOW_XCD_BLOCK", 1);
             if (xcd_block && sh.wgs && !skip0 && sh.wgs % 8 == 0) {
                 const int mb = (sh.M + SH_BM - 1) / SH_BM, np_ = ((sh.N + SH_BN - 1) / SH_BN + 1) / 2;
@@ -1964,7 +2095,7 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
             if (Np > N) hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, q, Yt + N * dp, (Np - N) * dp);
             assemble_dual_system(Yt, Yt, dp, S, (int)Np, q, base + ws.off_SK);      // S = I + Yt Yt^T (lower tiles)
         }
-        ShadowJob job{Yt, dp, X, dp, P, dp, (int)Np, (int)dp, (int)dp, 0, 0, 0, nullptr, 0, 0};
+        ShadowJob job{Yt, dp, X, dp, P, dp, (int)Np, (int)dp, (int)dp, 0, 0, 0, nullptr, 0, 0, 0};
         job.wgs = (int)((Np + SH_BM - 1) / SH_BM) * (int)(((dp + SH_BN - 1) / SH_BN + 1) / 2);
         EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q, shadow ? &job : nullptr));
         // RT[h, Np] = Rt^T ; Z^T = RT S^-1 (two solves with h rows)
