@@ -2119,15 +2119,24 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
         } else {
             EMCID_TRY(cholesky_solve_impl(LS, Np, Np, invS, RT, Y2, h, Np, q));
         }
-        {
-            ScopedProf sp(KC_DELTA_W, q);       // U[h, dp] = Z^T P  (shadow)  or  V[h, dp] = Z^T Yt
-            GemmShape g{RT, Np, shadow ? P : Yt, dp, (int)h, (int)dp, (int)Np, 0};
-            launch_gemm_f64<true, false>(g, EpiAxpby{shadow ? U : V, dp, 1.0, 0.0}, q);
+        if (!shadow) {
+            ScopedProf sp(KC_DELTA_W, q);       // V[h, dp] = Z^T Yt
+            GemmShape g{RT, Np, Yt, dp, (int)h, (int)dp, (int)Np, 0};
+            launch_gemm_f64<true, false>(g, EpiAxpby{V, dp, 1.0, 0.0}, q);
         }
         if (!use_inverse) trsm_backward(Lb, dp, dp, Ib, V, U, (int)h, dp, q);   // U L = V by block substitution
         return check_launch("emcid_edit_dual_apply_stage2_f64");
     }));
-    if (use_inverse && !shadow)   // U = V inv(L)  (V's padding columns are zero: Kt's are, X is the identity there)
+    if (shadow) {
+        // U = Z^T P straight into the weights: W = W0 + float(U), dW = float(U) in the GEMM's epilogue (outside the cached graph:
+        // W0 / W / dW are the caller's tensors and change from layer to layer and call to call)
+        ScopedProf sp(KC_DELTA_W, st);
+        GemmShape g{RT, Np, P, dp, (int)h, (int)d, (int)Np, 0};
+        launch_gemm_f64<true, false>(g, EpiDeltaW{W0, W, d, dW_out, d, nullptr, 0}, st);
+        EMCID_CHECK_LAUNCH();
+        return EMCID_OK;
+    }
+    if (use_inverse)   // U = V inv(L)  (V's padding columns are zero: Kt's are, X is the identity there)
         apply_inverse_backward(X, dp, V, (int)h, (int)dp, U, dp, st, base + ws.off_SK);
     hipLaunchKernelGGL(apply_u2d_kernel, dim3((unsigned)h), dim3(256), 0, st, U, dp, W0, W, dW_out, (int)d);
     EMCID_CHECK_LAUNCH();
