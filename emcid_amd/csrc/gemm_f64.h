@@ -971,9 +971,9 @@ inline int64_t streamk_workspace_doubles(int wgs) { return (int64_t)2 * wgs * 12
 
 // C = alpha * A B (+ diag_add on the diagonal); C needs no initial value.  `work`: streamk_workspace_doubles(wgs) doubles whose
 // counter part (the last 8192 doubles) is zero (it is left zero).
-template <bool KCA, bool KCB, int BK>
-inline void launch_gemm_f64_streamk2_bk(GemmShape p, EpiAxpby epi, hipStream_t stream, int wgs, double* work, double diag_add) {
-    constexpr int BM = 128, BN = 128;
+template <bool KCA, bool KCB, int BK, int BM, int BN, int WGM, int WGN>
+inline void launch_gemm_f64_streamk2_tile(GemmShape p, EpiAxpby epi, hipStream_t stream, int wgs_alloc, int runs_per_cu, double* work,
+                                          double diag_add) {
     const int MT = (p.M + BM - 1) / BM, NTL = (p.N + BN - 1) / BN, KT = (p.K + BK - 1) / BK;
     long long total = 0;
     if (p.lower_only) total = (long long)MT * (MT + 1) / 2 * KT;
@@ -984,6 +984,9 @@ inline void launch_gemm_f64_streamk2_bk(GemmShape p, EpiAxpby epi, hipStream_t s
         total += (long long)MT * depth;
     }
     if (total <= 0) return;
+    // runs: wgs_alloc * runs_per_cu, as long as their 2 partial slots each fit what the caller allocated for 128 x 128 tiles
+    int wgs = wgs_alloc * runs_per_cu;
+    while (wgs > wgs_alloc && (long long)2 * wgs * BM * BN > (long long)2 * wgs_alloc * 128 * 128) wgs -= wgs_alloc;
     long long per = (total + wgs - 1) / wgs;
     if (per < 128 / BK) per = 128 / BK;                      // never less than a 128-deep run per workgroup
     unsigned grid = (unsigned)((total + per - 1) / per);
@@ -993,15 +996,33 @@ inline void launch_gemm_f64_streamk2_bk(GemmShape p, EpiAxpby epi, hipStream_t s
         const unsigned g8 = (grid + 7) / 8 * 8;
         if ((int)g8 <= wgs) grid = g8; else map = 0;
     }
-    StreamKWork w{work, reinterpret_cast<unsigned*>(work + (int64_t)2 * wgs * BM * BN), diag_add, g_streamk_stamps};
+    // the ticket counters sit behind the slot area of the ALLOCATION (fixed place, whatever tile shape a launch uses)
+    StreamKWork w{work, reinterpret_cast<unsigned*>(work + (int64_t)2 * wgs_alloc * 128 * 128), diag_add, g_streamk_stamps};
     static const int fast = [] { const char* v = getenv("EMCID_GEMM_FAST"); return v ? atoi(v) : 1; }();
     p.nofast = !fast;
     // 11: one K tile of global loads in flight + LDS fragments of the next k8 step fetched ahead.  With the interior fast path
     // this instantiation runs the SYRK 20 % faster than the plain one (80 vs 100 us) and the triangular GEMMs 1-2 % faster
     static const int pf = [] { const char* v = getenv("EMCID_STREAMK_PF"); return v ? atoi(v) : 11; }();
-    if (pf == 11) hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, 2, 4, 11>), dim3(grid), dim3(512), 0, stream, p, epi, w, total, per, map);
-    else if (pf <= 1) hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, 2, 4, 1>), dim3(grid), dim3(512), 0, stream, p, epi, w, total, per, map);
-    else hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, 2, 4, 2>), dim3(grid), dim3(512), 0, stream, p, epi, w, total, per, map);
+    constexpr int NTH = WGM * WGN * 64;
+    if (pf == 11) hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, WGM, WGN, 11>), dim3(grid), dim3(NTH), 0, stream, p, epi, w, total, per, map);
+    else if (pf <= 1) hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, WGM, WGN, 1>), dim3(grid), dim3(NTH), 0, stream, p, epi, w, total, per, map);
+    else hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, WGM, WGN, 2>), dim3(grid), dim3(NTH), 0, stream, p, epi, w, total, per, map);
+}
+
+template <bool KCA, bool KCB, int BK>
+inline void launch_gemm_f64_streamk2_bk(GemmShape p, EpiAxpby epi, hipStream_t stream, int wgs, double* work, double diag_add) {
+    // EMCID_STREAMK_TILE (experiment): 1 = 64 x 128 tiles on 4-wave workgroups, two per compute unit with independent barriers
+    // (triangular GEMMs only: the SYRK numbering wants square tiles); 2 = 64 x 64 tiles, 4 waves, three per compute unit
+    // Measured (scripts/mb_tri.py, us: Yt = Kt X^T / U = G X / S = I + Yt Yt^T): 128 x 128 214 / 168 / 81, 64 x 128 270 / 222 / -,
+    // 64 x 64 243 / 217 / 74: independent barriers do not make up for the smaller tiles' operand traffic, except on the SYRK's 36
+    // big tiles -> the SYRK takes 64 x 64 by default (EMCID_STREAMK_SYRK_TILE=0: 128 x 128)
+    static const int tile = [] { const char* v = getenv("EMCID_STREAMK_TILE"); return v ? atoi(v) : 0; }();
+    static const int syrk_tile = [] { const char* v = getenv("EMCID_STREAMK_SYRK_TILE"); return v ? atoi(v) : 2; }();
+    if constexpr (BK == 16) {
+        if (tile == 1 && !p.lower_only) { launch_gemm_f64_streamk2_tile<KCA, KCB, BK, 64, 128, 2, 2>(p, epi, stream, wgs, 2, work, diag_add); return; }
+        if (tile == 2 || (p.lower_only && syrk_tile == 2)) { launch_gemm_f64_streamk2_tile<KCA, KCB, BK, 64, 64, 2, 2>(p, epi, stream, wgs, 3, work, diag_add); return; }
+    }
+    launch_gemm_f64_streamk2_tile<KCA, KCB, BK, 128, 128, 2, 4>(p, epi, stream, wgs, 1, work, diag_add);
 }
 
 // C = alpha * A B (+ diag_add on the diagonal); C needs no initial value.  `work`: streamk_workspace_doubles(wgs) doubles whose
