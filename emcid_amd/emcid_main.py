@@ -45,9 +45,22 @@ Stage1Fn = Callable[..., torch.Tensor]
 
 # ---- statistics ---------------------------------------------------------------------------------------
 
+_RESOLVED_DIRS: Dict[Tuple[str, str], str] = {}     # (cwd, stat_dir as given) -> resolved path (Path.resolve is a chain of readlinks)
+
+
+def _resolved(stat_dir) -> str:
+    k = (os.getcwd(), str(stat_dir))
+    r = _RESOLVED_DIRS.get(k)
+    if r is None:
+        if len(_RESOLVED_DIRS) > 256:
+            _RESOLVED_DIRS.clear()
+        r = _RESOLVED_DIRS[k] = str(Path(stat_dir).resolve())
+    return r
+
+
 def _cov_key(model, layer_name, stat_dir, mom2_n_samples, mom2_dtype):
     model_name = model.config._name_or_path.replace("/", "_")
-    return (model_name, layer_name, str(Path(stat_dir).resolve()), mom2_n_samples, mom2_dtype)
+    return (model_name, layer_name, _resolved(stat_dir), mom2_n_samples, mom2_dtype)
 
 
 def get_cov_text_encoder(model, tok, layer_name: str, mom2_dataset: str, mom2_n_samples: int, mom2_dtype: str,
@@ -64,8 +77,8 @@ def get_cov_text_encoder(model, tok, layer_name: str, mom2_dataset: str, mom2_n_
                                         sample_size=mom2_n_samples, precision=mom2_dtype,
                                         force_recompute=force_recompute)
         COV_CACHE[key] = stat.mom2.moment().float().to("cpu")
-        _COV_DEVICE_CACHE.pop((key, str(device)), None)
-    dkey = (key, str(device))
+        _COV_DEVICE_CACHE.pop((key, device), None)
+    dkey = (key, device)
     if dkey not in _COV_DEVICE_CACHE:
         _COV_DEVICE_CACHE[dkey] = COV_CACHE[key].to(device)
     c = _COV_DEVICE_CACHE[dkey]
@@ -383,8 +396,8 @@ def get_cov_cross_attn(pipe, layer_name: str, mom2_dataset: str, sample_size: in
         stat = layer_stats_cross_attn_kv(pipe, layer_name, stats_dir, mom2_dataset, to_collect=["mom2"],
                                          sample_size=sample_size, precision=mom2_dtype, force_recompute=force_recompute)
         COV_CACHE[key] = stat.mom2.moment().float().to("cpu")
-        _COV_DEVICE_CACHE.pop((key, str(device)), None)
-    dkey = (key, str(device))
+        _COV_DEVICE_CACHE.pop((key, device), None)
+    dkey = (key, device)
     if dkey not in _COV_DEVICE_CACHE:
         _COV_DEVICE_CACHE[dkey] = COV_CACHE[key].to(device)
     c = _COV_DEVICE_CACHE[dkey]
