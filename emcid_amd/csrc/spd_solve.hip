@@ -523,7 +523,6 @@ struct ShadowJob {
     int M, N, K;
     int wgs;                          // workgroups per launch: ceil(M / 64) * ceil(ceil(N / 128) / 2); 0 = no job
     int skip_xcd0;                    // keep the shadow workgroups off the XCD the leaf runs on
-    int variant;                      // tile pipeline variant (see chol_step_leaf_kernel)
     long long* stamps;                // diagnostic (usually null): per launch slice and workgroup [start, mid, end, kind]
     int xcd_gx;                       // > 0: XCD-blocked tile assignment, the 8 XCDs as a xcd_gx x (8 / xcd_gx) grid (set by the launcher)
     int nofast;                       // GemmShape.nofast for the shadow tiles (EMCID_GEMM_FAST=0)
@@ -1170,10 +1169,7 @@ static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, do
             ShadowJob sh{};
             if (shadow) sh = *shadow;
             static const int skip0 = env_flag("EMCID_SHADOW_SKIP_XCD0", 0);
-            static const int dbg_scale = env_flag("EMCID_SHADOW_DEBUG_SCALE", 1);   // timing experiments only (> 1: part of P is never computed)
             sh.skip_xcd0 = skip0;
-            static const int variant = env_flag("EMCID_SHADOW_VARIANT", 0);
-            sh.variant = variant;
             sh.stamps = g_step_stamps;
             sh.xcd_gx = 0;
             static const int gemm_fast = env_flag("EMCID_GEMM_FAST", 1);
@@ -1191,7 +1187,7 @@ static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, do
             const int shadow_ids = (sh.wgs && skip0) ? (sh.wgs * 8 + 6) / 7 + 8 : sh.wgs;
             ScopedProf sp(KC_CHOL_LEAF, st);
             hipLaunchKernelGGL(chol_step_leaf_kernel, dim3(1 + ntiles + shadow_ids), dim3(LEAF_T), 0, st, A + o * lda + o, lda,
-                               L + o * lda + o, lda, inv, (int64_t)OB, info, (int)o, tr, te, ntiles, sh, j, nb * dbg_scale);
+                               L + o * lda + o, lda, inv, (int64_t)OB, info, (int)o, tr, te, ntiles, sh, j, nb);
         }
         if (j == nb - 1) break;
         {   // B_j
@@ -2095,7 +2091,7 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
             if (Np > N) hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, q, Yt + N * dp, (Np - N) * dp);
             assemble_dual_system(Yt, Yt, dp, S, (int)Np, q, base + ws.off_SK);      // S = I + Yt Yt^T (lower tiles)
         }
-        ShadowJob job{Yt, dp, X, dp, P, dp, (int)Np, (int)dp, (int)dp, 0, 0, 0, nullptr, 0, 0, 0};
+        ShadowJob job{Yt, dp, X, dp, P, dp, (int)Np, (int)dp, (int)dp, 0, 0, nullptr, 0, 0, 0};
         job.wgs = (int)((Np + SH_BM - 1) / SH_BM) * (int)(((dp + SH_BN - 1) / SH_BN + 1) / 2);
         EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q, shadow ? &job : nullptr));
         // RT[h, Np] = Rt^T ; Z^T = RT S^-1 (two solves with h rows)
