@@ -680,3 +680,52 @@ def test_templated_prompt_path_equals_generic_path(monkeypatch):
     with pytest.raises(ValueError):                              # subject not in the prompt: the scalar walk's error
         monkeypatch.setenv("EMCID_TEMPLATED", "1")
         list(cz.iter_prompt_chunks(tok, [{"source": "zu", "dest": "x", "prompts": ["art by ka {}"[:9]], "seed_train": 1}] * 4, 1))
+
+
+def test_templated_prompt_path_randomised(monkeypatch):
+    """Seeded random requests (names with spaces, capitals, apostrophes, digits, punctuation; templates with the braces glued to
+    letters, digits, punctuation or white space; ragged template sets): wherever the templated path serves a request list it
+    must give exactly what the generic path gives; where the generic path raises, so must it."""
+    from emcid_amd import compute_z as cz, host_text
+    if not host_text.available():
+        pytest.skip("libemcid_host.so not built")
+    tok = syn.build_tokenizer(*syn.synthetic_vocab(syllables=True))
+    if host_text.NativeClipBpe.for_tokenizer(tok) is None:
+        pytest.skip("no native twin for the synthetic tokenizer")
+    rng = np.random.default_rng(11)
+    syll = syn.syllable_names(40)
+    glue = ["", " ", "  ", "-", "'s ", ", ", "7", ".", " the ", "\t"]
+
+    def name():
+        parts = [syll[int(rng.integers(len(syll)))] for _ in range(int(rng.integers(1, 4)))]
+        s = glue[int(rng.integers(len(glue)))].join(parts) if rng.random() < 0.3 else " ".join(parts)
+        if rng.random() < 0.2:
+            s = s.title()
+        if rng.random() < 0.1:
+            s = s + "'s"
+        return s.strip() or syll[0]
+
+    def template():
+        pre = glue[int(rng.integers(len(glue)))].join(syll[int(rng.integers(len(syll)))] for _ in range(int(rng.integers(0, 3))))
+        suf = glue[int(rng.integers(len(glue)))].join(syll[int(rng.integers(len(syll)))] for _ in range(int(rng.integers(0, 3))))
+        return pre + glue[int(rng.integers(len(glue)))] + "{}" + glue[int(rng.integers(len(glue)))] + suf
+
+    served = 0
+    for trial in range(25):
+        sets = [[template() for _ in range(int(rng.integers(1, 4)))] for _ in range(int(rng.integers(1, 3)))]
+        reqs = [{"source": name(), "dest": "x", "prompts": sets[int(rng.integers(len(sets)))], "seed_train": 1}
+                for _ in range(int(rng.integers(3, 40)))]
+        out = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("EMCID_TEMPLATED", flag)
+            try:
+                out[flag] = list(cz.iter_prompt_chunks(tok, reqs, 1))
+            except ValueError as e:
+                out[flag] = ("ValueError", str(e)[:40])
+        if isinstance(out["0"], tuple) or isinstance(out["1"], tuple):
+            assert isinstance(out["0"], tuple) and isinstance(out["1"], tuple), (trial, out["0"] if isinstance(out["0"], tuple) else out["1"])
+            continue
+        served += cz.templated_prompt_chunk(tok, reqs, reqs[0]) is not None
+        for a, b in zip(out["1"], out["0"]):
+            _chunks_equal(a, b)
+    assert served >= 15
