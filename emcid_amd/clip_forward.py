@@ -142,12 +142,13 @@ class TokenTrie:
     lookup_in_query: torch.Tensor  # (B,) int64 index of each prompt's lookup node inside query_rows
     n_nodes: int               # distinct prefixes (the arrays above are padded to a multiple of ROW_BUCKET rows)
     n_tokens_dense: int        # B * S the dense forward would process
+    tail: Optional[torch.Tensor] = None   # the caller's own int64 array uploaded with the trie (build_trie(tail=...))
 
 
 ROW_BUCKET = 256   # node / query-row counts are padded to a multiple of this: a few GEMM shapes per encoder, not one per batch
 
 
-def build_trie(input_ids, lookup: Sequence[int], device, bucket: int = ROW_BUCKET) -> TokenTrie:
+def build_trie(input_ids, lookup: Sequence[int], device, bucket: int = ROW_BUCKET, tail: Optional[np.ndarray] = None) -> TokenTrie:
     """Trie of the prompts' prefixes up to each lookup token.  ``input_ids``: (B, S) array (or equal-length rows).
     Nodes are numbered by depth, then by (parent, token).  Built by ``libemcid_host.so`` (``emcid_trie_build``: one packed image
     in pinned memory, ONE asynchronous upload) when that library is there, else level by level with numpy
@@ -164,19 +165,32 @@ def build_trie(input_ids, lookup: Sequence[int], device, bucket: int = ROW_BUCKE
     if host_text.available() and B > 0 and int(lk.min()) >= 0 and dmax <= tok.shape[1] and int(tok[:, :dmax].min()) >= 0:
         dev = torch.device(device)
 
+        extra = np.ascontiguousarray(tail, dtype=np.int64) if tail is not None else None
+        sizes = {}
+
         def alloc(nbytes):
-            buf = torch.empty(nbytes, dtype=torch.uint8, pin_memory=(dev.type == "cuda"))
+            # ``tail`` (the caller's own int64 index array, e.g. the request segment offsets) rides behind the trie image in the
+            # same pinned buffer: one upload for everything
+            sizes["trie"] = (nbytes + 7) // 8 * 8
+            buf = torch.empty(sizes["trie"] + (extra.nbytes if extra is not None else 0), dtype=torch.uint8,
+                              pin_memory=(dev.type == "cuda"))
             return buf, buf.data_ptr()
 
         host, z = host_text.build_trie_packed(tok, lk, bucket, alloc)
+        if extra is not None:
+            host[sizes["trie"]:].view(torch.int64).copy_(torch.from_numpy(extra))
         img = host.to(dev, non_blocking=True)
         U, n, R, D = z["U"], z["n"], z["R_pad"], z["dmax"]
         o32 = 8 * (U + 2 * n)
+        tail_dev = img[sizes["trie"]:].view(torch.int64) if extra is not None else None
         return TokenTrie(img[:8 * U].view(torch.int64), img[o32:o32 + 4 * U].view(torch.int32),
                          img[o32 + 4 * (U + R):o32 + 4 * (U + R + U * D)].view(torch.int32).view(U, D),
                          img[8 * U:8 * (U + n)].view(torch.int64), img[o32 + 4 * U:o32 + 4 * (U + R)].view(torch.int32),
-                         img[8 * (U + n):o32].view(torch.int64), z["n_real"], B * tok.shape[1])
-    return build_trie_numpy(tok, lk, device, bucket)
+                         img[8 * (U + n):o32].view(torch.int64), z["n_real"], B * tok.shape[1], tail_dev)
+    t = build_trie_numpy(tok, lk, device, bucket)
+    if tail is not None:
+        t.tail = torch.from_numpy(np.ascontiguousarray(tail, dtype=np.int64)).to(device)
+    return t
 
 
 def build_trie_numpy(tok: np.ndarray, lk: np.ndarray, device, bucket: int = ROW_BUCKET) -> TokenTrie:

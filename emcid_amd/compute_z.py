@@ -227,13 +227,20 @@ def templated_prompt_chunk(tokenizer, requests: Sequence[Dict], first: Dict) -> 
             lengths[i] = len(r)
     S = int(lengths.max())
     # as tokenize_lists does on every call: the longest row against the public tokenizer call
+    # (a prompt string that has been compared once is not compared again: both tokenizers are deterministic functions of it)
     j = int(lengths.argmax())
-    probe = tokenizer([prompt(j)], padding=True, truncation=True)
-    want = probe["input_ids"][0]
-    if S < len(want) or ids[j, :len(want)].tolist() != want or int(lengths[j]) != int(sum(probe["attention_mask"][0])) \
-            or set(probe.keys()) != {"input_ids", "attention_mask"}:
-        host_text.NativeClipBpe.disable(tokenizer)
-        return None
+    pj = prompt(j)
+    seen = twin.__dict__.setdefault("_verified_prompts", {})
+    if seen.get(pj) != ids[j, :int(lengths[j])].tobytes():
+        probe = tokenizer([pj], padding=True, truncation=True)
+        want = probe["input_ids"][0]
+        if S < len(want) or ids[j, :len(want)].tolist() != want or int(lengths[j]) != int(sum(probe["attention_mask"][0])) \
+                or set(probe.keys()) != {"input_ids", "attention_mask"}:
+            host_text.NativeClipBpe.disable(tokenizer)
+            return None
+        if len(seen) > 4096:
+            seen.clear()
+        seen[pj] = ids[j, :int(lengths[j])].tobytes()
     ids = ids[:, :S]
     lk = finder_for(tokenizer).last_tokens(ids, names, name_idx, packed=packed_names)
     bad = np.nonzero((lk < 0) | (lk >= S))[0]

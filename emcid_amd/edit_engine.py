@@ -284,8 +284,8 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
                 if pc is None:
                     break
                 with phase("trie"):
-                    trie = clip_forward.build_trie(pc.ids, pc.lookup, device)
-                    seg = torch.from_numpy(np.cumsum([0] + pc.counts).astype(np.int64)).to(device)
+                    trie = clip_forward.build_trie(pc.ids, pc.lookup, device, tail=np.cumsum([0] + list(pc.counts)).astype(np.int64))
+                    seg = trie.tail
                 with phase("gemm_tuning"):
                     plan.gemm_tuning_s += clip_forward.tune_projections(graph, trie, max(plan.layers), tune_mode)
                 with phase("prefix launches"), torch.no_grad():
@@ -297,6 +297,12 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
     if plan.chunks is None:
         with phase("tokenize+lookup"):
             plan.ensure_batch()
+    # ``zs_t`` / ``covs`` may be callables: the caller's v* cache check and statistics lookups, run HERE — after the leading
+    # layers have been launched, so that these host milliseconds too pass underneath the GPU (v* first, as the reference)
+    if callable(zs_t) and not hasattr(zs_t, "result"):
+        zs_t = zs_t()
+    if callable(covs):
+        covs = covs()
     plan.covs = {l: c.to(device=device, dtype=torch.float32).contiguous() for l, c in covs.items()}
     plan.zs_pending = zs_t          # a tensor, or the caller's reader-thread future: resolved where the first solve needs it
     if not hasattr(zs_t, "result"):

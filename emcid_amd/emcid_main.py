@@ -279,19 +279,26 @@ class _LazyVstars:
 def prepare_text_encoder_edit(text_encoder, tokenizer, requests, hparams, layers, lam, stat_dir, cache_name,
                               suffix="", verbose=True, shard=None, stage1=None) -> EncoderEditPlan:
     """Host side of one encoder's edit: v* rows, C per layer (HBM-resident), tokenized prompts + lookup."""
-    zs_future = _LazyVstars(requests, hparams, cache_name, suffix, stage1)
-    if _any_vstar_missing(requests, hparams, cache_name, suffix):
-        # a cache miss is handled FIRST, as the reference does (:873-969 come before the layer loop's covariance reads): Stage 1
-        # runs (or the miss is reported) before statistics are read or computed and before anything is launched
-        zs_future = load_v_stars(requests, hparams, cache_name, suffix, stage1)
-    covs = {layer: get_cov_text_encoder(text_encoder, tokenizer, hparams.rewrite_module_tmp.format(layer),
-                                        hparams.mom2_dataset, hparams.mom2_n_samples, hparams.mom2_dtype,
-                                        stat_dir=stat_dir, verbose=verbose)
-            for layer in layers}
     for layer in layers:   # resolve every edited weight now: LookupError before any GPU work, like the reference (:858-863)
         nethook.get_parameter(text_encoder, f"{hparams.rewrite_module_tmp.format(layer)}.weight")
+
+    def targets():
+        # a cache miss is handled FIRST, as the reference does (:873-969 come before the layer loop's covariance reads): Stage 1
+        # runs (or the miss is reported) before statistics are read or computed
+        if _any_vstar_missing(requests, hparams, cache_name, suffix):
+            return load_v_stars(requests, hparams, cache_name, suffix, stage1)
+        return _LazyVstars(requests, hparams, cache_name, suffix, stage1)
+
+    def statistics():
+        return {layer: get_cov_text_encoder(text_encoder, tokenizer, hparams.rewrite_module_tmp.format(layer),
+                                            hparams.mom2_dataset, hparams.mom2_n_samples, hparams.mom2_dtype,
+                                            stat_dir=stat_dir, verbose=verbose)
+                for layer in layers}
+
+    # both run inside prepare_encoder_edit right AFTER it has launched the unedited leading layers (they need nothing but the
+    # prompts), in this order
     return prepare_encoder_edit(text_encoder, tokenizer, requests, layers, hparams.rewrite_module_tmp, lam,
-                                hparams.edit_weight, zs_future, covs, _shard_from_env(shard),
+                                hparams.edit_weight, targets, statistics, _shard_from_env(shard),
                                 layer_module_tmp=getattr(hparams, "layer_module_tmp", None))
 
 

@@ -170,6 +170,8 @@ def test_native_trie_equals_numpy_trie(B, S, vocab, bucket, seed):
         assert x.dtype == y.dtype and x.shape == y.shape and torch.equal(x, y), f
     with pytest.raises(RuntimeError):
         host_text.build_trie_packed(ids, np.full(B, S, dtype=np.int64), bucket, lambda n: (None, 0))      # lookup outside the row
+    t = cf.build_trie(ids, lookup, "cpu", bucket=bucket, tail=np.arange(B + 1) * 3)       # the caller's array behind the image
+    assert t.tail.dtype == torch.int64 and t.tail.tolist() == (np.arange(B + 1) * 3).tolist() and torch.equal(t.anc, b.anc)
 
 
 def test_prompt_batch_matches_oracle_lookup():
