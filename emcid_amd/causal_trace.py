@@ -162,6 +162,9 @@ class TokenRangeFinder:
     def _native_tables(self, ids: np.ndarray):
         """Per-token tables for ``emcid_find_token_ranges``, grown when the batch shows token ids not decoded before."""
         top = int(ids.max()) + 1
+        if self._native is not None and self._native[4].size >= top and self._native[1] is not None \
+                and self._native[4][ids.ravel()].all():
+            return self._native[1], self._native[2], self._native[3]          # every token of the batch is in the tables already
         if self._native is None:
             self._native = [[], b"", np.zeros(1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=bool)]
         pieces, blob, off, plen, known = self._native
