@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void apply_u2d_kernel(const double* __restrict
 // reads (16 rows x 2 k) hit 64 distinct banks.
 
 constexpr int LEAF_T = 512;   // 8 waves: wave 0 factors the diagonal sub-blocks, all 8 run the MFMA phases
+constexpr int LEAF_LOAD_BATCH = 16;   // all of a thread's 16 block vectors in flight at once (8: two dependent round trips)
 constexpr int SB = 32;        // register-factored diagonal sub-block
 constexpr int SLD = NB + 2;   // 130
 constexpr int ZLD = 48;       // temp tiles [32][48]: k-row stride == 32 (mod 64) dwords
@@ -363,19 +364,21 @@ __device__ __forceinline__ void chol_leaf_body(const double* __restrict__ A, int
     stamp();
 
     {
-        // 128 x 128 block = 8192 16-byte vectors, 32 per thread, fetched in batches of 8 independent loads
+        // 128 x 128 block = 8192 16-byte vectors, 16 per thread, fetched in batches of LEAF_LOAD_BATCH independent loads: the block
+        // was written by other compute units in the launch before, so every batch pays a cold-read latency of its own
         constexpr int VPR = NB / 2;   // vectors per row
+        constexpr int LB = LEAF_LOAD_BATCH;
 #pragma unroll 1
-        for (int b0 = 0; b0 < NB * VPR / LEAF_T; b0 += 8) {
-            v2d x[8];
+        for (int b0 = 0; b0 < NB * VPR / LEAF_T; b0 += LB) {
+            v2d x[LB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < LB; ++u) {
                 const int v = tid + (b0 + u) * LEAF_T;
                 const int i = v / VPR, j = 2 * (v % VPR);
                 x[u] = (j <= i) ? *reinterpret_cast<const v2d*>(A + (int64_t)i * lda + j) : (v2d){0.0, 0.0};
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < LB; ++u) {
                 const int v = tid + (b0 + u) * LEAF_T;
                 const int i = v / VPR, j = 2 * (v % VPR);
                 if (j + 1 > i) x[u][1] = 0.0;   // strictly-upper element of a pair straddling the diagonal
@@ -808,6 +811,9 @@ __device__ __forceinline__ void chol_spine_body(const double* __restrict__ Ablk,
     // every global vector this thread will stage, fetched up front (32 independent 16-byte loads: the two A strips, the
     // 64 x 64 and the 64 x 128 halves of the triangular inverse), so the kernel pays ONE memory latency, not one per vector
     v2d ra[8], r0[8], r1[16];
+    double dold[4];         // the D tile as it is (wave 0 subtracts from it at the very end: fetched NOW, not then — a cold read is ~2.5 us)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dold[q] = D[(int64_t)(bi * SP_R + l4 + 4 * q) * lda + bj * SP_R + l15];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int v = tid + u * SP_T;                               // 2 strips x 16 rows x 64 vectors
@@ -851,10 +857,28 @@ __device__ __forceinline__ void chol_spine_body(const double* __restrict__ Ablk,
         // wave — the deeper tiles of the second half go to the waves that had the shallow ones in the first
         const int tl = half ? 3 - wave : wave;          // tile inside the half
         const int t = 4 * half + tl, K = SP_R * (t + 1);
-        const v4d pi = leaf_tile_k(lds, [&](int i, int k) { return (int)(sAi - lds) + i * SLD + k; },
-                                   [&](int k, int j) { return (tl * SP_R + j) * SLD + k; }, l15, l4, K);
-        const v4d pj = leaf_tile_k(lds, [&](int i, int k) { return (int)(sAj - lds) + i * SLD + k; },
-                                   [&](int k, int j) { return (tl * SP_R + j) * SLD + k; }, l15, l4, K);
+        // P_i and P_j tiles in ONE loop: they share the inverse fragment (B operand), and four independent accumulator chains
+        // cover the LDS latency that two chains per call left exposed (stamps: a spine workgroup was 12.5 us, 5 of them here)
+        v4d pi0 = {0.0, 0.0, 0.0, 0.0}, pi1 = pi0, pj0 = pi0, pj1 = pi0;
+        {
+            const double* ai = sAi + l15 * SLD + l4;
+            const double* aj = sAj + l15 * SLD + l4;
+            const double* bb = sInv + (tl * SP_R + l15) * SLD + l4;
+            for (int k = 0; k < K; k += 16) {       // K is a multiple of 16: two 8-deep steps per trip, all twelve reads up front
+                const double b0 = bb[k], b1 = bb[k + 4], b2 = bb[k + 8], b3 = bb[k + 12];
+                const double x0 = ai[k], x1 = ai[k + 4], x2 = ai[k + 8], x3 = ai[k + 12];
+                const double y0 = aj[k], y1 = aj[k + 4], y2 = aj[k + 8], y3 = aj[k + 12];
+                pi0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, b0, pi0, 0, 0, 0);
+                pj0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, b0, pj0, 0, 0, 0);
+                pi1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b1, pi1, 0, 0, 0);
+                pj1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, b1, pj1, 0, 0, 0);
+                pi0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, b2, pi0, 0, 0, 0);
+                pj0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y2, b2, pj0, 0, 0, 0);
+                pi1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, b3, pi1, 0, 0, 0);
+                pj1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y3, b3, pj1, 0, 0, 0);
+            }
+        }
+        const v4d pi = pi0 + pi1, pj = pj0 + pj1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             sPi[(l4 + 4 * q) * SLD + t * SP_R + l15] = pi[q];
@@ -876,8 +900,7 @@ __device__ __forceinline__ void chol_spine_body(const double* __restrict__ Ablk,
         for (int q = 0; q < 4; ++q) {
             const int r = l4 + 4 * q;
             const double sum = (sInv[r * SLD + l15] + sInv[(SP_R + r) * SLD + l15]) + (sInv[(2 * SP_R + r) * SLD + l15] + sInv[(3 * SP_R + r) * SLD + l15]);
-            double* d = D + (int64_t)(bi * SP_R + r) * lda + bj * SP_R + l15;
-            *d -= sum;
+            D[(int64_t)(bi * SP_R + r) * lda + bj * SP_R + l15] = dold[q] - sum;
         }
     }
     if (bj == 0) {      // this column of workgroups covers every strip once: P_i -> L[j+1, j]
@@ -898,14 +921,19 @@ __global__ __launch_bounds__(SP_T) void chol_spine_kernel(const double* __restri
 // inv(L_jj)^T): both need leaf j only, neither needs the other.
 __global__ __launch_bounds__(SP_T) void chol_step_spine_kernel(const double* __restrict__ Ablk, int64_t lda, const double* __restrict__ inv,
                                                                 int64_t ldi, double* __restrict__ Lout, int64_t ldl, double* __restrict__ D,
-                                                                GemmShape panel, EpiAxpby panel_epi) {
+                                                                GemmShape panel, EpiAxpby panel_epi, long long* stamps, int step) {
     __shared__ __attribute__((aligned(16))) double lds[SP_LDS];
+    // diagnostic (stamps usually null): [start, -, end, kind] per workgroup behind the leaf launches' table (kind 4 spine, 5 panel)
+    long long* stamp = (stamps && blockIdx.x < 512) ? stamps + ((int64_t)(16 + step) * 512 + blockIdx.x) * 4 : nullptr;
+    if (stamp && threadIdx.x == 0) stamp[0] = (long long)__builtin_amdgcn_s_memrealtime();
     if (blockIdx.x < 36) {
         chol_spine_body(Ablk, lda, inv, ldi, Lout, ldl, D, (int)blockIdx.x, lds);
+        if (stamp && threadIdx.x == 0) { stamp[2] = (long long)__builtin_amdgcn_s_memrealtime(); stamp[3] = 4; }
         return;
     }
     const int t = (int)blockIdx.x - 36;
     gemm_f64_tile<true, true, 32, 64, 16, 2, 2, EpiAxpby>(panel, panel_epi, t / 2, t % 2, 0, lds);
+    if (stamp && threadIdx.x == 0) { stamp[2] = (long long)__builtin_amdgcn_s_memrealtime(); stamp[3] = 5; }
 }
 
 // ---- host orchestration -------------------------------------------------------------------------------
@@ -1204,7 +1232,7 @@ static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, do
             }
             ScopedProf sp(KC_CHOL_PANEL, st);
             hipLaunchKernelGGL(chol_step_spine_kernel, dim3(36 + npanel), dim3(SP_T), 0, st, A + (o + NB) * lda + o, lda, inv,
-                               (int64_t)OB, L + (o + NB) * lda + o, lda, A + (o + NB) * lda + o + NB, ps, pe);
+                               (int64_t)OB, L + (o + NB) * lda + o, lda, A + (o + NB) * lda + o + NB, ps, pe, g_step_stamps, j);
         }
     }
     build_block_inverses(L, n, lda, invw, st);
@@ -1697,7 +1725,8 @@ int emcid_dgemm_streamk_f64(int tb, int64_t M, int64_t N, int64_t K, double alph
  * [0] start, [1] end, cycles in [2] K loops, [3] partial-tile publishes, [4] last-ticket reductions, [5] epilogues,
  * [6] segments, [7] run index */
 /* diagnostic: chol_step_leaf_kernel writes, per launch slice s < 16 and workgroup b < 512, [start, -, end, kind] (constant
- * 100 MHz clock; kind 1 leaf, 2 trailing tile, 3 shadow tile pair) at stamps_dev[(s * 512 + b) * 4]; null switches it off.
+ * 100 MHz clock; kind 1 leaf, 2 trailing tile, 3 shadow tile pair) at stamps_dev[(s * 512 + b) * 4], and the same for the spine
+ * launches (kind 4 spine tile, 5 panel tile) at stamps_dev[((16 + s) * 512 + b) * 4]: 32 * 512 * 4 values; null switches it off.
  * Set it before the first edit of the process (captured graphs keep the pointer they were captured with). */
 int emcid_debug_step_stamps(long long* stamps_dev) {
     g_step_stamps = stamps_dev;

@@ -13,7 +13,7 @@ from emcid_amd.emcid_hparams import EMCIDHyperParams
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 dev = "cuda:0"
 lib = hip.load()
-stamps = torch.zeros(16 * 512 * 4, dtype=torch.int64, device=dev)
+stamps = torch.zeros(32 * 512 * 4, dtype=torch.int64, device=dev)
 lib.emcid_debug_step_stamps(C.c_void_p(stamps.data_ptr()))       # before the first edit: the graphs capture the pointer
 work = Path(tempfile.gettempdir()) / f"emcid_bench_{os.getuid()}"
 work.mkdir(exist_ok=True)
@@ -23,9 +23,9 @@ for _ in range(4):
     stamps.zero_()
     em.apply_emcid_to_text_encoder(pipe, reqs, hp, dev, cache_name=cache, stats_dir=stats, verbose=False)
 torch.cuda.synchronize()
-s = stamps.view(16, 512, 4).cpu()
-kinds = {1: "leaf", 2: "trailing", 3: "shadow"}
-for sl in range(16):
+s = stamps.view(32, 512, 4).cpu()
+kinds = {1: "leaf", 2: "trailing", 3: "shadow", 4: "spine", 5: "panel"}
+for sl in range(32):
     rows = s[sl][s[sl][:, 3] > 0]
     if rows.numel() == 0:
         continue
