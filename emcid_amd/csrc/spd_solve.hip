@@ -2048,7 +2048,10 @@ int emcid_edit_dual_apply_stage1_f64(const float* K, const float* Zc, const floa
     }
     const int64_t rows = n_hi - n_lo;
     if (use_inverse) {
-        apply_inverse_forward(cov_inverse(cov_factor_ws, n_layers, dp, layer_index), dp, Kt + n_lo * dp, Yt + n_lo * dp, (int)rows,
+        // the whole concept range: run over the Np padded rows (Kt's padding rows are zero, so are the products) — every
+        // 128-row tile then lies inside the operand and takes the interior fast path of the stream-K K loop
+        const int64_t gemm_rows = (n_lo == 0 && n_hi == N) ? ws.Np : rows;
+        apply_inverse_forward(cov_inverse(cov_factor_ws, n_layers, dp, layer_index), dp, Kt + n_lo * dp, Yt + n_lo * dp, (int)gemm_rows,
                               st, base + ws.off_SK);
         EMCID_CHECK_LAUNCH();
         return EMCID_OK;
@@ -2157,7 +2160,8 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
         // W0 / W / dW are the caller's tensors and change from layer to layer and call to call)
         ScopedProf sp(KC_DELTA_W, st);
         GemmShape g{RT, Np, P, dp, (int)h, (int)d, (int)Np, 0};
-        launch_gemm_f64<true, false>(g, EpiDeltaW{W0, W, d, dW_out, d, nullptr, 0}, st);
+        static const int u_cfg = env_flag("EMCID_U_GEMM_CFG", -1);      // -1: the launcher's choice (32 x 64 tiles); 1: 64 x 64; 0: 128 x 128
+        launch_gemm_f64<true, false>(g, EpiDeltaW{W0, W, d, dW_out, d, nullptr, 0}, st, u_cfg);
         EMCID_CHECK_LAUNCH();
         return EMCID_OK;
     }

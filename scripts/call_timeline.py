@@ -71,3 +71,16 @@ for seg in calls[-n_calls:]:
 print(f"--- kernel totals per segment (mean over {nseg} segments), us: name, launches, total, mean")
 for k, (t, c) in sorted(tot.items(), key=lambda kv: -kv[1][0])[:40]:
     print(f"   {k:72s} {c / nseg:7.1f} {t / nseg / 1e3:9.1f} {t / c / 1e3:8.2f}")
+
+# launch-by-launch listing of the solve of the last edited layer (from its prep_kr_kernel to the end of the call), with durations
+# and the gap before each launch: argv[5] = "list"
+if len(sys.argv) > 5 and sys.argv[5] == "list":
+    seg = calls[-1]
+    starts = [i for i, r in enumerate(seg) if "prep_kr_kernel" in r[2]]
+    if starts:
+        prev_end = seg[starts[-1] - 1][1] if starts[-1] > 0 else seg[starts[-1]][0]
+        t0l = seg[starts[-1]][0]
+        print("--- last layer's solve, launch by launch: +start us, duration us, gap before us, kernel")
+        for s_, e_, n_ in seg[starts[-1]:]:
+            print(f"   +{(s_ - t0l) / 1e3:8.1f} {(e_ - s_) / 1e3:8.1f} {(s_ - prev_end) / 1e3:7.1f}  {short(n_)}")
+            prev_end = max(prev_end, e_)
