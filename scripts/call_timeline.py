@@ -84,3 +84,13 @@ if len(sys.argv) > 5 and sys.argv[5] == "list":
         for s_, e_, n_ in seg[starts[-1]:]:
             print(f"   +{(s_ - t0l) / 1e3:8.1f} {(e_ - s_) / 1e3:8.1f} {(s_ - prev_end) / 1e3:7.1f}  {short(n_)}")
             prev_end = max(prev_end, e_)
+
+# argv[5] = "head:<n>": the first n launches of the last full call (prefix forward), launch by launch
+if len(sys.argv) > 5 and sys.argv[5].startswith("head:"):
+    n_ = int(sys.argv[5].split(":")[1])
+    seg = max(calls[-4:], key=len)
+    t0l, prev_end = seg[0][0], seg[0][0]
+    print("--- first launches of the call: +start us, duration us, gap before us, kernel")
+    for s_, e_, k_ in seg[:n_]:
+        print(f"   +{(s_ - t0l) / 1e3:8.1f} {(e_ - s_) / 1e3:8.1f} {(s_ - prev_end) / 1e3:7.1f}  {short(k_)}")
+        prev_end = max(prev_end, e_)
