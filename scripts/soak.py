@@ -1,0 +1,26 @@
+import os, sys, tempfile, time, statistics
+from pathlib import Path
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch, bench
+from emcid_amd import emcid_main as em
+from emcid_amd.emcid_hparams import EMCIDHyperParams
+from emcid_amd.nethook import get_parameter
+dev = "cuda:0"
+work = Path(tempfile.gettempdir()) / f"emcid_bench_{os.getuid()}"; work.mkdir(exist_ok=True)
+pipe, reqs, hp_d, cache, stats, names = bench.build_inputs(1000, dev, work)
+hp = EMCIDHyperParams(**hp_d)
+orig = {n: get_parameter(pipe.text_encoder, n + ".weight").detach().clone() for n in names}
+def call():
+    with torch.no_grad():
+        for n in names: get_parameter(pipe.text_encoder, n + ".weight").copy_(orig[n])
+    em.apply_emcid_to_text_encoder(pipe, reqs, hp, dev, cache_name=cache, stats_dir=stats, verbose=False)
+for _ in range(5): call()
+ref = {n: get_parameter(pipe.text_encoder, n + ".weight").detach().clone() for n in names}
+m0 = torch.cuda.memory_allocated(); r0 = torch.cuda.memory_reserved()
+ts = []
+for i in range(400):
+    t = time.perf_counter(); call(); ts.append((time.perf_counter() - t) * 1e3)
+same = all(torch.equal(ref[n], get_parameter(pipe.text_encoder, n + ".weight")) for n in names)
+print("calls 400 median", round(statistics.median(ts), 2), "p95", round(sorted(ts)[380], 2), "max", round(max(ts), 2),
+      "first100", round(statistics.median(ts[:100]), 2), "last100", round(statistics.median(ts[-100:]), 2))
+print("bit-identical weights after 400 calls:", same, "alloc delta MB", (torch.cuda.memory_allocated() - m0) / 1e6, "reserved delta MB", (torch.cuda.memory_reserved() - r0) / 1e6)
