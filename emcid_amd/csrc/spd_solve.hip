@@ -1391,12 +1391,32 @@ static int build_full_inverse(const double* L, int64_t dp, int64_t lda, const do
 static const int kStreamKWgs = 256;
 static const int kStreamKForm = env_flag("EMCID_STREAMK_V", 2);      // 2: two-phase, reproducible; 1: f64 atomics into a zeroed C
 
+// With the interior fast path of the small-tile ring, mirrored PAIRS of 32 x 64 tiles (every workgroup contracts over the same
+// total depth, three 4-wave workgroups per compute unit, no split, no fix-up) beat the stream-K form whenever their count fills
+// the chip's 768 slots evenly (scripts/mb_tri_small.py, d = 3072, us stream-K / pairs: 1024 rows 187 / 172 and 195 / 177; 768
+// rows 146 / 161; 512 rows 104 / 118), and for very few rows on the backward product (128 rows: 114 / 80; 256: 98 / 81), where a
+// stream-K run is mostly fix-up.  EMCID_TRI_PAIRS=0 keeps stream-K everywhere.
+static inline bool pairs_fill_the_chip(int rows, int64_t dp, bool backward) {
+    static const int enabled = env_flag("EMCID_TRI_PAIRS", 1);
+    if (!enabled) return false;
+    const int64_t wgs = (int64_t)((rows + 31) / 32) * (((dp + 63) / 64 + 1) / 2);
+    if (backward && rows <= 256) return true;
+    if (wgs < 768) return false;
+    const int64_t tail = wgs % 768;
+    return tail == 0 || tail >= 700;
+}
+
 // Yt[rows, dp] = Kt[rows, dp] * X^T  (= Kt L^-T: the forward substitution as one GEMM)
 static void apply_inverse_forward(const double* X, int64_t dp, const double* Kt, double* Yt, int rows, hipStream_t st,
                                   double* sk_work = nullptr) {
     ScopedProf sp(KC_INV_APPLY, st);
     GemmShape g{Kt, dp, X, dp, rows, (int)dp, (int)dp, 0};
     g.tri = 1;       // B(k, n) = X[n][k], zero for k > n
+    if (pairs_fill_the_chip(rows, dp, false)) {
+        g.pair = 1;
+        launch_gemm_f64<true, true>(g, EpiAxpby{Yt, dp, 1.0, 0.0}, st, 2);
+        return;
+    }
     if (sk_work && kStreamKForm == 2) {
         launch_gemm_f64_streamk2<true, true>(g, EpiAxpby{Yt, dp, 1.0, 0.0}, st, kStreamKWgs, sk_work);
         return;
@@ -1411,6 +1431,11 @@ static void apply_inverse_backward(const double* X, int64_t dp, const double* V,
     ScopedProf sp(KC_INV_APPLY, st);
     GemmShape g{V, dp, X, dp, rows, ncols, (int)dp, 0};
     g.tri = 2;       // B(k, n) = X[k][n], zero for k < n
+    if (ncols == (int)dp && pairs_fill_the_chip(rows, dp, true)) {
+        g.pair = 1;
+        launch_gemm_f64<true, false>(g, EpiAxpby{C, ldc, 1.0, 0.0}, st, 2);
+        return;
+    }
     if (sk_work && kStreamKForm == 2) {
         launch_gemm_f64_streamk2<true, false>(g, EpiAxpby{C, ldc, 1.0, 0.0}, st, kStreamKWgs, sk_work);
         return;
