@@ -170,8 +170,9 @@ KERNEL_OF_CLASS = {
     "trsm_update": "gemm_f64_kernel<KC,*,*,*,16,EpiAxpby> launched as rank-512 TRSM update",
     "trsm_diag": "gemm_f64_kernel<KC,*,32,64,16,2,2,EpiAxpby> launched as TRSM diagonal-block multiply",
     "delta_w": "gemm_f64_kernel (V = Z^T Yt in the dual solver, dW = R^T X in the direct one)",
-    "inv_apply": "gemm_f64_streamk_kernel<KC,*,128,128,16,2,4>: GEMM against the explicit inverse factor (Kt X^T, V X; "
-                 "triangular K range)",
+    "inv_apply": "GEMM against the explicit inverse factor (Yt = Kt X^T; triangular K range): gemm_f64_kernel<KC,KC,32,64,16,2,2> on "
+                 "mirrored tile pairs where their count fills the chip evenly (N = 1000, d = 3072), else gemm_f64_streamk2_kernel "
+                 "<KC,*,128,128,16,2,4>",
     "inv_build": "gemm_f64_kernel<KC,!KC,*,*,16,*> launched as recursive-halving build of X = inv(L)",
 }
 FP64_CLASSES = ["assemble", "chol_leaf", "chol_panel", "chol_trail", "chol_inner", "chol_fused", "inv_block", "trsm_diag",
