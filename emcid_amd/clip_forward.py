@@ -330,8 +330,8 @@ def tune_projections(graph: ClipTextGraph, trie: TokenTrie, upto: int, mode: str
         t.set_max_tuning_iterations(10)
         # Timing every library solution of a shape normally takes ~0.5 s per shape; on a box whose page cache has never seen
         # the GEMM libraries' code objects it was measured at 70-130 s in total.  Past the budget (EMCID_TUNE_BUDGET_S, default
-        # 30 s per process) the remaining shapes keep the library's own choice (a few per cent slower) and are not retried.
-        budget = float(os.environ.get("EMCID_TUNE_BUDGET_S", "30"))
+        # 150 s per process) the remaining shapes keep the library's own choice (a few per cent slower) and are not retried.
+        budget = float(os.environ.get("EMCID_TUNE_BUDGET_S", "150"))
         with torch.no_grad():
             for rows, k, n, has_bias in todo:
                 if TUNING_SECONDS_TOTAL + (time.perf_counter() - t0) > budget:
