@@ -199,6 +199,93 @@ __global__ __launch_bounds__(256) void quick_gelu_f32_kernel(const float* __rest
 
 using namespace emcid;
 
+// Chains of at most 8 nodes (the mass-edit prompts: BOS + a few template words + a few name tokens): everything a workgroup needs
+// is fetched in TWO dependent rounds — its chain, then q and every k / v row of all its heads — and the softmax over <= 8 keys
+// lives in registers (two keys per 16-lane group, combined with shuffles): no LDS, no barrier.  The general kernel above pays two
+// dependent global reads and three barriers per round of four heads (38 us for 6 400 nodes x 12 heads; this one: see DESIGN.md).
+template <int ROUNDS, int KPS>
+__global__ __launch_bounds__(256) void tree_attention_short_kernel(TreeAttnArgs a) {
+    // KPS keys per 16-lane group: chains of up to 4 * KPS nodes (KPS = 2: 8, KPS = 4: 16)
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = lane >> 4, dl = lane & 15;
+    const int qi = blockIdx.x;
+    const int u = a.rows ? a.rows[qi] : qi;
+    const int nk = a.depth[u] + 1;
+    bool has[KPS];
+    int64_t pk[KPS];
+#pragma unroll
+    for (int c = 0; c < KPS; ++c) {
+        has[c] = slot + 4 * c < nk;
+        pk[c] = a.anc[(int64_t)u * a.anc_ld + (has[c] ? slot + 4 * c : 0)];
+    }
+    const bool dok = 4 * dl < a.D;
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    v4f q4[ROUNDS], kk[ROUNDS][KPS], vv[ROUNDS][KPS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int h = r * 4 + wave;
+        const int64_t col = (int64_t)(h < a.H ? h : 0) * a.D + (dok ? 4 * dl : 0);
+        q4[r] = *reinterpret_cast<const v4f*>(a.q + (int64_t)qi * a.ldq + col);
+#pragma unroll
+        for (int c = 0; c < KPS; ++c) {
+            kk[r][c] = *reinterpret_cast<const v4f*>(a.k + pk[c] * a.ld + col);
+            vv[r][c] = *reinterpret_cast<const v4f*>(a.v + pk[c] * a.ld + col);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int h = r * 4 + wave;
+        float sc[KPS];
+#pragma unroll
+        for (int c = 0; c < KPS; ++c)
+            sc[c] = dok ? q4[r][0] * kk[r][c][0] + q4[r][1] * kk[r][c][1] + q4[r][2] * kk[r][c][2] + q4[r][3] * kk[r][c][3] : 0.f;
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1)
+#pragma unroll
+            for (int c = 0; c < KPS; ++c) sc[c] += __shfl_xor(sc[c], o);
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < KPS; ++c) {
+            sc[c] = has[c] ? sc[c] * a.scale : -INFINITY;
+            m = fmaxf(m, sc[c]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.f;
+        v4f acc = zero;
+#pragma unroll
+        for (int c = 0; c < KPS; ++c) {
+            const float e = has[c] ? expf(sc[c] - m) : 0.f;
+            l += e;
+            if (dok) acc += e * vv[r][c];
+        }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[e] += __shfl_xor(acc[e], 16);
+            acc[e] += __shfl_xor(acc[e], 32);
+        }
+        if (h < a.H && slot == 0 && dok) {
+            const float inv = 1.f / l;
+            *reinterpret_cast<v4f*>(a.out + (int64_t)qi * a.ldo + (int64_t)h * a.D + 4 * dl) = acc * inv;
+        }
+    }
+}
+
+template <int KPS>
+static void launch_tree_attention_short(const TreeAttnArgs& a, int rounds, hipStream_t st) {
+    const dim3 g((unsigned)a.n_rows), b(256);
+    switch (rounds) {
+        case 1: hipLaunchKernelGGL((tree_attention_short_kernel<1, KPS>), g, b, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((tree_attention_short_kernel<2, KPS>), g, b, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((tree_attention_short_kernel<3, KPS>), g, b, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((tree_attention_short_kernel<4, KPS>), g, b, 0, st, a); break;
+        default: hipLaunchKernelGGL((tree_attention_short_kernel<5, KPS>), g, b, 0, st, a); break;
+    }
+}
+
 extern "C" int emcid_tree_attention_f32(const float* q, int64_t ldq, const float* k, const float* v, int64_t ld, const int* anc,
                                         int64_t anc_ld, const int* depth, const int* rows, int64_t n_rows, int64_t H,
                                         int64_t D, float scale, float* out, int64_t ldo, void* stream) {
@@ -207,7 +294,14 @@ extern "C" int emcid_tree_attention_f32(const float* q, int64_t ldq, const float
     EMCID_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out) && n_rows < (1LL << 31));
     TreeAttnArgs a{q, ldq, k, v, ld, anc, anc_ld, depth, rows, (int)n_rows, (int)H, (int)D, scale, out, ldo};
     ScopedProf sp(KC_MISC, (hipStream_t)stream);
-    hipLaunchKernelGGL(tree_attention_f32_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, a);
+    static const int short_ok = [] { const char* e = getenv("EMCID_TREE_ATTN_SHORT"); return e ? atoi(e) : 1; }();
+    const int rounds = (int)((H + 3) / 4);
+    if (short_ok && anc_ld <= 16 && rounds <= 5) {      // every chain has at most anc_ld nodes
+        if (anc_ld <= 8) launch_tree_attention_short<2>(a, rounds, (hipStream_t)stream);
+        else launch_tree_attention_short<4>(a, rounds, (hipStream_t)stream);
+    } else {
+        hipLaunchKernelGGL(tree_attention_f32_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, a);
+    }
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }

@@ -216,7 +216,9 @@ def test_quick_gelu_vs_torch():
     torch.testing.assert_close(hip.quick_gelu(y), y * torch.sigmoid(1.702 * y), rtol=2e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("U,H,D,max_depth", [(300, 3, 16, None), (300, 12, 64, 9), (400, 20, 64, 15), (300, 5, 32, 16)])
+@pytest.mark.parametrize("U,H,D,max_depth", [(300, 3, 16, None), (300, 12, 64, 9), (400, 20, 64, 15), (300, 5, 32, 16),
+                                             (700, 12, 64, 6), (300, 20, 64, 7), (300, 12, 64, 2), (300, 1, 8, 4),   # <= 8 nodes
+                                             (300, 12, 64, 40)])                                                      # general kernel
 def test_tree_attention_vs_dense_reference(U, H, D, max_depth):
     """Random trie: every node attends to its ancestor chain; compare with per-node dense softmax in torch.
     Short chains (mass-edit prompts) and long ones, CLIP-L and bigG head shapes."""
