@@ -143,6 +143,7 @@ class TokenTrie:
     n_nodes: int               # distinct prefixes (the arrays above are padded to a multiple of ROW_BUCKET rows)
     n_tokens_dense: int        # B * S the dense forward would process
     tail: Optional[torch.Tensor] = None   # the caller's own int64 array uploaded with the trie (build_trie(tail=...))
+    max_token: int = -1        # largest token id (host copy; -1: not recorded) — range check of the fused embedding kernel
 
 
 ROW_BUCKET = 256   # node / query-row counts are padded to a multiple of this: a few GEMM shapes per encoder, not one per batch
@@ -186,8 +187,10 @@ def build_trie(input_ids, lookup: Sequence[int], device, bucket: int = ROW_BUCKE
         return TokenTrie(img[:8 * U].view(torch.int64), img[o32:o32 + 4 * U].view(torch.int32),
                          img[o32 + 4 * (U + R):o32 + 4 * (U + R + U * D)].view(torch.int32).view(U, D),
                          img[8 * U:8 * (U + n)].view(torch.int64), img[o32 + 4 * U:o32 + 4 * (U + R)].view(torch.int32),
-                         img[8 * (U + n):o32].view(torch.int64), z["n_real"], B * tok.shape[1], tail_dev)
+                         img[8 * (U + n):o32].view(torch.int64), z["n_real"], B * tok.shape[1], tail_dev,
+                         int(tok[:, :dmax].max()))
     t = build_trie_numpy(tok, lk, device, bucket)
+    t.max_token = int(tok[:, :dmax].max())
     if tail is not None:
         t.tail = torch.from_numpy(np.ascontiguousarray(tail, dtype=np.int64)).to(device)
     return t
@@ -479,7 +482,17 @@ def run_prefix(graph: ClipTextGraph, trie: TokenTrie, stop: int):
     """Layers 0..stop-1 on every node: the state (residual stream, LN1 of it or None) that enters layer ``stop``."""
     _check_fp32(graph)
     with tuned_gemms():
-        hs, x_ln1 = embed(graph, trie), None
+        ln0 = graph.layers[0].ln1 if stop > 0 and graph.layers else None
+        te, pe = graph.token_embedding, graph.position_embedding
+        if ln0 is not None and _fusable(ln0) and te.weight.is_cuda and te.weight.dtype == torch.float32 \
+                and te.weight.stride(1) == 1 and pe.weight.stride(1) == 1 and te.padding_idx is None and te.max_norm is None \
+                and pe.max_norm is None and trie.depth.dtype == torch.int32 and trie.token.dtype == torch.int64 \
+                and 0 <= trie.max_token < te.num_embeddings and trie.anc.shape[1] <= pe.num_embeddings:
+            # embeddings + the first layer's LN1 in one launch; token and position ranges are checked on the host copies
+            # (anything out of range takes the torch path, which raises like the reference's forward)
+            hs, x_ln1 = hip.embed_layernorm(te.weight, pe.weight, trie.token, trie.depth, ln0)
+        else:
+            hs, x_ln1 = embed(graph, trie), None
         for i in range(stop):
             hs, x_ln1 = _layer_full(graph, i, trie, hs, x_ln1, stop)
     return hs, x_ln1

@@ -313,11 +313,13 @@ constexpr int LN_MAX_V4 = 8;    // float4 chunks per thread: rows up to 8 * 256 
 __global__ __launch_bounds__(256) void add_layernorm_f32_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
                                                                  int64_t ldb, const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta, float eps, int cols,
-                                                                 float* __restrict__ y, float* __restrict__ z) {
+                                                                 float* __restrict__ y, float* __restrict__ z,
+                                                                 const int64_t* __restrict__ ia, const int* __restrict__ ib) {
+    // ia / ib (usually null): row r reads a[ia[r]] and b[ib[r]] — the embedding lookups of the first layer's input
     const int64_t row = blockIdx.x;
     const int nv = cols / 4;
-    const float4* pa = reinterpret_cast<const float4*>(a + row * lda);
-    const float4* pb = reinterpret_cast<const float4*>(b + row * ldb);
+    const float4* pa = reinterpret_cast<const float4*>(a + (ia ? ia[row] : row) * lda);
+    const float4* pb = reinterpret_cast<const float4*>(b + (ib ? (int64_t)ib[row] : row) * ldb);
     float4 v[LN_MAX_V4];
     float sum = 0.f;
 #pragma unroll
@@ -373,7 +375,23 @@ extern "C" int emcid_add_layernorm_f32(const float* a, int64_t lda, const float*
     EMCID_CHECK_ARG(aligned16(a) && aligned16(b) && aligned16(gamma) && aligned16(beta) && aligned16(y) && aligned16(z));
     ScopedProf sp(KC_MISC, (hipStream_t)stream);
     hipLaunchKernelGGL(add_layernorm_f32_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, gamma,
-                       beta, eps, (int)cols, y, z);
+                       beta, eps, (int)cols, y, z, (const int64_t*)nullptr, (const int*)nullptr);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+/* y[r] = tok[token[r]] + pos[position[r]] ; z = LayerNorm(y): the embedding stage of the text encoder (HF CLIPTextEmbeddings:
+ * token_embedding(ids) + position_embedding(position_ids)) and the first layer's LN1 in one launch instead of five (two gathers,
+ * a cast, an add, a LayerNorm) — at the head of an edit call the GPU waits for every one of those launches. */
+extern "C" int emcid_embed_layernorm_f32(const float* tok, int64_t ld_tok, int64_t n_tok, const float* pos, int64_t ld_pos,
+                                         int64_t n_pos, const int64_t* token, const int* position, const float* gamma,
+                                         const float* beta, float eps, int64_t rows, int64_t cols, float* y, float* z, void* stream) {
+    EMCID_CHECK_ARG(tok && pos && token && position && gamma && beta && y && z && rows > 0 && cols > 0 && rows < (1LL << 31));
+    EMCID_CHECK_ARG(n_tok > 0 && n_pos > 0 && cols % 4 == 0 && cols <= LN_MAX_V4 * 256 * 4 && ld_tok % 4 == 0 && ld_pos % 4 == 0);
+    EMCID_CHECK_ARG(aligned16(tok) && aligned16(pos) && aligned16(gamma) && aligned16(beta) && aligned16(y) && aligned16(z));
+    ScopedProf sp(KC_MISC, (hipStream_t)stream);
+    hipLaunchKernelGGL(add_layernorm_f32_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, tok, ld_tok, pos, ld_pos,
+                       gamma, beta, eps, (int)cols, y, z, token, position);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }

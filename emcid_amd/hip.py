@@ -20,7 +20,7 @@ EXPORTS = [
     "emcid_gather_mean_f32", "emcid_edit_workspace_bytes", "emcid_edit_layer_f64", "emcid_assemble_spd_f64",
     "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_dgemm_ex_f64", "emcid_dgemm_batched_f64", "emcid_streamk_workspace_bytes", "emcid_dgemm_streamk_f64", "emcid_debug_streamk_stamps", "emcid_debug_step_stamps", "emcid_axpy_f32",
     "emcid_profile_enable", "emcid_profile_collect", "emcid_attention_f32", "emcid_edit_layer_shard_f64",
-    "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32", "emcid_add_layernorm_f32", "emcid_tree_attention_f32", "emcid_debug_leaf_stamps",
+    "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32", "emcid_add_layernorm_f32", "emcid_embed_layernorm_f32", "emcid_tree_attention_f32", "emcid_debug_leaf_stamps",
     "emcid_cov_factor_workspace_bytes", "emcid_factor_cov_f64", "emcid_cov_inverse_f64",
     "emcid_edit_dual_workspace_bytes",
     "emcid_edit_dual_stage1_f64", "emcid_edit_dual_pt", "emcid_edit_dual_stage2_f64",
@@ -33,7 +33,7 @@ EXPORTS = [
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block"]
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 NB = 128      # Cholesky block (csrc/common.h)
 NPAD = 64     # concept padding of the f64 stacks (csrc/common.h)
 
@@ -102,6 +102,7 @@ def load():
         "emcid_axpy_f32": (i32, [p, p, i64, p]),
         "emcid_quick_gelu_f32": (i32, [p, p, i64, p]),
         "emcid_add_layernorm_f32": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p]),
+        "emcid_embed_layernorm_f32": (i32, [p, i64, i64, p, i64, i64, p, p, p, p, C.c_float, i64, i64, p, p, p]),
         "emcid_tree_attention_f32": (i32, [p, i64, p, p, i64, p, i64, p, p, i64, i64, i64, f32, p, i64, p]),
         "emcid_profile_enable": (i32, [C.c_uint]),
         "emcid_profile_collect": (i32, [p, p, i32]),
@@ -474,6 +475,25 @@ def add_layernorm(a: torch.Tensor, b: torch.Tensor, ln: torch.nn.LayerNorm):
     _check(load().emcid_add_layernorm_f32(_ptr(a, torch.float32, "a"), a.stride(0), _ptr(b, torch.float32, "b"), b.stride(0),
                                           _ptr(ln.weight, torch.float32, "gamma"), _ptr(ln.bias, torch.float32, "beta"),
                                           float(ln.eps), rows, cols, _ptr(y), _ptr(z), _stream(a)), "emcid_add_layernorm_f32")
+    return y, z
+
+
+def embed_layernorm(tok_emb: torch.Tensor, pos_emb: torch.Tensor, token: torch.Tensor, position: torch.Tensor,
+                    ln: torch.nn.LayerNorm):
+    """(tok_emb[token] + pos_emb[position], LayerNorm of it) in one launch; token int64 (rows,), position int32 (rows,)."""
+    rows, cols = token.numel(), tok_emb.shape[1]
+    if tok_emb.stride(1) != 1 or pos_emb.stride(1) != 1 or pos_emb.shape[1] != cols or position.numel() != rows:
+        raise EmcidHipError("embed_layernorm: embedding tables with unit column stride and one index pair per row")
+    if ln.weight is None or ln.bias is None or tuple(ln.normalized_shape) != (cols,):
+        raise EmcidHipError("embed_layernorm: LayerNorm over the last dimension with affine parameters")
+    y = torch.empty(rows, cols, dtype=torch.float32, device=tok_emb.device)
+    z = torch.empty_like(y)
+    _check(load().emcid_embed_layernorm_f32(_ptr(tok_emb, torch.float32, "tok_emb"), tok_emb.stride(0), tok_emb.shape[0],
+                                            _ptr(pos_emb, torch.float32, "pos_emb"), pos_emb.stride(0), pos_emb.shape[0],
+                                            _ptr(token, torch.int64, "token"), _ptr(position, torch.int32, "position"),
+                                            _ptr(ln.weight, torch.float32, "gamma"), _ptr(ln.bias, torch.float32, "beta"),
+                                            float(ln.eps), rows, cols, _ptr(y), _ptr(z), _stream(tok_emb)),
+           "emcid_embed_layernorm_f32")
     return y, z
 
 

@@ -28,7 +28,7 @@ extern "C" {
 #define EMCID_ERR_HIP (-2)
 #define EMCID_ERR_WORKSPACE (-3)
 
-#define EMCID_ABI_VERSION 7
+#define EMCID_ABI_VERSION 8
 
 /* ABI version of the loaded library (host-only, no GPU needed). */
 int emcid_abi_version(void);
@@ -99,6 +99,14 @@ int emcid_quick_gelu_f32(const float* x, float* y, int64_t n, void* stream);
  * pass.  a/b: [rows, cols] with row strides lda/ldb (elements); y, z: [rows, cols] contiguous; cols % 4 == 0, <= 8192. */
 int emcid_add_layernorm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gamma, const float* beta,
                             float eps, int64_t rows, int64_t cols, float* y, float* z, void* stream);
+
+/* y[r] = tok[token[r]] + pos[position[r]] ; z = LayerNorm(y): the encoder's embedding stage (transformers CLIPTextEmbeddings,
+ * called inside the hooked forward of emcid/compute_z.py:2296-2308) fused with the first layer's LN1.  tok [n_tok, cols], pos
+ * [n_pos, cols] (row strides ld_tok / ld_pos); token int64 [rows] in [0, n_tok), position int32 [rows] in [0, n_pos) — the
+ * caller guarantees the ranges (HF raises an index error instead); y, z [rows, cols] contiguous. */
+int emcid_embed_layernorm_f32(const float* tok, int64_t ld_tok, int64_t n_tok, const float* pos, int64_t ld_pos, int64_t n_pos,
+                              const int64_t* token, const int* position, const float* gamma, const float* beta, float eps,
+                              int64_t rows, int64_t cols, float* y, float* z, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage 2 — per-layer closed form (reference: emcid/emcid_main.py:1016-1061).
