@@ -367,6 +367,73 @@ __global__ __launch_bounds__(256) void add_layernorm_f32_kernel(const float* __r
     }
 }
 
+// Rows of up to 2048 columns: one WAVE per row (four rows per workgroup), both reductions by shuffles — no LDS, no barrier; a
+// workgroup's four rows are independent, so nothing in it waits for anything but its own loads (15 -> 11 us at 6400 x 768).
+__global__ __launch_bounds__(256) void add_layernorm_wave_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
+                                                                  int64_t ldb, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float eps, int cols, int rows,
+                                                                  float* __restrict__ y, float* __restrict__ z,
+                                                                  const int64_t* __restrict__ ia, const int* __restrict__ ib) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = cols / 4;
+    const float4* pa = reinterpret_cast<const float4*>(a + (ia ? ia[row] : row) * lda);
+    const float4* pb = reinterpret_cast<const float4*>(b + (ib ? (int64_t)ib[row] : row) * ldb);
+    float4 v[LN_MAX_V4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float4 x = pa[c], w = pb[c];
+            v[i] = make_float4(x.x + w.x, x.y + w.y, x.z + w.z, x.w + w.w);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum / (float)cols;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+            sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    const float rstd = rsqrtf(sq / (float)cols + eps);
+    float4* py = reinterpret_cast<float4*>(y + row * (int64_t)cols);
+    float4* pz = reinterpret_cast<float4*>(z + row * (int64_t)cols);
+    const float4* pg = reinterpret_cast<const float4*>(gamma);
+    const float4* pe = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            const float4 g = pg[c], e = pe[c];
+            py[c] = v[i];
+            pz[c] = make_float4((v[i].x - mean) * rstd * g.x + e.x, (v[i].y - mean) * rstd * g.y + e.y,
+                                (v[i].z - mean) * rstd * g.z + e.z, (v[i].w - mean) * rstd * g.w + e.w);
+        }
+    }
+}
+
+static void launch_add_layernorm(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gamma, const float* beta,
+                                 float eps, int64_t rows, int64_t cols, float* y, float* z, const int64_t* ia, const int* ib,
+                                 hipStream_t st) {
+    static const int wave_rows = [] { const char* e = getenv("EMCID_LN_WAVE"); return e ? atoi(e) : 1; }();
+    if (wave_rows && cols <= LN_MAX_V4 * 64 * 4)
+        hipLaunchKernelGGL(add_layernorm_wave_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a, lda, b, ldb, gamma, beta,
+                           eps, (int)cols, (int)rows, y, z, ia, ib);
+    else
+        hipLaunchKernelGGL(add_layernorm_f32_kernel, dim3((unsigned)rows), dim3(256), 0, st, a, lda, b, ldb, gamma, beta, eps,
+                           (int)cols, y, z, ia, ib);
+}
+
 extern "C" int emcid_add_layernorm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gamma,
                                        const float* beta, float eps, int64_t rows, int64_t cols, float* y, float* z,
                                        void* stream) {
@@ -374,8 +441,7 @@ extern "C" int emcid_add_layernorm_f32(const float* a, int64_t lda, const float*
     EMCID_CHECK_ARG(cols % 4 == 0 && cols <= LN_MAX_V4 * 256 * 4 && lda % 4 == 0 && ldb % 4 == 0);
     EMCID_CHECK_ARG(aligned16(a) && aligned16(b) && aligned16(gamma) && aligned16(beta) && aligned16(y) && aligned16(z));
     ScopedProf sp(KC_MISC, (hipStream_t)stream);
-    hipLaunchKernelGGL(add_layernorm_f32_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, gamma,
-                       beta, eps, (int)cols, y, z, (const int64_t*)nullptr, (const int*)nullptr);
+    launch_add_layernorm(a, lda, b, ldb, gamma, beta, eps, rows, cols, y, z, nullptr, nullptr, (hipStream_t)stream);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }
@@ -390,8 +456,7 @@ extern "C" int emcid_embed_layernorm_f32(const float* tok, int64_t ld_tok, int64
     EMCID_CHECK_ARG(n_tok > 0 && n_pos > 0 && cols % 4 == 0 && cols <= LN_MAX_V4 * 256 * 4 && ld_tok % 4 == 0 && ld_pos % 4 == 0);
     EMCID_CHECK_ARG(aligned16(tok) && aligned16(pos) && aligned16(gamma) && aligned16(beta) && aligned16(y) && aligned16(z));
     ScopedProf sp(KC_MISC, (hipStream_t)stream);
-    hipLaunchKernelGGL(add_layernorm_f32_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, tok, ld_tok, pos, ld_pos,
-                       gamma, beta, eps, (int)cols, y, z, token, position);
+    launch_add_layernorm(tok, ld_tok, pos, ld_pos, gamma, beta, eps, rows, cols, y, z, token, position, (hipStream_t)stream);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }
