@@ -2078,9 +2078,14 @@ int emcid_edit_dual_apply_stage1_f64(const float* K, const float* Zc, const floa
         const int64_t gemm_rows = (n_lo == 0 && n_hi == N) ? ws.Np : rows;
         apply_inverse_forward(cov_inverse(cov_factor_ws, n_layers, dp, layer_index), dp, Kt + n_lo * dp, Yt + n_lo * dp, (int)gemm_rows,
                               st, base + ws.off_SK);
+        // stage 1 leaves the padding rows [N, Np) of Yt zero (the later stages rely on it): the full-range GEMM has just produced
+        // them; a partial range (row-sharded callers) zeroes them here
+        if (gemm_rows != ws.Np && ws.Np > N)
+            hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, st, Yt + N * dp, (ws.Np - N) * dp);
         EMCID_CHECK_LAUNCH();
         return EMCID_OK;
     }
+    if (ws.Np > N) hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, st, Yt + N * dp, (ws.Np - N) * dp);
     if (hipMemcpyAsync(Bs + n_lo * dp, Kt + n_lo * dp, rows * dp * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
         return fail(EMCID_ERR_HIP, __func__, "hipMemcpyAsync");
     return with_graph(make_key(5, {Lb, Ib, Bs + n_lo * dp, Yt + n_lo * dp}, {dp, rows}), st, [&](hipStream_t q) {
@@ -2106,7 +2111,6 @@ int emcid_edit_dual_apply_assemble_f64(int64_t N, int64_t d, int64_t h, void* wo
     double* base = (double*)workspace;
     double *Yt = base + ws.off_Y, *S = base + ws.off_S;
     const int64_t dp = ws.dp, Np = ws.Np;
-    if (Np > N) hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, st, Yt + N * dp, (Np - N) * dp);
     assemble_dual_system(Yt, Yt, dp, S, (int)Np, st, base + ws.off_SK);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
@@ -2145,7 +2149,6 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
                                   {dp, Np, N, hp, (int64_t)(uintptr_t)Lb, use_inverse + 2 * (assembled != 0) + 4 * (int)shadow}), st,
                          [&](hipStream_t q) {
         if (!assembled) {
-            if (Np > N) hipLaunchKernelGGL(zero_f64_kernel, dim3(256), dim3(256), 0, q, Yt + N * dp, (Np - N) * dp);
             assemble_dual_system(Yt, Yt, dp, S, (int)Np, q, base + ws.off_SK);      // S = I + Yt Yt^T (lower tiles)
         }
         ShadowJob job{Yt, dp, X, dp, P, dp, (int)Np, (int)dp, (int)dp, 0, 0, nullptr, 0, 0, 0};
