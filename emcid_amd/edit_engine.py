@@ -603,11 +603,19 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
 
 def solver_info(plan: EncoderEditPlan) -> int:
     """One host sync: 0, or 1 + the column of the first non-positive pivot any factorization of the last run met."""
-    code = 0
-    for holder in (plan.ws, plan.dual_ws, plan.cov_factors):
-        if holder is not None and code == 0:
-            code = int(holder.info.item())
-    return code
+    infos = [holder.info for holder in (plan.ws, plan.dual_ws, plan.cov_factors) if holder is not None]
+    if not infos:
+        return 0
+    if len(infos) == 1 or not infos[0].is_cuda:
+        vals = [int(t.item()) for t in infos]
+    else:       # all the flag words through ONE synchronisation: asynchronous copies into a pinned buffer, then one stream sync
+        dev = infos[0].device
+        host = torch.empty(len(infos), dtype=infos[0].dtype, pin_memory=True)
+        for i, t in enumerate(infos):
+            host[i:i + 1].copy_(t.reshape(-1)[:1], non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        vals = [int(v) for v in host.tolist()]
+    return next((v for v in vals if v != 0), 0)
 
 
 def run_checked(plan: EncoderEditPlan, keep_factors: bool = False, restore: bool = False) -> List[LayerEdit]:
