@@ -13,6 +13,7 @@ MI355X-first differences, results identical:
   torch-CPU's ``.mean(0)``;
 * the forward stops at the hooked module (the reference runs the remaining layers and discards them).
 """
+import operator
 import os
 import weakref
 from dataclasses import dataclass
@@ -162,6 +163,9 @@ class PromptChunk:
     n_requests: int
 
 
+_GET_SOURCE, _GET_PROMPTS = operator.itemgetter("source"), operator.itemgetter("prompts")
+
+
 def templated_prompt_chunk(tokenizer, requests: Sequence[Dict], first: Dict) -> Optional[PromptChunk]:
     """The (few templates) x (many names) shape of a mass edit WITHOUT building, joining and re-splitting the prompt strings:
     ``p.format(source)`` (reference compute_z.py:2278-2283) for templates with exactly one ``{}`` and no other brace is
@@ -176,10 +180,10 @@ def templated_prompt_chunk(tokenizer, requests: Sequence[Dict], first: Dict) -> 
     if twin is None:
         return None
     try:
-        names = [r["source"] for r in requests]
-        keys = [tuple(r["prompts"]) for r in requests]
+        names = list(map(_GET_SOURCE, requests))                 # (C-level iteration: this runs before the GPU has anything to do)
+        keys = list(map(tuple, map(_GET_PROMPTS, requests)))
         distinct = dict.fromkeys(keys)                   # the distinct template tuples, in order of first appearance
-    except TypeError:                                    # unhashable prompt entries
+    except TypeError:                                    # unhashable prompt entries, requests that are not mappings
         return None
     if set(map(type, names)) != {str}:                   # format() would str() anything else
         return None
