@@ -29,6 +29,9 @@ constexpr int GBK = 16;   // tokens per stage
 // ALIGNED (d % 4 == 0): a float4 of a row is entirely inside or entirely outside the matrix, so the global loads are
 // unconditional (clamped address + select) and the compiler can keep all of a stage's loads in flight; the general form
 // has per-element tails, whose branches serialise the loads behind `s_waitcnt vmcnt(0)`.
+#ifndef GRAM_PIN_PREFETCH
+#define GRAM_PIN_PREFETCH 1
+#endif
 template <int MI, bool ALIGNED, bool FAST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void gram_f32_kernel(const float* __restrict__ X, int t, int d, int64_t ldx,
                                                         float* __restrict__ G, int64_t ldg, int kchunk, int use_atomic,
@@ -159,11 +162,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 #pragma unroll
                 for (int j = 0; j < 2; ++j) b[nxt][j] = Bs[((kk + 1) * 2 + l5) * GB + wn0 + j * 32 + l31];
             }
+            if (GRAM_PIN_PREFETCH) __builtin_amdgcn_sched_barrier(0);     // left alone, hipcc sinks those reads BELOW the four MFMAs
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            if (GRAM_PIN_PREFETCH) __builtin_amdgcn_sched_barrier(0);
         }
         if (nx < T_fast) store_fast(smem + (nx & 1) * STAGE);
         else if (nx < T) store(smem + (nx & 1) * STAGE);
