@@ -14,7 +14,12 @@ A STEP is ONE CALL of the drop-in entry point, timed from outside exactly like t
     apply_emcid_to_text_encoder(pipe, requests, hparams, device, cache_name=..., stats_dir=...)
 
 with the model resident in HBM, the v* files on disk and C_l in the covariance cache ("all v* and C
-pre-cached").  Inside the call: tokenizer, subject search, prefix trie, v* reads (host), then one partial
+pre-cached").  EVERY warm-up and timed step edits a request set the process has NOT seen before (1 000 other names, its
+own v* directory of 1 000 npz files; up to 32 sets, cycled beyond that) — the reference's harness never repeats a call
+either (experiments/emcid_test.py:1168-1179 shuffles, :924-930 sweeps the weights).  Reported beside it:
+`replay_ms_per_call` (the same 1 000 requests again and again), `new_lambda_ms_per_call` / `new_edit_weight_ms_per_call`
+(same requests, a mom2_update_weight / edit_weight never used before), `cold_process` (a CHILD process making one call:
+what the reference's one-call CLI user gets), and the records `n100` (BASELINE config 2) and `sdxl` (config 4).  Inside the call: tokenizer, subject search, prefix trie, v* reads (host), then one partial
 prefix-deduplicated encoder forward that runs gather -> assemble -> Cholesky -> TRSM -> dW on the HIP kernels at each
 edited layer's fc2 (device), then the not-SPD flag read (one sync).  Before every call the four fc2 weights are put
 back to their original values (four device copies, inside the timed region), so every step performs the same edit.
@@ -53,20 +58,35 @@ LAM, EW = 4000, 0.5
 KIND = "sd-v1.4"
 
 
+MAX_REQUEST_SETS = 32
+
+
+def request_set(n_concepts, workdir, index=0, write=True):
+    """Request set `index` of the workload: n_concepts 3-syllable names drawn with their own seed (set 0 = the names of the
+    reference-minted N = 1000 golden) and the directory holding their v* npz files."""
+    from emcid_amd import synthetic as syn
+
+    reqs = syn.make_requests(n_concepts, names="syllable", name_seed=3 + 101 * index)   # 3-token names, 7-token prompts like real CLIP BPE
+    cache = str(Path(workdir) / (f"cache_{n_concepts}" if index == 0 else f"cache_{n_concepts}_set{index}")) + "/"
+    done = Path(cache) / ".complete"
+    if write and not done.exists():
+        syn.write_vstar_cache(cache, reqs, syn.ENCODER_DIMS[KIND][0], seed=1 + index, scale=0.5)
+        done.touch()
+    return reqs, cache
+
+
 def build_inputs(n_concepts, device, workdir):
     from emcid_amd import synthetic as syn
 
     pipe = syn.build_pipe(KIND, device, syllables=True)
-    hidden, inter = syn.ENCODER_DIMS[KIND][:2]
-    reqs = syn.make_requests(n_concepts, names="syllable")   # 3-token names, 7-token prompts like real CLIP BPE
+    inter = syn.ENCODER_DIMS[KIND][1]
     hp_d = syn.sd_hparams_dict(layers=LAYERS, mom2_update_weight=LAM, edit_weight=EW)
-    cache = str(Path(workdir) / f"cache_{n_concepts}") + "/"
+    reqs, cache = request_set(n_concepts, workdir, 0)
     stats = Path(workdir) / "stats"
     layer_names = [hp_d["rewrite_module_tmp"].format(l) for l in LAYERS]
-    if not Path(cache).exists():
-        syn.write_vstar_cache(cache, reqs, hidden, seed=1, scale=0.5)
-    if not stats.exists():
+    if not (stats / ".complete").exists():
         syn.write_stats_cache(stats, layer_names, inter, hp_d["mom2_n_samples"], seed=2, t=2 * inter)
+        (stats / ".complete").touch()
     return pipe, reqs, hp_d, cache, str(stats), layer_names
 
 
@@ -187,9 +207,14 @@ def main():
     ap.add_argument("--concepts", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage0", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the n100 / sdxl / cold_process records")
+    ap.add_argument("--no-cpu-full", action="store_true", help="skip the full 1 000-concept run of the CPU baseline (~1 min)")
+    ap.add_argument("--cold-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--stage0-captions", type=int, default=100000)
     args = ap.parse_args()
 
+    if args.cold_child:
+        return cold_child(args.cold_child, args.concepts)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -222,13 +247,19 @@ def main():
     # the benchmark models a long-running editing service: the projection GEMM solutions are tuned once per shape (inside
     # the FIRST call, reported in first_call_ms / gemm_tuning_ms); `untuned_ms_per_step` is the library default
     os.environ.setdefault("EMCID_TUNE_GEMM", "1")
+    os.environ.setdefault("EMCID_MANAGE_THREADS", "1")      # an editing process of its own: thread pools sized to the CPU quota
+    os.environ.setdefault("EMCID_FACTOR_CACHE", "8")        # the edit_weight sweep below must not evict the workload's own factors
     workdir = Path(tempfile.gettempdir()) / f"emcid_bench_{os.getuid()}"
+    n_sets = min(MAX_REQUEST_SETS, 1 + args.warmup + args.steps)      # set 0: the first call; then one per warm-up / timed step
     if rank == 0:
         workdir.mkdir(exist_ok=True, mode=0o700)
         build_inputs(args.concepts, "cpu", workdir)     # writes the synthetic v*/stats caches once
+        for j in range(1, n_sets):
+            request_set(args.concepts, workdir, j)
     if world > 1:
         dist.barrier()
     pipe, reqs, hp_d, cache, stats, layer_names = build_inputs(args.concepts, device, workdir)
+    sets = [(reqs, cache)] + [request_set(args.concepts, workdir, j, write=False) for j in range(1, n_sets)]
     hp = EMCIDHyperParams(**hp_d)
     originals = {n: get_parameter(pipe.text_encoder, n + ".weight").detach().clone() for n in layer_names}
 
@@ -237,37 +268,63 @@ def main():
             for n in layer_names:
                 get_parameter(pipe.text_encoder, n + ".weight").copy_(originals[n])
 
-    def call():
+    def call(which=0, hparams=None, **kw):
+        r, c = sets[which % len(sets)]
         restore_weights()
-        em.apply_emcid_to_text_encoder(pipe, reqs, hp, device, cache_name=cache, stats_dir=stats, verbose=False, shard=shard)
+        em.apply_emcid_to_text_encoder(pipe, r, hparams or hp, device, cache_name=c, stats_dir=stats, verbose=False, shard=shard, **kw)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_calls(k):
-        """k calls bracketed by barrier + synchronize; returns (total seconds, per-call seconds)."""
+    def timed_calls(k, first_set=None, **kw):
+        """k calls bracketed by barrier + synchronize; call i edits request set first_set + i (None: set 0 every time).
+        Returns (total seconds, per-call seconds)."""
         per = []
         sync()
         t0 = time.perf_counter()
-        for _ in range(k):
+        for i in range(k):
             t1 = time.perf_counter()
-            call()
+            call(0 if first_set is None else first_set + i, **kw)
             per.append(time.perf_counter() - t1)
         sync()
         return time.perf_counter() - t0, per
 
+    def each_synced(k, fn):
+        """k single calls, each between two synchronisations: milliseconds per call."""
+        out = []
+        for i in range(k):
+            sync()
+            t1 = time.perf_counter()
+            fn(i)
+            sync()
+            out.append((time.perf_counter() - t1) * 1e3)
+        return out
+
     # ---- the first call of the process: everything cold ------------------------------------------------------------------
     first_s, _ = timed_calls(1)
-    for _ in range(args.warmup):
-        call()
-    elapsed, per_call = timed_calls(args.steps)
+    # ---- warm-up and the K timed steps: every call a request set this process has never seen ------------------------------
+    for i in range(args.warmup):
+        call(1 + i)
+    elapsed, per_call = timed_calls(args.steps, first_set=1 + args.warmup)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     value = args.concepts * args.steps / elapsed
+
+    # ---- the same 1 000 requests again and again (what rounds 1-2 reported as the step) ------------------------------------
+    call(0)
+    replay_s, replay_per = timed_calls(max(5, args.steps // 2))
+    # ---- same requests, weights never used before: a new mom2_update_weight reuses the cached factor of C' (chol(lam C') =
+    # sqrt(lam) chol(C')); a new edit_weight changes C' itself (fp32 rounding per entry) and is refactored -------------------
+    import copy
+    lam_list = [2500, 3000, 5000, 6000, 8000]
+    ew_list = [0.35, 0.4, 0.45, 0.55, 0.6]
+    new_lam_ms = each_synced(len(lam_list), lambda i: call(0, copy.deepcopy(hp), mom2_weight=lam_list[i]))
+    new_ew_ms = each_synced(len(ew_list), lambda i: call(0, copy.deepcopy(hp), edit_weight=ew_list[i]))
+    call(0)        # (lam, e_w) of the workload again (its factors are still cached)
 
     # ---- library-default GEMM selection (no TunableOp table): a few calls -------------------------------------------------
     from emcid_amd import clip_forward
@@ -355,24 +412,41 @@ def main():
                     "selection": "the fp64 class with the most time per step among ALL classes of the solve",
                     "solver": "dual" if dual else "direct"}
 
+    replay_ms = statistics.median(replay_per) * 1e3
+    fresh_ms = statistics.median(per_call) * 1e3
     out = {
         "metric": "concept-edits/sec (1 000-concept batch, SD-v1.4)", "value": value, "unit": "concept-edits/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.concepts}-concept edit, SD-v1.4 text-encoder dims (768/3072/12L), layers 7-10, "
                                f"lambda 4000, 3 prompts/concept; one step = one apply_emcid_to_text_encoder call, timer "
-                               f"around the call (v* npz on disk, C_l in the covariance cache, model in HBM)",
+                               f"around the call (v* npz on disk, C_l in the covariance cache, model in HBM); every step "
+                               f"edits a request set the process has not seen before",
                    "concepts": args.concepts, "prompts_per_rank": plan.n_prompts,
+                   "request_sets": {"distinct": len(sets), "used_by_first_warmup_timed": 1 + args.warmup + args.steps,
+                                    "note": "set i = 1 000 other syllable names + its own directory of 1 000 v* npz files; "
+                                            "cycled when warmup + steps exceed the distinct sets"},
                    "forward": ("prefix-trie: %d unique rows of %d tokens in %d slice(s)" % (*plan.trie_rows, len(plan.chunks)))
                    if plan.chunks is not None else "hooked HF forward",
-                   "caches": {"covariance_in_hbm": True, "cov_factor_cache": "warm" if plan.factors_from_cache else "off",
-                              "vstar_files": "in-process copy validated by (path, mtime, size) per call",
+                   "caches": {"covariance_in_hbm": True,
+                              "cov_factor_cache": ("warm (keyed by statistics + edit_weight; any mom2_update_weight)"
+                                                   if plan.factors_from_cache else "off"),
+                              "vstar_files": "read from the files in every call (native batch reader, no in-process copy)",
                               "gemm_selection": "TunableOp table built in the first call"},
                    "backend": (dist.get_backend() if world > 1 else None),
                    "parallelism": f"concept-shard x{world}"},
-        "ms_per_call_median": statistics.median(per_call) * 1e3,
+        "ms_per_call_median": fresh_ms,
         "ms_per_call_min": min(per_call) * 1e3,
         "ms_per_call": [round(t * 1e3, 3) for t in per_call],
+        "fresh_requests_ms": fresh_ms,                   # = the timed steps themselves
+        "replay_ms_per_call": replay_ms, "replay_ms_per_call_all": [round(t * 1e3, 3) for t in replay_per],
+        "fresh_over_replay": fresh_ms / replay_ms,
+        "new_weights_ms": {"new_lambda_ms_per_call": statistics.median(new_lam_ms), "lambdas": lam_list,
+                           "new_lambda_ms_all": [round(t, 3) for t in new_lam_ms],
+                           "new_edit_weight_ms_per_call": statistics.median(new_ew_ms), "edit_weights": ew_list,
+                           "new_edit_weight_ms_all": [round(t, 3) for t in new_ew_ms],
+                           "note": "same requests as the replay; a new lambda reuses the cached factor of C' (lam_ratio), a new "
+                                   "edit_weight refactors the four 3072 x 3072 matrices on the side stream under the forward"},
         "first_call_ms": first_s * 1e3,
         "untuned_ms_per_step": untuned_ms,
         "host_prepare_ms": statistics.median(prep_ms),
@@ -383,8 +457,15 @@ def main():
         "kernel_classes": classes,
     }
 
+    if rank == 0 and world == 1 and not args.no_variants:
+        for name, fn in (("n100", lambda: n100_record(workdir, device)), ("sdxl", lambda: sdxl_record(workdir, device)),
+                         ("cold_process", lambda: cold_process_record(workdir, device))):
+            try:
+                out[name] = fn()
+            except Exception as e:     # the headline line must survive a problem in a secondary record
+                out[name] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out.update(cpu_baseline_and_error(workdir, device))
+        out.update(cpu_baseline_and_error(workdir, device, full_n=0 if args.no_cpu_full else args.concepts))
     if rank == 0 and world == 1 and not args.no_stage0:
         try:
             out["stage0"] = stage0_record(workdir, device, args.stage0_captions)
@@ -407,19 +488,18 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline_and_error(workdir, device, n_sample=100, budget_s=40.0):
+def cpu_baseline_and_error(workdir, device, n_sample=100, budget_s=40.0, full_n=0):
     """Oracle on the host cores over a 100-concept sample of the workload (median of up to 3 runs inside `budget_s`) +
-    dW error of the HIP path on the same sample.  host_s = tokenizer, subject search, v*/C reads inside the oracle call."""
+    dW error of the HIP path on the same sample; with `full_n`, ONE more run on the full request set of the GPU number
+    ("same request sets"; about a minute).  host_s = tokenizer, subject search, v*/C reads inside the call."""
     import copy
     import torch
-    from emcid_amd import emcid_main as em, synthetic as syn
+    from emcid_amd import effective_cpu_count, emcid_main as em, synthetic as syn
     from emcid_amd.emcid_hparams import EMCIDHyperParams
     from emcid_amd.nethook import get_parameter
     from oracle import emcid_oracle as orc
 
     cores = torch.get_num_threads()
-    pipe_c, reqs, hp_d, cache, stats, layer_names = build_inputs(n_sample, "cpu", workdir)
-    w0 = {ln: orc.get_parameter(pipe_c.text_encoder, ln + ".weight").clone() for ln in layer_names}
     host_acc = [0.0]
 
     def timed(fn):
@@ -433,42 +513,309 @@ def cpu_baseline_and_error(workdir, device, n_sample=100, budget_s=40.0):
 
     host_fns = ("tokenize_prompts", "find_token_range", "load_vstars", "load_cov")
     saved = {n: getattr(orc, n) for n in host_fns}
-    runs = []
-    try:
-        for n in host_fns:
-            setattr(orc, n, timed(saved[n]))
-        t_all = time.perf_counter()
-        while len(runs) < 3 and (not runs or time.perf_counter() - t_all + runs[-1][0] < budget_s):
-            with torch.no_grad():
-                for ln in layer_names:
-                    orc.get_parameter(pipe_c.text_encoder, ln + ".weight").copy_(w0[ln])
-            host_acc[0] = 0.0
-            t0 = time.perf_counter()
-            orc.apply_emcid_to_text_encoder(pipe_c, reqs, copy.deepcopy(hp_d), cache_name=cache, stats_dir=stats)
-            runs.append((time.perf_counter() - t0, host_acc[0]))
-    finally:
-        for n in host_fns:
-            setattr(orc, n, saved[n])
-    runs.sort()
+
+    def oracle_runs(n_concepts, max_runs, budget):
+        pipe_c, reqs, hp_d, cache, stats, layer_names = build_inputs(n_concepts, "cpu", workdir)
+        w0 = {ln: orc.get_parameter(pipe_c.text_encoder, ln + ".weight").clone() for ln in layer_names}
+        runs = []
+        try:
+            for n in host_fns:
+                setattr(orc, n, timed(saved[n]))
+            t_all = time.perf_counter()
+            while len(runs) < max_runs and (not runs or time.perf_counter() - t_all + runs[-1][0] < budget):
+                with torch.no_grad():
+                    for ln in layer_names:
+                        orc.get_parameter(pipe_c.text_encoder, ln + ".weight").copy_(w0[ln])
+                host_acc[0] = 0.0
+                t0 = time.perf_counter()
+                orc.apply_emcid_to_text_encoder(pipe_c, reqs, copy.deepcopy(hp_d), cache_name=cache, stats_dir=stats)
+                runs.append((time.perf_counter() - t0, host_acc[0]))
+        finally:
+            for n in host_fns:
+                setattr(orc, n, saved[n])
+        runs.sort()
+        return runs, (pipe_c, reqs, hp_d, cache, stats, layer_names, w0)
+
+    def dw_error(ctx):
+        pipe_c, reqs, hp_d, cache, stats, layer_names, w0 = ctx
+        pipe_g = syn.build_pipe(KIND, device, syllables=True)
+        em.apply_emcid_to_text_encoder(pipe_g, reqs, EMCIDHyperParams(**hp_d), device, cache_name=cache, stats_dir=stats,
+                                       verbose=False)
+        err_abs, err_rel = 0.0, 0.0
+        for ln in layer_names:
+            ref = orc.get_parameter(pipe_c.text_encoder, ln + ".weight").double() - w0[ln].double()
+            got = get_parameter(pipe_g.text_encoder, ln + ".weight").cpu().double() - w0[ln].double()
+            e = (got - ref).abs().max().item()
+            err_abs = max(err_abs, e)
+            err_rel = max(err_rel, e / ref.abs().max().item())
+        return err_abs, err_rel
+
+    runs, ctx = oracle_runs(n_sample, 3, budget_s)
     cpu_s, host_s = runs[len(runs) // 2]
-    pipe_g = syn.build_pipe(KIND, device, syllables=True)
-    em.apply_emcid_to_text_encoder(pipe_g, reqs, EMCIDHyperParams(**hp_d), device, cache_name=cache, stats_dir=stats,
-                                   verbose=False)
-    err_abs, err_rel = 0.0, 0.0
-    for ln in layer_names:
-        ref = orc.get_parameter(pipe_c.text_encoder, ln + ".weight").double() - w0[ln].double()
-        got = get_parameter(pipe_g.text_encoder, ln + ".weight").cpu().double() - w0[ln].double()
-        e = (got - ref).abs().max().item()
-        err_abs = max(err_abs, e)
-        err_rel = max(err_rel, e / ref.abs().max().item())
-    return {"cpu_baseline": {"value": n_sample / cpu_s, "unit": "concept-edits/s", "cores": cores, "kind": "port",
-                             "cpu_model": cpu_model(), "runs": len(runs), "seconds_per_run": [r[0] for r in runs],
-                             "host_s": host_s, "compute_s": cpu_s - host_s,
-                             "sample": f"{n_sample}-concept edit (300 prompts), same dims/layers/lambda through the oracle's "
-                                       f"op-for-op port of apply_emcid_to_text_encoder, timer around the call (median "
-                                       f"{cpu_s:.1f} s of {len(runs)} runs; the cost is ~linear in the concept count: 2 full "
-                                       f"encoder forwards per edited layer over all prompts)"},
-            "dw_max_abs_err": err_abs, "dw_max_rel_err": err_rel}
+    err_abs, err_rel = dw_error(ctx)
+    rec = {"value": n_sample / cpu_s, "unit": "concept-edits/s", "cores": cores, "kind": "port",
+           "cores_note": f"torch intra-op threads = the CPUs this process may use (cgroup quota / affinity: "
+                         f"{effective_cpu_count()}; the machine shows {os.cpu_count()} hardware threads); bench.py runs under "
+                         f"EMCID_MANAGE_THREADS=1, which lowers PyTorch's default pool to that number",
+           "cpu_model": cpu_model(), "runs": len(runs), "seconds_per_run": [r[0] for r in runs],
+           "host_s": host_s, "compute_s": cpu_s - host_s,
+           "sample": f"{n_sample}-concept edit (300 prompts), same dims/layers/lambda through the oracle's "
+                     f"op-for-op port of apply_emcid_to_text_encoder, timer around the call (median "
+                     f"{cpu_s:.1f} s of {len(runs)} runs; the cost is ~linear in the concept count: 2 full "
+                     f"encoder forwards per edited layer over all prompts)"}
+    out = {"cpu_baseline": rec, "dw_max_abs_err": err_abs, "dw_max_rel_err": err_rel}
+    if full_n and full_n != n_sample:
+        runs_f, ctx_f = oracle_runs(full_n, 1, 0.0)
+        fa, fr = dw_error(ctx_f)
+        rec["full"] = {"value": full_n / runs_f[0][0], "unit": "concept-edits/s", "seconds": runs_f[0][0], "host_s": runs_f[0][1],
+                       "sample": f"the full {full_n}-concept request set of the GPU number (set 0), one run",
+                       "dw_max_abs_err": fa, "dw_max_rel_err": fr}
+    return out
+
+
+def profiled_classes(steps, step_fn, flops):
+    """`steps` runs of step_fn with every kernel class bracketed by HIP events on the launch stream: ({class: record},
+    solve record).  flops: {class: algorithmic flops per step}."""
+    import torch
+    from emcid_amd import hip
+    hip.profile_enable([c for c in hip.PROF_CLASSES])
+    for _ in range(steps):
+        step_fn()
+    torch.cuda.synchronize()
+    prof = hip.profile_collect()
+    hip.profile_enable([])
+    classes = {}
+    for c, (ms, launches) in prof.items():
+        rec = {"ms_per_step": ms / steps, "launches_per_step": launches / steps}
+        if c in flops or c in FP64_CLASSES:
+            fl = flops.get(c, 0)
+            rec["algorithmic_flops_per_step"] = fl
+            rec["tflops"] = fl * steps / (ms * 1e-3) / 1e12 if ms > 0 else None
+            rec["frac_f64_mfma_peak"] = rec["tflops"] / F64_MFMA_PEAK_TFLOPS if rec["tflops"] is not None else None
+        classes[c] = rec
+    f64 = [c for c in prof if c in FP64_CLASSES]
+    solve_ms = sum(prof[c][0] for c in f64) / steps
+    solve_flops = sum(flops.get(c, 0) for c in f64)
+    solve = {"ms_per_step": solve_ms, "algorithmic_flops_per_step": solve_flops,
+             "tflops": solve_flops / (solve_ms * 1e-3) / 1e12 if solve_ms else None,
+             "frac_f64_mfma_peak": solve_flops / (solve_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS if solve_ms else None}
+    top = max(f64, key=lambda c: prof[c][0]) if f64 else None
+    roofline = None
+    if top is not None:
+        ms, launches = prof[top]
+        ach = flops.get(top, 0) * steps / (ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "class": top, "kernel": KERNEL_OF_CLASS.get(top, top), "achieved": ach,
+                    "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_us": ms * 1e3 / launches, "launches": launches}
+    return classes, solve, roofline
+
+
+def n100_record(workdir, device, n=100, calls=9):
+    """BASELINE config 2: the 100-concept batch on SD-v1.4 dims, one GPU: wall of apply_emcid_to_text_encoder (median; every
+    call a request set the process has not seen before)."""
+    import torch
+    from emcid_amd import emcid_main as em
+    from emcid_amd.emcid_hparams import EMCIDHyperParams
+    from emcid_amd.nethook import get_parameter
+
+    pipe, reqs, hp_d, cache, stats, layer_names = build_inputs(n, device, workdir)
+    sets = [(reqs, cache)] + [request_set(n, workdir, j) for j in range(1, calls + 3)]
+    hp = EMCIDHyperParams(**hp_d)
+    w0 = {ln: get_parameter(pipe.text_encoder, ln + ".weight").detach().clone() for ln in layer_names}
+    ms = []
+    for i, (r, c) in enumerate(sets):
+        with torch.no_grad():
+            for ln in layer_names:
+                get_parameter(pipe.text_encoder, ln + ".weight").copy_(w0[ln])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        em.apply_emcid_to_text_encoder(pipe, r, hp, device, cache_name=c, stats_dir=stats, verbose=False)
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) * 1e3)
+    timed = ms[3:]
+    med = statistics.median(timed)
+    return {"workload": f"{n}-concept edit, SD-v1.4 dims, layers 7-10, lambda 4000 (BASELINE config 2), one GPU; every call a "
+                        f"never-seen request set", "ms_per_call_median": med, "ms_per_call": [round(t, 3) for t in timed],
+            "concept_edits_per_s": n / (med * 1e-3), "first_call_ms_this_shape": ms[0], "calls": len(timed)}
+
+
+def sdxl_record(workdir, device, n=1000, calls=5):
+    """BASELINE config 4 on one GPU: SDXL dual text-encoder edit (TE1 768/3072/12L layers 8-10, TE2 1280/5120/32L layers
+    26-30), N = 1000: wall of apply_emcid_to_sdxl_text_encoders, TE1 / TE2 device steps alone, roofline of the dominant
+    class of the two encoders' solves."""
+    import torch
+    from emcid_amd import emcid_main as em, synthetic as syn
+    from emcid_amd.edit_engine import check_info, run_encoder_edit
+    from emcid_amd.emcid_hparams import EMCIDXLHyperParams
+    from emcid_amd.nethook import get_parameter
+
+    tmp = Path(workdir) / "sdxl"
+    pipe = syn.build_pipe("sd-v1.4", device, sdxl=True, syllables=True)
+    reqs = syn.make_requests(n, names="syllable")
+    hp_d = syn.sdxl_hparams_dict()
+    hp = EMCIDXLHyperParams(**hp_d)
+    cache = str(tmp / f"cache_{n}") + "/"
+    n1 = [hp.rewrite_module_tmp.format(l) for l in hp.layers]
+    n2 = [hp.rewrite_module_tmp.format(l) for l in hp.layers_2]
+    if not (tmp / ".complete").exists():
+        syn.write_vstar_cache(cache, reqs, 768, seed=1, scale=0.5)
+        syn.write_vstar_cache(cache, reqs, 1280, seed=5, scale=0.5, suffix="_2")
+        syn.write_stats_cache(tmp / "s1", n1, 3072, hp.mom2_n_samples, seed=2, t=6144)
+        syn.write_stats_cache(tmp / "s2", n2, 5120, hp.mom2_n_samples, seed=7, t=10240)
+        (tmp / ".complete").touch()
+    w1 = {nm: get_parameter(pipe.text_encoder, nm + ".weight").detach().clone() for nm in n1}
+    w2 = {nm: get_parameter(pipe.text_encoder_2, nm + ".weight").detach().clone() for nm in n2}
+
+    def restore():
+        with torch.no_grad():
+            for nm, w in w1.items():
+                get_parameter(pipe.text_encoder, nm + ".weight").copy_(w)
+            for nm, w in w2.items():
+                get_parameter(pipe.text_encoder_2, nm + ".weight").copy_(w)
+
+    def apply_call():
+        restore()
+        em.apply_emcid_to_sdxl_text_encoders(pipe, reqs, hp, device, cache_name=cache, stat_dir=str(tmp / "s1"),
+                                             stat_dir_2=str(tmp / "s2"), verbose=False)
+
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    apply_call()
+    torch.cuda.synchronize()
+    first_ms = (time.perf_counter() - t0) * 1e3
+    apply_call()
+    ms = []
+    for _ in range(calls):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        apply_call()
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) * 1e3)
+    med = statistics.median(ms)
+    p1, p2 = em._sdxl_plans(pipe, reqs, hp, cache, str(tmp / "s1"), str(tmp / "s2"), False, None, None)
+
+    def alone(p, k=3):
+        def f():
+            restore()
+            run_encoder_edit(p)
+        f()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(k):
+            f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / k * 1e3
+
+    t1, t2 = alone(p1), alone(p2)
+    first_x = max(0, int(os.environ.get("EMCID_INVERSE_FROM", "1")))
+    f1 = step_flops(n, n, 3072, 768, len(hp.layers), p1.dual_ws is not None, True, p1.factors_from_cache, min(len(hp.layers), first_x))
+    f2 = step_flops(n, n, 5120, 1280, len(hp.layers_2), p2.dual_ws is not None, True, p2.factors_from_cache,
+                    min(len(hp.layers_2), first_x))
+    flops = {c: f1.get(c, 0) + f2.get(c, 0) for c in set(f1) | set(f2)}
+
+    def both():
+        restore()
+        run_encoder_edit(p1)
+        run_encoder_edit(p2)
+
+    classes, solve, roofline = profiled_classes(2, both, flops)
+    check_info(p1)
+    check_info(p2)
+    survey = len(hp.layers) * (n * 3072 ** 2 + 3072 ** 3 // 3 + 2 * n * 3072 ** 2 + 2 * 768 * n * 3072) \
+        + len(hp.layers_2) * (n * 5120 ** 2 + 5120 ** 3 // 3 + 2 * n * 5120 ** 2 + 2 * 1280 * n * 5120)
+    return {"workload": f"SDXL dual text-encoder edit, {n} concepts, TE1 768/3072/12L layers 8-10 (lambda 4000) + TE2 "
+                        f"1280/5120/32L layers 26-30 (lambda_2 10000), one GPU, two HIP streams (BASELINE config 4); timer around "
+                        f"apply_emcid_to_sdxl_text_encoders, same request set every call",
+            "ms_per_call_median": med, "ms_per_call": [round(t, 3) for t in ms], "concept_edits_per_s": n / (med * 1e-3),
+            "first_call_ms": first_ms, "te1_device_ms": t1, "te2_device_ms": t2,
+            "trie_rows": [p1.trie.n_nodes, p2.trie.n_nodes], "survey_8d_flops_per_step": survey,
+            "roofline": roofline, "solve": solve,
+            "kernel_classes": {c: r for c, r in classes.items() if c in FP64_CLASSES}}
+
+
+def cold_child(workdir, n):
+    """Child-process mode (`bench.py --cold-child WORKDIR`): ONE call in a process that has never edited — the reference's
+    one-call CLI user (scripts/run_emcid.py:99) — with the parent's TunableOp file in place; then the pieces of that
+    call one at a time.  Prints one JSON line."""
+    t_start = time.perf_counter()
+    os.environ.setdefault("EMCID_MANAGE_THREADS", "1")
+    os.environ["EMCID_TUNE_GEMM"] = "auto"          # load an existing table, never tune
+    import torch
+    t_torch = time.perf_counter()
+    from emcid_amd import edit_engine, emcid_main as em, hip, host_text
+    from emcid_amd.emcid_hparams import EMCIDHyperParams
+    from emcid_amd.nethook import get_parameter
+    hip.load()
+    host_text.load()
+    t_lib = time.perf_counter()
+    device = "cuda:0"
+    torch.cuda.set_device(0)
+    torch.zeros(1, device=device)
+    torch.cuda.synchronize()
+    t_ctx = time.perf_counter()
+    pipe, reqs, hp_d, cache, stats, layer_names = build_inputs(n, device, workdir)
+    hp = EMCIDHyperParams(**hp_d)
+    w0 = {ln: get_parameter(pipe.text_encoder, ln + ".weight").detach().clone() for ln in layer_names}
+    torch.cuda.synchronize()
+    t_model = time.perf_counter()
+
+    def one(which=0):
+        r, c = request_set(n, workdir, which, write=False) if which else (reqs, cache)
+        with torch.no_grad():
+            for ln in layer_names:
+                get_parameter(pipe.text_encoder, ln + ".weight").copy_(w0[ln])
+        torch.cuda.synchronize()
+        edit_engine.TIMING.clear()
+        t0 = time.perf_counter()
+        em.apply_emcid_to_text_encoder(pipe, r, hp, device, cache_name=c, stats_dir=stats, verbose=False)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3, {k: round(v * 1e3, 3) for k, v in edit_engine.TIMING.items()}
+
+    first_ms, first_phases = one(0)
+    from emcid_amd import clip_forward
+    warm = [one(1 + i)[0] for i in range(3)]
+    with edit_engine.ENGINE_LOCK:
+        edit_engine._FACTOR_CACHE.clear()
+    cold_factor_ms, _ = one(4)
+    em.clear_caches()
+    edit_engine.clear_engine_caches()
+    cold_stats_ms, stats_phases = one(5)
+    warm_ms = statistics.median(warm)
+    print(json.dumps({
+        "cold_process_ms": first_ms, "host_phases_ms_first_call": first_phases,
+        "tunable_table_loaded": bool(clip_forward._TUNED["done"]),
+        "before_the_call_ms": {"import_torch": (t_torch - t_start) * 1e3, "import_package_and_load_libraries": (t_lib - t_torch) * 1e3,
+                               "gpu_context": (t_ctx - t_lib) * 1e3, "synthetic_model_to_hbm": (t_model - t_ctx) * 1e3},
+        "second_to_fourth_call_ms": [round(t, 3) for t in warm], "warm_call_ms": warm_ms,
+        "call_with_cold_factor_cache_ms": cold_factor_ms, "factor_and_inverses_ms": cold_factor_ms - warm_ms,
+        "call_with_cold_statistics_and_factors_ms": cold_stats_ms,
+        "statistics_npz_to_hbm_ms": stats_phases.get("statistics"),
+        "vstar_reads_ms_first_call": first_phases.get("vstar join + h2d"),
+        "first_call_minus_warm_ms": first_ms - warm_ms,
+        "libraries_and_kernels_first_use_ms": first_ms - cold_stats_ms,
+        "note": "cold_process_ms = wall of the ONE apply_emcid_to_text_encoder call of a fresh process (model already in HBM, "
+                "an existing TunableOp table is loaded, nothing is tuned); call_with_cold_statistics_and_factors = the same "
+                "work in a process whose libraries and kernels have run before; the difference is first-use cost (code objects, "
+                "GEMM library initialisation, allocator growth)"}))
+    return 0
+
+
+def cold_process_record(workdir, device):
+    """Runs cold_child as a CHILD process (never an exec from this GPU-touching process) and returns its JSON."""
+    import torch
+    from emcid_amd import clip_forward
+    try:        # leave the GEMM table of this process on disk now (TunableOp itself writes it at exit)
+        torch.cuda.tunable.write_file(clip_forward._tunable_file(torch.device(device)))
+    except Exception:
+        pass
+    env = dict(os.environ)
+    env.pop("EMCID_TUNE_GEMM", None)
+    r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--cold-child", str(workdir)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"child exited {r.returncode}", "stderr_tail": r.stderr[-800:]}
+    return json.loads(lines[-1])
 
 
 def stage0_record(workdir, device, n_captions):

@@ -90,5 +90,20 @@ def _cap_tokenizer_threads():
         os.environ["RAYON_NUM_THREADS"] = str(n)
 
 
-_cap_tokenizer_threads()
-_respect_cpu_quota()
+_THREADS_MANAGED = False
+
+
+def manage_threads(force: bool = False) -> bool:
+    """Opt-in host-thread hygiene for an editing process: lower PyTorch's intra-op pool to the CPUs the container may use
+    (_respect_cpu_quota) and give the `tokenizers` backend a bounded rayon pool (_cap_tokenizer_threads).  Nothing happens
+    at import: a host application that embeds this package keeps its own settings.  The first ``prepare_*`` call of a
+    process runs this when EMCID_MANAGE_THREADS=1 — which bench.py, the run_emcid CLI and the test suite set by default
+     — or call it yourself.  Returns whether it acted."""
+    global _THREADS_MANAGED
+    import os
+    if _THREADS_MANAGED or not (force or os.environ.get("EMCID_MANAGE_THREADS", "0") == "1"):
+        return False
+    _THREADS_MANAGED = True
+    _cap_tokenizer_threads()
+    _respect_cpu_quota()
+    return True

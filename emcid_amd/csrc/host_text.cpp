@@ -81,7 +81,7 @@ struct emcid_bpe {
 
 extern "C" {
 
-int emcid_host_abi_version(void) { return 3; }
+int emcid_host_abi_version(void) { return 4; }
 
 const char* emcid_host_last_error(void) { return g_error.c_str(); }
 

@@ -38,16 +38,18 @@ void prof_end(int cls, hipStream_t st) {
 
 // ---- element-wise preparation ---------------------------------------------------------------------
 
-// Kt64[n][j] = double(K[n][j]) * s (zero padded to [Np][dp]);
-// Rt[n][i]   = double(zs_t[n][i] - Zc[n][i]) * s / layers_left  (fp32 subtract first, like the reference).
+// Kt64[n][j] = double(K[n][j]) * s * g (zero padded to [Np][dp]);
+// Rt[n][i]   = double(zs_t[n][i] - Zc[n][i]) * s / layers_left * g  (fp32 subtract first, like the reference).
+// g = 1 for the direct solver.  The dual solver passes g = sqrt(lam_factored / lam): it then works with a factor of
+// lam_factored * C' whatever the call's lam is (chol(lam C') = sqrt(lam) chol(C')), see emcid_factor_cov_f64.
 __global__ __launch_bounds__(256) void prep_kr_kernel(const float* __restrict__ K, const float* __restrict__ Zc,
                                                        const float* __restrict__ zs_t, int N, int d, int h, double s,
                                                        double layers_left, double* __restrict__ Kt64, int Np, int dp,
-                                                       double* __restrict__ Rt, int hp) {
+                                                       double* __restrict__ Rt, int hp, double g = 1.0) {
     const int n = blockIdx.x;
     for (int j = threadIdx.x; j < dp; j += 256) {
         double v = 0.0;
-        if (n < N && j < d) v = (double)K[(int64_t)n * d + j] * s;
+        if (n < N && j < d) v = (double)K[(int64_t)n * d + j] * s * g;
         Kt64[(int64_t)n * dp + j] = v;
     }
     if (Rt) {
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void prep_kr_kernel(const float* __restrict__ 
             double v = 0.0;
             if (n < N && i < h) {
                 const float src = zs_t[(int64_t)n * h + i] - Zc[(int64_t)n * h + i];
-                v = ((double)src * s) / layers_left;
+                v = ((double)src * s) / layers_left * g;
             }
             Rt[(int64_t)n * hp + i] = v;
         }
@@ -63,9 +65,9 @@ __global__ __launch_bounds__(256) void prep_kr_kernel(const float* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void copy2d_f64_kernel(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst,
-                                                          int64_t ldd, int rows, int cols) {
+                                                          int64_t ldd, int rows, int cols, double scale = 1.0) {
     const int r = blockIdx.x;
-    for (int c = threadIdx.x; c < cols; c += 256) dst[(int64_t)r * ldd + c] = src[(int64_t)r * lds_ + c];
+    for (int c = threadIdx.x; c < cols; c += 256) dst[(int64_t)r * ldd + c] = src[(int64_t)r * lds_ + c] * scale;
 }
 
 // zero fill by kernel: a hipMemset node inside a captured graph binds the allocation object of capture time, which
@@ -1975,11 +1977,12 @@ int64_t emcid_edit_dual_workspace_bytes(int64_t N, int64_t d, int64_t h) {
 
 /* stage 1: Kt64 = s*K, Rt, and the shard's rows of Pt = Kt64 M^-1 (into Pt_rows_out if given, else only the workspace) */
 int emcid_edit_dual_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
-                               double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
+                               double edit_weight, int layers_left, double lam_ratio, const void* cov_factor_ws, int64_t n_layers,
                                int64_t layer_index, int64_t n_lo, int64_t n_hi, int use_inverse, void* workspace,
                                int64_t workspace_bytes, void* stream) {
     EMCID_CHECK_ARG(K && Zc && zs_t && N > 0 && d > 0 && h > 0 && layers_left > 0 && cov_factor_ws && workspace);
     EMCID_CHECK_ARG(0 <= layer_index && layer_index < n_layers && 0 <= n_lo && n_lo < n_hi && n_hi <= N);
+    EMCID_CHECK_ARG(lam_ratio > 0.0 && lam_ratio < 1e300);
     DualWorkspace ws(N, d, h);
     if (workspace_bytes < ws.total * (int64_t)sizeof(double)) return fail(EMCID_ERR_WORKSPACE, __func__, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -1992,7 +1995,7 @@ int emcid_edit_dual_stage1_f64(const float* K, const float* Zc, const float* zs_
     {
         ScopedProf sp(KC_PREP, st);
         hipLaunchKernelGGL(prep_kr_kernel, dim3((unsigned)ws.Np), dim3(256), 0, st, K, Zc, zs_t, (int)N, (int)d, (int)h, s,
-                           (double)layers_left, Kt, (int)ws.Np, (int)dp, R, (int)ws.hp);
+                           (double)layers_left, Kt, (int)ws.Np, (int)dp, R, (int)ws.hp, 1.0 / sqrt(lam_ratio));
     }
     const int64_t rows = n_hi - n_lo;
     if (use_inverse) {
@@ -2017,9 +2020,10 @@ double* emcid_edit_dual_pt(void* workspace, int64_t N, int64_t d, int64_t h) {
 }
 
 /* stage 2 (needs ALL rows of Pt): S = I + Pt Kt^T, S = L_S L_S^T, adj_k = (S^-1 Pt)^T  [d, Np], U = Rt^T Xt, W = W0 + float(U) */
-int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, const float* W0, float* W, double* adjk_out, double* Rt_out,
+int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, double lam_ratio, const float* W0, float* W, double* adjk_out, double* Rt_out,
                                float* dW_out, void* workspace, int64_t workspace_bytes, int* info_dev, void* stream) {
     EMCID_CHECK_ARG(N > 0 && d > 0 && h > 0 && workspace && info_dev && ((W == nullptr) || (W0 != nullptr)));
+    EMCID_CHECK_ARG(lam_ratio > 0.0 && lam_ratio < 1e300);
     DualWorkspace ws(N, d, h);
     if (workspace_bytes < ws.total * (int64_t)sizeof(double)) return fail(EMCID_ERR_WORKSPACE, __func__, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -2041,8 +2045,11 @@ int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, const float* W0,
         GemmShape g{R, ws.hp, PT, Np, (int)h, (int)d, (int)Np, 0};
         launch_gemm_f64<false, true>(g, EpiDeltaW{W0, W, d, dW_out, d, nullptr, d}, st);
     }
-    if (adjk_out) hipLaunchKernelGGL(copy2d_f64_kernel, dim3((unsigned)d), dim3(256), 0, st, PT, Np, adjk_out, N, (int)d, (int)N);
-    if (Rt_out) hipLaunchKernelGGL(copy2d_f64_kernel, dim3((unsigned)N), dim3(256), 0, st, R, ws.hp, Rt_out, h, (int)N, (int)h);
+    // the workspace holds sqrt(lam_ratio) * adj_k and Rt / sqrt(lam_ratio) (stage 1's gain): the caller gets both in its own scale
+    const double root = sqrt(lam_ratio);
+    if (adjk_out)
+        hipLaunchKernelGGL(copy2d_f64_kernel, dim3((unsigned)d), dim3(256), 0, st, PT, Np, adjk_out, N, (int)d, (int)N, 1.0 / root);
+    if (Rt_out) hipLaunchKernelGGL(copy2d_f64_kernel, dim3((unsigned)N), dim3(256), 0, st, R, ws.hp, Rt_out, h, (int)N, (int)h, root);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }
@@ -2052,11 +2059,12 @@ int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, const float* W0,
  * One forward solve on the N concept rows, a true SYRK, the N x N Cholesky, two solves with only h right-hand sides,
  * one GEMM and one backward solve on h rows.  Same algebra as stage1 + stage2 by associativity. */
 int emcid_edit_dual_apply_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
-                                     double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
+                                     double edit_weight, int layers_left, double lam_ratio, const void* cov_factor_ws, int64_t n_layers,
                                      int64_t layer_index, int64_t n_lo, int64_t n_hi, int use_inverse, void* workspace,
                                      int64_t workspace_bytes, void* stream) {
     EMCID_CHECK_ARG(K && Zc && zs_t && N > 0 && d > 0 && h > 0 && layers_left > 0 && cov_factor_ws && workspace);
     EMCID_CHECK_ARG(0 <= layer_index && layer_index < n_layers && 0 <= n_lo && n_lo < n_hi && n_hi <= N);
+    EMCID_CHECK_ARG(lam_ratio > 0.0 && lam_ratio < 1e300);
     DualWorkspace ws(N, d, h);
     if (workspace_bytes < ws.total * (int64_t)sizeof(double)) return fail(EMCID_ERR_WORKSPACE, __func__, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
@@ -2069,7 +2077,7 @@ int emcid_edit_dual_apply_stage1_f64(const float* K, const float* Zc, const floa
     {
         ScopedProf sp(KC_PREP, st);
         hipLaunchKernelGGL(prep_kr_kernel, dim3((unsigned)ws.Np), dim3(256), 0, st, K, Zc, zs_t, (int)N, (int)d, (int)h, s,
-                           (double)layers_left, Kt, (int)ws.Np, (int)dp, R, (int)ws.hp);
+                           (double)layers_left, Kt, (int)ws.Np, (int)dp, R, (int)ws.hp, 1.0 / sqrt(lam_ratio));
     }
     const int64_t rows = n_hi - n_lo;
     if (use_inverse) {
@@ -2146,7 +2154,8 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
     double* P = base + ws.off_P;
     const double* X = use_inverse ? cov_inverse(cov_factor_ws, n_layers, dp, layer_index) : nullptr;
     EMCID_TRY(with_graph(make_key(6, {Yt, R, S, LS, RT, V, U, info_dev},
-                                  {dp, Np, N, hp, (int64_t)(uintptr_t)Lb, use_inverse + 2 * (assembled != 0) + 4 * (int)shadow}), st,
+                                  {dp, Np, N, hp, (int64_t)(uintptr_t)Lb, use_inverse + 2 * (assembled != 0) + 4 * (int)shadow + 8 * h + (d << 32)}),
+                         st,
                          [&](hipStream_t q) {
         if (!assembled) {
             assemble_dual_system(Yt, Yt, dp, S, (int)Np, q, base + ws.off_SK);      // S = I + Yt Yt^T (lower tiles)
@@ -2222,11 +2231,11 @@ static int check_tiles(const int* tiles, int n_tiles, int64_t dp) {
 }
 
 int emcid_edit_dual_cols_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
-                                    double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
+                                    double edit_weight, int layers_left, double lam_ratio, const void* cov_factor_ws, int64_t n_layers,
                                     int64_t layer_index, const int* tiles_host, int n_tiles, void* workspace,
                                     int64_t workspace_bytes, void* stream) {
     EMCID_CHECK_ARG(K && Zc && zs_t && N > 0 && d > 0 && h > 0 && layers_left > 0 && cov_factor_ws && workspace);
-    EMCID_CHECK_ARG(0 <= layer_index && layer_index < n_layers);
+    EMCID_CHECK_ARG(0 <= layer_index && layer_index < n_layers && lam_ratio > 0.0 && lam_ratio < 1e300);
     DualWorkspace ws(N, d, h);
     EMCID_CHECK_ARG(check_tiles(tiles_host, n_tiles, ws.dp));
     if (workspace_bytes < ws.total * (int64_t)sizeof(double)) return fail(EMCID_ERR_WORKSPACE, __func__, "workspace too small");
@@ -2239,7 +2248,7 @@ int emcid_edit_dual_cols_stage1_f64(const float* K, const float* Zc, const float
     {
         ScopedProf sp(KC_PREP, st);
         hipLaunchKernelGGL(prep_kr_kernel, dim3((unsigned)Np), dim3(256), 0, st, K, Zc, zs_t, (int)N, (int)d, (int)h, s,
-                           (double)layers_left, Kt, (int)Np, (int)dp, R, (int)ws.hp);
+                           (double)layers_left, Kt, (int)Np, (int)dp, R, (int)ws.hp, 1.0 / sqrt(lam_ratio));
     }
     for (int i = 0; i < n_tiles; ++i) {        // Yc[:, 128 i : 128 i + 128] = Kt[:, 0 : kd] X[128 t : 128 t + 128, 0 : kd]^T,  kd = 128 (t + 1)
         const int64_t t = tiles_host[i], kd = (t + 1) * NB;

@@ -21,6 +21,7 @@ touches only HBM-resident inputs — that is the region bench.py times.
 import os
 import threading
 import time
+import weakref
 from collections import OrderedDict
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
@@ -151,51 +152,72 @@ class EncoderEditPlan:
         return self.batch
 
 
-# ---- state kept across calls (all guarded by ENGINE_LOCK: the engine serialises edits per process) ------------------
+# ---- state kept across calls (every access under ENGINE_LOCK) --------------------------------------------------------
 ENGINE_LOCK = threading.RLock()
-_WS_CACHE: "OrderedDict[tuple, object]" = OrderedDict()        # (kind, device, N, d, h) -> reusable f64 workspace
+_WS_CACHE: "OrderedDict[tuple, list]" = OrderedDict()          # (kind, device, N, d, h) -> reusable f64 workspaces of that shape
 _FACTOR_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()     # see factor_cache_key -> (CovFactors, cov tensors)
 WS_CACHE_SIZE = 4
+WS_PER_SHAPE = 2
 
 
 def _factor_cache_size() -> int:
     return int(os.environ.get("EMCID_FACTOR_CACHE", "4"))
 
 
-def _workspace(kind: str, N: int, d: int, h: int, dev):
+def _workspace(kind: str, N: int, d: int, h: int, dev, plan):
+    """A workspace (buffers + its device `info` word) LEASED to ``plan`` until its check_info: two plans in flight —
+    prepare(A), prepare(B), run(A), run(B), check_info(A) — or two threads never share buffers or a flag word; a plan that
+    runs again gets its own workspace back.  A lease whose plan is gone (never checked) is free again."""
     key = (kind, str(dev), N, d, h)
-    ws = _WS_CACHE.get(key)
-    if ws is None:
-        ws = {"dual": hip.DualWorkspace, "lu": hip.LuWorkspace}.get(kind, hip.EditWorkspace)(N, d, h, dev)
-        _WS_CACHE[key] = ws
-        while len(_WS_CACHE) > WS_CACHE_SIZE:
-            _WS_CACHE.popitem(last=False)
-    else:
-        _WS_CACHE.move_to_end(key)
-    return ws
+    with ENGINE_LOCK:
+        pool = _WS_CACHE.get(key)
+        if pool is None:
+            pool = _WS_CACHE[key] = []
+            while len(_WS_CACHE) > WS_CACHE_SIZE:
+                _WS_CACHE.popitem(last=False)
+        else:
+            _WS_CACHE.move_to_end(key)
+        free = None
+        for ws in pool:
+            holder = ws.lease() if getattr(ws, "lease", None) is not None else None
+            if holder is plan:
+                return ws
+            if holder is None and free is None:
+                free = ws
+        if free is None:
+            free = {"dual": hip.DualWorkspace, "lu": hip.LuWorkspace}.get(kind, hip.EditWorkspace)(N, d, h, dev)
+            if len(pool) < WS_PER_SHAPE:      # beyond that the workspace lives as long as its plan
+                pool.append(free)
+        free.lease = weakref.ref(plan)
+        return free
 
 
-_PINNED: Dict[tuple, torch.Tensor] = {}
+def _release_workspaces(plan):
+    with ENGINE_LOCK:
+        for ws in (plan.ws, plan.dual_ws):
+            if ws is not None and getattr(ws, "lease", None) is not None and ws.lease() is plan:
+                ws.lease = None
 
 
 def _pinned_like(t: torch.Tensor) -> torch.Tensor:
-    """``t`` copied into a cached page-locked buffer of its shape (reused by later calls: every edit ends with a host
-    synchronisation, so the previous asynchronous copy out of the buffer has completed)."""
-    key = (tuple(t.shape), t.dtype)
-    buf = _PINNED.get(key)
-    if buf is None:
-        if len(_PINNED) > 8:
-            _PINNED.clear()
-        buf = _PINNED[key] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    """``t`` in page-locked memory: itself when it already is (the native v* reader fills pinned rows), else a copy in a
+    buffer from torch's caching host allocator — which keeps a block alive until the asynchronous copies issued from it have
+    finished (it records an event per stream use), so two plans prepared back to back never share a staging buffer."""
+    if t.is_pinned():
+        return t
+    buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     buf.copy_(t)
     return buf
 
 
 def factor_cache_key(covs: Sequence[torch.Tensor], lam: float, edit_weight: float) -> tuple:
-    """lam*C'_l and its Cholesky factor / explicit inverse factor are pure functions of (the statistics, lam, edit_weight):
-    keyed by the identity and version counter of the HBM-resident C tensors (the entries of emcid_main's covariance
-    cache), so a second edit with the same statistics and weights factors only its own N x N systems."""
-    return (tuple((c.device.index, c.data_ptr(), c._version, tuple(c.shape)) for c in covs), float(lam), float(edit_weight))
+    """The Cholesky factor of lam*C'_l and its explicit inverse are functions of (the statistics, edit_weight) up to a scalar:
+    chol(lam C') = sqrt(lam) chol(C'), so ``lam`` is NOT part of the key — an edit with another mom2_update_weight (the
+    reference's most common sweep, experiments/emcid_test.py:924-930, ablation.py:80-83) reuses the factors and hands the
+    library the ratio (include/emcid_hip.h, "lam_ratio").  edit_weight stays in the key: C' = fl32(fl32(C (1 - e_w)) / 0.5)
+    is rounded per entry in fp32 (reference :1037), which a scalar cannot reproduce.  The statistics are identified by the
+    identity and version counter of the HBM-resident C tensors (the entries of emcid_main's covariance cache)."""
+    return (tuple((c.device.index, c.data_ptr(), c._version, tuple(c.shape)) for c in covs), float(edit_weight))
 
 
 def clear_engine_caches():
@@ -245,6 +267,8 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
                          edit_weight, zs_t: torch.Tensor, covs: Dict[int, torch.Tensor],
                          shard: Optional[ConceptShard] = None, layer_module_tmp: Optional[str] = None,
                          forward_mode: Optional[str] = None) -> EncoderEditPlan:
+    from . import manage_threads
+    manage_threads()                    # acts once per process, and only under EMCID_MANAGE_THREADS=1
     shard = shard or ConceptShard()
     device = next(text_encoder.parameters()).device
     lo, hi = shard.bounds(len(requests))
@@ -300,9 +324,11 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
     # ``zs_t`` / ``covs`` may be callables: the caller's v* cache check and statistics lookups, run HERE — after the leading
     # layers have been launched, so that these host milliseconds too pass underneath the GPU (v* first, as the reference)
     if callable(zs_t) and not hasattr(zs_t, "result"):
-        zs_t = zs_t()
+        with phase("vstar check"):
+            zs_t = zs_t()
     if callable(covs):
-        covs = covs()
+        with phase("statistics"):
+            covs = covs()
     plan.covs = {l: c.to(device=device, dtype=torch.float32).contiguous() for l, c in covs.items()}
     plan.zs_pending = zs_t          # a tensor, or the caller's reader-thread future: resolved where the first solve needs it
     if not hasattr(zs_t, "result"):
@@ -377,15 +403,19 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
     lazy, first_x = False, 0
     plan.factor_key, plan.factors_from_cache = None, False
     if dual:
-        plan.dual_ws = _workspace("dual", plan.n_total, d, h, dev)
+        plan.dual_ws = _workspace("dual", plan.n_total, d, h, dev, plan)
         plan.dual_ws.info.zero_()
         fkey = factor_cache_key([plan.covs[l] for l in plan.layers], plan.lam, plan.edit_weight)
-        hit = _FACTOR_CACHE.get(fkey) if _factor_cache_size() > 0 else None
+        with ENGINE_LOCK:
+            hit = _FACTOR_CACHE.get(fkey) if _factor_cache_size() > 0 and plan.lam > 0 else None
+            if hit is not None and not (hit[0].lam and hit[0].lam > 0):
+                hit = None
+            if hit is not None:
+                _FACTOR_CACHE.move_to_end(fkey)
         if hit is not None:
-            # lam * C'_l = L L^T and X = inv(L) of every edited layer are already in HBM from an earlier edit with the
-            # same statistics, lam and edit_weight: every M-solve of this pass is a GEMM against X, nothing is factored
-            # but the N x N systems
-            _FACTOR_CACHE.move_to_end(fkey)
+            # lam0 * C'_l = L L^T and X = inv(L) of every edited layer are already in HBM from an earlier edit with the
+            # same statistics and edit_weight (any lam0: the solve stages take lam / lam0): every M-solve of this pass is a
+            # GEMM against X, nothing is factored but the N x N systems
             plan.cov_factors, plan.factors_from_cache = hit[0], True
             if plan.cov_factors.ready is not None:
                 torch.cuda.current_stream(dev).wait_event(plan.cov_factors.ready)
@@ -433,11 +463,11 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
             if os.environ.get("EMCID_FACTOR_FIRST", "0") == "1":    # experiment: no overlap of the factorization with the forward
                 torch.cuda.current_stream(dev).wait_event(chol_done)
     elif _solver_mode(plan) == "lu":
-        plan.ws = _workspace("lu", plan.n_total, d, h, dev)
+        plan.ws = _workspace("lu", plan.n_total, d, h, dev, plan)
         plan.ws.info.zero_()
         plan.dual_ws = None
     else:
-        plan.ws = _workspace("direct", plan.n_total, d, h, dev)
+        plan.ws = _workspace("direct", plan.n_total, d, h, dev, plan)
         plan.ws.info.zero_()
 
     def solve(i, layer, K_local, Zc_local):
@@ -471,7 +501,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                     res = hip.edit_layer_dual_cols(
                         K, Zc, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, backups[layer], weights[layer].data,
                         hip.column_tiles(plan.shard.rank, plan.shard.world, n_tiles),
-                        lambda t: _all_reduce_sum(t, plan.shard.group), ws=plan.dual_ws)
+                        lambda t: _all_reduce_sum(t, plan.shard.group), ws=plan.dual_ws, lam=plan.lam)
                     edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], None, None,
                                            K if trace else None, Zc if trace else None))
                     return
@@ -482,7 +512,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                     K, Zc, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, backups[layer], weights[layer].data,
                     ws=plan.dual_ws, rows=plan.shard.bounds(plan.n_total) if split else None,
                     gather_yt=(lambda rows_: _all_gather_rows(rows_.contiguous(), plan)) if split else None,
-                    on_factor_start=lazy_inverse if ahead else None)
+                    on_factor_start=lazy_inverse if ahead else None, lam=plan.lam)
                 edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], None, None,
                                        K if trace else None, Zc if trace else None))
                 return
@@ -490,7 +520,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                 K, Zc, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, W0=backups[layer], W=weights[layer].data,
                 want_factors=keep_factors, ws=plan.dual_ws,
                 rows=plan.shard.bounds(plan.n_total) if sharded else None,
-                gather_pt=(lambda rows_: _all_gather_rows(rows_.contiguous(), plan)) if sharded else None)
+                gather_pt=(lambda rows_: _all_gather_rows(rows_.contiguous(), plan)) if sharded else None, lam=plan.lam)
             xt = res["adj_k"].t() if res["adj_k"] is not None else None
             edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], xt, res["Rt"],
                                    K if trace else None, Zc if trace else None))
@@ -640,7 +670,8 @@ def check_info(plan: EncoderEditPlan, restore_on_failure: bool = True):
     """One host sync at the very end: did any factorization meet a non-positive pivot?  If so the edited weights hold
     garbage: they are put back to the values they had before the run, then FloatingPointError is raised (callers that can
     retry — emcid_main — catch it and rerun with the pivoted-LU solver, the reference's own semantics)."""
-    code = solver_info(plan)
+    code = solver_info(plan)          # (a host synchronisation: nothing of this plan's run is still using its workspaces)
+    _release_workspaces(plan)
     if code != 0 and plan.solver == "lu":
         if restore_on_failure and plan.backups is not None:
             with torch.no_grad():

@@ -156,8 +156,12 @@ def _npz_single_array(blob: bytes, key: str) -> Optional[np.ndarray]:
         return None
 
 
+_VSTAR_CACHE_MAX = 4096     # entries of the per-file memo below (the numpy path only); oldest dropped first
+
+
 def _read_vstar(path: str) -> np.ndarray:
-    """``np.load(path)["v_star"]``, memoised on (path, mtime, size): an unchanged cache file is read once per process."""
+    """``np.load(path)["v_star"]`` for ONE file — the path of every file the native batch reader does not serve (other npz
+    layouts, compressed members) and of processes without libemcid_host.so; memoised on (path, mtime, size), bounded."""
     st = os.stat(path)
     key = (path, st.st_mtime_ns, st.st_size)
     v = _VSTAR_CACHE.get(key)
@@ -168,18 +172,57 @@ def _read_vstar(path: str) -> np.ndarray:
         if v is None:
             with np.load(path) as z:
                 v = np.asarray(z["v_star"])
+        while len(_VSTAR_CACHE) >= _VSTAR_CACHE_MAX:
+            _VSTAR_CACHE.pop(next(iter(_VSTAR_CACHE)))
         _VSTAR_CACHE[key] = v
     return v
 
 
+def _read_threads() -> int:
+    n = os.environ.get("EMCID_READ_THREADS", "")
+    if n:
+        return max(1, int(n))
+    from . import effective_cpu_count
+    return max(1, min(8, effective_cpu_count() // 2))
+
+
+def _native_vstar_rows(names: Sequence[Optional[str]], width: int, pin: bool):
+    """All cache files in one native call (csrc/host_io.cpp: a few threads, open/read/parse straight into the row buffer —
+    page-locked when the rows go to a GPU next, so the upload needs no staging copy).  Returns (rows (N, width) fp32 tensor,
+    status uint8 array: 0 = row read, 1 = no such file, 2 = a file for numpy), or None without the host library."""
+    from . import host_text
+    if os.environ.get("EMCID_NATIVE_VSTAR", "1") == "0" or not host_text.available() or any(n is None for n in names):
+        return None
+    lib = host_text.load()
+    n = len(names)
+    blob, off = host_text.pack_strings(names)
+    rows = torch.empty((n, width), dtype=torch.float32, pin_memory=bool(pin))
+    status = np.empty(n, dtype=np.uint8)
+    rc = lib.emcid_read_npz_rows_f32(blob, off.ctypes.data, n, b"v_star", width, rows.data_ptr(), width,
+                                     status.ctypes.data, _read_threads())
+    if rc < 0:
+        return None
+    return rows, status
+
+
 def load_v_stars(requests: Sequence[Dict], hparams, cache_name: Optional[str], suffix: str = "",
-                 stage1: Optional[Stage1Fn] = None) -> torch.Tensor:
-    """(N, hidden) fp32 on the host: one row per request, the transpose of the reference's ``zs`` (:977)."""
+                 stage1: Optional[Stage1Fn] = None, width: Optional[int] = None, pin: bool = False) -> torch.Tensor:
+    """(N, hidden) fp32 on the host: one row per request, the transpose of the reference's ``zs`` (:977).  ``width``: the
+    encoder's hidden size when the caller knows it (then every cache file is read by the native batch reader; files it does
+    not serve, and every miss, take the per-file path below, which is the reference's: np.load, recompute on an unreadable
+    file :903-904, Stage 1 on a miss :905-969)."""
+    names = [vstar_cache_name(cache_name, request, hparams, idx, suffix) for idx, request in enumerate(requests)]
+    native = _native_vstar_rows(names, int(width), pin) if (width and cache_name is not None and len(names)) else None
+    if native is not None and not native[1].any():
+        return native[0]
     rows = []
     for idx, request in enumerate(requests):
-        f = vstar_cache_name(cache_name, request, hparams, idx, suffix)
+        f = names[idx]
+        if native is not None and native[1][idx] == 0:
+            rows.append(native[0][idx].numpy())
+            continue
         v = None
-        if f is not None:
+        if f is not None and not (native is not None and native[1][idx] == 1):
             try:
                 v = _read_vstar(f)
             except FileNotFoundError:
@@ -269,25 +312,29 @@ class _LazyVstars:
     edited layer's solve — by then the encoder forward up to that layer is queued on the GPU, so the file-system calls of
     the cache reads (and Stage 1 on a miss) cost no wall-clock of their own."""
 
-    def __init__(self, *args):
-        self.args = args
+    def __init__(self, *args, **kwargs):
+        self.args, self.kwargs = args, kwargs
 
     def result(self):
-        return load_v_stars(*self.args)
+        return load_v_stars(*self.args, **self.kwargs)
 
 
 def prepare_text_encoder_edit(text_encoder, tokenizer, requests, hparams, layers, lam, stat_dir, cache_name,
                               suffix="", verbose=True, shard=None, stage1=None) -> EncoderEditPlan:
     """Host side of one encoder's edit: v* rows, C per layer (HBM-resident), tokenized prompts + lookup."""
+    w = None
     for layer in layers:   # resolve every edited weight now: LookupError before any GPU work, like the reference (:858-863)
-        nethook.get_parameter(text_encoder, f"{hparams.rewrite_module_tmp.format(layer)}.weight")
+        w = nethook.get_parameter(text_encoder, f"{hparams.rewrite_module_tmp.format(layer)}.weight")
+    # v* rows have the encoder's hidden size = the rows of the edited projection (h, d); known here, it lets the cache files be
+    # read natively, in one call, into page-locked rows (load_v_stars)
+    how = dict(width=int(w.shape[0]) if w is not None and w.dim() == 2 else None, pin=bool(w is not None and w.is_cuda))
 
     def targets():
         # a cache miss is handled FIRST, as the reference does (:873-969 come before the layer loop's covariance reads): Stage 1
         # runs (or the miss is reported) before statistics are read or computed
         if _any_vstar_missing(requests, hparams, cache_name, suffix):
-            return load_v_stars(requests, hparams, cache_name, suffix, stage1)
-        return _LazyVstars(requests, hparams, cache_name, suffix, stage1)
+            return load_v_stars(requests, hparams, cache_name, suffix, stage1, **how)
+        return _LazyVstars(requests, hparams, cache_name, suffix, stage1, **how)
 
     def statistics():
         return {layer: get_cov_text_encoder(text_encoder, tokenizer, hparams.rewrite_module_tmp.format(layer),

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from pathlib import Path
 from typing import Optional
 
@@ -33,7 +34,7 @@ EXPORTS = [
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block"]
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 NB = 128      # Cholesky block (csrc/common.h)
 NPAD = 64     # concept padding of the f64 stacks (csrc/common.h)
 
@@ -75,15 +76,15 @@ def load():
         "emcid_factor_cov_f64": (i32, [p, i64, i64, f64, f64, p, i64, p, p]),
         "emcid_cov_inverse_f64": (i32, [p, i64, i64, i64, i64, p]),
         "emcid_edit_dual_workspace_bytes": (i64, [i64, i64, i64]),
-        "emcid_edit_dual_stage1_f64": (i32, [p, p, p, i64, i64, i64, f64, i32, p, i64, i64, i64, i64, i32, p, i64, p]),
+        "emcid_edit_dual_stage1_f64": (i32, [p, p, p, i64, i64, i64, f64, i32, f64, p, i64, i64, i64, i64, i32, p, i64, p]),
         "emcid_edit_dual_pt": (p, [p, i64, i64, i64]),
-        "emcid_edit_dual_stage2_f64": (i32, [i64, i64, i64, p, p, p, p, p, p, i64, p, p]),
-        "emcid_edit_dual_apply_stage1_f64": (i32, [p, p, p, i64, i64, i64, f64, i32, p, i64, i64, i64, i64, i32, p, i64, p]),
+        "emcid_edit_dual_stage2_f64": (i32, [i64, i64, i64, f64, p, p, p, p, p, p, i64, p, p]),
+        "emcid_edit_dual_apply_stage1_f64": (i32, [p, p, p, i64, i64, i64, f64, i32, f64, p, i64, i64, i64, i64, i32, p, i64, p]),
         "emcid_edit_dual_yt": (p, [p, i64, i64, i64]),
         "emcid_edit_dual_apply_stage2_f64": (i32, [i64, i64, i64, p, i64, i64, i32, i32, p, p, p, p, i64, p, p]),
         "emcid_edit_dual_apply_assemble_f64": (i32, [i64, i64, i64, p, i64, p]),
         "emcid_cholesky_solve_f64": (i32, [p, i64, i64, p, p, p, i64, i64, p]),
-        "emcid_edit_dual_cols_stage1_f64": (i32, [p, p, p, i64, i64, i64, f64, i32, p, i64, i64, p, i32, p, i64, p]),
+        "emcid_edit_dual_cols_stage1_f64": (i32, [p, p, p, i64, i64, i64, f64, i32, f64, p, i64, i64, p, i32, p, i64, p]),
         "emcid_edit_dual_s": (p, [p, i64, i64, i64]),
         "emcid_edit_dual_u": (p, [p, i64, i64, i64]),
         "emcid_edit_dual_cols_stage2_f64": (i32, [i64, i64, i64, p, i64, i64, p, i32, p, i64, p, p]),
@@ -117,12 +118,13 @@ def load():
     return lib
 
 
-_restore_device = []      # device ordinals to go back to after the call in flight (see _stream)
+_tls = threading.local()  # .restore: device ordinals to go back to after the call in flight (see _stream), per thread
 
 
 def _check(rc: int, what: str):
-    if _restore_device:
-        torch.cuda.set_device(_restore_device.pop())
+    restore = getattr(_tls, "restore", None)
+    if restore:
+        torch.cuda.set_device(restore.pop())
     if rc != 0:
         raise EmcidHipError(f"{what} failed (rc={rc}): {load().emcid_last_error().decode()}")
 
@@ -145,7 +147,9 @@ def _stream(t: torch.Tensor):
     idx = t.device.index
     cur = torch.cuda.current_device()
     if idx is not None and idx != cur:
-        _restore_device.append(cur)
+        if getattr(_tls, "restore", None) is None:
+            _tls.restore = []
+        _tls.restore.append(cur)
         torch.cuda.set_device(idx)
     return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
@@ -535,6 +539,17 @@ class CovFactors:
         self.have_inverse = set()                                        # layers whose X = inv(L) has been built
         self.ready = None       # HIP event after the last kernel that wrote this workspace on another stream (or None)
         self.cached = False     # True once the edit engine shares it between edits (then it is read-only)
+        self.lam = None         # the lam the workspace was factored with (factor_cov); edits with another lam pass the ratio
+        self.edit_weight = None
+
+    def lam_ratio(self, lam: Optional[float]) -> float:
+        """lam of an edit / the lam of the factorization: the gain the dual stages fold into Kt64 and Rt
+        (include/emcid_hip.h, "lam_ratio")."""
+        if lam is None or self.lam is None or float(lam) == self.lam:
+            return 1.0
+        if not (lam > 0.0 and self.lam > 0.0):
+            raise EmcidHipError(f"mom2_update_weight must be positive for the Cholesky path (got {lam})")
+        return float(lam) / float(self.lam)
 
     def L(self, layer: int) -> torch.Tensor:
         """(dp, dp) view of the Cholesky factor of lam*C'_layer (lower triangle valid)."""
@@ -568,6 +583,7 @@ def factor_cov(covs, lam: float, edit_weight: float, factors: Optional[CovFactor
     _check(load().emcid_factor_cov_f64(arr, len(covs), d, float(lam), float(edit_weight), _ptr(factors.buf), factors.nbytes,
                                        _ptr(factors.info, torch.int32), _stream(covs[0])), "emcid_factor_cov_f64")
     factors.have_inverse = set()
+    factors.lam, factors.edit_weight = float(lam), float(edit_weight)
     if inverse:
         cov_inverse(factors)
     return factors
@@ -595,8 +611,9 @@ class DualWorkspace:
 
 def edit_layer_dual(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_weight: float, layers_left: int,
                     W0=None, W=None, want_factors: bool = False, want_dw: bool = True, ws: Optional[DualWorkspace] = None,
-                    rows=None, gather_pt=None, use_inverse: Optional[bool] = None):
-    """One edited layer through the dual solver.  ``rows=(lo, hi)`` + ``gather_pt(Pt_rows) -> all rows`` split the
+                    rows=None, gather_pt=None, use_inverse: Optional[bool] = None, lam: Optional[float] = None):
+    """One edited layer through the dual solver.  ``lam``: this edit's mom2_update_weight when it differs from the one
+    ``factors`` was built with (None: the same).  ``rows=(lo, hi)`` + ``gather_pt(Pt_rows) -> all rows`` split the
     M-solves over ranks.  ``use_inverse``: solve against M with GEMMs on X = inv(L) (default: if cov_inverse built it)
     or by block substitution with L.  Returns dict(adj_k (d,N) | None, Rt (N,h) | None, dW, ws)."""
     if use_inverse is None:
@@ -612,7 +629,7 @@ def edit_layer_dual(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_wei
     lib = load()
     _check(lib.emcid_edit_dual_stage1_f64(
         _ptr(K, torch.float32, "K"), _ptr(Zc, torch.float32, "Zc"), _ptr(zs_t, torch.float32, "zs_t"), N, d, h,
-        float(edit_weight), int(layers_left), _ptr(factors.buf), factors.n_layers, int(layer_index), lo, hi,
+        float(edit_weight), int(layers_left), factors.lam_ratio(lam), _ptr(factors.buf), factors.n_layers, int(layer_index), lo, hi,
         int(bool(use_inverse)), _ptr(ws.buf), ws.nbytes, _stream(K)), "emcid_edit_dual_stage1_f64")
     if gather_pt is not None:
         ws.Pt[:N].copy_(gather_pt(ws.Pt[lo:hi]))
@@ -622,7 +639,7 @@ def edit_layer_dual(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_wei
     dW = torch.empty(h, d, dtype=torch.float32, device=dev) if want_dw else None
     if W is not None:
         assert W.is_contiguous() and W.shape == (h, d) and W0 is not None and W0.is_contiguous()
-    _check(lib.emcid_edit_dual_stage2_f64(N, d, h, _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"), _ptr(adj_k),
+    _check(lib.emcid_edit_dual_stage2_f64(N, d, h, factors.lam_ratio(lam), _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"), _ptr(adj_k),
                                           _ptr(Rt), _ptr(dW), _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32),
                                           _stream(K)), "emcid_edit_dual_stage2_f64")
     return {"adj_k": adj_k, "Rt": Rt, "dW": dW, "ws": ws}
@@ -645,8 +662,9 @@ def column_tiles(rank: int, world: int, n_tiles: int):
 class _HipColsBackend:
     """The two stages of the column-sharded solve on the C library (include/emcid_hip.h)."""
 
-    def __init__(self, K, Zc, zs_t, factors, layer_index, edit_weight, layers_left, ws):
+    def __init__(self, K, Zc, zs_t, factors, layer_index, edit_weight, layers_left, ws, lam=None):
         self.a = (K, Zc, zs_t, factors, layer_index, edit_weight, layers_left, ws)
+        self.lam_ratio = factors.lam_ratio(lam)
 
     def stage1(self, tiles):
         K, Zc, zs_t, factors, layer_index, edit_weight, layers_left, ws = self.a
@@ -654,8 +672,8 @@ class _HipColsBackend:
         arr = (C.c_int * len(tiles))(*tiles)
         _check(load().emcid_edit_dual_cols_stage1_f64(
             _ptr(K, torch.float32, "K"), _ptr(Zc, torch.float32, "Zc"), _ptr(zs_t, torch.float32, "zs_t"), N, d, Zc.shape[1],
-            float(edit_weight), int(layers_left), _ptr(factors.buf), factors.n_layers, int(layer_index), arr, len(tiles),
-            _ptr(ws.buf), ws.nbytes, _stream(K)), "emcid_edit_dual_cols_stage1_f64")
+            float(edit_weight), int(layers_left), self.lam_ratio, _ptr(factors.buf), factors.n_layers, int(layer_index), arr,
+            len(tiles), _ptr(ws.buf), ws.nbytes, _stream(K)), "emcid_edit_dual_cols_stage1_f64")
         return ws.S
 
     def stage2(self, tiles):
@@ -677,7 +695,8 @@ class _HipColsBackend:
 
 
 def edit_layer_dual_cols(K, Zc, zs_t, factors, layer_index: int, edit_weight: float, layers_left: int, W0, W,
-                         tiles, all_reduce, want_dw: bool = True, ws: Optional["DualWorkspace"] = None, backend=None):
+                         tiles, all_reduce, want_dw: bool = True, ws: Optional["DualWorkspace"] = None, backend=None,
+                         lam: Optional[float] = None):
     """Apply-only dual solver with the layer's GEMMs split over ranks by column tiles of d (include/emcid_hip.h,
     "COLUMN-SHARDED").  ``tiles``: this rank's tile indices (column_tiles); ``all_reduce(t)``: sums a tensor over the
     ranks in place (two calls: the N x N partial S, the h x dp partial U).  Needs the layer's explicit inverse factor.
@@ -696,7 +715,7 @@ def edit_layer_dual_cols(K, Zc, zs_t, factors, layer_index: int, edit_weight: fl
             raise EmcidHipError("edit_layer_dual_cols needs the explicit inverse factor of the layer (cov_inverse)")
         if ws is None or ws.key != (N, d, h):
             ws = DualWorkspace(N, d, h, K.device)
-        backend = _HipColsBackend(K, Zc, zs_t, factors, layer_index, edit_weight, layers_left, ws)
+        backend = _HipColsBackend(K, Zc, zs_t, factors, layer_index, edit_weight, layers_left, ws, lam)
     S = backend.stage1(tiles)            # partial S_r = Yc Yc^T (no identity)
     all_reduce(S)
     U = backend.stage2(tiles)            # partial U_r = (Z^T Yc) X[tiles, :]
@@ -707,7 +726,7 @@ def edit_layer_dual_cols(K, Zc, zs_t, factors, layer_index: int, edit_weight: fl
 
 def edit_layer_dual_apply(K, Zc, zs_t, factors: CovFactors, layer_index: int, edit_weight: float, layers_left: int,
                           W0, W, want_dw: bool = True, ws: Optional[DualWorkspace] = None, rows=None, gather_yt=None,
-                          use_inverse: Optional[bool] = None, on_factor_start=None):
+                          use_inverse: Optional[bool] = None, on_factor_start=None, lam: Optional[float] = None):
     """Apply-only dual solver: W = W0 + float(U) without ever forming adj_k.  ``on_factor_start()``: called (host side)
     right after S = I + Yt Yt^T has been enqueued, i.e. the stream position where the latency-bound Cholesky of S
     begins.  Returns dict(dW, ws)."""
@@ -724,7 +743,7 @@ def edit_layer_dual_apply(K, Zc, zs_t, factors: CovFactors, layer_index: int, ed
     lib = load()
     _check(lib.emcid_edit_dual_apply_stage1_f64(
         _ptr(K, torch.float32, "K"), _ptr(Zc, torch.float32, "Zc"), _ptr(zs_t, torch.float32, "zs_t"), N, d, h,
-        float(edit_weight), int(layers_left), _ptr(factors.buf), factors.n_layers, int(layer_index), lo, hi,
+        float(edit_weight), int(layers_left), factors.lam_ratio(lam), _ptr(factors.buf), factors.n_layers, int(layer_index), lo, hi,
         int(bool(use_inverse)), _ptr(ws.buf), ws.nbytes, _stream(K)), "emcid_edit_dual_apply_stage1_f64")
     if gather_yt is not None:
         ws.Yt[:N].copy_(gather_yt(ws.Yt[lo:hi]))

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _LIB = None
 _LOCK = threading.Lock()
 
@@ -62,6 +62,8 @@ def load():
         lib.emcid_trie_export.argtypes = [P, P, I64]
         lib.emcid_trie_destroy.restype = None
         lib.emcid_trie_destroy.argtypes = [P]
+        lib.emcid_read_npz_rows_f32.restype = I64
+        lib.emcid_read_npz_rows_f32.argtypes = [ctypes.c_char_p, P, I64, ctypes.c_char_p, I64, P, I64, P, I32]
         if lib.emcid_host_abi_version() != ABI_VERSION:
             raise RuntimeError(f"{path}: ABI {lib.emcid_host_abi_version()}, this package needs {ABI_VERSION}; rebuild")
         _LIB = lib

@@ -150,6 +150,17 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
         if shard is None or shard[0] == 0:
             save_cached_state(files[ln], stats[ln], args)
     if len(todo) > 1:
+        # Kernels stay on the CALLING thread and its stream: the last Gram flush and the symmetrize pass of every layer are
+        # issued here, in order behind the accumulations (which may sit on a caller-chosen stream), and completed before the
+        # workers start; the workers only copy finished matrices to the host and write files.
+        cuda_devs = set()
+        for ln in todo:
+            m2 = getattr(stats[ln], "mom2", None)
+            full = getattr(m2, "mom2", None) if m2 is not None else None
+            if torch.is_tensor(full) and full.is_cuda:
+                cuda_devs.add(full.device)
+        for dv in cuda_devs:
+            torch.cuda.current_stream(dv).synchronize()
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=min(4, len(todo))) as ex:
             list(ex.map(finish, todo))

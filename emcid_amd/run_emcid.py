@@ -13,6 +13,7 @@ included when ``--synthetic_caches`` is given.
 """
 import argparse
 import json
+import os
 import sys
 import time
 from pathlib import Path
@@ -105,6 +106,7 @@ def main(argv=None):
     ap.add_argument("--synthetic_caches", action="store_true",
                     help="with --pipe synthetic: write synthetic v* / statistics caches for the instruction first")
     a = ap.parse_args(argv)
+    os.environ.setdefault("EMCID_MANAGE_THREADS", "1")      # this process exists to edit: thread pools sized to the CPU quota
     if a.synthetic_caches:
         if a.pipe != "synthetic":
             raise SystemExit("--synthetic_caches only makes sense with --pipe synthetic")

@@ -147,9 +147,17 @@ class SecondMoment(Stat):
 
         self.flush()
         acc = self._lower if self._lower is not None else self._full
-        if acc is None:
-            raise RuntimeError("all_reduce_ on an empty SecondMoment")
-        staged = acc.is_cuda and dist.get_backend(group) == "gloo"   # gloo (tests) cannot take HBM tensors; RCCL does
+        # An empty shard (a rank that was dealt no caption) must not leave its peers waiting inside the all-reduce below: every
+        # rank first learns whether ALL ranks hold data (one tiny MIN all-reduce), and all of them raise the same error if not.
+        backend = dist.get_backend(group)
+        flag_dev = "cpu" if backend == "gloo" else (acc.device if acc is not None and acc.is_cuda
+                                                    else torch.device("cuda", torch.cuda.current_device()))
+        have = torch.tensor([0 if acc is None else 1], dtype=torch.int32, device=flag_dev)
+        dist.all_reduce(have, op=dist.ReduceOp.MIN, group=group)
+        if int(have.item()) == 0:
+            raise RuntimeError("all_reduce_ on an empty SecondMoment: at least one rank of the group collected nothing "
+                               "(sample smaller than the world size?) — raised on every rank")
+        staged = acc.is_cuda and backend == "gloo"   # gloo (tests) cannot take HBM tensors; RCCL does
         if staged:
             host = acc.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)

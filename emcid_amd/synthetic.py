@@ -331,12 +331,13 @@ def write_xattn_vstar_cache(cache_name: str, requests: Sequence[Dict], layer_dim
 
 
 def make_requests(n: int, dest: str = "a realist artist", templates: Sequence[str] = ARTIST_TEMPLATES,
-                  seed_train: int = 2024, ragged: bool = False, names: str = "index") -> List[Dict]:
+                  seed_train: int = 2024, ragged: bool = False, names: str = "index", name_seed: int = 3) -> List[Dict]:
     """n unique synthetic concepts in the reference's request schema: ``c0000`` … (``names="index"``) or
-    3-syllable names (``names="syllable"``, needs the ``syllables=True`` vocabulary to tokenize compactly).
+    3-syllable names (``names="syllable"``, needs the ``syllables=True`` vocabulary to tokenize compactly; ``name_seed``
+    draws another set of names: 729 000 possible, so two seeds share about one name in a thousand).
     ``ragged`` gives requests differing prompt counts (1..len(templates))."""
     reqs = []
-    sources = syllable_names(n) if names == "syllable" else [f"c{i:04d}" for i in range(n)]
+    sources = syllable_names(n, seed=name_seed) if names == "syllable" else [f"c{i:04d}" for i in range(n)]
     for i in range(n):
         k = len(templates) if not ragged else 1 + (i % len(templates))
         reqs.append({

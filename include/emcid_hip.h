@@ -28,7 +28,7 @@ extern "C" {
 #define EMCID_ERR_HIP (-2)
 #define EMCID_ERR_WORKSPACE (-3)
 
-#define EMCID_ABI_VERSION 8
+#define EMCID_ABI_VERSION 9
 
 /* ABI version of the loaded library (host-only, no GPU needed). */
 int emcid_abi_version(void);
@@ -164,17 +164,23 @@ int emcid_apply_update_f32(const double* U, const float* W0, float* W, float* dW
  *   emcid_edit_dual_stage1    Kt64, Rt, and rows [n_lo, n_hi) of Pt = Kt64 M^-1 (= (Kt64 X^T) X with use_inverse).
  *   emcid_edit_dual_pt        address of the Pt stack [Np, dp] inside the workspace (multi-GPU: all-gather rows there).
  *   emcid_edit_dual_stage2    needs all rows of Pt: S, its Cholesky, adj_k = (S^-1 Pt)^T [d,N], U = Rt^T Xt, W = W0 + float(U).
+ * lam_ratio (every stage-1 entry point of the dual forms, and emcid_edit_dual_stage2_f64) = lam of THIS edit / the lam the
+ * workspace was factored with.  chol(lam C') = sqrt(lam) chol(C'), so a factored workspace serves every lam: stage 1 scales
+ * Kt64 and Rt by 1/sqrt(lam_ratio), which makes Yt, S, Z and U exactly those of the call's own lam (the reference's
+ * mom2_update_weight sweep, experiments/emcid_test.py:924-930, then costs no factorization); 1.0 reproduces the factored lam
+ * bit for bit.  edit_weight is NOT covered: C' = fl32(fl32(C (1 - e_w)) / 0.5) is rounded in fp32 per entry (:1037), so a
+ * new edit_weight needs its own emcid_factor_cov_f64.
  * ------------------------------------------------------------------------------------------- */
 int64_t emcid_cov_factor_workspace_bytes(int64_t n_layers, int64_t d);
 int emcid_factor_cov_f64(const float* const* C_host_list, int64_t n_layers, int64_t d, double lam, double edit_weight,
                          void* workspace, int64_t workspace_bytes, int* info_dev, void* stream);
 int64_t emcid_edit_dual_workspace_bytes(int64_t N, int64_t d, int64_t h);
 int emcid_edit_dual_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
-                               double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
+                               double edit_weight, int layers_left, double lam_ratio, const void* cov_factor_ws, int64_t n_layers,
                                int64_t layer_index, int64_t n_lo, int64_t n_hi, int use_inverse, void* workspace,
                                int64_t workspace_bytes, void* stream);
 double* emcid_edit_dual_pt(void* workspace, int64_t N, int64_t d, int64_t h);
-int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, const float* W0, float* W, double* adjk_out, double* Rt_out,
+int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, double lam_ratio, const float* W0, float* W, double* adjk_out, double* Rt_out,
                                float* dW_out, void* workspace, int64_t workspace_bytes, int* info_dev, void* stream);
 
 /* Apply-only form of the dual solver (adj_k is never formed; used when only the edited weights are wanted):
@@ -182,7 +188,7 @@ int emcid_edit_dual_stage2_f64(int64_t N, int64_t d, int64_t h, const float* W0,
  * stage1 computes rows [n_lo, n_hi) of Yt (one forward solve), emcid_edit_dual_yt gives the Yt stack [Np, dp] inside the
  * workspace (multi-GPU all-gather target), stage2 needs all rows of Yt. */
 int emcid_edit_dual_apply_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
-                                     double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
+                                     double edit_weight, int layers_left, double lam_ratio, const void* cov_factor_ws, int64_t n_layers,
                                      int64_t layer_index, int64_t n_lo, int64_t n_hi, int use_inverse, void* workspace,
                                      int64_t workspace_bytes, void* stream);
 double* emcid_edit_dual_yt(void* workspace, int64_t N, int64_t d, int64_t h);
@@ -224,7 +230,7 @@ int emcid_lu_solve_f64(double* A, int64_t lda, int64_t n, double* B, int64_t ldb
  * Summed over the ranks this is exactly emcid_edit_dual_apply_stage1/2 (same algebra, sums in another order).
  * ------------------------------------------------------------------------------------------- */
 int emcid_edit_dual_cols_stage1_f64(const float* K, const float* Zc, const float* zs_t, int64_t N, int64_t d, int64_t h,
-                                    double edit_weight, int layers_left, const void* cov_factor_ws, int64_t n_layers,
+                                    double edit_weight, int layers_left, double lam_ratio, const void* cov_factor_ws, int64_t n_layers,
                                     int64_t layer_index, const int* tiles_host, int n_tiles, void* workspace,
                                     int64_t workspace_bytes, void* stream);
 double* emcid_edit_dual_s(void* workspace, int64_t N, int64_t d, int64_t h);

@@ -1,4 +1,4 @@
-/* emcid_host.h — C ABI of libemcid_host.so: the host-side text work on the edit path (no GPU, no HIP).
+/* emcid_host.h — C ABI of libemcid_host.so: the host-side text work and cache reads on the edit path (no GPU, no HIP).
  *
  * The reference tokenizes every prompt of an edit with the pipeline's own Hugging Face CLIP tokenizer
  * (`tokenize_prompts`, emcid/compute_z.py:65: `tokenizer(prompts, return_tensors="pt", padding=True, truncation=True)`, called
@@ -83,6 +83,16 @@ void emcid_trie_sizes(const emcid_trie* t, int64_t* U, int64_t* n_real, int64_t*
 int64_t emcid_trie_packed_bytes(const emcid_trie* t);
 int emcid_trie_export(const emcid_trie* t, void* out, int64_t out_bytes);
 void emcid_trie_destroy(emcid_trie* t);
+
+/* The v* rows of an edit straight from the reference's cache files (emcid/emcid_main.py:885-899 reads them with np.load, one
+ * per request; :951-968 writes them with np.savez(f, v_star=...)).  File i is paths[off[i] .. off[i+1]); each is read whole
+ * and accepted when its FIRST zip member is "<member>.npy", stored uncompressed, dtype <f4 or <f8, shape (width,) or
+ * (1, width); the values go to out[i * ld .. i * ld + width) as float32 (f8 rounded to nearest, like numpy's astype).
+ * status[i]: 0 = row written, 1 = no such file, 2 = not such a file (the caller reads it with numpy and gets numpy's
+ * behaviour, errors included).  The files are dealt to at most n_threads threads (at least 64 files each).
+ * Returns the number of rows with status != 0, or -1 on a bad argument.  `out` may be page-locked memory. */
+int64_t emcid_read_npz_rows_f32(const char* paths, const int64_t* off, int64_t n, const char* member, int64_t width, float* out,
+                                int64_t ld, uint8_t* status, int32_t n_threads);
 
 const char* emcid_host_last_error(void);
 

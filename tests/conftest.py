@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 import torch
 
+os.environ.setdefault("EMCID_MANAGE_THREADS", "1")      # the test box is a container with a CPU quota (emcid_amd.manage_threads)
 REPO = Path(__file__).resolve().parents[1]
 GOLDEN = REPO / "tests" / "golden"
 if str(REPO) not in sys.path:

@@ -721,6 +721,8 @@ def main():
                           ragged=False, full=False, syllables=True, store_vstar=False)
             elif which == "real_sdxl_summary":
                 golden_sdxl_real(em, XLHP, scratch)
+            elif which == "real_sdxl_n1000_summary":     # BASELINE config 4 at its full size (N = 1000: the solver's
+                golden_sdxl_real(em, XLHP, scratch, tag=which, n_req=1000)      # two-round stream-K / pairs path at d = 5120)
             elif which == "real_stage0_summary":
                 golden_stage0_real(ls, scratch)
             elif which == "toy_extras":

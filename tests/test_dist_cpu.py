@@ -176,3 +176,28 @@ def test_column_tiles_are_balanced():
             assert sorted(sum(tiles, [])) == list(range(n_tiles))
             cost = [sum(t + 1 for t in ts) for ts in tiles]                 # tile t of the triangular factor costs ~ t + 1
             assert max(cost) <= 1.25 * (sum(cost) / world) + 1, (world, n_tiles, cost)
+
+
+def _empty_shard_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from emcid_amd import runningstats as rs
+        st = rs.SecondMoment()
+        if rank == 0:       # rank 1 was dealt no caption: its statistic is empty
+            st.load_state_dict({"count": 3, "mom2": np.eye(4, dtype=np.float32)})
+        try:
+            st.all_reduce_()
+            verdict = "returned"
+        except RuntimeError as e:
+            verdict = "raised" if "every rank" in str(e) else f"other: {e}"
+        with open(os.path.join(tmp, f"verdict{rank}.txt"), "w") as f:
+            f.write(verdict)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_empty_caption_shard_fails_on_every_rank(tmp_path):
+    """A rank without data must not leave its peers inside the all-reduce: every rank raises the same error (round-2 review)."""
+    mp.spawn(_empty_shard_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f"verdict{r}.txt").read() for r in range(2)] == ["raised", "raised"]

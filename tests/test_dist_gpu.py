@@ -165,6 +165,59 @@ def test_two_ranks_headline_edit_matches_reference_summary(tmp_path):
             np.testing.assert_allclose(np.abs(r0[n]).max(), scale, rtol=1e-4)
 
 
+def _sdxl_full_worker(rank, world, port, tmp):
+    import json
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      EMCID_SDXL_SPLIT="0")       # both encoders on both ranks: TE2's solve is column-sharded at d = 5120
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from emcid_amd import emcid_main as em, synthetic as syn
+        from emcid_amd.emcid_hparams import EMCIDXLHyperParams
+        from emcid_amd.nethook import get_parameter
+        meta = json.load(open(tmp + "/meta.json"))
+        reqs = syn.make_requests(meta["n_requests"], names="syllable")
+        pipe = syn.build_pipe("sdxl", "cuda:0", sdxl=True, syllables=True)
+        encs = (("", meta["layer_names"], pipe.text_encoder), ("_2", meta["layer_names_2"], pipe.text_encoder_2))
+        w0 = {(sfx, n): get_parameter(enc, n + ".weight").detach().cpu().double() for sfx, names, enc in encs for n in names}
+        em.apply_emcid_to_sdxl_text_encoders(pipe, reqs, EMCIDXLHyperParams(**meta["hparams"]), "cuda:0", cache_name=tmp + "/cache/",
+                                             stat_dir=tmp + "/s1", stat_dir_2=tmp + "/s2", verbose=False)
+        np.savez(f"{tmp}/sdxl_full_rank{rank}.npz",
+                 **{f"{sfx}/{n}": (get_parameter(enc, n + ".weight").cpu().double() - w0[(sfx, n)]).numpy()
+                    for sfx, names, enc in encs for n in names})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_sdxl_full_size_matches_reference_summary(tmp_path):
+    """BASELINE config 4 at its full size on two ranks (sharing the test GPU): 1 000 concepts, TE1 (d 3072) and TE2 (d 5120:
+    40 column tiles dealt to the two ranks, the N x N system and U all-reduced) — against the REAL reference's summaries
+    (fixture real_sdxl_n1000_summary, TE2 with the reference's double apply); both ranks bit-identical."""
+    import json
+    from conftest import load_golden
+    from emcid_amd import synthetic as syn
+    z, meta = load_golden("real_sdxl_n1000_summary")
+    tmp = str(tmp_path)
+    reqs = syn.make_requests(meta["n_requests"], names="syllable")
+    syn.write_vstar_cache(tmp + "/cache/", reqs, 768, seed=meta["vstar"]["seed"], scale=meta["vstar"]["scale"])
+    syn.write_vstar_cache(tmp + "/cache/", reqs, 1280, seed=meta["vstar"]["seed_2"], scale=meta["vstar"]["scale"], suffix="_2")
+    ns = meta["stats"]["n_samples"]
+    syn.write_stats_cache(tmp + "/s1", meta["layer_names"], 3072, ns, seed=meta["stats"]["seed"], t=6144)
+    syn.write_stats_cache(tmp + "/s2", meta["layer_names_2"], 5120, ns, seed=meta["stats"]["seed_2"], t=10240)
+    json.dump(meta, open(tmp + "/meta.json", "w"))
+    mp.spawn(_sdxl_full_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+    r0, r1 = np.load(f"{tmp}/sdxl_full_rank0.npz"), np.load(f"{tmp}/sdxl_full_rank1.npz")
+    for sfx, names in (("", meta["layer_names"]), ("_2", meta["layer_names_2"])):
+        probe = z[f"probe{sfx}"]
+        for li, n in enumerate(names):
+            dw = r0[f"{sfx}/{n}"]
+            assert np.array_equal(dw, r1[f"{sfx}/{n}"]), (sfx, n)
+            scale = float(z[f"dw_maxabs{sfx}/{li}"])
+            assert np.abs(dw @ probe - z[f"dw_probe{sfx}/{li}"]).max() <= 1e-4 * scale * np.linalg.norm(probe, axis=0).max(), (sfx, li)
+            np.testing.assert_allclose(np.linalg.norm(dw), float(z[f"dw_fro{sfx}/{li}"]), rtol=1e-4)
+            np.testing.assert_allclose(np.abs(dw).max(), scale, rtol=1e-4)
+
+
 def _sdxl_worker(rank, world, port, tmp, split):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),

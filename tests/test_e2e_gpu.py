@@ -589,10 +589,13 @@ def test_headline_n1000_edit_matches_reference_summary(tmp_path):
         _summary_close(dw, z, li, "", probe)
 
 
-def test_sdxl_n300_edit_matches_reference_summary(tmp_path):
-    """BASELINE config 4 at real dimensions and N = 300 against the REAL reference's summaries (fixture real_sdxl_summary):
-    TE1 768/3072 layers 8-10 (lambda 4000), TE2 1280/5120/32L layers 26-30 (lambda 10000), incl. the TE2 double apply."""
-    z, meta = load_golden("real_sdxl_summary")
+@pytest.mark.parametrize("fixture", ["real_sdxl_summary", "real_sdxl_n1000_summary"])
+def test_sdxl_edit_matches_reference_summary(tmp_path, fixture):
+    """BASELINE config 4 at real dimensions against the REAL reference's summaries — N = 300 (fixture real_sdxl_summary) and
+    the configuration's full N = 1000 (real_sdxl_n1000_summary: at d = 5120 the solver then runs without the shadow product,
+    on stream-K / paired tiles): TE1 768/3072 layers 8-10 (lambda 4000), TE2 1280/5120/32L layers 26-30 (lambda 10000),
+    incl. the TE2 double apply."""
+    z, meta = load_golden(fixture)
     reqs = syn.make_requests(meta["n_requests"], names="syllable")
     hp_d = meta["hparams"]
     n1, n2 = meta["layer_names"], meta["layer_names_2"]

@@ -731,3 +731,144 @@ def test_templated_prompt_path_randomised(monkeypatch):
         for a, b in zip(out["1"], out["0"]):
             _chunks_equal(a, b)
     assert served >= 15
+
+
+# ---- round 3: native v* reader, lambda-free factor key, leased workspaces, opt-in thread management --------------------
+
+def _vstar_setup(tmp_path, n=70, width=48):
+    from emcid_amd import emcid_main as em
+    reqs = syn.make_requests(n, names="syllable")
+    cache = str(tmp_path / "cache") + "/"
+    vs = syn.write_vstar_cache(cache, reqs, width, seed=1, scale=0.5)
+    hp = EMCIDHyperParams(**syn.sd_hparams_dict(layers=(1, 2), mom2_update_weight=50, edit_weight=0.5))
+    return em, reqs, cache, vs, hp
+
+
+def test_native_vstar_reader_equals_numpy_reader(tmp_path, monkeypatch):
+    """emcid_read_npz_rows_f32 (csrc/host_io.cpp) against np.load on the files np.savez writes (reference :951-968):
+    identical rows; files it does not serve (compressed member, other first member) are flagged and read by numpy, a
+    float64 / (1, width) file is converted like astype; a missing file goes to stage1; any thread count gives the same rows."""
+    em, reqs, cache, vs, hp = _vstar_setup(tmp_path)
+    name = lambda i: em.vstar_cache_name(cache, reqs[i], hp, i)
+    np.savez_compressed(name(3), v_star=vs[3])
+    np.savez(name(4), v_star=vs[4].astype(np.float64))
+    np.savez(name(5), v_star=vs[5][None])
+    np.savez(name(6), other=np.zeros(3), v_star=vs[6])
+    Path(name(7)).unlink()
+    monkeypatch.setenv("EMCID_NATIVE_VSTAR", "0")
+    ref = em.load_v_stars(reqs, hp, cache, stage1=lambda r, sfx: torch.full((48,), 7.0))
+    Path(name(7)).unlink()          # the numpy pass wrote Stage 1's result to the cache; make it a miss again
+    monkeypatch.setenv("EMCID_NATIVE_VSTAR", "1")
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("EMCID_READ_THREADS", threads)
+        rows, status = em._native_vstar_rows([name(i) for i in range(len(reqs))], 48, False)
+        assert list(status[:9]) == [0, 0, 0, 2, 0, 0, 2, 1, 0] and not status[9:].any()
+        keep = status == 0
+        assert np.array_equal(rows.numpy()[keep], ref.numpy()[keep])
+    got = em.load_v_stars(reqs, hp, cache, stage1=lambda r, sfx: torch.full((48,), 7.0), width=48)
+    assert torch.equal(got, ref) and torch.equal(got[7], torch.full((48,), 7.0))
+    assert Path(name(7)).exists()                                   # Stage 1's v* was written to the cache (:951-968)
+    # a wrong width is "not such a file": numpy reads it and the engine's own shape check reports it
+    rows, status = em._native_vstar_rows([name(0)], 32, False)
+    assert list(status) == [2]
+    # without a width (callers that do not know the hidden size) the per-file path serves everything
+    assert torch.equal(em.load_v_stars(reqs, hp, cache), ref)
+
+
+def test_vstar_memo_is_bounded(tmp_path, monkeypatch):
+    em, reqs, cache, vs, hp = _vstar_setup(tmp_path, n=12)
+    monkeypatch.setattr(em, "_VSTAR_CACHE_MAX", 5)
+    em._VSTAR_CACHE.clear()
+    monkeypatch.setenv("EMCID_NATIVE_VSTAR", "0")
+    em.load_v_stars(reqs, hp, cache)
+    assert len(em._VSTAR_CACHE) == 5
+
+
+def test_factor_cache_key_ignores_lambda_but_not_edit_weight():
+    from emcid_amd.edit_engine import factor_cache_key
+    c = [torch.zeros(4, 4), torch.ones(4, 4)]
+    assert factor_cache_key(c, 4000.0, 0.5) == factor_cache_key(c, 123.0, 0.5)
+    assert factor_cache_key(c, 4000.0, 0.5) != factor_cache_key(c, 4000.0, 0.6)
+    assert factor_cache_key(c, 4000.0, 0.5) != factor_cache_key(c[::-1], 4000.0, 0.5)
+    c[0].add_(1.0)                                  # statistics changed in place: version counter moves
+    k2 = factor_cache_key(c, 4000.0, 0.5)
+    c[0].add_(1.0)
+    assert k2 != factor_cache_key(c, 4000.0, 0.5)
+
+
+def test_lam_ratio_rules():
+    f = hip.CovFactors.__new__(hip.CovFactors)
+    f.lam = 4000.0
+    assert f.lam_ratio(None) == 1.0 and f.lam_ratio(4000) == 1.0 and f.lam_ratio(1000.0) == 0.25
+    with pytest.raises(hip.EmcidHipError):
+        f.lam_ratio(0.0)
+    f.lam = None
+    assert f.lam_ratio(5.0) == 1.0
+
+
+def test_workspaces_are_leased_per_plan(monkeypatch):
+    """Two plans of one shape in flight never share a workspace (buffers + info word); a plan gets its own back; a lease ends
+    at check_info or with the plan."""
+    import gc
+    from types import SimpleNamespace
+    from emcid_amd import edit_engine as ee
+
+    class FakeWs:
+        made = 0
+
+        def __init__(self, N, d, h, dev):
+            FakeWs.made += 1
+            self.key = (N, d, h)
+
+    monkeypatch.setattr(hip, "DualWorkspace", FakeWs)
+    ee.clear_engine_caches()
+
+    class Plan(SimpleNamespace):
+        pass
+
+    a, b = Plan(ws=None, dual_ws=None), Plan(ws=None, dual_ws=None)
+    a.dual_ws = ee._workspace("dual", 10, 128, 32, "cuda:0", a)
+    b.dual_ws = ee._workspace("dual", 10, 128, 32, "cuda:0", b)
+    assert a.dual_ws is not b.dual_ws and FakeWs.made == 2
+    assert ee._workspace("dual", 10, 128, 32, "cuda:0", a) is a.dual_ws          # a second run of the same plan
+    ee._release_workspaces(a)                                                    # what check_info does
+    c = Plan(ws=None, dual_ws=None)
+    c.dual_ws = ee._workspace("dual", 10, 128, 32, "cuda:0", c)
+    assert c.dual_ws is a.dual_ws and FakeWs.made == 2
+    held = b.dual_ws
+    del b
+    gc.collect()                                                                 # a plan that was never checked
+    d_ = Plan(ws=None, dual_ws=None)
+    assert ee._workspace("dual", 10, 128, 32, "cuda:0", d_) is held
+    e = Plan(ws=None, dual_ws=None)
+    extra = ee._workspace("dual", 10, 128, 32, "cuda:0", e)                      # both pooled ones leased: a third, unpooled
+    assert extra is not held and extra is not c.dual_ws and FakeWs.made == 3
+    ee.clear_engine_caches()
+
+
+def test_import_has_no_thread_side_effects():
+    """`import emcid_amd` leaves the host application's thread pools and environment alone; manage_threads() is opt-in."""
+    import subprocess
+    import sys
+    code = ("import os, torch\n"
+            "os.environ.pop('RAYON_NUM_THREADS', None); os.environ.pop('EMCID_MANAGE_THREADS', None)\n"
+            "torch.set_num_threads(3); before = torch.get_num_threads()\n"
+            "import emcid_amd, emcid_amd.edit_engine, emcid_amd.emcid_main\n"
+            "assert torch.get_num_threads() == before and 'RAYON_NUM_THREADS' not in os.environ\n"
+            "assert emcid_amd.manage_threads() is False\n"
+            "assert emcid_amd.manage_threads(force=True) is True and emcid_amd.manage_threads(force=True) is False\n"
+            "assert torch.get_num_threads() <= before\n"
+            "print('OK')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(REPO), timeout=300)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+def test_host_library_exports_every_declared_symbol():
+    from emcid_amd import host_text
+    header = (REPO / "include" / "emcid_host.h").read_text()
+    declared = set(re.findall(r"\b(emcid_[a-z0-9_]+)\s*\(", header))
+    lib = ctypes.CDLL(str(host_text.lib_path()))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert host_text.load().emcid_host_abi_version() == host_text.ABI_VERSION
+    assert lib.emcid_read_npz_rows_f32(None, None, 1, b"v_star", 4, None, 4, None, 1) == -1

@@ -89,7 +89,8 @@ def _edit_inputs(N, d, h, seed):
 @pytest.mark.parametrize("N,d,h,lam,ew,left", [(8, 128, 32, 50.0, 0.6, 3), (5, 192, 48, 90.0, 0.5, 1),
                                               (50, 1400, 96, 300.0, 0.5, 2),     # dp = 1408: short last 512-block
                                               (100, 3072, 768, 4000.0, 0.5, 4), (1000, 3072, 768, 4000.0, 0.5, 2),
-                                              (1, 3072, 768, 4000.0, 0.5, 1), (130, 5120, 1280, 10000.0, 0.5, 5)])
+                                              (1, 3072, 768, 4000.0, 0.5, 1), (130, 5120, 1280, 10000.0, 0.5, 5),
+                                              (1000, 5120, 1280, 10000.0, 0.5, 5)])      # BASELINE config 4 (SDXL TE2) at its full size
 def test_edit_layer_vs_oracle(N, d, h, lam, ew, left):
     """The whole per-layer closed form against the oracle's fp64 LU restatement on identical inputs.
     Bar (BASELINE.json): dW max-abs error < 1e-4 and <= 1e-4 relative; observed ~1e-12."""
@@ -264,7 +265,9 @@ def test_tree_attention_vs_dense_reference(U, H, D, max_depth):
 @pytest.mark.parametrize("N,d,h,lam,ew,left", [(8, 128, 32, 50.0, 0.6, 3), (5, 192, 48, 90.0, 0.5, 1),
                                               (50, 1400, 96, 300.0, 0.5, 2),     # dp = 1408: short last 512-block
                                               (100, 3072, 768, 4000.0, 0.5, 4), (1000, 3072, 768, 4000.0, 0.5, 2),
-                                              (300, 5120, 1280, 10000.0, 0.5, 5)])
+                                              (300, 5120, 1280, 10000.0, 0.5, 5),
+                                              (1000, 5120, 1280, 10000.0, 0.5, 5)])      # config 4 full size: Np = 1024 at dp = 5120 (no shadow
+                                                                                         # product: two rounds of stream-K / paired tiles)
 def test_dual_solver_vs_oracle(N, d, h, lam, ew, left):
     """The Woodbury form (batched factor of lam*C', N x N system per layer) against the oracle's fp64 LU."""
     K, Zc, zs, Cov, W0 = _edit_inputs(N, d, h, seed=N + d)
@@ -311,6 +314,73 @@ def test_dual_solver_vs_oracle(N, d, h, lam, ew, left):
                                 want_dw=False)
             parts.append(ws2.Pt[lo:hi].clone())
         torch.testing.assert_close(torch.cat(parts), out["ws"].Pt[:N], rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("N,d,h,lam0,lam,left", [(8, 128, 32, 50.0, 7.5, 3), (100, 3072, 768, 4000.0, 20000.0, 4),
+                                                 (1000, 3072, 768, 4000.0, 1000.0, 2), (300, 5120, 1280, 10000.0, 6000.0, 5)])
+def test_dual_solver_reuses_factor_for_another_lambda(N, d, h, lam0, lam, left):
+    """chol(lam C') = sqrt(lam) chol(C'): a workspace factored at lam0 serves an edit at lam through `lam_ratio` (the stage-1
+    gain on Kt64 / Rt; include/emcid_hip.h).  Every dual form against the oracle's fp64 LU AT lam, and against a workspace
+    factored at lam itself; the returned adj_k / resid are in the caller's scale."""
+    ew = 0.5
+    K, Zc, zs, Cov, W0 = _edit_inputs(N, d, h, seed=N + d + 1)
+    adj_k, resid, upd = orc.closed_form_layer(K, Zc, zs, Cov, lam, ew, left)
+    scale = upd.abs().max().item()
+    Kd, Zd, zd, W0d = K.to(DEV), Zc.to(DEV), zs.t().contiguous().to(DEV), W0.to(DEV)
+    fac0 = hip.factor_cov([Cov.to(DEV)], lam0, ew)
+    assert fac0.lam == lam0 and fac0.lam_ratio(lam) == lam / lam0 and fac0.lam_ratio(None) == 1.0
+    full = hip.edit_layer_dual(Kd, Zd, zd, fac0, 0, ew, left, W0=W0d, W=torch.empty(h, d, device=DEV), want_factors=True, lam=lam)
+    assert int(fac0.info.item()) == 0 and int(full["ws"].info.item()) == 0
+    torch.testing.assert_close(full["Rt"].cpu(), resid.t().contiguous(), rtol=1e-14, atol=0)
+    assert (full["adj_k"].cpu() - adj_k).abs().max().item() <= 1e-8 * adj_k.abs().max().item()
+    assert (full["dW"].cpu().double() - upd).abs().max().item() <= 1e-6 * scale + 1e-12
+    own = hip.factor_cov([Cov.to(DEV)], lam, ew)
+    for use_inv in (True, False):
+        W = torch.empty(h, d, device=DEV)
+        got = hip.edit_layer_dual_apply(Kd, Zd, zd, fac0, 0, ew, left, W0d, W, use_inverse=use_inv, lam=lam)
+        assert int(got["ws"].info.item()) == 0
+        err = (got["dW"].cpu().double() - upd).abs().max().item()
+        assert err <= 1e-6 * scale + 1e-12 and err < 1e-4, (use_inv, err, scale)
+        assert (W.cpu() - (W0 + upd.float())).abs().max().item() <= 1e-6 * max(scale, 1.0)
+        ref = hip.edit_layer_dual_apply(Kd, Zd, zd, own, 0, ew, left, W0d, torch.empty(h, d, device=DEV), use_inverse=use_inv)
+        assert (got["dW"] - ref["dW"]).abs().max().item() <= 2e-7 * scale      # same numbers up to the fp32 rounding of dW
+    # the column-sharded form (one rank owning every tile)
+    W = torch.empty(h, d, device=DEV)
+    cols = hip.edit_layer_dual_cols(Kd, Zd, zd, fac0, 0, ew, left, W0d, W, list(range(fac0.dp // 128)), lambda t: t, lam=lam)
+    assert (cols["dW"].cpu().double() - upd).abs().max().item() <= 1e-6 * scale + 1e-12
+    # lam_ratio = 1 is bit-identical to not passing lam at all
+    a = hip.edit_layer_dual_apply(Kd, Zd, zd, fac0, 0, ew, left, W0d, torch.empty(h, d, device=DEV))
+    b = hip.edit_layer_dual_apply(Kd, Zd, zd, fac0, 0, ew, left, W0d, torch.empty(h, d, device=DEV), lam=lam0)
+    assert torch.equal(a["dW"], b["dW"])
+
+
+@pytest.mark.parametrize("N,d,h,lam,world", [(1000, 5120, 1280, 10000.0, 2), (300, 5120, 1280, 10000.0, 7), (1000, 3072, 768, 4000.0, 8)])
+def test_column_sharded_solve_ranks_emulated(N, d, h, lam, world):
+    """The column-sharded solve (multi-GPU form, include/emcid_hip.h) with its ranks emulated on one GPU: every rank's
+    stage 1 on its own tiles and workspace, the partial S summed as the all-reduce would, every rank's stage 2, the partial
+    U summed — against the oracle.  TE2 width (40 tiles over 2 and 7 ranks) and the headline shape over 8."""
+    ew, left = 0.5, 3
+    K, Zc, zs, Cov, W0 = _edit_inputs(N, d, h, seed=N + d + world)
+    _, _, upd = orc.closed_form_layer(K, Zc, zs, Cov, lam, ew, left)
+    Kd, Zd, zd, W0d = K.to(DEV), Zc.to(DEV), zs.t().contiguous().to(DEV), W0.to(DEV)
+    fac = hip.factor_cov([Cov.to(DEV)], lam, ew)
+    n_tiles = fac.dp // 128
+    tiles = [hip.column_tiles(r, world, n_tiles) for r in range(world)]
+    assert sorted(t for ts in tiles for t in ts) == list(range(n_tiles))
+    backends = [hip._HipColsBackend(Kd, Zd, zd, fac, 0, ew, left, hip.DualWorkspace(N, d, h, DEV)) for _ in range(world)]
+    S = sum(b.stage1(ts).clone() for b, ts in zip(backends, tiles))
+    U = None
+    for b, ts in zip(backends, tiles):
+        b.a[-1].S.copy_(S)
+        u = b.stage2(ts).clone()
+        U = u if U is None else U + u
+        assert int(b.a[-1].info.item()) == 0
+    W = torch.empty(h, d, device=DEV)
+    dW = backends[0].apply(U, W0d, W, True)
+    scale = upd.abs().max().item()
+    err = (dW.cpu().double() - upd).abs().max().item()
+    assert err <= 1e-6 * scale + 1e-12 and err < 1e-4, (err, scale)
+    assert (W.cpu() - (W0 + upd.float())).abs().max().item() <= 1e-6 * max(scale, 1.0)
 
 
 @pytest.mark.parametrize("rows,cols", [(5, 32), (300, 768), (6400, 768), (77, 1280), (3, 8192)])
@@ -490,7 +560,7 @@ from oracle import emcid_oracle as orc
 from test_kernels_gpu import _edit_inputs
 worst = 0.0
 for N, d, h, lam in ((200, 3072, 768, 4000.0), (300, 5120, 1280, 10000.0), (260, 1400, 96, 300.0), (640, 1152, 64, 500.0),
-                     (1000, 3072, 768, 4000.0)):
+                     (1000, 3072, 768, 4000.0), (1000, 5120, 1280, 10000.0)):
     K, Zc, zs, Cov, W0 = _edit_inputs(N, d, h, seed=N + d)
     _, _, upd = orc.closed_form_layer(K, Zc, zs, Cov, lam, 0.5, 2)
     fac = hip.factor_cov([Cov.cuda()], lam, 0.5)
