@@ -28,7 +28,7 @@ four lam*C' and their inverse factors, GEMM selection) is timed separately as `f
 is a pure function of (statistics, lambda, edit_weight) — `config.caches` says what was warm.
 
 Secondary fields: `device_ms_per_step` (run_encoder_edit on an HBM-resident plan: what round 1 reported as the step),
-`host_prepare_ms` (prepare_text_encoder_edit alone, median), `untuned_ms_per_step` (library-default GEMM selection).
+`host_prepare_ms` (prepare_text_encoder_edit alone, median), `forward_gemm` (the call with the other GEMM path: A/B).
 
 `roofline`: the same K device steps once more with every kernel class of the solve bracketed by HIP events on the
 launch stream (emcid_profile_*); `kernel_classes` lists every class with its ALGORITHMIC flops (SURVEY.md §8d counts),
@@ -59,6 +59,12 @@ KIND = "sd-v1.4"
 
 
 MAX_REQUEST_SETS = 32
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """Progress line on stderr (the JSON line on stdout stays alone): a long silent run looks hung to the GPU box's watchdog."""
+    print(f"[bench {time.perf_counter() - _T0:7.1f} s] {msg}", file=sys.stderr, flush=True)
 
 
 def request_set(n_concepts, workdir, index=0, write=True):
@@ -244,9 +250,9 @@ def main():
         assert dist.get_backend() == backend and dist.get_world_size() == world
     shard = ConceptShard(rank, world, None)
 
-    # the benchmark models a long-running editing service: the projection GEMM solutions are tuned once per shape (inside
-    # the FIRST call, reported in first_call_ms / gemm_tuning_ms); `untuned_ms_per_step` is the library default
-    os.environ.setdefault("EMCID_TUNE_GEMM", "1")
+    # the forward's projections run on the library's own GEMM (no selection step); under EMCID_OWN_GEMM=0 they are torch's
+    # F.linear with library-default selection (EMCID_TUNE_GEMM=1 would time hipBLASLt's solutions in the first call)
+    os.environ.setdefault("EMCID_TUNE_GEMM", "auto")
     os.environ.setdefault("EMCID_MANAGE_THREADS", "1")      # an editing process of its own: thread pools sized to the CPU quota
     os.environ.setdefault("EMCID_FACTOR_CACHE", "8")        # the edit_weight sweep below must not evict the workload's own factors
     workdir = Path(tempfile.gettempdir()) / f"emcid_bench_{os.getuid()}"
@@ -303,7 +309,9 @@ def main():
         return out
 
     # ---- the first call of the process: everything cold ------------------------------------------------------------------
+    log(f"inputs ready ({len(sets)} request sets); first call")
     first_s, _ = timed_calls(1)
+    log(f"first call {first_s * 1e3:.0f} ms; warm-up + {args.steps} timed steps")
     # ---- warm-up and the K timed steps: every call a request set this process has never seen ------------------------------
     for i in range(args.warmup):
         call(1 + i)
@@ -315,6 +323,7 @@ def main():
     value = args.concepts * args.steps / elapsed
 
     # ---- the same 1 000 requests again and again (what rounds 1-2 reported as the step) ------------------------------------
+    log(f"{elapsed / args.steps * 1e3:.2f} ms per step; replay / new-weight variants")
     call(0)
     replay_s, replay_per = timed_calls(max(5, args.steps // 2))
     # ---- same requests, weights never used before: a new mom2_update_weight reuses the cached factor of C' (chol(lam C') =
@@ -326,14 +335,17 @@ def main():
     new_ew_ms = each_synced(len(ew_list), lambda i: call(0, copy.deepcopy(hp), edit_weight=ew_list[i]))
     call(0)        # (lam, e_w) of the workload again (its factors are still cached)
 
-    # ---- library-default GEMM selection (no TunableOp table): a few calls -------------------------------------------------
+    log("GEMM A/B, host/device split, roofline pass")
+    # ---- the forward's projections on torch's F.linear (hipBLASLt, library-default selection, element-wise passes unfused)
+    # instead of the library's own fp32-MFMA GEMM with fused epilogues (csrc/gemm_f32.hip): a few calls -----------------------
     from emcid_amd import clip_forward
-    tuned_state = dict(clip_forward._TUNED)
-    clip_forward._TUNED["done"] = False
+    own_gemm = bool(clip_forward.OWN_GEMM)
+    clip_forward.OWN_GEMM = not own_gemm
     call()
-    untuned_s, _ = timed_calls(max(3, args.steps // 2))
-    untuned_ms = untuned_s / max(3, args.steps // 2) * 1e3
-    clip_forward._TUNED.update(tuned_state)
+    other_s, _ = timed_calls(max(3, args.steps // 2))
+    other_gemm_ms = other_s / max(3, args.steps // 2) * 1e3
+    clip_forward.OWN_GEMM = own_gemm
+    call()
 
     # ---- host / device split: prepare alone (median), then run_encoder_edit on the HBM-resident plan ---------------------
     prep_ms = []
@@ -432,7 +444,7 @@ def main():
                               "cov_factor_cache": ("warm (keyed by statistics + edit_weight; any mom2_update_weight)"
                                                    if plan.factors_from_cache else "off"),
                               "vstar_files": "read from the files in every call (native batch reader, no in-process copy)",
-                              "gemm_selection": "TunableOp table built in the first call"},
+                              "gemm_selection": "none needed (own GEMM)" if own_gemm else "TunableOp table built in the first call"},
                    "backend": (dist.get_backend() if world > 1 else None),
                    "parallelism": f"concept-shard x{world}"},
         "ms_per_call_median": fresh_ms,
@@ -448,7 +460,12 @@ def main():
                            "note": "same requests as the replay; a new lambda reuses the cached factor of C' (lam_ratio), a new "
                                    "edit_weight refactors the four 3072 x 3072 matrices on the side stream under the forward"},
         "first_call_ms": first_s * 1e3,
-        "untuned_ms_per_step": untuned_ms,
+        "forward_gemm": {"this_run": "emcid_linear_f32 (own fp32-MFMA GEMM, fused bias / activation / residual)" if own_gemm
+                         else "torch F.linear (hipBLASLt)",
+                         "other_path_ms_per_step": other_gemm_ms,
+                         "other_path": "torch F.linear (hipBLASLt, library-default selection) + separate element-wise passes"
+                         if own_gemm else "emcid_linear_f32",
+                         "note": "replay calls (same 1 000 requests); compare with replay_ms_per_call"},
         "host_prepare_ms": statistics.median(prep_ms),
         "device_ms_per_step": device_ms,
         "gemm_tuning_ms": clip_forward.TUNING_SECONDS_TOTAL * 1e3,     # inside first_call_ms
@@ -458,15 +475,19 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_variants:
+        log("secondary records: n100, sdxl, cold_process")
         for name, fn in (("n100", lambda: n100_record(workdir, device)), ("sdxl", lambda: sdxl_record(workdir, device)),
                          ("cold_process", lambda: cold_process_record(workdir, device))):
             try:
                 out[name] = fn()
             except Exception as e:     # the headline line must survive a problem in a secondary record
                 out[name] = {"error": repr(e)}
+            log(f"{name} done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("cpu_baseline (oracle on the host cores)")
         out.update(cpu_baseline_and_error(workdir, device, full_n=0 if args.no_cpu_full else args.concepts))
     if rank == 0 and world == 1 and not args.no_stage0:
+        log("stage0")
         try:
             out["stage0"] = stage0_record(workdir, device, args.stage0_captions)
         except Exception as e:     # the headline line must survive a Stage-0 problem
@@ -552,6 +573,7 @@ def cpu_baseline_and_error(workdir, device, n_sample=100, budget_s=40.0, full_n=
 
     runs, ctx = oracle_runs(n_sample, 3, budget_s)
     cpu_s, host_s = runs[len(runs) // 2]
+    log(f"cpu_baseline: {n_sample}-concept sample {cpu_s:.1f} s per run")
     err_abs, err_rel = dw_error(ctx)
     rec = {"value": n_sample / cpu_s, "unit": "concept-edits/s", "cores": cores, "kind": "port",
            "cores_note": f"torch intra-op threads = the CPUs this process may use (cgroup quota / affinity: "
@@ -565,6 +587,7 @@ def cpu_baseline_and_error(workdir, device, n_sample=100, budget_s=40.0, full_n=
                      f"encoder forwards per edited layer over all prompts)"}
     out = {"cpu_baseline": rec, "dw_max_abs_err": err_abs, "dw_max_rel_err": err_rel}
     if full_n and full_n != n_sample:
+        log(f"cpu_baseline: full {full_n}-concept run (about {cpu_s * full_n / n_sample:.0f} s)")
         runs_f, ctx_f = oracle_runs(full_n, 1, 0.0)
         fa, fr = dw_error(ctx_f)
         rec["full"] = {"value": full_n / runs_f[0][0], "unit": "concept-edits/s", "seconds": runs_f[0][0], "host_s": runs_f[0][1],

@@ -17,6 +17,7 @@ Same arithmetic as the HF module tree (its own weights, LayerNorm eps, activatio
 match the hooked HF forward to fp32 rounding (tests/test_e2e_gpu.py).  Encoders that do not look like HF's
 CLIPTextModel raise ``UnsupportedEncoder`` and the engine falls back to the hooked HF forward.
 """
+import os
 import weakref
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
@@ -31,6 +32,33 @@ from .nethook import get_module
 
 class UnsupportedEncoder(Exception):
     pass
+
+
+OWN_GEMM = os.environ.get("EMCID_OWN_GEMM", "1") != "0"     # 0: torch's F.linear (hipBLASLt) + separate element-wise passes
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, act=None, act_code: Optional[int] = None,
+           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x @ w.T + b) + residual for the row-wise projections of the forward.  On the library's own fp32-MFMA GEMM
+    (csrc/gemm_f32.hip) with bias / activation / residual add in its epilogue whenever the operands allow it (fp32, HBM,
+    K % 16 == 0); otherwise — and under EMCID_OWN_GEMM=0 — torch's F.linear and separate passes."""
+    if OWN_GEMM and hip.linear_supported(x, w) and (b is None or b.is_contiguous()) and \
+            (residual is None or (residual.stride(1) == 1 and residual.dtype == torch.float32)):
+        if act is None or act_code is not None:
+            return hip.linear(x, w, b, act=act_code if act is not None else hip.ACT_NONE, residual=residual)
+        y = act(hip.linear(x, w, b))
+        return y if residual is None else residual + y
+    y = F.linear(x, w, b)
+    if act is not None:
+        y = act(y)
+    return y if residual is None else residual + y
+
+
+def norm_of(x: torch.Tensor, ln) -> torch.Tensor:
+    """LayerNorm(x) on the library's kernel when it fits, else the module itself."""
+    if _fusable(ln) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1:
+        return hip.add_layernorm(x, None, ln)[1]
+    return ln(x)
 
 
 @dataclass
@@ -48,6 +76,7 @@ class ClipLayer:
     scale: float
     qkv_w: Optional[torch.Tensor] = None   # [3h, h] rows of q, k, v stacked: one projection GEMM instead of three
     qkv_b: Optional[torch.Tensor] = None
+    act_code: Optional[int] = None         # hip.ACT_* when the activation can ride in the fc1 GEMM's epilogue
 
     def fuse_qkv(self):
         """Snapshot q/k/v into one stacked weight (they are never edited by this path; call again if they change)."""
@@ -81,10 +110,13 @@ def discover(text_encoder, layer_module_tmp: str) -> ClipTextGraph:
             if hd > 64 or hd % 4:
                 raise UnsupportedEncoder(f"head_dim {hd} not supported by the tree-attention kernel")
             act = mlp.activation_fn
+            act_code = None
             if type(act).__name__ == "QuickGELUActivation":
-                act = hip.quick_gelu
+                act, act_code = hip.quick_gelu, hip.ACT_QUICK_GELU
+            elif type(act).__name__ == "GELUActivation" and getattr(act, "act", None) is F.gelu:
+                act_code = hip.ACT_GELU_ERF            # transformers' "gelu": torch's exact (erf) form
             layers.append(ClipLayer(lm.layer_norm1, at.q_proj, at.k_proj, at.v_proj, at.out_proj, lm.layer_norm2,
-                                    mlp.fc1, act, mlp.fc2, heads, float(getattr(at, "scale", hd ** -0.5))))
+                                    mlp.fc1, act, mlp.fc2, heads, float(getattr(at, "scale", hd ** -0.5)), act_code=act_code))
         for l in layers:
             for m in (l.q, l.k, l.v, l.out, l.fc1, l.fc2):
                 if not isinstance(m, torch.nn.Linear):
@@ -242,6 +274,9 @@ class tuned_gemms:
     of the forward, and put the process-wide switches back afterwards.  No tuning happens inside the context."""
 
     def __enter__(self):
+        self.prev = None
+        if OWN_GEMM:                 # nothing of torch's GEMM selection is touched on the default path
+            return self
         t = torch.cuda.tunable
         self.prev = (t.is_enabled(), t.tuning_is_enabled())
         if _TUNED["done"]:
@@ -250,9 +285,10 @@ class tuned_gemms:
         return self
 
     def __exit__(self, *exc):
-        t = torch.cuda.tunable
-        t.tuning_enable(self.prev[1])
-        t.enable(self.prev[0])
+        if self.prev is not None:
+            t = torch.cuda.tunable
+            t.tuning_enable(self.prev[1])
+            t.enable(self.prev[0])
         return False
 
 
@@ -290,9 +326,8 @@ def tune_projections(graph: ClipTextGraph, trie: TokenTrie, upto: int, mode: str
     user's cache directory) — what a long-running editing service or the benchmark wants; "auto" (the library default) only LOADS
     that file if an earlier process left one, so a one-off call never pays for tuning; "0" leaves torch alone.
     Returns the seconds spent."""
-    import os
     import time
-    if mode == "0":
+    if mode == "0" or OWN_GEMM:      # the library's own GEMM needs no selection; torch's switches are left alone
         return 0.0
     layer = graph.layers[upto]
     dev = layer.fc2.weight.device
@@ -437,21 +472,24 @@ def layer_attention_block(layer: ClipLayer, hs: torch.Tensor, trie: TokenTrie, r
     x = layer.ln1(hs) if x_ln1 is None else x_ln1
     if rows is None and layer.qkv_w is not None:
         hdim = layer.q.out_features
-        qkv = F.linear(x, layer.qkv_w, layer.qkv_b)          # (U, 3h): q | k | v as strided row views
+        qkv = linear(x, layer.qkv_w, layer.qkv_b)            # (U, 3h): q | k | v as strided row views
         ctx = hip.tree_attention(qkv[:, :hdim], qkv[:, hdim:2 * hdim], qkv[:, 2 * hdim:], trie.anc, trie.depth, layer.heads,
                                  layer.scale, None)
         res = hs
     else:
-        k = layer.k(x)
-        v = layer.v(x)
+        k = linear(x, layer.k.weight, layer.k.bias)
+        v = linear(x, layer.v.weight, layer.v.bias)
         if rows is None:
-            q = layer.q(x)
+            q = linear(x, layer.q.weight, layer.q.bias)
             res = hs
         else:
             idx = rows.long()
-            q = layer.q(x.index_select(0, idx))
+            q = linear(x.index_select(0, idx), layer.q.weight, layer.q.bias)
             res = hs.index_select(0, idx)
         ctx = hip.tree_attention(q, k, v, trie.anc, trie.depth, layer.heads, layer.scale, rows)
+    if OWN_GEMM:
+        mid = linear(ctx, layer.out.weight, layer.out.bias, residual=res)     # residual add in the GEMM's epilogue
+        return mid, norm_of(mid, layer.ln2)
     o = layer.out(ctx)
     if _fusable(layer.ln2):
         return hip.add_layernorm(res, o, layer.ln2)          # residual add + LN2 in one pass
@@ -461,7 +499,7 @@ def layer_attention_block(layer: ClipLayer, hs: torch.Tensor, trie: TokenTrie, r
 
 def mlp_hidden(layer: ClipLayer, ln2_mid: torch.Tensor) -> torch.Tensor:
     """fc2 INPUT (the "key" space): act(fc1(LN2(hs_mid)))."""
-    return layer.act(layer.fc1(ln2_mid))
+    return linear(ln2_mid, layer.fc1.weight, layer.fc1.bias, act=layer.act, act_code=layer.act_code)
 
 
 def run_layers(graph: ClipTextGraph, trie: TokenTrie, upto: int, on_fc2=None, last_rows_only: bool = True,
@@ -501,15 +539,18 @@ def run_prefix(graph: ClipTextGraph, trie: TokenTrie, stop: int):
 def _layer_full(graph, i, trie, hs, x_ln1, n_layers_needed):
     layer = graph.layers[i]
     mid, ln2_mid = layer_attention_block(layer, hs, trie, None, x_ln1)
-    out = layer.fc2(mlp_hidden(layer, ln2_mid))
     nxt = graph.layers[i + 1].ln1 if i + 1 < len(graph.layers) and i + 1 <= n_layers_needed else None
+    if OWN_GEMM:
+        hs = linear(mlp_hidden(layer, ln2_mid), layer.fc2.weight, layer.fc2.bias, residual=mid)     # fc2 + residual add
+        return hs, (norm_of(hs, nxt) if nxt is not None and _fusable(nxt) else None)
+    out = layer.fc2(mlp_hidden(layer, ln2_mid))
     if nxt is not None and _fusable(nxt):
         return hip.add_layernorm(mid, out, nxt)          # residual add + the next layer's LN1 in one pass
     return mid + out, None
 
 
 def run_layers_multi(graph: ClipTextGraph, tries: Sequence[TokenTrie], states, start: int, upto: int, on_fc2=None,
-                     last_rows_only: bool = True, fc2_by_callback=()):
+                     last_rows_only: bool = True, fc2_by_callback=(), callback_adds_residual: bool = False):
     """Layers start..upto (inclusive) for several tries at once, layer by layer: the prompt list of an edit may arrive in
     slices (compute_z.iter_prompt_chunks), each with its own trie; rows of different slices never attend to each other,
     but an edited layer's solve needs the keys of all of them before any slice can go on.  ``states[c]``: (residual
@@ -531,14 +572,26 @@ def run_layers_multi(graph: ClipTextGraph, tries: Sequence[TokenTrie], states, s
                 xs.append(mlp_hidden(layer, ln2_mid))
                 mids.append(mid)
             # layers in ``fc2_by_callback``: the callback produces fc2's output itself (out is passed as None), so an
-            # edited layer's projection is computed once, with the new weight, instead of twice
-            outs = [None if i in by_cb else layer.fc2(x) for x in xs]
+            # edited layer's projection is computed once, with the new weight, instead of twice.  With ``callback_adds_residual``
+            # the callback gets the residual streams too and returns fc2(x) + mid (the add in its GEMM's epilogue).
+            nxt = graph.layers[i + 1].ln1 if i < upto else None
+            summed = False
+            if i in by_cb or not OWN_GEMM:
+                outs = [None if i in by_cb else layer.fc2(x) for x in xs]
+            else:
+                outs = [linear(x, layer.fc2.weight, layer.fc2.bias, residual=mid) for x, mid in zip(xs, mids)]
+                summed = True
             if on_fc2 is not None:
-                outs = on_fc2(i, xs, outs)
+                if callback_adds_residual and not summed:
+                    outs = on_fc2(i, xs, outs, mids)
+                    summed = outs is not None
+                else:
+                    outs = on_fc2(i, xs, outs)
                 if outs is None:
                     return None
-            nxt = graph.layers[i + 1].ln1 if i < upto else None
-            if nxt is not None and _fusable(nxt):
+            if summed:
+                states = [(hs, norm_of(hs, nxt) if nxt is not None and _fusable(nxt) else None) for hs in outs]
+            elif nxt is not None and _fusable(nxt):
                 states = [hip.add_layernorm(mid, out, nxt) for mid, out in zip(mids, outs)]
             else:
                 states = [(mid + out, None) for mid, out in zip(mids, outs)]

@@ -319,14 +319,14 @@ __global__ __launch_bounds__(256) void add_layernorm_f32_kernel(const float* __r
     const int64_t row = blockIdx.x;
     const int nv = cols / 4;
     const float4* pa = reinterpret_cast<const float4*>(a + (ia ? ia[row] : row) * lda);
-    const float4* pb = reinterpret_cast<const float4*>(b + (ib ? (int64_t)ib[row] : row) * ldb);
+    const float4* pb = b ? reinterpret_cast<const float4*>(b + (ib ? (int64_t)ib[row] : row) * ldb) : nullptr;   // null: z = LN(a)
     float4 v[LN_MAX_V4];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i) {
         const int c = threadIdx.x + i * 256;
         if (c < nv) {
-            const float4 x = pa[c], w = pb[c];
+            const float4 x = pa[c], w = pb ? pb[c] : make_float4(0.f, 0.f, 0.f, 0.f);
             v[i] = make_float4(x.x + w.x, x.y + w.y, x.z + w.z, x.w + w.w);
             sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void add_layernorm_f32_kernel(const float* __r
         const int c = threadIdx.x + i * 256;
         if (c < nv) {
             const float4 g = pg[c], e = pe[c];
-            py[c] = v[i];
+            if (y) py[c] = v[i];
             pz[c] = make_float4((v[i].x - mean) * rstd * g.x + e.x, (v[i].y - mean) * rstd * g.y + e.y,
                                 (v[i].z - mean) * rstd * g.z + e.z, (v[i].w - mean) * rstd * g.w + e.w);
         }
@@ -379,14 +379,14 @@ __global__ __launch_bounds__(256) void add_layernorm_wave_kernel(const float* __
     if (row >= rows) return;
     const int nv = cols / 4;
     const float4* pa = reinterpret_cast<const float4*>(a + (ia ? ia[row] : row) * lda);
-    const float4* pb = reinterpret_cast<const float4*>(b + (ib ? (int64_t)ib[row] : row) * ldb);
+    const float4* pb = b ? reinterpret_cast<const float4*>(b + (ib ? (int64_t)ib[row] : row) * ldb) : nullptr;   // null: z = LN(a)
     float4 v[LN_MAX_V4];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
-            const float4 x = pa[c], w = pb[c];
+            const float4 x = pa[c], w = pb ? pb[c] : make_float4(0.f, 0.f, 0.f, 0.f);
             v[i] = make_float4(x.x + w.x, x.y + w.y, x.z + w.z, x.w + w.w);
             sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void add_layernorm_wave_kernel(const float* __
         const int c = lane + i * 64;
         if (c < nv) {
             const float4 g = pg[c], e = pe[c];
-            py[c] = v[i];
+            if (y) py[c] = v[i];
             pz[c] = make_float4((v[i].x - mean) * rstd * g.x + e.x, (v[i].y - mean) * rstd * g.y + e.y,
                                 (v[i].z - mean) * rstd * g.z + e.z, (v[i].w - mean) * rstd * g.w + e.w);
         }
@@ -437,8 +437,8 @@ static void launch_add_layernorm(const float* a, int64_t lda, const float* b, in
 extern "C" int emcid_add_layernorm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gamma,
                                        const float* beta, float eps, int64_t rows, int64_t cols, float* y, float* z,
                                        void* stream) {
-    EMCID_CHECK_ARG(a && b && gamma && beta && y && z && rows > 0 && cols > 0 && rows < (1LL << 31));
-    EMCID_CHECK_ARG(cols % 4 == 0 && cols <= LN_MAX_V4 * 256 * 4 && lda % 4 == 0 && ldb % 4 == 0);
+    EMCID_CHECK_ARG(a && gamma && beta && z && rows > 0 && cols > 0 && rows < (1LL << 31));
+    EMCID_CHECK_ARG(cols % 4 == 0 && cols <= LN_MAX_V4 * 256 * 4 && lda % 4 == 0 && (b == nullptr || ldb % 4 == 0));
     EMCID_CHECK_ARG(aligned16(a) && aligned16(b) && aligned16(gamma) && aligned16(beta) && aligned16(y) && aligned16(z));
     ScopedProf sp(KC_MISC, (hipStream_t)stream);
     launch_add_layernorm(a, lda, b, ldb, gamma, beta, eps, rows, cols, y, z, nullptr, nullptr, (hipStream_t)stream);

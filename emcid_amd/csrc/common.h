@@ -51,7 +51,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // A ScopedProf around a launch records an event pair on the launch stream when its class is enabled.
 enum KernelClass : int {
     KC_PREP = 0, KC_ASSEMBLE = 1, KC_CHOL_LEAF = 2, KC_CHOL_PANEL = 3, KC_CHOL_TRAIL = 4, KC_TRSM_DIAG = 5,
-    KC_TRSM_UPDATE = 6, KC_DELTA_W = 7, KC_GRAM = 8, KC_GATHER = 9, KC_DGEMM = 10, KC_MISC = 11, KC_INV_BUILD = 12, KC_CHOL_INNER = 13, KC_INV_APPLY = 14, KC_INV_BLOCK = 15, KC_COUNT = 16
+    KC_TRSM_UPDATE = 6, KC_DELTA_W = 7, KC_GRAM = 8, KC_GATHER = 9, KC_DGEMM = 10, KC_MISC = 11, KC_INV_BUILD = 12, KC_CHOL_INNER = 13, KC_INV_APPLY = 14, KC_INV_BLOCK = 15, KC_LINEAR = 16, KC_COUNT = 17
 };
 void prof_begin(int cls, hipStream_t st);
 void prof_end(int cls, hipStream_t st);

@@ -563,20 +563,25 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
 
         zc_from_keys = os.environ.get("EMCID_ZC_FROM_KEYS", "1") != "0"      # 0: fc2 over every node + gather (A/B switch)
 
-        def on_fc2(li, xs, outs):
+        def on_fc2(li, xs, outs, mids=None):
+            """fc2 of an edited layer: keys -> closed form -> the projection with the NEW weight.  ``mids`` (the residual
+            streams): the callback returns fc2(x) + mid, the add riding in the GEMM's epilogue."""
             if li not in order:
                 return outs
             m = mods[li]
             K_loc = keys(li, xs)
+            lin = clip_forward.linear
             if not zc_from_keys:
-                solve(order[li], li, K_loc, keys(li, [F.linear(x, m.weight, m.bias) for x in xs]))
-                return None if li == last else [F.linear(x, m.weight, m.bias) for x in xs]
-            # fc2 is affine, so the mean over a request's prompts of its output at the lookup rows IS fc2 of the mean
-            # key: Zc = K W^T + b on N rows (to fp32 rounding) instead of fc2 over every node followed by a gather
-            solve(order[li], li, K_loc, lambda K_all: F.linear(K_all, m.weight, m.bias))
+                solve(order[li], li, K_loc, keys(li, [lin(x, m.weight, m.bias) for x in xs]))
+            else:
+                # fc2 is affine, so the mean over a request's prompts of its output at the lookup rows IS fc2 of the mean
+                # key: Zc = K W^T + b on N rows (to fp32 rounding) instead of fc2 over every node followed by a gather
+                solve(order[li], li, K_loc, lambda K_all: lin(K_all, m.weight, m.bias))
             if li == last:
                 return None
-            return [F.linear(x, m.weight, m.bias) for x in xs]
+            if mids is None:
+                return [lin(x, m.weight, m.bias) for x in xs]
+            return [lin(x, m.weight, m.bias, residual=mid) for x, mid in zip(xs, mids)]
 
         with torch.no_grad():
             # the unedited leading layers: already launched by prepare (underneath the host's tokenization), else here
@@ -588,7 +593,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                     states.append(clip_forward.run_prefix(plan.graph, ch.trie, first_edit))
                 ch.state = None         # single use: the residual stream below belongs to the weights of this very call
             clip_forward.run_layers_multi(plan.graph, [ch.trie for ch in chunks], states, first_edit, last, on_fc2,
-                                          fc2_by_callback=order)
+                                          fc2_by_callback=order, callback_adds_residual=True)
     else:
         def make_hook(i, layer):
             def hook(mod, inputs, output):

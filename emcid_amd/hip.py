@@ -29,10 +29,10 @@ EXPORTS = [
     "emcid_edit_dual_apply_assemble_f64",
     "emcid_edit_lu_workspace_bytes", "emcid_edit_layer_lu_f64", "emcid_lu_solve_f64",
     "emcid_edit_dual_cols_stage1_f64", "emcid_edit_dual_s", "emcid_edit_dual_u", "emcid_edit_dual_cols_stage2_f64",
-    "emcid_apply_update2d_f32",
+    "emcid_apply_update2d_f32", "emcid_linear_f32",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
-                "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block"]
+                "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block", "linear"]
 
 ABI_VERSION = 9
 NB = 128      # Cholesky block (csrc/common.h)
@@ -102,6 +102,7 @@ def load():
         "emcid_dgemm_streamk_f64": (i32, [i32, i64, i64, i64, f64, p, i64, p, i64, p, i64, i32, i32, f64, p, i64, p]),
         "emcid_axpy_f32": (i32, [p, p, i64, p]),
         "emcid_quick_gelu_f32": (i32, [p, p, i64, p]),
+        "emcid_linear_f32": (i32, [p, i64, p, i64, p, p, i64, p, i64, i64, i64, i64, i32, i32, p]),
         "emcid_add_layernorm_f32": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p]),
         "emcid_embed_layernorm_f32": (i32, [p, i64, i64, p, i64, i64, p, p, p, p, C.c_float, i64, i64, p, p, p]),
         "emcid_tree_attention_f32": (i32, [p, i64, p, p, i64, p, i64, p, p, i64, i64, i64, f32, p, i64, p]),
@@ -467,19 +468,55 @@ def quick_gelu(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def add_layernorm(a: torch.Tensor, b: torch.Tensor, ln: torch.nn.LayerNorm):
-    """(a + b, LayerNorm(a + b)) in one pass; a, b (rows, cols) fp32 with unit column stride."""
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
+
+
+def linear_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
+    """True when ``linear`` takes these operands: fp32 in HBM, K contiguous and a multiple of 16, 16-byte aligned rows."""
+    return (x.is_cuda and w.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.dim() == 2 and w.dim() == 2
+            and x.shape[1] == w.shape[1] and x.shape[1] % 16 == 0 and x.stride(1) == 1 and w.stride(1) == 1
+            and x.stride(0) % 4 == 0 and w.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and x.shape[0] > 0)
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+           residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, cfg: int = -1) -> torch.Tensor:
+    """act(x @ w.T + bias) + residual in one launch (csrc/gemm_f32.hip): x (M, K), w (N, K) like nn.Linear.weight, bias (N,),
+    residual (M, N) row views; fp32, exact-f32 MFMA."""
+    if not linear_supported(x, w):
+        raise EmcidHipError("linear: fp32 HBM operands with K contiguous, K % 16 == 0 and 16-byte aligned rows")
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    if out.shape != (M, N) or out.stride(1) != 1 or out.dtype != torch.float32:
+        raise EmcidHipError("linear: out must be an (M, N) fp32 row view")
+    if bias is not None and (bias.shape != (N,) or not bias.is_contiguous()):
+        raise EmcidHipError("linear: bias must be a contiguous (N,) vector")
+    if residual is not None and (residual.shape != (M, N) or residual.stride(1) != 1):
+        raise EmcidHipError("linear: residual must be an (M, N) row view")
+    _check(load().emcid_linear_f32(_ptr(x, torch.float32, "x"), x.stride(0), _ptr(w, torch.float32, "w"), w.stride(0),
+                                   _ptr(bias, torch.float32, "bias"), _ptr(residual, torch.float32, "residual"),
+                                   residual.stride(0) if residual is not None else 0, _ptr(out, torch.float32, "out"),
+                                   out.stride(0), M, N, K, int(act), int(cfg), _stream(x)), "emcid_linear_f32")
+    return out
+
+
+def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], ln: torch.nn.LayerNorm, want_sum: bool = True):
+    """(a + b, LayerNorm(a + b)) in one pass; a, b (rows, cols) fp32 with unit column stride.  ``b=None``: LayerNorm(a)
+    alone (returns (a, LayerNorm(a)); nothing but z is written)."""
     rows, cols = a.shape
-    if a.stride(1) != 1 or b.stride(1) != 1 or b.shape != a.shape:
+    if a.stride(1) != 1 or (b is not None and (b.stride(1) != 1 or b.shape != a.shape)):
         raise EmcidHipError("add_layernorm: (rows, cols) operands with unit column stride")
     if ln.weight is None or ln.bias is None or tuple(ln.normalized_shape) != (cols,):
         raise EmcidHipError("add_layernorm: LayerNorm over the last dimension with affine parameters")
-    y = torch.empty(rows, cols, dtype=torch.float32, device=a.device)
-    z = torch.empty_like(y)
-    _check(load().emcid_add_layernorm_f32(_ptr(a, torch.float32, "a"), a.stride(0), _ptr(b, torch.float32, "b"), b.stride(0),
+    y = torch.empty(rows, cols, dtype=torch.float32, device=a.device) if (b is not None and want_sum) else None
+    z = torch.empty(rows, cols, dtype=torch.float32, device=a.device)
+    _check(load().emcid_add_layernorm_f32(_ptr(a, torch.float32, "a"), a.stride(0), _ptr(b, torch.float32, "b"),
+                                          b.stride(0) if b is not None else 0,
                                           _ptr(ln.weight, torch.float32, "gamma"), _ptr(ln.bias, torch.float32, "beta"),
                                           float(ln.eps), rows, cols, _ptr(y), _ptr(z), _stream(a)), "emcid_add_layernorm_f32")
-    return y, z
+    return (a if b is None else y), z
 
 
 def embed_layernorm(tok_emb: torch.Tensor, pos_emb: torch.Tensor, token: torch.Tensor, position: torch.Tensor,

@@ -94,9 +94,20 @@ int emcid_tree_attention_f32(const float* q, int64_t ldq, const float* k, const 
  * instead of the framework's three).  x may alias y. */
 int emcid_quick_gelu_f32(const float* x, float* y, int64_t n, void* stream);
 
+/* Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]) + residual[M,N]: a row-wise projection of the text-encoder forward (nn.Linear inside
+ * CLIPTextModel.forward, which the reference runs for every prompt, emcid/compute_z.py:2296-2316) with its element-wise
+ * neighbours fused: bias (may be NULL), act = 0 none / 1 quick_gelu x*sigmoid(1.702x) / 2 erf-gelu, residual (may be NULL,
+ * added after the activation).  fp32 in, exact-f32 MFMA accumulate, fp32 out; X and W row-major with K contiguous, K % 16 == 0,
+ * ldx / ldw % 4 == 0, 16-byte aligned.  cfg: -1 = pick the tile by the launch's fill of the 256 compute units; 0 = 160 x 128,
+ * 1 = 128 x 128, 2 = 256 x 128, 3 = 64 x 64.  Y may alias residual (each element is read then written by the same lane). */
+int emcid_linear_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual,
+                     int64_t ldr, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, int act, int cfg, void* stream);
+
 /* y = a + b ; z = LayerNorm(y) * gamma + beta over the last dimension (biased variance, eps inside the root, as
  * torch.nn.LayerNorm) — the residual add and the LayerNorm after it of every block of the same hooked forward, one
- * pass.  a/b: [rows, cols] with row strides lda/ldb (elements); y, z: [rows, cols] contiguous; cols % 4 == 0, <= 8192. */
+ * pass.  a/b: [rows, cols] with row strides lda/ldb (elements); y, z: [rows, cols] contiguous; cols % 4 == 0, <= 8192.
+ * b == NULL: z = LayerNorm(a) (the residual add already happened in emcid_linear_f32's epilogue); y == NULL: the sum is not
+ * written. */
 int emcid_add_layernorm_f32(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gamma, const float* beta,
                             float eps, int64_t rows, int64_t cols, float* y, float* z, void* stream);
 

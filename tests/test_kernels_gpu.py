@@ -3,6 +3,7 @@ Run on the MI355X box:  python -m pytest tests -m gpu -x -q"""
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -584,3 +585,49 @@ def test_shadow_product_forced_and_off(mode):
     env = dict(os.environ, EMCID_SHADOW_P=mode)
     r = subprocess.run([sys.executable, "-c", _SHADOW_SCRIPT, str(REPO)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SHADOW_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("M,K,N", [(6400, 768, 2304), (6400, 768, 768), (6400, 3072, 768), (3072, 768, 3072), (1000, 3072, 768),
+                                   (777, 1280, 3840), (37, 48, 200), (1, 16, 1), (300, 5120, 1280), (161, 32, 129)])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3])
+def test_linear_f32_vs_torch(M, K, N, cfg):
+    """emcid_linear_f32 (csrc/gemm_f32.hip) against torch: the plain projection to fp32 rounding of an exact-f32 accumulation
+    (reference of the same op: F.linear in fp64 rounded, and torch's own fp32 F.linear), every tile configuration, ragged
+    edges; the fused epilogues (bias, quick_gelu, erf-gelu, residual — also in place) against the unfused torch ops."""
+    if cfg >= 0 and M * N * K > 6400 * 768 * 2304 // 2 and cfg == 3:
+        pytest.skip("64 x 64 tiles on the large shapes: covered by the smaller ones")
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K + 4, generator=g).to(DEV)[:, :K]                 # row stride K + 4: a strided row view
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r = torch.randn(M, N, generator=g).to(DEV)
+    ref = F.linear(x.double(), w.double(), b.double())
+    scale = ref.abs().max().item()
+    tol = 4e-7 * scale * max(1.0, (K / 768) ** 0.5) + 1e-6
+    y = hip.linear(x, w, b, cfg=cfg)
+    assert (y.double() - ref).abs().max().item() <= tol
+    assert (y - F.linear(x, w, b)).abs().max().item() <= 2 * tol
+    y0 = hip.linear(x, w, None, cfg=cfg)
+    assert (y0.double() - F.linear(x.double(), w.double())).abs().max().item() <= tol
+    yq = hip.linear(x, w, b, act=hip.ACT_QUICK_GELU, cfg=cfg)
+    torch.testing.assert_close(yq, (ref * torch.sigmoid(1.702 * ref)).float(), rtol=2e-6, atol=tol)
+    ye = hip.linear(x, w, b, act=hip.ACT_GELU_ERF, cfg=cfg)
+    torch.testing.assert_close(ye, F.gelu(ref).float(), rtol=2e-6, atol=tol)
+    yr = hip.linear(x, w, b, residual=r, cfg=cfg)
+    torch.testing.assert_close(yr, (ref + r.double()).float(), rtol=0, atol=tol)
+    rr = r.clone()
+    hip.linear(x, w, b, residual=rr, out=rr, cfg=cfg)                     # in place on the residual stream
+    assert torch.equal(rr, yr)
+    # an output that is a column block of a wider buffer (leading dimension > N)
+    wide = torch.full((M, N + 8), 7.0, device=DEV)
+    hip.linear(x, w, b, out=wide[:, :N], cfg=cfg)
+    assert torch.equal(wide[:, :N], y) and bool((wide[:, N:] == 7.0).all())
+
+
+def test_linear_f32_rejects_unsupported_operands():
+    x = torch.randn(8, 24, device=DEV)
+    w = torch.randn(4, 24, device=DEV)
+    assert not hip.linear_supported(x, w)                                 # K % 16 != 0
+    with pytest.raises(hip.EmcidHipError):
+        hip.linear(x, w)
+    assert not hip.linear_supported(torch.randn(8, 32, device=DEV).double(), torch.randn(4, 32, device=DEV).double())
