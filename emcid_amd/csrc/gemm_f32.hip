@@ -21,6 +21,12 @@
 // so no LDS or barrier latency sits between two MFMAs of a wave even at one wave per SIMD (a 240-tile launch gives every
 // compute unit ONE workgroup), and no global load is outstanding at the barrier (hipcc drains vmcnt before s_barrier).
 //
+// KS = 2 (the default): EIGHT waves per workgroup, two per SIMD — waves 0-3 contract the first 16 of a 32-deep stage, waves
+// 4-7 the second 16, both over the whole tile; at the end waves 4-7 hand their accumulators to waves 0-3 through LDS (a fixed
+// order: bit-reproducible).  A launch of 240 tiles puts ONE workgroup on a compute unit; with four waves its SIMDs each run
+// one wave and every barrier / wait is an idle matrix pipe (measured: 73 % of the MFMA rate even with no memory traffic at
+// all), with eight the partner wave issues meanwhile.  Rows are then fetched 128 B at a time (whole cache lines).
+//
 // Tiles: waves in a WM x WN grid, each (32 MI) x (32 NJ).  160 x 128 (1 x 4 waves of 160 x 32) is the workhorse: the trie
 // forward's row counts are multiples of 256 (6 400 at N = 1000 x 3 templates) and N in {768, 2304, 3072}, where it gives
 // 240 / 720 / 960 tiles = 0.94 / 2.81 / 3.75 rounds of the 256 compute units (128 x 128: 300 tiles = 59 % of two rounds).
@@ -31,21 +37,30 @@ namespace emcid {
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int LBK = 16;      // K depth of a stage
-constexpr int LLD = 20;      // LDS row stride in floats (16 + 4 padding)
+constexpr int LBK = 16;      // K depth of a stage per wave group (a stage is 16 KS deep)
 
 enum LinearAct : int { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU_ERF = 2 };
 
-template <int MI, int NJ, int WM, int WN>
-__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
-                                                          int64_t ldw, const float* __restrict__ bias,
-                                                          const float* __restrict__ res, int64_t ldr, float* __restrict__ Y,
-                                                          int64_t ldy, int M, int N, int K, int act, int tiles_n, int tiles) {
-    static_assert(WM * WN == 4, "four waves");
+template <int V> struct IC { static constexpr int value = V; };
+
+// PF: how many stages ahead the global loads run (= register sets of staged data).  DBG (timing experiments only, results
+// wrong): 1 = no global loads inside the loop, 2 = also no LDS stores.
+template <int MI, int NJ, int WM, int WN, int PF, int DBG, int KS>
+__global__ __launch_bounds__(256 * KS) void linear_f32_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
+                                                               int64_t ldw, const float* __restrict__ bias,
+                                                               const float* __restrict__ res, int64_t ldr, float* __restrict__ Y,
+                                                               int64_t ldy, int M, int N, int K, int act, int tiles_n, int tiles) {
+    static_assert(WM * WN == 4 && (KS == 1 || KS == 2), "four waves per K group");
+    constexpr int NT = 256 * KS;                     // threads
+    constexpr int SBK = LBK * KS;                    // K depth of a stage
+    constexpr int LLD = SBK + 4;                     // LDS row stride in floats: 20 / 36, conflict-free for the b128 lane groups
+    constexpr int CPR = SBK / 4;                     // float4 per row and stage
     constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
-    constexpr int VA = (BM * 4 + 255) / 256, VB = (BN * 4 + 255) / 256;      // float4 per thread and stage
+    constexpr int VA = (BM * CPR + NT - 1) / NT, VB = (BN * CPR + NT - 1) / NT;      // float4 per thread and stage
     constexpr int STAGE = (BM + BN) * LLD;
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    constexpr int RED = KS == 2 ? 4 * MI * NJ * 16 * 64 : 0;                         // floats the final hand-over needs
+    constexpr int SMEM = 2 * STAGE > RED ? 2 * STAGE : RED;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
     // Workgroups go to the 8 XCDs round-robin by linear id.  XCD x takes the tiles [x * per, (x + 1) * per): a contiguous
     // run of row tiles with all their column tiles, so the rows of X an XCD streams are its own and every column tile of W
@@ -56,46 +71,48 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
     const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
     const int m0 = bm * BM, n0 = bn * BN;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8;      // grp: which 16 of a stage's K
     const int l31 = lane & 31, l5 = lane >> 5;
     const int wm0 = (wave / WN) * (32 * MI), wn0 = (wave % WN) * (32 * NJ);
 
-    // global -> register staging: vector v = tid + 256 s of an image is row v / 4, floats 4 (v % 4) .. + 3 of the stage
+    // global -> register staging: vector v = tid + NT s of an image is row v / CPR, floats 4 (v % CPR) .. + 3 of the stage
     const float* pa[VA];
     const float* pb[VB];
     int wa[VA], wb[VB];
 #pragma unroll
     for (int s = 0; s < VA; ++s) {
-        const int v = tid + 256 * s, row = min(v >> 2, BM - 1);
-        pa[s] = X + (int64_t)min(m0 + row, M - 1) * ldx + 4 * (v & 3);          // rows past M: a valid row, never stored
-        wa[s] = row * LLD + 4 * (v & 3);
+        const int v = tid + NT * s, row = min(v / CPR, BM - 1);
+        pa[s] = X + (int64_t)min(m0 + row, M - 1) * ldx + 4 * (v % CPR);        // rows past M: a valid row, never stored
+        wa[s] = row * LLD + 4 * (v % CPR);
     }
 #pragma unroll
     for (int s = 0; s < VB; ++s) {
-        const int v = tid + 256 * s, row = min(v >> 2, BN - 1);
-        pb[s] = W + (int64_t)min(n0 + row, N - 1) * ldw + 4 * (v & 3);
-        wb[s] = BM * LLD + row * LLD + 4 * (v & 3);
+        const int v = tid + NT * s, row = min(v / CPR, BN - 1);
+        pb[s] = W + (int64_t)min(n0 + row, N - 1) * ldw + 4 * (v % CPR);
+        wb[s] = BM * LLD + row * LLD + 4 * (v % CPR);
     }
-    constexpr bool TAIL_A = (BM * 4) % 256 != 0, TAIL_B = (BN * 4) % 256 != 0;
-    const bool last_a = !TAIL_A || tid + 256 * (VA - 1) < BM * 4;               // wave-uniform (multiples of 64 threads)
-    const bool last_b = !TAIL_B || tid + 256 * (VB - 1) < BN * 4;
+    constexpr bool TAIL_A = (BM * CPR) % NT != 0, TAIL_B = (BN * CPR) % NT != 0;
+    const bool last_a = !TAIL_A || tid + NT * (VA - 1) < BM * CPR;              // wave-uniform (multiples of 64 threads)
+    const bool last_b = !TAIL_B || tid + NT * (VB - 1) < BN * CPR;
 
-    v4f ga[VA], gb[VB];
-    auto gload = [&](int k0) {
+    v4f ga[PF][VA], gb[PF][VB];
+    auto gload = [&](int k0, auto rc) {
+        constexpr int R = decltype(rc)::value;
 #pragma unroll
         for (int s = 0; s < VA; ++s)
-            if (s + 1 < VA || last_a) ga[s] = *reinterpret_cast<const v4f*>(pa[s] + k0);
+            if (s + 1 < VA || last_a) ga[R][s] = *reinterpret_cast<const v4f*>(pa[s] + k0);
 #pragma unroll
         for (int s = 0; s < VB; ++s)
-            if (s + 1 < VB || last_b) gb[s] = *reinterpret_cast<const v4f*>(pb[s] + k0);
+            if (s + 1 < VB || last_b) gb[R][s] = *reinterpret_cast<const v4f*>(pb[s] + k0);
     };
-    auto lstore = [&](float* stage) {
+    auto lstore = [&](float* stage, auto rc) {
+        constexpr int R = decltype(rc)::value;
 #pragma unroll
         for (int s = 0; s < VA; ++s)
-            if (s + 1 < VA || last_a) *reinterpret_cast<v4f*>(stage + wa[s]) = ga[s];
+            if (s + 1 < VA || last_a) *reinterpret_cast<v4f*>(stage + wa[s]) = ga[R][s];
 #pragma unroll
         for (int s = 0; s < VB; ++s)
-            if (s + 1 < VB || last_b) *reinterpret_cast<v4f*>(stage + wb[s]) = gb[s];
+            if (s + 1 < VB || last_b) *reinterpret_cast<v4f*>(stage + wb[s]) = gb[R][s];
     };
 
     v16f acc[MI][NJ];
@@ -106,8 +123,8 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int fa_off = (wm0 + l31) * LLD + 4 * l5;                 // + 32 i rows, + 8 q floats
-    const int fb_off = BM * LLD + (wn0 + l31) * LLD + 4 * l5;
+    const int fa_off = (wm0 + l31) * LLD + 4 * l5 + LBK * grp;     // + 32 i rows, + 8 q floats
+    const int fb_off = BM * LLD + (wn0 + l31) * LLD + 4 * l5 + LBK * grp;
     v4f fa[2][MI], fb[2][NJ];
     auto fread = [&](const float* stage, int q, int slot) {
 #pragma unroll
@@ -128,13 +145,16 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
 
     // The fragment reads of the NEXT block are issued right after the first k-step's MFMAs of the current one: the wait in front
     // of those first MFMAs then covers only reads issued a whole block ago (hipcc emits lgkmcnt(0) there, not a counted wait).
-    const int T = K / LBK;
-    gload(0);
-    lstore(smem);
+    // Stage s is loaded into register set s % PF; iteration `it` stores stage it+1 and refills that set with stage it+1+PF.
+    const int T = K / SBK;
+    gload(0, IC<0>{});
+    lstore(smem, IC<0>{});
+    if (T > 1) gload(SBK, IC<1 % PF>{});
+    if constexpr (PF > 1) if (T > 2) gload(2 * SBK, IC<2 % PF>{});
+    if constexpr (PF > 2) if (T > 3) gload(3 * SBK, IC<3 % PF>{});
     __syncthreads();
-    if (T > 1) gload(LBK);
     fread(smem, 0, 0);
-    for (int it = 0; it < T; ++it) {
+    auto body = [&](auto rc, int it) {
         float* cur = smem + (it & 1) * STAGE;
         float* oth = smem + ((it + 1) & 1) * STAGE;
         __builtin_amdgcn_sched_barrier(0);
@@ -144,19 +164,64 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
         __builtin_amdgcn_sched_barrier(0);
         mfmas(0, 1, 4);
         __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 < T) lstore(oth);           // stage it+1 (loaded during the previous stage) -> the other buffer
+        if (DBG < 2 && it + 1 < T) lstore(oth, rc);       // stage it+1 (loaded PF stages ago) -> the other buffer
         __syncthreads();
-        if (it + 2 < T) gload((it + 2) * LBK);
+        if (DBG < 1 && it + 1 + PF < T) gload((it + 1 + PF) * SBK, rc);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(1, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
         if (it + 1 < T) fread(oth, 0, 0);      // block 0 of the next stage: lands under the MFMAs of block 1
         __builtin_amdgcn_sched_barrier(0);
         mfmas(1, 1, 4);
+    };
+    for (int it0 = 0; it0 < T; it0 += PF) {
+        body(IC<1 % PF>{}, it0);
+        if constexpr (PF > 1) if (it0 + 1 < T) body(IC<2 % PF>{}, it0 + 1);
+        if constexpr (PF > 2) if (it0 + 2 < T) body(IC<3 % PF>{}, it0 + 2);
+    }
+
+    // KS == 2: the two wave groups hold the two halves of every sum.  They swap HALF of their accumulator blocks through LDS
+    // (lane-linear 16-byte pieces: [wave][block][4][lane]) — group 0 ends up owning blocks [0, HB), group 1 blocks [HB, MI NJ),
+    // each complete — so that all eight waves share the epilogue.  Fixed order of the two addends: bit-reproducible.
+    constexpr int NBLK = MI * NJ, HB = KS == 2 ? (NBLK + 1) / 2 : NBLK;
+    if constexpr (KS == 2) {
+        __syncthreads();                                       // everybody is done with the stage buffers
+        v4f* red = reinterpret_cast<v4f*>(smem) + wave * (NBLK * 4 * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int t = i * NJ + j;
+                if ((t < HB) == (grp == 1)) {                  // a block the OTHER group will own
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v4f v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                        red[(t * 4 + q) * 64] = v;
+                    }
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int t = i * NJ + j;
+                if ((t < HB) == (grp == 0)) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const v4f v = red[(t * 4 + q) * 64];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)       // group 0's partial first, then group 1's, whoever adds
+                            acc[i][j][4 * q + e] = grp == 0 ? acc[i][j][4 * q + e] + v[e] : v[e] + acc[i][j][4 * q + e];
+                    }
+                }
+            }
     }
 
     // epilogue: C[row][col], row = (r & 3) + 8 (r >> 2) + 4 l5 inside a 32 x 32 block, col = l31: a wave instruction writes two
-    // runs of 32 consecutive floats.  The activation is chosen once, outside the unrolled element loops.
+    // runs of 32 consecutive floats.  The activation is chosen once, outside the unrolled element loops; a tile that lies inside
+    // the matrix takes a path without per-element predicates (the residual loads of a block are then issued together).
+    const bool interior = m0 + BM <= M && n0 + BN <= N;
     auto epilogue = [&](auto actfn) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -164,16 +229,34 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
             const bool n_ok = n < N;
             const float bv = (bias != nullptr && n_ok) ? bias[n] : 0.f;
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i = 0; i < MI; ++i) {
+                const int t = i * NJ + j;
+                if (KS == 2 && (t < HB) != (grp == 0)) continue;
+                const int mb = m0 + wm0 + i * 32 + 4 * l5;
+                if (interior) {
+                    float rv[16];
+                    if (res != nullptr) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * l5;
-                    if (n_ok && m < M) {
+                        for (int r = 0; r < 16; ++r) rv[r] = res[(int64_t)(mb + (r & 3) + 8 * (r >> 2)) * ldr + n];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
                         float v = actfn(acc[i][j][r] + bv);
-                        if (res != nullptr) v += res[(int64_t)m * ldr + n];
-                        Y[(int64_t)m * ldy + n] = v;
+                        if (res != nullptr) v += rv[r];
+                        Y[(int64_t)(mb + (r & 3) + 8 * (r >> 2)) * ldy + n] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mb + (r & 3) + 8 * (r >> 2);
+                        if (n_ok && m < M) {
+                            float v = actfn(acc[i][j][r] + bv);
+                            if (res != nullptr) v += res[(int64_t)m * ldr + n];
+                            Y[(int64_t)m * ldy + n] = v;
+                        }
                     }
                 }
+            }
         }
     };
     if (act == ACT_QUICK_GELU) epilogue([](float x) { return x / (1.0f + __expf(-1.702f * x)); });       // x * sigmoid(1.702 x)
@@ -195,32 +278,63 @@ int emcid_linear_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, c
     EMCID_CHECK_ARG(X && W && Y && M > 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N);
     EMCID_CHECK_ARG(K % LBK == 0 && ldx % 4 == 0 && ldw % 4 == 0 && aligned16(X) && aligned16(W));
     EMCID_CHECK_ARG(M < (1 << 24) && N < (1 << 24) && K < (1 << 24) && (residual == nullptr || ldr >= N));
-    EMCID_CHECK_ARG(act >= ACT_NONE && act <= ACT_GELU_ERF && cfg >= -1 && cfg < 4);
-    if (cfg < 0) {
-        // every compute unit gets ceil(tiles / 256) tiles (a second resident workgroup shares its matrix pipe): the launch
-        // lasts rounds * BM * BN; the small tile pays ~25 % more per flop (one MFMA per fragment pair)
-        double best = 0.0;
-        for (int c = 0; c < 4; ++c) {
-            const int64_t t = ((M + kLinearCfgs[c].bm - 1) / kLinearCfgs[c].bm) * ((N + kLinearCfgs[c].bn - 1) / kLinearCfgs[c].bn);
-            const double cost = (double)((t + 255) / 256) * kLinearCfgs[c].bm * kLinearCfgs[c].bn * (c == 3 ? 1.25 : c == 2 ? 0.97 : 1.0);
-            if (cfg < 0 || cost < best) best = cost, cfg = c;
-        }
+    EMCID_CHECK_ARG(act >= ACT_NONE && act <= ACT_GELU_ERF && cfg >= -1 && cfg < 128);
+    // cfg: bits 0-1 tile, bits 2-3 prefetch distance - 1 (0..2), bits 4-5 DBG (tile 0, one K group only), bit 6: ONE K group
+    // (4 waves) instead of two (8 waves); -1: auto
+    int tile_sel = cfg < 0 ? -1 : (cfg & 3);
+    static const int pf_env = [] { const char* e = getenv("EMCID_LINEAR_PF"); return e ? atoi(e) : 1; }();
+    static const int ks_env = [] { const char* e = getenv("EMCID_LINEAR_KS"); return e ? atoi(e) : 2; }();
+    int pf = cfg < 0 ? (pf_env >= 1 && pf_env <= 3 ? pf_env : 1) : ((cfg >> 2) & 3) + 1;
+    const int dbg = cfg < 0 ? 0 : (cfg >> 4) & 3;
+    int ks = cfg < 0 ? (ks_env == 1 ? 1 : 2) : ((cfg >> 6) & 1) ? 1 : 2;
+    if (K % (2 * LBK) != 0) ks = 1;
+    if (dbg) ks = 1;
+    EMCID_CHECK_ARG(pf >= 1 && pf <= 3 && dbg <= 2 && (dbg == 0 || tile_sel == 0));
+    if (tile_sel < 0) {
+        // Pick (tile, waves) by fill x base rate.  fill: a compute unit works through ceil(tiles / 256) tiles (co-resident
+        // workgroups share its matrix pipe), the average one through tiles / 256.  Base rates = fraction of the f32 MFMA rate
+        // measured with scripts/mb_linear.py on MI355X at full fill (profiles/r03_mb_linear.txt):
+        //   128 x 128, 4 waves, prefetch 2, two workgroups per compute unit: 0.83 (K = 768) .. 0.90 (K = 5120)
+        //   160 x 128, 8 waves (K split inside the workgroup), one per compute unit: 0.765, 0.83 from K = 2048
+        //   64 x 64, up to 8 workgroups per compute unit: 0.70
+        auto fill = [](int64_t t) { return ((double)t / 256.0) / (double)((t + 255) / 256); };
+        const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128), t160 = ((M + 159) / 160) * ((N + 127) / 128);
+        const int64_t t64 = ((M + 63) / 64) * ((N + 63) / 64);
+        const bool split_ok = K % (2 * LBK) == 0 && ks_env != 1;
+        const double s128 = (K < 1024 ? 0.83 : K < 4096 ? 0.875 : 0.90) * fill(t128);
+        const double s160 = split_ok ? (K >= 2048 ? 0.83 : 0.765) * fill(t160) : 0.0;
+        const double s64 = 0.70 * fill(t64);
+        if (s128 >= s160 && s128 >= s64) tile_sel = 1, ks = 1, pf = 2;
+        else if (s160 >= s64) tile_sel = 0, ks = 2, pf = 2;
+        else tile_sel = 3, ks = (K >= 2048 && split_ok) ? 2 : 1, pf = ks == 2 ? 2 : 3;
     }
-    const int bm = kLinearCfgs[cfg].bm, bn = kLinearCfgs[cfg].bn;
+    const int bm = kLinearCfgs[tile_sel].bm, bn = kLinearCfgs[tile_sel].bn;
     const int tiles_m = (int)((M + bm - 1) / bm), tiles_n = (int)((N + bn - 1) / bn);
     const int tiles = tiles_m * tiles_n;
     const int per = (tiles + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
     ScopedProf sp(KC_LINEAR, st);
-#define EMCID_LINEAR_LAUNCH(MI_, NJ_, WM_, WN_)                                                                              \
-    hipLaunchKernelGGL((linear_f32_kernel<MI_, NJ_, WM_, WN_>), dim3((unsigned)(per * 8)), dim3(256), 0, st, X, ldx, W, ldw, \
-                       bias, residual, ldr, Y, ldy, (int)M, (int)N, (int)K, act, tiles_n, tiles)
-    switch (cfg) {
-        case 0: EMCID_LINEAR_LAUNCH(5, 1, 1, 4); break;
-        case 1: EMCID_LINEAR_LAUNCH(2, 2, 2, 2); break;
-        case 2: EMCID_LINEAR_LAUNCH(4, 2, 2, 2); break;
-        default: EMCID_LINEAR_LAUNCH(1, 1, 2, 2); break;
+#define EMCID_LINEAR_LAUNCH(MI_, NJ_, WM_, WN_, PF_, DBG_, KS_)                                                              \
+    hipLaunchKernelGGL((linear_f32_kernel<MI_, NJ_, WM_, WN_, PF_, DBG_, KS_>), dim3((unsigned)(per * 8)), dim3(256 * KS_), 0, \
+                       st, X, ldx, W, ldw, bias, residual, ldr, Y, ldy, (int)M, (int)N, (int)K, act, tiles_n, tiles)
+#define EMCID_LINEAR_PF(MI_, NJ_, WM_, WN_)                                              \
+    do {                                                                                  \
+        if (ks == 2) {                                                                    \
+            if (pf == 1) EMCID_LINEAR_LAUNCH(MI_, NJ_, WM_, WN_, 1, 0, 2);                \
+            else EMCID_LINEAR_LAUNCH(MI_, NJ_, WM_, WN_, 2, 0, 2);                        \
+        } else if (pf == 1) EMCID_LINEAR_LAUNCH(MI_, NJ_, WM_, WN_, 1, 0, 1);             \
+        else if (pf == 2) EMCID_LINEAR_LAUNCH(MI_, NJ_, WM_, WN_, 2, 0, 1);               \
+        else EMCID_LINEAR_LAUNCH(MI_, NJ_, WM_, WN_, 3, 0, 1);                            \
+    } while (0)
+    if (dbg == 1) EMCID_LINEAR_LAUNCH(5, 1, 1, 4, 2, 1, 1);
+    else if (dbg == 2) EMCID_LINEAR_LAUNCH(5, 1, 1, 4, 2, 2, 1);
+    else switch (tile_sel) {
+        case 0: EMCID_LINEAR_PF(5, 1, 1, 4); break;
+        case 1: EMCID_LINEAR_PF(2, 2, 2, 2); break;
+        case 2: EMCID_LINEAR_PF(4, 2, 2, 2); break;
+        default: EMCID_LINEAR_PF(1, 1, 2, 2); break;
     }
+#undef EMCID_LINEAR_PF
 #undef EMCID_LINEAR_LAUNCH
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;

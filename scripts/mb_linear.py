@@ -50,9 +50,14 @@ for M, K, N, name in shapes:
         t = timeit(lambda: F.linear(x, w, b))
         tn.enable(False)
         line.append(f"tuned {t:7.1f} us {fl / t / 1e6:6.1f} TF")
-    for cfg, cn in ((-1, "auto"), (0, "160x128"), (1, "128x128"), (2, "256x128"), (3, "64x64")):
+    names = {0: "160x128", 1: "128x128", 2: "256x128", 3: "64x64"}
+    cfgs = [(-1, "auto")] + [(tile + 4 * (pf - 1), f"{names[tile]}/8w/pf{pf}") for tile in (0, 1, 2, 3) for pf in (1, 2)]
+    cfgs += [(64 + tile + 4 * (pf - 1), f"{names[tile]}/4w/pf{pf}") for tile, pf in ((0, 3), (1, 2), (3, 3))]
+    if os.environ.get("MB_DBG", "0") == "1":       # timing-only variants (wrong results): no loads in the loop / no LDS stores either
+        cfgs += [(0 + 4 + 16, "160x128/4w/noload"), (0 + 4 + 32, "160x128/4w/noload-nostore")]
+    for cfg, cn in cfgs:
         t = timeit(lambda: hip.linear(x, w, b, out=y, cfg=cfg))
-        line.append(f"{cn} {t:7.1f} us {fl / t / 1e6:6.1f} TF")
+        line.append(f"{cn} {t:6.1f} us {fl / t / 1e6:5.1f} TF")
     t = timeit(lambda: hip.linear(x, w, b, act=hip.ACT_QUICK_GELU, out=y))
     line.append(f"+gelu {t:7.1f}")
     t = timeit(lambda: hip.linear(x, w, b, residual=r, out=y))

@@ -589,12 +589,12 @@ def test_shadow_product_forced_and_off(mode):
 
 @pytest.mark.parametrize("M,K,N", [(6400, 768, 2304), (6400, 768, 768), (6400, 3072, 768), (3072, 768, 3072), (1000, 3072, 768),
                                    (777, 1280, 3840), (37, 48, 200), (1, 16, 1), (300, 5120, 1280), (161, 32, 129)])
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 64, 65 + 4, 66, 67 + 8, 64 + 8])   # tile + 4 (prefetch - 1) + 64 (4 waves)
 def test_linear_f32_vs_torch(M, K, N, cfg):
     """emcid_linear_f32 (csrc/gemm_f32.hip) against torch: the plain projection to fp32 rounding of an exact-f32 accumulation
     (reference of the same op: F.linear in fp64 rounded, and torch's own fp32 F.linear), every tile configuration, ragged
     edges; the fused epilogues (bias, quick_gelu, erf-gelu, residual — also in place) against the unfused torch ops."""
-    if cfg >= 0 and M * N * K > 6400 * 768 * 2304 // 2 and cfg == 3:
+    if cfg >= 0 and M * N * K > 6400 * 768 * 2304 // 2 and (cfg & 3) == 3:
         pytest.skip("64 x 64 tiles on the large shapes: covered by the smaller ones")
     g = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K + 4, generator=g).to(DEV)[:, :K]                 # row stride K + 4: a strided row view
@@ -603,7 +603,7 @@ def test_linear_f32_vs_torch(M, K, N, cfg):
     r = torch.randn(M, N, generator=g).to(DEV)
     ref = F.linear(x.double(), w.double(), b.double())
     scale = ref.abs().max().item()
-    tol = 4e-7 * scale * max(1.0, (K / 768) ** 0.5) + 1e-6
+    tol = 3e-6 * scale * max(1.0, (K / 768) ** 0.5) + 1e-6         # fp32 accumulation over K terms (torch's own: the same size)
     y = hip.linear(x, w, b, cfg=cfg)
     assert (y.double() - ref).abs().max().item() <= tol
     assert (y - F.linear(x, w, b)).abs().max().item() <= 2 * tol
