@@ -561,11 +561,253 @@ def compute_z_text_encoder(pipe, request: Dict, hparams, layer: int, device=None
     return (state["source_init"] + delta).detach()
 
 
-def stage1_for(pipe, hparams, layer: int, **kw):
+def compute_z_text_encoder_batched(pipe, requests: Sequence[Dict], hparams, layer: int, device=None, noise_scheduler=None,
+                                   resolution: int = 512, rng_device=None, batch_size: int = 8) -> List[torch.Tensor]:
+    """``[compute_z_text_encoder(pipe, r, ...) for r in requests]`` with ``batch_size`` concepts per Adam step: ONE hooked
+    text-encoder forward and ONE UNet forward / backward over the stacked prompts of the concepts (batched
+    across concepts Stage 1 is the wall-clock of a real mass edit; the reference runs it per request from the loop at
+    emcid/emcid_main.py:871-969).  Every concept keeps its own ``delta`` (one row of a (B, hidden) Adam parameter: Adam is
+    element-wise), its own loss terms, norm clamp and — what makes the result that of B sequential calls — its own random
+    draws: before the optimisation the draws of concept 1 (image flips; per step sample indices, VAE posterior noise, latent
+    noise, timesteps), then those of concept 2, ... are taken in exactly the order sequential calls would take them and kept.
+    The UNet and the encoder treat batch rows independently, so d(sum of losses)/d(delta_c) is concept c's own gradient;
+    what differs from sequential calls is fp32 rounding inside differently shaped GEMMs.  Concepts are stacked only with
+    concepts whose tokenized prompts have the same padded lengths (the UNet sees every position of the sequence)."""
+    from PIL import Image
+    hp = hparams
+    if getattr(hp, "use_ewc", False):
+        raise NotImplementedError("use_ewc needs the Fisher statistics of emcid/fim_cal.py (Stage-1 option outside the shipped hparams)")
+    te = pipe.text_encoder
+    dev = next(te.parameters()).device
+    rdev = torch.device(rng_device) if rng_device is not None else dev
+    host_draw = rdev.type == "cpu" and dev.type != "cpu"
+    tok = pipe.tokenizer
+    sched = noise_scheduler if noise_scheduler is not None else default_noise_scheduler()
+    objective = hp.objective
+    if objective not in ("ablate-source", "ablate-dest", "esd"):
+        raise ValueError(f"Objective {objective} can not be used for compute_z.")
+    spp, steps = hp.samples_per_prompt, hp.v_num_grad_steps
+    finder = finder_for(tok)
+    results: List[Optional[torch.Tensor]] = [None] * len(requests)
+    frozen = [prm for m in (te, pipe.vae, pipe.unet) for prm in m.parameters() if prm.requires_grad]
+    for prm in frozen:
+        prm.requires_grad_(False)
+    mod = get_module(te, hp.layer_module_tmp.format(layer))
+    try:
+        for lo in range(0, len(requests), max(1, int(batch_size))):
+            chunk = list(range(lo, min(len(requests), lo + max(1, int(batch_size)))))
+            # ---- phase A: per concept, in request order: inputs, loop invariants and ALL random draws ---------------------
+            ctxs = []
+            for ri in chunk:
+                request = requests[ri]
+                c = {"ri": ri, "request": request}
+                source_prompts = [p.format(request["source"]) for p in request["prompts"]]
+                dest_prompts = ["" for _ in request["prompts"]] if objective == "esd" else [p.format(request["dest"]) for p in request["prompts"]]
+                if "training_img_paths" in request and objective != "esd":
+                    images = [Image.open(path) for path in request["training_img_paths"]]
+                elif "images" in request and objective != "esd":
+                    images = request["images"]
+                else:
+                    gen = torch.Generator(dev).manual_seed(int(request["seed_train"])) if request.get("seed_train") is not None else None
+                    images = []
+                    for _ in range(spp):
+                        images.extend(pipe(source_prompts, guidance_scale=7.5, generator=gen).images)
+                pixels = preprocess_img(images, resolution)
+                bsz = len(source_prompts)
+                pixels = pixels.reshape(spp, bsz, *pixels.shape[1:]).transpose(0, 1)
+                if len(pixels) % bsz:
+                    raise AssertionError(f"len(img_batch) {len(pixels)} should be n times of batch size {bsz}")
+                src_inp, dst_inp = tokenize_prompts(source_prompts, tok, dev), tokenize_prompts(dest_prompts, tok, dev)
+                src_lookup = [finder(ids, request["source"])[-1] - 1 for ids in src_inp["input_ids"].tolist()]
+                dst_lookup = [finder(ids, request["dest"])[-1] - 1 for ids in dst_inp["input_ids"].tolist()]
+                if not (len(src_inp["input_ids"]) == len(dst_inp["input_ids"]) == len(pixels)):
+                    raise AssertionError("The number of prompts and images should be the same.")
+                c.update(bsz=bsz, src_inp=src_inp, src_lookup=src_lookup, dst_lookup=dst_lookup)
+                with torch.no_grad():
+                    c["dest_repr"], c["dest_pool"] = te(**dst_inp)[0:2]
+                    c["source_repr"] = te(**src_inp)[0] if (objective == "esd" or hp.cal_text_repr_loss) else None
+                    if hp.contrastive_text_loss:
+                        c["neg_pool"] = te(**tokenize_prompts(request["negative_prompts"], tok, dev))[1]
+                        c["single_pool"] = te(**tokenize_prompts([request["dest"]], tok, dev))[1]
+                    if hp.align_obj_eos_pad:
+                        full = lambda ps: {k: v.to(dev) for k, v in tok(ps, max_length=tok.model_max_length, return_tensors="pt",
+                                                                        padding="max_length", truncation=True).items()}
+                        src_full, dst_full = full(source_prompts), full(dest_prompts)
+                        src_eos = [int(m.sum()) - 1 for m in src_full["attention_mask"]]
+                        dst_eos = [int(m.sum()) - 1 for m in dst_full["attention_mask"]]
+                        far = max(src_eos + dst_eos)
+                        c["src_full"] = src_full
+                        c["src_slices"] = [list(range(e, tok.model_max_length - max(0, far - e))) for e in src_eos]
+                        dst_slices = [list(range(e, tok.model_max_length - max(0, far - e))) for e in dst_eos]
+                        dest_full = te(**dst_full)[0]
+                        c["d_pad"] = torch.stack([dest_full[i, sl, :] for i, sl in enumerate(dst_slices)], dim=0)
+                # the draws of every step, in the order compute_z_text_encoder takes them
+                posteriors, draws = {}, []
+                for _ in range(steps):
+                    sample_indices = torch.randint(0, spp, (bsz,))
+                    key = tuple(sample_indices.tolist())
+                    if key not in posteriors:
+                        with torch.no_grad():
+                            posteriors[key] = pipe.vae.encode(pixels[torch.arange(bsz), sample_indices].to(dev)).latent_dist
+                    with torch.no_grad():
+                        latents = posteriors[key].sample(torch.default_generator) if host_draw else posteriors[key].sample()
+                        latents = latents * pipe.vae.config.scaling_factor
+                    if host_draw:
+                        noise = torch.randn(latents.shape, dtype=latents.dtype).to(dev)
+                        timesteps = torch.randint(0, sched.config.num_train_timesteps, (bsz,)).long().to(dev)
+                    else:
+                        noise = torch.randn_like(latents, device=dev)
+                        timesteps = torch.randint(0, sched.config.num_train_timesteps, (bsz,), device=dev).long()
+                    draws.append((sched.add_noise(latents, noise, timesteps), noise, timesteps))
+                c["draws"] = draws
+                ctxs.append(c)
+            # ---- phase B: concepts with equal padded prompt lengths share the forward / backward passes --------------------
+            groups: Dict[tuple, List[dict]] = {}
+            for c in ctxs:
+                groups.setdefault((c["src_inp"]["input_ids"].shape[1], c["dest_repr"].shape[1]), []).append(c)
+            for members in groups.values():
+                _stage1_optimise_group(pipe, te, mod, hp, members, steps, dev)
+                for c in members:
+                    results[c["ri"]] = c["v_star"]
+    finally:
+        for prm in frozen:
+            prm.requires_grad_(True)
+    return results
+
+
+def _stage1_optimise_group(pipe, te, mod, hp, members, steps, dev):
+    """The Adam loop of compute_z_text_encoder for several concepts at once (rows of concept c: [off[c], off[c + 1]))."""
+    objective = hp.objective
+    B = len(members)
+    sizes = [c["bsz"] for c in members]
+    off = np.cumsum([0] + sizes)
+    rows = int(off[-1])
+    owner = torch.tensor(np.repeat(np.arange(B), sizes), device=dev)                   # concept of every stacked row
+    ar = torch.arange(rows, device=dev)
+    src_idx = torch.tensor([i for c in members for i in c["src_lookup"]], device=dev)
+    dst_idx = torch.tensor([i for c in members for i in c["dst_lookup"]], device=dev)
+    cat = lambda key: {k: torch.cat([c[key][k] for c in members], dim=0) for k in members[0][key]}
+    src_inp = cat("src_inp")
+    dest_repr = torch.cat([c["dest_repr"] for c in members], dim=0)
+    dest_pool = torch.cat([c["dest_pool"] for c in members], dim=0)
+    source_repr = torch.cat([c["source_repr"] for c in members], dim=0) if members[0]["source_repr"] is not None else None
+    src_full = cat("src_full") if hp.align_obj_eos_pad else None
+    delta = torch.zeros((B, te.config.hidden_size), requires_grad=True, device=dev)
+    opt = torch.optim.Adam([delta], lr=hp.v_lr)
+    state = {"edit": False, "source_init": None}
+
+    def hook(module, args, out):
+        if not state["edit"]:
+            return out
+        h = out[0] if isinstance(out, tuple) else out
+        if state["source_init"] is None:          # per concept: the clean state at the lookup token of its FIRST prompt
+            first = torch.tensor(off[:-1], device=dev)
+            state["source_init"] = h[first, src_idx[first]].detach().clone()
+        h = h.clone()
+        per_row = delta.index_select(0, owner)
+        h[ar, src_idx, :] = per_row if hp.replace_repr else h[ar, src_idx, :] + per_row
+        return (h,) + tuple(out[1:]) if isinstance(out, tuple) else h
+
+    def edited(inp):
+        state["edit"] = True
+        try:
+            return te(**inp)[0:2]
+        finally:
+            state["edit"] = False
+
+    def per_concept_mse(a, b):
+        """[F.mse_loss(a[rows of c], b[rows of c]) for c]: every row has the same number of elements."""
+        per_row = ((a - b) ** 2).reshape(rows, -1).mean(dim=1)
+        return torch.zeros(B, device=dev, dtype=per_row.dtype).index_add(0, owner, per_row) / torch.tensor(sizes, device=dev, dtype=per_row.dtype)
+
+    handle = mod.register_forward_hook(hook)
+    try:
+        for it in range(steps):
+            opt.zero_grad()
+            noisy = torch.cat([c["draws"][it][0] for c in members], dim=0)
+            noise = torch.cat([c["draws"][it][1] for c in members], dim=0)
+            timesteps = torch.cat([c["draws"][it][2] for c in members], dim=0)
+            edit_repr, edit_pool = edited(src_inp)
+            source_init = state["source_init"]                                       # (B, hidden)
+            if not hp.no_noise_loss:
+                edit_pred = pipe.unet(noisy, timesteps, edit_repr).sample
+                with torch.no_grad():
+                    pred_dest = pipe.unet(noisy, timesteps, dest_repr).sample
+            reg = hp.v_weight_decay * (torch.norm(delta, dim=1) / torch.norm(source_init, dim=1) ** 2)       # (B,)
+            if "ablate" in objective:
+                if getattr(hp, "use_sampled_noise", False):
+                    loss = per_concept_mse(noise, edit_pred) + reg
+                elif hp.no_noise_loss:
+                    loss = reg
+                else:
+                    real = [bool(c["request"].get("use_real_noise", False)) for c in members]
+                    loss = per_concept_mse(edit_pred, pred_dest) + reg
+                    if any(real):
+                        sel = torch.tensor(real, device=dev)
+                        loss = torch.where(sel, per_concept_mse(noise, edit_pred) + reg, loss)
+            else:
+                with torch.no_grad():
+                    pred_source = pipe.unet(noisy, timesteps, source_repr).sample
+                loss = per_concept_mse(edit_pred, pred_dest - hp.esd_mu * (pred_source - pred_dest)) + reg
+            if hp.cal_text_repr_loss:
+                scale = hp.text_repr_loss_scale_factor
+                align = torch.tensor([bool(c["request"].get("txt_align", True)) for c in members], device=dev)
+                if hp.contrastive_text_loss:
+                    terms = []
+                    for ci, c in enumerate(members):
+                        emb = torch.cat([c["single_pool"], c["neg_pool"]], dim=0)
+                        scores = torch.squeeze(-torch.cdist(edit_pool[off[ci]:off[ci + 1]].unsqueeze(0), emb.unsqueeze(0)))
+                        terms.append(-torch.log_softmax(scores, dim=1)[:, 0].mean(dim=0))
+                    term = torch.stack(terms)
+                elif hp.align_object_token:
+                    term = per_concept_mse(edit_repr[ar, src_idx, :], dest_repr[ar, dst_idx, :])
+                elif hp.align_obj_eos_pad:
+                    e_full = edited(src_full)[0]
+                    terms = []
+                    for ci, c in enumerate(members):
+                        r0 = int(off[ci])
+                        e_pad = torch.stack([e_full[r0 + i, sl, :] for i, sl in enumerate(c["src_slices"])], dim=0)
+                        sl_rows = slice(r0, int(off[ci + 1]))
+                        terms.append(F.mse_loss(torch.cat([edit_repr[ar[sl_rows], src_idx[sl_rows], :].unsqueeze(1), e_pad], dim=1),
+                                                torch.cat([dest_repr[ar[sl_rows], dst_idx[sl_rows], :].unsqueeze(1), c["d_pad"]], dim=1),
+                                                reduction="mean"))
+                    term = torch.stack(terms)
+                else:
+                    term = per_concept_mse(edit_pool, dest_pool)
+                loss = loss + torch.where(align, scale * term, torch.zeros_like(term))
+            loss.sum().backward()
+            opt.step()
+            with torch.no_grad():
+                max_norm = hp.clamp_norm_factor * source_init.norm(dim=1)
+                nrm = delta.norm(dim=1)
+                factor = torch.where(nrm > max_norm, max_norm / nrm, torch.ones_like(nrm))
+                delta.mul_(factor.unsqueeze(1))
+    finally:
+        handle.remove()
+    out = (state["source_init"] + delta).detach()
+    for ci, c in enumerate(members):
+        c["v_star"] = out[ci].clone()
+        c.pop("draws", None)
+
+
+def stage1_for(pipe, hparams, layer: int, batch_size: Optional[int] = None, **kw):
     """The ``stage1=`` callable emcid_main's v* cache expects (``stage1(request, suffix) -> v*``) for a pipeline that carries
-    a UNet and a VAE: Stage 1 on a cache miss, like the reference (emcid_main.py:905-969)."""
+    a UNet and a VAE: Stage 1 on a cache miss, like the reference (emcid_main.py:905-969).  Its ``batch(requests, suffix)``
+    attribute serves all misses of a request list at once (compute_z_text_encoder_batched; EMCID_STAGE1_BATCH concepts per
+    Adam step, default 8; 1 = one concept at a time)."""
     def stage1(request, suffix=""):
         if suffix:
             raise NotImplementedError("the SDXL pair optimisation compute_z_sdxl_text_encoders (compute_z.py:651-1037) is not built")
         return compute_z_text_encoder(pipe, request, hparams, layer, **kw)
+
+    def batch(requests, suffix=""):
+        if suffix:
+            raise NotImplementedError("the SDXL pair optimisation compute_z_sdxl_text_encoders (compute_z.py:651-1037) is not built")
+        import os
+        bs = batch_size if batch_size is not None else int(os.environ.get("EMCID_STAGE1_BATCH", "8"))
+        if bs <= 1:
+            return [compute_z_text_encoder(pipe, r, hparams, layer, **kw) for r in requests]
+        return compute_z_text_encoder_batched(pipe, requests, hparams, layer, batch_size=bs, **kw)
+
+    stage1.batch = batch
     return stage1

@@ -215,11 +215,12 @@ def load_v_stars(requests: Sequence[Dict], hparams, cache_name: Optional[str], s
     native = _native_vstar_rows(names, int(width), pin) if (width and cache_name is not None and len(names)) else None
     if native is not None and not native[1].any():
         return native[0]
-    rows = []
+    rows: List[Optional[np.ndarray]] = [None] * len(requests)
+    missing: List[int] = []
     for idx, request in enumerate(requests):
         f = names[idx]
         if native is not None and native[1][idx] == 0:
-            rows.append(native[0][idx].numpy())
+            rows[idx] = native[0][idx].numpy()
             continue
         v = None
         if f is not None and not (native is not None and native[1][idx] == 1):
@@ -236,18 +237,31 @@ def load_v_stars(requests: Sequence[Dict], hparams, cache_name: Optional[str], s
                     f"no cached v* for request {idx} ([{request['source']}] -> [{request['dest']}]) at {f}: "
                     f"pass cache_name pointing at v_star npz files (reference emcid_main.py:873-890) or a stage1= "
                     f"callable (emcid_amd.compute_z.compute_z_text_encoder is the reference's Stage 1)")
-            with torch.enable_grad():      # Stage 1 is an optimisation through the UNet, whatever mode the caller is in
-                v = stage1(request, suffix).detach().float().cpu().numpy()
-            if f is not None:
-                Path(f).parent.mkdir(exist_ok=True, parents=True)
-                np.savez(f, v_star=v)
+            missing.append(idx)
+            continue
+        rows[idx] = v
+    if missing:
+        # Stage 1 for every miss, in request order like the reference's loop (:871-969) — through the callable's ``batch``
+        # attribute when it has one (compute_z.stage1_for: several concepts per Adam step), else one request at a time
+        with torch.enable_grad():      # Stage 1 is an optimisation through the UNet, whatever mode the caller is in
+            if hasattr(stage1, "batch") and len(missing) > 1:
+                found = stage1.batch([requests[i] for i in missing], suffix)
+            else:
+                found = [stage1(requests[i], suffix) for i in missing]
+        for idx, v in zip(missing, found):
+            v = v.detach().float().cpu().numpy()
+            if names[idx] is not None:
+                Path(names[idx]).parent.mkdir(exist_ok=True, parents=True)
+                np.savez(names[idx], v_star=v)
+            rows[idx] = v
+    for idx, v in enumerate(rows):
         if v.dtype != np.float32:
             v = v.astype(np.float32)
         if v.ndim == 2:   # use_new_compute_z layout (num_edit_tokens, hidden) with num_edit_tokens == 1
             if v.shape[0] != 1:
                 raise NotImplementedError("num_edit_tokens > 1 is not built (unused by shipped hparams)")
             v = v[0]
-        rows.append(v)
+        rows[idx] = v
     return torch.from_numpy(np.stack(rows, axis=0))
 
 

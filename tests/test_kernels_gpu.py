@@ -349,10 +349,13 @@ def test_dual_solver_reuses_factor_for_another_lambda(N, d, h, lam0, lam, left):
     W = torch.empty(h, d, device=DEV)
     cols = hip.edit_layer_dual_cols(Kd, Zd, zd, fac0, 0, ew, left, W0d, W, list(range(fac0.dp // 128)), lambda t: t, lam=lam)
     assert (cols["dW"].cpu().double() - upd).abs().max().item() <= 1e-6 * scale + 1e-12
-    # lam_ratio = 1 is bit-identical to not passing lam at all
+    # lam_ratio = 1 is the call without lam: the same launches with the same arguments — bit-identical where the schedule is
+    # reproducible (from 512 padded concepts the N x N SYRK is the two-phase stream-K; below, its K split adds with f64 atomics)
     a = hip.edit_layer_dual_apply(Kd, Zd, zd, fac0, 0, ew, left, W0d, torch.empty(h, d, device=DEV))
     b = hip.edit_layer_dual_apply(Kd, Zd, zd, fac0, 0, ew, left, W0d, torch.empty(h, d, device=DEV), lam=lam0)
-    assert torch.equal(a["dW"], b["dW"])
+    if N > 384:
+        assert torch.equal(a["dW"], b["dW"])
+    assert (a["dW"] - b["dW"]).abs().max().item() <= 2e-7 * a["dW"].abs().max().item()
 
 
 @pytest.mark.parametrize("N,d,h,lam,world", [(1000, 5120, 1280, 10000.0, 2), (300, 5120, 1280, 10000.0, 7), (1000, 3072, 768, 4000.0, 8)])

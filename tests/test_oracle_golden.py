@@ -303,3 +303,48 @@ def test_uce_closed_form_golden(case):
                     assert (mods[n].weight - want).abs().max().item() <= tol * want.abs().max().item(), n
                 else:
                     assert torch.equal(mods[n].weight, w0[n])
+
+
+def _stage1_requests(z, meta, name, n):
+    """n concepts derived from a golden case: other sources / dests / prompt subsets / images (ragged prompt counts and token lengths)."""
+    from PIL import Image
+    c = meta["cases"][name]
+    base = c["request"]
+    imgs = [Image.fromarray(a, "RGB") for a in z[f"{name}/images"]]
+    P = len(base["prompts"])
+    spp = len(imgs) // P
+    per_prompt = [[imgs[s * P + b] for s in range(spp)] for b in range(P)]          # "(s b)" order of the fixture
+    names = [base["source"], "c0001", "vincent", "c0002 c0003", "church"]
+    dests = [base["dest"], "a photo", "tench", "c0009", "a realist artist"]
+    reqs = []
+    for i in range(n):
+        keep = list(range(P)) if i % 2 == 0 else list(range(max(1, P - 1)))
+        r = dict(base, source=names[i % len(names)], dest=dests[i % len(dests)], prompts=[base["prompts"][b] for b in keep])
+        r["images"] = [per_prompt[b][s] for s in range(spp) for b in keep]
+        if "negative_prompts" in base:
+            r["negative_prompts"] = base["negative_prompts"]
+        reqs.append(r)
+    return c, reqs
+
+
+@pytest.mark.parametrize("name", ["shipped", "ablate_source_object_token", "eos_pad_replace"])
+def test_stage1_batched_equals_sequential_calls(name):
+    """compute_z_text_encoder_batched == [compute_z_text_encoder(r) for r in requests] (B concepts per Adam
+    step): same random draws per concept in the same order, per-concept losses / Adam rows / norm clamps; what differs is fp32
+    rounding inside differently shaped batches.  Five ragged concepts (prompt counts, token lengths), batch sizes 2 and 5;
+    the first concept alone is the golden case itself.  Observed: <= 2.4e-7 relative."""
+    from emcid_amd.compute_z import compute_z_text_encoder, compute_z_text_encoder_batched
+    z, meta = load_golden("toy_stage1")
+    c, reqs = _stage1_requests(z, meta, name, 5)
+    hp = EMCIDHyperParams(**c["hparams"])
+    kw = dict(noise_scheduler=syn.DDPMNoiseSchedule(), resolution=meta["resolution"])
+    pipe = syn.add_diffusion(syn.build_pipe("toy", "cpu"))
+    torch.manual_seed(c["seed"])
+    seq = [compute_z_text_encoder(pipe, r, hp, c["layer"], **kw) for r in reqs]
+    for bs in (2, 5):
+        torch.manual_seed(c["seed"])
+        got = compute_z_text_encoder_batched(pipe, reqs, hp, c["layer"], batch_size=bs, **kw)
+        assert len(got) == len(seq)
+        for a, b in zip(got, seq):
+            assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item(), (bs, (a - b).abs().max().item(), b.abs().max().item())
+    assert all(p.requires_grad is False for p in pipe.text_encoder.parameters())
