@@ -200,6 +200,8 @@ KERNEL_OF_CLASS = {
                  "mirrored tile pairs where their count fills the chip evenly (N = 1000, d = 3072), else gemm_f64_streamk2_kernel "
                  "<KC,*,128,128,16,2,4>",
     "inv_build": "gemm_f64_kernel<KC,!KC,*,*,16,*> launched as recursive-halving build of X = inv(L)",
+    "linear": "linear_f32_kernel (csrc/gemm_f32.hip): the forward's projections Y = act(X W^T + b) + residual on v_mfma_f32_32x32x2_f32, "
+              "128 x 128 tiles on 4 waves or 160 x 128 on 8 waves (K split inside the workgroup) by the launch's fill of the chip",
 }
 FP64_CLASSES = ["assemble", "chol_leaf", "chol_panel", "chol_trail", "chol_inner", "chol_fused", "inv_block", "trsm_diag",
                 "trsm_update", "delta_w", "inv_build", "inv_apply"]
@@ -375,9 +377,11 @@ def main():
     # ---- roofline: the same K device steps once more with every kernel class bracketed by HIP events on the launch stream
     # (emcid_profile_*; graph replay is bypassed while events are recorded, kernels and arguments are identical) ------------
     hip.profile_enable([c for c in hip.PROF_CLASSES])
+    hip.LINEAR_FLOPS.update(count=True, flops=0.0, launches=0)
     for _ in range(args.steps):
         device_step()
     sync()
+    hip.LINEAR_FLOPS["count"] = False
     prof = hip.profile_collect()
     hip.profile_enable([])
     d, h = 3072, 768
@@ -404,9 +408,48 @@ def main():
              "survey_8d_flops_per_step": survey_flops,
              "survey_8d_frac_over_solve_time": survey_flops / (solve_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS if solve_ms else None,
              "survey_8d_frac_over_device_step": survey_flops / (device_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS}
+    # the forward's projections (class "linear", fp32 MFMA): algorithmic 2 M N K of every launch of the profiled steps.  The
+    # device step does not include the leading layers (prepare launches them), so they are timed by a separate prepare here.
+    lin = None
+    if "linear" in prof:
+        lin_ms, lin_launches = prof["linear"]
+        lin_flops = hip.LINEAR_FLOPS["flops"]
+        hip.profile_enable(["linear"])
+        hip.LINEAR_FLOPS.update(count=True, flops=0.0, launches=0)
+        for _ in range(3):
+            em.prepare_text_encoder_edit(pipe.text_encoder, pipe.tokenizer, reqs, hp, hp.layers, hp.mom2_update_weight, stats, cache, "",
+                                         verbose=False, shard=shard)
+        sync()
+        hip.LINEAR_FLOPS["count"] = False
+        pre = hip.profile_collect().get("linear", (0.0, 0))
+        hip.profile_enable([])
+        pre_flops = hip.LINEAR_FLOPS["flops"]
+        tot_ms = lin_ms / args.steps + pre[0] / 3
+        tot_flops = lin_flops / args.steps + pre_flops / 3
+        tot_launches = lin_launches / args.steps + pre[1] / 3
+        lin = {"ms_per_step": tot_ms, "launches_per_step": tot_launches, "algorithmic_flops_per_step": tot_flops,
+               "tflops": tot_flops / (tot_ms * 1e-3) / 1e12, "frac_f32_mfma_peak": tot_flops / (tot_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+               "leading_layers_ms": pre[0] / 3, "edited_layers_ms": lin_ms / args.steps}
+        classes["linear"] = lin
     roofline = None
-    if f64:
-        top = max(f64, key=lambda c: prof[c][0])
+    top = max(f64, key=lambda c: prof[c][0]) if f64 else None
+    if lin is not None and (top is None or lin["ms_per_step"] >= prof[top][0] / args.steps):
+        # the class with the most time of a call is the forward's GEMM kernel
+        pmc = REPO / "profiles" / "r03_pmc_linear.json"
+        traffic = traffic_note = None
+        if pmc.exists():
+            with open(pmc) as fh:
+                rec = json.load(fh)
+            traffic, traffic_note = rec.get("traffic_bytes_per_launch"), rec.get("note")
+        roofline = {"bound": "mfma", "kernel": KERNEL_OF_CLASS["linear"], "class": "linear", "achieved": lin["tflops"],
+                    "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": lin["frac_f32_mfma_peak"], "dtype": "f32",
+                    "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_note": traffic_note,
+                    "avg_launch_us": lin["ms_per_step"] * 1e3 / lin["launches_per_step"], "launches_per_step": lin["launches_per_step"],
+                    "flops_per_launch": lin["algorithmic_flops_per_step"] / lin["launches_per_step"],
+                    "selection": "the kernel class with the most time per call over ALL classes (forward GEMMs and fp64 solve)",
+                    "next": (None if top is None else {"class": top, "ms_per_step": prof[top][0] / args.steps,
+                                                       "frac_f64_mfma_peak": classes[top].get("frac_f64_mfma_peak")})}
+    elif top is not None:
         ms, launches = prof[top]
         achieved = flops.get(top, 0) * args.steps / (ms * 1e-3) / 1e12      # = flops per launch / average launch duration
         traffic, traffic_note = None, None
@@ -421,7 +464,7 @@ def main():
                     "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_note": traffic_note,
                     "avg_launch_us": ms * 1e3 / launches, "launches": launches,
                     "flops_per_launch": flops.get(top, 0) * args.steps / launches,
-                    "selection": "the fp64 class with the most time per step among ALL classes of the solve",
+                    "selection": "the kernel class with the most time per call over ALL classes (forward GEMMs and fp64 solve)",
                     "solver": "dual" if dual else "direct"}
 
     replay_ms = statistics.median(replay_per) * 1e3
@@ -475,8 +518,9 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_variants:
-        log("secondary records: n100, sdxl, cold_process")
+        log("secondary records: n100, sdxl, stage1, cold_process")
         for name, fn in (("n100", lambda: n100_record(workdir, device)), ("sdxl", lambda: sdxl_record(workdir, device)),
+                         ("stage1", lambda: stage1_record(device)),
                          ("cold_process", lambda: cold_process_record(workdir, device))):
             try:
                 out[name] = fn()
@@ -754,6 +798,45 @@ def sdxl_record(workdir, device, n=1000, calls=5):
             "trie_rows": [p1.trie.n_nodes, p2.trie.n_nodes], "survey_8d_flops_per_step": survey,
             "roofline": roofline, "solve": solve,
             "kernel_classes": {c: r for c, r in classes.items() if c in FP64_CLASSES}}
+
+
+def stage1_record(device, n=16, steps=10, batch=8):
+    """Stage 1 (compute_z_text_encoder: the Adam optimisation of v* through the UNet) on this GPU: concepts/s
+    one concept at a time and `batch` concepts per Adam step.  SD-v1.4 text encoder (768 / 12 layers, random init); the UNet /
+    VAE are the synthetic stand-ins (the 32 cross-attention projections at their real widths; no conv stack — there is no
+    diffusers package or checkpoint here), so this prices the text-encoder side and the per-step overheads, not a real UNet."""
+    import torch
+    from emcid_amd import synthetic as syn
+    from emcid_amd.compute_z import compute_z_text_encoder, compute_z_text_encoder_batched
+    from emcid_amd.emcid_hparams import EMCIDHyperParams
+
+    pipe = syn.add_diffusion(syn.build_pipe(KIND, device, syllables=True), KIND)
+    reqs = [dict(r, images=syn.make_images(len(r["prompts"]), 64, seed=90 + i))
+            for i, r in enumerate(syn.make_requests(n, names="syllable"))]
+    hp_d = syn.sd_hparams_dict(layers=LAYERS, mom2_update_weight=LAM, edit_weight=EW)
+    hp_d.update(v_num_grad_steps=steps, cal_text_repr_loss=True)
+    hp = EMCIDHyperParams(**hp_d)
+    kw = dict(noise_scheduler=syn.DDPMNoiseSchedule(), resolution=64)
+    compute_z_text_encoder(pipe, reqs[0], hp, LAYERS[-1], **kw)                    # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    torch.manual_seed(3)
+    seq = [compute_z_text_encoder(pipe, r, hp, LAYERS[-1], **kw) for r in reqs]
+    torch.cuda.synchronize()
+    t_seq = time.perf_counter() - t0
+    compute_z_text_encoder_batched(pipe, reqs[:batch], hp, LAYERS[-1], batch_size=batch, **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    torch.manual_seed(3)
+    bat = compute_z_text_encoder_batched(pipe, reqs, hp, LAYERS[-1], batch_size=batch, **kw)
+    torch.cuda.synchronize()
+    t_bat = time.perf_counter() - t0
+    dev_err = max(((a - b).abs().max() / b.abs().max()).item() for a, b in zip(bat, seq))
+    return {"workload": f"{n} concepts x 3 prompts, {steps} Adam steps each (shipped: 100), SD-v1.4 text encoder, synthetic UNet / VAE "
+                        f"stand-ins, 64 x 64 images",
+            "concepts_per_s_sequential": n / t_seq, "concepts_per_s_batched": n / t_bat, "batch": batch,
+            "seconds_sequential": t_seq, "seconds_batched": t_bat, "speedup": t_seq / t_bat,
+            "max_rel_deviation_batched_vs_sequential": dev_err}
 
 
 def cold_child(workdir, n):

@@ -469,6 +469,7 @@ def quick_gelu(x: torch.Tensor) -> torch.Tensor:
 
 
 ACT_NONE, ACT_QUICK_GELU, ACT_GELU_ERF = 0, 1, 2
+LINEAR_FLOPS = {"count": False, "flops": 0.0, "launches": 0}      # bench.py's roofline pass: algorithmic 2 M N K of every launch
 
 
 def linear_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
@@ -495,6 +496,9 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         raise EmcidHipError("linear: bias must be a contiguous (N,) vector")
     if residual is not None and (residual.shape != (M, N) or residual.stride(1) != 1):
         raise EmcidHipError("linear: residual must be an (M, N) row view")
+    if LINEAR_FLOPS["count"]:
+        LINEAR_FLOPS["flops"] += 2.0 * M * N * K
+        LINEAR_FLOPS["launches"] += 1
     _check(load().emcid_linear_f32(_ptr(x, torch.float32, "x"), x.stride(0), _ptr(w, torch.float32, "w"), w.stride(0),
                                    _ptr(bias, torch.float32, "bias"), _ptr(residual, torch.float32, "residual"),
                                    residual.stride(0) if residual is not None else 0, _ptr(out, torch.float32, "out"),

@@ -702,21 +702,25 @@ def test_vstar_cache_miss_runs_stage1_then_edits(tmp_path):
     syn.write_stats_cache(tmp_path / "stats", names, 128, 1000, seed=2, t=512)
     cache = str(tmp_path / "cache") + "/"
     import emcid_amd.compute_z as cz
-    real = cz.compute_z_text_encoder
+    real, real_b = cz.compute_z_text_encoder, cz.compute_z_text_encoder_batched
     calls = []
 
     def small(pipe, request, hparams, layer, **kw):
         calls.append(request["source"])
         return real(pipe, request, hparams, layer, noise_scheduler=syn.DDPMNoiseSchedule(), resolution=32, **kw)
 
-    cz.compute_z_text_encoder = small
+    def small_b(pipe, requests, hparams, layer, **kw):       # the misses of one call arrive together, in request order
+        calls.extend(r["source"] for r in requests)
+        return real_b(pipe, requests, hparams, layer, noise_scheduler=syn.DDPMNoiseSchedule(), resolution=32, **kw)
+
+    cz.compute_z_text_encoder, cz.compute_z_text_encoder_batched = small, small_b
     try:
         pipe = syn.add_diffusion(syn.build_pipe("toy", DEV))
         torch.manual_seed(3)
         em.apply_emcid_to_text_encoder(pipe, reqs, EMCIDHyperParams(**hp_d), DEV, cache_name=cache,
                                        stats_dir=str(tmp_path / "stats"), verbose=False)
     finally:
-        cz.compute_z_text_encoder = real
+        cz.compute_z_text_encoder, cz.compute_z_text_encoder_batched = real, real_b
     assert calls == [r["source"] for r in reqs]
     files = sorted((tmp_path / "cache").glob("*.npz"))
     assert len(files) == 3 and np.load(files[0])["v_star"].shape == (32,)
@@ -726,3 +730,56 @@ def test_vstar_cache_miss_runs_stage1_then_edits(tmp_path):
                                    stats_dir=str(tmp_path / "stats"), verbose=False, stage1=lambda *a: 1 / 0)   # served from the cache
     for n in names:
         assert torch.equal(get_parameter(pipe2.text_encoder, n + ".weight").cpu(), w1[n])
+
+
+def _stage1_sd_setup(n, steps=4):
+    reqs = [dict(r, images=syn.make_images(len(r["prompts"]), 32, seed=70 + i))
+            for i, r in enumerate(syn.make_requests(n, names="syllable", ragged=True))]
+    hp_d = syn.sd_hparams_dict(layers=(7, 8, 9, 10), mom2_update_weight=4000, edit_weight=0.5, mom2_n_samples=1000)
+    hp_d.update(v_num_grad_steps=steps, cal_text_repr_loss=True)
+    return reqs, hp_d
+
+
+def test_stage1_real_width_gpu_vs_cpu_oracle():
+    """Stage 1 at SD-v1.4 text-encoder dimensions (hidden 768, 12 layers, the 32 cross-attention projections of the UNet
+    stand-in at their real widths): the product on the MI355X (random draws from the host generator) against the oracle's
+    op-for-op restatement on the CPU, same seed — fp32 forward / backward on two devices."""
+    from emcid_amd.compute_z import compute_z_text_encoder
+    reqs, hp_d = _stage1_sd_setup(2)
+    kw = dict(noise_scheduler=syn.DDPMNoiseSchedule(), resolution=32)
+    cpu = syn.add_diffusion(syn.build_pipe("sd-v1.4", "cpu", syllables=True), "sd-v1.4")
+    gpu = syn.add_diffusion(syn.build_pipe("sd-v1.4", DEV, syllables=True), "sd-v1.4")
+    for r in reqs:
+        torch.manual_seed(11)
+        ref = orc.compute_z_text_encoder(cpu, r, hp_d, 10, syn.DDPMNoiseSchedule(), 32)
+        torch.manual_seed(11)
+        got = compute_z_text_encoder(gpu, r, EMCIDHyperParams(**hp_d), 10, rng_device="cpu", **kw)
+        assert got.is_cuda and got.shape == (768,)
+        assert (got.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+def test_stage1_batched_through_apply_on_a_cold_cache(tmp_path, monkeypatch):
+    """apply_emcid_to_text_encoder on a cold v* cache with 7 ragged requests at SD-v1.4 dims: the misses are collected and
+    optimised in batches (compute_z_text_encoder_batched, 4 concepts per Adam step), the cache is written, and v* and the
+    edited weights equal those of one-concept-at-a-time Stage 1 (EMCID_STAGE1_BATCH=1) on the same seed."""
+    reqs, hp_d = _stage1_sd_setup(7, steps=3)
+    names = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers"]]
+    syn.write_stats_cache(tmp_path / "stats", names, 3072, 1000, seed=2, t=6144)
+    out = {}
+    for mode, bs in (("seq", "1"), ("batched", "4")):
+        monkeypatch.setenv("EMCID_STAGE1_BATCH", bs)
+        em.clear_caches()
+        pipe = syn.add_diffusion(syn.build_pipe("sd-v1.4", DEV, syllables=True), "sd-v1.4")
+        cache = str(tmp_path / f"cache_{mode}") + "/"
+        torch.manual_seed(5)
+        from emcid_amd.compute_z import stage1_for
+        st1 = stage1_for(pipe, EMCIDHyperParams(**hp_d), 10, noise_scheduler=syn.DDPMNoiseSchedule(), resolution=32, rng_device="cpu")
+        em.apply_emcid_to_text_encoder(pipe, reqs, EMCIDHyperParams(**hp_d), DEV, cache_name=cache,
+                                       stats_dir=str(tmp_path / "stats"), verbose=False, stage1=st1)
+        vs = em.load_v_stars(reqs, EMCIDHyperParams(**hp_d), cache)
+        assert vs.shape == (7, 768)
+        out[mode] = (vs, {n: get_parameter(pipe.text_encoder, n + ".weight").detach().cpu() for n in names})
+    assert (out["batched"][0] - out["seq"][0]).abs().max().item() <= 1e-5 * out["seq"][0].abs().max().item()
+    for n in names:
+        a, b = out["batched"][1][n], out["seq"][1][n]
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
