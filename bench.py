@@ -408,28 +408,14 @@ def main():
              "survey_8d_flops_per_step": survey_flops,
              "survey_8d_frac_over_solve_time": survey_flops / (solve_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS if solve_ms else None,
              "survey_8d_frac_over_device_step": survey_flops / (device_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS}
-    # the forward's projections (class "linear", fp32 MFMA): algorithmic 2 M N K of every launch of the profiled steps.  The
-    # device step does not include the leading layers (prepare launches them), so they are timed by a separate prepare here.
+    # the forward's projections (class "linear", fp32 MFMA): algorithmic 2 M N K of every launch of the profiled steps (a device
+    # step on a plan whose prepared state has been used runs the leading layers itself, so all of the forward is in here)
     lin = None
-    if "linear" in prof:
+    if "linear" in prof and hip.LINEAR_FLOPS["flops"] > 0:
         lin_ms, lin_launches = prof["linear"]
-        lin_flops = hip.LINEAR_FLOPS["flops"]
-        hip.profile_enable(["linear"])
-        hip.LINEAR_FLOPS.update(count=True, flops=0.0, launches=0)
-        for _ in range(3):
-            em.prepare_text_encoder_edit(pipe.text_encoder, pipe.tokenizer, reqs, hp, hp.layers, hp.mom2_update_weight, stats, cache, "",
-                                         verbose=False, shard=shard)
-        sync()
-        hip.LINEAR_FLOPS["count"] = False
-        pre = hip.profile_collect().get("linear", (0.0, 0))
-        hip.profile_enable([])
-        pre_flops = hip.LINEAR_FLOPS["flops"]
-        tot_ms = lin_ms / args.steps + pre[0] / 3
-        tot_flops = lin_flops / args.steps + pre_flops / 3
-        tot_launches = lin_launches / args.steps + pre[1] / 3
+        tot_ms, tot_flops, tot_launches = lin_ms / args.steps, hip.LINEAR_FLOPS["flops"] / args.steps, lin_launches / args.steps
         lin = {"ms_per_step": tot_ms, "launches_per_step": tot_launches, "algorithmic_flops_per_step": tot_flops,
-               "tflops": tot_flops / (tot_ms * 1e-3) / 1e12, "frac_f32_mfma_peak": tot_flops / (tot_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
-               "leading_layers_ms": pre[0] / 3, "edited_layers_ms": lin_ms / args.steps}
+               "tflops": tot_flops / (tot_ms * 1e-3) / 1e12, "frac_f32_mfma_peak": tot_flops / (tot_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS}
         classes["linear"] = lin
     roofline = None
     top = max(f64, key=lambda c: prof[c][0]) if f64 else None

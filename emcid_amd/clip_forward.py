@@ -477,14 +477,22 @@ def layer_attention_block(layer: ClipLayer, hs: torch.Tensor, trie: TokenTrie, r
                                  layer.scale, None)
         res = hs
     else:
-        k = linear(x, layer.k.weight, layer.k.bias)
-        v = linear(x, layer.v.weight, layer.v.bias)
+        if layer.qkv_w is not None:
+            # every node's k | v in ONE projection (the stacked weight's k and v rows), q for the query rows only
+            hdim = layer.q.out_features
+            kv = linear(x, layer.qkv_w[hdim:], layer.qkv_b[hdim:] if layer.qkv_b is not None else None)
+            k, v = kv[:, :hdim], kv[:, hdim:]
+            qw, qb = layer.qkv_w[:hdim], (layer.qkv_b[:hdim] if layer.qkv_b is not None else None)
+        else:
+            k = linear(x, layer.k.weight, layer.k.bias)
+            v = linear(x, layer.v.weight, layer.v.bias)
+            qw, qb = layer.q.weight, layer.q.bias
         if rows is None:
-            q = linear(x, layer.q.weight, layer.q.bias)
+            q = linear(x, qw, qb)
             res = hs
         else:
             idx = rows.long()
-            q = linear(x.index_select(0, idx), layer.q.weight, layer.q.bias)
+            q = linear(x.index_select(0, idx), qw, qb)
             res = hs.index_select(0, idx)
         ctx = hip.tree_attention(q, k, v, trie.anc, trie.depth, layer.heads, layer.scale, rows)
     if OWN_GEMM:
