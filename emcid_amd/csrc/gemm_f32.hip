@@ -45,6 +45,11 @@ template <int V> struct IC { static constexpr int value = V; };
 
 // PF: how many stages ahead the global loads run (= register sets of staged data).  DBG (timing experiments only, results
 // wrong): 1 = no global loads inside the loop, 2 = also no LDS stores.
+// Measured and dropped (profiles/r03_mb_linear_variants.txt): the 128 x 128 four-wave kernel compiled for THREE workgroups per
+// compute unit (amdgpu_waves_per_eu(3, 8): 148 registers, no spills) runs 4-10 % slower than at two (qkv 105.9 vs 117.4 TF);
+// a persistent form that walks a workgroup's tiles as one software pipeline (next tile's first stages loaded during the current
+// tile's last ones, stage 0 in LDS before the epilogue) 6-8 % slower (110.6 / 112.5 vs 117.4 / 121.1 TF) — the hardware's own
+// dispatch of one-tile workgroups balances the compute units better than a static walk gains from the hidden prologue.
 template <int MI, int NJ, int WM, int WN, int PF, int DBG, int KS>
 __global__ __launch_bounds__(256 * KS) void linear_f32_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
                                                                int64_t ldw, const float* __restrict__ bias,

@@ -591,6 +591,7 @@ def test_shadow_product_forced_and_off(mode):
 
 
 @pytest.mark.parametrize("M,K,N", [(6400, 768, 2304), (6400, 768, 768), (6400, 3072, 768), (3072, 768, 3072), (1000, 3072, 768),
+                                   (6300, 768, 3000), (9000, 32, 2304),
                                    (777, 1280, 3840), (37, 48, 200), (1, 16, 1), (300, 5120, 1280), (161, 32, 129)])
 @pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 64, 65 + 4, 66, 67 + 8, 64 + 8])   # tile + 4 (prefetch - 1) + 64 (4 waves)
 def test_linear_f32_vs_torch(M, K, N, cfg):
