@@ -45,11 +45,22 @@ def stats_filename(stats_dir, model_name, ds_name, layer_name, precision, to_col
 def _check_precision(precision):
     if precision is None:
         precision = "float64"   # the reference's default when unset (layer_stats.py:161-162)
-    if precision not in ("float32", "float64"):
-        raise NotImplementedError(
-            f"precision={precision!r}: the statistics are accumulated by the fp32 (reference CLI default, layer_stats.py:51) "
-            f"or the fp64 MFMA SYRK; float16 sums are not built")
+    if precision not in ("float16", "float32", "float64"):       # the reference CLI's choices (layer_stats.py:51)
+        raise NotImplementedError(f"precision={precision!r}: float16, float32 (reference CLI default) or float64")
     return precision
+
+
+def _stat_dtypes(precision):
+    """(dtype the features are rounded to, dtype they are accumulated in, dtype the sums are stored in).  float32 / float64:
+    all three that type (fp32 / fp64 MFMA SYRK).  float16: the reference casts the features to half and accumulates
+    ``mom2 += a.t().mm(a)`` in half (layer_stats.py:51,:218; runningstats.py:493) — sums that saturate at 65 504 after a
+    few thousand tokens; here the features are rounded to half exactly like that, the sums are carried in fp32 (no kernel
+    accumulates in half) and only the stored matrix is half, so the file has the reference's schema and a value that is the
+    half-rounded exact sum wherever the reference's is finite."""
+    if precision == "float16":
+        return torch.float16, torch.float32, torch.float16
+    t = getattr(torch, precision)
+    return t, t, t
 
 
 def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str], stats_dir=STATS_DIR,
@@ -104,9 +115,12 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
         raise ValueError("forward='trie' needs a HF CLIP text encoder and fc2 layer names")
     if packed is not None:
         return _collect_packed(model, tokenizer, ds, sample, pool, packed, todo, stats, files, args, shard, group, device,
-                               progress, device_batch_tokens, getattr(torch, precision))
+                               progress, device_batch_tokens, _stat_dtypes(precision))
     loader = groups()
-    stat_dtype = getattr(torch, precision)
+    round_dtype, stat_dtype, store_dtype = _stat_dtypes(precision)
+    for ln in todo:
+        if getattr(stats[ln], "mom2", None) is not None:
+            stats[ln].mom2.store_dtype = store_dtype
     # forward order of the hooked modules decides which one is "deepest" (the one that stops the pass)
     order = {name: i for i, (name, _) in enumerate(model.named_modules())}
     mods = {ln: get_module(model, ln) for ln in todo}
@@ -135,7 +149,7 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
                     for ln in todo:
                         x = grabbed[ln]
                         feats = x.reshape(-1, x.size(-1)).index_select(0, attended)  # == flatten_masked_batch(x, mask)
-                        stats[ln].add(feats.to(dtype=stat_dtype))        # reference: feats.to(dtype=dtype) (:218)
+                        stats[ln].add(feats.to(dtype=round_dtype).to(dtype=stat_dtype))        # reference: feats.to(dtype=dtype) (:218)
                     grabbed.clear()
     finally:
         for h in handles:
@@ -194,7 +208,7 @@ def _packed_plan(model, layer_names, mods_of=None):
 
 
 def _collect_packed(model, tokenizer, ds, sample, pool, packed, todo, stats, files, args, shard, group, device, progress,
-                    device_batch_tokens, stat_dtype=torch.float32):
+                    device_batch_tokens, stat_dtypes=(torch.float32, torch.float32, torch.float32)):
     """Stage 0 on the packed prefix trie: the captions of a pool share their common prefixes ("<bos> a photo of ...") and
     carry no padding; every DISTINCT prefix is a row, computed once and entered into the Gram scaled by the square root
     of the number of captions that pass through it — sum_tokens x x^T exactly as the reference's attended-token sum
@@ -202,6 +216,10 @@ def _collect_packed(model, tokenizer, ds, sample, pool, packed, todo, stats, fil
     same caption pools as the hooked forward."""
     from . import clip_forward
     graph, index = packed
+    round_dtype, stat_dtype, store_dtype = stat_dtypes
+    for ln in todo:
+        if getattr(stats[ln], "mom2", None) is not None:
+            stats[ln].mom2.store_dtype = store_dtype
     deepest = max(index.values())
     wanted = {i: [ln for ln in todo if index[ln] == i] for i in set(index.values())}
     wrap = progress if progress is not None else (lambda it, total=None: it)
@@ -222,7 +240,7 @@ def _collect_packed(model, tokenizer, ds, sample, pool, packed, todo, stats, fil
 
             def on_fc2(i, x, out):
                 if i in wanted:
-                    feats = x[:n_real].to(stat_dtype) * root
+                    feats = x[:n_real].to(round_dtype).to(stat_dtype) * root
                     for ln in wanted[i]:
                         stats[ln].add(feats, count=tokens)
                 return None if i == deepest else out

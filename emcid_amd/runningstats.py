@@ -70,6 +70,7 @@ class SecondMoment(Stat):
         self._staged = 0
         self.stage_tokens = stage_tokens
         self.ksplit = ksplit
+        self.store_dtype = None   # dtype of the stored sums when it differs from the accumulator's (float16 statistics)
         self.split_batch = split_batch
         if state is not None:
             super().__init__(state)
@@ -171,7 +172,10 @@ class SecondMoment(Stat):
             self._full = None
 
     def state_dict(self):
-        return dict(constructor=self.CONSTRUCTOR, count=self.count, mom2=self.mom2.cpu().numpy())
+        m2 = self.mom2.cpu()
+        if self.store_dtype is not None and m2.dtype != self.store_dtype:
+            m2 = m2.to(self.store_dtype)
+        return dict(constructor=self.CONSTRUCTOR, count=self.count, mom2=m2.numpy())
 
     def load_state_dict(self, state):
         self.count = int(state["count"])

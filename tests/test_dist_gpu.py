@@ -368,3 +368,24 @@ def test_rccl_column_sharded_solve_at_headline_size(tmp_path):
         assert np.abs(got[n] @ probe - z[f"dw_probe/{li}"]).max() <= 1e-4 * scale * np.linalg.norm(probe, axis=0).max(), li
         np.testing.assert_allclose(np.linalg.norm(got[n]), float(z[f"dw_fro/{li}"]), rtol=1e-4)
         np.testing.assert_allclose(np.abs(got[n]).max(), scale, rtol=1e-4)
+
+
+def test_bench_self_launch_two_ranks_gloo(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: the script starts its own torch.distributed.run child before touching the
+    GPU and the two ranks (sharing this box's GPU, EMCID_BENCH_BACKEND=gloo: collectives staged through the host) produce ONE
+    JSON line with the contract's fields — the path the driver's N > 1 runs take, kept from rotting on a one-GPU box."""
+    import json
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, EMCID_BENCH_BACKEND="gloo", TMPDIR=str(tmp_path))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--concepts", "200",
+                        "--no-cpu-baseline", "--no-stage0", "--no-variants"], env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["config"]["backend"] == "gloo"
+    assert out["value"] > 0 and out["ms_per_step"] > 0 and out["scaling"] == "strong" and out["unit"] == "concept-edits/s"
+    assert out["config"]["parallelism"] == "concept-shard x2" and out["roofline"] is not None

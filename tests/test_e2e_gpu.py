@@ -784,3 +784,25 @@ def test_stage1_batched_through_apply_on_a_cold_cache(tmp_path, monkeypatch):
     for n in names:
         a, b = out["batched"][1][n], out["seq"][1][n]
         assert (a - b).abs().max().item() <= 1e-4 * b.abs().max().item()
+
+
+@pytest.mark.parametrize("forward", ["trie", "hf"])
+def test_stage0_float16_precision(tmp_path, forward):
+    """--precision float16 (reference layer_stats.py:51): features rounded to half, sums carried in fp32, stored as half under
+    the reference's file name; the stored matrix is the half rounding of the Gram of the half-rounded features."""
+    from emcid_amd.layer_stats import layer_stats_text_encoder_multi, stats_filename
+    data = tmp_path / "caps.json"
+    syn.write_captions(data, 60, seed=4)
+    pipe = syn.build_pipe("toy", DEV)
+    name = "encoder.layers.2.mlp.fc2"
+    kw = dict(sample_size=40, batch_tokens=600, data_path=str(data), progress=None, num_workers=0, forward=forward)
+    st16 = layer_stats_text_encoder_multi(pipe.text_encoder, pipe.tokenizer, [name], tmp_path / "s16", precision="float16", **kw)
+    st32 = layer_stats_text_encoder_multi(pipe.text_encoder, pipe.tokenizer, [name], tmp_path / "s32", precision="float32", **kw)
+    f = stats_filename(tmp_path / "s16", "text_encoder", "ccs_filtered", name, "float16", ["mom2"], 600, 40)
+    with np.load(f) as z:
+        assert z["mom2.mom2"].dtype == np.float16 and int(z["mom2.count"]) == st32[name].mom2.count
+        got = z["mom2.mom2"].astype(np.float64)
+    ref = st32[name].mom2.mom2.double().numpy()
+    # half inputs: relative 2^-11 per feature -> ~1e-3 on the sums; half storage: another 2^-11
+    assert np.abs(got - ref).max() <= 4e-3 * np.abs(ref).max()
+    assert np.abs(got - ref).max() > 0          # it IS a different statistic from the fp32 one
