@@ -561,6 +561,198 @@ def compute_z_text_encoder(pipe, request: Dict, hparams, layer: int, device=None
     return (state["source_init"] + delta).detach()
 
 
+def compute_z_sdxl_text_encoders(pipe, request: Dict, hparams, layers, device=None, resolution: int = 512, rng_device=None):
+    """(v*, v*_2) of one concept for SDXL's two text encoders: the hidden states of ``layer_module_tmp.format(layer)`` /
+    ``.format(layer_2)`` at the last subject token of the first prompt plus vectors found by ONE Adam over both (reference:
+    emcid/compute_z.py:651-1037; same arguments, same return).  The UNet sees the concatenated PENULTIMATE hidden states of the
+    two encoders as context and the second encoder's ``text_embeds`` + the size ids as added conditions; the loss is the MSE
+    between its predictions under the edited source and under the destination embeddings (or the sampled noise), both weight
+    decays and, with ``cal_text_repr_loss``, the alignment of both pooled outputs.
+
+    Reference behaviours kept because they decide the result: the destination forward of the SECOND encoder is fed the FIRST
+    tokenizer's ids (:842-843); the schedule is ``pipe.scheduler`` (:741).  Results-identical restructuring as in
+    compute_z_text_encoder: forward hooks that return an edited copy instead of in-place writes; the clean destination
+    forwards and the size ids (loop invariants the reference recomputes every step) run once; the penultimate hidden state is
+    taken at the input of each encoder's last layer instead of through ``output_hidden_states``; no loss log file."""
+    from PIL import Image
+    hp = hparams
+    if getattr(hp, "use_ewc", False):
+        raise ValueError("ewc not implemented for sdxl")          # reference :951
+    te1, te2 = pipe.text_encoder, pipe.text_encoder_2
+    dev = next(te1.parameters()).device
+    rdev = torch.device(rng_device) if rng_device is not None else dev
+    host_draw = rdev.type == "cpu" and dev.type != "cpu"
+    layer, layer_2 = layers
+    objective = hp.objective
+    if objective not in ("ablate-source", "ablate-dest"):
+        raise ValueError(f"Objective {objective} can not be used for compute_z.")
+    sched = pipe.scheduler
+    source_prompts = [p.format(request["source"]) for p in request["prompts"]]
+    dest_prompts = [p.format(request["dest"]) for p in request["prompts"]]
+    spp = hp.samples_per_prompt
+    if "training_img_paths" in request:
+        images = [Image.open(path) for path in request["training_img_paths"]]
+    elif "images" in request:
+        images = request["images"]
+    else:
+        gen = torch.Generator(dev).manual_seed(int(request["seed_train"])) if request.get("seed_train") is not None else None
+        images = []
+        with torch.no_grad():
+            if objective == "ablate-source":
+                for _ in range(spp):
+                    images.extend(pipe(source_prompts, guidance_scale=7.5, generator=gen).images)
+            else:       # one prompt at a time (:776-779)
+                for _ in range(spp):
+                    for prompt in source_prompts:
+                        images.append(pipe(prompt, guidance_scale=7.5, generator=gen).images[0])
+    pixels = preprocess_img(images, resolution)
+    bsz = len(source_prompts)
+    pixels = pixels.reshape(spp, bsz, *pixels.shape[1:]).transpose(0, 1)
+    if len(pixels) % bsz:
+        raise AssertionError(f"len(img_batch) {len(pixels)} should be n times of batch size {bsz}")
+    tok1, tok2 = pipe.tokenizer, pipe.tokenizer_2
+    src_inp, dst_inp = tokenize_prompts(source_prompts, tok1, dev), tokenize_prompts(dest_prompts, tok1, dev)
+    src_inp_2, dst_inp_2 = tokenize_prompts(source_prompts, tok2, dev), tokenize_prompts(dest_prompts, tok2, dev)
+    f1, f2 = finder_for(tok1), finder_for(tok2)
+    src_lookup = [f1(ids, request["source"])[-1] - 1 for ids in src_inp["input_ids"].tolist()]
+    src_lookup_2 = [f2(ids, request["source"])[-1] - 1 for ids in src_inp_2["input_ids"].tolist()]
+    for ids in dst_inp["input_ids"].tolist():        # the reference looks the destination up too (:818-829): a ValueError if absent
+        f1(ids, request["dest"])
+    for ids in dst_inp_2["input_ids"].tolist():
+        f2(ids, request["dest"])
+    if not (len(src_inp["input_ids"]) == len(dst_inp["input_ids"]) == len(pixels)):
+        raise AssertionError("The number of prompts and images should be the same.")
+    ar = torch.arange(bsz, device=dev)
+    idx1, idx2 = torch.tensor(src_lookup, device=dev), torch.tensor(src_lookup_2, device=dev)
+    frozen = [prm for m in (te1, te2, pipe.vae, pipe.unet) for prm in m.parameters() if prm.requires_grad]
+    for prm in frozen:
+        prm.requires_grad_(False)
+    delta = torch.zeros((te1.config.hidden_size,), requires_grad=True, device=dev)
+    deltas_2 = torch.zeros((te2.config.hidden_size,), requires_grad=True, device=dev)
+    opt = torch.optim.Adam([delta, deltas_2], lr=hp.v_lr)
+    state = {"edit": False, "init": [None, None], "penult": [None, None]}
+
+    def edit_hook(k, idx, first, dvec):
+        def hook(mod, args, out):
+            if not state["edit"]:
+                return out
+            h = out[0] if isinstance(out, tuple) else out
+            if state["init"][k] is None:
+                state["init"][k] = h[0, first].detach().clone()
+            h = h.clone()
+            h[ar, idx, :] = dvec if hp.replace_repr else h[ar, idx, :] + dvec
+            return (h,) + tuple(out[1:]) if isinstance(out, tuple) else h
+        return hook
+
+    def penult_hook(k):           # the input of the LAST layer = hidden_states[-2] (after an edit at any earlier layer)
+        def hook(mod, args, kwargs):
+            state["penult"][k] = args[0] if args else kwargs["hidden_states"]
+        return hook
+
+    def last_layer(te):
+        return get_module(te, hp.layer_module_tmp.format(te.config.num_hidden_layers - 1))
+
+    handles = [get_module(te1, hp.layer_module_tmp.format(layer)).register_forward_hook(edit_hook(0, idx1, src_lookup[0], delta)),
+               get_module(te2, hp.layer_module_tmp.format(layer_2)).register_forward_hook(edit_hook(1, idx2, src_lookup_2[0], deltas_2)),
+               last_layer(te1).register_forward_pre_hook(penult_hook(0), with_kwargs=True),
+               last_layer(te2).register_forward_pre_hook(penult_hook(1), with_kwargs=True)]
+
+    def run(te, k, inp, pooled):
+        out = te(**inp)
+        return state["penult"][k], getattr(out, pooled)
+
+    try:
+        with torch.no_grad():       # loop invariants (the reference recomputes them every step from the same frozen encoders)
+            dest_txt, dest_pool = run(te1, 0, dst_inp, "pooler_output")
+            dest_txt_2, dest_pool_2 = run(te2, 1, dst_inp, "text_embeds")             # the FIRST tokenizer's ids (:842)
+            dest_embeds = torch.cat([dest_txt, dest_txt_2], dim=-1)
+            height = width = pipe.default_sample_size * pipe.vae_scale_factor
+            try:
+                add_time_ids = pipe._get_add_time_ids((height, width), (0, 0), (height, width), dtype=dest_embeds.dtype,
+                                                      text_encoder_projection_dim=te2.config.projection_dim)
+            except (AttributeError, TypeError):      # a pipeline without that helper: diffusers' own layout
+                add_time_ids = torch.tensor([[height, width, 0, 0, height, width]], dtype=dest_embeds.dtype)
+            add_time_ids = add_time_ids.repeat(bsz, 1).to(dev)
+            dest_cond = {"text_embeds": dest_pool_2, "time_ids": add_time_ids}
+        posteriors = {}
+        for it in range(hp.v_num_grad_steps):
+            opt.zero_grad()
+            sample_indices = torch.randint(0, spp, (bsz,))
+            key = tuple(sample_indices.tolist())
+            if key not in posteriors:
+                with torch.no_grad():
+                    posteriors[key] = pipe.vae.encode(pixels[torch.arange(bsz), sample_indices].to(dev)).latent_dist
+            with torch.no_grad():
+                latents = posteriors[key].sample(torch.default_generator) if host_draw else posteriors[key].sample()
+                latents = latents * pipe.vae.config.scaling_factor
+            if host_draw:
+                noise = torch.randn(latents.shape, dtype=latents.dtype).to(dev)
+                timesteps = torch.randint(0, sched.config.num_train_timesteps, (bsz,)).long().to(dev)
+            else:
+                noise = torch.randn_like(latents, device=dev)
+                timesteps = torch.randint(0, sched.config.num_train_timesteps, (bsz,), device=dev).long()
+            noisy = sched.add_noise(latents, noise, timesteps)
+            state["edit"] = True
+            try:
+                edit_txt, edit_pool = run(te1, 0, src_inp, "pooler_output")
+                edit_txt_2, edit_pool_2 = run(te2, 1, src_inp_2, "text_embeds")
+            finally:
+                state["edit"] = False
+            edit_embeds = torch.cat([edit_txt, edit_txt_2], dim=-1)
+            edit_cond = {"text_embeds": edit_pool_2, "time_ids": add_time_ids}
+            if not hp.no_noise_loss:
+                edit_pred = pipe.unet(noisy, timesteps, encoder_hidden_states=edit_embeds, added_cond_kwargs=edit_cond).sample
+                with torch.no_grad():
+                    pred_dest = pipe.unet(noisy, timesteps, encoder_hidden_states=dest_embeds, added_cond_kwargs=dest_cond).sample
+            init1, init2 = state["init"]
+            reg = hp.v_weight_decay * (torch.norm(delta) / torch.norm(init1) ** 2)
+            reg_2 = hp.v_weight_decay * (torch.norm(deltas_2) / torch.norm(init2) ** 2)
+            if getattr(hp, "use_sampled_noise", False) or request.get("use_real_noise", False):
+                loss = F.mse_loss(noise, edit_pred, reduction="mean") + reg + reg_2
+            elif hp.no_noise_loss:
+                loss = reg + reg_2
+            else:
+                loss = F.mse_loss(edit_pred, pred_dest, reduction="mean") + reg + reg_2
+            if hp.cal_text_repr_loss and request.get("txt_align", True):
+                scale = hp.text_repr_loss_scale_factor
+                loss = loss + scale * F.mse_loss(edit_pool, dest_pool, reduction="mean") \
+                    + scale * F.mse_loss(edit_pool_2, dest_pool_2, reduction="mean")
+            loss.backward()
+            opt.step()
+            for dvec, init in ((delta, init1), (deltas_2, init2)):
+                max_norm = hp.clamp_norm_factor * init.norm()
+                if dvec.norm() > max_norm:
+                    with torch.no_grad():
+                        dvec[...] = dvec * max_norm / dvec.norm()
+    finally:
+        for hd in handles:
+            hd.remove()
+        for prm in frozen:
+            prm.requires_grad_(True)
+    return (state["init"][0] + delta).detach(), (state["init"][1] + deltas_2).detach()
+
+
+def stage1_for_sdxl(pipe, hparams, layers=None, **kw):
+    """``stage1(request, suffix) -> v*`` for an SDXL pipeline: the pair optimisation runs ONCE per request — the reference
+    computes and caches both vectors together (emcid_main.py:1157-1230) — and is kept until both encoders' loaders (suffix ""
+    for text_encoder, "_2" for text_encoder_2) have asked for their half."""
+    layers = layers if layers is not None else (hparams.layers[-1], hparams.layers_2[-1])
+    pending: Dict[int, list] = {}
+
+    def stage1(request, suffix=""):
+        key = id(request)
+        if key not in pending:
+            v1, v2 = compute_z_sdxl_text_encoders(pipe, request, hparams, layers, **kw)
+            pending[key] = [request, {"": v1, "_2": v2}]
+        halves = pending[key][1]
+        v = halves.pop(suffix)
+        if not halves:
+            del pending[key]
+        return v
+
+    return stage1
+
+
 def compute_z_text_encoder_batched(pipe, requests: Sequence[Dict], hparams, layer: int, device=None, noise_scheduler=None,
                                    resolution: int = 512, rng_device=None, batch_size: int = 8) -> List[torch.Tensor]:
     """``[compute_z_text_encoder(pipe, r, ...) for r in requests]`` with ``batch_size`` concepts per Adam step: ONE hooked
@@ -797,12 +989,12 @@ def stage1_for(pipe, hparams, layer: int, batch_size: Optional[int] = None, **kw
     Adam step, default 8; 1 = one concept at a time)."""
     def stage1(request, suffix=""):
         if suffix:
-            raise NotImplementedError("the SDXL pair optimisation compute_z_sdxl_text_encoders (compute_z.py:651-1037) is not built")
+            raise ValueError("a suffixed v* belongs to SDXL's second encoder: use stage1_for_sdxl (compute_z_sdxl_text_encoders)")
         return compute_z_text_encoder(pipe, request, hparams, layer, **kw)
 
     def batch(requests, suffix=""):
         if suffix:
-            raise NotImplementedError("the SDXL pair optimisation compute_z_sdxl_text_encoders (compute_z.py:651-1037) is not built")
+            raise ValueError("a suffixed v* belongs to SDXL's second encoder: use stage1_for_sdxl (compute_z_sdxl_text_encoders)")
         import os
         bs = batch_size if batch_size is not None else int(os.environ.get("EMCID_STAGE1_BATCH", "8"))
         if bs <= 1:

@@ -17,7 +17,8 @@ leaves TE2 edited and ``apply_*`` then adds the deltas again, so TE2 ends at W +
 reproduced by default (``SDXL_TE2_DOUBLE_APPLY``).  Deliberate differences: ``COV_CACHE`` is keyed by the
 statistics directory too (the reference's key ignores it and silently reuses a stale C, SURVEY.md §5);
 per-request progress prints obey ``verbose``; a v* cache miss runs Stage 1 (compute_z.compute_z_text_encoder) when the
-pipeline carries a UNet and a VAE, and raises otherwise.
+pipeline carries a UNet and a VAE (SDXL: compute_z.compute_z_sdxl_text_encoders, both vectors in one optimisation), and raises
+otherwise.
 """
 import os
 from copy import deepcopy
@@ -377,6 +378,16 @@ def _default_stage1(pipe, hparams, stage1):
     return stage1_for(pipe, hparams, hparams.layers[-1])
 
 
+def _default_stage1_sdxl(pipe, hparams, stage1):
+    """Stage 1 of the SDXL pair on a v* cache miss, like the reference (:1157-1230): without a caller-supplied ``stage1=`` and
+    with a UNet and a VAE in the pipeline, compute_z.compute_z_sdxl_text_encoders optimises (v*, v*_2) together at the last
+    edited layer of each encoder; each encoder's loader writes its own cache file."""
+    if stage1 is not None or getattr(pipe, "unet", None) is None or getattr(pipe, "vae", None) is None:
+        return stage1
+    from .compute_z import stage1_for_sdxl
+    return stage1_for_sdxl(pipe, hparams)
+
+
 def _deltas_to_host(edits: List[LayerEdit]) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
     """Reference return format: {weight_name: (adj_k (d, N) f64 cpu, resid (h, N) f64 cpu)} (:1062-1065)."""
     return {e.weight_name: (e.Xt.t().contiguous().cpu(), e.Rt.t().contiguous().cpu()) for e in edits}
@@ -664,6 +675,7 @@ def execute_emcid_sd_xl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
     """(deltas, deltas_2).  TE1 is restored; TE2 is left at W + dW exactly as the reference leaves it (:1410)."""
     _sdxl_overrides(hparams, mom2_weight, mom2_weight_2, edit_weight)
     _announce(requests, verbose)
+    stage1 = _default_stage1_sdxl(pipe, hparams, stage1)
     p1, p2 = _sdxl_plans(pipe, requests, hparams, cache_name, stat_dir, stat_dir_2, verbose, shard, stage1)
     e1 = run_checked(p1, keep_factors=True, restore=True)
     e2 = run_checked(p2, keep_factors=True, restore=not SDXL_TE2_DOUBLE_APPLY)
@@ -680,6 +692,7 @@ def apply_emcid_to_sdxl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
     o2 = deepcopy(pipe.text_encoder_2) if return_orig_text_encoder else None
     _sdxl_overrides(hparams, mom2_weight, mom2_weight_2, edit_weight)
     _announce(requests, verbose)
+    stage1 = _default_stage1_sdxl(pipe, hparams, stage1)
     split = _sdxl_split(_shard_from_env(shard))
     if split is not None:
         # TE1 || TE2 on disjoint GPU groups (BASELINE config 4): this rank edits ONE encoder, concept-sharded

@@ -106,9 +106,10 @@ def build_tokenizer(vocab: Optional[Dict[str, int]] = None, merges=None, model_m
 
 
 def build_text_encoder(kind: str = "toy", vocab_size: Optional[int] = None, seed: int = 0,
-                       name_or_path: str = "synthetic/clip-text"):
-    """Seeded random-init CLIPTextModel (fp32, eval, no grad)."""
-    from transformers import CLIPTextConfig, CLIPTextModel
+                       name_or_path: str = "synthetic/clip-text", projection_dim: Optional[int] = None):
+    """Seeded random-init CLIPTextModel (fp32, eval, no grad); with ``projection_dim`` a CLIPTextModelWithProjection (SDXL's
+    second encoder: ``.text_embeds``, what Stage 1 of the SDXL pair reads)."""
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
 
     hidden, inter, layers, heads, act = ENCODER_DIMS[kind]
     if vocab_size is None:
@@ -117,11 +118,11 @@ def build_text_encoder(kind: str = "toy", vocab_size: Optional[int] = None, seed
         hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers,
         num_attention_heads=heads, vocab_size=vocab_size, max_position_embeddings=77,
         hidden_act=act, bos_token_id=vocab_size - 2, eos_token_id=vocab_size - 1,
-        pad_token_id=vocab_size - 1,
+        pad_token_id=vocab_size - 1, **({"projection_dim": projection_dim} if projection_dim else {}),
     )
     gen_state = torch.random.get_rng_state()
     torch.manual_seed(seed)
-    model = CLIPTextModel(cfg).eval()
+    model = (CLIPTextModelWithProjection(cfg) if projection_dim else CLIPTextModel(cfg)).eval()
     torch.random.set_rng_state(gen_state)
     for p in model.parameters():
         p.requires_grad_(False)
@@ -150,7 +151,7 @@ class SyntheticPipe(SimpleNamespace):
 
 
 def build_pipe(kind: str = "toy", device: str = "cpu", sdxl: bool = False, seed: int = 0,
-               syllables: bool = False) -> SyntheticPipe:
+               syllables: bool = False, projection_dim: Optional[int] = None) -> SyntheticPipe:
     vocab, merges = synthetic_vocab(syllables=syllables)
     tok = build_tokenizer(vocab, merges)
     if not sdxl:
@@ -158,7 +159,7 @@ def build_pipe(kind: str = "toy", device: str = "cpu", sdxl: bool = False, seed:
         return SyntheticPipe(text_encoder=te.to(device), tokenizer=tok)
     kind1, kind2 = ("toy", "toy2") if kind.startswith("toy") else ("sdxl-te1", "sdxl-te2")
     te1 = build_text_encoder(kind1, len(vocab), seed=seed, name_or_path="synthetic/clip-text-1")
-    te2 = build_text_encoder(kind2, len(vocab), seed=seed + 1, name_or_path="synthetic/clip-text-2")
+    te2 = build_text_encoder(kind2, len(vocab), seed=seed + 1, name_or_path="synthetic/clip-text-2", projection_dim=projection_dim)
     return SyntheticPipe(text_encoder=te1.to(device), tokenizer=tok,
                          text_encoder_2=te2.to(device), tokenizer_2=build_tokenizer(vocab, merges))
 
@@ -300,6 +301,51 @@ def add_diffusion(pipe: "SyntheticPipe", kind: str = "toy") -> "SyntheticPipe":
     scheduler attribute: everything Stage 1 (compute_z_text_encoder) reads from a pipeline besides the text encoder."""
     add_unet(pipe, kind)
     pipe.vae = SyntheticVAE().to(pipe.device)
+    return pipe
+
+
+class SyntheticUNetXL(SyntheticUNet):
+    """SyntheticUNet with SDXL's extra conditioning: ``forward(sample, timestep, encoder_hidden_states=, added_cond_kwargs=
+    {"text_embeds", "time_ids"})``; the output also depends (smoothly) on the pooled text embedding and the size ids."""
+
+    def __init__(self, text_hidden: int, add_dim: int, kind: str = "toy", seed: int = 13):
+        super().__init__(text_hidden, kind, seed)
+        st = torch.random.get_rng_state()
+        torch.manual_seed(seed + 1)
+        self.add_embedding = torch.nn.Linear(add_dim + 6, 8)
+        torch.random.set_rng_state(st)
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    def forward(self, sample, timestep, encoder_hidden_states=None, added_cond_kwargs=None, **kw):
+        out = super().forward(sample, timestep, encoder_hidden_states).sample
+        if added_cond_kwargs is not None:
+            cond = torch.cat([added_cond_kwargs["text_embeds"], added_cond_kwargs["time_ids"].to(sample.dtype) / 1024.0], dim=-1)
+            a = torch.tanh(self.add_embedding(cond)).mean(dim=1)
+            out = out * (1.0 + 0.2 * a).reshape(-1, *([1] * (sample.dim() - 1)))
+        return SimpleNamespace(sample=out)
+
+
+def add_sdxl_diffusion(pipe: "SyntheticPipe", kind: str = "toy", sample_size: int = 4) -> "SyntheticPipe":
+    """What Stage 1 of the SDXL pair (compute_z_sdxl_text_encoders) reads from a StableDiffusionXLPipeline besides the two text
+    encoders: the UNet with ``added_cond_kwargs``, the VAE, ``scheduler`` (add_noise), ``default_sample_size``,
+    ``vae_scale_factor`` and ``_get_add_time_ids``.  ``pipe.text_encoder_2`` must carry a projection (``build_pipe(...,
+    projection_dim=...)``)."""
+    h1, h2 = pipe.text_encoder.config.hidden_size, pipe.text_encoder_2.config.hidden_size
+    dev = pipe.device
+    pipe.unet = SyntheticUNetXL(h1 + h2, pipe.text_encoder_2.config.projection_dim, kind).to(dev)
+    pipe.vae = SyntheticVAE().to(dev)
+    pipe.scheduler = DDPMNoiseSchedule()
+    pipe.default_sample_size, pipe.vae_scale_factor = sample_size, 8
+
+    def _get_add_time_ids(original_size, crops_coords_top_left, target_size=None, dtype=None, text_encoder_projection_dim=None,
+                          source_size=None):
+        # diffusers: list(original_size + crops_coords_top_left + target_size) as one row (the reference's pinned version names
+        # the last argument source_size, emcid/compute_z.py:868-874)
+        last = target_size if target_size is not None else source_size
+        return torch.tensor([list(original_size) + list(crops_coords_top_left) + list(last)], dtype=dtype)
+
+    pipe._get_add_time_ids = _get_add_time_ids
     return pipe
 
 

@@ -196,6 +196,143 @@ def _hidden(out):
     return out[0] if isinstance(out, tuple) else out      # transformers 4.x layers return a tuple, 5.x the tensor
 
 
+def compute_z_sdxl_text_encoders(pipe, request: Dict, hparams: Dict, layers, resolution: int = 512):
+    """Stage 1 of the SDXL pair (compute_z.py:651-1037), op for op: ONE Adam over (delta, deltas_2) added at each prompt's last
+    subject token in ``layer_module_tmp.format(layer)`` of text_encoder / text_encoder_2 (hooks on the pipeline's own encoders,
+    active only around the edited forwards); per step one VAE encode, the clean destination forwards of both encoders, the
+    edited source forwards, two UNet forwards with the concatenated penultimate hidden states as context and the second
+    encoder's text_embeds + size ids as added conditions; MSE + both weight decays (+ both pooled-output alignment terms);
+    both deltas projected onto their L2 balls.  Reference quirks kept: the destination forward of the SECOND encoder is fed
+    the FIRST tokenizer's ids (:842-843); ``noise_scheduler = pipe.scheduler`` (:741).  Returns (v*, v*_2)."""
+    import torch.nn.functional as F
+    hp = lambda k, d=None: hparams.get(k, d)
+    device = next(pipe.text_encoder.parameters()).device
+    layer, layer_2 = layers
+    te1, te2 = pipe.text_encoder, pipe.text_encoder_2
+    source_prompts = [p.format(request["source"]) for p in request["prompts"]]
+    objective = hp("objective")
+    dest_prompts = ["" for _ in request["prompts"]] if objective == "esd" else [p.format(request["dest"]) for p in request["prompts"]]
+    delta = torch.zeros((te1.config.hidden_size,), requires_grad=True, device=device)
+    deltas_2 = torch.zeros((te2.config.hidden_size,), requires_grad=True, device=device)
+    state = {"source_init": None, "source_init_2": None, "edit": False}
+    opt = torch.optim.Adam([delta, deltas_2], lr=hp("v_lr"))
+    noise_scheduler = pipe.scheduler
+    for m in (pipe.vae, pipe.unet, te1, te2):
+        for prm in m.parameters():
+            prm.requires_grad = False
+    spp = hp("samples_per_prompt", 1)
+    if objective not in ("ablate-source", "ablate-dest"):
+        raise ValueError(f"Objective {objective} can not be used for compute_z.")
+    if "training_img_paths" in request:
+        from PIL import Image
+        all_imgs = [Image.open(path) for path in request["training_img_paths"]]
+    elif "images" in request:
+        all_imgs = request["images"]
+    else:
+        generator = torch.Generator(device).manual_seed(int(request["seed_train"])) if request["seed_train"] is not None else None
+        all_imgs = []
+        with torch.no_grad():
+            if objective == "ablate-source":
+                for _ in range(spp):
+                    all_imgs.extend(pipe(source_prompts, guidance_scale=7.5, generator=generator).images)
+            else:
+                for _ in range(spp):
+                    for prompt in source_prompts:
+                        all_imgs.append(pipe(prompt, guidance_scale=7.5, generator=generator).images[0])
+    all_imgs = preprocess_img(all_imgs, resolution)
+    bsz = len(source_prompts)
+    all_imgs = all_imgs.reshape(spp, bsz, *all_imgs.shape[1:]).transpose(0, 1)       # "(s b) c h w -> b s c h w"
+    assert len(all_imgs) % bsz == 0
+    src_inp = tokenize_prompts(source_prompts, pipe.tokenizer, device)
+    dst_inp = tokenize_prompts(dest_prompts, pipe.tokenizer, device)
+    src_inp_2 = tokenize_prompts(source_prompts, pipe.tokenizer_2, device)
+    dst_inp_2 = tokenize_prompts(dest_prompts, pipe.tokenizer_2, device)
+    src_lookup = [find_token_range(pipe.tokenizer, ids, request["source"])[-1] - 1 for ids in src_inp["input_ids"]]
+    src_lookup_2 = [find_token_range(pipe.tokenizer_2, ids, request["source"])[-1] - 1 for ids in src_inp_2["input_ids"]]
+    [find_token_range(pipe.tokenizer, ids, request["dest"]) for ids in dst_inp["input_ids"]]          # (:818-821, :827-829: computed,
+    [find_token_range(pipe.tokenizer_2, ids, request["dest"]) for ids in dst_inp_2["input_ids"]]      #  raise if the dest is absent)
+    assert len(src_inp["input_ids"]) == len(dst_inp["input_ids"]) == len(all_imgs)
+
+    def make_hook(which, lookup, dvec):
+        def hook(mod, args, out):
+            if not state["edit"]:
+                return out
+            h = _hidden(out)
+            if state[which] is None:
+                state[which] = h[0, lookup[0]].detach().clone()
+            for i, idx in enumerate(lookup):
+                if hp("replace_repr", False):
+                    h[i, idx, :] = dvec
+                else:
+                    h[i, idx, :] += dvec
+            return out
+        return hook
+
+    handles = [get_module(te1, hparams["layer_module_tmp"].format(layer)).register_forward_hook(make_hook("source_init", src_lookup, delta)),
+               get_module(te2, hparams["layer_module_tmp"].format(layer_2)).register_forward_hook(make_hook("source_init_2", src_lookup_2, deltas_2))]
+    try:
+        for it in range(hp("v_num_grad_steps")):
+            opt.zero_grad()
+            sample_indices = torch.randint(0, spp, (bsz,))
+            img_batch = all_imgs[torch.arange(bsz), sample_indices].to(device)
+            with torch.no_grad():
+                latents = pipe.vae.encode(img_batch).latent_dist.sample() * pipe.vae.config.scaling_factor
+                d1 = te1(**dst_inp, output_hidden_states=True)
+                dest_txt, dest_pool = d1.hidden_states[-2], d1.pooler_output
+                d2 = te2(**dst_inp, output_hidden_states=True)                 # the FIRST tokenizer's ids, as the reference (:842)
+                dest_txt_2, dest_pool_2 = d2.hidden_states[-2], d2.text_embeds
+                dest_embeds = torch.cat([dest_txt, dest_txt_2], dim=-1)
+                height = width = pipe.default_sample_size * pipe.vae_scale_factor
+                add_time_ids = pipe._get_add_time_ids(original_size=(height, width), crops_coords_top_left=(0, 0),
+                                                      source_size=(height, width), dtype=dest_embeds.dtype,
+                                                      text_encoder_projection_dim=te2.config.projection_dim)
+                add_time_ids = add_time_ids.repeat(bsz, 1).to(device)
+                dest_cond = {"text_embeds": dest_pool_2, "time_ids": add_time_ids}
+            noise = torch.randn_like(latents, device=device)
+            timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (bsz,), device=device).long()
+            noisy = noise_scheduler.add_noise(latents, noise, timesteps)
+            state["edit"] = True
+            try:
+                e1 = te1(**src_inp, output_hidden_states=True)
+                e2 = te2(**src_inp_2, output_hidden_states=True)
+            finally:
+                state["edit"] = False
+            edit_txt, edit_pool = e1.hidden_states[-2], e1.pooler_output
+            edit_txt_2, edit_pool_2 = e2.hidden_states[-2], e2.text_embeds
+            edit_embeds = torch.cat([edit_txt, edit_txt_2], dim=-1)
+            edit_cond = {"text_embeds": edit_pool_2, "time_ids": add_time_ids}
+            if not hp("no_noise_loss", False):
+                edit_pred = pipe.unet(noisy, timesteps, encoder_hidden_states=edit_embeds, added_cond_kwargs=edit_cond).sample
+                pred_dest = pipe.unet(noisy, timesteps, encoder_hidden_states=dest_embeds, added_cond_kwargs=dest_cond).sample
+            if hp("use_sampled_noise", False) or request.get("use_real_noise", False):
+                mse = F.mse_loss(noise, edit_pred, reduction="mean")
+            elif hp("no_noise_loss", False):
+                mse = None
+            else:
+                mse = F.mse_loss(edit_pred, pred_dest, reduction="mean")
+            reg = hp("v_weight_decay") * (torch.norm(delta) / torch.norm(state["source_init"]) ** 2)
+            reg_2 = hp("v_weight_decay") * (torch.norm(deltas_2) / torch.norm(state["source_init_2"]) ** 2)
+            loss = reg + reg_2 if mse is None else mse + reg + reg_2
+            if hp("cal_text_repr_loss", False) and request.get("txt_align", True):
+                scale = hp("text_repr_loss_scale_factor")
+                loss = loss + scale * F.mse_loss(edit_pool, dest_pool, reduction="mean") \
+                    + scale * F.mse_loss(edit_pool_2, dest_pool_2, reduction="mean")
+            loss.backward()
+            opt.step()
+            max_norm = hp("clamp_norm_factor") * state["source_init"].norm()
+            max_norm_2 = hp("clamp_norm_factor") * state["source_init_2"].norm()
+            if delta.norm() > max_norm:
+                with torch.no_grad():
+                    delta[...] = delta * max_norm / delta.norm()
+            if deltas_2.norm() > max_norm_2:
+                with torch.no_grad():
+                    deltas_2[...] = deltas_2 * max_norm_2 / deltas_2.norm()
+    finally:
+        for h_ in handles:
+            h_.remove()
+    return (state["source_init"] + delta).detach(), (state["source_init_2"] + deltas_2).detach()
+
+
 def compute_z_text_encoder(pipe, request: Dict, hparams: Dict, layer: int, noise_scheduler, resolution: int = 512) -> torch.Tensor:
     """Per-concept Adam optimisation of v* through the UNet (compute_z.py:315-649), op for op: deep copy of the encoder
     with a hook that adds ``delta`` at each prompt's last subject token in ``layer_module_tmp.format(layer)``'s output,

@@ -217,6 +217,57 @@ def golden_stage1(cz, EMCIDHyperParams, scratch, tag="toy_stage1"):
     print(f"[golden] {tag}: wrote {len(out)} arrays: " + ", ".join(f"{k}: |v*| {np.linalg.norm(out[k + '/v_star']):.4f}" for k in STAGE1_CASES))
 
 
+STAGE1_XL_CASES = {
+    # the shipped SDXL hparams' Stage-1 settings (hparams/sdxl-dest_s-100_c-1.2_ly-8-11_ly2-26-31_lr-0.1_wd-8e-03_txt-align-0.01.json), fewer steps
+    "shipped_xl": dict(hp=dict(objective="ablate-dest", cal_text_repr_loss=True, text_repr_loss_scale_factor=0.005, v_lr=0.1,
+                               v_weight_decay=8e-3, clamp_norm_factor=1.2, v_num_grad_steps=8), layers=(3, 5), seed=321, req={}),
+    "ablate_source_xl": dict(hp=dict(objective="ablate-source", cal_text_repr_loss=False, v_lr=0.2, v_weight_decay=1e-3,
+                                     clamp_norm_factor=0.5, v_num_grad_steps=6, samples_per_prompt=2), layers=(2, 4), seed=99,
+                             req={"use_real_noise": True}),
+    "replace_xl": dict(hp=dict(objective="ablate-dest", cal_text_repr_loss=True, replace_repr=True, text_repr_loss_scale_factor=0.02,
+                               v_lr=0.05, v_weight_decay=5e-4, clamp_norm_factor=1.2, v_num_grad_steps=5), layers=(4, 6), seed=7, req={}),
+}
+STAGE1_XL_PROJECTION = 40
+
+
+def stage1_xl_pipe(device="cpu", wrap=True):
+    """Synthetic SDXL pipe for Stage 1 of the pair: toy / toy2 encoders (the second with a projection), UNet / VAE / scheduler
+    stand-ins.  ``wrap``: transformers-4.27 conventions for the REFERENCE run (tuple-returning layers, `text_model.` names)."""
+    pipe = syn.add_sdxl_diffusion(syn.build_pipe("toy", device, sdxl=True, projection_dim=STAGE1_XL_PROJECTION))
+    if wrap:
+        as_transformers_427(pipe.text_encoder)
+        as_transformers_427(pipe.text_encoder_2)
+        pipe.text_encoder = _PrefixedEncoder(pipe.text_encoder)       # 5.x CLIPTextModel has no `text_model.` level; WithProjection has
+    return pipe
+
+
+def golden_stage1_sdxl(cz, EMCIDXLHyperParams, scratch, tag="toy_stage1_sdxl"):
+    """Stage 1 of the SDXL pair: the REAL reference's compute_z_sdxl_text_encoders (compute_z.py:651-1037) on the synthetic SDXL
+    pipe (UNet with added_cond_kwargs, VAE, DDPM schedule stand-ins) with caller-supplied training images."""
+    (scratch / "log").mkdir(exist_ok=True)            # the reference appends its losses to log/loss_text_encoder.txt (:993)
+    out, meta = {}, {"cases": {}, "resolution": STAGE1_RESOLUTION, "projection_dim": STAGE1_XL_PROJECTION}
+    for name, c in STAGE1_XL_CASES.items():
+        pipe = stage1_xl_pipe()
+        hp_d = syn.sdxl_hparams_dict(layers=(1, 2, 3, 4), layers_2=(2, 3, 4, 5, 6), prefix="text_model.")
+        hp_d.update(c["hp"])
+        hp = EMCIDXLHyperParams(**hp_d)
+        request = {"source": "tocife" if name != "shipped_xl" else "c0042", "dest": "a realist artist",
+                   "prompts": list(syn.ARTIST_TEMPLATES), "seed_train": 2024}
+        request.update(c["req"])
+        imgs = syn.make_images(len(request["prompts"]) * hp.samples_per_prompt, STAGE1_RESOLUTION, seed=131 + c["seed"])
+        torch.manual_seed(c["seed"])
+        with contextlib.redirect_stdout(io.StringIO()):
+            v1, v2 = cz.compute_z_sdxl_text_encoders(pipe, dict(request, images=imgs), hp, c["layers"], device="cpu")
+        out[f"{name}/v_star"], out[f"{name}/v_star_2"] = v1.detach().numpy(), v2.detach().numpy()
+        out[f"{name}/images"] = np.stack([np.asarray(im) for im in imgs])
+        meta["cases"][name] = {"hparams": hp_d, "layers": list(c["layers"]), "seed": c["seed"], "request": request}
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump(meta, f, indent=1)
+    print(f"[golden] {tag}: wrote {len(out)} arrays: " + ", ".join(
+        f"{k}: |v*| {np.linalg.norm(out[k + '/v_star']):.4f} / {np.linalg.norm(out[k + '/v_star_2']):.4f}" for k in STAGE1_XL_CASES))
+
+
 def state_np(model, prefix="w/"):
     return {prefix + k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
 
@@ -729,6 +780,8 @@ def main():
                 golden_toy_extras(cz, ls, scratch)
             elif which == "toy_stage1":
                 golden_stage1(cz, HP, scratch)
+            elif which == "toy_stage1_sdxl":
+                golden_stage1_sdxl(cz, XLHP, scratch)
             else:
                 raise SystemExit(f"unknown fixture {which}")
             return
@@ -742,6 +795,7 @@ def main():
         golden_instruction(em, HP, scratch)
         golden_toy_extras(cz, ls, scratch)
         golden_stage1(cz, HP, scratch)
+        golden_stage1_sdxl(cz, XLHP, scratch)
         if "--skip-real" not in sys.argv:
             golden_sd(em, HP, scratch, "real_sd_summary", "sd-v1.4", n_req=24, layers=(7, 8, 9, 10), lam=4000,
                       ew=0.5, ragged=False, full=False)

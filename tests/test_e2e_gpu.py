@@ -806,3 +806,48 @@ def test_stage0_float16_precision(tmp_path, forward):
     # half inputs: relative 2^-11 per feature -> ~1e-3 on the sums; half storage: another 2^-11
     assert np.abs(got - ref).max() <= 4e-3 * np.abs(ref).max()
     assert np.abs(got - ref).max() > 0          # it IS a different statistic from the fp32 one
+
+
+def test_sdxl_cache_miss_runs_pair_stage1_then_edits(tmp_path):
+    """apply_emcid_to_sdxl_text_encoders on a cold v* cache with a pipeline that carries a UNet and a VAE: Stage 1 of the pair
+    (compute_z_sdxl_text_encoders, ONE optimisation per request for both encoders, reference emcid_main.py:1157-1230) fills
+    both caches (``..._dest_X.npz`` and ``..._dest_X_2.npz``); the edit that follows equals an edit served from those caches,
+    and the cached vectors are those of a direct Stage-1 call on the same seed."""
+    from emcid_amd.compute_z import compute_z_sdxl_text_encoders
+    reqs = [dict(r, images=syn.make_images(len(r["prompts"]), 32, seed=50 + i)) for i, r in enumerate(syn.make_requests(3, ragged=True))]
+    hp_d = syn.sdxl_hparams_dict(layers=(1, 2, 3), layers_2=(3, 4, 5), mom2_update_weight=50, mom2_update_weight_2=80,
+                                 mom2_n_samples=1000)
+    hp_d.update(v_num_grad_steps=4, cal_text_repr_loss=True)
+    n1 = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers"]]
+    n2 = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers_2"]]
+    syn.write_stats_cache(tmp_path / "s1", n1, 128, 1000, seed=2, t=512)
+    syn.write_stats_cache(tmp_path / "s2", n2, 192, 1000, seed=3, t=768)
+    cache = str(tmp_path / "cache") + "/"
+    build = lambda: syn.add_sdxl_diffusion(syn.build_pipe("toy", DEV, sdxl=True, projection_dim=40))
+    from emcid_amd.compute_z import stage1_for_sdxl
+    pipe = build()
+    torch.manual_seed(9)
+    st1 = stage1_for_sdxl(pipe, EMCIDXLHyperParams(**hp_d), resolution=32, rng_device="cpu")
+    em.apply_emcid_to_sdxl_text_encoders(pipe, reqs, EMCIDXLHyperParams(**hp_d), DEV, cache_name=cache, stat_dir=str(tmp_path / "s1"),
+                                         stat_dir_2=str(tmp_path / "s2"), verbose=False, stage1=st1)
+    files = sorted(p.name for p in (tmp_path / "cache").glob("*.npz"))
+    assert len(files) == 6 and sum(f.endswith("_2.npz") for f in files) == 3
+    w = {n: get_parameter(pipe.text_encoder, n + ".weight").cpu().clone() for n in n1}
+    w.update({n + "/2": get_parameter(pipe.text_encoder_2, n + ".weight").cpu().clone() for n in n2})
+    pipe2 = build()
+    em.apply_emcid_to_sdxl_text_encoders(pipe2, reqs, EMCIDXLHyperParams(**hp_d), DEV, cache_name=cache, stat_dir=str(tmp_path / "s1"),
+                                         stat_dir_2=str(tmp_path / "s2"), verbose=False, stage1=lambda *a: 1 / 0)
+    for n in n1:
+        assert torch.equal(get_parameter(pipe2.text_encoder, n + ".weight").cpu(), w[n])
+    for n in n2:
+        assert torch.equal(get_parameter(pipe2.text_encoder_2, n + ".weight").cpu(), w[n + "/2"])
+    # the cached pair of the FIRST request = a direct call on the same seed (later requests continue the same random stream)
+    pipe3 = build()
+    torch.manual_seed(9)
+    v1, v2 = compute_z_sdxl_text_encoders(pipe3, reqs[0], EMCIDXLHyperParams(**hp_d), (3, 5), resolution=32, rng_device="cpu")
+    got = em.load_v_stars(reqs[:1], EMCIDXLHyperParams(**hp_d), cache), em.load_v_stars(reqs[:1], EMCIDXLHyperParams(**hp_d), cache, "_2")
+    assert (got[0][0] - v1.cpu()).abs().max().item() <= 1e-5 * v1.abs().max().item()
+    assert (got[1][0] - v2.cpu()).abs().max().item() <= 1e-5 * v2.abs().max().item()
+    # the default wiring: no stage1= argument, the pipeline's UNet / VAE are enough
+    assert em._default_stage1_sdxl(pipe3, EMCIDXLHyperParams(**hp_d), None) is not None
+    assert em._default_stage1_sdxl(syn.build_pipe("toy", DEV, sdxl=True), EMCIDXLHyperParams(**hp_d), None) is None

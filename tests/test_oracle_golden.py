@@ -9,7 +9,7 @@ import torch
 
 from conftest import GOLDEN, load_golden, pipe_from_golden, write_cov_npz, write_vstars, xattn_from_golden
 from emcid_amd import synthetic as syn
-from emcid_amd.emcid_hparams import EMCIDHyperParams
+from emcid_amd.emcid_hparams import EMCIDHyperParams, EMCIDXLHyperParams
 from oracle import emcid_oracle as orc
 
 
@@ -348,3 +348,32 @@ def test_stage1_batched_equals_sequential_calls(name):
         for a, b in zip(got, seq):
             assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item(), (bs, (a - b).abs().max().item(), b.abs().max().item())
     assert all(p.requires_grad is False for p in pipe.text_encoder.parameters())
+
+
+def _stage1_xl_case(z, meta, name, device="cpu"):
+    from PIL import Image
+    c = meta["cases"][name]
+    pipe = syn.add_sdxl_diffusion(syn.build_pipe("toy", device, sdxl=True, projection_dim=meta["projection_dim"]))
+    imgs = [Image.fromarray(a, "RGB") for a in z[f"{name}/images"]]
+    return c, pipe, dict(c["request"], images=imgs)
+
+
+@pytest.mark.parametrize("name", ["shipped_xl", "ablate_source_xl", "replace_xl"])
+def test_stage1_sdxl_pair_matches_reference(name):
+    """Stage 1 of the SDXL pair (compute_z_sdxl_text_encoders, compute_z.py:651-1037): the oracle's op-for-op restatement
+    reproduces the REAL reference's (v*, v*_2) bit for bit (fixture toy_stage1_sdxl: UNet-with-added-conditions / VAE / DDPM
+    stand-ins, second encoder with projection; cases: shipped settings, ablate-source on the sampled noise, replace_repr with
+    both edits in the encoders' LAST layers); the product agrees to fp32 rounding."""
+    from emcid_amd.compute_z import compute_z_sdxl_text_encoders
+    z, meta = load_golden("toy_stage1_sdxl")
+    ref1, ref2 = z[f"{name}/v_star"], z[f"{name}/v_star_2"]
+    c, pipe, request = _stage1_xl_case(z, meta, name)
+    torch.manual_seed(c["seed"])
+    v1, v2 = orc.compute_z_sdxl_text_encoders(pipe, request, c["hparams"], c["layers"], meta["resolution"])
+    np.testing.assert_array_equal(v1.numpy(), ref1)
+    np.testing.assert_array_equal(v2.numpy(), ref2)
+    c, pipe, request = _stage1_xl_case(z, meta, name)
+    torch.manual_seed(c["seed"])
+    v1, v2 = compute_z_sdxl_text_encoders(pipe, request, EMCIDXLHyperParams(**c["hparams"]), c["layers"], resolution=meta["resolution"])
+    assert np.abs(v1.numpy() - ref1).max() <= 2e-6 * np.abs(ref1).max()
+    assert np.abs(v2.numpy() - ref2).max() <= 2e-6 * np.abs(ref2).max()
