@@ -217,6 +217,8 @@ def main():
     ap.add_argument("--no-stage0", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the n100 / sdxl / cold_process records")
     ap.add_argument("--no-cpu-full", action="store_true", help="skip the full 1 000-concept run of the CPU baseline (~1 min)")
+    ap.add_argument("--no-gemm-ab", action="store_true", help="skip the calls on the OTHER forward-GEMM path (keeps a profiler trace "
+                                                              "of this run free of that path's kernels)")
     ap.add_argument("--cold-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--stage0-captions", type=int, default=100000)
     args = ap.parse_args()
@@ -317,7 +319,9 @@ def main():
     # ---- warm-up and the K timed steps: every call a request set this process has never seen ------------------------------
     for i in range(args.warmup):
         call(1 + i)
+    edit_engine.TIMING.clear()
     elapsed, per_call = timed_calls(args.steps, first_set=1 + args.warmup)
+    host_phases = {k: round(v / args.steps * 1e3, 4) for k, v in edit_engine.TIMING.items()}      # host wall-clock per phase and call
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -342,12 +346,14 @@ def main():
     # instead of the library's own fp32-MFMA GEMM with fused epilogues (csrc/gemm_f32.hip): a few calls -----------------------
     from emcid_amd import clip_forward
     own_gemm = bool(clip_forward.OWN_GEMM)
-    clip_forward.OWN_GEMM = not own_gemm
-    call()
-    other_s, _ = timed_calls(max(3, args.steps // 2))
-    other_gemm_ms = other_s / max(3, args.steps // 2) * 1e3
-    clip_forward.OWN_GEMM = own_gemm
-    call()
+    other_gemm_ms = None
+    if not args.no_gemm_ab:
+        clip_forward.OWN_GEMM = not own_gemm
+        call()
+        other_s, _ = timed_calls(max(3, args.steps // 2))
+        other_gemm_ms = other_s / max(3, args.steps // 2) * 1e3
+        clip_forward.OWN_GEMM = own_gemm
+        call()
 
     # ---- host / device split: prepare alone (median), then run_encoder_edit on the HBM-resident plan ---------------------
     prep_ms = []
@@ -489,6 +495,7 @@ def main():
                            "note": "same requests as the replay; a new lambda reuses the cached factor of C' (lam_ratio), a new "
                                    "edit_weight refactors the four 3072 x 3072 matrices on the side stream under the forward"},
         "first_call_ms": first_s * 1e3,
+        "host_phases_ms_per_call": host_phases,
         "forward_gemm": {"this_run": "emcid_linear_f32 (own fp32-MFMA GEMM, fused bias / activation / residual)" if own_gemm
                          else "torch F.linear (hipBLASLt)",
                          "other_path_ms_per_step": other_gemm_ms,

@@ -80,19 +80,26 @@ __global__ __launch_bounds__(256 * KS) void linear_f32_kernel(const float* __res
     const int l31 = lane & 31, l5 = lane >> 5;
     const int wm0 = (wave / WN) * (32 * MI), wn0 = (wave % WN) * (32 * NJ);
 
-    // global -> register staging: vector v = tid + NT s of an image is row v / CPR, floats 4 (v % CPR) .. + 3 of the stage
+    // global -> register staging: vector v = tid + NT s of an image is one 16-byte piece of one row of the stage.  A ds_write_b128
+    // is served in groups of 8 consecutive lanes over 32 banks: with 36-dword rows (KS = 2) the 8 pieces of ONE row fill them
+    // exactly; with 20-dword rows (KS = 1, 4 pieces per row) rows r and r + 1 would overlap on 4 banks (rocprofv3: one LDS cycle in
+    // three a conflict), rows r and r + 4 (80 dwords = 16 mod 32) do not — so a group of 8 lanes takes rows r and r + 4.
+    auto row_of = [](int v) {
+        if (CPR == 4) return (v >> 5) * 8 + ((v >> 3) & 3) + 4 * ((v >> 2) & 1);
+        return v / CPR;
+    };
     const float* pa[VA];
     const float* pb[VB];
     int wa[VA], wb[VB];
 #pragma unroll
     for (int s = 0; s < VA; ++s) {
-        const int v = tid + NT * s, row = min(v / CPR, BM - 1);
+        const int v = tid + NT * s, row = min(row_of(v), BM - 1);
         pa[s] = X + (int64_t)min(m0 + row, M - 1) * ldx + 4 * (v % CPR);        // rows past M: a valid row, never stored
         wa[s] = row * LLD + 4 * (v % CPR);
     }
 #pragma unroll
     for (int s = 0; s < VB; ++s) {
-        const int v = tid + NT * s, row = min(v / CPR, BN - 1);
+        const int v = tid + NT * s, row = min(row_of(v), BN - 1);
         pb[s] = W + (int64_t)min(n0 + row, N - 1) * ldw + 4 * (v % CPR);
         wb[s] = BM * LLD + row * LLD + 4 * (v % CPR);
     }

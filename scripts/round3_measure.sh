@@ -5,7 +5,7 @@ tag=${1:-r03_a}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err && echo bench ok
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -- python3 bench.py --no-cpu-baseline --no-stage0 --no-variants > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_prof.err && echo prof ok
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -- python3 bench.py --no-cpu-baseline --no-stage0 --no-variants --no-gemm-ab > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_prof.err && echo prof ok
 f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${tag}_bench_kernel_stats.csv; rm -rf gpurun_out/${tag}_prof
 bash scripts/pmc_passes.sh gpurun_out/${tag}_pmc_lin scripts/pmc_linear.py > gpurun_out/${tag}_pmc_linear_summary.json 2> gpurun_out/${tag}_pmc_lin.err && echo pmc linear ok
 find gpurun_out/${tag}_pmc_lin -name "*.csv" -delete; find gpurun_out/${tag}_pmc_lin -type d -empty -delete
