@@ -50,6 +50,10 @@ template <int V> struct IC { static constexpr int value = V; };
 // a persistent form that walks a workgroup's tiles as one software pipeline (next tile's first stages loaded during the current
 // tile's last ones, stage 0 in LDS before the epilogue) 6-8 % slower (110.6 / 112.5 vs 117.4 / 121.1 TF) — the hardware's own
 // dispatch of one-tile workgroups balances the compute units better than a static walk gains from the hidden prologue.
+// A v_mfma_f32_16x16x4_f32 form of the same pipeline (tile edges in steps of 16: 96 x 160, 128 x 160, 192 x 160 — the shapes
+// hipBLASLt's tuned solutions take for these projections: 510 / 250 tiles for qkv / out at 6 400 rows) compiled to 254-436
+// registers per lane (one wave per SIMD for the two larger tiles) and reached 95-109 TF on qkv, 61-87 on out
+// (profiles/r03_mb_linear_mfma16.txt): removed.
 template <int MI, int NJ, int WM, int WN, int PF, int DBG, int KS>
 __global__ __launch_bounds__(256 * KS) void linear_f32_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
                                                                int64_t ldw, const float* __restrict__ bias,
