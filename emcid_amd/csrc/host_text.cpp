@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -49,15 +50,9 @@ struct emcid_bpe {
 
     // The ids of one pre-token (lower-case printable ASCII, no spaces); false if a character is not in the vocabulary.
     // tokenizers' BPE: start from characters (the last one carries the suffix), repeatedly apply the applicable merge of
-    // lowest rank, leftmost first.
-    bool word(const char* w, size_t n, const std::vector<int32_t>** out) {
-        std::string k(w, n);
-        auto it = cache.find(k);
-        if (it != cache.end()) {
-            *out = &it->second;
-            return true;
-        }
-        std::vector<int32_t> s(n);
+    // lowest rank, leftmost first.  Pure (reads the model only): safe from several threads at once.
+    bool merge_word(const char* w, size_t n, std::vector<int32_t>& s) const {
+        s.resize(n);
         for (size_t i = 0; i < n; ++i) {
             const unsigned char c = (unsigned char)w[i];
             s[i] = (i + 1 == n) ? sym_end[c] : sym[c];
@@ -73,6 +68,19 @@ struct emcid_bpe {
             s[at] = id;
             s.erase(s.begin() + at + 1);
         }
+        return true;
+    }
+
+    // merge_word through the pre-token cache (caller holds `lock`)
+    bool word(const char* w, size_t n, const std::vector<int32_t>** out) {
+        std::string k(w, n);
+        auto it = cache.find(k);
+        if (it != cache.end()) {
+            *out = &it->second;
+            return true;
+        }
+        std::vector<int32_t> s;
+        if (!merge_word(w, n, s)) return false;
         if (cache.size() > (1u << 20)) cache.clear();
         *out = &(cache[k] = std::move(s));
         return true;
@@ -140,7 +148,8 @@ void emcid_bpe_destroy(emcid_bpe* m) { delete m; }
 // One text -> the ids of its pre-tokens appended to `row` (no bos/eos), stopping once `budget` ids are there (truncation keeps
 // a prefix: later pieces cannot matter).  false: the text is outside what this library restates (see emcid_host.h).
 // Caller holds m->lock.
-static bool encode_text(emcid_bpe* m, const char* s, size_t len, std::string& low, std::vector<int32_t>& row, int32_t budget) {
+static bool encode_text(emcid_bpe* m, const char* s, size_t len, std::string& low, std::vector<int32_t>& row, int32_t budget,
+                        bool use_cache = true) {
     low.assign(s, len);
     for (size_t p = 0; p < len; ++p) {
         const unsigned char c = (unsigned char)low[p];
@@ -165,9 +174,15 @@ static bool encode_text(emcid_bpe* m, const char* s, size_t len, std::string& lo
                     ++q;
             }
         }
-        const std::vector<int32_t>* w = nullptr;
-        if (!m->word(low.data() + p, q - p, &w)) return false;
-        row.insert(row.end(), w->begin(), w->end());
+        if (use_cache) {
+            const std::vector<int32_t>* w = nullptr;
+            if (!m->word(low.data() + p, q - p, &w)) return false;
+            row.insert(row.end(), w->begin(), w->end());
+        } else {        // worker threads: the model is only read, nothing is memoised
+            std::vector<int32_t> w;
+            if (!m->merge_word(low.data() + p, q - p, w)) return false;
+            row.insert(row.end(), w.begin(), w.end());
+        }
         p = q;
         if ((int32_t)row.size() >= budget) break;
     }
@@ -238,6 +253,28 @@ int64_t emcid_bpe_encode_templated(emcid_bpe* m, const char* pre, const int64_t*
         const int64_t la = aoff[ka + 1] - aoff[ka], lb = boff[kb + 1] - boff[kb];
         return la == 0 || lb == 0 || is_space((unsigned char)a[aoff[ka + 1] - 1]) || is_space((unsigned char)b[boff[kb]]);
     };
+    // A mass edit brings ~1 000 names the cache has never seen (~1 us of merges each): the distinct names are encoded up front by
+    // a few threads, without the cache (names of a request set are not expected back; a replayed set costs the same again).
+    if (n_names >= 256) {
+        for (int64_t k = 0; k < n_names; ++k)
+            if (name_off[k + 1] < name_off[k]) {
+                g_error = "emcid_bpe_encode_templated: index or offsets out of range";
+                return -1;
+            }
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int nt = (int)std::min<int64_t>(std::min<int64_t>(4, hw ? hw : 1), n_names / 128);
+        auto work = [&](int64_t lo, int64_t hi) {
+            std::string low_t;
+            for (int64_t k = lo; k < hi; ++k) {
+                Piece& pc = Nm[(size_t)k];
+                pc.state = encode_text(m, names + name_off[k], (size_t)(name_off[k + 1] - name_off[k]), low_t, pc.ids, budget, false) ? 1 : 2;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work, n_names * t / nt, n_names * (t + 1) / nt);
+        work(0, n_names / (nt > 0 ? nt : 1));
+        for (auto& th : pool) th.join();
+    }
     int64_t n_fallback = 0;
     std::vector<int32_t> row;
     std::string whole;
