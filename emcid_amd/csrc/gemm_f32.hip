@@ -54,6 +54,11 @@ template <int V> struct IC { static constexpr int value = V; };
 // hipBLASLt's tuned solutions take for these projections: 510 / 250 tiles for qkv / out at 6 400 rows) compiled to 254-436
 // registers per lane (one wave per SIMD for the two larger tiles) and reached 95-109 TF on qkv, 61-87 on out
 // (profiles/r03_mb_linear_mfma16.txt): removed.
+// Staging by LDS-DMA (global_load_lds_dwordx4 into an unpadded image with 16-byte pieces XOR-swizzled by (row >> 2) & 3 — conflict
+// free for the b128 fragment reads —, three stage buffers, DMAs two stages ahead behind counted s_waitcnt vmcnt and a bare
+// s_barrier, no staging registers, no ds_write): correct, 111 / 119 TF on qkv / fc1 against 118 / 121 for the register-staged
+// form, 124-130 against 131-134 on the SDXL shapes (profiles/r03_mb_linear_dma.txt): the LDS store path is not what holds the
+// loop back; removed.
 template <int MI, int NJ, int WM, int WN, int PF, int DBG, int KS>
 __global__ __launch_bounds__(256 * KS) void linear_f32_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
                                                                int64_t ldw, const float* __restrict__ bias,
