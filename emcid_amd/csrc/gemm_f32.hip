@@ -63,7 +63,7 @@ template <int MI, int NJ, int WM, int WN, int PF, int DBG, int KS>
 __global__ __launch_bounds__(256 * KS) void linear_f32_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
                                                                int64_t ldw, const float* __restrict__ bias,
                                                                const float* __restrict__ res, int64_t ldr, float* __restrict__ Y,
-                                                               int64_t ldy, int M, int N, int K, int act, int tiles_n, int tiles) {
+                                                               int64_t ldy, int M, int N, int K, int act, int tiles_n, int tiles, int rb) {
     static_assert(WM * WN == 4 && (KS == 1 || KS == 2), "four waves per K group");
     constexpr int NT = 256 * KS;                     // threads
     constexpr int SBK = LBK * KS;                    // K depth of a stage
@@ -82,7 +82,16 @@ __global__ __launch_bounds__(256 * KS) void linear_f32_kernel(const float* __res
     const int per = (tiles + 7) / 8;
     const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (tile >= tiles || (int)(blockIdx.x >> 3) >= per) return;
-    const int bm = tile / tiles_n, bn = tile - bm * tiles_n;
+    // Tile order: super-rows of `rb` row tiles, column-major inside a super-row — the ~64 tiles an XCD has in flight then share
+    // `rb` row tiles of X (kept in its 4 MB L2) and walk the column tiles of W together, instead of re-streaming all of W for
+    // every row tile (rb = 1: row-major; L2-miss traffic of the 128 x 128 launches 2.8x the algorithmic bytes).
+    int bm, bn;
+    {
+        const int tiles_m = tiles / tiles_n, sr = tile / (rb * tiles_n), rem = tile - sr * rb * tiles_n;
+        const int rows = min(rb, tiles_m - sr * rb);
+        bn = rem / rows;
+        bm = sr * rb + (rem - bn * rows);
+    }
     const int m0 = bm * BM, n0 = bn * BN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8;      // grp: which 16 of a stage's K
@@ -334,10 +343,12 @@ int emcid_linear_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, c
     const int tiles = tiles_m * tiles_n;
     const int per = (tiles + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
+    static const int rb_env = [] { const char* e = getenv("EMCID_LINEAR_RB"); return e ? atoi(e) : 4; }();
+    const int rb = rb_env >= 1 ? rb_env : 1;
     ScopedProf sp(KC_LINEAR, st);
 #define EMCID_LINEAR_LAUNCH(MI_, NJ_, WM_, WN_, PF_, DBG_, KS_)                                                              \
     hipLaunchKernelGGL((linear_f32_kernel<MI_, NJ_, WM_, WN_, PF_, DBG_, KS_>), dim3((unsigned)(per * 8)), dim3(256 * KS_), 0, \
-                       st, X, ldx, W, ldw, bias, residual, ldr, Y, ldy, (int)M, (int)N, (int)K, act, tiles_n, tiles)
+                       st, X, ldx, W, ldw, bias, residual, ldr, Y, ldy, (int)M, (int)N, (int)K, act, tiles_n, tiles, rb)
 #define EMCID_LINEAR_PF(MI_, NJ_, WM_, WN_)                                              \
     do {                                                                                  \
         if (ks == 2) {                                                                    \
