@@ -279,6 +279,43 @@ def test_npz_cache_protocol_roundtrip(tmp_path):
     assert list(rs.tally(st3, None, cache=f, sample_size=50, quiet=True)) == [] and st3.mom2.count == 7
 
 
+def test_stored_npz_parser_equals_numpy_load_or_declines(tmp_path):
+    """read_npz_stored: the members numpy.load gives, same dtypes, same bytes, writable (torch.from_numpy takes them without a
+    warning); anything it does not parse — compressed, pickled, truncated, not a zip — is None, i.e. numpy.load's business."""
+    import warnings
+    g = np.random.default_rng(3)
+    dat = {"mom2.count": np.array(12345), "mom2.mom2": g.standard_normal((33, 33)).astype(np.float32),
+           "mom2.constructor": np.array("util.runningstats.SecondMoment()"), "sample_size": np.array(50),
+           "f64": g.standard_normal(7), "i8": np.arange(5, dtype=np.int8), "empty": np.zeros((0, 4), np.float32)}
+    f = tmp_path / "s.npz"
+    np.savez(f, **dat)
+    got = rs.read_npz_stored(f)
+    with np.load(f) as z:
+        assert sorted(got) == sorted(z.files)
+        for k in z.files:
+            assert got[k].dtype == z[k].dtype and got[k].shape == z[k].shape and np.array_equal(got[k], z[k])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert torch.equal(torch.from_numpy(got["mom2.mom2"]), torch.from_numpy(dat["mom2.mom2"]))
+    # the loader uses it
+    st = rs.CombinedStat(mom2=rs.SecondMoment())
+    st.load_state_dict(rs.load_cached_state(f, {"sample_size": 50}, quiet=True))
+    assert st.mom2.count == 12345
+    # declined cases
+    np.savez_compressed(tmp_path / "c.npz", **dat)
+    assert rs.read_npz_stored(tmp_path / "c.npz") is None
+    np.savez(tmp_path / "o.npz", a=np.array([{"x": 1}], dtype=object))
+    assert rs.read_npz_stored(tmp_path / "o.npz") is None
+    raw = f.read_bytes()
+    (tmp_path / "t.npz").write_bytes(raw[:len(raw) // 2])
+    assert rs.read_npz_stored(tmp_path / "t.npz") is None
+    (tmp_path / "n.npz").write_bytes(b"not a zip at all" * 8)
+    assert rs.read_npz_stored(tmp_path / "n.npz") is None
+    assert rs.read_npz_stored(tmp_path / "missing.npz") is None
+    # and the loader still serves the compressed file through numpy
+    assert rs.load_cached_state(tmp_path / "c.npz", {"sample_size": 50}, quiet=True)["mom2.count"] == 12345
+
+
 def test_hparams_load_shipped_schema(tmp_path):
     d = syn.sd_hparams_dict()
     p = tmp_path / "h.json"
