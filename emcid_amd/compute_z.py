@@ -63,6 +63,7 @@ class PromptBatch:
     n_requests: int
     lookup_host: List[int]
     ids_host: Optional[np.ndarray] = None   # (B, S) int64 copy of input_ids on the host (the trie is built from it)
+    lookup_multi: Optional[torch.Tensor] = None   # (k, B) int64, num_edit_tokens = k > 1: [last subject token, EOS, EOS + 1, ...] per prompt
 
     @property
     def n_prompts(self):
@@ -283,12 +284,42 @@ def iter_prompt_chunks(tokenizer, requests: Sequence[Dict], n_chunks: int):
 
 
 def gather_request_means(act: torch.Tensor, batch: PromptBatch) -> torch.Tensor:
-    """(B, S, c) activations -> (N, c): row at each prompt's lookup token, averaged per request."""
+    """(B, S, c) activations -> (N, c): row at each prompt's lookup token, averaged per request.  A multi-token batch
+    (``lookup_multi``, k rows per prompt) gives (N k, c) in the reference's "rq num" order (emcid_main.py:993-1014)."""
     if act.dtype != torch.float32:
         raise hip.EmcidHipError(f"K/Z assembly is fp32 (reference loads the encoder in fp32); got {act.dtype}")
     if act.stride(-1) != 1:
         act = act.contiguous()
+    if batch.lookup_multi is not None:
+        per = [hip.gather_mean(act, col, batch.seg) for col in batch.lookup_multi]          # k x (N, c)
+        return torch.stack(per, dim=1).reshape(-1, act.shape[-1])
     return hip.gather_mean(act, batch.lookup, batch.seg)
+
+
+def build_prompt_batch_multi(tokenizer, requests: Sequence[Dict], device, k: int) -> PromptBatch:
+    """The prompt batch of the ``num_fact_token = k > 1`` branch (reference: compute_z.py:2329-2360): every prompt padded to
+    (longest + k - 2) tokens with padding="max_length"; per prompt the rows [last subject token, EOS, the k - 2 positions
+    behind it].  No truncation: those rows lie at and behind the EOS."""
+    if k < 2:
+        raise ValueError(f"num_fact_token must be >= 2 here, got {k}")
+    prompts, subjects, counts = expand_request_prompts(requests)
+    first = tokenizer(prompts, padding=True, truncation=True)
+    n_pad = k - 2
+    enc = tokenizer(prompts, padding="max_length", truncation=True, max_length=len(first["input_ids"][0]) + n_pad)
+    ids = np.asarray(enc["input_ids"], dtype=np.int64)
+    mask = np.asarray(enc["attention_mask"], dtype=np.int64)
+    last_subject = np.asarray([r[-1] - 1 for r in finder_for(tokenizer).batch(ids, subjects)], dtype=np.int64)
+    eos = mask.sum(axis=1) - 1
+    idx = np.concatenate([last_subject[:, None], eos[:, None] + np.arange(n_pad + 1)[None, :]], axis=1)      # (B, k)
+    if idx.max() >= ids.shape[1] or idx.min() < 0:
+        raise ValueError("lookup index outside the padded prompt")
+    seg = np.cumsum([0] + counts).astype(np.int64)
+    if seg[-1] != len(prompts):
+        raise ValueError(f"request prompt counts ({seg[-1]}) do not cover the {len(prompts)} prompts")
+    return PromptBatch(inputs={"input_ids": torch.from_numpy(ids).to(device), "attention_mask": torch.from_numpy(mask).to(device)},
+                       lookup=torch.from_numpy(np.ascontiguousarray(idx[:, 0])).to(device), seg=torch.from_numpy(seg).to(device),
+                       n_requests=len(requests), lookup_host=idx[:, 0].tolist(), ids_host=ids,
+                       lookup_multi=torch.from_numpy(np.ascontiguousarray(idx.T)).to(device))
 
 
 def get_module_input_output_at_words(text_encoder, tok, requests: List[Dict], module_name: str,
@@ -321,23 +352,12 @@ def get_module_input_output_at_words(text_encoder, tok, requests: List[Dict], mo
 
 
 def _module_input_output_multi(text_encoder, tok, requests: List[Dict], module_name: str, k: int):
-    """The ``num_fact_token > 1`` branch (reference: compute_z.py:2329-2382).  No token truncation here: the rows wanted
-    lie at and behind each prompt's EOS."""
+    """The ``num_fact_token > 1`` branch (reference: compute_z.py:2329-2382): (N, k, d) inputs and (N, k, h) outputs of
+    ``module_name`` at [last subject token, EOS, k - 2 padding positions], mean over each request's prompts."""
     if k < 2:
         raise ValueError(f"num_fact_token must be >= 1, got {k}")
     device = next(text_encoder.parameters()).device
-    prompts, subjects, counts = expand_request_prompts(requests)
-    first = tok(prompts, padding=True, truncation=True)
-    n_pad = k - 2
-    enc = tok(prompts, padding="max_length", truncation=True, max_length=len(first["input_ids"][0]) + n_pad)
-    ids = np.asarray(enc["input_ids"], dtype=np.int64)
-    mask = np.asarray(enc["attention_mask"], dtype=np.int64)
-    last_subject = np.asarray([r[-1] - 1 for r in finder_for(tok).batch(ids, subjects)], dtype=np.int64)
-    eos = mask.sum(axis=1) - 1
-    idx = np.concatenate([last_subject[:, None], eos[:, None] + np.arange(n_pad + 1)[None, :]], axis=1)      # (B, k)
-    if idx.max() >= ids.shape[1] or idx.min() < 0:
-        raise ValueError("lookup index outside the padded prompt")
-    seg = torch.from_numpy(np.cumsum([0] + counts).astype(np.int64)).to(device)
+    batch = build_prompt_batch_multi(tok, requests, device, k)
     grabbed = {}
 
     def hook(mod, inputs, output):
@@ -348,19 +368,14 @@ def _module_input_output_multi(text_encoder, tok, requests: List[Dict], module_n
     try:
         with torch.no_grad(), hip_attention(text_encoder):
             try:
-                text_encoder(input_ids=torch.from_numpy(ids).to(device), attention_mask=torch.from_numpy(mask).to(device))
+                text_encoder(**batch.inputs)
             except StopForward:
                 pass
     finally:
         handle.remove()
-    ins, outs = [], []
-    for j in range(k):          # one gather + per-request mean per looked-up position (bit-compatible with torch's mean)
-        col = torch.from_numpy(np.ascontiguousarray(idx[:, j])).to(device)
-        for act, acc in ((grabbed["in"], ins), (grabbed["out"], outs)):
-            if act.dtype != torch.float32:
-                raise hip.EmcidHipError(f"K/Z assembly is fp32; got {act.dtype}")
-            acc.append(hip.gather_mean(act if act.stride(-1) == 1 else act.contiguous(), col, seg))
-    return torch.stack(ins, dim=1), torch.stack(outs, dim=1)
+    n = len(requests)
+    return (gather_request_means(grabbed["in"], batch).reshape(n, k, -1),          # one gather + per-request mean per looked-up
+            gather_request_means(grabbed["out"], batch).reshape(n, k, -1))         # position (bit-compatible with torch's mean)
 
 
 # ---- Stage 1: v* by Adam through the UNet (reference: emcid/compute_z.py:34-53, :315-649) ----------------------------------
@@ -559,6 +574,158 @@ def compute_z_text_encoder(pipe, request: Dict, hparams, layer: int, device=None
         for prm in frozen:
             prm.requires_grad_(True)
     return (state["source_init"] + delta).detach()
+
+
+def compute_z_text_encoder_v2(pipe, request: Dict, hparams, layer: int, device=None, noise_scheduler=None,
+                              resolution: int = 512, rng_device=None) -> torch.Tensor:
+    """The ``use_new_compute_z`` Stage 1: ``hparams.num_edit_tokens`` vectors per concept, (k, hidden) — row 0 for the last
+    subject token, rows 1.. for the EOS token and the k - 2 padding positions behind it, with the prompts tokenized to
+    (longest + k - 2) by padding="max_length" (reference: emcid/compute_z.py:1041-1357; same arguments, same return; the
+    dispatch is emcid_main.py:927-936).  Same restructuring and random-draw order as ``compute_z_text_encoder``.
+
+    What the reference's text does here, followed as is: for the ablate objectives the weight decay is built under no_grad
+    from the row norms (:1277-1281) — a constant of the loss, so it is not formed at all; the text term is the MSE over the
+    k looked-up rows of the edited source and the destination embeddings for k >= 2, the pooled outputs' MSE for k = 1
+    (:1297-1317); the L2 ball is per row, against that row's own initial norm (:1339-1343).  ``objective == "esd"`` and
+    ``use_ewc`` read ``source_init`` before it is ever assigned in the reference (:1275, :1292: UnboundLocalError on the first
+    step); here they raise NotImplementedError up front."""
+    from PIL import Image
+    hp = hparams
+    objective = hp.objective
+    if objective not in ("ablate-source", "ablate-dest", "esd"):
+        raise ValueError(f"Objective {objective} can not be used for compute_z.")
+    if objective == "esd" or getattr(hp, "use_ewc", False):
+        raise NotImplementedError("compute_z_text_encoder_v2: the reference fails on esd / use_ewc (source_init read before assignment, "
+                                  "compute_z.py:1275, :1292)")
+    k = int(hp.num_edit_tokens)
+    if k < 1:
+        raise ValueError(f"num_edit_tokens must be >= 1, got {k}")
+    te = pipe.text_encoder
+    dev = next(te.parameters()).device
+    rdev = torch.device(rng_device) if rng_device is not None else dev
+    tok = pipe.tokenizer
+    sched = noise_scheduler if noise_scheduler is not None else default_noise_scheduler()
+    source_prompts = [p.format(request["source"]) for p in request["prompts"]]
+    dest_prompts = [p.format(request["dest"]) for p in request["prompts"]]
+    spp = hp.samples_per_prompt
+    if "training_img_paths" in request:
+        images = [Image.open(path) for path in request["training_img_paths"]]
+    elif "images" in request:
+        images = request["images"]
+    else:
+        gen = torch.Generator(dev).manual_seed(int(request["seed_train"])) if request.get("seed_train") is not None else None
+        images = []
+        for _ in range(spp):
+            images.extend(pipe(source_prompts, guidance_scale=7.5, generator=gen).images)
+    pixels = preprocess_img(images, resolution)
+    bsz = len(source_prompts)
+    pixels = pixels.reshape(spp, bsz, *pixels.shape[1:]).transpose(0, 1)              # "(s b) c h w -> b s c h w"
+    if len(pixels) % bsz:
+        raise AssertionError(f"len(img_batch) {len(pixels)} should be n times of batch size {bsz}")
+    src_inp, dst_inp = tokenize_prompts(source_prompts, tok, dev), tokenize_prompts(dest_prompts, tok, dev)
+    n_pad = k - 2
+    if k > 1:
+        padded = max(src_inp["input_ids"].shape[1], dst_inp["input_ids"].shape[1]) + n_pad
+        src_inp = tokenize_prompts(source_prompts, tok, dev, padding_length=padded)
+        dst_inp = tokenize_prompts(dest_prompts, tok, dev, padding_length=padded)
+    finder = finder_for(tok)
+
+    def lookup_rows(inp, subject):       # (B, k): [last subject token, EOS, EOS + 1, ...]
+        rows = [[finder(ids, subject)[-1] - 1] for ids in inp["input_ids"].tolist()]
+        if k >= 2:
+            eos = (inp["attention_mask"].sum(dim=1) - 1).tolist()
+            rows = [r + list(range(e, e + n_pad + 1)) for r, e in zip(rows, eos)]
+        t = torch.tensor(rows, device=dev)
+        if int(t.max()) >= inp["input_ids"].shape[1] or int(t.min()) < 0:
+            raise ValueError("lookup index outside the padded prompt")
+        return t
+
+    src_idx, dst_idx = lookup_rows(src_inp, request["source"]), lookup_rows(dst_inp, request["dest"])
+    if not (len(src_inp["input_ids"]) == len(dst_inp["input_ids"]) == len(pixels)):
+        raise AssertionError("The number of prompts and images should be the same.")
+    ar = torch.arange(bsz, device=dev)[:, None]
+    frozen = [prm for m in (te, pipe.vae, pipe.unet) for prm in m.parameters() if prm.requires_grad]
+    for prm in frozen:
+        prm.requires_grad_(False)
+    deltas = torch.zeros((k, te.config.hidden_size), requires_grad=True, device=dev)
+    opt = torch.optim.Adam([deltas], lr=hp.v_lr)
+    state = {"edit": False, "inits": None}
+
+    def hook(mod, args, out):
+        if not state["edit"]:
+            return out
+        h = out[0] if isinstance(out, tuple) else out
+        if state["inits"] is None:
+            state["inits"] = h[0, src_idx[0]].detach().clone()           # (k, hidden): the rows of the FIRST prompt
+        h = h.clone()
+        if hp.replace_repr:
+            h[ar, src_idx, :] = deltas.unsqueeze(0).expand(bsz, -1, -1)
+        else:
+            h[ar, src_idx, :] = h[ar, src_idx, :] + deltas
+        return (h,) + tuple(out[1:]) if isinstance(out, tuple) else h
+
+    def edited(inp):
+        state["edit"] = True
+        try:
+            return te(**inp)[0:2]
+        finally:
+            state["edit"] = False
+
+    handle = get_module(te, hp.layer_module_tmp.format(layer)).register_forward_hook(hook)
+    try:
+        with torch.no_grad():
+            dest_repr, dest_pool = te(**dst_inp)[0:2]
+            wanted_rows = dest_repr[ar, dst_idx, :]
+        posteriors = {}
+        host_draw = rdev.type == "cpu" and dev.type != "cpu"
+        for it in range(hp.v_num_grad_steps):
+            opt.zero_grad()
+            sample_indices = torch.randint(0, spp, (bsz,))
+            key = tuple(sample_indices.tolist())
+            if key not in posteriors:
+                with torch.no_grad():
+                    posteriors[key] = pipe.vae.encode(pixels[torch.arange(bsz), sample_indices].to(dev)).latent_dist
+            with torch.no_grad():
+                latents = posteriors[key].sample(torch.default_generator) if host_draw else posteriors[key].sample()
+                latents = latents * pipe.vae.config.scaling_factor
+            if host_draw:
+                noise = torch.randn(latents.shape, dtype=latents.dtype).to(dev)
+                timesteps = torch.randint(0, sched.config.num_train_timesteps, (bsz,)).long().to(dev)
+            else:
+                noise = torch.randn_like(latents, device=dev)
+                timesteps = torch.randint(0, sched.config.num_train_timesteps, (bsz,), device=dev).long()
+            noisy = sched.add_noise(latents, noise, timesteps)
+            edit_repr, edit_pool = edited(src_inp)
+            loss = None
+            if not hp.no_noise_loss:
+                edit_pred = pipe.unet(noisy, timesteps, edit_repr).sample
+                if getattr(hp, "use_sampled_noise", False) or request.get("use_real_noise", False):
+                    loss = F.mse_loss(noise, edit_pred, reduction="mean")
+                else:
+                    with torch.no_grad():
+                        pred_dest = pipe.unet(noisy, timesteps, dest_repr).sample
+                    loss = F.mse_loss(edit_pred, pred_dest, reduction="mean")
+            if hp.cal_text_repr_loss and request.get("txt_align", True):
+                if k >= 2:
+                    term = F.mse_loss(edit_repr[ar, src_idx, :], wanted_rows, reduction="mean")
+                else:
+                    term = F.mse_loss(edit_pool, dest_pool, reduction="mean")
+                loss = hp.text_repr_loss_scale_factor * term if loss is None else loss + hp.text_repr_loss_scale_factor * term
+            if loss is not None:         # (no_noise_loss without a text term: the loss is the constant weight decay, no gradient)
+                loss.backward()
+                opt.step()
+            with torch.no_grad():
+                max_norm = hp.clamp_norm_factor * state["inits"].norm(dim=1)
+                norms = deltas.norm(dim=1)
+                over = norms > max_norm
+                if bool(over.any()):
+                    scaled = deltas * max_norm.unsqueeze(1) / norms.unsqueeze(1)
+                    deltas.copy_(torch.where(over.unsqueeze(1), scaled, deltas))
+    finally:
+        handle.remove()
+        for prm in frozen:
+            prm.requires_grad_(True)
+    return (deltas + state["inits"]).detach()
 
 
 def compute_z_sdxl_text_encoders(pipe, request: Dict, hparams, layers, device=None, resolution: int = 512, rng_device=None):
@@ -987,14 +1154,20 @@ def stage1_for(pipe, hparams, layer: int, batch_size: Optional[int] = None, **kw
     a UNet and a VAE: Stage 1 on a cache miss, like the reference (emcid_main.py:905-969).  Its ``batch(requests, suffix)``
     attribute serves all misses of a request list at once (compute_z_text_encoder_batched; EMCID_STAGE1_BATCH concepts per
     Adam step, default 8; 1 = one concept at a time)."""
+    new_z = bool(getattr(hparams, "use_new_compute_z", False))      # (num_edit_tokens, hidden) per concept (emcid_main.py:927-936)
+
     def stage1(request, suffix=""):
         if suffix:
             raise ValueError("a suffixed v* belongs to SDXL's second encoder: use stage1_for_sdxl (compute_z_sdxl_text_encoders)")
+        if new_z:
+            return compute_z_text_encoder_v2(pipe, request, hparams, layer, **kw)
         return compute_z_text_encoder(pipe, request, hparams, layer, **kw)
 
     def batch(requests, suffix=""):
         if suffix:
             raise ValueError("a suffixed v* belongs to SDXL's second encoder: use stage1_for_sdxl (compute_z_sdxl_text_encoders)")
+        if new_z:
+            return [compute_z_text_encoder_v2(pipe, r, hparams, layer, **kw) for r in requests]
         import os
         bs = batch_size if batch_size is not None else int(os.environ.get("EMCID_STAGE1_BATCH", "8"))
         if bs <= 1:

@@ -34,7 +34,7 @@ import torch.nn.functional as F
 from . import hip
 from . import clip_forward
 from .clip_attention import hip_attention
-from .compute_z import PromptBatch, build_prompt_batch, gather_request_means, iter_prompt_chunks
+from .compute_z import PromptBatch, build_prompt_batch, build_prompt_batch_multi, gather_request_means, iter_prompt_chunks
 from .nethook import StopForward, get_module, get_parameter
 
 
@@ -105,6 +105,7 @@ class EncoderEditPlan:
     backups: Optional[Dict[int, torch.Tensor]] = None    # W0 of the edited layers of the last run (failure recovery)
     factor_key: Optional[tuple] = None   # set by a run that factored lam*C' itself: check_info caches the factors if sound
     factors_from_cache: bool = False
+    num_edit_tokens: int = 1             # k > 1: k key / value rows per request (last subject token, EOS, padding), n_total = N k
 
     def weight_name(self, layer):
         return f"{self.rewrite_module_tmp.format(layer)}.weight"
@@ -148,7 +149,10 @@ class EncoderEditPlan:
     def ensure_batch(self) -> PromptBatch:
         if self.batch is None:
             dev = next(self.text_encoder.parameters()).device
-            self.batch = build_prompt_batch(self.tokenizer, self.local_requests, dev)
+            if self.num_edit_tokens > 1:
+                self.batch = build_prompt_batch_multi(self.tokenizer, self.local_requests, dev, self.num_edit_tokens)
+            else:
+                self.batch = build_prompt_batch(self.tokenizer, self.local_requests, dev)
         return self.batch
 
 
@@ -266,7 +270,7 @@ def _use_dual(plan, d: int) -> bool:
 def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], layers, rewrite_module_tmp, lam,
                          edit_weight, zs_t: torch.Tensor, covs: Dict[int, torch.Tensor],
                          shard: Optional[ConceptShard] = None, layer_module_tmp: Optional[str] = None,
-                         forward_mode: Optional[str] = None) -> EncoderEditPlan:
+                         forward_mode: Optional[str] = None, num_edit_tokens: int = 1) -> EncoderEditPlan:
     from . import manage_threads
     manage_threads()                    # acts once per process, and only under EMCID_MANAGE_THREADS=1
     shard = shard or ConceptShard()
@@ -277,6 +281,16 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
     local = list(requests[lo:hi])
     mode = forward_mode or FORWARD_MODE
     graph = None
+    k = int(num_edit_tokens)
+    if k < 1:
+        raise ValueError(f"num_edit_tokens must be >= 1, got {k}")
+    if k > 1:
+        # k rows per request ([last subject token, EOS, k - 2 padding positions], reference compute_z.py:2329-2382 and
+        # emcid_main.py:993-1014): the rows behind the EOS need the padded prompts, so this runs on the hooked forward over the
+        # padded batch (no prefix trie, no token truncation) and on one rank; the closed form then sees N k concepts
+        if shard.collective:
+            raise NotImplementedError("num_edit_tokens > 1 is a single-rank path")
+        mode = "hf"
     if mode == "trie" and layer_module_tmp is not None and device.type == "cuda":
         try:
             with phase("graph"):
@@ -289,7 +303,7 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
         except (clip_forward.UnsupportedEncoder, IndexError, LookupError):
             graph = None
     plan = EncoderEditPlan(text_encoder, list(layers), rewrite_module_tmp, float(lam), float(edit_weight), None,
-                           None, covs, len(requests), shard, tokenizer=tokenizer, local_requests=local)
+                           None, covs, len(requests) * k, shard, tokenizer=tokenizer, local_requests=local, num_edit_tokens=k)
     if graph is not None:
         # As soon as the prompts are tokenized their prefix trie is built and the unedited leading layers are LAUNCHED here,
         # so the GPU runs them underneath the rest of the host preparation (v* reads, statistics lookups).  The prompt list

@@ -208,7 +208,8 @@ def _native_vstar_rows(names: Sequence[Optional[str]], width: int, pin: bool):
 
 def load_v_stars(requests: Sequence[Dict], hparams, cache_name: Optional[str], suffix: str = "",
                  stage1: Optional[Stage1Fn] = None, width: Optional[int] = None, pin: bool = False) -> torch.Tensor:
-    """(N, hidden) fp32 on the host: one row per request, the transpose of the reference's ``zs`` (:977).  ``width``: the
+    """(N, hidden) fp32 on the host: one row per request, the transpose of the reference's ``zs`` (:977) — (N k, hidden), row
+    ``rq * k + num``, for ``use_new_compute_z`` files of k = num_edit_tokens rows each (:972-975).  ``width``: the
     encoder's hidden size when the caller knows it (then every cache file is read by the native batch reader; files it does
     not serve, and every miss, take the per-file path below, which is the reference's: np.load, recompute on an unreadable
     file :903-904, Stage 1 on a miss :905-969)."""
@@ -255,15 +256,24 @@ def load_v_stars(requests: Sequence[Dict], hparams, cache_name: Optional[str], s
                 Path(names[idx]).parent.mkdir(exist_ok=True, parents=True)
                 np.savez(names[idx], v_star=v)
             rows[idx] = v
+    new_z = bool(getattr(hparams, "use_new_compute_z", False))
     for idx, v in enumerate(rows):
         if v.dtype != np.float32:
             v = v.astype(np.float32)
-        if v.ndim == 2:   # use_new_compute_z layout (num_edit_tokens, hidden) with num_edit_tokens == 1
+        if new_z:         # files of shape (num_edit_tokens, hidden) (:946-957); zs = "rq num c_i -> c_i (rq num)" of their stack (:972-975)
+            if v.ndim == 1:
+                v = v[None, :]
+            if v.ndim != 2 or v.shape[0] != int(hparams.num_edit_tokens):
+                raise ValueError(f"v* of request {idx} has shape {tuple(v.shape)}; use_new_compute_z with num_edit_tokens = "
+                                 f"{hparams.num_edit_tokens} expects ({hparams.num_edit_tokens}, hidden)")
+        elif v.ndim == 2:
             if v.shape[0] != 1:
-                raise NotImplementedError("num_edit_tokens > 1 is not built (unused by shipped hparams)")
+                raise ValueError(f"v* of request {idx} has {v.shape[0]} rows: a multi-token v* needs hparams.use_new_compute_z "
+                                 f"(reference emcid_main.py:898-900, :972-977)")
             v = v[0]
         rows[idx] = v
-    return torch.from_numpy(np.stack(rows, axis=0))
+    out = np.stack(rows, axis=0)
+    return torch.from_numpy(out.reshape(-1, out.shape[-1]) if new_z else out)
 
 
 # ---- plans --------------------------------------------------------------------------------------------
@@ -361,18 +371,20 @@ def prepare_text_encoder_edit(text_encoder, tokenizer, requests, hparams, layers
     # prompts), in this order
     return prepare_encoder_edit(text_encoder, tokenizer, requests, layers, hparams.rewrite_module_tmp, lam,
                                 hparams.edit_weight, targets, statistics, _shard_from_env(shard),
-                                layer_module_tmp=getattr(hparams, "layer_module_tmp", None))
+                                layer_module_tmp=getattr(hparams, "layer_module_tmp", None),
+                                num_edit_tokens=int(getattr(hparams, "num_edit_tokens", 1)))
 
 
 def _default_stage1(pipe, hparams, stage1):
     """Stage 1 on a v* cache miss, like the reference (:905-969): when the caller gave no ``stage1=`` and the pipeline
     carries a UNet and a VAE, the missing v* is optimised by compute_z.compute_z_text_encoder at z_layer =
-    hparams.layers[-1] (:868) and written to the cache.  The reference's other Stage-1 variants (sld_supervision,
-    txt_img_align_scale_factor != 0, use_new_compute_z) are not built."""
+    hparams.layers[-1] (:868) and written to the cache — by compute_z_text_encoder_v2, (num_edit_tokens, hidden) per concept,
+    under ``use_new_compute_z`` (:927-936).  Not built: the two variants that fetch their own hub checkpoints
+    (``sld_supervision`` -> compute_z_text_encoder_global with the safe-latent-diffusion pipeline, :911-918;
+    ``txt_img_align_scale_factor != 0`` -> compute_z_text_encoder_v1 with openai/clip-vit-large-patch14, :919-926)."""
     if stage1 is not None or getattr(pipe, "unet", None) is None or getattr(pipe, "vae", None) is None:
         return stage1
-    if getattr(hparams, "sld_supervision", False) or getattr(hparams, "txt_img_align_scale_factor", 0) != 0 \
-            or getattr(hparams, "use_new_compute_z", False):
+    if getattr(hparams, "sld_supervision", False) or getattr(hparams, "txt_img_align_scale_factor", 0) != 0:
         return None
     from .compute_z import stage1_for
     return stage1_for(pipe, hparams, hparams.layers[-1])

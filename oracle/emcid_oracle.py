@@ -89,8 +89,12 @@ def find_token_range(tokenizer, token_array, substring_orig: str) -> Tuple[int, 
 # K/Z assembly (reference: emcid/compute_z.py:56-74, 2252-2325; emcid/compute_ks.py:21-41)
 # --------------------------------------------------------------------------------------
 
-def tokenize_prompts(prompts: List[str], tokenizer, device):
-    enc = tokenizer(prompts, return_tensors="pt", padding=True, truncation=True)
+def tokenize_prompts(prompts: List[str], tokenizer, device, padding_length=None):
+    """compute_z.py:56-74."""
+    if padding_length is None:
+        enc = tokenizer(prompts, return_tensors="pt", padding=True, truncation=True)
+    else:
+        enc = tokenizer(prompts, return_tensors="pt", padding="max_length", truncation=True, max_length=padding_length)
     return {k: v.to(device) for k, v in enc.items()}
 
 
@@ -471,6 +475,128 @@ def compute_z_text_encoder(pipe, request: Dict, hparams: Dict, layer: int, noise
     return (state["source_init"] + delta).detach()
 
 
+def compute_z_text_encoder_v2(pipe, request: Dict, hparams: Dict, layer: int, noise_scheduler, resolution: int = 512) -> torch.Tensor:
+    """The ``use_new_compute_z`` Stage 1 (compute_z.py:1041-1357), op for op: ``num_edit_tokens`` vectors per concept — the
+    last subject token, then (k >= 2) the EOS token and the k - 2 padding positions behind it, the prompts re-tokenized to
+    (longest + k - 2) with padding="max_length" (:1074-1083, :1182-1207).  Returns (k, hidden).  What the reference's text
+    does and this follows: the weight decay of the ablate objectives is formed under no_grad from float32 copies of the row
+    norms (:1277-1281), i.e. it is a constant of the loss; the text term is the MSE over the k looked-up rows for k >= 2, the
+    pooled outputs' MSE for k = 1 (:1297-1317); the L2 ball is per row (:1339-1343).  The esd objective and use_ewc read
+    ``source_init`` before any assignment (:1275, :1292) — an UnboundLocalError in the reference, NotImplementedError here."""
+    from copy import deepcopy
+    import torch.nn.functional as F
+    hp = lambda k, d=None: hparams.get(k, d)
+    objective = hp("objective")
+    if objective not in ("ablate-source", "ablate-dest", "esd"):
+        raise ValueError(f"Objective {objective} can not be used for compute_z.")
+    if objective == "esd" or hp("use_ewc", False):
+        raise NotImplementedError("compute_z_text_encoder_v2 reads source_init before assignment for esd / use_ewc (reference :1275, :1292)")
+    k = int(hp("num_edit_tokens", 1))
+    device = next(pipe.text_encoder.parameters()).device
+    te_edit = deepcopy(pipe.text_encoder).to(device)
+    tok = pipe.tokenizer
+    source_prompts = [p.format(request["source"]) for p in request["prompts"]]
+    dest_prompts = [p.format(request["dest"]) for p in request["prompts"]]
+    src_inp = tokenize_prompts(source_prompts, tok, device)
+    dst_inp = tokenize_prompts(dest_prompts, tok, device)
+    n_pad = k - 2
+    if k > 1:
+        padded = max(len(src_inp["input_ids"][0]), len(dst_inp["input_ids"][0])) + n_pad
+        src_inp = tokenize_prompts(source_prompts, tok, device, padding_length=padded)
+        dst_inp = tokenize_prompts(dest_prompts, tok, device, padding_length=padded)
+    deltas = torch.zeros((k, te_edit.config.hidden_size), requires_grad=True, device=device)
+    state = {"inits": None}
+    opt = torch.optim.Adam([deltas], lr=hp("v_lr"))
+    for m in (te_edit, pipe.vae, pipe.unet, pipe.text_encoder):
+        for prm in m.parameters():
+            prm.requires_grad = False
+    spp = hp("samples_per_prompt", 1)
+    if "training_img_paths" in request:
+        from PIL import Image
+        all_imgs = [Image.open(path) for path in request["training_img_paths"]]
+    elif "images" in request:
+        all_imgs = request["images"]
+    else:
+        generator = torch.Generator(device).manual_seed(int(request["seed_train"])) if request["seed_train"] is not None else None
+        all_imgs = []
+        for _ in range(spp):
+            all_imgs.extend(pipe(source_prompts, guidance_scale=7.5, generator=generator).images)
+    all_imgs = preprocess_img(all_imgs, resolution)
+    bsz = len(source_prompts)
+    all_imgs = all_imgs.reshape(spp, bsz, *all_imgs.shape[1:]).transpose(0, 1)       # "(s b) c h w -> b s c h w"
+    assert len(all_imgs) % bsz == 0
+    src_lookup = [[find_token_range(tok, ids, request["source"])[-1] - 1] for ids in src_inp["input_ids"]]
+    dst_lookup = [[find_token_range(tok, ids, request["dest"])[-1] - 1] for ids in dst_inp["input_ids"]]
+    if k >= 2:
+        src_eos = [int(m.sum()) - 1 for m in src_inp["attention_mask"]]
+        dst_eos = [int(m.sum()) - 1 for m in dst_inp["attention_mask"]]
+        src_lookup = [lk + list(range(e, e + n_pad + 1)) for lk, e in zip(src_lookup, src_eos)]
+        dst_lookup = [lk + list(range(e, e + n_pad + 1)) for lk, e in zip(dst_lookup, dst_eos)]
+    assert len(src_inp["input_ids"]) == len(dst_inp["input_ids"]) == len(all_imgs)
+    layer_mod = get_module(te_edit, hparams["layer_module_tmp"].format(layer))
+
+    def hook(mod, args, out):
+        h = _hidden(out)
+        if state["inits"] is None:
+            state["inits"] = h[0, src_lookup[0]].detach().clone()          # (k, hidden): rows of the FIRST prompt
+        for i, indices in enumerate(src_lookup):
+            for j, index in enumerate(indices):
+                if hp("replace_repr", False):
+                    h[i, index, :] = deltas[j, :]
+                else:
+                    h[i, index, :] += deltas[j, :]
+        return out
+
+    handle = layer_mod.register_forward_hook(hook)
+    try:
+        for it in range(hp("v_num_grad_steps")):
+            opt.zero_grad()
+            sample_indices = torch.randint(0, spp, (bsz,))
+            img_batch = all_imgs[torch.arange(bsz), sample_indices].to(device)
+            with torch.no_grad():
+                latents = pipe.vae.encode(img_batch).latent_dist.sample() * pipe.vae.config.scaling_factor
+                dest_repr, dest_pool = pipe.text_encoder(**dst_inp)[0:2]
+                if hp("cal_text_repr_loss", False):
+                    source_repr = pipe.text_encoder(**src_inp)[0]
+            noise = torch.randn_like(latents, device=device)
+            timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (bsz,), device=device).long()
+            noisy = noise_scheduler.add_noise(latents, noise, timesteps)
+            edit_repr, edit_pool = te_edit(**src_inp)[0:2]
+            if not hp("no_noise_loss", False):
+                edit_pred = pipe.unet(noisy, timesteps, edit_repr).sample
+                pred_dest = pipe.unet(noisy, timesteps, dest_repr).sample
+            inits = state["inits"]
+            if hp("use_sampled_noise", False) or request.get("use_real_noise", False):
+                mse = F.mse_loss(noise, edit_pred, reduction="mean")
+            elif hp("no_noise_loss", False):
+                mse = None
+            else:
+                mse = F.mse_loss(edit_pred, pred_dest, reduction="mean")
+            with torch.no_grad():
+                delta_norm = torch.Tensor([d_.norm() for d_ in deltas]).mean(0)
+                init_norm = torch.Tensor([s_.norm() for s_ in inits]).mean(0)
+            reg = hp("v_weight_decay") * (delta_norm / init_norm ** 2)
+            loss = reg if hp("no_noise_loss", False) else mse + reg
+            if hp("cal_text_repr_loss", False) and request.get("txt_align", True):
+                scale = hp("text_repr_loss_scale_factor")
+                if k >= 2:
+                    edited_rows = torch.stack([edit_repr[i, idx, :] for i, idx in enumerate(src_lookup)], dim=0)
+                    wanted_rows = torch.stack([dest_repr[i, idx, :] for i, idx in enumerate(dst_lookup)], dim=0)
+                    loss = loss + scale * F.mse_loss(edited_rows, wanted_rows, reduction="mean")
+                else:
+                    loss = loss + scale * F.mse_loss(edit_pool, dest_pool, reduction="mean")
+            loss.backward()
+            opt.step()
+            for i, s_ in enumerate(inits):
+                max_norm = hp("clamp_norm_factor") * s_.norm()
+                if deltas[i].norm() > max_norm:
+                    with torch.no_grad():
+                        deltas[i] = deltas[i] * max_norm / deltas[i].norm()
+    finally:
+        handle.remove()
+    return (deltas + state["inits"]).detach()
+
+
 # --------------------------------------------------------------------------------------
 # second moment + Stage 0 (reference: util/runningstats.py:469-511, 1551-1600;
 # dsets/stat_dataset.py:71-172; emcid/layer_stats.py:140-220)
@@ -587,12 +713,16 @@ def load_cov(stat_dir, layer_name, n_samples, precision="float32") -> torch.Tens
     return (mom2 / count).float()
 
 
-def load_vstars(cache_name: str, requests, suffix: str = "") -> torch.Tensor:
-    """zs = stack(v_star, dim=1) -> (hidden, N) fp32 (emcid_main.py:885-899, 977)."""
+def load_vstars(cache_name: str, requests, suffix: str = "", use_new_compute_z: bool = False) -> torch.Tensor:
+    """zs = stack(v_star, dim=1) -> (hidden, N) fp32 (emcid_main.py:885-899, 977); with ``use_new_compute_z`` the files hold
+    (num_edit_tokens, hidden) and zs = "rq num c_i -> c_i (rq num)" of their stack (:972-975)."""
     vs = []
     for r in requests:
         with np.load(Path(cache_name + f"source_{r['source']}_dest_{r['dest']}{suffix}.npz")) as z:
             vs.append(torch.from_numpy(z["v_star"]))
+    if use_new_compute_z:
+        zs = torch.stack(vs, dim=0)                     # (rq, num, c_i)
+        return zs.reshape(-1, zs.shape[-1]).t()
     return torch.stack(vs, dim=1)
 
 
@@ -617,9 +747,10 @@ def closed_form_layer(K: torch.Tensor, Zc: torch.Tensor, zs: torch.Tensor, C: to
 
 def execute_text_encoder(text_encoder, tokenizer, requests, layers: Sequence[int], rewrite_module_tmp: str,
                          zs: torch.Tensor, covs: Dict[int, torch.Tensor], lam: float, edit_weight: float,
-                         restore: bool = True, trace: Optional[list] = None):
+                         restore: bool = True, trace: Optional[list] = None, num_edit_tokens: int = 1):
     """Sequential per-layer loop: K fwd, Zc fwd, solve, write W_orig + upd.float() into the live model
-    (emcid_main.py:981-1078).  `restore=False` reproduces the SDXL TE2 path (never restored)."""
+    (emcid_main.py:981-1078).  `restore=False` reproduces the SDXL TE2 path (never restored).  ``num_edit_tokens`` > 1: the
+    (N, k, .) rows of the num_fact_token branch flattened "rq num c_i -> c_i (rq num)" (:993-1014)."""
     names = [rewrite_module_tmp.format(l) + ".weight" for l in layers]
     weights = {n: get_parameter(text_encoder, n) for n in names}
     backup = {n: w.detach().clone() for n, w in weights.items()}
@@ -627,8 +758,13 @@ def execute_text_encoder(text_encoder, tokenizer, requests, layers: Sequence[int
     with torch.no_grad():
         for i, layer in enumerate(layers):
             mod = rewrite_module_tmp.format(layer)
-            K, _ = module_input_output_at_words(text_encoder, tokenizer, requests, mod)
-            _, Zc = module_input_output_at_words(text_encoder, tokenizer, requests, mod)
+            if num_edit_tokens > 1:
+                K, _ = module_input_output_at_words_multi(text_encoder, tokenizer, requests, mod, num_edit_tokens)
+                _, Zc = module_input_output_at_words_multi(text_encoder, tokenizer, requests, mod, num_edit_tokens)
+                K, Zc = K.reshape(-1, K.shape[-1]), Zc.reshape(-1, Zc.shape[-1])
+            else:
+                K, _ = module_input_output_at_words(text_encoder, tokenizer, requests, mod)
+                _, Zc = module_input_output_at_words(text_encoder, tokenizer, requests, mod)
             adj_k, resid, upd = closed_form_layer(K, Zc, zs, covs[layer], lam, edit_weight, len(layers) - i)
             n = mod + ".weight"
             if upd.shape != weights[n].shape:
@@ -662,11 +798,12 @@ def apply_emcid_to_text_encoder(pipe, requests, hparams: Dict, mom2_weight=None,
     hparams["edit_weight"] = edit_weight if edit_weight is not None else hparams.get("edit_weight", 0.5)
     requests = copy.deepcopy(requests)
     tmpl = hparams["rewrite_module_tmp"]
-    zs = load_vstars(cache_name, requests)
+    zs = load_vstars(cache_name, requests, use_new_compute_z=hparams.get("use_new_compute_z", False))
     covs = {l: load_cov(stats_dir, tmpl.format(l), hparams["mom2_n_samples"], hparams["mom2_dtype"])
             for l in hparams["layers"]}
     deltas = execute_text_encoder(pipe.text_encoder, pipe.tokenizer, requests, hparams["layers"], tmpl, zs, covs,
-                                  hparams["mom2_update_weight"], hparams["edit_weight"], trace=trace)
+                                  hparams["mom2_update_weight"], hparams["edit_weight"], trace=trace,
+                                  num_edit_tokens=int(hparams.get("num_edit_tokens", 1)))
     insert_deltas(pipe.text_encoder, deltas)
     return pipe, deltas
 

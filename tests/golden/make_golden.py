@@ -361,6 +361,73 @@ def golden_sd(em, EMCIDHyperParams, scratch, tag, kind, n_req, layers, lam, ew, 
     print(f"[golden] {tag}: wrote {len(out)} arrays")
 
 
+MULTI_TOKEN = dict(k=3, n_req=4, layers=(1, 2, 3, 4), lam=60, ew=0.55, seed=4321,
+                   hp=dict(objective="ablate-dest", cal_text_repr_loss=True, text_repr_loss_scale_factor=0.02, v_lr=0.1,
+                           v_weight_decay=5e-4, clamp_norm_factor=0.8, v_num_grad_steps=6, use_new_compute_z=True, num_edit_tokens=3))
+
+
+def golden_multi_token(em, EMCIDHyperParams, scratch, tag="toy_multi_token"):
+    """``use_new_compute_z`` with ``num_edit_tokens = 3``, end to end through the REAL reference: an empty v* cache, so
+    execute_emcid_text_encoder runs compute_z_text_encoder_v2 per request (compute_z.py:1041-1357; files of shape (3, hidden),
+    emcid_main.py:946-957), then the layer loop on (N, 3, .) key / value rows flattened "rq num" (:993-1014), then the
+    apply.  UNet / VAE / DDPM stand-ins and 4.27 layer convention as for toy_stage1; the wrapper puts the layers' own modules
+    one level down (``.inner``), which the REFERENCE run's rewrite_module_tmp spells out (data, not code)."""
+    c = MULTI_TOKEN
+    pipe = syn.add_diffusion(syn.build_pipe("toy", "cpu"))
+    w_names = [f"encoder.layers.{l}.mlp.fc2" for l in c["layers"]]
+    w0 = {n: em.nethook.get_parameter(pipe.text_encoder, n + ".weight").detach().clone() for n in w_names}
+    state0 = {k: v.copy() for k, v in state_np(pipe.text_encoder).items()}      # (state_np's arrays alias the live weights)
+    as_transformers_427(pipe.text_encoder)
+    hidden, inter = syn.ENCODER_DIMS["toy"][:2]
+    reqs = syn.make_requests(c["n_req"], ragged=True)
+    hp_d = syn.sd_hparams_dict(layers=c["layers"], mom2_update_weight=c["lam"] + 1, edit_weight=0.5, mom2_n_samples=1000, prefix="")
+    hp_d.update(c["hp"])
+    ref_d = dict(hp_d, rewrite_module_tmp="encoder.layers.{}.inner.mlp.fc2")
+    imgs = [syn.make_images(len(r["prompts"]) * hp_d.get("samples_per_prompt", 1), STAGE1_RESOLUTION, seed=500 + i)
+            for i, r in enumerate(reqs)]
+    run_reqs = [dict(r, images=im) for r, im in zip(reqs, imgs)]
+    cache = str(scratch / f"cache_{tag}") + "/"
+    stats_dir = scratch / f"stats_{tag}"
+    ref_names = [ref_d["rewrite_module_tmp"].format(l) for l in c["layers"]]
+    covs = syn.write_stats_cache(stats_dir, ref_names, inter, 1000, seed=2, t=max(2 * inter, 512))
+    em.COV_CACHE.clear()
+    rec = []
+    orig, cks = record_kz(em, rec)
+    torch.manual_seed(c["seed"])
+    with contextlib.redirect_stdout(io.StringIO()):
+        deltas = em.execute_emcid_text_encoder(pipe, run_reqs, EMCIDHyperParams(**ref_d), cache_name=cache, mom2_weight=c["lam"],
+                                               edit_weight=c["ew"], verbose=False, stat_dir=str(stats_dir))
+    unrecord_kz(em, orig, cks)
+    em.COV_CACHE.clear()
+    with contextlib.redirect_stdout(io.StringIO()):
+        pipe2, _ = em.apply_emcid_to_text_encoder(pipe, run_reqs, EMCIDHyperParams(**ref_d), "cpu", mom2_weight=c["lam"],
+                                                  edit_weight=c["ew"], cache_name=cache, stats_dir=str(stats_dir), verbose=False)
+    out = dict(state0)
+    for i, r in enumerate(reqs):
+        with np.load(cache + f"source_{r['source']}_dest_{r['dest']}.npz") as z:
+            out[f"vstar/{i}"] = z["v_star"]
+        assert out[f"vstar/{i}"].shape == (c["k"], hidden)
+        out[f"images/{i}"] = np.stack([np.asarray(im) for im in imgs[i]])
+    for li, (n, rn) in enumerate(zip(w_names, ref_names)):
+        adj_k, resid = deltas[rn + ".weight"]
+        k_in, _ = rec[2 * li]
+        _, z_out = rec[2 * li + 1]
+        out[f"cov/{li}"] = covs[rn].astype(np.float32)
+        out[f"K/{li}"] = k_in.numpy()                 # (N, k, d)
+        out[f"Zc/{li}"] = z_out.numpy()               # (N, k, h)
+        out[f"adj_k/{li}"] = adj_k.numpy()            # (d, N k)
+        out[f"resid/{li}"] = resid.numpy()            # (h, N k)
+        out[f"w_orig/{li}"] = w0[n].numpy()
+        out[f"w_final/{li}"] = em.nethook.get_parameter(pipe2.text_encoder, rn + ".weight").detach().numpy()
+    meta = {"kind": "toy", "requests": reqs, "hparams": hp_d, "layers": list(c["layers"]), "lam": c["lam"], "ew": c["ew"],
+            "seed": c["seed"], "k": c["k"], "layer_names": w_names, "resolution": STAGE1_RESOLUTION,
+            "stats": {"seed": 2, "t": max(2 * inter, 512), "n_samples": 1000}}
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump(meta, f, indent=1)
+    print(f"[golden] {tag}: wrote {len(out)} arrays; |v*| " + ", ".join(f"{np.linalg.norm(out[f'vstar/{i}']):.4f}" for i in range(len(reqs))))
+
+
 def golden_sdxl(em, EMCIDXLHyperParams, scratch, tag="toy_sdxl"):
     pipe = syn.build_pipe("toy", "cpu", sdxl=True)
     reqs = syn.make_requests(6)
@@ -782,6 +849,8 @@ def main():
                 golden_stage1(cz, HP, scratch)
             elif which == "toy_stage1_sdxl":
                 golden_stage1_sdxl(cz, XLHP, scratch)
+            elif which == "toy_multi_token":
+                golden_multi_token(em, HP, scratch)
             else:
                 raise SystemExit(f"unknown fixture {which}")
             return
@@ -796,6 +865,7 @@ def main():
         golden_toy_extras(cz, ls, scratch)
         golden_stage1(cz, HP, scratch)
         golden_stage1_sdxl(cz, XLHP, scratch)
+        golden_multi_token(em, HP, scratch)
         if "--skip-real" not in sys.argv:
             golden_sd(em, HP, scratch, "real_sd_summary", "sd-v1.4", n_req=24, layers=(7, 8, 9, 10), lam=4000,
                       ew=0.5, ragged=False, full=False)

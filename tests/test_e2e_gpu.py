@@ -808,6 +808,77 @@ def test_stage0_float16_precision(tmp_path, forward):
     assert np.abs(got - ref).max() > 0          # it IS a different statistic from the fp32 one
 
 
+def _multi_token(tmp_path):
+    from PIL import Image
+    z, meta = load_golden("toy_multi_token")
+    te = pipe_from_golden(z, meta["kind"]).to(DEV)
+    pipe = syn.add_diffusion(syn.SyntheticPipe(text_encoder=te, tokenizer=syn.build_tokenizer()))
+    reqs = [dict(r, images=[Image.fromarray(a, "RGB") for a in z[f"images/{i}"]]) for i, r in enumerate(meta["requests"])]
+    for li, ln in enumerate(meta["layer_names"]):
+        write_cov_npz(tmp_path / "stats", ln, z[f"cov/{li}"], meta["hparams"]["mom2_n_samples"])
+    return z, meta, pipe, reqs
+
+
+def test_multi_token_edit_from_reference_vstars(tmp_path):
+    """``use_new_compute_z`` with ``num_edit_tokens = 3``, Stage 2 alone: the reference's own (3, hidden) v* files in the cache,
+    then execute_* / apply_* on the MI355X against the factors and final weights the REAL reference produced (fixture
+    toy_multi_token).  The closed form sees N k = 12 concepts: rows [last subject token, EOS, one padding position] of every
+    request, "rq num" order (reference emcid_main.py:993-1014)."""
+    z, meta, pipe, reqs = _multi_token(tmp_path)
+    k, n = meta["k"], len(reqs)
+    cache = str(tmp_path / "cache") + "/"
+    write_vstars(cache, meta["requests"], [z[f"vstar/{i}"] for i in range(n)])
+    before = {ln: get_parameter(pipe.text_encoder, ln + ".weight").clone() for ln in meta["layer_names"]}
+    deltas = em.execute_emcid_text_encoder(pipe, meta["requests"], EMCIDHyperParams(**meta["hparams"]), cache_name=cache,
+                                           mom2_weight=meta["lam"], edit_weight=meta["ew"], verbose=False,
+                                           stat_dir=str(tmp_path / "stats"))
+    for li, ln in enumerate(meta["layer_names"]):
+        adj_k, resid = deltas[ln + ".weight"]
+        ref_a, ref_r = z[f"adj_k/{li}"], z[f"resid/{li}"]
+        assert adj_k.shape == ref_a.shape == (ref_a.shape[0], n * k) and resid.shape == ref_r.shape
+        np.testing.assert_allclose(adj_k.numpy(), ref_a, rtol=0, atol=2e-4 * np.abs(ref_a).max())
+        np.testing.assert_allclose(resid.numpy(), ref_r, rtol=0, atol=2e-5 * np.abs(ref_r).max())
+        assert torch.equal(get_parameter(pipe.text_encoder, ln + ".weight"), before[ln])
+    em.apply_emcid_to_text_encoder(pipe, meta["requests"], EMCIDHyperParams(**meta["hparams"]), DEV, mom2_weight=meta["lam"],
+                                   edit_weight=meta["ew"], cache_name=cache, stats_dir=str(tmp_path / "stats"), verbose=False)
+    for li, ln in enumerate(meta["layer_names"]):
+        dw_ref = z[f"w_final/{li}"].astype(np.float64) - z[f"w_orig/{li}"]
+        dw = get_parameter(pipe.text_encoder, ln + ".weight").double().cpu().numpy() - z[f"w_orig/{li}"]
+        assert np.abs(dw - dw_ref).max() <= 1e-4 * np.abs(dw_ref).max()
+    # the K / Zc rows themselves, through the public function
+    from emcid_amd.compute_z import get_module_input_output_at_words
+    te = pipe_from_golden(z, meta["kind"]).to(DEV)
+    K, Zc = get_module_input_output_at_words(te, pipe.tokenizer, meta["requests"], meta["layer_names"][0], num_fact_token=k)
+    assert tuple(K.shape) == z["K/0"].shape and tuple(Zc.shape) == z["Zc/0"].shape
+    assert np.abs(K.cpu().numpy() - z["K/0"]).max() <= 2e-5 * np.abs(z["K/0"]).max()
+    assert np.abs(Zc.cpu().numpy() - z["Zc/0"]).max() <= 2e-5 * np.abs(z["Zc/0"]).max()
+
+
+def test_multi_token_cold_cache_runs_stage1_v2_then_edits(tmp_path):
+    """The same fixture from an EMPTY cache, as the reference minted it: Stage 1 (compute_z_text_encoder_v2, one concept after
+    the other under one seed, random draws from the host generator) writes (3, hidden) files, the edit follows.  v* on
+    another device through 6 Adam steps: 2e-4 like the other GPU Stage-1 tests; the weights inherit that."""
+    from emcid_amd.compute_z import stage1_for
+    z, meta, pipe, reqs = _multi_token(tmp_path)
+    k, n = meta["k"], len(reqs)
+    hp = EMCIDHyperParams(**meta["hparams"])
+    cache = str(tmp_path / "cache") + "/"
+    stage1 = stage1_for(pipe, hp, meta["layers"][-1], noise_scheduler=syn.DDPMNoiseSchedule(), resolution=meta["resolution"],
+                        rng_device="cpu")
+    torch.manual_seed(meta["seed"])
+    em.apply_emcid_to_text_encoder(pipe, reqs, hp, DEV, mom2_weight=meta["lam"], edit_weight=meta["ew"], cache_name=cache,
+                                   stats_dir=str(tmp_path / "stats"), verbose=False, stage1=stage1)
+    for i, r in enumerate(meta["requests"]):
+        with np.load(syn.vstar_cache_path(cache, r)) as f:
+            v = f["v_star"]
+        ref = z[f"vstar/{i}"]
+        assert v.shape == ref.shape == (k, 32) and np.abs(v - ref).max() <= 2e-4 * np.abs(ref).max()
+    for li, ln in enumerate(meta["layer_names"]):
+        dw_ref = z[f"w_final/{li}"].astype(np.float64) - z[f"w_orig/{li}"]
+        dw = get_parameter(pipe.text_encoder, ln + ".weight").double().cpu().numpy() - z[f"w_orig/{li}"]
+        assert np.abs(dw - dw_ref).max() <= 2e-3 * np.abs(dw_ref).max()
+
+
 def test_sdxl_cache_miss_runs_pair_stage1_then_edits(tmp_path):
     """apply_emcid_to_sdxl_text_encoders on a cold v* cache with a pipeline that carries a UNet and a VAE: Stage 1 of the pair
     (compute_z_sdxl_text_encoders, ONE optimisation per request for both encoders, reference emcid_main.py:1157-1230) fills

@@ -165,6 +165,86 @@ def test_stage1_v_star_matches_reference(name):
     assert all(p.requires_grad is False for p in pipe.text_encoder.parameters())      # synthetic encoders are frozen: left as found
 
 
+def _multi_token_case(z, meta, tmp_path, device="cpu"):
+    from PIL import Image
+    te = pipe_from_golden(z, meta["kind"], device=device)
+    pipe = syn.add_diffusion(syn.SyntheticPipe(text_encoder=te, tokenizer=syn.build_tokenizer()))
+    reqs = [dict(r, images=[Image.fromarray(a, "RGB") for a in z[f"images/{i}"]]) for i, r in enumerate(meta["requests"])]
+    for li, ln in enumerate(meta["layer_names"]):
+        write_cov_npz(tmp_path / "stats", ln, z[f"cov/{li}"], meta["hparams"]["mom2_n_samples"])
+    return pipe, reqs
+
+
+def test_multi_token_stage1_v2_and_edit_match_reference(tmp_path):
+    """``use_new_compute_z`` with ``num_edit_tokens = 3`` (fixture toy_multi_token, minted by the REAL reference from an empty
+    v* cache): the oracle's compute_z_text_encoder_v2 reproduces every request's (3, hidden) v* bit for bit when the requests
+    are optimised in order under one seed, and its layer loop on the "rq num"-flattened rows reproduces K, Zc, adj_k, resid
+    and the final weights."""
+    z, meta = load_golden("toy_multi_token")
+    pipe, reqs = _multi_token_case(z, meta, tmp_path)
+    k = meta["k"]
+    torch.manual_seed(meta["seed"])
+    vs = [orc.compute_z_text_encoder_v2(pipe, r, meta["hparams"], meta["layers"][-1], syn.DDPMNoiseSchedule(), meta["resolution"])
+          for r in reqs]
+    for i, v in enumerate(vs):
+        assert tuple(v.shape) == (k, syn.ENCODER_DIMS["toy"][0])
+        np.testing.assert_array_equal(v.numpy(), z[f"vstar/{i}"])
+    cache = str(tmp_path / "cache") + "/"
+    write_vstars(cache, meta["requests"], [z[f"vstar/{i}"] for i in range(len(reqs))])
+    hp = copy.deepcopy(meta["hparams"])
+    trace = []
+    pipe, deltas = orc.apply_emcid_to_text_encoder(pipe, meta["requests"], hp, mom2_weight=meta["lam"], edit_weight=meta["ew"],
+                                                   cache_name=cache, stats_dir=str(tmp_path / "stats"), trace=trace)
+    n = len(reqs)
+    for li, ln in enumerate(meta["layer_names"]):
+        np.testing.assert_array_equal(trace[li]["K"].numpy().reshape(n, k, -1), z[f"K/{li}"])
+        np.testing.assert_array_equal(trace[li]["Zc"].numpy().reshape(n, k, -1), z[f"Zc/{li}"])
+        adj_k, resid = deltas[ln + ".weight"]
+        assert adj_k.shape[1] == n * k
+        np.testing.assert_allclose(adj_k.numpy(), z[f"adj_k/{li}"], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(resid.numpy(), z[f"resid/{li}"], rtol=1e-13, atol=0)
+        np.testing.assert_array_equal(orc.get_parameter(pipe.text_encoder, ln + ".weight").numpy(), z[f"w_final/{li}"])
+
+
+def test_multi_token_product_stage1_v2_and_host_side(tmp_path):
+    """The product's compute_z_text_encoder_v2 (hook in place, hoisted invariants, vectorised rows) against the reference's
+    (3, hidden) v* on the same device to fp32 rounding; the v* loader's "rq num" flattening and its shape checks; the padded
+    multi-token prompt batch against the oracle's lookup rows."""
+    from emcid_amd import emcid_main as em
+    from emcid_amd.compute_z import build_prompt_batch_multi, stage1_for
+    z, meta = load_golden("toy_multi_token")
+    pipe, reqs = _multi_token_case(z, meta, tmp_path)
+    hp = EMCIDHyperParams(**meta["hparams"])
+    k, n = meta["k"], len(reqs)
+    stage1 = stage1_for(pipe, hp, meta["layers"][-1], noise_scheduler=syn.DDPMNoiseSchedule(), resolution=meta["resolution"])
+    torch.manual_seed(meta["seed"])
+    cache = str(tmp_path / "cache") + "/"
+    zs = em.load_v_stars(reqs, hp, cache, stage1=stage1)          # every file missing: Stage 1 in request order, files written
+    assert tuple(zs.shape) == (n * k, syn.ENCODER_DIMS["toy"][0])
+    for i in range(n):
+        ref = z[f"vstar/{i}"]
+        assert np.abs(zs[i * k:(i + 1) * k].numpy() - ref).max() <= 3e-6 * np.abs(ref).max()
+        with np.load(syn.vstar_cache_path(cache, reqs[i])) as f:
+            assert f["v_star"].shape == (k, zs.shape[1])
+    again = em.load_v_stars(reqs, hp, cache, stage1=lambda *a: 1 / 0, width=zs.shape[1])      # served from the files
+    assert torch.equal(again, zs)
+    with pytest.raises(ValueError, match="use_new_compute_z"):
+        em.load_v_stars(reqs, EMCIDHyperParams(**dict(meta["hparams"], use_new_compute_z=False)), cache)
+    with pytest.raises(ValueError, match="expects"):
+        em.load_v_stars(reqs, EMCIDHyperParams(**dict(meta["hparams"], num_edit_tokens=2)), cache)
+    # lookup rows of the padded batch == the oracle's
+    batch = build_prompt_batch_multi(pipe.tokenizer, meta["requests"], "cpu", k)
+    prompts, subjects, counts = orc.expand_requests(meta["requests"])
+    first = orc.tokenize_prompts(prompts, pipe.tokenizer, "cpu")
+    inp = orc.tokenize_prompts(prompts, pipe.tokenizer, "cpu", padding_length=first["input_ids"].shape[1] + k - 2)
+    want = [[orc.find_token_range(pipe.tokenizer, ids, w)[-1] - 1] + list(range(int(m.sum()) - 1, int(m.sum()) - 1 + k - 1))
+            for ids, w, m in zip(inp["input_ids"], subjects, inp["attention_mask"])]
+    assert batch.lookup_multi.t().tolist() == want and torch.equal(batch.inputs["input_ids"], inp["input_ids"])
+    for bad in ("esd",):
+        with pytest.raises(NotImplementedError):
+            stage1_for(pipe, EMCIDHyperParams(**dict(meta["hparams"], objective=bad)), 4)(reqs[0])
+
+
 def test_headline_workload_keys_at_first_edited_layer():
     """bench.py's workload itself (1 000 syllable-named concepts, 3 000 prompts, SD-v1.4 dims): the oracle's keys at the
     first edited layer against the REAL reference's (fixture real_sd_n1000_summary; one 12-layer forward, ~15 s).  Pins
