@@ -17,7 +17,7 @@ import operator
 import os
 import weakref
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -162,19 +162,23 @@ class PromptChunk:
     lookup: Sequence[int]    # position of the last subject token per prompt (list or int64 array)
     counts: List[int]        # prompts per request
     n_requests: int
+    verify: Optional[Callable[[], bool]] = None      # deferred tokenizer cross-check (templated_prompt_chunk), None = already done
 
 
 _GET_SOURCE, _GET_PROMPTS = operator.itemgetter("source"), operator.itemgetter("prompts")
 
 
-def templated_prompt_chunk(tokenizer, requests: Sequence[Dict], first: Dict) -> Optional[PromptChunk]:
+def templated_prompt_chunk(tokenizer, requests: Sequence[Dict], first: Dict, defer_probe: bool = False) -> Optional[PromptChunk]:
     """The (few templates) x (many names) shape of a mass edit WITHOUT building, joining and re-splitting the prompt strings:
     ``p.format(source)`` (reference compute_z.py:2278-2283) for templates with exactly one ``{}`` and no other brace is
     ``prefix + source + suffix``, so ``libemcid_host`` encodes every distinct prefix, suffix and source once
     (``emcid_bpe_encode_templated``) and walks each row for its subject with the subjects passed once
     (``emcid_find_token_ranges_idx``).  Same ids and lookup positions as the generic path (tests/test_host_cpu.py); returns
     None whenever the request list is outside that shape (pre-formatted ``source_prompts``, other format fields, a
-    tokenizer without a native twin, a non-string source) and the caller takes the generic path."""
+    tokenizer without a native twin, a non-string source) and the caller takes the generic path.  ``defer_probe``: the
+    per-call comparison of the longest row against the public tokenizer call (a never-seen prompt: ~0.1 ms of the HF
+    tokenizer) is handed back as ``chunk.verify`` instead of being run here — the engine calls it after it has launched the
+    leading layers and redoes the preparation on the generic path if it ever says no."""
     if "source_prompts" in first or "prompts" not in first or len(requests) < 3 or getattr(tokenizer, "_tokenizer", None) is None:
         return None
     twin = host_text.NativeClipBpe.for_tokenizer(tokenizer)
@@ -234,28 +238,36 @@ def templated_prompt_chunk(tokenizer, requests: Sequence[Dict], first: Dict) -> 
     # as tokenize_lists does on every call: the longest row against the public tokenizer call
     # (a prompt string that has been compared once is not compared again: both tokenizers are deterministic functions of it)
     j = int(lengths.argmax())
-    pj = prompt(j)
+    pj, lj = prompt(j), int(lengths[j])
+    row_j = ids[j, :lj].copy()
     seen = twin.__dict__.setdefault("_verified_prompts", {})
-    if seen.get(pj) != ids[j, :int(lengths[j])].tobytes():
+
+    def probe_agrees() -> bool:
+        if seen.get(pj) == row_j.tobytes():
+            return True
         probe = tokenizer([pj], padding=True, truncation=True)
         want = probe["input_ids"][0]
-        if S < len(want) or ids[j, :len(want)].tolist() != want or int(lengths[j]) != int(sum(probe["attention_mask"][0])) \
-                or set(probe.keys()) != {"input_ids", "attention_mask"}:
-            host_text.NativeClipBpe.disable(tokenizer)
-            return None
+        mask_len = int(sum(probe["attention_mask"][0]))
+        if lj != mask_len or row_j.tolist() != list(want) or set(probe.keys()) != {"input_ids", "attention_mask"}:
+            host_text.NativeClipBpe.disable(tokenizer)      # never trust a twin that disagreed once
+            return False
         if len(seen) > 4096:
             seen.clear()
-        seen[pj] = ids[j, :int(lengths[j])].tobytes()
+        seen[pj] = row_j.tobytes()
+        return True
+
+    if not defer_probe and not probe_agrees():
+        return None
     ids = ids[:, :S]
     lk = finder_for(tokenizer).last_tokens(ids, names, name_idx, packed=packed_names)
     bad = np.nonzero((lk < 0) | (lk >= S))[0]
     if bad.size:
         j = int(bad[0])
         raise ValueError(f"lookup index {int(lk[j])} outside the padded prompt (S={S}) for prompt {prompt(j)!r}")
-    return PromptChunk(np.ascontiguousarray(ids[:, :int(lk.max()) + 1]), lk, counts, n)
+    return PromptChunk(np.ascontiguousarray(ids[:, :int(lk.max()) + 1]), lk, counts, n, verify=probe_agrees if defer_probe else None)
 
 
-def iter_prompt_chunks(tokenizer, requests: Sequence[Dict], n_chunks: int):
+def iter_prompt_chunks(tokenizer, requests: Sequence[Dict], n_chunks: int, defer_probe: bool = False):
     """The request list in ``n_chunks`` contiguous slices, each tokenized, searched and truncated on its own, lazily: the
     caller builds a slice's prefix trie and launches its share of the encoder forward before asking for the next slice,
     so the GPU works on slice i while the host tokenizes slice i+1 (no helper thread: the launches are asynchronous)."""
@@ -266,7 +278,7 @@ def iter_prompt_chunks(tokenizer, requests: Sequence[Dict], n_chunks: int):
     for i in range(n_chunks):
         lo, hi = (n * i) // n_chunks, (n * (i + 1)) // n_chunks
         if os.environ.get("EMCID_TEMPLATED", "1") != "0":
-            fast = templated_prompt_chunk(tokenizer, requests[lo:hi], first)
+            fast = templated_prompt_chunk(tokenizer, requests[lo:hi], first, defer_probe)
             if fast is not None:
                 yield fast
                 continue

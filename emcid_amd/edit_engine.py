@@ -315,7 +315,7 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
         chunks: List[TrieChunk] = []
         tune_mode = os.environ.get("EMCID_TUNE_GEMM", "auto")
         try:
-            it = iter_prompt_chunks(tokenizer, local, n_chunks)
+            it = iter_prompt_chunks(tokenizer, local, n_chunks, defer_probe=True)
             while True:
                 with phase("tokenize+lookup"):
                     pc = next(it, None)
@@ -329,6 +329,15 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
                 with phase("prefix launches"), torch.no_grad():
                     hs, x_ln1 = clip_forward.run_prefix(graph, trie, first_edit)
                 chunks.append(TrieChunk(trie, seg, pc.n_requests, len(pc.lookup), (first_edit, hs, x_ln1)))
+                if pc.verify is not None:
+                    # the native tokenizer's per-call cross-check against the public tokenizer call, run now that the GPU has
+                    # this slice's leading layers to work on.  It has never said no; if it does, the twin is disabled for good and
+                    # the preparation starts over on the generic path (what was launched above is simply abandoned).
+                    with phase("tokenize+lookup"):
+                        agreed = pc.verify()
+                    if not agreed:
+                        return prepare_encoder_edit(text_encoder, tokenizer, requests, layers, rewrite_module_tmp, lam, edit_weight,
+                                                    zs_t, covs, shard, layer_module_tmp, forward_mode, num_edit_tokens)
             plan.graph, plan.chunks = graph, chunks
         except (clip_forward.UnsupportedEncoder, IndexError):
             plan.graph = plan.chunks = None

@@ -668,6 +668,38 @@ def _chunks_equal(a, b):
     assert np.array_equal(np.asarray(a.ids), np.asarray(b.ids)) and np.asarray(a.lookup).tolist() == np.asarray(b.lookup).tolist()
 
 
+def test_templated_path_deferred_probe(monkeypatch):
+    """``defer_probe``: the chunk carries the longest row's cross-check against the public tokenizer call instead of running it;
+    it says yes on an honest twin, and on a disagreement it says no and retires the twin (the engine then redoes the
+    preparation on the generic path)."""
+    from emcid_amd import compute_z as cz, host_text
+    if not host_text.available():
+        pytest.skip("libemcid_host.so not built")
+    tok = syn.build_tokenizer(*syn.synthetic_vocab(syllables=True))
+    if host_text.NativeClipBpe.for_tokenizer(tok) is None:
+        pytest.skip("no native twin for the synthetic tokenizer")
+    reqs = syn.make_requests(40, names="syllable", name_seed=77)
+    now = cz.templated_prompt_chunk(tok, reqs, reqs[0])
+    assert now is not None and now.verify is None
+    later = cz.templated_prompt_chunk(tok, syn.make_requests(40, names="syllable", name_seed=78), reqs[0], defer_probe=True)
+    assert later is not None and callable(later.verify) and later.verify() is True and later.verify() is True
+    third = cz.templated_prompt_chunk(tok, syn.make_requests(40, names="syllable", name_seed=79), reqs[0], defer_probe=True)
+    real = type(tok).__call__
+
+    def lying(self, prompts, **kw):
+        out = real(self, prompts, **kw)
+        out["input_ids"][0][1] += 1
+        return out
+
+    monkeypatch.setattr(type(tok), "__call__", lying)
+    assert third.verify() is False
+    monkeypatch.setattr(type(tok), "__call__", real)
+    assert host_text.NativeClipBpe.for_tokenizer(tok) is None and cz.templated_prompt_chunk(tok, reqs, reqs[0]) is None
+    chunks = list(cz.iter_prompt_chunks(tok, reqs, 1, defer_probe=True))          # generic path now: nothing left to verify
+    assert len(chunks) == 1 and chunks[0].verify is None
+    _chunks_equal(chunks[0], now)
+
+
 def test_templated_prompt_path_equals_generic_path(monkeypatch):
     """templated_prompt_chunk (prefix/name/suffix encoded once, subjects passed once) against the generic path (every prompt
     formatted, tokenized and searched as a string): same ids, lookup positions, counts — mass-edit shape, ragged template
