@@ -36,7 +36,7 @@ from .globals import STATS_DIR, XL_STATS_DIR1, XL_STATS_DIR2
 from .compute_ks import get_layers_input_output_at_words_cross_attn
 from .layer_stats import get_all_cross_attn_kv_layer_names, layer_stats_cross_attn_kv, layer_stats_text_encoder
 
-COV_CACHE: Dict[tuple, torch.Tensor] = {}          # key -> (d, d) fp32 on cpu, like the reference's (:36)
+COV_CACHE: Dict[tuple, object] = {}                # key -> (d, d) fp32 on cpu, like the reference's (:36), or a _HostMoment that makes it on demand
 _COV_DEVICE_CACHE: Dict[tuple, torch.Tensor] = {}  # (key, device) -> the same matrix resident in HBM
 _VSTAR_CACHE: Dict[tuple, np.ndarray] = {}         # (path, mtime_ns, size) -> v_star
 SDXL_TE2_DOUBLE_APPLY = True                       # reference quirk, see module docstring
@@ -64,6 +64,62 @@ def _cov_key(model, layer_name, stat_dir, mom2_n_samples, mom2_dtype):
     return (model_name, layer_name, _resolved(stat_dir), mom2_n_samples, mom2_dtype)
 
 
+class _HostMoment:
+    """COV_CACHE entry of a statistic that went from its file straight to the GPU (``_cov_from_file``): the host tensor the
+    reference keeps there (mom2 / count, fp32) is fetched back from the device copy if anyone ever asks for it."""
+
+    def __init__(self, on_device: torch.Tensor):
+        self.on_device, self._c = on_device, None
+
+    def tensor(self) -> torch.Tensor:
+        if self._c is None:
+            self._c = self.on_device.cpu()
+        return self._c
+
+
+def _host_cov(entry) -> torch.Tensor:
+    return entry.tensor() if isinstance(entry, _HostMoment) else entry
+
+
+def _cov_from_file(path, sample_size, device):
+    """(C on ``device``, COV_CACHE entry) of a float32 second-moment file in the reference's npz format, or None (no such file,
+    another layout or dtype, recorded sample_size differs: the general path then loads — or computes — it).  The file is read
+    into ONE page-locked buffer (no zipfile, no CRC pass: runningstats.read_npz_stored), its mom2 member uploaded from there
+    and divided by the count on the GPU — element-wise IEEE division by a device scalar, the same fp32 quotients as the
+    host's ``mom2 / count`` (tests/test_e2e_gpu.py) — instead of: read, divide into a fresh 37.7 MB host tensor, pageable
+    upload, each paying first-touch page faults (27 ms per layer in a cold process on the test box; 5 ms this way)."""
+    from . import runningstats as rs
+    if torch.device(device).type != "cuda" or not rs.global_load_cache_enabled or os.environ.get("EMCID_COV_FAST", "1") == "0":
+        return None
+    keep = {}
+
+    def alloc(nbytes):
+        keep["t"] = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        return keep["t"].numpy()
+
+    dat = rs.read_npz_stored(path, alloc=alloc)
+    if dat is None:
+        return None
+    try:
+        dat = rs.unbox_numpy_null(dat)
+        m, count = dat["mom2.mom2"], int(dat["mom2.count"])
+        if sample_size is not None and dat.get("sample_size") != sample_size:
+            return None
+    except (KeyError, TypeError, ValueError):
+        return None
+    if m.dtype != np.float32 or m.ndim != 2 or m.shape[0] != m.shape[1] or count <= 0:
+        return None
+    # m is a view of the page-locked image: its bytes are uploaded as a slice of that very tensor (so the caching host allocator
+    # knows the block is in use until the copy has run) and re-typed on the device, where the allocation is aligned
+    image = keep["t"]
+    off = m.__array_interface__["data"][0] - image.data_ptr()
+    if off < 0 or off + m.nbytes > image.numel() or not m.flags.c_contiguous:
+        return None
+    dev = image[off:off + m.nbytes].to(device, non_blocking=True).view(torch.float32).reshape(m.shape)
+    c = torch.div(dev, torch.full((), float(count), dtype=torch.float32, device=device))
+    return c, _HostMoment(c)
+
+
 def get_cov_text_encoder(model, tok, layer_name: str, mom2_dataset: str, mom2_n_samples: int, mom2_dtype: str,
                          inv: bool = False, force_recompute: bool = False, verbose: bool = True,
                          stat_dir=STATS_DIR) -> torch.Tensor:
@@ -73,15 +129,23 @@ def get_cov_text_encoder(model, tok, layer_name: str, mom2_dataset: str, mom2_n_
     device = next(model.parameters()).device
     if verbose:
         print(f"Retrieving covariance statistics for {key[0]} @ {layer_name}.")
-    if key not in COV_CACHE or force_recompute:
-        stat = layer_stats_text_encoder(model, tok, layer_name, stat_dir, mom2_dataset, to_collect=["mom2"],
-                                        sample_size=mom2_n_samples, precision=mom2_dtype,
-                                        force_recompute=force_recompute)
-        COV_CACHE[key] = stat.mom2.moment().float().to("cpu")
-        _COV_DEVICE_CACHE.pop((key, device), None)
     dkey = (key, device)
+    if key not in COV_CACHE or force_recompute:
+        fast = None
+        if not force_recompute and mom2_dtype == "float32":
+            from .layer_stats import stats_filename
+            fast = _cov_from_file(stats_filename(stat_dir, "text_encoder", mom2_dataset, layer_name, mom2_dtype, ["mom2"], 3 * 1024,
+                                                 mom2_n_samples), mom2_n_samples, device)
+        if fast is not None:
+            _COV_DEVICE_CACHE[dkey], COV_CACHE[key] = fast
+        else:
+            stat = layer_stats_text_encoder(model, tok, layer_name, stat_dir, mom2_dataset, to_collect=["mom2"],
+                                            sample_size=mom2_n_samples, precision=mom2_dtype,
+                                            force_recompute=force_recompute)
+            COV_CACHE[key] = stat.mom2.moment().float().to("cpu")
+            _COV_DEVICE_CACHE.pop(dkey, None)
     if dkey not in _COV_DEVICE_CACHE:
-        _COV_DEVICE_CACHE[dkey] = COV_CACHE[key].to(device)
+        _COV_DEVICE_CACHE[dkey] = _host_cov(COV_CACHE[key]).to(device)
     c = _COV_DEVICE_CACHE[dkey]
     return torch.inverse(c) if inv else c
 

@@ -255,16 +255,29 @@ def unbox_numpy_null(d):
     return None if is_null_numpy_value(d) else d
 
 
-def read_npz_stored(path) -> Optional[dict]:
+def read_npz_stored(path, alloc=None) -> Optional[dict]:
     """{member: array} of an npz whose members are all STORED (uncompressed — what ``numpy.savez`` writes, hence every statistics
     file of the reference, util/runningstats.py:1409-1454) with plain numeric / string dtypes, parsed straight from the bytes: the
     local file headers (zip64 sizes from their extra field), each member's npy header, a ``frombuffer`` view of its data.
     ``numpy.load`` goes through ``zipfile``, which computes a CRC-32 over every member it reads — 62 % of the 35 ms a 37.7 MB
     second-moment file costs to load.  Returns None for anything else (compressed or pickled members, data descriptors, other
-    layouts): the caller then uses ``numpy.load`` and gets numpy's behaviour, errors included."""
+    layouts): the caller then uses ``numpy.load`` and gets numpy's behaviour, errors included.  ``alloc(nbytes)``: where the
+    file's bytes go — a writable uint8 array of that size (e.g. the numpy view of a page-locked torch tensor, so that a member
+    can be uploaded without a staging copy); default: a fresh numpy array."""
     import ast
     try:
-        buf = numpy.fromfile(path, dtype=numpy.uint8)      # writable: the arrays below are views of it (torch wants writable ones)
+        if alloc is None:
+            buf = numpy.fromfile(path, dtype=numpy.uint8)  # writable: the arrays below are views of it (torch wants writable ones)
+        else:
+            with open(path, "rb", buffering=0) as f:
+                size = os.fstat(f.fileno()).st_size
+                buf = alloc(size)
+                got, view = 0, memoryview(buf)
+                while got < size:
+                    r = f.readinto(view[got:])
+                    if not r:
+                        return None
+                    got += r
     except (OSError, ValueError):
         return None
     blob = memoryview(buf)

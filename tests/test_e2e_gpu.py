@@ -808,6 +808,42 @@ def test_stage0_float16_precision(tmp_path, forward):
     assert np.abs(got - ref).max() > 0          # it IS a different statistic from the fp32 one
 
 
+def test_statistics_file_straight_to_gpu_equals_the_general_path(tmp_path, monkeypatch):
+    """get_cov_text_encoder's direct route (stored npz -> one page-locked image -> mom2 uploaded from it -> divided by the count
+    on the GPU) against the general one (numpy members -> SecondMoment -> host division -> upload): the same fp32 quotients bit
+    for bit at d = 3072 with a count that is no power of two; the host copy the reference's COV_CACHE would hold is served on
+    demand; a file of another dtype, or a recorded sample_size that differs, is left to the general path."""
+    d, n_samples = 3072, 1000
+    names = ["encoder.layers.7.mlp.fc2", "encoder.layers.8.mlp.fc2"]
+    syn.write_stats_cache(tmp_path / "stats", names, d, n_samples, seed=5, t=6143)
+    with np.load(syn.stats_file(tmp_path / "stats", names[0], n_samples)) as z:
+        want = torch.from_numpy(z["mom2.mom2"]) / int(z["mom2.count"])
+        assert int(z["mom2.count"]) == 6143
+    pipe = syn.build_pipe("sd-v1.4", DEV, syllables=True)
+    args = (pipe.text_encoder, pipe.tokenizer, names[0], "ccs_filtered", n_samples, "float32")
+    kw = dict(stat_dir=str(tmp_path / "stats"), verbose=False)
+    fast = em.get_cov_text_encoder(*args, **kw)
+    entry = next(iter(em.COV_CACHE.values()))
+    assert isinstance(entry, em._HostMoment) and fast.is_cuda and fast.dtype == torch.float32
+    assert torch.equal(fast.cpu(), want) and torch.equal(entry.tensor(), want)
+    em.clear_caches()
+    monkeypatch.setenv("EMCID_COV_FAST", "0")
+    slow = em.get_cov_text_encoder(*args, **kw)
+    assert not isinstance(next(iter(em.COV_CACHE.values())), em._HostMoment) and torch.equal(slow, fast)
+    monkeypatch.delenv("EMCID_COV_FAST")
+    em.clear_caches()
+    from emcid_amd.layer_stats import stats_filename
+    f = stats_filename(tmp_path / "stats", "text_encoder", "ccs_filtered", names[1], "float32", ["mom2"], 3 * 1024, n_samples)
+    assert em._cov_from_file(f, n_samples, DEV) is not None and em._cov_from_file(f, n_samples + 1, DEV) is None
+    assert em._cov_from_file(f, n_samples, "cpu") is None and em._cov_from_file(str(f) + ".absent", n_samples, DEV) is None
+    with np.load(f) as z:
+        members = {k: z[k] for k in z.files}
+    np.savez(f, **dict(members, **{"mom2.mom2": members["mom2.mom2"].astype(np.float64)}))
+    assert em._cov_from_file(f, n_samples, DEV) is None
+    np.savez_compressed(f, **members)
+    assert em._cov_from_file(f, n_samples, DEV) is None
+
+
 def _multi_token(tmp_path):
     from PIL import Image
     z, meta = load_golden("toy_multi_token")
