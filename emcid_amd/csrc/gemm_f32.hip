@@ -43,57 +43,48 @@ enum LinearAct : int { ACT_NONE = 0, ACT_QUICK_GELU = 1, ACT_GELU_ERF = 2 };
 
 template <int V> struct IC { static constexpr int value = V; };
 
+struct LinearArgs {
+    const float* X; int64_t ldx;
+    const float* W; int64_t ldw;
+    const float* bias;
+    const float* res; int64_t ldr;
+    float* Y; int64_t ldy;
+    int M, N, K, act, tiles_n, tiles, rb;
+};
+
+// Tile order: super-rows of `rb` row tiles, column-major inside a super-row — the ~64 tiles an XCD has in flight then share
+// `rb` row tiles of X (kept in its 4 MB L2) and walk the column tiles of W together, instead of re-streaming all of W for
+// every row tile (rb = 1: row-major; L2-miss traffic of the 128 x 128 launches 2.8x the algorithmic bytes).
+__device__ __forceinline__ void linear_tile_of(const LinearArgs& a, int tile, int& bm, int& bn) {
+    const int tiles_m = a.tiles / a.tiles_n, sr = tile / (a.rb * a.tiles_n), rem = tile - sr * a.rb * a.tiles_n;
+    const int rows = min(a.rb, tiles_m - sr * a.rb);
+    bn = rem / rows;
+    bm = sr * a.rb + (rem - bn * rows);
+}
+
+template <int MI, int NJ, int WM, int WN, int PF, int DBG, int KS>
+struct LinearGeom {
+    static constexpr int NT = 256 * KS;                      // threads
+    static constexpr int SBK = LBK * KS;                     // K depth of a stage
+    static constexpr int LLD = SBK + 4;                      // LDS row stride in floats: 20 / 36, conflict-free for the b128 lane groups
+    static constexpr int CPR = SBK / 4;                      // float4 per row and stage
+    static constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
+    static constexpr int VA = (BM * CPR + NT - 1) / NT, VB = (BN * CPR + NT - 1) / NT;      // float4 per thread and stage
+    static constexpr int STAGE = (BM + BN) * LLD;
+    static constexpr int RED = KS == 2 ? 4 * MI * NJ * 16 * 64 : 0;                         // floats the final hand-over needs
+    static constexpr int SMEM = 2 * STAGE > RED ? 2 * STAGE : RED;
+    static constexpr int NBLK = MI * NJ, HB = KS == 2 ? (NBLK + 1) / 2 : NBLK;
+};
+
+// The K loop of one tile over the stages [it_lo, it_hi) of its K range: acc += X[m0.., k] W[n0.., k]^T.
 // PF: how many stages ahead the global loads run (= register sets of staged data).  DBG (timing experiments only, results
 // wrong): 1 = no global loads inside the loop, 2 = also no LDS stores.
-// Measured and dropped (profiles/r03_mb_linear_variants.txt): the 128 x 128 four-wave kernel compiled for THREE workgroups per
-// compute unit (amdgpu_waves_per_eu(3, 8): 148 registers, no spills) runs 4-10 % slower than at two (qkv 105.9 vs 117.4 TF);
-// a persistent form that walks a workgroup's tiles as one software pipeline (next tile's first stages loaded during the current
-// tile's last ones, stage 0 in LDS before the epilogue) 6-8 % slower (110.6 / 112.5 vs 117.4 / 121.1 TF) — the hardware's own
-// dispatch of one-tile workgroups balances the compute units better than a static walk gains from the hidden prologue.
-// A v_mfma_f32_16x16x4_f32 form of the same pipeline (tile edges in steps of 16: 96 x 160, 128 x 160, 192 x 160 — the shapes
-// hipBLASLt's tuned solutions take for these projections: 510 / 250 tiles for qkv / out at 6 400 rows) compiled to 254-436
-// registers per lane (one wave per SIMD for the two larger tiles) and reached 95-109 TF on qkv, 61-87 on out
-// (profiles/r03_mb_linear_mfma16.txt): removed.
-// Staging by LDS-DMA (global_load_lds_dwordx4 into an unpadded image with 16-byte pieces XOR-swizzled by (row >> 2) & 3 — conflict
-// free for the b128 fragment reads —, three stage buffers, DMAs two stages ahead behind counted s_waitcnt vmcnt and a bare
-// s_barrier, no staging registers, no ds_write): correct, 111 / 119 TF on qkv / fc1 against 118 / 121 for the register-staged
-// form, 124-130 against 131-134 on the SDXL shapes (profiles/r03_mb_linear_dma.txt): the LDS store path is not what holds the
-// loop back; removed.
 template <int MI, int NJ, int WM, int WN, int PF, int DBG, int KS>
-__global__ __launch_bounds__(256 * KS) void linear_f32_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
-                                                               int64_t ldw, const float* __restrict__ bias,
-                                                               const float* __restrict__ res, int64_t ldr, float* __restrict__ Y,
-                                                               int64_t ldy, int M, int N, int K, int act, int tiles_n, int tiles, int rb) {
-    static_assert(WM * WN == 4 && (KS == 1 || KS == 2), "four waves per K group");
-    constexpr int NT = 256 * KS;                     // threads
-    constexpr int SBK = LBK * KS;                    // K depth of a stage
-    constexpr int LLD = SBK + 4;                     // LDS row stride in floats: 20 / 36, conflict-free for the b128 lane groups
-    constexpr int CPR = SBK / 4;                     // float4 per row and stage
-    constexpr int BM = 32 * MI * WM, BN = 32 * NJ * WN;
-    constexpr int VA = (BM * CPR + NT - 1) / NT, VB = (BN * CPR + NT - 1) / NT;      // float4 per thread and stage
-    constexpr int STAGE = (BM + BN) * LLD;
-    constexpr int RED = KS == 2 ? 4 * MI * NJ * 16 * 64 : 0;                         // floats the final hand-over needs
-    constexpr int SMEM = 2 * STAGE > RED ? 2 * STAGE : RED;
-    __shared__ __attribute__((aligned(16))) float smem[SMEM];
-
-    // Workgroups go to the 8 XCDs round-robin by linear id.  XCD x takes the tiles [x * per, (x + 1) * per): a contiguous
-    // run of row tiles with all their column tiles, so the rows of X an XCD streams are its own and every column tile of W
-    // is re-read from that XCD's L2.
-    const int per = (tiles + 7) / 8;
-    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (tile >= tiles || (int)(blockIdx.x >> 3) >= per) return;
-    // Tile order: super-rows of `rb` row tiles, column-major inside a super-row — the ~64 tiles an XCD has in flight then share
-    // `rb` row tiles of X (kept in its 4 MB L2) and walk the column tiles of W together, instead of re-streaming all of W for
-    // every row tile (rb = 1: row-major; L2-miss traffic of the 128 x 128 launches 2.8x the algorithmic bytes).
-    int bm, bn;
-    {
-        const int tiles_m = tiles / tiles_n, sr = tile / (rb * tiles_n), rem = tile - sr * rb * tiles_n;
-        const int rows = min(rb, tiles_m - sr * rb);
-        bn = rem / rows;
-        bm = sr * rb + (rem - bn * rows);
-    }
-    const int m0 = bm * BM, n0 = bn * BN;
-
+__device__ __forceinline__ void linear_accumulate(const LinearArgs& a, int m0, int n0, int it_lo, int it_hi, float* smem,
+                                                  v16f (&acc)[MI][NJ]) {
+    using G = LinearGeom<MI, NJ, WM, WN, PF, DBG, KS>;
+    constexpr int NT = G::NT, SBK = G::SBK, LLD = G::LLD, CPR = G::CPR, BM = G::BM, BN = G::BN, VA = G::VA, VB = G::VB,
+                  STAGE = G::STAGE;
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8;      // grp: which 16 of a stage's K
     const int l31 = lane & 31, l5 = lane >> 5;
     const int wm0 = (wave / WN) * (32 * MI), wn0 = (wave % WN) * (32 * NJ);
@@ -109,16 +100,17 @@ __global__ __launch_bounds__(256 * KS) void linear_f32_kernel(const float* __res
     const float* pa[VA];
     const float* pb[VB];
     int wa[VA], wb[VB];
+    const int64_t kbase = (int64_t)it_lo * SBK;
 #pragma unroll
     for (int s = 0; s < VA; ++s) {
         const int v = tid + NT * s, row = min(row_of(v), BM - 1);
-        pa[s] = X + (int64_t)min(m0 + row, M - 1) * ldx + 4 * (v % CPR);        // rows past M: a valid row, never stored
+        pa[s] = a.X + (int64_t)min(m0 + row, a.M - 1) * a.ldx + 4 * (v % CPR) + kbase;        // rows past M: a valid row, never stored
         wa[s] = row * LLD + 4 * (v % CPR);
     }
 #pragma unroll
     for (int s = 0; s < VB; ++s) {
         const int v = tid + NT * s, row = min(row_of(v), BN - 1);
-        pb[s] = W + (int64_t)min(n0 + row, N - 1) * ldw + 4 * (v % CPR);
+        pb[s] = a.W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + 4 * (v % CPR) + kbase;
         wb[s] = BM * LLD + row * LLD + 4 * (v % CPR);
     }
     constexpr bool TAIL_A = (BM * CPR) % NT != 0, TAIL_B = (BN * CPR) % NT != 0;
@@ -145,14 +137,6 @@ __global__ __launch_bounds__(256 * KS) void linear_f32_kernel(const float* __res
             if (s + 1 < VB || last_b) *reinterpret_cast<v4f*>(stage + wb[s]) = gb[R][s];
     };
 
-    v16f acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const int fa_off = (wm0 + l31) * LLD + 4 * l5 + LBK * grp;     // + 32 i rows, + 8 q floats
     const int fb_off = BM * LLD + (wn0 + l31) * LLD + 4 * l5 + LBK * grp;
     v4f fa[2][MI], fb[2][NJ];
@@ -176,7 +160,7 @@ __global__ __launch_bounds__(256 * KS) void linear_f32_kernel(const float* __res
     // The fragment reads of the NEXT block are issued right after the first k-step's MFMAs of the current one: the wait in front
     // of those first MFMAs then covers only reads issued a whole block ago (hipcc emits lgkmcnt(0) there, not a counted wait).
     // Stage s is loaded into register set s % PF; iteration `it` stores stage it+1 and refills that set with stage it+1+PF.
-    const int T = K / SBK;
+    const int T = it_hi - it_lo;
     gload(0, IC<0>{});
     lstore(smem, IC<0>{});
     if (T > 1) gload(SBK, IC<1 % PF>{});
@@ -209,11 +193,19 @@ __global__ __launch_bounds__(256 * KS) void linear_f32_kernel(const float* __res
         if constexpr (PF > 1) if (it0 + 1 < T) body(IC<2 % PF>{}, it0 + 1);
         if constexpr (PF > 2) if (it0 + 2 < T) body(IC<3 % PF>{}, it0 + 2);
     }
+}
 
+// The end of a tile: (KS = 2: the two wave groups' halves of every sum are brought together,) bias, activation, residual, store.
+template <int MI, int NJ, int WM, int WN, int PF, int DBG, int KS>
+__device__ __forceinline__ void linear_finish(const LinearArgs& a, int m0, int n0, float* smem, v16f (&acc)[MI][NJ]) {
+    using G = LinearGeom<MI, NJ, WM, WN, PF, DBG, KS>;
+    constexpr int BM = G::BM, BN = G::BN, NBLK = G::NBLK, HB = G::HB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8;
+    const int l31 = lane & 31, l5 = lane >> 5;
+    const int wm0 = (wave / WN) * (32 * MI), wn0 = (wave % WN) * (32 * NJ);
     // KS == 2: the two wave groups hold the two halves of every sum.  They swap HALF of their accumulator blocks through LDS
     // (lane-linear 16-byte pieces: [wave][block][4][lane]) — group 0 ends up owning blocks [0, HB), group 1 blocks [HB, MI NJ),
     // each complete — so that all eight waves share the epilogue.  Fixed order of the two addends: bit-reproducible.
-    constexpr int NBLK = MI * NJ, HB = KS == 2 ? (NBLK + 1) / 2 : NBLK;
     if constexpr (KS == 2) {
         __syncthreads();                                       // everybody is done with the stage buffers
         v4f* red = reinterpret_cast<v4f*>(smem) + wave * (NBLK * 4 * 64) + lane;
@@ -251,6 +243,11 @@ __global__ __launch_bounds__(256 * KS) void linear_f32_kernel(const float* __res
     // epilogue: C[row][col], row = (r & 3) + 8 (r >> 2) + 4 l5 inside a 32 x 32 block, col = l31: a wave instruction writes two
     // runs of 32 consecutive floats.  The activation is chosen once, outside the unrolled element loops; a tile that lies inside
     // the matrix takes a path without per-element predicates (the residual loads of a block are then issued together).
+    const float* __restrict__ bias = a.bias;
+    const float* __restrict__ res = a.res;
+    float* __restrict__ Y = a.Y;
+    const int64_t ldr = a.ldr, ldy = a.ldy;
+    const int M = a.M, N = a.N;
     const bool interior = m0 + BM <= M && n0 + BN <= N;
     auto epilogue = [&](auto actfn) {
 #pragma unroll
@@ -289,11 +286,60 @@ __global__ __launch_bounds__(256 * KS) void linear_f32_kernel(const float* __res
             }
         }
     };
-    if (act == ACT_QUICK_GELU) epilogue([](float x) { return x / (1.0f + __expf(-1.702f * x)); });       // x * sigmoid(1.702 x)
-    else if (act == ACT_GELU_ERF) epilogue([](float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); });
+    if (a.act == ACT_QUICK_GELU) epilogue([](float x) { return x / (1.0f + __expf(-1.702f * x)); });       // x * sigmoid(1.702 x)
+    else if (a.act == ACT_GELU_ERF) epilogue([](float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); });
     else epilogue([](float x) { return x; });
 }
 
+// Measured and dropped (profiles/r03_mb_linear_variants.txt): the 128 x 128 four-wave kernel compiled for THREE workgroups per
+// compute unit (amdgpu_waves_per_eu(3, 8): 148 registers, no spills) runs 4-10 % slower than at two (qkv 105.9 vs 117.4 TF);
+// a persistent form that walks a workgroup's tiles as one software pipeline (next tile's first stages loaded during the current
+// tile's last ones, stage 0 in LDS before the epilogue) 6-8 % slower (110.6 / 112.5 vs 117.4 / 121.1 TF) — the hardware's own
+// dispatch of one-tile workgroups balances the compute units better than a static walk gains from the hidden prologue.
+// A v_mfma_f32_16x16x4_f32 form of the same pipeline (tile edges in steps of 16: 96 x 160, 128 x 160, 192 x 160 — the shapes
+// hipBLASLt's tuned solutions take for these projections: 510 / 250 tiles for qkv / out at 6 400 rows) compiled to 254-436
+// registers per lane (one wave per SIMD for the two larger tiles) and reached 95-109 TF on qkv, 61-87 on out
+// (profiles/r03_mb_linear_mfma16.txt): removed.
+// Staging by LDS-DMA (global_load_lds_dwordx4 into an unpadded image with 16-byte pieces XOR-swizzled by (row >> 2) & 3 — conflict
+// free for the b128 fragment reads —, three stage buffers, DMAs two stages ahead behind counted s_waitcnt vmcnt and a bare
+// s_barrier, no staging registers, no ds_write): correct, 111 / 119 TF on qkv / fc1 against 118 / 121 for the register-staged
+// form, 124-130 against 131-134 on the SDXL shapes (profiles/r03_mb_linear_dma.txt): the LDS store path is not what holds the
+// loop back; removed.
+template <int MI, int NJ, int WM, int WN, int PF, int DBG, int KS>
+__global__ __launch_bounds__(256 * KS) void linear_f32_kernel(LinearArgs a) {
+    static_assert(WM * WN == 4 && (KS == 1 || KS == 2), "four waves per K group");
+    using G = LinearGeom<MI, NJ, WM, WN, PF, DBG, KS>;
+    __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
+    // Workgroups go to the 8 XCDs round-robin by linear id.  XCD x takes the tiles [x * per, (x + 1) * per): a contiguous
+    // run of row tiles with all their column tiles, so the rows of X an XCD streams are its own and every column tile of W
+    // is re-read from that XCD's L2.
+    const int per = (a.tiles + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile >= a.tiles || (int)(blockIdx.x >> 3) >= per) return;
+    int bm, bn;
+    linear_tile_of(a, tile, bm, bn);
+    v16f acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    linear_accumulate<MI, NJ, WM, WN, PF, DBG, KS>(a, bm * G::BM, bn * G::BN, 0, a.K / G::SBK, smem, acc);
+    linear_finish<MI, NJ, WM, WN, PF, DBG, KS>(a, bm * G::BM, bn * G::BN, smem, acc);
+}
+
+// Measured and dropped — a "stream-K tail" for the partial last round of tiles.  A launch of t 128 x 128 tiles on the chip's 512
+// workgroup slots takes ceil(t / 512) rounds whatever the fraction of the last one: 6 400 x 768 -> 2 304 (900 tiles, 1.76 rounds)
+// costs what 1 008 tiles cost, 114 TF against 129; fc1 (1 200 tiles) 124 against 133 at three full rounds
+// (scripts/mb_linear_rounds.py, profiles/r03_mb_linear_rounds.txt).  The form built for it: the first floor(t / 512) * 512 tiles
+// as they are, the rest cut by K into 512 equal runs of stages whatever tile borders they cross, partial tiles published to a
+// workspace (write-through stores, ticket per tile, the last arriver sums all parts in run order: bit-reproducible, nobody waits)
+// — correct on every test shape, and worth 2 % on qkv (121.2 vs 118.7 TF), nothing on fc1 (123.1 vs 124.4), less than the
+// 160 x 128 eight-wave tiles on out / fc2 (95.6 vs 111.9, 122.1 vs 122.9 TF; profiles/r03_mb_linear_tail.txt): an fp32 128 x 128
+// tile is 48 us of one compute unit's matrix pipe, a partial tile 64 KB out to memory and 64 KB back in — with two to three
+// parts per tile the exchange costs what the balanced last round gains.  Two independent half-size chains on two streams
+// (scripts/mb_two_streams.py) fill each other's tails and end up at the one-stream rate (120 TF), not above it.
 struct LinearCfg { int bm, bn; };
 static const LinearCfg kLinearCfgs[] = {{160, 128}, {128, 128}, {256, 128}, {64, 64}};
 
@@ -345,10 +391,11 @@ int emcid_linear_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, c
     hipStream_t st = (hipStream_t)stream;
     static const int rb_env = [] { const char* e = getenv("EMCID_LINEAR_RB"); return e ? atoi(e) : 4; }();
     const int rb = rb_env >= 1 ? rb_env : 1;
+    const LinearArgs a{X, ldx, W, ldw, bias, residual, ldr, Y, ldy, (int)M, (int)N, (int)K, act, tiles_n, tiles, rb};
     ScopedProf sp(KC_LINEAR, st);
 #define EMCID_LINEAR_LAUNCH(MI_, NJ_, WM_, WN_, PF_, DBG_, KS_)                                                              \
     hipLaunchKernelGGL((linear_f32_kernel<MI_, NJ_, WM_, WN_, PF_, DBG_, KS_>), dim3((unsigned)(per * 8)), dim3(256 * KS_), 0, \
-                       st, X, ldx, W, ldw, bias, residual, ldr, Y, ldy, (int)M, (int)N, (int)K, act, tiles_n, tiles, rb)
+                       st, a)
 #define EMCID_LINEAR_PF(MI_, NJ_, WM_, WN_)                                              \
     do {                                                                                  \
         if (ks == 2) {                                                                    \
