@@ -340,6 +340,9 @@ __global__ __launch_bounds__(256 * KS) void linear_f32_kernel(LinearArgs a) {
 // tile is 48 us of one compute unit's matrix pipe, a partial tile 64 KB out to memory and 64 KB back in — with two to three
 // parts per tile the exchange costs what the balanced last round gains.  Two independent half-size chains on two streams
 // (scripts/mb_two_streams.py) fill each other's tails and end up at the one-stream rate (120 TF), not above it.
+// Sixteen waves per workgroup (four K groups) for the few 64 x 64 tiles of the mean keys through fc2 (1 000 x 3072 -> 768, 192
+// tiles: at most one workgroup per compute unit): 64.5 us against 66.1 with eight (profiles/r03_mb_linear_16w.txt) — that launch
+// is not short of waves; removed.
 struct LinearCfg { int bm, bn; };
 static const LinearCfg kLinearCfgs[] = {{160, 128}, {128, 128}, {256, 128}, {64, 64}};
 

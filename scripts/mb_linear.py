@@ -12,7 +12,8 @@ from emcid_amd import hip
 dev = "cuda"
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 6400
 shapes = [(rows, 768, 2304, "qkv"), (rows, 768, 768, "out"), (rows, 768, 3072, "fc1"), (rows, 3072, 768, "fc2"),
-          (3072, 768, 768, "out@query"), (3072, 768, 3072, "fc1@query"), (1000, 3072, 768, "fc2(K)"),
+          (3072, 768, 768, "out@query"), (3072, 768, 3072, "fc1@query"), (1000, 3072, 768, "fc2(K)"), (640, 768, 2304, "qkv@n100"),
+          (640, 3072, 768, "fc2@n100"), (1000, 5120, 1280, "fc2(K)-bigG"),
           (rows, 1280, 3840, "qkv-bigG"), (rows, 1280, 5120, "fc1-bigG"), (rows, 5120, 1280, "fc2-bigG")]
 tune = os.environ.get("MB_TUNE", "1") == "1"
 
