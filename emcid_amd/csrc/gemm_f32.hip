@@ -343,6 +343,11 @@ __global__ __launch_bounds__(256 * KS) void linear_f32_kernel(LinearArgs a) {
 // Sixteen waves per workgroup (four K groups) for the few 64 x 64 tiles of the mean keys through fc2 (1 000 x 3072 -> 768, 192
 // tiles: at most one workgroup per compute unit): 64.5 us against 66.1 with eight (profiles/r03_mb_linear_16w.txt) — that launch
 // is not short of waves; removed.
+// Split-K for launches of few tiles (every 128 x 128 tile's K range over 2..8 workgroups, partial tiles through a workspace with
+// the same ticket scheme, summed in part order): 640 x 3072 -> 768 61.7 -> 43.2 us (8 parts), 1 000 x 5120 -> 1280 173.8 -> 123.0,
+// 1 000 x 3072 -> 768 65.2 -> 61.6, K = 768 launches slower (profiles/r03_mb_linear_splitk.txt; hipBLASLt: 30 / 107 / 41 us) —
+// a part's publish and the last arriver's re-read + epilogue cost ~15 us per launch.  No bench record moved (the 100-concept edit
+// is host-bound at 4.5 ms, the mean-keys GEMM is 4 x 65 us of a 14 ms call): removed with its workspace entry point.
 struct LinearCfg { int bm, bn; };
 static const LinearCfg kLinearCfgs[] = {{160, 128}, {128, 128}, {256, 128}, {64, 64}};
 
