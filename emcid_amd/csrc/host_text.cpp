@@ -89,7 +89,7 @@ struct emcid_bpe {
 
 extern "C" {
 
-int emcid_host_abi_version(void) { return 4; }
+int emcid_host_abi_version(void) { return 5; }
 
 const char* emcid_host_last_error(void) { return g_error.c_str(); }
 
@@ -232,7 +232,8 @@ int64_t emcid_bpe_encode_batch(emcid_bpe* m, const char* text, const int64_t* of
 int64_t emcid_bpe_encode_templated(emcid_bpe* m, const char* pre, const int64_t* pre_off, const char* suf, const int64_t* suf_off,
                                    int64_t n_templates, const char* names, const int64_t* name_off, int64_t n_names,
                                    const int32_t* tmpl_idx, const int32_t* name_idx, int64_t n, int32_t bos, int32_t eos,
-                                   int32_t pad, int32_t max_len, int64_t* ids, int32_t* lengths, uint8_t* fallback) {
+                                   int32_t pad, int32_t max_len, int64_t* ids, int32_t* lengths, uint8_t* fallback,
+                                   int32_t* name_last) {
     if (!m || !pre || !pre_off || !suf || !suf_off || n_templates <= 0 || !names || !name_off || n_names <= 0 || !tmpl_idx ||
         !name_idx || n < 0 || max_len < 2 || !ids || !lengths || !fallback) {
         g_error = "emcid_bpe_encode_templated: bad argument";
@@ -283,6 +284,7 @@ int64_t emcid_bpe_encode_templated(emcid_bpe* m, const char* pre, const int64_t*
         for (int32_t j = 0; j < max_len; ++j) out[j] = pad;
         lengths[i] = 0;
         fallback[i] = 0;
+        if (name_last) name_last[i] = -1;
         const int64_t t = tmpl_idx[i], k = name_idx[i];
         if (t < 0 || t >= n_templates || k < 0 || k >= n_names || pre_off[t + 1] < pre_off[t] || suf_off[t + 1] < suf_off[t] ||
             name_off[k + 1] < name_off[k]) {
@@ -296,7 +298,10 @@ int64_t emcid_bpe_encode_templated(emcid_bpe* m, const char* pre, const int64_t*
             if (ok) {
                 row = P[(size_t)t].ids;
                 row.insert(row.end(), Nm[(size_t)k].ids.begin(), Nm[(size_t)k].ids.end());
+                // position (BOS included) of the name's last token, when the row is not cut by the length budget
+                const size_t upto = row.size();
                 row.insert(row.end(), Sx[(size_t)t].ids.begin(), Sx[(size_t)t].ids.end());
+                if (name_last && !Nm[(size_t)k].ids.empty() && row.size() <= (size_t)budget) name_last[i] = (int32_t)upto;
             }
         } else {                                   // pre-tokens may span a boundary: encode the formatted text as a whole
             whole.assign(pre + pre_off[t], (size_t)(pre_off[t + 1] - pre_off[t]));

@@ -270,7 +270,7 @@ def _use_dual(plan, d: int) -> bool:
 def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], layers, rewrite_module_tmp, lam,
                          edit_weight, zs_t: torch.Tensor, covs: Dict[int, torch.Tensor],
                          shard: Optional[ConceptShard] = None, layer_module_tmp: Optional[str] = None,
-                         forward_mode: Optional[str] = None, num_edit_tokens: int = 1) -> EncoderEditPlan:
+                         forward_mode: Optional[str] = None, num_edit_tokens: int = 1, _defer_checks: bool = True) -> EncoderEditPlan:
     from . import manage_threads
     manage_threads()                    # acts once per process, and only under EMCID_MANAGE_THREADS=1
     shard = shard or ConceptShard()
@@ -315,7 +315,7 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
         chunks: List[TrieChunk] = []
         tune_mode = os.environ.get("EMCID_TUNE_GEMM", "auto")
         try:
-            it = iter_prompt_chunks(tokenizer, local, n_chunks, defer_probe=True)
+            it = iter_prompt_chunks(tokenizer, local, n_chunks, defer_probe=_defer_checks)
             while True:
                 with phase("tokenize+lookup"):
                     pc = next(it, None)
@@ -330,14 +330,17 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
                     hs, x_ln1 = clip_forward.run_prefix(graph, trie, first_edit)
                 chunks.append(TrieChunk(trie, seg, pc.n_requests, len(pc.lookup), (first_edit, hs, x_ln1)))
                 if pc.verify is not None:
-                    # the native tokenizer's per-call cross-check against the public tokenizer call, run now that the GPU has
-                    # this slice's leading layers to work on.  It has never said no; if it does, the twin is disabled for good and
-                    # the preparation starts over on the generic path (what was launched above is simply abandoned).
+                    # the checks of the templated tokenization that need not hold the first launch back — the native tokenizer's
+                    # cross-check against the public tokenizer call, the reference's subject walk against the lookup positions
+                    # known from the construction of the rows — run now that the GPU has this slice's leading layers to work on.
+                    # If one says no (a name that also occurs earlier in its prompt; a tokenizer disagreement retires the native
+                    # twin for good), the preparation starts over with every check up front; what was launched is abandoned.
                     with phase("tokenize+lookup"):
                         agreed = pc.verify()
                     if not agreed:
                         return prepare_encoder_edit(text_encoder, tokenizer, requests, layers, rewrite_module_tmp, lam, edit_weight,
-                                                    zs_t, covs, shard, layer_module_tmp, forward_mode, num_edit_tokens)
+                                                    zs_t, covs, shard, layer_module_tmp, forward_mode, num_edit_tokens,
+                                                    _defer_checks=False)
             plan.graph, plan.chunks = graph, chunks
         except (clip_forward.UnsupportedEncoder, IndexError):
             plan.graph = plan.chunks = None

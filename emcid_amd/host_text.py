@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _LIB = None
 _LOCK = threading.Lock()
 
@@ -49,7 +49,7 @@ def load():
         lib.emcid_find_token_ranges.restype = I64
         lib.emcid_find_token_ranges.argtypes = [P, I64, I64, P, P, P, I64, P, P, ctypes.c_char_p, P, P, P]
         lib.emcid_bpe_encode_templated.restype = I64
-        lib.emcid_bpe_encode_templated.argtypes = [P, P, P, P, P, I64, P, P, I64, P, P, I64, I32, I32, I32, I32, P, P, P]
+        lib.emcid_bpe_encode_templated.argtypes = [P, P, P, P, P, I64, P, P, I64, P, P, I64, I32, I32, I32, I32, P, P, P, P]
         lib.emcid_find_token_ranges_idx.restype = I64
         lib.emcid_find_token_ranges_idx.argtypes = [P, I64, I64, P, P, P, I64, P, P, P, I64, ctypes.c_int, ctypes.c_char_p, P, P, P]
         lib.emcid_trie_build.restype = P
@@ -182,9 +182,10 @@ class NativeClipBpe:
         return ids, lengths, fb.astype(bool)
 
     def encode_templated(self, pre: Sequence[str], suf: Sequence[str], names: Sequence[str], tmpl_idx: np.ndarray,
-                         name_idx: np.ndarray):
+                         name_idx: np.ndarray, want_name_last: bool = False):
         """``encode`` of the prompts ``pre[t] + names[k] + suf[t]`` for (t, k) = (tmpl_idx[i], name_idx[i]) without building
-        the strings: (ids (B, max_len), lengths, fallback) exactly as ``encode`` gives for them."""
+        the strings: (ids (B, max_len), lengths, fallback) exactly as ``encode`` gives for them.  ``want_name_last``: a fourth
+        array, the position of the name's last token in each row (-1 where the row is not a plain concatenation)."""
         n = len(tmpl_idx)
         pb, po = pack_strings(pre)
         sb, so = pack_strings(suf)
@@ -194,11 +195,14 @@ class NativeClipBpe:
         ids = np.empty((n, self.max_len), dtype=np.int64)
         lengths = np.empty(n, dtype=np.int32)
         fb = np.empty(n, dtype=np.uint8)
+        name_last = np.empty(n, dtype=np.int32) if want_name_last else None
         rc = self._lib.emcid_bpe_encode_templated(self._h, pb, _ptr(po), sb, _ptr(so), len(pre), nb, _ptr(no), len(no) - 1,
                                                   _ptr(tmpl_idx), _ptr(name_idx), n, self.bos, self.eos, self.pad, self.max_len,
-                                                  _ptr(ids), _ptr(lengths), _ptr(fb))
+                                                  _ptr(ids), _ptr(lengths), _ptr(fb), _ptr(name_last) if want_name_last else None)
         if rc < 0:
             raise RuntimeError((self._lib.emcid_host_last_error() or b"").decode())
+        if want_name_last:
+            return ids, lengths, fb.astype(bool), name_last
         return ids, lengths, fb.astype(bool)
 
     def tokenize(self, tokenizer, prompts: Sequence[str]) -> Dict[str, np.ndarray]:

@@ -54,11 +54,15 @@ int64_t emcid_find_token_ranges(const int64_t* ids, int64_t n, int64_t S, const 
  * templates x many names; reference compute_z.py:2278-2283 formats every prompt, :65 tokenizes every string): prompt i is
  * pre[tmpl_idx[i]] + names[name_idx[i]] + suf[tmpl_idx[i]].  Every distinct piece is encoded once and rows are concatenations
  * whenever white space (or an empty piece) separates the pieces — pre-tokens never span white space — else the formatted text is
- * encoded as a whole; same ids, lengths and fallback flags as emcid_bpe_encode_batch on the formatted strings. */
+ * encoded as a whole; same ids, lengths and fallback flags as emcid_bpe_encode_batch on the formatted strings.  name_last (may be
+ * NULL): per row the position of the LAST token of the name inside the row (BOS counted) where the row is such a concatenation
+ * and not cut by max_len, else -1 — where find_token_range's walk (causal_trace.py:1046-1103) will put the lookup token unless the
+ * name also occurs earlier in the prompt; the caller still runs the walk, but may do so after it has started the GPU. */
 int64_t emcid_bpe_encode_templated(emcid_bpe* m, const char* pre, const int64_t* pre_off, const char* suf, const int64_t* suf_off,
                                    int64_t n_templates, const char* names, const int64_t* name_off, int64_t n_names,
                                    const int32_t* tmpl_idx, const int32_t* name_idx, int64_t n, int32_t bos, int32_t eos,
-                                   int32_t pad, int32_t max_len, int64_t* ids, int32_t* lengths, uint8_t* fallback);
+                                   int32_t pad, int32_t max_len, int64_t* ids, int32_t* lengths, uint8_t* fallback,
+                                   int32_t* name_last);
 
 /* emcid_find_token_ranges with the subjects given once: row i searches subject subj_idx[i] of n_subj (subj_idx NULL: row i
  * searches subject i).  normalize != 0: the subjects are the caller's raw strings and are lower-cased and stripped of ' '

@@ -124,6 +124,42 @@ def test_real_dims_apply_vs_oracle(tmp_path, n_req, ragged):
         assert err < 1e-4 and err <= 1e-4 * dw_ref.abs().max().item(), (ln, err, dw_ref.abs().max().item())
 
 
+def test_prepare_starts_over_when_a_name_occurs_earlier_in_its_prompt(tmp_path, monkeypatch):
+    """The templated tokenization hands the engine lookup positions known from the construction of the rows and checks them
+    against the reference's subject walk only after the leading layers are launched.  A template that repeats a name makes the walk
+    stop earlier than the construction says: the deferred check says no, the preparation starts over with the walk up front, and
+    the edit equals the oracle's (which walks every prompt like the reference)."""
+    from emcid_amd import edit_engine
+    names = syn.syllable_names(12)
+    reqs = [{"source": nm, "dest": "a realist artist", "prompts": [f"art by {names[0]} and {{}}", "style of {}", "painting by {}"],
+             "seed_train": 1} for nm in names]
+    hp_d = syn.sd_hparams_dict(layers=(1, 2, 3), mom2_update_weight=60, edit_weight=0.5, mom2_n_samples=1000)
+    layer_names = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers"]]
+    cache = str(tmp_path / "cache") + "/"
+    syn.write_vstar_cache(cache, reqs, 32, seed=1, scale=0.5)
+    syn.write_stats_cache(tmp_path / "stats", layer_names, 128, 1000, seed=2, t=512)
+    cpu_pipe = syn.build_pipe("toy", "cpu", syllables=True)
+    w0 = {ln: orc.get_parameter(cpu_pipe.text_encoder, ln + ".weight").clone() for ln in layer_names}
+    orc.apply_emcid_to_text_encoder(cpu_pipe, reqs, copy.deepcopy(hp_d), cache_name=cache, stats_dir=str(tmp_path / "stats"))
+    starts = []
+    real = edit_engine.prepare_encoder_edit
+
+    def counting(*a, **k):
+        starts.append(k.get("_defer_checks", True))
+        return real(*a, **k)
+
+    monkeypatch.setattr(edit_engine, "prepare_encoder_edit", counting)
+    monkeypatch.setattr(em, "prepare_encoder_edit", counting)
+    gpu_pipe = syn.build_pipe("toy", DEV, syllables=True)
+    em.apply_emcid_to_text_encoder(gpu_pipe, reqs, EMCIDHyperParams(**hp_d), DEV, cache_name=cache, stats_dir=str(tmp_path / "stats"),
+                                   verbose=False)
+    assert starts == [True, False]
+    for ln in layer_names:
+        dw_ref = (orc.get_parameter(cpu_pipe.text_encoder, ln + ".weight").double() - w0[ln].double())
+        dw = get_parameter(gpu_pipe.text_encoder, ln + ".weight").cpu().double() - w0[ln].double()
+        assert (dw - dw_ref).abs().max().item() <= 1e-4 * dw_ref.abs().max().item()
+
+
 def test_get_module_input_output_at_words_vs_oracle():
     pipe = syn.build_pipe("toy", "cpu")
     reqs = syn.make_requests(7, ragged=True)

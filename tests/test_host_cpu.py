@@ -681,8 +681,22 @@ def test_templated_path_deferred_probe(monkeypatch):
     reqs = syn.make_requests(40, names="syllable", name_seed=77)
     now = cz.templated_prompt_chunk(tok, reqs, reqs[0])
     assert now is not None and now.verify is None
-    later = cz.templated_prompt_chunk(tok, syn.make_requests(40, names="syllable", name_seed=78), reqs[0], defer_probe=True)
+    reqs78 = syn.make_requests(40, names="syllable", name_seed=78)
+    later = cz.templated_prompt_chunk(tok, reqs78, reqs[0], defer_probe=True)
     assert later is not None and callable(later.verify) and later.verify() is True and later.verify() is True
+    _chunks_equal(later, cz.templated_prompt_chunk(tok, reqs78, reqs[0]))      # lookup positions from the construction == the walk's
+    # a name that also occurs EARLIER in its prompt: the reference's walk stops at the first occurrence, the construction points at
+    # the name itself -> the deferred check says no (the tokenizer twin stays: nothing is wrong with it), the up-front path is right
+    nm = syn.syllable_names(3)
+    twice = [{"source": nm[i], "dest": "x", "prompts": [f"art by {nm[0]} and {{}}", "style of {}"], "seed_train": 1} for i in range(3)]
+    early = cz.templated_prompt_chunk(tok, twice, twice[0], defer_probe=True)
+    sure = cz.templated_prompt_chunk(tok, twice, twice[0])
+    assert early is not None and sure is not None and early.verify() is False
+    assert host_text.NativeClipBpe.for_tokenizer(tok) is not None
+    assert np.asarray(sure.lookup).tolist()[0] < np.asarray(early.lookup).tolist()[0]
+    monkeypatch.setenv("EMCID_TEMPLATED", "0")
+    _chunks_equal(sure, list(cz.iter_prompt_chunks(tok, twice, 1))[0])
+    monkeypatch.setenv("EMCID_TEMPLATED", "1")
     third = cz.templated_prompt_chunk(tok, syn.make_requests(40, names="syllable", name_seed=79), reqs[0], defer_probe=True)
     real = type(tok).__call__
 
