@@ -8,6 +8,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -254,68 +255,90 @@ int64_t emcid_bpe_encode_templated(emcid_bpe* m, const char* pre, const int64_t*
         const int64_t la = aoff[ka + 1] - aoff[ka], lb = boff[kb + 1] - boff[kb];
         return la == 0 || lb == 0 || is_space((unsigned char)a[aoff[ka + 1] - 1]) || is_space((unsigned char)b[boff[kb]]);
     };
-    // A mass edit brings ~1 000 names the cache has never seen (~1 us of merges each): the distinct names are encoded up front by
-    // a few threads, without the cache (names of a request set are not expected back; a replayed set costs the same again).
-    if (n_names >= 256) {
-        for (int64_t k = 0; k < n_names; ++k)
-            if (name_off[k + 1] < name_off[k]) {
-                g_error = "emcid_bpe_encode_templated: index or offsets out of range";
-                return -1;
-            }
-        const unsigned hw = std::thread::hardware_concurrency();
-        const int nt = (int)std::min<int64_t>(std::min<int64_t>(4, hw ? hw : 1), n_names / 128);
-        auto work = [&](int64_t lo, int64_t hi) {
-            std::string low_t;
-            for (int64_t k = lo; k < hi; ++k) {
-                Piece& pc = Nm[(size_t)k];
-                pc.state = encode_text(m, names + name_off[k], (size_t)(name_off[k + 1] - name_off[k]), low_t, pc.ids, budget, false) ? 1 : 2;
-            }
-        };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; ++t) pool.emplace_back(work, n_names * t / nt, n_names * (t + 1) / nt);
-        work(0, n_names / (nt > 0 ? nt : 1));
-        for (auto& th : pool) th.join();
-    }
-    int64_t n_fallback = 0;
-    std::vector<int32_t> row;
-    std::string whole;
-    for (int64_t i = 0; i < n; ++i) {
-        int64_t* out = ids + i * (int64_t)max_len;
-        for (int32_t j = 0; j < max_len; ++j) out[j] = pad;
-        lengths[i] = 0;
-        fallback[i] = 0;
-        if (name_last) name_last[i] = -1;
-        const int64_t t = tmpl_idx[i], k = name_idx[i];
-        if (t < 0 || t >= n_templates || k < 0 || k >= n_names || pre_off[t + 1] < pre_off[t] || suf_off[t + 1] < suf_off[t] ||
-            name_off[k + 1] < name_off[k]) {
+    for (int64_t k = 0; k < n_names; ++k)
+        if (name_off[k + 1] < name_off[k]) {
             g_error = "emcid_bpe_encode_templated: index or offsets out of range";
             return -1;
         }
-        row.clear();
-        bool ok;
-        if (name_off[k + 1] > name_off[k] && joins(pre, pre_off, t, names, name_off, k) && joins(names, name_off, k, suf, suf_off, t)) {
-            ok = piece(P[(size_t)t], pre, pre_off, t) && piece(Nm[(size_t)k], names, name_off, k) && piece(Sx[(size_t)t], suf, suf_off, t);
-            if (ok) {
-                row = P[(size_t)t].ids;
-                row.insert(row.end(), Nm[(size_t)k].ids.begin(), Nm[(size_t)k].ids.end());
-                // position (BOS included) of the name's last token, when the row is not cut by the length budget
-                const size_t upto = row.size();
-                row.insert(row.end(), Sx[(size_t)t].ids.begin(), Sx[(size_t)t].ids.end());
-                if (name_last && !Nm[(size_t)k].ids.empty() && row.size() <= (size_t)budget) name_last[i] = (int32_t)upto;
-            }
-        } else {                                   // pre-tokens may span a boundary: encode the formatted text as a whole
-            whole.assign(pre + pre_off[t], (size_t)(pre_off[t + 1] - pre_off[t]));
-            whole.append(names + name_off[k], (size_t)(name_off[k + 1] - name_off[k]));
-            whole.append(suf + suf_off[t], (size_t)(suf_off[t + 1] - suf_off[t]));
-            ok = encode_text(m, whole.data(), whole.size(), low, row, budget);
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t t = tmpl_idx[i], k = name_idx[i];
+        if (t < 0 || t >= n_templates || k < 0 || k >= n_names || pre_off[t + 1] < pre_off[t] || suf_off[t + 1] < suf_off[t]) {
+            g_error = "emcid_bpe_encode_templated: index or offsets out of range";
+            return -1;
         }
-        if (!ok) {
-            fallback[i] = 1;
-            ++n_fallback;
-            continue;
-        }
-        write_row(out, row, bos, eos, max_len, lengths + i);
     }
+    // rows [lo, hi): concatenations of encoded pieces, or the formatted text encoded as a whole.  `shared_cache`: the caller's
+    // thread (pieces are encoded on demand, through the model's pre-token cache); worker threads find every piece encoded
+    // already and encode whole texts without the cache (the model is only read).
+    auto assemble = [&](int64_t lo, int64_t hi, bool shared_cache, std::string& low_t) -> int64_t {
+        int64_t n_fb = 0;
+        std::vector<int32_t> row;
+        std::string whole;
+        for (int64_t i = lo; i < hi; ++i) {
+            int64_t* out = ids + i * (int64_t)max_len;
+            for (int32_t j = 0; j < max_len; ++j) out[j] = pad;
+            lengths[i] = 0;
+            fallback[i] = 0;
+            if (name_last) name_last[i] = -1;
+            const int64_t t = tmpl_idx[i], k = name_idx[i];
+            row.clear();
+            bool ok;
+            if (name_off[k + 1] > name_off[k] && joins(pre, pre_off, t, names, name_off, k) && joins(names, name_off, k, suf, suf_off, t)) {
+                if (shared_cache)
+                    ok = piece(P[(size_t)t], pre, pre_off, t) && piece(Nm[(size_t)k], names, name_off, k) && piece(Sx[(size_t)t], suf, suf_off, t);
+                else
+                    ok = P[(size_t)t].state == 1 && Nm[(size_t)k].state == 1 && Sx[(size_t)t].state == 1;
+                if (ok) {
+                    row = P[(size_t)t].ids;
+                    row.insert(row.end(), Nm[(size_t)k].ids.begin(), Nm[(size_t)k].ids.end());
+                    // position (BOS included) of the name's last token, when the row is not cut by the length budget
+                    const size_t upto = row.size();
+                    row.insert(row.end(), Sx[(size_t)t].ids.begin(), Sx[(size_t)t].ids.end());
+                    if (name_last && !Nm[(size_t)k].ids.empty() && row.size() <= (size_t)budget) name_last[i] = (int32_t)upto;
+                }
+            } else {                                   // pre-tokens may span a boundary: encode the formatted text as a whole
+                whole.assign(pre + pre_off[t], (size_t)(pre_off[t + 1] - pre_off[t]));
+                whole.append(names + name_off[k], (size_t)(name_off[k + 1] - name_off[k]));
+                whole.append(suf + suf_off[t], (size_t)(suf_off[t + 1] - suf_off[t]));
+                ok = encode_text(m, whole.data(), whole.size(), low_t, row, budget, shared_cache);
+            }
+            if (!ok) {
+                fallback[i] = 1;
+                ++n_fb;
+                continue;
+            }
+            write_row(out, row, bos, eos, max_len, lengths + i);
+        }
+        return n_fb;
+    };
+    // A mass edit brings ~1 000 names the cache has never seen (~1 us of merges each): a few threads encode the distinct names
+    // (without the cache: names of a request set are not expected back; a replayed set costs the same again), meet, and then
+    // assemble the rows, each its share.
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = n_names >= 256 ? (int)std::min<int64_t>(std::min<int64_t>(4, hw ? hw : 1), n_names / 128) : 1;
+    if (nt <= 1) return assemble(0, n, true, low);
+    for (int64_t t = 0; t < n_templates; ++t) {          // the few template pieces: here, through the cache
+        piece(P[(size_t)t], pre, pre_off, t);
+        piece(Sx[(size_t)t], suf, suf_off, t);
+    }
+    std::atomic<int> arrived{0};
+    std::vector<int64_t> n_fb((size_t)nt, 0);
+    auto work = [&](int w) {
+        std::string low_t;
+        for (int64_t k = n_names * w / nt; k < n_names * (w + 1) / nt; ++k) {
+            Piece& pc = Nm[(size_t)k];
+            pc.state = encode_text(m, names + name_off[k], (size_t)(name_off[k + 1] - name_off[k]), low_t, pc.ids, budget, false) ? 1 : 2;
+        }
+        arrived.fetch_add(1, std::memory_order_acq_rel);
+        while (arrived.load(std::memory_order_acquire) < nt) std::this_thread::yield();
+        n_fb[(size_t)w] = assemble(n * w / nt, n * (w + 1) / nt, false, low_t);
+    };
+    std::vector<std::thread> pool;
+    for (int w = 1; w < nt; ++w) pool.emplace_back(work, w);
+    work(0);
+    for (auto& th : pool) th.join();
+    int64_t n_fallback = 0;
+    for (int64_t v : n_fb) n_fallback += v;
     return n_fallback;
 }
 
