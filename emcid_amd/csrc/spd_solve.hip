@@ -944,6 +944,8 @@ __global__ __launch_bounds__(SP_T) void chol_step_spine_kernel(const double* __r
 static inline double* inv_block(double* invw, int64_t J) { return invw + J * (int64_t)OB * OB; }
 static inline const double* inv_block(const double* invw, int64_t J) { return invw + J * (int64_t)OB * OB; }
 
+static int env_flag(const char* name, int dflt);
+
 // Completes inv(L_JJ) for every OB x OB diagonal block from the leaf's 128 x 128 inverses, two levels of
 //   inv([[A,0],[C,B]]) = [[A^-1, 0], [-B^-1 C A^-1, B^-1]]      (batched over the blocks)
 static void build_block_inverses(const double* L, int64_t dp, int64_t lda, double* invw, hipStream_t st, int nmat = 1,
@@ -964,7 +966,28 @@ static void build_block_inverses(const double* L, int64_t dp, int64_t lda, doubl
     };
     ScopedProf sp(KC_INV_BLOCK, st);
     const int64_t sI = (int64_t)OB * OB, sT = (int64_t)TB * TB, sL = (int64_t)OB * lda + OB;
-    // level a: 256-blocks from pairs of 128-inverses.  u selects the pair inside an OB block.
+    // level a: 256-blocks from pairs of 128-inverses.  u selects the pair inside an OB block.  ONE matrix with whole OB blocks
+    // only (the N x N system of the dual solver at N = 1000): its second batch dimension is free, so the two pairs of every
+    // block share a launch (two launches instead of four on the tail behind the last leaf, ~8 us each).
+    static const int pair_batch = env_flag("EMCID_INV_PAIR_BATCH", 1);
+    if (pair_batch && nmat == 1 && rem == 0 && nfull > 0) {
+        const int64_t hopL = 2 * NB * (lda + 1), hopI = 2 * NB * (int64_t)(OB + 1), hopT = (int64_t)NB * TB;
+        const double* Cb = L + (int64_t)NB * lda;
+        double* Ai = inv_block(invw, 0);
+        double* Bi = inv_block(invw, 0) + NB * (int64_t)(OB + 1);
+        double* X = inv_block(invw, 0) + NB * (int64_t)OB;
+        GemmShape p1{Cb, lda, Ai, OB, NB, NB, NB, 0, sL, sI, (int)nfull};
+        p1.sA2 = hopL; p1.sB2 = hopI; p1.batch2 = 2;
+        p1.tri = 2;
+        EpiAxpby e1{tmp, TB, 1.0, 0.0, sT};
+        e1.sC2 = hopT;
+        launch_gemm_f64<true, false>(p1, e1, st, 2);                                                 // T = C A^-1
+        GemmShape p2{Bi, OB, tmp, TB, NB, NB, NB, 0, sI, sT, (int)nfull};
+        p2.sA2 = hopI; p2.sB2 = hopT; p2.batch2 = 2;
+        EpiAxpby e2{X, OB, -1.0, 0.0, sI};
+        e2.sC2 = hopI;
+        launch_gemm_f64<true, false>(p2, e2, st, 2);                                                 // X = -B^-1 T
+    } else
     for (int u = 0; u < 2; ++u) {
         auto level_a = [&](int64_t J0, int cnt) {
             const double* Cb = L + ((J0 * 4 + 2 * u + 1) * NB) * lda + (J0 * 4 + 2 * u) * NB;
