@@ -97,7 +97,10 @@ def _cov_from_file(path, sample_size, device):
         keep["t"] = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
         return keep["t"].numpy()
 
-    dat = rs.read_npz_stored(path, alloc=alloc)
+    try:
+        dat = rs.read_npz_stored(path, alloc=alloc)
+    except RuntimeError:            # no page-locked memory to be had: the general path reads into pageable memory
+        return None
     if dat is None:
         return None
     try:

@@ -21,7 +21,7 @@ for s, e, n in rows[1:]:
     cur.append((s, e, n))
     end = max(end, e)
 calls.append(cur)
-sizes = Counter(len(c) for c in calls)
+sizes = Counter(len(c) for c in calls if len(c) >= 50)      # (the process's set-up shows as many short runs)
 main = sizes.most_common(1)[0][0]
 print("calls", len(calls), "most common kernel count per call", main, "x", sizes[main])
 spans, busys, gaps_tot, gap_by = [], [], [], defaultdict(list)
@@ -47,5 +47,18 @@ for c in calls:
         gap_by[k].append(v / 1e6)
 print(f"span ms median {statistics.median(spans):.3f}  busy {statistics.median(busys):.3f}  between kernels {statistics.median(gaps_tot):.3f}")
 print("gap histogram (us bucket: count over the counted calls):", dict(sorted(hist.items())))
-for k, v in sorted(gap_by.items(), key=lambda kv: -statistics.median(kv[1]))[:14]:
+for k, v in sorted(gap_by.items(), key=lambda kv: -statistics.median(kv[1]))[:6]:
     print(f"  before {k:62s} {statistics.median(v):.3f} ms per call")
+dur, cnt = defaultdict(float), defaultdict(int)
+n_counted = 0
+for c in calls:
+    if len(c) != main:
+        continue
+    n_counted += 1
+    for s_, e_, n_ in c:
+        key = n_.split("(")[0][-70:]
+        dur[key] += e_ - s_
+        cnt[key] += 1
+print("kernel time per call:")
+for k, v in sorted(dur.items(), key=lambda kv: -kv[1])[:16]:
+    print(f"  {k:72s} {v / n_counted / 1e6:7.3f} ms in {cnt[k] / n_counted:5.1f} launches")
