@@ -2176,13 +2176,20 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
     }
     double* P = base + ws.off_P;
     const double* X = use_inverse ? cov_inverse(cov_factor_ws, n_layers, dp, layer_index) : nullptr;
+    // Few concepts (a 100-concept edit: Np = 128, no chain of leaves to ride in): U = Z^T (Yt X) with the triangle multiplied on the
+    // Np-row side as a launch of its own, instead of U = (Z^T Yt) X on the h-row side — 128 rows against 768 at SD dims
+    // (61 + ~15 us instead of ~20 + 155 per layer).  EMCID_P_FIRST=0: the h-side form.
+    static const int p_first_env = env_flag("EMCID_P_FIRST", 1);
+    const bool p_first = p_first_env && !shadow && use_inverse && Np < h;
     EMCID_TRY(with_graph(make_key(6, {Yt, R, S, LS, RT, V, U, info_dev},
-                                  {dp, Np, N, hp, (int64_t)(uintptr_t)Lb, use_inverse + 2 * (assembled != 0) + 4 * (int)shadow + 8 * h + (d << 32)}),
+                                  {dp, Np, N, hp, (int64_t)(uintptr_t)Lb,
+                                   use_inverse + 2 * (assembled != 0) + 4 * (int)shadow + 8 * h + ((int64_t)p_first << 31) + (d << 32)}),
                          st,
                          [&](hipStream_t q) {
         if (!assembled) {
             assemble_dual_system(Yt, Yt, dp, S, (int)Np, q, base + ws.off_SK);      // S = I + Yt Yt^T (lower tiles)
         }
+        if (p_first) apply_inverse_backward(X, dp, Yt, (int)Np, (int)dp, P, dp, q, base + ws.off_SK);       // P = Yt X
         ShadowJob job{Yt, dp, X, dp, P, dp, (int)Np, (int)dp, (int)dp, 0, 0, nullptr, 0, 0, 0};
         job.wgs = (int)((Np + SH_BM - 1) / SH_BM) * (int)(((dp + SH_BN - 1) / SH_BN + 1) / 2);
         EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q, shadow ? &job : nullptr));
@@ -2207,7 +2214,7 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
         } else {
             EMCID_TRY(cholesky_solve_impl(LS, Np, Np, invS, RT, Y2, h, Np, q));
         }
-        if (!shadow) {
+        if (!shadow && !p_first) {
             ScopedProf sp(KC_DELTA_W, q);       // V[h, dp] = Z^T Yt
             GemmShape g{RT, Np, Yt, dp, (int)h, (int)dp, (int)Np, 0};
             launch_gemm_f64<true, false>(g, EpiAxpby{V, dp, 1.0, 0.0}, q);
@@ -2215,7 +2222,7 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
         if (!use_inverse) trsm_backward(Lb, dp, dp, Ib, V, U, (int)h, dp, q);   // U L = V by block substitution
         return check_launch("emcid_edit_dual_apply_stage2_f64");
     }));
-    if (shadow) {
+    if (shadow || p_first) {
         // U = Z^T P straight into the weights: W = W0 + float(U), dW = float(U) in the GEMM's epilogue (outside the cached graph:
         // W0 / W / dW are the caller's tensors and change from layer to layer and call to call)
         ScopedProf sp(KC_DELTA_W, st);

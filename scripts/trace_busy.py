@@ -22,7 +22,7 @@ for s, e, n in rows[1:]:
     end = max(end, e)
 calls.append(cur)
 sizes = Counter(len(c) for c in calls if len(c) >= 50)      # (the process's set-up shows as many short runs)
-main = sizes.most_common(1)[0][0]
+main = max(k for k, v in sizes.items() if v >= 5)      # the longest run that repeats: a whole call the host never starved
 print("calls", len(calls), "most common kernel count per call", main, "x", sizes[main])
 spans, busys, gaps_tot, gap_by = [], [], [], defaultdict(list)
 hist = Counter()
