@@ -32,6 +32,8 @@
 // 240 / 720 / 960 tiles = 0.94 / 2.81 / 3.75 rounds of the 256 compute units (128 x 128: 300 tiles = 59 % of two rounds).
 #include "common.h"
 
+#include <algorithm>
+
 namespace emcid {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -343,11 +345,101 @@ __global__ __launch_bounds__(256 * KS) void linear_f32_kernel(LinearArgs a) {
 // Sixteen waves per workgroup (four K groups) for the few 64 x 64 tiles of the mean keys through fc2 (1 000 x 3072 -> 768, 192
 // tiles: at most one workgroup per compute unit): 64.5 us against 66.1 with eight (profiles/r03_mb_linear_16w.txt) — that launch
 // is not short of waves; removed.
-// Split-K for launches of few tiles (every 128 x 128 tile's K range over 2..8 workgroups, partial tiles through a workspace with
-// the same ticket scheme, summed in part order): 640 x 3072 -> 768 61.7 -> 43.2 us (8 parts), 1 000 x 5120 -> 1280 173.8 -> 123.0,
-// 1 000 x 3072 -> 768 65.2 -> 61.6, K = 768 launches slower (profiles/r03_mb_linear_splitk.txt; hipBLASLt: 30 / 107 / 41 us) —
-// a part's publish and the last arriver's re-read + epilogue cost ~15 us per launch.  No bench record moved (the 100-concept edit
-// is host-bound at 4.5 ms, the mean-keys GEMM is 4 x 65 us of a 14 ms call): removed with its workspace entry point.
+// ---- few tiles, long K: the K range of every tile cut over several workgroups ("split-K") -----------------------------------
+// fc2 of a 100-concept edit (640 x 3072 -> 768) or of the mean keys of a 1 000-concept one (1 000 x 3072 -> 768) is 30-48 tiles of
+// 128 x 128 on a K of 3072: most compute units would get nothing, and 64 x 64 tiles (one workgroup each, 120-192 of them) stream
+// 16 flop per byte.  Here tile t is computed by `parts` workgroups, part p over the stages [p T / parts, (p + 1) T / parts); every
+// part publishes its accumulators to workspace slot [t][p] (lane-linear image) and takes a ticket on the tile's counter; the one
+// whose ticket is the last re-reads ALL slots of the tile in part order (its own included: the sum order never depends on who came
+// last — bit-reproducible), runs the epilogue and puts the counter back to zero.  Nobody waits for anybody.  Cross-CU hand-off
+// as in gemm_f64.h's stream-K (cdna_hip_programming.md Guideline 16, write-through form): sc1 stores -> every wave's s_waitcnt
+// vmcnt(0) -> barrier -> lane 0 relaxed agent-scope ticket; last arriver: lane 0 acquire fence (agent) -> barrier -> plain loads.
+// The parts of a tile are dealt to ONE XCD (consecutive there).
+struct LinearSplit {
+    int parts;
+    float* partials;             // [tiles][parts][256 * 64]
+    unsigned* counters;          // [tiles], zero on entry, zero again on exit
+};
+
+template <int PF>
+__global__ __launch_bounds__(256) void linear_f32_splitk_kernel(LinearArgs a, LinearSplit w) {
+    constexpr int MI = 2, NJ = 2, WM = 2, WN = 2;
+    using G = LinearGeom<MI, NJ, WM, WN, PF, 0, 1>;
+    constexpr int NT = G::NT, SLOT = NT * 16 * MI * NJ;
+    __shared__ __attribute__((aligned(16))) float smem[G::SMEM];
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    const int T = a.K / G::SBK;
+    // work item u = tile * parts + part; XCD x takes the items [x * per, (x + 1) * per): all parts of a tile on one XCD
+    const int items = a.tiles * w.parts, per = ((a.tiles + 7) / 8) * w.parts;
+    const int u = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (u >= items || (int)(blockIdx.x >> 3) >= per) return;
+    const int tile = u / w.parts, part = u - tile * w.parts;
+    const int it_lo = (int)((int64_t)part * T / w.parts), it_hi = (int)((int64_t)(part + 1) * T / w.parts);
+    int bm, bn;
+    linear_tile_of(a, tile, bm, bn);
+    const int m0 = bm * G::BM, n0 = bn * G::BN;
+    v16f acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (it_hi > it_lo) linear_accumulate<MI, NJ, WM, WN, PF, 0, 1>(a, m0, n0, it_lo, it_hi, smem, acc);
+    float* slots = w.partials + (int64_t)tile * w.parts * SLOT;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v4f x = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                float* dst = slots + (int64_t)part * SLOT + ((int64_t)((i * NJ + j) * 4 + q) * NT + tid) * 4;
+                // write-through (sc1): the bytes leave the XCD's L2 as they are stored, so publishing them needs no agent-scope
+                // release (an L2 write-back of everything the workgroup's XCD has dirtied)
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(x) : "memory");
+            }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(w.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old == (unsigned)(w.parts - 1)) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        w.counters[tile] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int p = 0; p < w.parts; ++p) {
+        const float* src = slots + (int64_t)p * SLOT;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4f x = *reinterpret_cast<const v4f*>(src + ((int64_t)((i * NJ + j) * 4 + q) * NT + tid) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += x[e];
+                }
+    }
+    linear_finish<MI, NJ, WM, WN, PF, 0, 1>(a, m0, n0, smem, acc);
+}
+
+constexpr int kSplitTiles = 256;                 // most tiles a split-K launch has (= ticket counters at the head of the workspace)
+constexpr int kSplitItems = 512;                 // most (tile, part) work items = partial-tile slots behind the counters
+constexpr int kSplitSlot = 256 * 64;             // floats of one partial 128 x 128 tile
+
 struct LinearCfg { int bm, bn; };
 static const LinearCfg kLinearCfgs[] = {{160, 128}, {128, 128}, {256, 128}, {64, 64}};
 
@@ -357,14 +449,22 @@ using namespace emcid;
 
 extern "C" {
 
-int emcid_linear_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual,
-                     int64_t ldr, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, int act, int cfg, void* stream) {
+/* bytes of the workspace emcid_linear_ws_f32 wants (ticket counters + partial-tile slots of the split-K form); zeroed ONCE by the
+ * caller when allocated, left zeroed by every launch; one per stream whose launches may overlap another's */
+int64_t emcid_linear_workspace_bytes(void) { return (int64_t)kSplitTiles * 4 + (int64_t)kSplitItems * kSplitSlot * 4; }
+
+int emcid_linear_ws_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual,
+                        int64_t ldr, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, int act, int cfg, void* workspace,
+                        int64_t workspace_bytes, void* stream) {
     EMCID_CHECK_ARG(X && W && Y && M > 0 && N > 0 && K > 0 && ldx >= K && ldw >= K && ldy >= N);
     EMCID_CHECK_ARG(K % LBK == 0 && ldx % 4 == 0 && ldw % 4 == 0 && aligned16(X) && aligned16(W));
     EMCID_CHECK_ARG(M < (1 << 24) && N < (1 << 24) && K < (1 << 24) && (residual == nullptr || ldr >= N));
-    EMCID_CHECK_ARG(act >= ACT_NONE && act <= ACT_GELU_ERF && cfg >= -1 && cfg < 128);
+    EMCID_CHECK_ARG(act >= ACT_NONE && act <= ACT_GELU_ERF && cfg >= -1 && cfg < 128 + 16 * 128);
+    EMCID_CHECK_ARG(workspace == nullptr || (workspace_bytes >= emcid_linear_workspace_bytes() && aligned16(workspace)));
     // cfg: bits 0-1 tile, bits 2-3 prefetch distance - 1 (0..2), bits 4-5 DBG (tile 0, one K group only), bit 6: ONE K group
-    // (4 waves) instead of two (8 waves); -1: auto
+    // (4 waves) instead of two (8 waves), bits 7-10: split-K parts (2..8; tile 1, bit 6 set, needs the workspace); -1: auto
+    int parts = cfg < 0 ? 0 : (cfg >> 7) & 15;
+    if (cfg >= 0) cfg &= 127;
     int tile_sel = cfg < 0 ? -1 : (cfg & 3);
     static const int pf_env = [] { const char* e = getenv("EMCID_LINEAR_PF"); return e ? atoi(e) : 1; }();
     static const int ks_env = [] { const char* e = getenv("EMCID_LINEAR_KS"); return e ? atoi(e) : 2; }();
@@ -374,6 +474,19 @@ int emcid_linear_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, c
     if (K % (2 * LBK) != 0) ks = 1;
     if (dbg) ks = 1;
     EMCID_CHECK_ARG(pf >= 1 && pf <= 3 && dbg <= 2 && (dbg == 0 || tile_sel == 0));
+    const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
+    EMCID_CHECK_ARG(parts == 0 || (parts >= 2 && parts <= 8 && tile_sel == 1 && ks == 1 && dbg == 0 && workspace != nullptr &&
+                                   t128 <= kSplitTiles && t128 * parts <= kSplitItems && K / LBK >= parts));
+    static const int split_env = [] { const char* e = getenv("EMCID_LINEAR_SPLITK"); return e ? atoi(e) : 1; }();
+    if (tile_sel < 0 && workspace != nullptr && split_env && t128 <= 128 && K >= 2048) {
+        // at most half the compute units would get a 128 x 128 tile: cut K so that about one workgroup per compute unit runs.
+        // Measured (scripts/mb_linear.py, profiles/r03_mb_linear_splitk.txt; us, 64 x 64 tiles -> split-K; hipBLASLt beside it):
+        // 640 x 3072 -> 768 61.7 -> 43.2 (8 parts; 30), 1 000 x 5120 -> 1280 173.8 -> 123.0 (6) / 131.1 (3; 107), 1 000 x 3072 ->
+        // 768 65.2 -> 61.6 (5; 41); a part's publish + the last arriver's re-read and epilogue cost ~15 us per launch, so K = 768
+        // launches (640 x 768 -> 2304: 31.6 -> 37.3) stay on the small tiles.
+        const int64_t want = std::min<int64_t>(std::min<int64_t>(8, 256 / t128), (K / LBK) / 8);
+        if (want >= 2) tile_sel = 1, ks = 1, pf = 2, parts = (int)want;
+    }
     if (tile_sel < 0) {
         // Pick (tile, waves) by fill x base rate.  fill: a compute unit works through ceil(tiles / 256) tiles (co-resident
         // workgroups share its matrix pipe), the average one through tiles / 256.  Base rates = fraction of the f32 MFMA rate
@@ -382,7 +495,7 @@ int emcid_linear_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, c
         //   160 x 128, 8 waves (K split inside the workgroup), one per compute unit: 0.765, 0.83 from K = 2048
         //   64 x 64, up to 8 workgroups per compute unit: 0.70
         auto fill = [](int64_t t) { return ((double)t / 256.0) / (double)((t + 255) / 256); };
-        const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128), t160 = ((M + 159) / 160) * ((N + 127) / 128);
+        const int64_t t160 = ((M + 159) / 160) * ((N + 127) / 128);
         const int64_t t64 = ((M + 63) / 64) * ((N + 63) / 64);
         const bool split_ok = K % (2 * LBK) == 0 && ks_env != 1;
         const double s128 = (K < 1024 ? 0.83 : K < 4096 ? 0.875 : 0.90) * fill(t128);
@@ -401,6 +514,15 @@ int emcid_linear_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, c
     const int rb = rb_env >= 1 ? rb_env : 1;
     const LinearArgs a{X, ldx, W, ldw, bias, residual, ldr, Y, ldy, (int)M, (int)N, (int)K, act, tiles_n, tiles, rb};
     ScopedProf sp(KC_LINEAR, st);
+    if (parts >= 2) {
+        LinearSplit w{parts, (float*)((char*)workspace + (int64_t)kSplitTiles * 4), (unsigned*)workspace};
+        const unsigned grid = (unsigned)(((tiles + 7) / 8) * parts * 8);
+        if (pf == 1) hipLaunchKernelGGL((linear_f32_splitk_kernel<1>), dim3(grid), dim3(256), 0, st, a, w);
+        else if (pf == 2) hipLaunchKernelGGL((linear_f32_splitk_kernel<2>), dim3(grid), dim3(256), 0, st, a, w);
+        else hipLaunchKernelGGL((linear_f32_splitk_kernel<3>), dim3(grid), dim3(256), 0, st, a, w);
+        EMCID_CHECK_LAUNCH();
+        return EMCID_OK;
+    }
 #define EMCID_LINEAR_LAUNCH(MI_, NJ_, WM_, WN_, PF_, DBG_, KS_)                                                              \
     hipLaunchKernelGGL((linear_f32_kernel<MI_, NJ_, WM_, WN_, PF_, DBG_, KS_>), dim3((unsigned)(per * 8)), dim3(256 * KS_), 0, \
                        st, a)
@@ -425,6 +547,11 @@ int emcid_linear_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, c
 #undef EMCID_LINEAR_LAUNCH
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
+}
+
+int emcid_linear_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual,
+                     int64_t ldr, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, int act, int cfg, void* stream) {
+    return emcid_linear_ws_f32(X, ldx, W, ldw, bias, residual, ldr, Y, ldy, M, N, K, act, cfg, nullptr, 0, stream);
 }
 
 }  // extern "C"

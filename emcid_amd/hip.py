@@ -29,12 +29,12 @@ EXPORTS = [
     "emcid_edit_dual_apply_assemble_f64",
     "emcid_edit_lu_workspace_bytes", "emcid_edit_layer_lu_f64", "emcid_lu_solve_f64",
     "emcid_edit_dual_cols_stage1_f64", "emcid_edit_dual_s", "emcid_edit_dual_u", "emcid_edit_dual_cols_stage2_f64",
-    "emcid_apply_update2d_f32", "emcid_linear_f32",
+    "emcid_apply_update2d_f32", "emcid_linear_f32", "emcid_linear_ws_f32", "emcid_linear_workspace_bytes",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block", "linear"]
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 NB = 128      # Cholesky block (csrc/common.h)
 NPAD = 64     # concept padding of the f64 stacks (csrc/common.h)
 
@@ -103,6 +103,8 @@ def load():
         "emcid_axpy_f32": (i32, [p, p, i64, p]),
         "emcid_quick_gelu_f32": (i32, [p, p, i64, p]),
         "emcid_linear_f32": (i32, [p, i64, p, i64, p, p, i64, p, i64, i64, i64, i64, i32, i32, p]),
+        "emcid_linear_ws_f32": (i32, [p, i64, p, i64, p, p, i64, p, i64, i64, i64, i64, i32, i32, p, i64, p]),
+        "emcid_linear_workspace_bytes": (i64, []),
         "emcid_add_layernorm_f32": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p]),
         "emcid_embed_layernorm_f32": (i32, [p, i64, i64, p, i64, i64, p, p, p, p, C.c_float, i64, i64, p, p, p]),
         "emcid_tree_attention_f32": (i32, [p, i64, p, p, i64, p, i64, p, p, i64, i64, i64, f32, p, i64, p]),
@@ -480,10 +482,31 @@ def linear_supported(x: torch.Tensor, w: torch.Tensor) -> bool:
             and x.shape[0] > 0)
 
 
+_LINEAR_WS = {}       # (device index, stream handle) -> the split-K form's workspace (zeroed once; every launch leaves its counters zero)
+
+
+def linear_split_cfg(parts: int, prefetch: int = 2) -> int:
+    """``cfg`` of the split-K form: 128 x 128 tiles, four waves, every tile's K range over ``parts`` (2..8) workgroups."""
+    return 64 + 1 + 4 * (prefetch - 1) + (int(parts) << 7)
+
+
+def _linear_workspace(dev: torch.device) -> torch.Tensor:
+    """Launches of one stream run one after the other and share the partial-tile slots; launches of different streams (the two
+    encoders of an SDXL edit) may overlap and get their own (32 MB each)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
+    ws = _LINEAR_WS.get(key)
+    if ws is None:
+        if len(_LINEAR_WS) >= 8:
+            _LINEAR_WS.clear()
+        ws = _LINEAR_WS[key] = torch.zeros(int(load().emcid_linear_workspace_bytes()), dtype=torch.uint8, device=dev)
+    return ws
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
            residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, cfg: int = -1) -> torch.Tensor:
     """act(x @ w.T + bias) + residual in one launch (csrc/gemm_f32.hip): x (M, K), w (N, K) like nn.Linear.weight, bias (N,),
-    residual (M, N) row views; fp32, exact-f32 MFMA."""
+    residual (M, N) row views; fp32, exact-f32 MFMA.  Launches of at most 128 tiles on a K of 2048 or more are cut by K over
+    several workgroups per tile (partial tiles meet in a per-stream workspace, fixed summation order)."""
     if not linear_supported(x, w):
         raise EmcidHipError("linear: fp32 HBM operands with K contiguous, K % 16 == 0 and 16-byte aligned rows")
     M, K = x.shape
@@ -499,10 +522,15 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     if LINEAR_FLOPS["count"]:
         LINEAR_FLOPS["flops"] += 2.0 * M * N * K
         LINEAR_FLOPS["launches"] += 1
-    _check(load().emcid_linear_f32(_ptr(x, torch.float32, "x"), x.stride(0), _ptr(w, torch.float32, "w"), w.stride(0),
-                                   _ptr(bias, torch.float32, "bias"), _ptr(residual, torch.float32, "residual"),
-                                   residual.stride(0) if residual is not None else 0, _ptr(out, torch.float32, "out"),
-                                   out.stride(0), M, N, K, int(act), int(cfg), _stream(x)), "emcid_linear_f32")
+    ws = None
+    if (cfg >= 128 or (cfg < 0 and K >= 2048 and -(-M // 128) * -(-N // 128) <= 128)) and not torch.cuda.is_current_stream_capturing():
+        ws = _linear_workspace(x.device)
+    _check(load().emcid_linear_ws_f32(_ptr(x, torch.float32, "x"), x.stride(0), _ptr(w, torch.float32, "w"), w.stride(0),
+                                      _ptr(bias, torch.float32, "bias"), _ptr(residual, torch.float32, "residual"),
+                                      residual.stride(0) if residual is not None else 0, _ptr(out, torch.float32, "out"),
+                                      out.stride(0), M, N, K, int(act), int(cfg),
+                                      C.c_void_p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0,
+                                      _stream(x)), "emcid_linear_ws_f32")
     return out
 
 

@@ -28,7 +28,7 @@ extern "C" {
 #define EMCID_ERR_HIP (-2)
 #define EMCID_ERR_WORKSPACE (-3)
 
-#define EMCID_ABI_VERSION 9
+#define EMCID_ABI_VERSION 10
 
 /* ABI version of the loaded library (host-only, no GPU needed). */
 int emcid_abi_version(void);
@@ -102,6 +102,18 @@ int emcid_quick_gelu_f32(const float* x, float* y, int64_t n, void* stream);
  * 1 = 128 x 128, 2 = 256 x 128, 3 = 64 x 64.  Y may alias residual (each element is read then written by the same lane). */
 int emcid_linear_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual,
                      int64_t ldr, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, int act, int cfg, void* stream);
+
+/* The same projection with a workspace, for launches of few tiles on a long K (fc2 of a 100-concept edit, the mean keys of a
+ * 1 000-concept one through fc2): given `workspace` (emcid_linear_workspace_bytes() bytes of HBM, 16-byte aligned, ZEROED ONCE
+ * by the caller when allocated — every launch leaves its ticket counters zero —, not shared by launches that may overlap on
+ * different streams) the automatic choice (cfg = -1) cuts the K range of every 128 x 128 tile over 2..8 workgroups when at most
+ * 128 tiles would otherwise run and K >= 2048 ("split-K": partial tiles meet in the workspace and are summed in part order —
+ * bit-reproducible from call to call, different from emcid_linear_f32's result by the summation order only).  cfg bits 7-10 =
+ * parts force that form (tile 1, bit 6 set).  workspace == NULL: exactly emcid_linear_f32. */
+int64_t emcid_linear_workspace_bytes(void);
+int emcid_linear_ws_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual,
+                        int64_t ldr, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, int act, int cfg, void* workspace,
+                        int64_t workspace_bytes, void* stream);
 
 /* y = a + b ; z = LayerNorm(y) * gamma + beta over the last dimension (biased variance, eps inside the root, as
  * torch.nn.LayerNorm) — the residual add and the LayerNorm after it of every block of the same hooked forward, one

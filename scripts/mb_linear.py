@@ -13,7 +13,7 @@ dev = "cuda"
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 6400
 shapes = [(rows, 768, 2304, "qkv"), (rows, 768, 768, "out"), (rows, 768, 3072, "fc1"), (rows, 3072, 768, "fc2"),
           (3072, 768, 768, "out@query"), (3072, 768, 3072, "fc1@query"), (1000, 3072, 768, "fc2(K)"), (640, 768, 2304, "qkv@n100"),
-          (640, 3072, 768, "fc2@n100"), (1000, 5120, 1280, "fc2(K)-bigG"),
+          (640, 768, 768, "out@n100"), (640, 768, 3072, "fc1@n100"), (640, 3072, 768, "fc2@n100"), (1000, 5120, 1280, "fc2(K)-bigG"),
           (rows, 1280, 3840, "qkv-bigG"), (rows, 1280, 5120, "fc1-bigG"), (rows, 5120, 1280, "fc2-bigG")]
 tune = os.environ.get("MB_TUNE", "1") == "1"
 
@@ -54,6 +54,8 @@ for M, K, N, name in shapes:
     names = {0: "160x128", 1: "128x128", 2: "256x128", 3: "64x64"}
     cfgs = [(-1, "auto")] + [(tile + 4 * (pf - 1), f"{names[tile]}/8w/pf{pf}") for tile in (0, 1, 2, 3) for pf in (1, 2)]
     cfgs += [(64 + tile + 4 * (pf - 1), f"{names[tile]}/4w/pf{pf}") for tile, pf in ((0, 3), (1, 2), (3, 3))]
+    t128 = -(-M // 128) * -(-N // 128)
+    cfgs += [(hip.linear_split_cfg(parts), f"128x128/splitK{parts}") for parts in (2, 3, 4, 6, 8) if t128 * parts <= 512 and t128 <= 256]
     if os.environ.get("MB_DBG", "0") == "1":       # timing-only variants (wrong results): no loads in the loop / no LDS stores either
         cfgs += [(0 + 4 + 16, "160x128/4w/noload"), (0 + 4 + 32, "160x128/4w/noload-nostore")]
     for cfg, cn in cfgs:

@@ -628,6 +628,46 @@ def test_linear_f32_vs_torch(M, K, N, cfg):
     assert torch.equal(wide[:, :N], y) and bool((wide[:, N:] == 7.0).all())
 
 
+@pytest.mark.parametrize("M,K,N", [(1000, 3072, 768), (640, 3072, 768), (640, 768, 2304), (800, 2048, 768), (1000, 5120, 1280),
+                                   (129, 4096, 257), (37, 2048, 200)])
+def test_linear_split_k_is_reproducible_and_leaves_its_workspace_clean(M, K, N):
+    """The split-K form of the 128 x 128 kernel for launches of few tiles (every tile's K range over 2..8 workgroups; partial
+    tiles meet in a per-stream workspace; the last arriver sums them in part order): fp32-rounding close to the fp64 product for
+    every part count, the same bits call after call, picked by the automatic choice where K is long, the fused epilogues intact,
+    the ticket counters back at zero, a second stream gets a second workspace."""
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r = torch.randn(M, N, generator=g).to(DEV)
+    ref = F.linear(x.double(), w.double(), b.double())
+    tol = 3e-6 * ref.abs().max().item() * max(1.0, (K / 768) ** 0.5) + 1e-6
+    tiles = -(-M // 128) * -(-N // 128)
+    for parts in (2, 3, 5, 8):
+        if tiles * parts > 512:
+            continue
+        cfg = hip.linear_split_cfg(parts)
+        y = hip.linear(x, w, b, cfg=cfg)
+        assert (y.double() - ref).abs().max().item() <= tol
+        for _ in range(3):
+            assert torch.equal(hip.linear(x, w, b, cfg=cfg), y)
+        yq = hip.linear(x, w, b, act=hip.ACT_QUICK_GELU, residual=r, cfg=cfg)
+        torch.testing.assert_close(yq, ((ref * torch.sigmoid(1.702 * ref)) + r.double()).float(), rtol=2e-6, atol=tol)
+    auto = hip.linear(x, w, b)
+    assert (auto.double() - ref).abs().max().item() <= tol and torch.equal(hip.linear(x, w, b), auto)
+    ws = hip._linear_workspace(torch.device(DEV))
+    torch.cuda.synchronize()
+    assert int(ws[:1024].view(torch.int32).abs().sum().item()) == 0
+    side = torch.cuda.Stream(device=DEV)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ys = [hip.linear(x, w, b) for _ in range(4)]
+        assert hip._linear_workspace(torch.device(DEV)) is not ws
+    ym = [hip.linear(x, w, b) for _ in range(4)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(t, auto) for t in ys + ym)
+
+
 def test_linear_f32_rejects_unsupported_operands():
     x = torch.randn(8, 24, device=DEV)
     w = torch.randn(4, 24, device=DEV)
