@@ -1,0 +1,413 @@
+// The row-wise projections of the CLIP text-encoder forward on gfx950 at fp32 accuracy on the 16-bit matrix pipe:
+//     Y = act(X W^T + bias) + residual          (emcid/compute_z.py:2296-2316 runs the encoder; q/k/v, out_proj, fc1, fc2)
+// The exact-f32 MFMA of gemm_f32.hip runs at 1/16 of the f16 rate (MI355X_MICROARCH.md, Matrix cores).  Here every fp32 operand
+// row is carried as TWO fp16 numbers per element under a per-row power-of-two scale,
+//     x * 2^e = hi + lo,   hi = fp16(x 2^e),  lo = fp16(x 2^e - hi)       (e: the row's largest |x| lands in [2^14, 2^15))
+// which keeps 22-23 significant bits of x (the sign of lo is the extra one; |lo| <= ulp(hi) / 2, and with the row's maximum at
+// the top of the fp16 range a lo below the fp16 normal range is below 2^-28 of the row's maximum), and the product is the three
+// MFMAs hi.hi + hi.lo + lo.hi accumulated in fp32 (the lo.lo term, <= 2^-22 of a product, is dropped; fp16 x fp16 products
+// are exact in the fp32 accumulate): 3/16 of the f32-MFMA issue time for the same contraction.  The scales are powers of two, so
+// undoing them in the epilogue is exact: Y[m][n] = acc * 2^-(e_x[m] + e_w[n]).
+//
+// Storage of a split matrix ("planes", one 4-byte unit per element like the fp32 matrix it stands for, so row views and row
+// gathers work on it as on an int32 matrix): per row, groups of 8 consecutive k: [hi k..k+7 (16 B)][lo k..k+7 (16 B)].  A lane's
+// MFMA fragment (v_mfma_f32_32x32x16_f16: 8 consecutive k of one row) is then ONE ds_read_b128 per plane, and a stage's 32 k of
+// a row are one whole 128-byte line in global memory.
+//
+// The MFMA runs "transposed": A operand = W rows (n), B operand = X rows (m), so a lane of the result holds ONE row m and four
+// consecutive n per register quad: 16-byte stores / residual loads in the epilogue, and the fp16 planes of the OUTPUT (when the
+// consumer is the next projection: quick_gelu(fc1) -> fc2) are written 8 bytes per plane per quad straight from the registers.
+#include "common.h"
+
+#include <algorithm>
+
+namespace emcid {
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+constexpr int SPK = 32;            // k per stage
+constexpr int SPROW = 144;         // LDS bytes per tile row and stage: 128 + 16 (36 dwords: the 16 lanes of every b128 lane
+                                   // group fall on 16 distinct 4-bank groups, 36 r mod 64 = 4 (9 r mod 16))
+
+enum SpAct : int { SP_ACT_NONE = 0, SP_ACT_QUICK_GELU = 1, SP_ACT_GELU_ERF = 2 };
+
+template <int V> struct SpIC { static constexpr int value = V; };
+
+__device__ __forceinline__ bool sp_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+struct SpArgs {
+    const uint32_t* X; int64_t ldx; const float* xs;      // planes of X [M][K], 2^-e per row
+    const uint32_t* W; int64_t ldw; const float* ws;      // planes of W [N][K], 2^-e per row
+    const float* bias;
+    const float* res; int64_t ldr;
+    float* Y; int64_t ldy;                                // fp32 result (may be null when only the planes are wanted)
+    uint32_t* P; int64_t ldp; const float* ps;            // planes of the result under the caller's per-row scale 2^e (or null)
+    int M, N, K, act, tiles_n, tiles, rb;
+};
+
+// Tile order as in gemm_f32.hip: super-rows of `rb` row tiles, column-major inside a super-row.
+__device__ __forceinline__ void sp_tile_of(const SpArgs& a, int tile, int& bm, int& bn) {
+    const int tiles_m = a.tiles / a.tiles_n, sr = tile / (a.rb * a.tiles_n), rem = tile - sr * a.rb * a.tiles_n;
+    const int rows = min(a.rb, tiles_m - sr * a.rb);
+    bn = rem / rows;
+    bm = sr * a.rb + (rem - bn * rows);
+}
+
+// MJ x NI blocks of 32 x 32 per wave (m x n), WM x WN waves per workgroup, PF register sets of staged global loads.
+template <int MJ, int NI, int WM, int WN, int PF>
+struct SpGeom {
+    static constexpr int NT = 64 * WM * WN;
+    static constexpr int BM = 32 * MJ * WM, BN = 32 * NI * WN;
+    static constexpr int VA = (BM * 8 + NT - 1) / NT, VB = (BN * 8 + NT - 1) / NT;      // 16-byte pieces per thread and stage
+    static constexpr int STAGE = (BM + BN) * SPROW;                                      // bytes
+    static constexpr int SMEM = 2 * STAGE;
+};
+
+template <int MJ, int NI, int WM, int WN, int PF>
+__device__ __forceinline__ void sp_accumulate(const SpArgs& a, int m0, int n0, int T, unsigned char* smem, v16f (&acc)[NI][MJ]) {
+    using G = SpGeom<MJ, NI, WM, WN, PF>;
+    constexpr int NT = G::NT, BM = G::BM, BN = G::BN, VA = G::VA, VB = G::VB, STAGE = G::STAGE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, l5 = lane >> 5;
+    const int wm0 = (wave / WN) * (32 * MJ), wn0 = (wave % WN) * (32 * NI);
+
+    // global -> registers -> LDS: piece v = tid + NT s of an operand's stage image is 16 bytes of one row; the 8 pieces of a row
+    // (one 128-byte line) go to 8 consecutive lanes, which is also one conflict-free ds_write_b128 group (32 banks).
+    const uint32_t* pa[VA];
+    const uint32_t* pb[VB];
+    int wa[VA], wb[VB];
+#pragma unroll
+    for (int s = 0; s < VA; ++s) {
+        const int v = tid + NT * s, row = min(v >> 3, BM - 1);
+        pa[s] = a.X + (int64_t)min(m0 + row, a.M - 1) * a.ldx + 4 * (v & 7);          // rows past M: a valid row, never stored
+        wa[s] = row * SPROW + 16 * (v & 7);
+    }
+#pragma unroll
+    for (int s = 0; s < VB; ++s) {
+        const int v = tid + NT * s, row = min(v >> 3, BN - 1);
+        pb[s] = a.W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + 4 * (v & 7);
+        wb[s] = (BM + row) * SPROW + 16 * (v & 7);
+    }
+    constexpr bool TAIL_A = (BM * 8) % NT != 0, TAIL_B = (BN * 8) % NT != 0;
+    const bool last_a = !TAIL_A || tid + NT * (VA - 1) < BM * 8;
+    const bool last_b = !TAIL_B || tid + NT * (VB - 1) < BN * 8;
+
+    v4u ga[PF][VA], gb[PF][VB];
+    auto gload = [&](int it, auto rc) {
+        constexpr int R = decltype(rc)::value;
+        const int k0 = it * SPK;
+#pragma unroll
+        for (int s = 0; s < VA; ++s)
+            if (s + 1 < VA || last_a) ga[R][s] = *reinterpret_cast<const v4u*>(pa[s] + k0);
+#pragma unroll
+        for (int s = 0; s < VB; ++s)
+            if (s + 1 < VB || last_b) gb[R][s] = *reinterpret_cast<const v4u*>(pb[s] + k0);
+    };
+    auto lstore = [&](unsigned char* stage, auto rc) {
+        constexpr int R = decltype(rc)::value;
+#pragma unroll
+        for (int s = 0; s < VA; ++s)
+            if (s + 1 < VA || last_a) *reinterpret_cast<v4u*>(stage + wa[s]) = ga[R][s];
+#pragma unroll
+        for (int s = 0; s < VB; ++s)
+            if (s + 1 < VB || last_b) *reinterpret_cast<v4u*>(stage + wb[s]) = gb[R][s];
+    };
+
+    // fragments: lane (row l31, half l5) of k16-step t reads group 2 t + l5 of its row: hi at +0, lo at +16
+    const int fx_off = (wm0 + l31) * SPROW + 32 * l5;
+    const int fw_off = (BM + wn0 + l31) * SPROW + 32 * l5;
+    v8h xh[2][MJ], xl[2][MJ], wh[2][NI], wl[2][NI];
+    auto fread = [&](const unsigned char* stage, int t, int slot) {
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            xh[slot][j] = *reinterpret_cast<const v8h*>(stage + fx_off + j * 32 * SPROW + 64 * t);
+            xl[slot][j] = *reinterpret_cast<const v8h*>(stage + fx_off + j * 32 * SPROW + 64 * t + 16);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            wh[slot][i] = *reinterpret_cast<const v8h*>(stage + fw_off + i * 32 * SPROW + 64 * t);
+            wl[slot][i] = *reinterpret_cast<const v8h*>(stage + fw_off + i * 32 * SPROW + 64 * t + 16);
+        }
+    };
+    // the two small products first, then hi x hi; p selects the product so that the three MFMAs of one accumulator are a
+    // block apart in the issue order
+    auto mfmas = [&](int slot, int p_lo, int p_hi) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            if (p >= p_lo && p < p_hi)
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p == 0 ? wl[slot][i] : wh[slot][i],
+                                                                           p == 1 ? xl[slot][j] : xh[slot][j], acc[i][j], 0, 0, 0);
+    };
+
+    gload(0, SpIC<0>{});
+    lstore(smem, SpIC<0>{});
+    if (T > 1) gload(1, SpIC<1 % PF>{});
+    if constexpr (PF > 1) if (T > 2) gload(2, SpIC<2 % PF>{});
+    __syncthreads();
+    fread(smem, 0, 0);
+    auto body = [&](auto rc, int it) {
+        unsigned char* cur = smem + (it & 1) * STAGE;
+        unsigned char* oth = smem + ((it + 1) & 1) * STAGE;
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        fread(cur, 1, 1);                                   // second k16 step of this stage: lands under the MFMAs of the first
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0, 1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < T) lstore(oth, rc);                    // stage it+1 (loaded PF stages ago) -> the other buffer
+        __syncthreads();
+        if (it + 1 + PF < T) gload(it + 1 + PF, rc);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (it + 1 < T) fread(oth, 0, 0);                   // first k16 step of the next stage
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1, 1, 3);
+    };
+    for (int it0 = 0; it0 < T; it0 += PF) {
+        body(SpIC<1 % PF>{}, it0);
+        if constexpr (PF > 1) if (it0 + 1 < T) body(SpIC<2 % PF>{}, it0 + 1);
+    }
+}
+
+// Epilogue.  acc[i][j][4 q + e] = element (m, n): m = m0 + wm0 + 32 j + l31, n = n0 + wn0 + 32 i + 8 q + 4 l5 + e.
+template <int MJ, int NI, int WM, int WN>
+__device__ __forceinline__ void sp_finish(const SpArgs& a, int m0, int n0, v16f (&acc)[NI][MJ]) {
+    constexpr int BM = 32 * MJ * WM, BN = 32 * NI * WN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, l5 = lane >> 5;
+    const int wm0 = (wave / WN) * (32 * MJ), wn0 = (wave % WN) * (32 * NI);
+    const float* __restrict__ bias = a.bias;
+    const float* __restrict__ res = a.res;
+    const float* __restrict__ ws = a.ws;
+    float* __restrict__ Y = a.Y;
+    uint32_t* __restrict__ P = a.P;
+    const int M = a.M, N = a.N;
+    const int64_t ldr = a.ldr, ldy = a.ldy, ldp = a.ldp;
+    const bool vec_ok = (N & 3) == 0 && (Y == nullptr || ((ldy & 3) == 0 && sp_al16(Y))) &&
+                        (res == nullptr || ((ldr & 3) == 0 && sp_al16(res))) && (bias == nullptr || sp_al16(bias)) && sp_al16(ws);
+    const bool interior = m0 + BM <= M && n0 + BN <= N && vec_ok;
+    auto epilogue = [&](auto actfn) {
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            const int m = m0 + wm0 + 32 * j + l31;
+            const bool m_ok = m < M;
+            const float sx = a.xs[min(m, M - 1)];
+            const float sp = a.ps != nullptr ? a.ps[min(m, M - 1)] : 1.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int nb = n0 + wn0 + 32 * i + 4 * l5;
+                if (interior) {
+                    v4f rv[4];
+                    if (res != nullptr) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const v4f*>(res + (int64_t)m * ldr + nb + 8 * q);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = nb + 8 * q;
+                        const v4f w4 = *reinterpret_cast<const v4f*>(ws + n);
+                        v4f b4 = {0.f, 0.f, 0.f, 0.f};
+                        if (bias != nullptr) b4 = *reinterpret_cast<const v4f*>(bias + n);
+                        v4f v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = actfn(acc[i][j][4 * q + e] * (sx * w4[e]) + b4[e]);
+                            if (res != nullptr) v[e] += rv[q][e];
+                        }
+                        if (Y != nullptr) *reinterpret_cast<v4f*>(Y + (int64_t)m * ldy + n) = v;
+                        if (P != nullptr) {
+                            v4h h, l;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float t = v[e] * sp;
+                                h[e] = (_Float16)t;
+                                l[e] = (_Float16)(t - (float)h[e]);
+                            }
+                            unsigned char* dst = reinterpret_cast<unsigned char*>(P + (int64_t)m * ldp) + (n >> 3) * 32 + 8 * l5;
+                            *reinterpret_cast<v4h*>(dst) = h;
+                            *reinterpret_cast<v4h*>(dst + 16) = l;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int n = nb + 8 * q + e;
+                            if (m_ok && n < N) {
+                                float v = actfn(acc[i][j][4 * q + e] * (sx * ws[n]) + (bias != nullptr ? bias[n] : 0.f));
+                                if (res != nullptr) v += res[(int64_t)m * ldr + n];
+                                if (Y != nullptr) Y[(int64_t)m * ldy + n] = v;
+                                if (P != nullptr) {
+                                    const float t = v * sp;
+                                    const _Float16 h = (_Float16)t, l = (_Float16)(t - (float)h);
+                                    _Float16* dst = reinterpret_cast<_Float16*>(reinterpret_cast<unsigned char*>(P + (int64_t)m * ldp) +
+                                                                               (n >> 3) * 32) + (n & 7);
+                                    dst[0] = h;
+                                    dst[8] = l;
+                                }
+                            }
+                        }
+                }
+            }
+        }
+    };
+    if (a.act == SP_ACT_QUICK_GELU) epilogue([](float x) { return x / (1.0f + __expf(-1.702f * x)); });
+    else if (a.act == SP_ACT_GELU_ERF) epilogue([](float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); });
+    else epilogue([](float x) { return x; });
+}
+
+template <int MJ, int NI, int WM, int WN, int PF, int WPE>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void linear_sp16_kernel(SpArgs a) {
+    using G = SpGeom<MJ, NI, WM, WN, PF>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::SMEM];
+    // XCD x (workgroups go round-robin by linear id) takes the tiles [x per, (x + 1) per) of the super-row order
+    const int per = (a.tiles + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile >= a.tiles || (int)(blockIdx.x >> 3) >= per) return;
+    int bm, bn;
+    sp_tile_of(a, tile, bm, bn);
+    v16f acc[NI][MJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    sp_accumulate<MJ, NI, WM, WN, PF>(a, bm * G::BM, bn * G::BN, a.K / SPK, smem, acc);
+    sp_finish<MJ, NI, WM, WN>(a, bm * G::BM, bn * G::BN, acc);
+}
+
+// ---- fp32 rows -> planes ------------------------------------------------------------------------------------------------------
+// 2^e for a row whose largest magnitude is amax: amax 2^e in [2^14, 2^15) (e clamped to +-120; zero / subnormal rows get the
+// clamp, inf / nan rows propagate through hi).
+__device__ __forceinline__ void sp_scale_of(float amax, float& s, float& inv) {
+    int ex = (int)((__float_as_uint(amax) >> 23) & 0xff);
+    ex = ex == 0 ? 1 : (ex == 255 ? 254 : ex);
+    int e = 141 - ex;                                          // 14 - (ex - 127)
+    e = e > 120 ? 120 : (e < -120 ? -120 : e);
+    s = __uint_as_float((unsigned)(e + 127) << 23);
+    inv = __uint_as_float((unsigned)(127 - e) << 23);
+}
+
+__device__ __forceinline__ void sp_split8(const v4f& a, const v4f& b, float s, v4u& hi, v4u& lo) {
+    v8h h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float t = (e < 4 ? a[e] : b[e - 4]) * s;
+        h[e] = (_Float16)t;
+        l[e] = (_Float16)(t - (float)h[e]);
+    }
+    hi = *reinterpret_cast<v4u*>(&h);
+    lo = *reinterpret_cast<v4u*>(&l);
+}
+
+// one wave per row, four rows per workgroup; two passes over the row (the second one hits L2)
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ X, int64_t ldx, int rows, int K,
+                                                          uint32_t* __restrict__ P, int64_t ldp, float* __restrict__ inv_scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* x = X + row * ldx;
+    const int ng = K / 8;
+    float amax = 0.f;
+    for (int g = lane; g < ng; g += 64) {
+        const v4f a = *reinterpret_cast<const v4f*>(x + 8 * g), b = *reinterpret_cast<const v4f*>(x + 8 * g + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(a[e]), fabsf(b[e])));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    float s, inv;
+    sp_scale_of(amax, s, inv);
+    if (lane == 0) inv_scale[row] = inv;
+    uint32_t* p = P + row * ldp;
+    for (int g = lane; g < ng; g += 64) {
+        const v4f a = *reinterpret_cast<const v4f*>(x + 8 * g), b = *reinterpret_cast<const v4f*>(x + 8 * g + 4);
+        v4u hi, lo;
+        sp_split8(a, b, s, hi, lo);
+        *reinterpret_cast<v4u*>(p + 8 * g) = hi;
+        *reinterpret_cast<v4u*>(p + 8 * g + 4) = lo;
+    }
+}
+
+struct SpCfg { int bm, bn; };
+static const SpCfg kSpCfgs[] = {{128, 128}, {256, 128}, {64, 64}, {128, 256}};
+
+}  // namespace emcid
+
+using namespace emcid;
+
+extern "C" {
+
+int emcid_split_rows_f16(const float* X, int64_t ldx, int64_t rows, int64_t K, void* planes, int64_t ldp, float* inv_scale,
+                         void* stream) {
+    EMCID_CHECK_ARG(X && planes && inv_scale && rows > 0 && K > 0 && K % 8 == 0 && ldx >= K && ldp >= K);
+    EMCID_CHECK_ARG(ldx % 4 == 0 && ldp % 4 == 0 && aligned16(X) && aligned16(planes) && rows < (1LL << 31) && K < (1 << 24));
+    ScopedProf sp(KC_MISC, (hipStream_t)stream);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X, ldx, (int)rows,
+                       (int)K, (uint32_t*)planes, ldp, inv_scale);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale, const void* Wp, int64_t ldw,
+                          const float* w_inv_scale, const float* bias, const float* residual, int64_t ldr, float* Y, int64_t ldy,
+                          void* Yp, int64_t ldp, const float* y_scale, int64_t M, int64_t N, int64_t K, int act, int cfg,
+                          void* stream) {
+    EMCID_CHECK_ARG(Xp && Wp && x_inv_scale && w_inv_scale && (Y || Yp) && M > 0 && N > 0 && K > 0 && ldx >= K && ldw >= K);
+    EMCID_CHECK_ARG(K % SPK == 0 && ldx % 4 == 0 && ldw % 4 == 0 && aligned16(Xp) && aligned16(Wp));
+    EMCID_CHECK_ARG(M < (1 << 24) && N < (1 << 24) && K < (1 << 24) && (residual == nullptr || ldr >= N) && (Y == nullptr || ldy >= N));
+    EMCID_CHECK_ARG(Yp == nullptr || (N % 8 == 0 && ldp >= N && ldp % 4 == 0 && aligned16(Yp)));
+    EMCID_CHECK_ARG(act >= SP_ACT_NONE && act <= SP_ACT_GELU_ERF && cfg >= -1 && cfg < 64);
+    // cfg: bits 0-1 tile (0: 128 x 128 on 4 waves, 1: 256 x 128 on 8 waves, 2: 64 x 64 on 4 waves, 3: 128 x 256 on 8 waves),
+    // bits 2-3: prefetch distance - 1; -1: auto
+    int tile_sel = cfg < 0 ? -1 : (cfg & 3);
+    int pf = cfg < 0 ? 2 : ((cfg >> 2) & 3) + 1;
+    EMCID_CHECK_ARG(pf >= 1 && pf <= 2);
+    if (tile_sel < 0) {
+        const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
+        tile_sel = t128 >= 384 ? 0 : 2;
+    }
+    const int bm = kSpCfgs[tile_sel].bm, bn = kSpCfgs[tile_sel].bn;
+    const int tiles_m = (int)((M + bm - 1) / bm), tiles_n = (int)((N + bn - 1) / bn);
+    const int tiles = tiles_m * tiles_n;
+    const int per = (tiles + 7) / 8;
+    hipStream_t st = (hipStream_t)stream;
+    static const int rb_env = [] { const char* e = getenv("EMCID_SP16_RB"); return e ? atoi(e) : 4; }();
+    const int rb = rb_env >= 1 ? rb_env : 1;
+    const SpArgs a{(const uint32_t*)Xp, ldx, x_inv_scale, (const uint32_t*)Wp, ldw, w_inv_scale, bias, residual, ldr, Y, ldy,
+                   (uint32_t*)Yp, ldp, y_scale, (int)M, (int)N, (int)K, act, tiles_n, tiles, rb};
+    ScopedProf sp(KC_LINEAR, st);
+#define EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, PF_, WPE_)                                                                         \
+    hipLaunchKernelGGL((linear_sp16_kernel<MJ_, NI_, WM_, WN_, PF_, WPE_>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, \
+                       st, a)
+#define EMCID_SP_PF(MJ_, NI_, WM_, WN_, WPE_)                         \
+    do {                                                              \
+        if (pf == 1) EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 1, WPE_);    \
+        else EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 2, WPE_);            \
+    } while (0)
+    switch (tile_sel) {
+        case 0: EMCID_SP_PF(2, 2, 2, 2, 2); break;
+        case 1: EMCID_SP_PF(2, 2, 4, 2, 2); break;
+        case 2: EMCID_SP_PF(1, 1, 2, 2, 4); break;
+        default: EMCID_SP_PF(2, 2, 2, 4, 2); break;
+    }
+#undef EMCID_SP_PF
+#undef EMCID_SP_LAUNCH
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+}  // extern "C"

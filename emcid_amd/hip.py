@@ -30,11 +30,12 @@ EXPORTS = [
     "emcid_edit_lu_workspace_bytes", "emcid_edit_layer_lu_f64", "emcid_lu_solve_f64",
     "emcid_edit_dual_cols_stage1_f64", "emcid_edit_dual_s", "emcid_edit_dual_u", "emcid_edit_dual_cols_stage2_f64",
     "emcid_apply_update2d_f32", "emcid_linear_f32", "emcid_linear_ws_f32", "emcid_linear_workspace_bytes",
+    "emcid_split_rows_f16", "emcid_linear_sp16_f32",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block", "linear"]
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 NB = 128      # Cholesky block (csrc/common.h)
 NPAD = 64     # concept padding of the f64 stacks (csrc/common.h)
 
@@ -105,6 +106,8 @@ def load():
         "emcid_linear_f32": (i32, [p, i64, p, i64, p, p, i64, p, i64, i64, i64, i64, i32, i32, p]),
         "emcid_linear_ws_f32": (i32, [p, i64, p, i64, p, p, i64, p, i64, i64, i64, i64, i32, i32, p, i64, p]),
         "emcid_linear_workspace_bytes": (i64, []),
+        "emcid_split_rows_f16": (i32, [p, i64, i64, i64, p, i64, p, p]),
+        "emcid_linear_sp16_f32": (i32, [p, i64, p, p, i64, p, p, p, i64, p, i64, p, i64, p, i64, i64, i64, i32, i32, p]),
         "emcid_add_layernorm_f32": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p]),
         "emcid_embed_layernorm_f32": (i32, [p, i64, i64, p, i64, i64, p, p, p, p, C.c_float, i64, i64, p, p, p]),
         "emcid_tree_attention_f32": (i32, [p, i64, p, p, i64, p, i64, p, p, i64, i64, i64, f32, p, i64, p]),
@@ -532,6 +535,90 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
                                       C.c_void_p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0,
                                       _stream(x)), "emcid_linear_ws_f32")
     return out
+
+
+class SplitRows:
+    """An fp32 matrix (rows, K) as two fp16 planes under per-row power-of-two scales (include/emcid_hip.h, "split fp16"):
+    ``planes`` int32 (rows, K) — one 4-byte unit per element, [hi x 8][lo x 8] per group of 8 k —, ``inv_scale`` fp32 (rows,)."""
+    __slots__ = ("planes", "inv_scale")
+
+    def __init__(self, planes: torch.Tensor, inv_scale: torch.Tensor):
+        self.planes, self.inv_scale = planes, inv_scale
+
+    @property
+    def shape(self):
+        return self.planes.shape
+
+    def index_select(self, idx: torch.Tensor) -> "SplitRows":
+        return SplitRows(self.planes.index_select(0, idx), self.inv_scale.index_select(0, idx))
+
+    def rows(self, lo: int, hi: int) -> "SplitRows":
+        return SplitRows(self.planes[lo:hi], self.inv_scale[lo:hi])
+
+    def float(self) -> torch.Tensor:
+        """Back to fp32 (tests): (hi + lo) * 2^-e."""
+        r, k = self.planes.shape
+        h = self.planes.contiguous().view(torch.float16).view(r, k // 8, 2, 8).float()
+        return ((h[:, :, 0] + h[:, :, 1]).reshape(r, k)) * self.inv_scale[:, None]
+
+
+def split_supported(x: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] % 32 == 0 and x.stride(1) == 1
+            and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and x.shape[0] > 0)
+
+
+def split_rows(x: torch.Tensor) -> SplitRows:
+    """fp32 rows -> split fp16 planes (csrc/gemm_sp16.hip: split_rows_kernel)."""
+    if not split_supported(x):
+        raise EmcidHipError("split_rows: fp32 HBM rows with K contiguous, K % 32 == 0 and 16-byte aligned rows")
+    rows, K = x.shape
+    planes = torch.empty(rows, K, dtype=torch.int32, device=x.device)
+    inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _check(load().emcid_split_rows_f16(_ptr(x, torch.float32, "x"), x.stride(0), rows, K, _ptr(planes), planes.stride(0), _ptr(inv),
+                                       _stream(x)), "emcid_split_rows_f16")
+    return SplitRows(planes, inv)
+
+
+def linear_sp(x: SplitRows, w: SplitRows, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+              residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, want_f32: bool = True,
+              planes_scale: Optional[torch.Tensor] = None, cfg: int = -1):
+    """act(x @ w.T + bias) + residual with both operands given as split fp16 matrices (three f16 MFMAs per k-step, fp32
+    accumulate).  Returns the fp32 result, or — with ``planes_scale`` (per-row 2^e, a bound on the result rows) — a pair
+    (fp32 result | None, SplitRows of the result)."""
+    M, K = x.planes.shape
+    N = w.planes.shape[0]
+    if w.planes.shape[1] != K or K % 32:
+        raise EmcidHipError("linear_sp: operands (M, K) and (N, K) with K % 32 == 0")
+    for t in (x.planes, w.planes):
+        if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16 or t.dtype != torch.int32:
+            raise EmcidHipError("linear_sp: planes must be int32 row views with 16-byte aligned rows")
+    dev = x.planes.device
+    y = None
+    if want_f32 or planes_scale is None:
+        y = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=dev)
+        if y.shape != (M, N) or y.stride(1) != 1 or y.dtype != torch.float32:
+            raise EmcidHipError("linear_sp: out must be an (M, N) fp32 row view")
+    yp = None
+    if planes_scale is not None:
+        if N % 32 or planes_scale.shape != (M,) or not planes_scale.is_contiguous():
+            raise EmcidHipError("linear_sp: planes output needs N % 32 == 0 and a contiguous (M,) scale")
+        yp = torch.empty(M, N, dtype=torch.int32, device=dev)
+    if bias is not None and (bias.shape != (N,) or not bias.is_contiguous()):
+        raise EmcidHipError("linear_sp: bias must be a contiguous (N,) vector")
+    if residual is not None and (residual.shape != (M, N) or residual.stride(1) != 1):
+        raise EmcidHipError("linear_sp: residual must be an (M, N) row view")
+    if LINEAR_FLOPS["count"]:
+        LINEAR_FLOPS["flops"] += 2.0 * M * N * K
+        LINEAR_FLOPS["launches"] += 1
+    _check(load().emcid_linear_sp16_f32(
+        _ptr(x.planes), x.planes.stride(0), _ptr(x.inv_scale, torch.float32, "x scale"), _ptr(w.planes), w.planes.stride(0),
+        _ptr(w.inv_scale, torch.float32, "w scale"), _ptr(bias, torch.float32, "bias"), _ptr(residual, torch.float32, "residual"),
+        residual.stride(0) if residual is not None else 0, _ptr(y), y.stride(0) if y is not None else 0, _ptr(yp),
+        yp.stride(0) if yp is not None else 0, _ptr(planes_scale, torch.float32, "planes scale"), M, N, K, int(act), int(cfg),
+        _stream(x.planes)), "emcid_linear_sp16_f32")
+    if planes_scale is None:
+        return y
+    return y, SplitRows(yp, 1.0 / planes_scale)
 
 
 def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], ln: torch.nn.LayerNorm, want_sum: bool = True):

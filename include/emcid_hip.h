@@ -28,7 +28,7 @@ extern "C" {
 #define EMCID_ERR_HIP (-2)
 #define EMCID_ERR_WORKSPACE (-3)
 
-#define EMCID_ABI_VERSION 10
+#define EMCID_ABI_VERSION 11
 
 /* ABI version of the loaded library (host-only, no GPU needed). */
 int emcid_abi_version(void);
@@ -114,6 +114,27 @@ int64_t emcid_linear_workspace_bytes(void);
 int emcid_linear_ws_f32(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, const float* residual,
                         int64_t ldr, float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K, int act, int cfg, void* workspace,
                         int64_t workspace_bytes, void* stream);
+
+/* ---- the same projections at fp32 accuracy on the 16-bit matrix pipe ("split fp16", csrc/gemm_sp16.hip) ------------------------
+ * A split matrix stands for an fp32 matrix [rows, K] (K % 8 == 0): every row r is carried under a power-of-two scale 2^e_r (the
+ * row's largest magnitude lands in [2^14, 2^15)) as hi = fp16(x 2^e), lo = fp16(x 2^e - hi), i.e. x = (hi + lo) 2^-e to 22-23
+ * significant bits.  `planes`: one 4-byte unit per element like the fp32 matrix (leading dimension ldp in those units, % 4 == 0);
+ * inside a row, groups of 8 consecutive k as [hi k..k+7 (16 bytes)][lo k..k+7 (16 bytes)].  `inv_scale[r]` = 2^-e_r.
+ * emcid_split_rows_f16 converts fp32 rows (nn.Linear weights once per weight version, activations once per producer). */
+int emcid_split_rows_f16(const float* X, int64_t ldx, int64_t rows, int64_t K, void* planes, int64_t ldp, float* inv_scale,
+                         void* stream);
+
+/* Y[M,N] = act(X W^T + bias) + residual like emcid_linear_f32 (the same nn.Linear calls of CLIPTextModel.forward,
+ * emcid/compute_z.py:2296-2316), with X [M,K] and W [N,K] given as split matrices: three v_mfma_f32_32x32x16_f16 per k-step
+ * (hi.hi + hi.lo + lo.hi, fp32 accumulate; the dropped lo.lo term is <= 2^-22 of a product), scales undone exactly in the
+ * epilogue.  K % 32 == 0.  Outputs: Y fp32 (may be NULL) and / or Yp = the result as a split matrix for the next projection,
+ * under the CALLER's per-row scale y_scale[m] = 2^e (a bound on the row's magnitude is enough: |Y[m][n]| y_scale[m] < 2^15
+ * must hold; NULL = 1); N % 8 == 0 for Yp.  cfg: -1 auto; bits 0-1 tile (0: 128 x 128, 1: 256 x 128 (M x N), 2: 64 x 64,
+ * 3: 128 x 256), bits 2-3 prefetch distance - 1. */
+int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale, const void* Wp, int64_t ldw,
+                          const float* w_inv_scale, const float* bias, const float* residual, int64_t ldr, float* Y, int64_t ldy,
+                          void* Yp, int64_t ldp, const float* y_scale, int64_t M, int64_t N, int64_t K, int act, int cfg,
+                          void* stream);
 
 /* y = a + b ; z = LayerNorm(y) * gamma + beta over the last dimension (biased variance, eps inside the root, as
  * torch.nn.LayerNorm) — the residual add and the LayerNorm after it of every block of the same hooked forward, one

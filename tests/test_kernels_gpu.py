@@ -675,3 +675,82 @@ def test_linear_f32_rejects_unsupported_operands():
     with pytest.raises(hip.EmcidHipError):
         hip.linear(x, w)
     assert not hip.linear_supported(torch.randn(8, 32, device=DEV).double(), torch.randn(4, 32, device=DEV).double())
+
+
+# ---- split-fp16 projections (csrc/gemm_sp16.hip) ----------------------------------------------------------------------------------
+
+def test_split_rows_keeps_22_bits_under_a_per_row_scale():
+    """emcid_split_rows_f16: x = (hi + lo) 2^-e with the row's largest magnitude in [2^14, 2^15) before the fp16 rounding; rows
+    spanning 60 binades between them, zero rows, tiny and large elements inside a row."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(300, 768, generator=g)
+    x *= torch.exp2(torch.randint(-30, 30, (300, 1), generator=g).float())       # rows on very different scales
+    x[:, ::7] *= 1e-4                                                              # small elements inside a row
+    x[17] = 0.0
+    x[18, 5:] = 0.0
+    xd = x.to(DEV)
+    sp = hip.split_rows(xd)
+    back = sp.float().cpu()
+    amax = x.abs().amax(1, keepdim=True)
+    # element-wise: 2^-22 of the element, or 2^-38 of the row's maximum where lo has left the fp16 normal range
+    tol = torch.maximum(x.abs() * 2.0 ** -22, amax * 2.0 ** -38)
+    assert bool(((back - x).abs() <= tol).all())
+    inv = sp.inv_scale.cpu()
+    live = amax[:, 0] > 0
+    top = amax[live, 0] / inv[live]
+    assert bool((top >= 2.0 ** 14).all()) and bool((top < 2.0 ** 15).all())
+    assert bool((torch.log2(inv) == torch.log2(inv).round()).all())             # powers of two
+    assert bool((back[17] == 0).all())
+    # a strided row view
+    wide = torch.randn(64, 136, generator=g).to(DEV)
+    sp2 = hip.split_rows(wide[:, :128])
+    assert (sp2.float() - wide[:, :128]).abs().max().item() <= wide.abs().max().item() * 2.0 ** -21
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 4, 1, 5, 2, 6, 3, 7])
+@pytest.mark.parametrize("M,K,N", [(6400, 768, 2304), (6400, 3072, 768), (1000, 3072, 768), (640, 768, 3072), (300, 1280, 1280),
+                                   (129, 96, 257), (37, 2048, 200), (256, 32, 32)])
+def test_linear_sp16_vs_torch(M, K, N, cfg):
+    """emcid_linear_sp16_f32 against the fp64 product at the UNCHANGED tolerance of the exact-f32 kernel's test
+    (test_linear_f32_vs_torch): every tile form, ragged edges, the fused epilogues, the split-fp16 output for the next
+    projection."""
+    if cfg >= 0 and M * N * K > 6400 * 768 * 2304 // 2 and (cfg & 3) == 2:
+        pytest.skip("64 x 64 tiles on the large shapes: covered by the smaller ones")
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K + 4, generator=g).to(DEV)[:, :K]
+    w = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    r = torch.randn(M, N, generator=g).to(DEV)
+    ref = F.linear(x.double(), w.double(), b.double())
+    scale = ref.abs().max().item()
+    tol = 3e-6 * scale * max(1.0, (K / 768) ** 0.5) + 1e-6
+    xs, ws_ = hip.split_rows(x), hip.split_rows(w)
+    y = hip.linear_sp(xs, ws_, b, cfg=cfg)
+    assert (y.double() - ref).abs().max().item() <= tol
+    assert (y - F.linear(x, w, b)).abs().max().item() <= 2 * tol
+    assert torch.equal(hip.linear_sp(xs, ws_, b, cfg=cfg), y)                   # the same bits call after call
+    y0 = hip.linear_sp(xs, ws_, None, cfg=cfg)
+    assert (y0.double() - F.linear(x.double(), w.double())).abs().max().item() <= tol
+    yq = hip.linear_sp(xs, ws_, b, act=hip.ACT_QUICK_GELU, cfg=cfg)
+    torch.testing.assert_close(yq, (ref * torch.sigmoid(1.702 * ref)).float(), rtol=2e-6, atol=tol)
+    ye = hip.linear_sp(xs, ws_, b, act=hip.ACT_GELU_ERF, cfg=cfg)
+    torch.testing.assert_close(ye, F.gelu(ref).float(), rtol=2e-6, atol=tol)
+    yr = hip.linear_sp(xs, ws_, b, residual=r, cfg=cfg)
+    torch.testing.assert_close(yr, (ref + r.double()).float(), rtol=0, atol=tol)
+    rr = r.clone()
+    hip.linear_sp(xs, ws_, b, residual=rr, out=rr, cfg=cfg)                      # in place on the residual stream
+    assert torch.equal(rr, yr)
+    wide = torch.full((M, N + 8), 7.0, device=DEV)
+    hip.linear_sp(xs, ws_, b, out=wide[:, :N], cfg=cfg)
+    assert torch.equal(wide[:, :N], y) and bool((wide[:, N:] == 7.0).all())
+    if N % 32 == 0:
+        # the result as a split matrix under a caller-given bound: the Cauchy-Schwarz bound the forward uses
+        bound = x.norm(dim=1) * w.norm(dim=1).max() + b.abs().max()
+        ps = torch.exp2(14 - torch.ceil(torch.log2(bound)))
+        yf, yp = hip.linear_sp(xs, ws_, b, act=hip.ACT_QUICK_GELU, planes_scale=ps, cfg=cfg)
+        assert torch.equal(yf, yq)
+        back = yp.float()
+        # 2^-22 of the element, or the fp16 floor under the bound's scale
+        assert bool(((back - yq).abs() <= torch.maximum(yq.abs() * 2.0 ** -21, (2.0 ** -24 / ps)[:, None])).all())
+        _, yp2 = hip.linear_sp(xs, ws_, b, act=hip.ACT_QUICK_GELU, planes_scale=ps, want_f32=False, cfg=cfg)
+        assert torch.equal(yp2.planes, yp.planes)
