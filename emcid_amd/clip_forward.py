@@ -35,19 +35,42 @@ class UnsupportedEncoder(Exception):
 
 
 OWN_GEMM = os.environ.get("EMCID_OWN_GEMM", "1") != "0"     # 0: torch's F.linear (hipBLASLt) + separate element-wise passes
+# 1 (default): the projections run on the split-fp16 kernel (csrc/gemm_sp16.hip: fp32 operands as hi + lo fp16 planes, three f16
+# MFMAs per k-step, fp32 accumulate — fp32-level accuracy at 3/16 of the f32-MFMA issue time); 0: the exact-f32 MFMA kernel
+SPLIT_GEMM = os.environ.get("EMCID_SPLIT_GEMM", "1") != "0"
+LAST_PATHS = {"linear_sp16": 0, "linear_f32": 0, "linear_torch": 0}     # which GEMM path the projections of this process took
 
 
-def linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None, act=None, act_code: Optional[int] = None,
-           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """act(x @ w.T + b) + residual for the row-wise projections of the forward.  On the library's own fp32-MFMA GEMM
-    (csrc/gemm_f32.hip) with bias / activation / residual add in its epilogue whenever the operands allow it (fp32, HBM,
-    K % 16 == 0); otherwise — and under EMCID_OWN_GEMM=0 — torch's F.linear and separate passes."""
+def split_ok(w: torch.Tensor) -> bool:
+    return SPLIT_GEMM and OWN_GEMM and hip.split_supported(w)
+
+
+def linear(x, w: torch.Tensor, b: Optional[torch.Tensor] = None, act=None, act_code: Optional[int] = None,
+           residual: Optional[torch.Tensor] = None, wsp: Optional["hip.SplitRows"] = None,
+           planes_scale: Optional[torch.Tensor] = None, want_f32: bool = True):
+    """act(x @ w.T + b) + residual for the row-wise projections of the forward.  ``wsp`` (the weight as a split-fp16 matrix,
+    ``ClipLayer.split_of``): the split-fp16 kernel (csrc/gemm_sp16.hip), x an fp32 row matrix (split here) or already a
+    ``hip.SplitRows``; ``planes_scale`` additionally asks for the result as a SplitRows for the next projection (returns a pair).
+    Otherwise the library's exact-f32 MFMA GEMM (csrc/gemm_f32.hip) with bias / activation / residual add in its epilogue
+    whenever the operands allow it (fp32, HBM, K % 16 == 0); otherwise — and under EMCID_OWN_GEMM=0 — torch's F.linear and
+    separate passes."""
+    fusable = (b is None or b.is_contiguous()) and (act is None or act_code is not None) and \
+        (residual is None or (residual.stride(1) == 1 and residual.dtype == torch.float32))
+    if wsp is not None and fusable and (isinstance(x, hip.SplitRows) or hip.split_supported(x)):
+        xs = x if isinstance(x, hip.SplitRows) else hip.split_rows(x)
+        LAST_PATHS["linear_sp16"] += 1
+        return hip.linear_sp(xs, wsp, b, act=act_code if act is not None else hip.ACT_NONE, residual=residual,
+                             planes_scale=planes_scale, want_f32=want_f32)
+    if isinstance(x, hip.SplitRows):
+        x = x.float()
     if OWN_GEMM and hip.linear_supported(x, w) and (b is None or b.is_contiguous()) and \
             (residual is None or (residual.stride(1) == 1 and residual.dtype == torch.float32)):
+        LAST_PATHS["linear_f32"] += 1
         if act is None or act_code is not None:
             return hip.linear(x, w, b, act=act_code if act is not None else hip.ACT_NONE, residual=residual)
         y = act(hip.linear(x, w, b))
         return y if residual is None else residual + y
+    LAST_PATHS["linear_torch"] += 1
     y = F.linear(x, w, b)
     if act is not None:
         y = act(y)
@@ -77,6 +100,7 @@ class ClipLayer:
     qkv_w: Optional[torch.Tensor] = None   # [3h, h] rows of q, k, v stacked: one projection GEMM instead of three
     qkv_b: Optional[torch.Tensor] = None
     act_code: Optional[int] = None         # hip.ACT_* when the activation can ride in the fc1 GEMM's epilogue
+    splits: Optional[dict] = None          # name -> (weight id, version, data_ptr, hip.SplitRows): the weights as split-fp16 planes
 
     def fuse_qkv(self):
         """Snapshot q/k/v into one stacked weight (they are never edited by this path; call again if they change)."""
@@ -84,6 +108,27 @@ class ClipLayer:
             self.qkv_w = torch.cat([self.q.weight, self.k.weight, self.v.weight], 0).contiguous()
             if self.q.bias is not None and self.k.bias is not None and self.v.bias is not None:
                 self.qkv_b = torch.cat([self.q.bias, self.k.bias, self.v.bias], 0).contiguous()
+        if self.splits is not None:
+            self.splits.pop("qkv", None)
+
+    def split_of(self, name: str) -> Optional["hip.SplitRows"]:
+        """The weight ``name`` (qkv | q | k | v | out | fc1 | fc2) as a split-fp16 matrix, made once per weight version: the
+        cache entry is checked against the tensor's identity, in-place version counter and address (code that writes a
+        weight through its raw pointer — the edit engine — bumps the counter, ``edit_engine._touch``).  None: the split
+        kernel does not take this weight (EMCID_SPLIT_GEMM=0, K % 32, not fp32 in HBM)."""
+        w = self.qkv_w if name == "qkv" else getattr(self, name).weight
+        if w is None or not split_ok(w):
+            return None
+        if self.splits is None:
+            self.splits = {}
+        sig = (id(w), w._version, w.data_ptr())
+        hit = self.splits.get(name)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        with torch.no_grad():
+            sp = hip.split_rows(w.detach())
+        self.splits[name] = (sig, sp)
+        return sp
 
 
 @dataclass
@@ -472,7 +517,7 @@ def layer_attention_block(layer: ClipLayer, hs: torch.Tensor, trie: TokenTrie, r
     x = layer.ln1(hs) if x_ln1 is None else x_ln1
     if rows is None and layer.qkv_w is not None:
         hdim = layer.q.out_features
-        qkv = linear(x, layer.qkv_w, layer.qkv_b)            # (U, 3h): q | k | v as strided row views
+        qkv = linear(x, layer.qkv_w, layer.qkv_b, wsp=layer.split_of("qkv"))     # (U, 3h): q | k | v as strided row views
         ctx = hip.tree_attention(qkv[:, :hdim], qkv[:, hdim:2 * hdim], qkv[:, 2 * hdim:], trie.anc, trie.depth, layer.heads,
                                  layer.scale, None)
         res = hs
@@ -480,23 +525,28 @@ def layer_attention_block(layer: ClipLayer, hs: torch.Tensor, trie: TokenTrie, r
         if layer.qkv_w is not None:
             # every node's k | v in ONE projection (the stacked weight's k and v rows), q for the query rows only
             hdim = layer.q.out_features
-            kv = linear(x, layer.qkv_w[hdim:], layer.qkv_b[hdim:] if layer.qkv_b is not None else None)
+            sp = layer.split_of("qkv")
+            if sp is not None and not isinstance(x, hip.SplitRows) and hip.split_supported(x):
+                x = hip.split_rows(x)              # once for both projections below
+            kv = linear(x, layer.qkv_w[hdim:], layer.qkv_b[hdim:] if layer.qkv_b is not None else None,
+                        wsp=sp.rows(hdim, 3 * hdim) if sp is not None else None)
             k, v = kv[:, :hdim], kv[:, hdim:]
             qw, qb = layer.qkv_w[:hdim], (layer.qkv_b[:hdim] if layer.qkv_b is not None else None)
+            qsp = sp.rows(0, hdim) if sp is not None else None
         else:
-            k = linear(x, layer.k.weight, layer.k.bias)
-            v = linear(x, layer.v.weight, layer.v.bias)
-            qw, qb = layer.q.weight, layer.q.bias
+            k = linear(x, layer.k.weight, layer.k.bias, wsp=layer.split_of("k"))
+            v = linear(x, layer.v.weight, layer.v.bias, wsp=layer.split_of("v"))
+            qw, qb, qsp = layer.q.weight, layer.q.bias, layer.split_of("q")
         if rows is None:
-            q = linear(x, qw, qb)
+            q = linear(x, qw, qb, wsp=qsp)
             res = hs
         else:
             idx = rows.long()
-            q = linear(x.index_select(0, idx), qw, qb)
+            q = linear(x.index_select(idx) if isinstance(x, hip.SplitRows) else x.index_select(0, idx), qw, qb, wsp=qsp)
             res = hs.index_select(0, idx)
         ctx = hip.tree_attention(q, k, v, trie.anc, trie.depth, layer.heads, layer.scale, rows)
     if OWN_GEMM:
-        mid = linear(ctx, layer.out.weight, layer.out.bias, residual=res)     # residual add in the GEMM's epilogue
+        mid = linear(ctx, layer.out.weight, layer.out.bias, residual=res, wsp=layer.split_of("out"))     # residual add in the GEMM's epilogue
         return mid, norm_of(mid, layer.ln2)
     o = layer.out(ctx)
     if _fusable(layer.ln2):
@@ -507,7 +557,7 @@ def layer_attention_block(layer: ClipLayer, hs: torch.Tensor, trie: TokenTrie, r
 
 def mlp_hidden(layer: ClipLayer, ln2_mid: torch.Tensor) -> torch.Tensor:
     """fc2 INPUT (the "key" space): act(fc1(LN2(hs_mid)))."""
-    return linear(ln2_mid, layer.fc1.weight, layer.fc1.bias, act=layer.act, act_code=layer.act_code)
+    return linear(ln2_mid, layer.fc1.weight, layer.fc1.bias, act=layer.act, act_code=layer.act_code, wsp=layer.split_of("fc1"))
 
 
 def run_layers(graph: ClipTextGraph, trie: TokenTrie, upto: int, on_fc2=None, last_rows_only: bool = True,
@@ -549,7 +599,7 @@ def _layer_full(graph, i, trie, hs, x_ln1, n_layers_needed):
     mid, ln2_mid = layer_attention_block(layer, hs, trie, None, x_ln1)
     nxt = graph.layers[i + 1].ln1 if i + 1 < len(graph.layers) and i + 1 <= n_layers_needed else None
     if OWN_GEMM:
-        hs = linear(mlp_hidden(layer, ln2_mid), layer.fc2.weight, layer.fc2.bias, residual=mid)     # fc2 + residual add
+        hs = linear(mlp_hidden(layer, ln2_mid), layer.fc2.weight, layer.fc2.bias, residual=mid, wsp=layer.split_of("fc2"))     # fc2 + residual add
         return hs, (norm_of(hs, nxt) if nxt is not None and _fusable(nxt) else None)
     out = layer.fc2(mlp_hidden(layer, ln2_mid))
     if nxt is not None and _fusable(nxt):
@@ -587,7 +637,8 @@ def run_layers_multi(graph: ClipTextGraph, tries: Sequence[TokenTrie], states, s
             if i in by_cb or not OWN_GEMM:
                 outs = [None if i in by_cb else layer.fc2(x) for x in xs]
             else:
-                outs = [linear(x, layer.fc2.weight, layer.fc2.bias, residual=mid) for x, mid in zip(xs, mids)]
+                fsp = layer.split_of("fc2")
+                outs = [linear(x, layer.fc2.weight, layer.fc2.bias, residual=mid, wsp=fsp) for x, mid in zip(xs, mids)]
                 summed = True
             if on_fc2 is not None:
                 if callback_adds_residual and not summed:

@@ -405,6 +405,12 @@ def _all_gather_rows(local: torch.Tensor, plan: EncoderEditPlan) -> torch.Tensor
     return torch.cat([out[r * nmax:r * nmax + s] for r, s in enumerate(sizes)], dim=0)
 
 
+def _touch(w: torch.Tensor):
+    """The kernels write an edited weight through its raw pointer, which torch's in-place version counter does not see; caches
+    keyed by (tensor, version) — the split-fp16 copies of the weights, clip_forward.ClipLayer.split_of — must."""
+    torch.autograd.graph.increment_version(w)
+
+
 def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: bool = False,
                      restore: bool = False) -> List[LayerEdit]:
     """Device-only Stage 2 for one encoder.  On return the edited fc2 weights hold W0 + dW (``restore=False``)
@@ -499,6 +505,12 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
     def solve(i, layer, K_local, Zc_local):
         """All-gather the shard's K/Zc rows, run the closed form, leave W0 + dW in the live weight.  ``Zc_local`` may be
         a callable K -> Zc (fc2 applied to the gathered keys): then only K crosses the links."""
+        try:
+            _solve(i, layer, K_local, Zc_local)
+        finally:
+            _touch(weights[layer])
+
+    def _solve(i, layer, K_local, Zc_local):
         K = _all_gather_rows(K_local, plan)
         Zc = Zc_local(K) if callable(Zc_local) else _all_gather_rows(Zc_local, plan)
         plan.resolve_targets()
@@ -605,9 +617,10 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                 solve(order[li], li, K_loc, lambda K_all: lin(K_all, m.weight, m.bias))
             if li == last:
                 return None
+            wsp = plan.graph.layers[li].split_of("fc2")          # of the NEW weight (solve() bumped its version counter)
             if mids is None:
-                return [lin(x, m.weight, m.bias) for x in xs]
-            return [lin(x, m.weight, m.bias, residual=mid) for x, mid in zip(xs, mids)]
+                return [lin(x, m.weight, m.bias, wsp=wsp) for x in xs]
+            return [lin(x, m.weight, m.bias, residual=mid, wsp=wsp) for x, mid in zip(xs, mids)]
 
         with torch.no_grad():
             # the unedited leading layers: already launched by prepare (underneath the host's tokenization), else here
