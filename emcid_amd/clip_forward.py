@@ -50,7 +50,8 @@ def linear(x, w: torch.Tensor, b: Optional[torch.Tensor] = None, act=None, act_c
            planes_scale: Optional[torch.Tensor] = None, want_f32: bool = True):
     """act(x @ w.T + b) + residual for the row-wise projections of the forward.  ``wsp`` (the weight as a split-fp16 matrix,
     ``ClipLayer.split_of``): the split-fp16 kernel (csrc/gemm_sp16.hip), x an fp32 row matrix (split here) or already a
-    ``hip.SplitRows``; ``planes_scale`` additionally asks for the result as a SplitRows for the next projection (returns a pair).
+    ``hip.SplitRows``; ``planes_scale`` asks for the result as a SplitRows for the next projection (with its fp32 twin
+    unless ``want_f32=False``).
     Otherwise the library's exact-f32 MFMA GEMM (csrc/gemm_f32.hip) with bias / activation / residual add in its epilogue
     whenever the operands allow it (fp32, HBM, K % 16 == 0); otherwise — and under EMCID_OWN_GEMM=0 — torch's F.linear and
     separate passes."""
@@ -77,11 +78,19 @@ def linear(x, w: torch.Tensor, b: Optional[torch.Tensor] = None, act=None, act_c
     return y if residual is None else residual + y
 
 
-def norm_of(x: torch.Tensor, ln) -> torch.Tensor:
-    """LayerNorm(x) on the library's kernel when it fits, else the module itself."""
+def norm_of(x: torch.Tensor, ln, wsp: Optional["hip.SplitRows"] = None, want_f32: bool = False, scale_output: bool = False):
+    """LayerNorm(x) on the library's kernel when it fits, else the module itself.  ``wsp`` (the split weight of the projection
+    that consumes the result): the result as a ``hip.SplitRows`` written by the LayerNorm kernel itself (``scale_output``: with
+    the per-row scale under which that projection may write its own output as planes)."""
     if _fusable(ln) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1:
+        if wsp is not None and _sp_ln_ok(ln):
+            return hip.add_layernorm_sp(x, None, ln, want_f32=want_f32, bound=wsp.bound if scale_output else None)[1]
         return hip.add_layernorm(x, None, ln)[1]
     return ln(x)
+
+
+def _sp_ln_ok(ln) -> bool:
+    return ln.normalized_shape[0] % 32 == 0 and ln.normalized_shape[0] <= 2048
 
 
 @dataclass
@@ -125,8 +134,9 @@ class ClipLayer:
         hit = self.splits.get(name)
         if hit is not None and hit[0] == sig:
             return hit[1]
+        b = self.qkv_b if name == "qkv" else getattr(self, name).bias
         with torch.no_grad():
-            sp = hip.split_rows(w.detach())
+            sp = hip.split_rows(w.detach(), b if b is not None and b.is_contiguous() else None, want_bound=True)
         self.splits[name] = (sig, sp)
         return sp
 
@@ -511,21 +521,29 @@ def _fusable(ln) -> bool:
 
 
 def layer_attention_block(layer: ClipLayer, hs: torch.Tensor, trie: TokenTrie, rows: Optional[torch.Tensor],
-                          x_ln1: Optional[torch.Tensor] = None):
+                          x_ln1=None, want_f32: bool = False):
     """hs (U, h) -> (residual stream after the attention block, LN2 of it), for every node (rows None) or the query
-    rows only.  ``x_ln1``: LN1(hs) when the previous layer's residual add already produced it."""
-    x = layer.ln1(hs) if x_ln1 is None else x_ln1
+    rows only.  ``x_ln1``: LN1(hs) when the previous layer's residual add already produced it (fp32, or a ``hip.SplitRows``
+    on the split-fp16 path).  On that path LN2's result is a SplitRows as well (``want_f32``: with its fp32 twin), carrying the
+    scale for fc1's split output."""
+    qkv_sp = layer.split_of("qkv") if layer.qkv_w is not None else None
+    if x_ln1 is None:
+        x = norm_of(hs, layer.ln1, qkv_sp) if qkv_sp is not None else layer.ln1(hs)
+    else:
+        x = x_ln1
+    out_sp = layer.split_of("out")
+    hdim = layer.q.out_features
+    ctx_sp = out_sp is not None and hip.tree_attention_sp_supported(trie.anc, layer.heads, hdim // layer.heads)
+    attn = hip.tree_attention_sp if ctx_sp else hip.tree_attention
     if rows is None and layer.qkv_w is not None:
-        hdim = layer.q.out_features
-        qkv = linear(x, layer.qkv_w, layer.qkv_b, wsp=layer.split_of("qkv"))     # (U, 3h): q | k | v as strided row views
-        ctx = hip.tree_attention(qkv[:, :hdim], qkv[:, hdim:2 * hdim], qkv[:, 2 * hdim:], trie.anc, trie.depth, layer.heads,
-                                 layer.scale, None)
+        qkv = linear(x, layer.qkv_w, layer.qkv_b, wsp=qkv_sp)     # (U, 3h): q | k | v as strided row views
+        ctx = attn(qkv[:, :hdim], qkv[:, hdim:2 * hdim], qkv[:, 2 * hdim:], trie.anc, trie.depth, layer.heads,
+                   layer.scale, None)
         res = hs
     else:
         if layer.qkv_w is not None:
             # every node's k | v in ONE projection (the stacked weight's k and v rows), q for the query rows only
-            hdim = layer.q.out_features
-            sp = layer.split_of("qkv")
+            sp = qkv_sp
             if sp is not None and not isinstance(x, hip.SplitRows) and hip.split_supported(x):
                 x = hip.split_rows(x)              # once for both projections below
             kv = linear(x, layer.qkv_w[hdim:], layer.qkv_b[hdim:] if layer.qkv_b is not None else None,
@@ -544,10 +562,12 @@ def layer_attention_block(layer: ClipLayer, hs: torch.Tensor, trie: TokenTrie, r
             idx = rows.long()
             q = linear(x.index_select(idx) if isinstance(x, hip.SplitRows) else x.index_select(0, idx), qw, qb, wsp=qsp)
             res = hs.index_select(0, idx)
-        ctx = hip.tree_attention(q, k, v, trie.anc, trie.depth, layer.heads, layer.scale, rows)
+        ctx = attn(q, k, v, trie.anc, trie.depth, layer.heads, layer.scale, rows)
     if OWN_GEMM:
-        mid = linear(ctx, layer.out.weight, layer.out.bias, residual=res, wsp=layer.split_of("out"))     # residual add in the GEMM's epilogue
-        return mid, norm_of(mid, layer.ln2)
+        mid = linear(ctx, layer.out.weight, layer.out.bias, residual=res, wsp=out_sp)     # residual add in the GEMM's epilogue
+        fc1_sp = layer.split_of("fc1")
+        scale_out = fc1_sp is not None and layer.split_of("fc2") is not None and layer.act_code is not None
+        return mid, norm_of(mid, layer.ln2, fc1_sp, want_f32=want_f32, scale_output=scale_out)
     o = layer.out(ctx)
     if _fusable(layer.ln2):
         return hip.add_layernorm(res, o, layer.ln2)          # residual add + LN2 in one pass
@@ -555,9 +575,12 @@ def layer_attention_block(layer: ClipLayer, hs: torch.Tensor, trie: TokenTrie, r
     return mid, layer.ln2(mid)
 
 
-def mlp_hidden(layer: ClipLayer, ln2_mid: torch.Tensor) -> torch.Tensor:
-    """fc2 INPUT (the "key" space): act(fc1(LN2(hs_mid)))."""
-    return linear(ln2_mid, layer.fc1.weight, layer.fc1.bias, act=layer.act, act_code=layer.act_code, wsp=layer.split_of("fc1"))
+def mlp_hidden(layer: ClipLayer, ln2_mid, want_f32: bool = True):
+    """fc2 INPUT (the "key" space): act(fc1(LN2(hs_mid))).  On the split-fp16 path (``ln2_mid`` a SplitRows carrying the output
+    scale) the result is a SplitRows written by fc1's epilogue, with its fp32 twin when ``want_f32``."""
+    ps = ln2_mid.out_scale if isinstance(ln2_mid, hip.SplitRows) else None
+    return linear(ln2_mid, layer.fc1.weight, layer.fc1.bias, act=layer.act, act_code=layer.act_code, wsp=layer.split_of("fc1"),
+                  planes_scale=ps, want_f32=want_f32 or ps is None)
 
 
 def run_layers(graph: ClipTextGraph, trie: TokenTrie, upto: int, on_fc2=None, last_rows_only: bool = True,
@@ -586,7 +609,11 @@ def run_prefix(graph: ClipTextGraph, trie: TokenTrie, stop: int):
                 and 0 <= trie.max_token < te.num_embeddings and trie.anc.shape[1] <= pe.num_embeddings:
             # embeddings + the first layer's LN1 in one launch; token and position ranges are checked on the host copies
             # (anything out of range takes the torch path, which raises like the reference's forward)
-            hs, x_ln1 = hip.embed_layernorm(te.weight, pe.weight, trie.token, trie.depth, ln0)
+            sp0 = graph.layers[0].split_of("qkv") if graph.layers[0].qkv_w is not None else None
+            if sp0 is not None and _sp_ln_ok(ln0):
+                hs, x_ln1 = hip.embed_layernorm_sp(te.weight, pe.weight, trie.token, trie.depth, ln0)
+            else:
+                hs, x_ln1 = hip.embed_layernorm(te.weight, pe.weight, trie.token, trie.depth, ln0)
         else:
             hs, x_ln1 = embed(graph, trie), None
         for i in range(stop):
@@ -594,13 +621,22 @@ def run_prefix(graph: ClipTextGraph, trie: TokenTrie, stop: int):
     return hs, x_ln1
 
 
+def _next_ln1(graph, nxt_index: int, hs: torch.Tensor, nxt):
+    """LN1 of the next layer on the residual stream (a SplitRows for its q | k | v projection on the split-fp16 path)."""
+    if nxt is None or not _fusable(nxt):
+        return None
+    nl = graph.layers[nxt_index]
+    return norm_of(hs, nxt, nl.split_of("qkv") if nl.qkv_w is not None else None)
+
+
 def _layer_full(graph, i, trie, hs, x_ln1, n_layers_needed):
     layer = graph.layers[i]
     mid, ln2_mid = layer_attention_block(layer, hs, trie, None, x_ln1)
     nxt = graph.layers[i + 1].ln1 if i + 1 < len(graph.layers) and i + 1 <= n_layers_needed else None
     if OWN_GEMM:
-        hs = linear(mlp_hidden(layer, ln2_mid), layer.fc2.weight, layer.fc2.bias, residual=mid, wsp=layer.split_of("fc2"))     # fc2 + residual add
-        return hs, (norm_of(hs, nxt) if nxt is not None and _fusable(nxt) else None)
+        hs = linear(mlp_hidden(layer, ln2_mid, want_f32=False), layer.fc2.weight, layer.fc2.bias, residual=mid,
+                    wsp=layer.split_of("fc2"))     # fc2 + residual add
+        return hs, _next_ln1(graph, i + 1, hs, nxt)
     out = layer.fc2(mlp_hidden(layer, ln2_mid))
     if nxt is not None and _fusable(nxt):
         return hip.add_layernorm(mid, out, nxt)          # residual add + the next layer's LN1 in one pass
@@ -608,13 +644,15 @@ def _layer_full(graph, i, trie, hs, x_ln1, n_layers_needed):
 
 
 def run_layers_multi(graph: ClipTextGraph, tries: Sequence[TokenTrie], states, start: int, upto: int, on_fc2=None,
-                     last_rows_only: bool = True, fc2_by_callback=(), callback_adds_residual: bool = False):
+                     last_rows_only: bool = True, fc2_by_callback=(), callback_adds_residual: bool = False,
+                     split_aware: bool = False):
     """Layers start..upto (inclusive) for several tries at once, layer by layer: the prompt list of an edit may arrive in
     slices (compute_z.iter_prompt_chunks), each with its own trie; rows of different slices never attend to each other,
     but an edited layer's solve needs the keys of all of them before any slice can go on.  ``states[c]``: (residual
     stream, LN1 of it | None) of slice c entering layer ``start`` (None: start from the embeddings, start == 0).
-    ``on_fc2(i, xs, outs) -> outs'``: lists over the slices.  Returns the list of final states, or None if the callback
-    ended the pass."""
+    ``on_fc2(i, xs, outs) -> outs'``: lists over the slices (``split_aware``: the fc2 inputs may arrive as ``hip.SplitRows``
+    with their fp32 twins — the edit engine feeds the planes to fc2 and gathers the keys from the twin; otherwise the callback
+    gets plain fp32 tensors).  Returns the list of final states, or None if the callback ended the pass."""
     _check_fp32(graph)
     by_cb = set(fc2_by_callback)
     with tuned_gemms():
@@ -627,7 +665,7 @@ def run_layers_multi(graph: ClipTextGraph, tries: Sequence[TokenTrie], states, s
             for trie, (hs, x_ln1) in zip(tries, states):
                 rows = trie.query_rows if (last_rows_only and i == upto) else None
                 mid, ln2_mid = layer_attention_block(layer, hs, trie, rows, x_ln1)
-                xs.append(mlp_hidden(layer, ln2_mid))
+                xs.append(mlp_hidden(layer, ln2_mid, want_f32=on_fc2 is not None))
                 mids.append(mid)
             # layers in ``fc2_by_callback``: the callback produces fc2's output itself (out is passed as None), so an
             # edited layer's projection is computed once, with the new weight, instead of twice.  With ``callback_adds_residual``
@@ -635,21 +673,22 @@ def run_layers_multi(graph: ClipTextGraph, tries: Sequence[TokenTrie], states, s
             nxt = graph.layers[i + 1].ln1 if i < upto else None
             summed = False
             if i in by_cb or not OWN_GEMM:
-                outs = [None if i in by_cb else layer.fc2(x) for x in xs]
+                outs = [None if i in by_cb else layer.fc2(x.float() if isinstance(x, hip.SplitRows) else x) for x in xs]
             else:
                 fsp = layer.split_of("fc2")
                 outs = [linear(x, layer.fc2.weight, layer.fc2.bias, residual=mid, wsp=fsp) for x, mid in zip(xs, mids)]
                 summed = True
             if on_fc2 is not None:
+                cb_xs = xs if split_aware else [x.float() if isinstance(x, hip.SplitRows) else x for x in xs]
                 if callback_adds_residual and not summed:
-                    outs = on_fc2(i, xs, outs, mids)
-                    summed = outs is not None
+                    outs = on_fc2(i, cb_xs, outs, mids)
+                    summed = outs is not None and i in by_cb
                 else:
-                    outs = on_fc2(i, xs, outs)
+                    outs = on_fc2(i, cb_xs, outs)
                 if outs is None:
                     return None
             if summed:
-                states = [(hs, norm_of(hs, nxt) if nxt is not None and _fusable(nxt) else None) for hs in outs]
+                states = [(hs, _next_ln1(graph, i + 1, hs, nxt)) for hs in outs]
             elif nxt is not None and _fusable(nxt):
                 states = [hip.add_layernorm(mid, out, nxt) for mid, out in zip(mids, outs)]
             else:

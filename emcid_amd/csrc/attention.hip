@@ -11,6 +11,7 @@
 // `causal` skips j > i (CLIP text is causal); an optional mask (bool keep-mask or additive float,
 // broadcastable over heads) covers right-padded prompts.
 #include "common.h"
+#include "sp16.h"
 
 namespace emcid {
 
@@ -109,6 +110,7 @@ struct TreeAttnArgs {
     const float* q; int64_t ldq; const float* k; const float* v; int64_t ld;
     const int* anc; int64_t anc_ld; const int* depth; const int* rows; int n_rows;
     int H, D; float scale; float* out; int64_t ldo;
+    uint32_t* P; int64_t ldp; float* inv_scale;        // the output as a split-fp16 matrix instead of `out` (short-chain kernel)
 };
 
 __global__ __launch_bounds__(256) void tree_attention_f32_kernel(TreeAttnArgs a) {
@@ -203,7 +205,7 @@ using namespace emcid;
 // is fetched in TWO dependent rounds — its chain, then q and every k / v row of all its heads — and the softmax over <= 8 keys
 // lives in registers (two keys per 16-lane group, combined with shuffles): no LDS, no barrier.  The general kernel above pays two
 // dependent global reads and three barriers per round of four heads (38 us for 6 400 nodes x 12 heads; this one: see DESIGN.md).
-template <int ROUNDS, int KPS>
+template <int ROUNDS, int KPS, bool SP>
 __global__ __launch_bounds__(256) void tree_attention_short_kernel(TreeAttnArgs a) {
     // KPS keys per 16-lane group: chains of up to 4 * KPS nodes (KPS = 2: 8, KPS = 4: 16)
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -267,23 +269,72 @@ __global__ __launch_bounds__(256) void tree_attention_short_kernel(TreeAttnArgs 
             acc[e] += __shfl_xor(acc[e], 16);
             acc[e] += __shfl_xor(acc[e], 32);
         }
-        if (h < a.H && slot == 0 && dok) {
+        if constexpr (SP) {
+            q4[r] = acc * (1.f / l);             // kept until the row's largest magnitude is known (q4[r] is dead by now)
+        } else if (h < a.H && slot == 0 && dok) {
             const float inv = 1.f / l;
             *reinterpret_cast<v4f*>(a.out + (int64_t)qi * a.ldo + (int64_t)h * a.D + 4 * dl) = acc * inv;
         }
     }
+    if constexpr (SP) {
+        // the row (all heads of this node) as planes under its own scale: largest magnitude over the workgroup's four waves first
+        __shared__ float wmax[4];
+        float amax = 0.f;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r)
+            if (r * 4 + wave < a.H && dok)
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(q4[r][0]), fabsf(q4[r][1]))), fmaxf(fabsf(q4[r][2]), fabsf(q4[r][3])));
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        if (lane == 0) wmax[wave] = amax;
+        __syncthreads();
+        amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        float s, inv;
+        sp_scale_of(amax, s, inv);
+        if (tid == 0) a.inv_scale[qi] = inv;
+        uint32_t* prow = a.P + (int64_t)qi * a.ldp;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int h = r * 4 + wave;
+            if (h < a.H && slot == 0 && dok) sp_store4(prow, h * a.D + 4 * dl, q4[r][0], q4[r][1], q4[r][2], q4[r][3], s);
+        }
+    }
 }
 
-template <int KPS>
+template <int KPS, bool SP>
 static void launch_tree_attention_short(const TreeAttnArgs& a, int rounds, hipStream_t st) {
     const dim3 g((unsigned)a.n_rows), b(256);
     switch (rounds) {
-        case 1: hipLaunchKernelGGL((tree_attention_short_kernel<1, KPS>), g, b, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((tree_attention_short_kernel<2, KPS>), g, b, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((tree_attention_short_kernel<3, KPS>), g, b, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((tree_attention_short_kernel<4, KPS>), g, b, 0, st, a); break;
-        default: hipLaunchKernelGGL((tree_attention_short_kernel<5, KPS>), g, b, 0, st, a); break;
+        case 1: hipLaunchKernelGGL((tree_attention_short_kernel<1, KPS, SP>), g, b, 0, st, a); break;
+        case 2: hipLaunchKernelGGL((tree_attention_short_kernel<2, KPS, SP>), g, b, 0, st, a); break;
+        case 3: hipLaunchKernelGGL((tree_attention_short_kernel<3, KPS, SP>), g, b, 0, st, a); break;
+        case 4: hipLaunchKernelGGL((tree_attention_short_kernel<4, KPS, SP>), g, b, 0, st, a); break;
+        default: hipLaunchKernelGGL((tree_attention_short_kernel<5, KPS, SP>), g, b, 0, st, a); break;
     }
+}
+
+/* 1 when emcid_tree_attention_sp16 serves chains of up to anc_ld nodes with H heads (the short-chain kernel), else 0 */
+extern "C" int emcid_tree_attention_sp16_supported(int64_t anc_ld, int64_t H, int64_t D) {
+    static const int short_ok = [] { const char* e = getenv("EMCID_TREE_ATTN_SHORT"); return e ? atoi(e) : 1; }();
+    return short_ok && anc_ld >= 1 && anc_ld <= 16 && (H + 3) / 4 <= 5 && D <= 64 && D % 8 == 0 ? 1 : 0;
+}
+
+/* emcid_tree_attention_f32 with the result written as a split-fp16 matrix (planes [n_rows, H * D] + inv_scale [n_rows]) for the
+ * out-projection that consumes it.  Chains of at most 16 nodes (emcid_tree_attention_sp16_supported). */
+extern "C" int emcid_tree_attention_sp16(const float* q, int64_t ldq, const float* k, const float* v, int64_t ld, const int* anc,
+                                         int64_t anc_ld, const int* depth, const int* rows, int64_t n_rows, int64_t H,
+                                         int64_t D, float scale, void* planes, int64_t ldp, float* inv_scale, void* stream) {
+    EMCID_CHECK_ARG(q && k && v && anc && depth && planes && inv_scale && n_rows > 0 && H > 0 && D > 0);
+    EMCID_CHECK_ARG(emcid_tree_attention_sp16_supported(anc_ld, H, D) && ld % 4 == 0 && ldq % 4 == 0 && ldp % 4 == 0 && ldp >= H * D);
+    EMCID_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(planes) && n_rows < (1LL << 31));
+    TreeAttnArgs a{q, ldq, k, v, ld, anc, anc_ld, depth, rows, (int)n_rows, (int)H, (int)D, scale, nullptr, 0,
+                   (uint32_t*)planes, ldp, inv_scale};
+    ScopedProf sp(KC_MISC, (hipStream_t)stream);
+    const int rounds = (int)((H + 3) / 4);
+    if (anc_ld <= 8) launch_tree_attention_short<2, true>(a, rounds, (hipStream_t)stream);
+    else launch_tree_attention_short<4, true>(a, rounds, (hipStream_t)stream);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
 }
 
 extern "C" int emcid_tree_attention_f32(const float* q, int64_t ldq, const float* k, const float* v, int64_t ld, const int* anc,
@@ -292,13 +343,13 @@ extern "C" int emcid_tree_attention_f32(const float* q, int64_t ldq, const float
     EMCID_CHECK_ARG(q && k && v && anc && depth && out && n_rows > 0 && H > 0 && D > 0);
     EMCID_CHECK_ARG(D <= 64 && D % 4 == 0 && ld % 4 == 0 && ldq % 4 == 0 && ldo % 4 == 0 && anc_ld >= 1 && anc_ld <= 128);
     EMCID_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out) && n_rows < (1LL << 31));
-    TreeAttnArgs a{q, ldq, k, v, ld, anc, anc_ld, depth, rows, (int)n_rows, (int)H, (int)D, scale, out, ldo};
+    TreeAttnArgs a{q, ldq, k, v, ld, anc, anc_ld, depth, rows, (int)n_rows, (int)H, (int)D, scale, out, ldo, nullptr, 0, nullptr};
     ScopedProf sp(KC_MISC, (hipStream_t)stream);
     static const int short_ok = [] { const char* e = getenv("EMCID_TREE_ATTN_SHORT"); return e ? atoi(e) : 1; }();
     const int rounds = (int)((H + 3) / 4);
     if (short_ok && anc_ld <= 16 && rounds <= 5) {      // every chain has at most anc_ld nodes
-        if (anc_ld <= 8) launch_tree_attention_short<2>(a, rounds, (hipStream_t)stream);
-        else launch_tree_attention_short<4>(a, rounds, (hipStream_t)stream);
+        if (anc_ld <= 8) launch_tree_attention_short<2, false>(a, rounds, (hipStream_t)stream);
+        else launch_tree_attention_short<4, false>(a, rounds, (hipStream_t)stream);
     } else {
         hipLaunchKernelGGL(tree_attention_f32_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, a);
     }
@@ -369,11 +420,20 @@ __global__ __launch_bounds__(256) void add_layernorm_f32_kernel(const float* __r
 
 // Rows of up to 2048 columns: one WAVE per row (four rows per workgroup), both reductions by shuffles — no LDS, no barrier; a
 // workgroup's four rows are independent, so nothing in it waits for anything but its own loads (15 -> 11 us at 6400 x 768).
+// The split-fp16 form of the output (include/emcid_hip.h, "split fp16"): z as planes under the row's own scale — the consumer is a
+// projection (q | k | v, fc1) — and, when `bound` = {largest row norm of that projection's weight, largest |bias|} is given, the
+// scale 2^e (out_scale[row]; its inverse at out_scale[rows + row]) under which the PROJECTION may write its own output as planes:
+// |act(z . w_j + b_j)| <= |z| max_j |w_j| + max_j |b_j|.
+struct LnPlanes {
+    uint32_t* P; int64_t ldp; float* inv_scale; const float* bound; float* out_scale;
+};
+
 __global__ __launch_bounds__(256) void add_layernorm_wave_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b,
                                                                   int64_t ldb, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, float eps, int cols, int rows,
                                                                   float* __restrict__ y, float* __restrict__ z,
-                                                                  const int64_t* __restrict__ ia, const int* __restrict__ ib) {
+                                                                  const int64_t* __restrict__ ia, const int* __restrict__ ib,
+                                                                  LnPlanes sp) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -410,25 +470,52 @@ __global__ __launch_bounds__(256) void add_layernorm_wave_kernel(const float* __
     float4* pz = reinterpret_cast<float4*>(z + row * (int64_t)cols);
     const float4* pg = reinterpret_cast<const float4*>(gamma);
     const float4* pe = reinterpret_cast<const float4*>(beta);
+    float amax = 0.f, ss = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
             const float4 g = pg[c], e = pe[c];
             if (y) py[c] = v[i];
-            pz[c] = make_float4((v[i].x - mean) * rstd * g.x + e.x, (v[i].y - mean) * rstd * g.y + e.y,
-                                (v[i].z - mean) * rstd * g.z + e.z, (v[i].w - mean) * rstd * g.w + e.w);
+            v[i] = make_float4((v[i].x - mean) * rstd * g.x + e.x, (v[i].y - mean) * rstd * g.y + e.y,
+                               (v[i].z - mean) * rstd * g.z + e.z, (v[i].w - mean) * rstd * g.w + e.w);
+            if (z) pz[c] = v[i];
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+            ss += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
         }
+    }
+    if (sp.P == nullptr) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        ss += __shfl_xor(ss, o, 64);
+    }
+    float s, inv;
+    sp_scale_of(amax, s, inv);
+    if (lane == 0) {
+        sp.inv_scale[row] = inv;
+        if (sp.out_scale != nullptr) {
+            float s2, inv2;
+            sp_scale_of(sqrtf(ss) * 1.0001f * sp.bound[0] + sp.bound[1], s2, inv2);
+            sp.out_scale[row] = s2;
+            sp.out_scale[rows + row] = inv2;
+        }
+    }
+    uint32_t* prow = sp.P + row * sp.ldp;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) sp_store4(prow, 4 * c, v[i].x, v[i].y, v[i].z, v[i].w, s);
     }
 }
 
 static void launch_add_layernorm(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gamma, const float* beta,
                                  float eps, int64_t rows, int64_t cols, float* y, float* z, const int64_t* ia, const int* ib,
-                                 hipStream_t st) {
+                                 hipStream_t st, LnPlanes sp = LnPlanes{nullptr, 0, nullptr, nullptr, nullptr}) {
     static const int wave_rows = [] { const char* e = getenv("EMCID_LN_WAVE"); return e ? atoi(e) : 1; }();
-    if (wave_rows && cols <= LN_MAX_V4 * 64 * 4)
+    if ((wave_rows || sp.P != nullptr) && cols <= LN_MAX_V4 * 64 * 4)
         hipLaunchKernelGGL(add_layernorm_wave_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a, lda, b, ldb, gamma, beta,
-                           eps, (int)cols, (int)rows, y, z, ia, ib);
+                           eps, (int)cols, (int)rows, y, z, ia, ib, sp);
     else
         hipLaunchKernelGGL(add_layernorm_f32_kernel, dim3((unsigned)rows), dim3(256), 0, st, a, lda, b, ldb, gamma, beta, eps,
                            (int)cols, y, z, ia, ib);
@@ -442,6 +529,38 @@ extern "C" int emcid_add_layernorm_f32(const float* a, int64_t lda, const float*
     EMCID_CHECK_ARG(aligned16(a) && aligned16(b) && aligned16(gamma) && aligned16(beta) && aligned16(y) && aligned16(z));
     ScopedProf sp(KC_MISC, (hipStream_t)stream);
     launch_add_layernorm(a, lda, b, ldb, gamma, beta, eps, rows, cols, y, z, nullptr, nullptr, (hipStream_t)stream);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+/* emcid_add_layernorm_f32 with z written as a split-fp16 matrix (planes + inv_scale) for the projection that consumes it; z
+ * itself optional.  bound / out_scale (optional, together): see LnPlanes.  cols % 8 == 0, <= 2048. */
+extern "C" int emcid_add_layernorm_sp16(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gamma,
+                                        const float* beta, float eps, int64_t rows, int64_t cols, float* y, float* z, void* planes,
+                                        int64_t ldp, float* inv_scale, const float* bound, float* out_scale, void* stream) {
+    EMCID_CHECK_ARG(a && gamma && beta && planes && inv_scale && rows > 0 && cols > 0 && rows < (1LL << 31));
+    EMCID_CHECK_ARG(cols % 8 == 0 && cols <= LN_MAX_V4 * 64 * 4 && lda % 4 == 0 && (b == nullptr || ldb % 4 == 0));
+    EMCID_CHECK_ARG(ldp >= cols && ldp % 4 == 0 && aligned16(planes) && ((bound == nullptr) == (out_scale == nullptr)));
+    EMCID_CHECK_ARG(aligned16(a) && aligned16(b) && aligned16(gamma) && aligned16(beta) && aligned16(y) && aligned16(z));
+    ScopedProf sp(KC_MISC, (hipStream_t)stream);
+    launch_add_layernorm(a, lda, b, ldb, gamma, beta, eps, rows, cols, y, z, nullptr, nullptr, (hipStream_t)stream,
+                         LnPlanes{(uint32_t*)planes, ldp, inv_scale, bound, out_scale});
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+/* emcid_embed_layernorm_f32 with the LayerNorm's output as a split-fp16 matrix (z optional). */
+extern "C" int emcid_embed_layernorm_sp16(const float* tok, int64_t ld_tok, int64_t n_tok, const float* pos, int64_t ld_pos,
+                                          int64_t n_pos, const int64_t* token, const int* position, const float* gamma,
+                                          const float* beta, float eps, int64_t rows, int64_t cols, float* y, float* z, void* planes,
+                                          int64_t ldp, float* inv_scale, void* stream) {
+    EMCID_CHECK_ARG(tok && pos && token && position && gamma && beta && y && planes && inv_scale && rows > 0 && cols > 0);
+    EMCID_CHECK_ARG(rows < (1LL << 31) && n_tok > 0 && n_pos > 0 && cols % 8 == 0 && cols <= LN_MAX_V4 * 64 * 4);
+    EMCID_CHECK_ARG(ld_tok % 4 == 0 && ld_pos % 4 == 0 && ldp >= cols && ldp % 4 == 0 && aligned16(planes));
+    EMCID_CHECK_ARG(aligned16(tok) && aligned16(pos) && aligned16(gamma) && aligned16(beta) && aligned16(y) && aligned16(z));
+    ScopedProf sp(KC_MISC, (hipStream_t)stream);
+    launch_add_layernorm(tok, ld_tok, pos, ld_pos, gamma, beta, eps, rows, cols, y, z, token, position, (hipStream_t)stream,
+                         LnPlanes{(uint32_t*)planes, ldp, inv_scale, nullptr, nullptr});
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }

@@ -18,6 +18,7 @@
 // consecutive n per register quad: 16-byte stores / residual loads in the epilogue, and the fp16 planes of the OUTPUT (when the
 // consumer is the next projection: quick_gelu(fc1) -> fc2) are written 8 bytes per plane per quad straight from the registers.
 #include "common.h"
+#include "sp16.h"
 
 #include <algorithm>
 
@@ -29,9 +30,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
-constexpr int SPK = 32;            // k per stage
-constexpr int SPROW = 144;         // LDS bytes per tile row and stage: 128 + 16 (36 dwords: the 16 lanes of every b128 lane
-                                   // group fall on 16 distinct 4-bank groups, 36 r mod 64 = 4 (9 r mod 16))
+constexpr int SPK = 32;            // k per stage and wave group (a stage is 32 KS deep)
+// LDS bytes per tile row and stage: 128 KS + 16.  KS = 1: 36 dwords, the 16 lanes of every b128 lane group fall on 16 distinct
+// 4-bank groups (36 r mod 64 = 4 (9 r mod 16)); KS = 2: 68 dwords (68 r mod 64 = 4 r).
 
 enum SpAct : int { SP_ACT_NONE = 0, SP_ACT_QUICK_GELU = 1, SP_ACT_GELU_ERF = 2 };
 
@@ -57,21 +58,31 @@ __device__ __forceinline__ void sp_tile_of(const SpArgs& a, int tile, int& bm, i
     bm = sr * a.rb + (rem - bn * rows);
 }
 
-// MJ x NI blocks of 32 x 32 per wave (m x n), WM x WN waves per workgroup, PF register sets of staged global loads.
-template <int MJ, int NI, int WM, int WN, int PF>
+// MJ x NI blocks of 32 x 32 per wave (m x n), WM x WN waves per K group, KS K groups per workgroup (KS = 2: waves 0..WM WN - 1
+// contract the first 32 of a 64-deep stage, the others the second 32, both over the whole tile; the halves meet through LDS at
+// the end — gemm_f32.hip's scheme: a launch whose tiles give a compute unit ONE workgroup still has two waves per SIMD), PF
+// register sets of staged global loads.
+template <int MJ, int NI, int WM, int WN, int PF, int KS>
 struct SpGeom {
-    static constexpr int NT = 64 * WM * WN;
+    static constexpr int NW = WM * WN;                        // waves per K group
+    static constexpr int NT = 64 * NW * KS;
     static constexpr int BM = 32 * MJ * WM, BN = 32 * NI * WN;
-    static constexpr int VA = (BM * 8 + NT - 1) / NT, VB = (BN * 8 + NT - 1) / NT;      // 16-byte pieces per thread and stage
-    static constexpr int STAGE = (BM + BN) * SPROW;                                      // bytes
-    static constexpr int SMEM = 2 * STAGE;
+    static constexpr int PPR = 8 * KS;                        // 16-byte pieces per row and stage
+    static constexpr int SBK = SPK * KS;
+    static constexpr int ROW = 128 * KS + 16;                 // LDS bytes per row and stage
+    static constexpr int VA = (BM * PPR + NT - 1) / NT, VB = (BN * PPR + NT - 1) / NT;      // 16-byte pieces per thread and stage
+    static constexpr int STAGE = (BM + BN) * ROW;                                          // bytes
+    static constexpr int NBLK = MJ * NI, HB = KS == 2 ? (NBLK + 1) / 2 : NBLK;
+    static constexpr int RED = KS == 2 ? NW * NBLK * 4 * 64 * 16 : 0;                       // bytes the final hand-over needs
+    static constexpr int SMEM = 2 * STAGE > RED ? 2 * STAGE : RED;
 };
 
-template <int MJ, int NI, int WM, int WN, int PF>
+template <int MJ, int NI, int WM, int WN, int PF, int DBG, int KS>
 __device__ __forceinline__ void sp_accumulate(const SpArgs& a, int m0, int n0, int T, unsigned char* smem, v16f (&acc)[NI][MJ]) {
-    using G = SpGeom<MJ, NI, WM, WN, PF>;
-    constexpr int NT = G::NT, BM = G::BM, BN = G::BN, VA = G::VA, VB = G::VB, STAGE = G::STAGE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    using G = SpGeom<MJ, NI, WM, WN, PF, KS>;
+    constexpr int NT = G::NT, BM = G::BM, BN = G::BN, VA = G::VA, VB = G::VB, STAGE = G::STAGE, PPR = G::PPR, SPROW = G::ROW,
+                  SBK = G::SBK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % G::NW, grp = (tid >> 6) / G::NW;
     const int l31 = lane & 31, l5 = lane >> 5;
     const int wm0 = (wave / WN) * (32 * MJ), wn0 = (wave % WN) * (32 * NI);
 
@@ -82,24 +93,24 @@ __device__ __forceinline__ void sp_accumulate(const SpArgs& a, int m0, int n0, i
     int wa[VA], wb[VB];
 #pragma unroll
     for (int s = 0; s < VA; ++s) {
-        const int v = tid + NT * s, row = min(v >> 3, BM - 1);
-        pa[s] = a.X + (int64_t)min(m0 + row, a.M - 1) * a.ldx + 4 * (v & 7);          // rows past M: a valid row, never stored
-        wa[s] = row * SPROW + 16 * (v & 7);
+        const int v = tid + NT * s, row = min(v / PPR, BM - 1);
+        pa[s] = a.X + (int64_t)min(m0 + row, a.M - 1) * a.ldx + 4 * (v % PPR);        // rows past M: a valid row, never stored
+        wa[s] = row * SPROW + 16 * (v % PPR);
     }
 #pragma unroll
     for (int s = 0; s < VB; ++s) {
-        const int v = tid + NT * s, row = min(v >> 3, BN - 1);
-        pb[s] = a.W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + 4 * (v & 7);
-        wb[s] = (BM + row) * SPROW + 16 * (v & 7);
+        const int v = tid + NT * s, row = min(v / PPR, BN - 1);
+        pb[s] = a.W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + 4 * (v % PPR);
+        wb[s] = (BM + row) * SPROW + 16 * (v % PPR);
     }
-    constexpr bool TAIL_A = (BM * 8) % NT != 0, TAIL_B = (BN * 8) % NT != 0;
-    const bool last_a = !TAIL_A || tid + NT * (VA - 1) < BM * 8;
-    const bool last_b = !TAIL_B || tid + NT * (VB - 1) < BN * 8;
+    constexpr bool TAIL_A = (BM * PPR) % NT != 0, TAIL_B = (BN * PPR) % NT != 0;
+    const bool last_a = !TAIL_A || tid + NT * (VA - 1) < BM * PPR;
+    const bool last_b = !TAIL_B || tid + NT * (VB - 1) < BN * PPR;
 
     v4u ga[PF][VA], gb[PF][VB];
-    auto gload = [&](int it, auto rc) {
+    auto gload = [&](int it, auto rc) __attribute__((always_inline)) {
         constexpr int R = decltype(rc)::value;
-        const int k0 = it * SPK;
+        const int k0 = it * SBK;
 #pragma unroll
         for (int s = 0; s < VA; ++s)
             if (s + 1 < VA || last_a) ga[R][s] = *reinterpret_cast<const v4u*>(pa[s] + k0);
@@ -107,7 +118,7 @@ __device__ __forceinline__ void sp_accumulate(const SpArgs& a, int m0, int n0, i
         for (int s = 0; s < VB; ++s)
             if (s + 1 < VB || last_b) gb[R][s] = *reinterpret_cast<const v4u*>(pb[s] + k0);
     };
-    auto lstore = [&](unsigned char* stage, auto rc) {
+    auto lstore = [&](unsigned char* stage, auto rc) __attribute__((always_inline)) {
         constexpr int R = decltype(rc)::value;
 #pragma unroll
         for (int s = 0; s < VA; ++s)
@@ -118,10 +129,11 @@ __device__ __forceinline__ void sp_accumulate(const SpArgs& a, int m0, int n0, i
     };
 
     // fragments: lane (row l31, half l5) of k16-step t reads group 2 t + l5 of its row: hi at +0, lo at +16
-    const int fx_off = (wm0 + l31) * SPROW + 32 * l5;
-    const int fw_off = (BM + wn0 + l31) * SPROW + 32 * l5;
-    v8h xh[2][MJ], xl[2][MJ], wh[2][NI], wl[2][NI];
-    auto fread = [&](const unsigned char* stage, int t, int slot) {
+    const int fx_off = (wm0 + l31) * SPROW + 32 * l5 + 128 * grp;
+    const int fw_off = (BM + wn0 + l31) * SPROW + 32 * l5 + 128 * grp;
+    constexpr int NSLOT = MJ * NI > 4 ? 1 : 2;
+    v8h xh[NSLOT][MJ], xl[NSLOT][MJ], wh[NSLOT][NI], wl[NSLOT][NI];
+    auto fread = [&](const unsigned char* stage, int t, int slot) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
             xh[slot][j] = *reinterpret_cast<const v8h*>(stage + fx_off + j * 32 * SPROW + 64 * t);
@@ -135,7 +147,7 @@ __device__ __forceinline__ void sp_accumulate(const SpArgs& a, int m0, int n0, i
     };
     // the two small products first, then hi x hi; p selects the product so that the three MFMAs of one accumulator are a
     // block apart in the issue order
-    auto mfmas = [&](int slot, int p_lo, int p_hi) {
+    auto mfmas = [&](int slot, int p_lo, int p_hi) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
             if (p >= p_lo && p < p_hi)
@@ -147,45 +159,130 @@ __device__ __forceinline__ void sp_accumulate(const SpArgs& a, int m0, int n0, i
                                                                            p == 1 ? xl[slot][j] : xh[slot][j], acc[i][j], 0, 0, 0);
     };
 
+    // Everything inside the loop is unconditional — past the end the loads re-fetch the last stage and the LDS writes / fragment
+    // reads touch a buffer nobody uses any more — because a load or store skipped under a branch makes hipcc's s_waitcnt for the
+    // older register set fall back to vmcnt(0), i.e. an effective prefetch distance of one stage.  DBG (timing experiments only,
+    // results wrong): 1 = no global loads inside the loop, 2 = also no LDS stores, 3 = also no fragment reads.
     gload(0, SpIC<0>{});
     lstore(smem, SpIC<0>{});
-    if (T > 1) gload(1, SpIC<1 % PF>{});
-    if constexpr (PF > 1) if (T > 2) gload(2, SpIC<2 % PF>{});
+    gload(min(1, T - 1), SpIC<1 % PF>{});
+    if constexpr (PF > 1) gload(min(2, T - 1), SpIC<2 % PF>{});
     __syncthreads();
-    fread(smem, 0, 0);
-    auto body = [&](auto rc, int it) {
+    constexpr bool ONE_SLOT = MJ * NI > 4;       // five blocks per wave: a second set of fragments would not fit in 256 registers
+    if constexpr (!ONE_SLOT) fread(smem, 0, 0);
+    if constexpr (DBG >= 3) fread(smem, 1, 1);
+    auto body = [&](auto rc, int it) __attribute__((always_inline)) {
         unsigned char* cur = smem + (it & 1) * STAGE;
         unsigned char* oth = smem + ((it + 1) & 1) * STAGE;
+        if constexpr (ONE_SLOT) {
+            // the partner wave of the other K group covers this wave's LDS latency
+            fread(cur, 0, 0);
+            mfmas(0, 0, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            fread(cur, 1, 0);
+            lstore(oth, rc);
+            __syncthreads();
+            gload(min(it + 1 + PF, T - 1), rc);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(0, 0, 3);
+            return;
+        }
         __builtin_amdgcn_sched_barrier(0);
         mfmas(0, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
-        fread(cur, 1, 1);                                   // second k16 step of this stage: lands under the MFMAs of the first
+        if constexpr (DBG < 3) fread(cur, 1, 1);            // second k16 step of this stage: lands under the MFMAs of the first
         __builtin_amdgcn_sched_barrier(0);
         mfmas(0, 1, 3);
         __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 < T) lstore(oth, rc);                    // stage it+1 (loaded PF stages ago) -> the other buffer
+        if constexpr (DBG < 2) lstore(oth, rc);             // stage it+1 (loaded PF stages ago) -> the other buffer
         __syncthreads();
-        if (it + 1 + PF < T) gload(it + 1 + PF, rc);
+        if constexpr (DBG < 1) gload(min(it + 1 + PF, T - 1), rc);
         __builtin_amdgcn_sched_barrier(0);
         mfmas(1, 0, 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (it + 1 < T) fread(oth, 0, 0);                   // first k16 step of the next stage
+        if constexpr (DBG < 3) fread(oth, 0, 0);            // first k16 step of the next stage
         __builtin_amdgcn_sched_barrier(0);
         mfmas(1, 1, 3);
     };
-    for (int it0 = 0; it0 < T; it0 += PF) {
-        body(SpIC<1 % PF>{}, it0);
-        if constexpr (PF > 1) if (it0 + 1 < T) body(SpIC<2 % PF>{}, it0 + 1);
+    if constexpr (PF == 1) {
+        for (int it = 0; it < T; ++it) body(SpIC<0>{}, it);
+    } else {
+        int it = 0;
+        for (; it + 1 < T; it += 2) {
+            body(SpIC<1>{}, it);
+            body(SpIC<0>{}, it + 1);
+        }
+        if (it < T) body(SpIC<1>{}, it);
     }
 }
 
 // Epilogue.  acc[i][j][4 q + e] = element (m, n): m = m0 + wm0 + 32 j + l31, n = n0 + wn0 + 32 i + 8 q + 4 l5 + e.
-template <int MJ, int NI, int WM, int WN>
-__device__ __forceinline__ void sp_finish(const SpArgs& a, int m0, int n0, v16f (&acc)[NI][MJ]) {
-    constexpr int BM = 32 * MJ * WM, BN = 32 * NI * WN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+template <int MJ, int NI, int WM, int WN, int KS>
+__device__ __forceinline__ void sp_finish(const SpArgs& a, int m0, int n0, unsigned char* smem, v16f (&acc)[NI][MJ]) {
+    constexpr int BM = 32 * MJ * WM, BN = 32 * NI * WN, NW = WM * WN, NBLK = MJ * NI, HB = KS == 2 ? (NBLK + 1) / 2 : NBLK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) % NW, grp = (tid >> 6) / NW;
     const int l31 = lane & 31, l5 = lane >> 5;
     const int wm0 = (wave / WN) * (32 * MJ), wn0 = (wave % WN) * (32 * NI);
+    // KS == 2: the two wave groups hold the two halves of every sum.  They swap HALF of their accumulator blocks through LDS
+    // (lane-linear 16-byte pieces: [wave][block][4][lane]) — group 0 ends up owning blocks [0, HB), group 1 blocks [HB, NBLK),
+    // each complete — so that all eight waves share the epilogue.  Fixed order of the two addends: bit-reproducible.
+    if constexpr (KS == 2) {
+        __syncthreads();                                       // everybody is done with the stage buffers
+        v4f* red = reinterpret_cast<v4f*>(smem) + wave * (NBLK * 4 * 64) + lane;
+        auto put = [&](auto tc) __attribute__((always_inline)) {
+            constexpr int t = decltype(tc)::value;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v4f v = {acc[t / MJ][t % MJ][4 * q], acc[t / MJ][t % MJ][4 * q + 1], acc[t / MJ][t % MJ][4 * q + 2],
+                         acc[t / MJ][t % MJ][4 * q + 3]};
+                red[(t * 4 + q) * 64] = v;
+            }
+        };
+        auto take = [&](auto tc, auto first) __attribute__((always_inline)) {      // group 0's partial first, whoever adds
+            constexpr int t = decltype(tc)::value;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const v4f v = red[(t * 4 + q) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float c = acc[t / MJ][t % MJ][4 * q + e];
+                    acc[t / MJ][t % MJ][4 * q + e] = decltype(first)::value ? c + v[e] : v[e] + c;
+                }
+            }
+        };
+        static_assert(NBLK <= 8, "blocks per wave");
+        if (grp == 1) {                                        // blocks the OTHER group will own
+            if constexpr (0 < HB) put(SpIC<0>{});
+            if constexpr (1 < HB) put(SpIC<1>{});
+            if constexpr (2 < HB) put(SpIC<2>{});
+            if constexpr (3 < HB) put(SpIC<3>{});
+        } else {
+            if constexpr (0 >= HB && 0 < NBLK) put(SpIC<0>{});
+            if constexpr (1 >= HB && 1 < NBLK) put(SpIC<1>{});
+            if constexpr (2 >= HB && 2 < NBLK) put(SpIC<2>{});
+            if constexpr (3 >= HB && 3 < NBLK) put(SpIC<3>{});
+            if constexpr (4 >= HB && 4 < NBLK) put(SpIC<4>{});
+            if constexpr (5 >= HB && 5 < NBLK) put(SpIC<5>{});
+            if constexpr (6 >= HB && 6 < NBLK) put(SpIC<6>{});
+            if constexpr (7 >= HB && 7 < NBLK) put(SpIC<7>{});
+        }
+        __syncthreads();
+        if (grp == 0) {
+            if constexpr (0 < HB) take(SpIC<0>{}, SpIC<1>{});
+            if constexpr (1 < HB) take(SpIC<1>{}, SpIC<1>{});
+            if constexpr (2 < HB) take(SpIC<2>{}, SpIC<1>{});
+            if constexpr (3 < HB) take(SpIC<3>{}, SpIC<1>{});
+        } else {
+            if constexpr (0 >= HB && 0 < NBLK) take(SpIC<0>{}, SpIC<0>{});
+            if constexpr (1 >= HB && 1 < NBLK) take(SpIC<1>{}, SpIC<0>{});
+            if constexpr (2 >= HB && 2 < NBLK) take(SpIC<2>{}, SpIC<0>{});
+            if constexpr (3 >= HB && 3 < NBLK) take(SpIC<3>{}, SpIC<0>{});
+            if constexpr (4 >= HB && 4 < NBLK) take(SpIC<4>{}, SpIC<0>{});
+            if constexpr (5 >= HB && 5 < NBLK) take(SpIC<5>{}, SpIC<0>{});
+            if constexpr (6 >= HB && 6 < NBLK) take(SpIC<6>{}, SpIC<0>{});
+            if constexpr (7 >= HB && 7 < NBLK) take(SpIC<7>{}, SpIC<0>{});
+        }
+    }
     const float* __restrict__ bias = a.bias;
     const float* __restrict__ res = a.res;
     const float* __restrict__ ws = a.ws;
@@ -196,7 +293,7 @@ __device__ __forceinline__ void sp_finish(const SpArgs& a, int m0, int n0, v16f 
     const bool vec_ok = (N & 3) == 0 && (Y == nullptr || ((ldy & 3) == 0 && sp_al16(Y))) &&
                         (res == nullptr || ((ldr & 3) == 0 && sp_al16(res))) && (bias == nullptr || sp_al16(bias)) && sp_al16(ws);
     const bool interior = m0 + BM <= M && n0 + BN <= N && vec_ok;
-    auto epilogue = [&](auto actfn) {
+    auto epilogue = [&](auto actfn) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
             const int m = m0 + wm0 + 32 * j + l31;
@@ -205,6 +302,7 @@ __device__ __forceinline__ void sp_finish(const SpArgs& a, int m0, int n0, v16f 
             const float sp = a.ps != nullptr ? a.ps[min(m, M - 1)] : 1.f;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
+                if (KS == 2 && ((i * MJ + j) < HB) != (grp == 0)) continue;        // the other group's block
                 const int nb = n0 + wn0 + 32 * i + 4 * l5;
                 if (interior) {
                     v4f rv[4];
@@ -267,10 +365,10 @@ __device__ __forceinline__ void sp_finish(const SpArgs& a, int m0, int n0, v16f 
     else epilogue([](float x) { return x; });
 }
 
-template <int MJ, int NI, int WM, int WN, int PF, int WPE>
-__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+template <int MJ, int NI, int WM, int WN, int PF, int WPE, int DBG, int KS>
+__global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void linear_sp16_kernel(SpArgs a) {
-    using G = SpGeom<MJ, NI, WM, WN, PF>;
+    using G = SpGeom<MJ, NI, WM, WN, PF, KS>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::SMEM];
     // XCD x (workgroups go round-robin by linear id) takes the tiles [x per, (x + 1) per) of the super-row order
     const int per = (a.tiles + 7) / 8;
@@ -285,22 +383,11 @@ void linear_sp16_kernel(SpArgs a) {
         for (int j = 0; j < MJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    sp_accumulate<MJ, NI, WM, WN, PF>(a, bm * G::BM, bn * G::BN, a.K / SPK, smem, acc);
-    sp_finish<MJ, NI, WM, WN>(a, bm * G::BM, bn * G::BN, acc);
+    sp_accumulate<MJ, NI, WM, WN, PF, DBG, KS>(a, bm * G::BM, bn * G::BN, a.K / G::SBK, smem, acc);
+    sp_finish<MJ, NI, WM, WN, KS>(a, bm * G::BM, bn * G::BN, smem, acc);
 }
 
 // ---- fp32 rows -> planes ------------------------------------------------------------------------------------------------------
-// 2^e for a row whose largest magnitude is amax: amax 2^e in [2^14, 2^15) (e clamped to +-120; zero / subnormal rows get the
-// clamp, inf / nan rows propagate through hi).
-__device__ __forceinline__ void sp_scale_of(float amax, float& s, float& inv) {
-    int ex = (int)((__float_as_uint(amax) >> 23) & 0xff);
-    ex = ex == 0 ? 1 : (ex == 255 ? 254 : ex);
-    int e = 141 - ex;                                          // 14 - (ex - 127)
-    e = e > 120 ? 120 : (e < -120 ? -120 : e);
-    s = __uint_as_float((unsigned)(e + 127) << 23);
-    inv = __uint_as_float((unsigned)(127 - e) << 23);
-}
-
 __device__ __forceinline__ void sp_split8(const v4f& a, const v4f& b, float s, v4u& hi, v4u& lo) {
     v8h h, l;
 #pragma unroll
@@ -315,20 +402,32 @@ __device__ __forceinline__ void sp_split8(const v4f& a, const v4f& b, float s, v
 
 // one wave per row, four rows per workgroup; two passes over the row (the second one hits L2)
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ X, int64_t ldx, int rows, int K,
-                                                          uint32_t* __restrict__ P, int64_t ldp, float* __restrict__ inv_scale) {
+                                                          uint32_t* __restrict__ P, int64_t ldp, float* __restrict__ inv_scale,
+                                                          float* __restrict__ max_row_norm) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* x = X + row * ldx;
     const int ng = K / 8;
-    float amax = 0.f;
+    float amax = 0.f, ss = 0.f;
     for (int g = lane; g < ng; g += 64) {
         const v4f a = *reinterpret_cast<const v4f*>(x + 8 * g), b = *reinterpret_cast<const v4f*>(x + 8 * g + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) amax = fmaxf(amax, fmaxf(fabsf(a[e]), fabsf(b[e])));
+        for (int e = 0; e < 4; ++e) {
+            amax = fmaxf(amax, fmaxf(fabsf(a[e]), fabsf(b[e])));
+            ss += a[e] * a[e] + b[e] * b[e];
+        }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    for (int o = 32; o > 0; o >>= 1) {
+        amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        ss += __shfl_xor(ss, o, 64);
+    }
+    // the largest Euclidean row norm (rounded up a little): with it a consumer bounds |x . w_j| <= |x| max_j |w_j| for every
+    // output column at once (the scale of a projection's split-fp16 OUTPUT, emcid_add_layernorm_sp16).  Non-negative floats
+    // order like their bit patterns.
+    if (max_row_norm != nullptr && lane == 0)
+        atomicMax(reinterpret_cast<unsigned int*>(max_row_norm), __float_as_uint(sqrtf(ss) * 1.0001f));
     float s, inv;
     sp_scale_of(amax, s, inv);
     if (lane == 0) inv_scale[row] = inv;
@@ -343,7 +442,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 }
 
 struct SpCfg { int bm, bn; };
-static const SpCfg kSpCfgs[] = {{128, 128}, {256, 128}, {64, 64}, {128, 256}};
+static const SpCfg kSpCfgs[] = {{128, 128}, {256, 128}, {64, 64}, {160, 128}};
 
 }  // namespace emcid
 
@@ -352,12 +451,12 @@ using namespace emcid;
 extern "C" {
 
 int emcid_split_rows_f16(const float* X, int64_t ldx, int64_t rows, int64_t K, void* planes, int64_t ldp, float* inv_scale,
-                         void* stream) {
+                         float* max_row_norm, void* stream) {
     EMCID_CHECK_ARG(X && planes && inv_scale && rows > 0 && K > 0 && K % 8 == 0 && ldx >= K && ldp >= K);
     EMCID_CHECK_ARG(ldx % 4 == 0 && ldp % 4 == 0 && aligned16(X) && aligned16(planes) && rows < (1LL << 31) && K < (1 << 24));
     ScopedProf sp(KC_MISC, (hipStream_t)stream);
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X, ldx, (int)rows,
-                       (int)K, (uint32_t*)planes, ldp, inv_scale);
+                       (int)K, (uint32_t*)planes, ldp, inv_scale, max_row_norm);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }
@@ -371,15 +470,22 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
     EMCID_CHECK_ARG(M < (1 << 24) && N < (1 << 24) && K < (1 << 24) && (residual == nullptr || ldr >= N) && (Y == nullptr || ldy >= N));
     EMCID_CHECK_ARG(Yp == nullptr || (N % 8 == 0 && ldp >= N && ldp % 4 == 0 && aligned16(Yp)));
     EMCID_CHECK_ARG(act >= SP_ACT_NONE && act <= SP_ACT_GELU_ERF && cfg >= -1 && cfg < 64);
-    // cfg: bits 0-1 tile (0: 128 x 128 on 4 waves, 1: 256 x 128 on 8 waves, 2: 64 x 64 on 4 waves, 3: 128 x 256 on 8 waves),
-    // bits 2-3: prefetch distance - 1; -1: auto
+    // cfg: bits 0-1 tile (0: 128 x 128 on 4 waves, 1: 256 x 128 on 8 waves, 2: 64 x 64 on 4 waves, 3: 160 x 128 on 8 waves with
+    // the K range of a 64-deep stage split between two wave groups), bits 2-3: prefetch distance - 1, bits 4-5: timing
+    // experiments (tile 0, prefetch 2; results wrong); -1: auto
+    const int dbg = cfg < 0 ? 0 : (cfg >> 4) & 3;
     int tile_sel = cfg < 0 ? -1 : (cfg & 3);
     int pf = cfg < 0 ? 2 : ((cfg >> 2) & 3) + 1;
     EMCID_CHECK_ARG(pf >= 1 && pf <= 2);
     if (tile_sel < 0) {
-        const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
-        tile_sel = t128 >= 384 ? 0 : 2;
+        // scripts/mb_linear_sp16.py.  A compute unit works through ceil(tiles / 256) tiles: 160 x 128 (one workgroup of eight
+        // waves per compute unit) where 128 x 128 tiles would leave the second round nearly empty (N = 768 at 6 400 rows: 300
+        // tiles = two rounds for 1.17 tiles per compute unit; 160 x 128: 240 tiles, one round).
+        const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128), t160 = ((M + 159) / 160) * ((N + 127) / 128);
+        if (K % 64 == 0 && t160 >= 160 && t160 <= 256 && t128 > 256) tile_sel = 3;
+        else tile_sel = (t128 >= 256 && (K >= 2048 || t128 >= 640)) ? 0 : 2;
     }
+    if (tile_sel == 3 && K % 64 != 0) tile_sel = 0;
     const int bm = kSpCfgs[tile_sel].bm, bn = kSpCfgs[tile_sel].bn;
     const int tiles_m = (int)((M + bm - 1) / bm), tiles_n = (int)((N + bn - 1) / bn);
     const int tiles = tiles_m * tiles_n;
@@ -390,19 +496,22 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
     const SpArgs a{(const uint32_t*)Xp, ldx, x_inv_scale, (const uint32_t*)Wp, ldw, w_inv_scale, bias, residual, ldr, Y, ldy,
                    (uint32_t*)Yp, ldp, y_scale, (int)M, (int)N, (int)K, act, tiles_n, tiles, rb};
     ScopedProf sp(KC_LINEAR, st);
-#define EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, PF_, WPE_)                                                                         \
-    hipLaunchKernelGGL((linear_sp16_kernel<MJ_, NI_, WM_, WN_, PF_, WPE_>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, \
-                       st, a)
-#define EMCID_SP_PF(MJ_, NI_, WM_, WN_, WPE_)                         \
-    do {                                                              \
-        if (pf == 1) EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 1, WPE_);    \
-        else EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 2, WPE_);            \
+#define EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, PF_, WPE_, DBG_, KS_)                                                               \
+    hipLaunchKernelGGL((linear_sp16_kernel<MJ_, NI_, WM_, WN_, PF_, WPE_, DBG_, KS_>), dim3((unsigned)(per * 8)),               \
+                       dim3(64 * WM_ * WN_ * KS_), 0, st, a)
+#define EMCID_SP_PF(MJ_, NI_, WM_, WN_, WPE_, KS_)                              \
+    do {                                                                        \
+        if (pf == 1) EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 1, WPE_, 0, KS_);      \
+        else EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 2, WPE_, 0, KS_);              \
     } while (0)
-    switch (tile_sel) {
-        case 0: EMCID_SP_PF(2, 2, 2, 2, 2); break;
-        case 1: EMCID_SP_PF(2, 2, 4, 2, 2); break;
-        case 2: EMCID_SP_PF(1, 1, 2, 2, 4); break;
-        default: EMCID_SP_PF(2, 2, 2, 4, 2); break;
+    if (dbg == 1) EMCID_SP_LAUNCH(2, 2, 2, 2, 2, 2, 1, 1);
+    else if (dbg == 2) EMCID_SP_LAUNCH(2, 2, 2, 2, 2, 2, 2, 1);
+    else if (dbg == 3) EMCID_SP_LAUNCH(2, 2, 2, 2, 2, 2, 3, 1);
+    else switch (tile_sel) {
+        case 0: EMCID_SP_PF(2, 2, 2, 2, 2, 1); break;
+        case 1: EMCID_SP_PF(2, 2, 4, 2, 2, 1); break;
+        case 2: EMCID_SP_PF(1, 1, 2, 2, 4, 1); break;
+        default: EMCID_SP_LAUNCH(5, 1, 1, 4, 1, 2, 0, 2); break;     // a 64-deep stage ahead; two register sets would spill
     }
 #undef EMCID_SP_PF
 #undef EMCID_SP_LAUNCH

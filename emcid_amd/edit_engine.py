@@ -593,6 +593,8 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
         first_edit = plan.layers[0]
 
         def rows_at(x, idx, ch):   # (rows, c) activations -> per-request means at each prompt's lookup row
+            if isinstance(x, hip.SplitRows):       # split-fp16 path: the keys come from the fp32 twin fc1's epilogue wrote
+                x = x.float()
             return hip.gather_mean(x.unsqueeze(0).expand(idx.numel(), -1, -1), idx, ch.seg)
 
         def keys(li, xs):          # this rank's (N_local, d) key rows, slices concatenated in request order
@@ -632,7 +634,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                     states.append(clip_forward.run_prefix(plan.graph, ch.trie, first_edit))
                 ch.state = None         # single use: the residual stream below belongs to the weights of this very call
             clip_forward.run_layers_multi(plan.graph, [ch.trie for ch in chunks], states, first_edit, last, on_fc2,
-                                          fc2_by_callback=order, callback_adds_residual=True)
+                                          fc2_by_callback=order, callback_adds_residual=True, split_aware=True)
     else:
         def make_hook(i, layer):
             def hook(mod, inputs, output):

@@ -30,7 +30,8 @@ EXPORTS = [
     "emcid_edit_lu_workspace_bytes", "emcid_edit_layer_lu_f64", "emcid_lu_solve_f64",
     "emcid_edit_dual_cols_stage1_f64", "emcid_edit_dual_s", "emcid_edit_dual_u", "emcid_edit_dual_cols_stage2_f64",
     "emcid_apply_update2d_f32", "emcid_linear_f32", "emcid_linear_ws_f32", "emcid_linear_workspace_bytes",
-    "emcid_split_rows_f16", "emcid_linear_sp16_f32",
+    "emcid_split_rows_f16", "emcid_linear_sp16_f32", "emcid_add_layernorm_sp16", "emcid_embed_layernorm_sp16",
+    "emcid_tree_attention_sp16", "emcid_tree_attention_sp16_supported",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block", "linear"]
@@ -106,7 +107,11 @@ def load():
         "emcid_linear_f32": (i32, [p, i64, p, i64, p, p, i64, p, i64, i64, i64, i64, i32, i32, p]),
         "emcid_linear_ws_f32": (i32, [p, i64, p, i64, p, p, i64, p, i64, i64, i64, i64, i32, i32, p, i64, p]),
         "emcid_linear_workspace_bytes": (i64, []),
-        "emcid_split_rows_f16": (i32, [p, i64, i64, i64, p, i64, p, p]),
+        "emcid_split_rows_f16": (i32, [p, i64, i64, i64, p, i64, p, p, p]),
+        "emcid_add_layernorm_sp16": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p, i64, p, p, p, p]),
+        "emcid_embed_layernorm_sp16": (i32, [p, i64, i64, p, i64, i64, p, p, p, p, C.c_float, i64, i64, p, p, p, i64, p, p]),
+        "emcid_tree_attention_sp16_supported": (i32, [i64, i64, i64]),
+        "emcid_tree_attention_sp16": (i32, [p, i64, p, p, i64, p, i64, p, p, i64, i64, i64, f32, p, i64, p, p]),
         "emcid_linear_sp16_f32": (i32, [p, i64, p, p, i64, p, p, p, i64, p, i64, p, i64, p, i64, i64, i64, i32, i32, p]),
         "emcid_add_layernorm_f32": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p]),
         "emcid_embed_layernorm_f32": (i32, [p, i64, i64, p, i64, i64, p, p, p, p, C.c_float, i64, i64, p, p, p]),
@@ -539,24 +544,31 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
 
 class SplitRows:
     """An fp32 matrix (rows, K) as two fp16 planes under per-row power-of-two scales (include/emcid_hip.h, "split fp16"):
-    ``planes`` int32 (rows, K) — one 4-byte unit per element, [hi x 8][lo x 8] per group of 8 k —, ``inv_scale`` fp32 (rows,)."""
-    __slots__ = ("planes", "inv_scale")
+    ``planes`` int32 (rows, K) — one 4-byte unit per element, [hi x 8][lo x 8] per group of 8 k —, ``inv_scale`` fp32 (rows,).
+    ``f32``: the fp32 matrix itself when the producer wrote it too; ``bound``: for a weight, the device pair
+    (largest row norm, largest |bias|) ``add_layernorm_sp`` turns into the scale of the projection's own split output."""
+    __slots__ = ("planes", "inv_scale", "f32", "bound", "out_scale")
 
-    def __init__(self, planes: torch.Tensor, inv_scale: torch.Tensor):
-        self.planes, self.inv_scale = planes, inv_scale
+    def __init__(self, planes: torch.Tensor, inv_scale: torch.Tensor, f32: Optional[torch.Tensor] = None,
+                 bound: Optional[torch.Tensor] = None, out_scale: Optional[torch.Tensor] = None):
+        self.planes, self.inv_scale, self.f32, self.bound = planes, inv_scale, f32, bound
+        self.out_scale = out_scale        # (2, rows): scale / inverse scale for the split OUTPUT of the projection that consumes this
 
     @property
     def shape(self):
         return self.planes.shape
 
     def index_select(self, idx: torch.Tensor) -> "SplitRows":
-        return SplitRows(self.planes.index_select(0, idx), self.inv_scale.index_select(0, idx))
+        return SplitRows(self.planes.index_select(0, idx), self.inv_scale.index_select(0, idx),
+                         self.f32.index_select(0, idx) if self.f32 is not None else None)
 
     def rows(self, lo: int, hi: int) -> "SplitRows":
-        return SplitRows(self.planes[lo:hi], self.inv_scale[lo:hi])
+        return SplitRows(self.planes[lo:hi], self.inv_scale[lo:hi], self.f32[lo:hi] if self.f32 is not None else None)
 
     def float(self) -> torch.Tensor:
-        """Back to fp32 (tests): (hi + lo) * 2^-e."""
+        """Back to fp32: the twin when there is one, else (hi + lo) * 2^-e (22-23 significant bits)."""
+        if self.f32 is not None:
+            return self.f32
         r, k = self.planes.shape
         h = self.planes.contiguous().view(torch.float16).view(r, k // 8, 2, 8).float()
         return ((h[:, :, 0] + h[:, :, 1]).reshape(r, k)) * self.inv_scale[:, None]
@@ -567,24 +579,30 @@ def split_supported(x: torch.Tensor) -> bool:
             and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and x.shape[0] > 0)
 
 
-def split_rows(x: torch.Tensor) -> SplitRows:
-    """fp32 rows -> split fp16 planes (csrc/gemm_sp16.hip: split_rows_kernel)."""
+def split_rows(x: torch.Tensor, bias: Optional[torch.Tensor] = None, want_bound: bool = False) -> SplitRows:
+    """fp32 rows -> split fp16 planes (csrc/gemm_sp16.hip: split_rows_kernel).  ``want_bound`` (weights): also the device pair
+    (largest Euclidean row norm, largest |bias|)."""
     if not split_supported(x):
         raise EmcidHipError("split_rows: fp32 HBM rows with K contiguous, K % 32 == 0 and 16-byte aligned rows")
     rows, K = x.shape
     planes = torch.empty(rows, K, dtype=torch.int32, device=x.device)
     inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+    bound = None
+    if want_bound:
+        bound = torch.zeros(2, dtype=torch.float32, device=x.device)
+        if bias is not None:
+            bound[1:2] = bias.detach().abs().max()
     _check(load().emcid_split_rows_f16(_ptr(x, torch.float32, "x"), x.stride(0), rows, K, _ptr(planes), planes.stride(0), _ptr(inv),
-                                       _stream(x)), "emcid_split_rows_f16")
-    return SplitRows(planes, inv)
+                                       _ptr(bound), _stream(x)), "emcid_split_rows_f16")
+    return SplitRows(planes, inv, None, bound)
 
 
 def linear_sp(x: SplitRows, w: SplitRows, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
               residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, want_f32: bool = True,
               planes_scale: Optional[torch.Tensor] = None, cfg: int = -1):
     """act(x @ w.T + bias) + residual with both operands given as split fp16 matrices (three f16 MFMAs per k-step, fp32
-    accumulate).  Returns the fp32 result, or — with ``planes_scale`` (per-row 2^e, a bound on the result rows) — a pair
-    (fp32 result | None, SplitRows of the result)."""
+    accumulate).  Returns the fp32 result, or — with ``planes_scale`` ((2, M): per-row 2^e bounding the result rows, and 2^-e) —
+    the result as a SplitRows (its ``f32`` twin too unless ``want_f32=False``)."""
     M, K = x.planes.shape
     N = w.planes.shape[0]
     if w.planes.shape[1] != K or K % 32:
@@ -600,8 +618,8 @@ def linear_sp(x: SplitRows, w: SplitRows, bias: Optional[torch.Tensor] = None, a
             raise EmcidHipError("linear_sp: out must be an (M, N) fp32 row view")
     yp = None
     if planes_scale is not None:
-        if N % 32 or planes_scale.shape != (M,) or not planes_scale.is_contiguous():
-            raise EmcidHipError("linear_sp: planes output needs N % 32 == 0 and a contiguous (M,) scale")
+        if N % 32 or planes_scale.shape != (2, M) or not planes_scale.is_contiguous():
+            raise EmcidHipError("linear_sp: planes output needs N % 32 == 0 and a contiguous (2, M) scale / inverse scale")
         yp = torch.empty(M, N, dtype=torch.int32, device=dev)
     if bias is not None and (bias.shape != (N,) or not bias.is_contiguous()):
         raise EmcidHipError("linear_sp: bias must be a contiguous (N,) vector")
@@ -618,7 +636,7 @@ def linear_sp(x: SplitRows, w: SplitRows, bias: Optional[torch.Tensor] = None, a
         _stream(x.planes)), "emcid_linear_sp16_f32")
     if planes_scale is None:
         return y
-    return y, SplitRows(yp, 1.0 / planes_scale)
+    return SplitRows(yp, planes_scale[1], y)
 
 
 def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], ln: torch.nn.LayerNorm, want_sum: bool = True):
@@ -636,6 +654,79 @@ def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], ln: torch.nn.Layer
                                           _ptr(ln.weight, torch.float32, "gamma"), _ptr(ln.bias, torch.float32, "beta"),
                                           float(ln.eps), rows, cols, _ptr(y), _ptr(z), _stream(a)), "emcid_add_layernorm_f32")
     return (a if b is None else y), z
+
+
+def add_layernorm_sp(a: torch.Tensor, b: Optional[torch.Tensor], ln: torch.nn.LayerNorm, want_sum: bool = True,
+                     want_f32: bool = False, bound: Optional[torch.Tensor] = None):
+    """``add_layernorm`` with the LayerNorm's output as a split-fp16 matrix for the projection that consumes it:
+    returns (a + b | a, SplitRows of LayerNorm(a + b) [with .f32 when ``want_f32``]).  ``bound`` (the consuming weight's
+    ``SplitRows.bound``): the result's ``out_scale`` (2, rows) = the per-row 2^e (and 2^-e) under which that projection may write its
+    own output as planes (``linear_sp(planes_scale=...)``)."""
+    rows, cols = a.shape
+    if a.stride(1) != 1 or (b is not None and (b.stride(1) != 1 or b.shape != a.shape)):
+        raise EmcidHipError("add_layernorm_sp: (rows, cols) operands with unit column stride")
+    if ln.weight is None or ln.bias is None or tuple(ln.normalized_shape) != (cols,) or cols % 32 or cols > 2048:
+        raise EmcidHipError("add_layernorm_sp: LayerNorm over the last dimension with affine parameters, cols % 32 == 0, <= 2048")
+    dev = a.device
+    y = torch.empty(rows, cols, dtype=torch.float32, device=dev) if (b is not None and want_sum) else None
+    z = torch.empty(rows, cols, dtype=torch.float32, device=dev) if want_f32 else None
+    planes = torch.empty(rows, cols, dtype=torch.int32, device=dev)
+    inv = torch.empty(rows, dtype=torch.float32, device=dev)
+    out_scale = torch.empty(2, rows, dtype=torch.float32, device=dev) if bound is not None else None
+    _check(load().emcid_add_layernorm_sp16(_ptr(a, torch.float32, "a"), a.stride(0), _ptr(b, torch.float32, "b"),
+                                           b.stride(0) if b is not None else 0,
+                                           _ptr(ln.weight, torch.float32, "gamma"), _ptr(ln.bias, torch.float32, "beta"),
+                                           float(ln.eps), rows, cols, _ptr(y), _ptr(z), _ptr(planes), planes.stride(0), _ptr(inv),
+                                           _ptr(bound, torch.float32, "bound"), _ptr(out_scale), _stream(a)),
+           "emcid_add_layernorm_sp16")
+    return (a if b is None else y), SplitRows(planes, inv, z, None, out_scale)
+
+
+def embed_layernorm_sp(tok_emb: torch.Tensor, pos_emb: torch.Tensor, token: torch.Tensor, position: torch.Tensor,
+                       ln: torch.nn.LayerNorm):
+    """``embed_layernorm`` with the LayerNorm's output as a split-fp16 matrix: (embeddings, SplitRows)."""
+    rows, cols = token.numel(), tok_emb.shape[1]
+    if tok_emb.stride(1) != 1 or pos_emb.stride(1) != 1 or pos_emb.shape[1] != cols or position.numel() != rows:
+        raise EmcidHipError("embed_layernorm_sp: embedding tables with unit column stride and one index pair per row")
+    if ln.weight is None or ln.bias is None or tuple(ln.normalized_shape) != (cols,) or cols % 32 or cols > 2048:
+        raise EmcidHipError("embed_layernorm_sp: LayerNorm over the last dimension with affine parameters, cols % 32 == 0, <= 2048")
+    y = torch.empty(rows, cols, dtype=torch.float32, device=tok_emb.device)
+    planes = torch.empty(rows, cols, dtype=torch.int32, device=tok_emb.device)
+    inv = torch.empty(rows, dtype=torch.float32, device=tok_emb.device)
+    _check(load().emcid_embed_layernorm_sp16(_ptr(tok_emb, torch.float32, "tok_emb"), tok_emb.stride(0), tok_emb.shape[0],
+                                             _ptr(pos_emb, torch.float32, "pos_emb"), pos_emb.stride(0), pos_emb.shape[0],
+                                             _ptr(token, torch.int64, "token"), _ptr(position, torch.int32, "position"),
+                                             _ptr(ln.weight, torch.float32, "gamma"), _ptr(ln.bias, torch.float32, "beta"),
+                                             float(ln.eps), rows, cols, _ptr(y), None, _ptr(planes), planes.stride(0), _ptr(inv),
+                                             _stream(tok_emb)), "emcid_embed_layernorm_sp16")
+    return y, SplitRows(planes, inv)
+
+
+def tree_attention_sp_supported(anc: torch.Tensor, H: int, D: int) -> bool:
+    return bool(load().emcid_tree_attention_sp16_supported(anc.shape[1], H, D)) and (H * D) % 32 == 0
+
+
+def tree_attention_sp(q, k, v, anc, depth, H: int, scale=None, rows=None) -> SplitRows:
+    """``tree_attention`` with the result as a split-fp16 matrix for the out-projection (short chains only)."""
+    U, HD = k.shape
+    D = HD // H
+    for t in (q, k, v):
+        if t.stride(1) != 1 or t.shape[1] != HD:
+            raise EmcidHipError("tree_attention_sp: q/k/v must be row-major")
+    if k.stride(0) != v.stride(0):
+        raise EmcidHipError("tree_attention_sp: k and v must share a leading dimension")
+    n = U if rows is None else rows.numel()
+    if q.shape[0] != n:
+        raise EmcidHipError(f"tree_attention_sp: {q.shape[0]} query rows for {n} query nodes")
+    planes = torch.empty(n, HD, dtype=torch.int32, device=q.device)
+    inv = torch.empty(n, dtype=torch.float32, device=q.device)
+    scale = float(D ** -0.5 if scale is None else scale)
+    _check(load().emcid_tree_attention_sp16(
+        _ptr(q, torch.float32, "q"), q.stride(0), _ptr(k, torch.float32, "k"), _ptr(v, torch.float32, "v"), k.stride(0),
+        _ptr(anc, torch.int32, "anc"), anc.stride(0), _ptr(depth, torch.int32, "depth"),
+        _ptr(rows, torch.int32, "rows") if rows is not None else None, n, H, D, scale, _ptr(planes), planes.stride(0), _ptr(inv),
+        _stream(q)), "emcid_tree_attention_sp16")
+    return SplitRows(planes, inv)
 
 
 def embed_layernorm(tok_emb: torch.Tensor, pos_emb: torch.Tensor, token: torch.Tensor, position: torch.Tensor,

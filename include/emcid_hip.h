@@ -120,9 +120,11 @@ int emcid_linear_ws_f32(const float* X, int64_t ldx, const float* W, int64_t ldw
  * row's largest magnitude lands in [2^14, 2^15)) as hi = fp16(x 2^e), lo = fp16(x 2^e - hi), i.e. x = (hi + lo) 2^-e to 22-23
  * significant bits.  `planes`: one 4-byte unit per element like the fp32 matrix (leading dimension ldp in those units, % 4 == 0);
  * inside a row, groups of 8 consecutive k as [hi k..k+7 (16 bytes)][lo k..k+7 (16 bytes)].  `inv_scale[r]` = 2^-e_r.
- * emcid_split_rows_f16 converts fp32 rows (nn.Linear weights once per weight version, activations once per producer). */
+ * emcid_split_rows_f16 converts fp32 rows (nn.Linear weights once per weight version, activations once per producer).
+ * max_row_norm (optional, one float the CALLER zeroed): raised to the largest Euclidean norm of a row (x 1.0001) — what
+ * emcid_add_layernorm_sp16 needs of a weight to bound the rows of the projection's output. */
 int emcid_split_rows_f16(const float* X, int64_t ldx, int64_t rows, int64_t K, void* planes, int64_t ldp, float* inv_scale,
-                         void* stream);
+                         float* max_row_norm, void* stream);
 
 /* Y[M,N] = act(X W^T + bias) + residual like emcid_linear_f32 (the same nn.Linear calls of CLIPTextModel.forward,
  * emcid/compute_z.py:2296-2316), with X [M,K] and W [N,K] given as split matrices: three v_mfma_f32_32x32x16_f16 per k-step
@@ -135,6 +137,28 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
                           const float* w_inv_scale, const float* bias, const float* residual, int64_t ldr, float* Y, int64_t ldy,
                           void* Yp, int64_t ldp, const float* y_scale, int64_t M, int64_t N, int64_t K, int act, int cfg,
                           void* stream);
+
+/* Producers that write their result straight as a split-fp16 matrix for the projection that consumes it (no fp32 round trip
+ * through HBM, no separate split pass):
+ *  - emcid_add_layernorm_sp16 / emcid_embed_layernorm_sp16: emcid_add_layernorm_f32 / emcid_embed_layernorm_f32 with z as planes
+ *    [rows, cols] + inv_scale [rows] under the row's own scale (z itself optional, NULL = not written); cols % 8 == 0, <= 2048.
+ *    bound = {largest Euclidean row norm of the consuming projection's weight (emcid_split_rows_f16's max_row_norm), largest
+ *    |bias|} (device, optional): then out_scale[r] = 2^e (and out_scale[rows + r] = 2^-e: 2 rows floats) with
+ *    (|z_r| bound[0] + bound[1]) 2^e in [2^14, 2^15) — the y_scale
+ *    under which emcid_linear_sp16_f32 may write act(z W^T + b) as planes (|act(t)| <= |t| for quick_gelu, erf-gelu, none).
+ *  - emcid_tree_attention_sp16: emcid_tree_attention_f32 with the [n_rows, H D] result as planes + inv_scale; chains of at most
+ *    16 nodes, D % 8 == 0 (emcid_tree_attention_sp16_supported). */
+int emcid_add_layernorm_sp16(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gamma, const float* beta,
+                             float eps, int64_t rows, int64_t cols, float* y, float* z, void* planes, int64_t ldp,
+                             float* inv_scale, const float* bound, float* out_scale, void* stream);
+int emcid_embed_layernorm_sp16(const float* tok, int64_t ld_tok, int64_t n_tok, const float* pos, int64_t ld_pos, int64_t n_pos,
+                               const int64_t* token, const int* position, const float* gamma, const float* beta, float eps,
+                               int64_t rows, int64_t cols, float* y, float* z, void* planes, int64_t ldp, float* inv_scale,
+                               void* stream);
+int emcid_tree_attention_sp16_supported(int64_t anc_ld, int64_t H, int64_t D);
+int emcid_tree_attention_sp16(const float* q, int64_t ldq, const float* k, const float* v, int64_t ld, const int* anc,
+                              int64_t anc_ld, const int* depth, const int* rows, int64_t n_rows, int64_t H, int64_t D, float scale,
+                              void* planes, int64_t ldp, float* inv_scale, void* stream);
 
 /* y = a + b ; z = LayerNorm(y) * gamma + beta over the last dimension (biased variance, eps inside the root, as
  * torch.nn.LayerNorm) — the residual add and the LayerNorm after it of every block of the same hooked forward, one

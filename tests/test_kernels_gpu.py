@@ -709,7 +709,7 @@ def test_split_rows_keeps_22_bits_under_a_per_row_scale():
 
 @pytest.mark.parametrize("cfg", [-1, 0, 4, 1, 5, 2, 6, 3, 7])
 @pytest.mark.parametrize("M,K,N", [(6400, 768, 2304), (6400, 3072, 768), (1000, 3072, 768), (640, 768, 3072), (300, 1280, 1280),
-                                   (129, 96, 257), (37, 2048, 200), (256, 32, 32)])
+                                   (129, 96, 257), (37, 2048, 200), (256, 32, 32), (330, 192, 130)])
 def test_linear_sp16_vs_torch(M, K, N, cfg):
     """emcid_linear_sp16_f32 against the fp64 product at the UNCHANGED tolerance of the exact-f32 kernel's test
     (test_linear_f32_vs_torch): every tile form, ragged edges, the fused epilogues, the split-fp16 output for the next
@@ -747,10 +747,71 @@ def test_linear_sp16_vs_torch(M, K, N, cfg):
         # the result as a split matrix under a caller-given bound: the Cauchy-Schwarz bound the forward uses
         bound = x.norm(dim=1) * w.norm(dim=1).max() + b.abs().max()
         ps = torch.exp2(14 - torch.ceil(torch.log2(bound)))
-        yf, yp = hip.linear_sp(xs, ws_, b, act=hip.ACT_QUICK_GELU, planes_scale=ps, cfg=cfg)
-        assert torch.equal(yf, yq)
-        back = yp.float()
+        ps2 = torch.stack([ps, 1.0 / ps]).contiguous()
+        yp = hip.linear_sp(xs, ws_, b, act=hip.ACT_QUICK_GELU, planes_scale=ps2, cfg=cfg)
+        assert torch.equal(yp.f32, yq)
+        back = hip.SplitRows(yp.planes, yp.inv_scale).float()
         # 2^-22 of the element, or the fp16 floor under the bound's scale
         assert bool(((back - yq).abs() <= torch.maximum(yq.abs() * 2.0 ** -21, (2.0 ** -24 / ps)[:, None])).all())
-        _, yp2 = hip.linear_sp(xs, ws_, b, act=hip.ACT_QUICK_GELU, planes_scale=ps, want_f32=False, cfg=cfg)
-        assert torch.equal(yp2.planes, yp.planes)
+        yp2 = hip.linear_sp(xs, ws_, b, act=hip.ACT_QUICK_GELU, planes_scale=ps2, want_f32=False, cfg=cfg)
+        assert yp2.f32 is None and torch.equal(yp2.planes, yp.planes)
+
+
+def test_producers_write_split_rows_directly():
+    """LayerNorm (with and without the residual add, with the embedding gather) and tree attention writing their result as a
+    split-fp16 matrix: the planes are exactly what emcid_split_rows_f16 makes of the fp32 kernel's result, and the scale the
+    LayerNorm hands to the consuming projection bounds that projection's rows."""
+    g = torch.Generator().manual_seed(11)
+    rows, cols = 777, 768
+    a = torch.randn(rows, cols, generator=g).to(DEV) * 3
+    b = torch.randn(rows, cols, generator=g).to(DEV)
+    ln = torch.nn.LayerNorm(cols).to(DEV)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(cols, generator=g).abs() + 0.2)
+        ln.bias.copy_(torch.randn(cols, generator=g) * 0.1)
+    w = (torch.randn(3072, cols, generator=g) * 0.05).to(DEV)
+    wb = torch.randn(3072, generator=g).to(DEV)
+    wsp = hip.split_rows(w, wb, want_bound=True)
+    assert abs(wsp.bound[0].item() / w.norm(dim=1).max().item() - 1.0001) < 1e-5 and wsp.bound[1].item() == wb.abs().max().item()
+    for bb in (b, None):
+        y_ref, z_ref = hip.add_layernorm(a, bb, ln)
+        y, zsp = hip.add_layernorm_sp(a, bb, ln, want_f32=True, bound=wsp.bound)
+        assert torch.equal(y, y_ref) and torch.equal(zsp.f32, z_ref)
+        ref_sp = hip.split_rows(z_ref)
+        assert torch.equal(zsp.planes, ref_sp.planes) and torch.equal(zsp.inv_scale, ref_sp.inv_scale)
+        # the projection's rows stay under the bound the LayerNorm derived: |act(z W^T + b)| * 2^e < 2^15
+        out = F.linear(z_ref, w, wb)
+        assert bool(((out.abs() * zsp.out_scale[0][:, None]) < 2.0 ** 15).all())
+        assert torch.equal(zsp.out_scale[0] * zsp.out_scale[1], torch.ones(rows, device=DEV))
+        _, zsp2 = hip.add_layernorm_sp(a, bb, ln)
+        assert zsp2.f32 is None and zsp2.out_scale is None and torch.equal(zsp2.planes, ref_sp.planes)
+        hq = hip.linear_sp(zsp, wsp, wb, act=hip.ACT_QUICK_GELU, planes_scale=zsp.out_scale)
+        assert (hq.f32 - hip.linear(z_ref, w, wb, act=hip.ACT_QUICK_GELU)).abs().max().item() <= 3e-6 * out.abs().max().item()
+    # embedding gather + LayerNorm
+    tok_e = torch.randn(500, cols, generator=g).to(DEV)
+    pos_e = torch.randn(16, cols, generator=g).to(DEV)
+    token = torch.randint(0, 500, (rows,), generator=g).to(DEV)
+    pos = torch.randint(0, 16, (rows,), generator=g).int().to(DEV)
+    y_ref, z_ref = hip.embed_layernorm(tok_e, pos_e, token, pos, ln)
+    y, zsp = hip.embed_layernorm_sp(tok_e, pos_e, token, pos, ln)
+    ref_sp = hip.split_rows(z_ref)
+    assert torch.equal(y, y_ref) and torch.equal(zsp.planes, ref_sp.planes) and torch.equal(zsp.inv_scale, ref_sp.inv_scale)
+    # tree attention over a small trie: chains of up to 7 and up to 13 nodes, all nodes and a row subset
+    for S in (7, 13):
+        U, H, D = 300, 12, 64
+        depth = torch.randint(0, S, (U,), generator=g).int()
+        anc = torch.zeros(U, S, dtype=torch.int32)
+        for u in range(U):
+            anc[u, :depth[u]] = torch.randint(0, U, (int(depth[u]),), generator=g).int()
+            anc[u, depth[u]] = u
+        q, k, v = (torch.randn(U, H * D, generator=g).to(DEV) for _ in range(3))
+        anc_d, depth_d = anc.to(DEV), depth.to(DEV)
+        assert hip.tree_attention_sp_supported(anc_d, H, D)
+        ref = hip.tree_attention(q, k, v, anc_d, depth_d, H)
+        sp = hip.tree_attention_sp(q, k, v, anc_d, depth_d, H)
+        ref_sp = hip.split_rows(ref)
+        assert torch.equal(sp.planes, ref_sp.planes) and torch.equal(sp.inv_scale, ref_sp.inv_scale)
+        rows_sel = torch.tensor([5, 17, 17, 299, 0], dtype=torch.int32, device=DEV)
+        ref = hip.tree_attention(q[rows_sel.long()], k, v, anc_d, depth_d, H, rows=rows_sel)
+        sp = hip.tree_attention_sp(q[rows_sel.long()], k, v, anc_d, depth_d, H, rows=rows_sel)
+        assert torch.equal(sp.planes, hip.split_rows(ref).planes)
