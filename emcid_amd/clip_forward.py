@@ -147,6 +147,78 @@ class ClipTextGraph:
     position_embedding: torch.nn.Embedding
     layers: List[ClipLayer]
     final_layer_norm: Optional[torch.nn.LayerNorm] = None
+    native: Optional[object] = None        # NativeLayers: the layers as the C structs of the layer runner (csrc/clip_layers.hip)
+
+
+NATIVE_RUNNER = os.environ.get("EMCID_NATIVE_LAYERS", "1") != "0"     # 0: one ctypes call per launch (the A/B path)
+
+
+class NativeLayers:
+    """The encoder's layers as an array of ``emcid_clip_layer_sp16`` for the native layer runner: ONE C call per run of layers
+    instead of one ctypes call (and two tensor allocations) per launch.  ``ready(lo, hi)`` (re)fills the entries of layers
+    [lo, hi) whose weights changed (ClipLayer.split_of's version check) and says whether all of them can take the runner: split
+    weights for q | k | v (stacked), out, fc1, fc2; affine LayerNorms the fused kernel takes; an activation the GEMM epilogue
+    knows.  The tensors the structs point to are kept alive here."""
+
+    def __init__(self, graph: "ClipTextGraph"):
+        self.n = len(graph.layers)
+        self.array = (hip.ClipLayerSp16 * self.n)()
+        self.sigs = [None] * self.n
+        self.keep = [None] * self.n
+        l0 = graph.layers[0]
+        self.h, self.d, self.heads, self.scale = l0.q.out_features, l0.fc1.out_features, l0.heads, l0.scale
+
+    def _fill(self, i: int, layer: ClipLayer) -> bool:
+        if layer.qkv_w is None or layer.act_code is None and layer.act is not None:
+            return False
+        if not (_fusable(layer.ln1) and _fusable(layer.ln2) and _sp_ln_ok(layer.ln1) and _sp_ln_ok(layer.ln2)):
+            return False
+        if (layer.q.out_features, layer.fc1.out_features, layer.heads, layer.scale) != (self.h, self.d, self.heads, self.scale):
+            return False
+        sps = [layer.split_of(n) for n in ("qkv", "out", "fc1", "fc2")]
+        if any(sp is None for sp in sps):
+            return False
+        biases = [layer.qkv_b, layer.out.bias, layer.fc1.bias, layer.fc2.bias]
+        if any(b is not None and not (b.is_contiguous() and b.dtype == torch.float32 and b.is_cuda) for b in biases):
+            return False
+        lns = [layer.ln1.weight, layer.ln1.bias, layer.ln2.weight, layer.ln2.bias]
+        if any(t.dtype != torch.float32 or not t.is_contiguous() for t in lns):
+            return False
+        sig = tuple((sp.planes.data_ptr(), sp.inv_scale.data_ptr(), sp.bound.data_ptr()) for sp in sps) + \
+            tuple(t.data_ptr() if t is not None else 0 for t in biases + lns) + (layer.act_code,)
+        if self.sigs[i] == sig:
+            return True
+        e = self.array[i]
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        e.ln1_gamma, e.ln1_beta, e.ln2_gamma, e.ln2_beta = (ptr(t) for t in lns)
+        e.ln1_eps, e.ln2_eps = float(layer.ln1.eps), float(layer.ln2.eps)
+        for name, sp, b in zip(("qkv", "out", "fc1", "fc2"), sps, biases):
+            setattr(e, name + "_planes", ptr(sp.planes))
+            setattr(e, name + "_inv_scale", ptr(sp.inv_scale))
+            setattr(e, name + "_bias", ptr(b))
+        e.fc1_bound = ptr(sps[2].bound)
+        e.act = int(layer.act_code) if layer.act is not None else 0
+        self.keep[i] = (sps, biases, lns)
+        self.sigs[i] = sig
+        return True
+
+    def ready(self, graph: "ClipTextGraph", lo: int, hi: int) -> bool:
+        if not (NATIVE_RUNNER and SPLIT_GEMM and OWN_GEMM):
+            return False
+        return all(self._fill(i, graph.layers[i]) for i in range(lo, hi))
+
+
+def native_of(graph: ClipTextGraph, trie: "TokenTrie", lo: int, hi: int) -> Optional[NativeLayers]:
+    """The graph's NativeLayers when layers [lo, hi) and this trie can take the native runner, else None."""
+    if not (NATIVE_RUNNER and SPLIT_GEMM and OWN_GEMM) or hi <= lo or not graph.layers:
+        return None
+    if graph.native is None:
+        graph.native = NativeLayers(graph)
+    nat = graph.native
+    if trie.anc.dtype != torch.int32 or trie.depth.dtype != torch.int32 or \
+            not hip.tree_attention_sp_supported(trie.anc, nat.heads, nat.h // nat.heads):
+        return None
+    return nat if nat.ready(graph, lo, hi) else None
 
 
 def discover(text_encoder, layer_module_tmp: str) -> ClipTextGraph:
@@ -612,6 +684,16 @@ def run_prefix(graph: ClipTextGraph, trie: TokenTrie, stop: int):
             sp0 = graph.layers[0].split_of("qkv") if graph.layers[0].qkv_w is not None else None
             if sp0 is not None and _sp_ln_ok(ln0):
                 hs, x_ln1 = hip.embed_layernorm_sp(te.weight, pe.weight, trie.token, trie.depth, ln0)
+                nat = native_of(graph, trie, 0, stop)
+                if nat is not None:
+                    # every layer of the prefix in ONE C call (csrc/clip_layers.hip), in place on hs / the LN1 planes
+                    nxt = graph.layers[stop].ln1 if stop < len(graph.layers) else None
+                    if nxt is not None and not (_fusable(nxt) and _sp_ln_ok(nxt) and graph.layers[stop].split_of("qkv") is not None):
+                        nxt = None
+                    hip.clip_layers(nat.array, 0, stop, hs.shape[0], nat.h, nat.d, nat.heads, nat.scale, trie.anc, trie.depth,
+                                    hs, x_ln1, nxt)
+                    LAST_PATHS["native_layers"] = LAST_PATHS.get("native_layers", 0) + stop
+                    return hs, (x_ln1 if nxt is not None else None)
             else:
                 hs, x_ln1 = hip.embed_layernorm(te.weight, pe.weight, trie.token, trie.depth, ln0)
         else:
@@ -662,8 +744,19 @@ def run_layers_multi(graph: ClipTextGraph, tries: Sequence[TokenTrie], states, s
         for i in range(start, upto + 1):
             layer = graph.layers[i]
             xs, mids = [], []
+            nats = []
             for trie, (hs, x_ln1) in zip(tries, states):
                 rows = trie.query_rows if (last_rows_only and i == upto) else None
+                nat = native_of(graph, trie, i, i + 1) if isinstance(x_ln1, hip.SplitRows) else None
+                nats.append(nat)
+                if nat is not None:
+                    # attention block + fc1 in ONE C call (csrc/clip_layers.hip)
+                    mid, x = hip.clip_layer_head(nat.array, i, hs.shape[0], nat.h, nat.d, nat.heads, nat.scale, trie.anc,
+                                                 trie.depth, rows, hs, x_ln1, want_f32=on_fc2 is not None)
+                    LAST_PATHS["native_layers"] = LAST_PATHS.get("native_layers", 0) + 1
+                    xs.append(x)
+                    mids.append(mid)
+                    continue
                 mid, ln2_mid = layer_attention_block(layer, hs, trie, rows, x_ln1)
                 xs.append(mlp_hidden(layer, ln2_mid, want_f32=on_fc2 is not None))
                 mids.append(mid)
@@ -672,8 +765,18 @@ def run_layers_multi(graph: ClipTextGraph, tries: Sequence[TokenTrie], states, s
             # the callback gets the residual streams too and returns fc2(x) + mid (the add in its GEMM's epilogue).
             nxt = graph.layers[i + 1].ln1 if i < upto else None
             summed = False
+            tail_states = None
             if i in by_cb or not OWN_GEMM:
                 outs = [None if i in by_cb else layer.fc2(x.float() if isinstance(x, hip.SplitRows) else x) for x in xs]
+            elif on_fc2 is None and all(nat is not None for nat in nats):
+                # fc2 + residual add + the next layer's LN1 in ONE C call
+                nl = nxt if nxt is not None and _fusable(nxt) and _sp_ln_ok(nxt) and \
+                    graph.layers[i + 1].qkv_w is not None and graph.layers[i + 1].split_of("qkv") is not None else None
+                tail_states = [hip.clip_layer_tail(nat.array, i, nat.h, nat.d, x, mid, nl) for nat, x, mid in zip(nats, xs, mids)]
+                if nl is None and nxt is not None:
+                    tail_states = [(hs, _next_ln1(graph, i + 1, hs, nxt)) for hs, _ in tail_states]
+                outs = [hs for hs, _ in tail_states]
+                summed = True
             else:
                 fsp = layer.split_of("fc2")
                 outs = [linear(x, layer.fc2.weight, layer.fc2.bias, residual=mid, wsp=fsp) for x, mid in zip(xs, mids)]
@@ -687,7 +790,9 @@ def run_layers_multi(graph: ClipTextGraph, tries: Sequence[TokenTrie], states, s
                     outs = on_fc2(i, cb_xs, outs)
                 if outs is None:
                     return None
-            if summed:
+            if tail_states is not None:
+                states = tail_states
+            elif summed:
                 states = [(hs, _next_ln1(graph, i + 1, hs, nxt)) for hs in outs]
             elif nxt is not None and _fusable(nxt):
                 states = [hip.add_layernorm(mid, out, nxt) for mid, out in zip(mids, outs)]

@@ -1,0 +1,177 @@
+// Native layer runner of the prefix-trie forward (emcid_amd/clip_forward.py) on the split-fp16 projections: ONE C call issues all
+// launches of a run of CLIP text-encoder layers — the loop the reference gets from CLIPTextModel.forward
+// (emcid/compute_z.py:2296-2316 runs the encoder; emcid/emcid_main.py:981-1073 is the layer loop around it) — instead of one
+// ctypes call, two tensor allocations and ~15-20 us of interpreter time per launch.  A 100-concept edit is ~150 launches whose
+// device time is under 2 ms; a 1 000-concept edit's forward outruns a Python launcher as well since the projections moved to the
+// 16-bit matrix pipe.  Same kernels, same order, same arguments as the Python path: the results are bit-identical to it.
+//
+// Per layer (rows = trie nodes, h = hidden, d = intermediate; x = LN1(hs) arrives as split-fp16 planes):
+//     qkv   = x Wqkv^T + b                       emcid_linear_sp16_f32            fp32 [rows, 3h]
+//     ctx   = tree attention(q, k, v)            emcid_tree_attention_sp16        planes [sel, h]
+//     mid   = ctx Wo^T + bo + hs                 emcid_linear_sp16_f32            fp32 [sel, h]
+//     z     = LN2(mid)                           emcid_add_layernorm_sp16         planes [sel, h] + fc1's output scale
+//     f     = act(z W1^T + b1)                   emcid_linear_sp16_f32            planes [sel, d] (+ fp32 twin for the keys)
+//     hs'   = f W2^T + b2 + mid                  emcid_linear_sp16_f32            fp32 [sel, h]
+//     x'    = LN1_next(hs')                      emcid_add_layernorm_sp16         planes [sel, h]
+// (sel = all rows, or the query rows of the last edited layer: k | v for every node, q / attention / MLP for the selected ones).
+#include "common.h"
+
+namespace emcid {
+
+// dst[r] = src[idx[r]] for rows of `row_bytes` bytes (a multiple of 16); one workgroup per destination row
+__global__ __launch_bounds__(256) void gather_rows16_kernel(const unsigned char* __restrict__ src, int64_t src_stride,
+                                                             const int* __restrict__ idx, unsigned char* __restrict__ dst,
+                                                             int64_t dst_stride, int row_bytes) {
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const int64_t r = blockIdx.x;
+    const v4u* s = reinterpret_cast<const v4u*>(src + (int64_t)idx[r] * src_stride);
+    v4u* d = reinterpret_cast<v4u*>(dst + r * dst_stride);
+    for (int i = threadIdx.x; i < row_bytes / 16; i += 256) d[i] = s[i];
+}
+
+__global__ __launch_bounds__(256) void gather_f32_kernel(const float* __restrict__ src, const int* __restrict__ idx,
+                                                          float* __restrict__ dst, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+struct ClipWs {
+    float* qkv;            // [rows, 3h]
+    float* mid;            // [rows, h]
+    uint32_t* ctx_p;       // [rows, h] planes
+    float* ctx_s;          // [rows]
+    uint32_t* z_p;         // [rows, h]
+    float* z_s;            // [rows]
+    float* f_scale;        // [2, rows]
+    uint32_t* f_p;         // [rows, d]
+    uint32_t* xq_p;        // [rows, h]  gathered LN1 rows (query-row form)
+    float* xq_s;           // [rows]
+    float* hs_q;           // [rows, h]  gathered residual rows (query-row form)
+};
+
+inline int64_t clip_ws_bytes(int64_t rows, int64_t h, int64_t d) {
+    const int64_t r = round_up(rows, 64);
+    return 4 * (r * 3 * h + r * h + r * h + r + r * h + r + 2 * r + r * d + r * h + r + r * h) + 16 * 16;
+}
+
+inline bool clip_ws_carve(void* base, int64_t bytes, int64_t rows, int64_t h, int64_t d, ClipWs& w) {
+    if (base == nullptr || !aligned16(base) || bytes < clip_ws_bytes(rows, h, d)) return false;
+    const int64_t r = round_up(rows, 64);
+    char* p = (char*)base;
+    auto take = [&](int64_t n4) { char* q = p; p += round_up(4 * n4, 16); return q; };
+    w.qkv = (float*)take(r * 3 * h);
+    w.mid = (float*)take(r * h);
+    w.ctx_p = (uint32_t*)take(r * h);
+    w.ctx_s = (float*)take(r);
+    w.z_p = (uint32_t*)take(r * h);
+    w.z_s = (float*)take(r);
+    w.f_scale = (float*)take(2 * r);
+    w.f_p = (uint32_t*)take(r * d);
+    w.xq_p = (uint32_t*)take(r * h);
+    w.xq_s = (float*)take(r);
+    w.hs_q = (float*)take(r * h);
+    return true;
+}
+
+}  // namespace emcid
+
+using namespace emcid;
+
+extern "C" {
+
+int64_t emcid_clip_workspace_bytes(int64_t rows, int64_t h, int64_t d) { return clip_ws_bytes(rows, h, d); }
+
+/* attention block + fc1 of one layer.  rows_sel == NULL: every node (n_sel = rows).  Outputs: mid [n_sel, h] fp32 (the residual
+ * stream after the attention block), f_planes [n_sel, d] + f_scale [2, n_sel] (scale and inverse scale of the planes' rows),
+ * f_f32 [n_sel, d] (optional fp32 twin of fc2's input: the keys). */
+int emcid_clip_layer_head_sp16(const emcid_clip_layer_sp16* L, int64_t rows, int64_t h, int64_t d, int64_t heads, float attn_scale,
+                               const int* anc, int64_t anc_ld, const int* depth, const int* rows_sel, int64_t n_sel,
+                               const float* hs, const void* x_planes, const float* x_inv_scale, float* mid, void* f_planes,
+                               float* f_scale, float* f_f32, void* workspace, int64_t workspace_bytes, void* stream) {
+    EMCID_CHECK_ARG(L && rows > 0 && h > 0 && d > 0 && heads > 0 && h % heads == 0 && anc && depth && hs && x_planes && x_inv_scale);
+    EMCID_CHECK_ARG(mid && f_planes && f_scale && n_sel > 0 && (rows_sel != nullptr || n_sel == rows) && h % 32 == 0 && d % 32 == 0);
+    ClipWs w;
+    if (!clip_ws_carve(workspace, workspace_bytes, rows, h, d, w)) return fail(EMCID_ERR_BAD_ARG, __func__, "workspace too small or misaligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t D = h / heads;
+    const float* q;
+    int64_t ldq;
+    const float* res;
+    if (rows_sel == nullptr) {
+        EMCID_TRY(emcid_linear_sp16_f32(x_planes, h, x_inv_scale, L->qkv_planes, h, L->qkv_inv_scale, L->qkv_bias, nullptr, 0, w.qkv,
+                                        3 * h, nullptr, 0, nullptr, rows, 3 * h, h, 0, -1, stream));
+        q = w.qkv, ldq = 3 * h, res = hs;
+    } else {
+        // k | v for every node (columns h .. 3h of the stacked projection), q for the selected rows only
+        EMCID_TRY(emcid_linear_sp16_f32(x_planes, h, x_inv_scale, (const uint32_t*)L->qkv_planes + h * h, h, L->qkv_inv_scale + h,
+                                        L->qkv_bias ? L->qkv_bias + h : nullptr, nullptr, 0, w.qkv + h, 3 * h, nullptr, 0, nullptr,
+                                        rows, 2 * h, h, 0, -1, stream));
+        {
+            ScopedProf sp(KC_MISC, st);
+            hipLaunchKernelGGL(gather_rows16_kernel, dim3((unsigned)n_sel), dim3(256), 0, st, (const unsigned char*)x_planes, 4 * h,
+                               rows_sel, (unsigned char*)w.xq_p, 4 * h, (int)(4 * h));
+            hipLaunchKernelGGL(gather_f32_kernel, dim3((unsigned)((n_sel + 255) / 256)), dim3(256), 0, st, x_inv_scale, rows_sel,
+                               w.xq_s, (int)n_sel);
+            hipLaunchKernelGGL(gather_rows16_kernel, dim3((unsigned)n_sel), dim3(256), 0, st, (const unsigned char*)hs, 4 * h,
+                               rows_sel, (unsigned char*)w.hs_q, 4 * h, (int)(4 * h));
+            EMCID_CHECK_LAUNCH();
+        }
+        // q into columns 0 .. h of the first n_sel rows of the same buffer (leading dimension 3h: k | v of those rows stay intact)
+        EMCID_TRY(emcid_linear_sp16_f32(w.xq_p, h, w.xq_s, L->qkv_planes, h, L->qkv_inv_scale, L->qkv_bias, nullptr, 0, w.mid, h,
+                                        nullptr, 0, nullptr, n_sel, h, h, 0, -1, stream));
+        q = w.mid, ldq = h, res = w.hs_q;
+    }
+    EMCID_TRY(emcid_tree_attention_sp16(q, ldq, w.qkv + h, w.qkv + 2 * h, 3 * h, anc, anc_ld, depth, rows_sel, n_sel, heads, D,
+                                        attn_scale, w.ctx_p, h, w.ctx_s, stream));
+    EMCID_TRY(emcid_linear_sp16_f32(w.ctx_p, h, w.ctx_s, L->out_planes, h, L->out_inv_scale, L->out_bias, res, h, mid, h, nullptr,
+                                    0, nullptr, n_sel, h, h, 0, -1, stream));
+    EMCID_TRY(emcid_add_layernorm_sp16(mid, h, nullptr, 0, L->ln2_gamma, L->ln2_beta, L->ln2_eps, n_sel, h, nullptr, nullptr, w.z_p,
+                                       h, w.z_s, L->fc1_bound, w.f_scale, stream));
+    // the LayerNorm kernel writes scale / inverse scale at [0, n) and [n, 2n) of ITS row count: hand them on in the caller's layout
+    if (f_scale != w.f_scale)
+        if (hipMemcpyAsync(f_scale, w.f_scale, 2 * n_sel * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return fail(EMCID_ERR_HIP, __func__, "hipMemcpyAsync");
+    EMCID_TRY(emcid_linear_sp16_f32(w.z_p, h, w.z_s, L->fc1_planes, h, L->fc1_inv_scale, L->fc1_bias, nullptr, 0, f_f32, d,
+                                    f_planes, d, w.f_scale, n_sel, d, h, L->act, -1, stream));
+    return EMCID_OK;
+}
+
+/* fc2 + residual add of one layer, then (next_ln_gamma != NULL) LN1 of the next layer as planes.
+ * hs_out = f W2^T + b2 + mid;  x_planes / x_inv_scale = LayerNorm_next(hs_out). */
+int emcid_clip_layer_tail_sp16(const emcid_clip_layer_sp16* L, int64_t n, int64_t h, int64_t d, const void* f_planes,
+                               const float* f_inv_scale, const float* mid, float* hs_out, const float* next_ln_gamma,
+                               const float* next_ln_beta, float next_ln_eps, void* x_planes, float* x_inv_scale, void* stream) {
+    EMCID_CHECK_ARG(L && n > 0 && h % 32 == 0 && d % 32 == 0 && f_planes && f_inv_scale && mid && hs_out);
+    EMCID_TRY(emcid_linear_sp16_f32(f_planes, d, f_inv_scale, L->fc2_planes, d, L->fc2_inv_scale, L->fc2_bias, mid, h, hs_out, h,
+                                    nullptr, 0, nullptr, n, h, d, 0, -1, stream));
+    if (next_ln_gamma != nullptr) {
+        EMCID_CHECK_ARG(next_ln_beta && x_planes && x_inv_scale);
+        EMCID_TRY(emcid_add_layernorm_sp16(hs_out, h, nullptr, 0, next_ln_gamma, next_ln_beta, next_ln_eps, n, h, nullptr, nullptr,
+                                           x_planes, h, x_inv_scale, nullptr, nullptr, stream));
+    }
+    return EMCID_OK;
+}
+
+/* A run of whole layers on every node: hs [rows, h] fp32 (in / out, in place), x_planes / x_inv_scale = LN1 of hs for layers[0]
+ * (in) and LN1 of the result under next_ln_* (out; next_ln_gamma == NULL: left as they are). */
+int emcid_clip_layers_sp16(const emcid_clip_layer_sp16* layers, int64_t n_layers, int64_t rows, int64_t h, int64_t d, int64_t heads,
+                           float attn_scale, const int* anc, int64_t anc_ld, const int* depth, float* hs, void* x_planes,
+                           float* x_inv_scale, const float* next_ln_gamma, const float* next_ln_beta, float next_ln_eps,
+                           void* workspace, int64_t workspace_bytes, void* stream) {
+    EMCID_CHECK_ARG(layers && n_layers > 0 && hs && x_planes && x_inv_scale);
+    ClipWs w;
+    if (!clip_ws_carve(workspace, workspace_bytes, rows, h, d, w)) return fail(EMCID_ERR_BAD_ARG, __func__, "workspace too small or misaligned");
+    for (int64_t i = 0; i < n_layers; ++i) {
+        const emcid_clip_layer_sp16* L = layers + i;
+        EMCID_TRY(emcid_clip_layer_head_sp16(L, rows, h, d, heads, attn_scale, anc, anc_ld, depth, nullptr, rows, hs, x_planes,
+                                             x_inv_scale, w.mid, w.f_p, w.f_scale, nullptr, workspace, workspace_bytes, stream));
+        const bool last = i + 1 == n_layers;
+        const float* g = last ? next_ln_gamma : layers[i + 1].ln1_gamma;
+        const float* b = last ? next_ln_beta : layers[i + 1].ln1_beta;
+        const float eps = last ? next_ln_eps : layers[i + 1].ln1_eps;
+        EMCID_TRY(emcid_clip_layer_tail_sp16(L, rows, h, d, w.f_p, w.f_scale + rows, w.mid, hs, g, b, eps, x_planes, x_inv_scale, stream));
+    }
+    return EMCID_OK;
+}
+
+}  // extern "C"

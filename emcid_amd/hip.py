@@ -31,7 +31,8 @@ EXPORTS = [
     "emcid_edit_dual_cols_stage1_f64", "emcid_edit_dual_s", "emcid_edit_dual_u", "emcid_edit_dual_cols_stage2_f64",
     "emcid_apply_update2d_f32", "emcid_linear_f32", "emcid_linear_ws_f32", "emcid_linear_workspace_bytes",
     "emcid_split_rows_f16", "emcid_linear_sp16_f32", "emcid_add_layernorm_sp16", "emcid_embed_layernorm_sp16",
-    "emcid_tree_attention_sp16", "emcid_tree_attention_sp16_supported",
+    "emcid_tree_attention_sp16", "emcid_tree_attention_sp16_supported", "emcid_clip_workspace_bytes",
+    "emcid_clip_layer_head_sp16", "emcid_clip_layer_tail_sp16", "emcid_clip_layers_sp16",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block", "linear"]
@@ -111,6 +112,10 @@ def load():
         "emcid_add_layernorm_sp16": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p, i64, p, p, p, p]),
         "emcid_embed_layernorm_sp16": (i32, [p, i64, i64, p, i64, i64, p, p, p, p, C.c_float, i64, i64, p, p, p, i64, p, p]),
         "emcid_tree_attention_sp16_supported": (i32, [i64, i64, i64]),
+        "emcid_clip_workspace_bytes": (i64, [i64, i64, i64]),
+        "emcid_clip_layer_head_sp16": (i32, [p, i64, i64, i64, i64, f32, p, i64, p, p, i64, p, p, p, p, p, p, p, p, i64, p]),
+        "emcid_clip_layer_tail_sp16": (i32, [p, i64, i64, i64, p, p, p, p, p, p, f32, p, p, p]),
+        "emcid_clip_layers_sp16": (i32, [p, i64, i64, i64, i64, i64, f32, p, i64, p, p, p, p, p, p, f32, p, i64, p]),
         "emcid_tree_attention_sp16": (i32, [p, i64, p, p, i64, p, i64, p, p, i64, i64, i64, f32, p, i64, p, p]),
         "emcid_linear_sp16_f32": (i32, [p, i64, p, p, i64, p, p, p, i64, p, i64, p, i64, p, i64, i64, i64, i32, i32, p]),
         "emcid_add_layernorm_f32": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p]),
@@ -769,6 +774,94 @@ def tree_attention(q, k, v, anc, depth, H: int, scale=None, rows=None):
         _ptr(rows, torch.int32, "rows") if rows is not None else None, n, H, D, scale, _ptr(out), out.stride(0),
         _stream(q)), "emcid_tree_attention_f32")
     return out
+
+
+# ---- native layer runner of the trie forward (csrc/clip_layers.hip) -----------------------------------------------------------
+
+class ClipLayerSp16(C.Structure):
+    """include/emcid_hip.h: emcid_clip_layer_sp16."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "ln1_gamma", "ln1_beta", "ln2_gamma", "ln2_beta", "qkv_planes", "qkv_inv_scale", "qkv_bias", "out_planes",
+        "out_inv_scale", "out_bias", "fc1_planes", "fc1_inv_scale", "fc1_bias", "fc1_bound", "fc2_planes", "fc2_inv_scale",
+        "fc2_bias")] + [("ln1_eps", C.c_float), ("ln2_eps", C.c_float), ("act", C.c_int32), ("reserved", C.c_int32)]
+
+
+_CLIP_WS = {}       # (device index, stream handle, rows, h, d) -> workspace of the layer runner
+
+
+def clip_workspace(dev: torch.device, rows: int, h: int, d: int) -> torch.Tensor:
+    """Launches of one stream run one after the other and may share the runner's scratch buffers."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream,
+           rows, h, d)
+    ws = _CLIP_WS.get(key)
+    if ws is None:
+        if len(_CLIP_WS) >= 16:
+            _CLIP_WS.clear()
+        ws = _CLIP_WS[key] = torch.empty(int(load().emcid_clip_workspace_bytes(rows, h, d)), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def clip_layers(layer_array, first: int, count: int, rows: int, h: int, d: int, heads: int, scale: float, anc: torch.Tensor,
+                depth: torch.Tensor, hs: torch.Tensor, x: "SplitRows", next_ln: Optional[torch.nn.LayerNorm]):
+    """``count`` whole layers starting at ``layer_array[first]`` on every trie node, in place on ``hs`` (rows, h) and on the
+    planes of ``x`` (LN1 of hs in, the next layer's LN1 of the result out when ``next_ln`` is given)."""
+    ws = clip_workspace(hs.device, rows, h, d)
+    if LINEAR_FLOPS["count"]:
+        LINEAR_FLOPS["flops"] += count * 2.0 * rows * h * (4 * h + 2 * d)
+        LINEAR_FLOPS["launches"] += 4 * count
+    base = C.addressof(layer_array) + first * C.sizeof(ClipLayerSp16)
+    g = _ptr(next_ln.weight, torch.float32, "gamma") if next_ln is not None else None
+    b = _ptr(next_ln.bias, torch.float32, "beta") if next_ln is not None else None
+    _check(load().emcid_clip_layers_sp16(C.c_void_p(base), count, rows, h, d, heads, float(scale), _ptr(anc, torch.int32, "anc"),
+                                         anc.stride(0), _ptr(depth, torch.int32, "depth"), _ptr(hs, torch.float32, "hs"),
+                                         _ptr(x.planes), _ptr(x.inv_scale), g, b, float(next_ln.eps) if next_ln is not None else 0.0,
+                                         C.c_void_p(ws.data_ptr()), ws.numel(), _stream(hs)), "emcid_clip_layers_sp16")
+
+
+def clip_layer_head(layer_array, index: int, rows: int, h: int, d: int, heads: int, scale: float, anc: torch.Tensor,
+                    depth: torch.Tensor, rows_sel: Optional[torch.Tensor], hs: torch.Tensor, x: "SplitRows", want_f32: bool):
+    """Attention block + fc1 of layer ``layer_array[index]``: returns (mid (n, h), SplitRows of fc2's input (n, d) [with its
+    fp32 twin when ``want_f32``]); n = every node, or the ``rows_sel`` query nodes."""
+    dev = hs.device
+    n = rows if rows_sel is None else rows_sel.numel()
+    ws = clip_workspace(dev, rows, h, d)
+    mid = torch.empty(n, h, dtype=torch.float32, device=dev)
+    f_planes = torch.empty(n, d, dtype=torch.int32, device=dev)
+    f_scale = torch.empty(2, n, dtype=torch.float32, device=dev)
+    f_f32 = torch.empty(n, d, dtype=torch.float32, device=dev) if want_f32 else None
+    if LINEAR_FLOPS["count"]:
+        LINEAR_FLOPS["flops"] += 2.0 * h * (rows * (3 * h if rows_sel is None else 2 * h) + n * (h if rows_sel is not None else 0)
+                                            + n * h + n * d)
+        LINEAR_FLOPS["launches"] += 3 if rows_sel is None else 4
+    base = C.addressof(layer_array) + index * C.sizeof(ClipLayerSp16)
+    _check(load().emcid_clip_layer_head_sp16(
+        C.c_void_p(base), rows, h, d, heads, float(scale), _ptr(anc, torch.int32, "anc"), anc.stride(0),
+        _ptr(depth, torch.int32, "depth"), _ptr(rows_sel, torch.int32, "rows") if rows_sel is not None else None, n,
+        _ptr(hs, torch.float32, "hs"), _ptr(x.planes), _ptr(x.inv_scale), _ptr(mid), _ptr(f_planes), _ptr(f_scale), _ptr(f_f32),
+        C.c_void_p(ws.data_ptr()), ws.numel(), _stream(hs)), "emcid_clip_layer_head_sp16")
+    return mid, SplitRows(f_planes, f_scale[1], f_f32)
+
+
+def clip_layer_tail(layer_array, index: int, h: int, d: int, f: "SplitRows", mid: torch.Tensor,
+                    next_ln: Optional[torch.nn.LayerNorm]):
+    """fc2 + residual add of layer ``layer_array[index]`` and the next layer's LN1 as planes: (hs (n, h), SplitRows | None)."""
+    dev = mid.device
+    n = mid.shape[0]
+    hs = torch.empty(n, h, dtype=torch.float32, device=dev)
+    x = None
+    if next_ln is not None:
+        x = SplitRows(torch.empty(n, h, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.float32, device=dev))
+    if LINEAR_FLOPS["count"]:
+        LINEAR_FLOPS["flops"] += 2.0 * n * h * d
+        LINEAR_FLOPS["launches"] += 1
+    base = C.addressof(layer_array) + index * C.sizeof(ClipLayerSp16)
+    _check(load().emcid_clip_layer_tail_sp16(
+        C.c_void_p(base), n, h, d, _ptr(f.planes), _ptr(f.inv_scale), _ptr(mid, torch.float32, "mid"), _ptr(hs),
+        _ptr(next_ln.weight, torch.float32, "gamma") if next_ln is not None else None,
+        _ptr(next_ln.bias, torch.float32, "beta") if next_ln is not None else None,
+        float(next_ln.eps) if next_ln is not None else 0.0, _ptr(x.planes) if x is not None else None,
+        _ptr(x.inv_scale) if x is not None else None, _stream(mid)), "emcid_clip_layer_tail_sp16")
+    return hs, x
 
 
 # ---- dual (Woodbury) solver ---------------------------------------------------------------------------------------------

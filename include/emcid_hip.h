@@ -160,6 +160,48 @@ int emcid_tree_attention_sp16(const float* q, int64_t ldq, const float* k, const
                               int64_t anc_ld, const int* depth, const int* rows, int64_t n_rows, int64_t H, int64_t D, float scale,
                               void* planes, int64_t ldp, float* inv_scale, void* stream);
 
+/* ---- native layer runner of the trie forward (csrc/clip_layers.hip) ---------------------------------------------------------------
+ * One C call issues all launches of a run of CLIP text-encoder layers on the split-fp16 projections (the forward the reference
+ * gets from CLIPTextModel.forward, emcid/compute_z.py:2296-2316, inside the layer loop of emcid/emcid_main.py:981-1073): the same
+ * kernels in the same order as the per-launch Python path, bit-identical results.  A layer's weights as split matrices
+ * (emcid_split_rows_f16; q | k | v stacked as one [3h, h] matrix; biases may be NULL; fc1_bound = the {max row norm, max |bias|}
+ * pair of fc1), LayerNorm parameters, act = 0 none / 1 quick_gelu / 2 erf-gelu. */
+typedef struct emcid_clip_layer_sp16 {
+    const float* ln1_gamma; const float* ln1_beta;
+    const float* ln2_gamma; const float* ln2_beta;
+    const void* qkv_planes; const float* qkv_inv_scale; const float* qkv_bias;
+    const void* out_planes; const float* out_inv_scale; const float* out_bias;
+    const void* fc1_planes; const float* fc1_inv_scale; const float* fc1_bias; const float* fc1_bound;
+    const void* fc2_planes; const float* fc2_inv_scale; const float* fc2_bias;
+    float ln1_eps, ln2_eps;
+    int32_t act, reserved;
+} emcid_clip_layer_sp16;
+
+int64_t emcid_clip_workspace_bytes(int64_t rows, int64_t h, int64_t d);
+
+/* Attention block + fc1 of one layer on the trie rows (anc / depth as emcid_tree_attention_f32; hs [rows, h] fp32 and its LN1 as
+ * planes x_planes / x_inv_scale come in).  rows_sel == NULL: every node (n_sel = rows); else k | v for every node and q,
+ * attention, out-projection, LN2, fc1 for the n_sel selected nodes only (the last edited layer's query rows).  Out: mid [n_sel, h]
+ * (residual stream after the attention block), f_planes [n_sel, d] + f_scale [2, n_sel] (scale, inverse scale) = act(fc1(LN2(mid)))
+ * as a split matrix, f_f32 (optional) its fp32 twin (the keys of an edited layer).  workspace: emcid_clip_workspace_bytes. */
+int emcid_clip_layer_head_sp16(const emcid_clip_layer_sp16* L, int64_t rows, int64_t h, int64_t d, int64_t heads, float attn_scale,
+                               const int* anc, int64_t anc_ld, const int* depth, const int* rows_sel, int64_t n_sel,
+                               const float* hs, const void* x_planes, const float* x_inv_scale, float* mid, void* f_planes,
+                               float* f_scale, float* f_f32, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* hs_out [n, h] = f W2^T + b2 + mid (fc2 + residual add; hs_out may not alias mid), then, if next_ln_gamma != NULL, the next
+ * layer's LN1 of it as planes. */
+int emcid_clip_layer_tail_sp16(const emcid_clip_layer_sp16* L, int64_t n, int64_t h, int64_t d, const void* f_planes,
+                               const float* f_inv_scale, const float* mid, float* hs_out, const float* next_ln_gamma,
+                               const float* next_ln_beta, float next_ln_eps, void* x_planes, float* x_inv_scale, void* stream);
+
+/* n_layers whole layers on every node, hs in place; x_planes / x_inv_scale: LN1 of hs for layers[0] in, LN1 of the result under
+ * next_ln_* out (next_ln_gamma == NULL: not computed). */
+int emcid_clip_layers_sp16(const emcid_clip_layer_sp16* layers, int64_t n_layers, int64_t rows, int64_t h, int64_t d, int64_t heads,
+                           float attn_scale, const int* anc, int64_t anc_ld, const int* depth, float* hs, void* x_planes,
+                           float* x_inv_scale, const float* next_ln_gamma, const float* next_ln_beta, float next_ln_eps,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
 /* y = a + b ; z = LayerNorm(y) * gamma + beta over the last dimension (biased variance, eps inside the root, as
  * torch.nn.LayerNorm) — the residual add and the LayerNorm after it of every block of the same hooked forward, one
  * pass.  a/b: [rows, cols] with row strides lda/ldb (elements); y, z: [rows, cols] contiguous; cols % 4 == 0, <= 8192.

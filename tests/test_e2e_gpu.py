@@ -994,3 +994,47 @@ def test_sdxl_cache_miss_runs_pair_stage1_then_edits(tmp_path):
     # the default wiring: no stage1= argument, the pipeline's UNet / VAE are enough
     assert em._default_stage1_sdxl(pipe3, EMCIDXLHyperParams(**hp_d), None) is not None
     assert em._default_stage1_sdxl(syn.build_pipe("toy", DEV, sdxl=True), EMCIDXLHyperParams(**hp_d), None) is None
+
+
+@pytest.mark.parametrize("kind,layers,n_req", [("toy", (1, 2, 3, 4), 9), ("sd-v1.4", (7, 8, 9, 10), 40)])
+def test_forward_paths_agree(tmp_path, kind, layers, n_req, monkeypatch):
+    """The three forms of the trie forward's projections end in the same edit: the native layer runner (one C call per run of
+    layers, csrc/clip_layers.hip) and the per-launch split-fp16 path issue the same kernels with the same arguments — the keys and
+    current values handed to every layer's solve are bit for bit equal (the solve of a COLD call, which factors the statistics on
+    a side stream, is reproducible to fp64 rounding only: scripts/paths_probe.py shows the same last-bit differences between two
+    runs of one path) —, and both agree with the exact-f32 MFMA path (EMCID_SPLIT_GEMM=0) to fp32 rounding; the path counters
+    say which one ran."""
+    from emcid_amd import clip_forward as cf, edit_engine as ee
+    hidden, inter = syn.ENCODER_DIMS[kind][:2]
+    reqs = syn.make_requests(n_req, ragged=True, names="syllable")
+    hp_d = syn.sd_hparams_dict(layers=layers, mom2_update_weight=60, mom2_n_samples=100)
+    names = [hp_d["rewrite_module_tmp"].format(l) for l in layers]
+    cache = str(tmp_path / "cache") + "/"
+    syn.write_vstar_cache(cache, reqs, hidden, seed=1, scale=0.5)
+    syn.write_stats_cache(tmp_path / "stats", names, inter, 100, seed=2, t=2 * inter)
+    results = {}
+    for mode, (split, native) in {"native": (True, True), "launches": (True, False), "f32": (False, False)}.items():
+        monkeypatch.setattr(cf, "SPLIT_GEMM", split)
+        monkeypatch.setattr(cf, "NATIVE_RUNNER", native)
+        em.clear_caches()
+        for k in list(cf.LAST_PATHS):
+            cf.LAST_PATHS[k] = 0
+        pipe = syn.build_pipe(kind, DEV, syllables=True)
+        hp = EMCIDHyperParams(**hp_d)
+        plan = em.prepare_text_encoder_edit(pipe.text_encoder, pipe.tokenizer, reqs, hp, hp.layers, 60,
+                                            str(tmp_path / "stats"), cache, verbose=False)
+        assert plan.trie is not None
+        edits = ee.run_encoder_edit(plan, trace=True)
+        ee.check_info(plan)
+        results[mode] = (edits, {n: get_parameter(pipe.text_encoder, n + ".weight").clone() for n in names}, dict(cf.LAST_PATHS))
+    paths = {m: r[2] for m, r in results.items()}
+    if hidden % 32 == 0 and inter % 32 == 0:
+        assert paths["native"].get("native_layers", 0) >= max(layers) and paths["launches"].get("native_layers", 0) == 0
+        assert paths["launches"]["linear_sp16"] > 0 and paths["f32"]["linear_sp16"] == 0 and paths["f32"]["linear_f32"] > 0
+    for en, el, ef in zip(results["native"][0], results["launches"][0], results["f32"][0]):
+        assert torch.equal(en.K, el.K) and torch.equal(en.Zc, el.Zc)
+        assert (en.dW - el.dW).abs().max().item() <= 1e-7 * el.dW.abs().max().item()
+        torch.testing.assert_close(en.K, ef.K, rtol=2e-4, atol=2e-5)
+        assert (en.dW - ef.dW).abs().max().item() <= 2e-5 * ef.dW.abs().max().item()
+    for n in names:
+        assert (results["native"][1][n] - results["launches"][1][n]).abs().max().item() <= 1e-7
