@@ -53,6 +53,7 @@ sys.path.insert(0, str(REPO))
 
 F64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak [external: AMD MI355X datasheet; MI355X_MICROARCH.md lists no fp64 row]
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md
+F16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: BF16 / F16 MFMA, dense
 LAYERS = (7, 8, 9, 10)
 LAM, EW = 4000, 0.5
 KIND = "sd-v1.4"
@@ -202,6 +203,10 @@ KERNEL_OF_CLASS = {
     "inv_build": "gemm_f64_kernel<KC,!KC,*,*,16,*> launched as recursive-halving build of X = inv(L)",
     "linear": "linear_f32_kernel (csrc/gemm_f32.hip): the forward's projections Y = act(X W^T + b) + residual on v_mfma_f32_32x32x2_f32, "
               "128 x 128 tiles on 4 waves or 160 x 128 on 8 waves (K split inside the workgroup) by the launch's fill of the chip",
+    "linear_sp16": "linear_sp16_kernel (csrc/gemm_sp16.hip): the forward's projections Y = act(X W^T + b) + residual at fp32 accuracy on "
+                   "v_mfma_f32_32x32x16_f16 — operands as hi + lo fp16 planes under per-row power-of-two scales, three MFMAs per "
+                   "k-step (hi.hi + hi.lo + lo.hi), fp32 accumulate; 128 x 128 tiles on 4 waves, 160 x 128 on 8 waves (K split "
+                   "inside the workgroup) or 64 x 64 by the launch's fill of the chip",
 }
 FP64_CLASSES = ["assemble", "chol_leaf", "chol_panel", "chol_trail", "chol_inner", "chol_fused", "inv_block", "trsm_diag",
                 "trsm_update", "delta_w", "inv_build", "inv_apply"]
@@ -346,13 +351,18 @@ def main():
     # instead of the library's own fp32-MFMA GEMM with fused epilogues (csrc/gemm_f32.hip): a few calls -----------------------
     from emcid_amd import clip_forward
     own_gemm = bool(clip_forward.OWN_GEMM)
+    split_gemm = own_gemm and bool(clip_forward.SPLIT_GEMM)
     other_gemm_ms = None
     if not args.no_gemm_ab:
-        clip_forward.OWN_GEMM = not own_gemm
+        # the A/B path: the exact-f32 MFMA kernel (csrc/gemm_f32.hip) when this run is on the split-fp16 kernel, else torch
+        if split_gemm:
+            clip_forward.SPLIT_GEMM = False
+        else:
+            clip_forward.OWN_GEMM = not own_gemm
         call()
         other_s, _ = timed_calls(max(3, args.steps // 2))
         other_gemm_ms = other_s / max(3, args.steps // 2) * 1e3
-        clip_forward.OWN_GEMM = own_gemm
+        clip_forward.OWN_GEMM, clip_forward.SPLIT_GEMM = own_gemm, (split_gemm or clip_forward.SPLIT_GEMM)
         call()
 
     # ---- host / device split: prepare alone (median), then run_encoder_edit on the HBM-resident plan ---------------------
@@ -433,14 +443,41 @@ def main():
             with open(pmc) as fh:
                 rec = json.load(fh)
             traffic, traffic_note = rec.get("traffic_bytes_per_launch"), rec.get("note")
-        roofline = {"bound": "mfma", "kernel": KERNEL_OF_CLASS["linear"], "class": "linear", "achieved": lin["tflops"],
-                    "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": lin["frac_f32_mfma_peak"], "dtype": "f32",
-                    "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_note": traffic_note,
-                    "avg_launch_us": lin["ms_per_step"] * 1e3 / lin["launches_per_step"], "launches_per_step": lin["launches_per_step"],
-                    "flops_per_launch": lin["algorithmic_flops_per_step"] / lin["launches_per_step"],
-                    "selection": "the kernel class with the most time per call over ALL classes (forward GEMMs and fp64 solve)",
-                    "next": (None if top is None else {"class": top, "ms_per_step": prof[top][0] / args.steps,
-                                                       "frac_f64_mfma_peak": classes[top].get("frac_f64_mfma_peak")})}
+        if split_gemm:
+            # three f16 MFMAs per algorithmic multiply-add: the rate at which this algorithm's 2 M N K can execute is a third of
+            # the dense f16 MFMA peak
+            peak = F16_MFMA_PEAK_TFLOPS / 3.0
+            lin["frac_f16_mfma_peak"] = lin["tflops"] / peak
+            lin["mfma_tflops_executed"] = 3.0 * lin["tflops"]
+            pmc = REPO / "profiles" / "r04_pmc_linear_sp16.json"
+            traffic = traffic_note = None
+            if pmc.exists():
+                with open(pmc) as fh:
+                    rec = json.load(fh)
+                traffic, traffic_note = rec.get("traffic_bytes_per_launch"), rec.get("note")
+            roofline = {"bound": "mfma", "kernel": KERNEL_OF_CLASS["linear_sp16"], "class": "linear", "achieved": lin["tflops"],
+                        "peak": peak, "unit": "TFLOP/s", "frac": lin["tflops"] / peak,
+                        "dtype": "f32 (2 x fp16 split: 3 f16 MFMAs per k-step, fp32 accumulate)",
+                        "peak_note": "algorithmic 2 M N K against a third of the dense f16 MFMA peak (2.5 PFLOP/s, "
+                                     "MI355X_MICROARCH.md): every multiply-add is three MFMA multiply-adds",
+                        "mfma_tflops_executed": 3.0 * lin["tflops"], "f16_mfma_peak": F16_MFMA_PEAK_TFLOPS,
+                        "over_f32_mfma_peak": lin["tflops"] / F32_MFMA_PEAK_TFLOPS,
+                        "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_note": traffic_note,
+                        "avg_launch_us": lin["ms_per_step"] * 1e3 / lin["launches_per_step"],
+                        "launches_per_step": lin["launches_per_step"],
+                        "flops_per_launch": lin["algorithmic_flops_per_step"] / lin["launches_per_step"],
+                        "selection": "the kernel class with the most time per call over ALL classes (forward GEMMs and fp64 solve)",
+                        "next": (None if top is None else {"class": top, "ms_per_step": prof[top][0] / args.steps,
+                                                           "frac_f64_mfma_peak": classes[top].get("frac_f64_mfma_peak")})}
+        else:
+            roofline = {"bound": "mfma", "kernel": KERNEL_OF_CLASS["linear"], "class": "linear", "achieved": lin["tflops"],
+                        "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": lin["frac_f32_mfma_peak"], "dtype": "f32",
+                        "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_note": traffic_note,
+                        "avg_launch_us": lin["ms_per_step"] * 1e3 / lin["launches_per_step"], "launches_per_step": lin["launches_per_step"],
+                        "flops_per_launch": lin["algorithmic_flops_per_step"] / lin["launches_per_step"],
+                        "selection": "the kernel class with the most time per call over ALL classes (forward GEMMs and fp64 solve)",
+                        "next": (None if top is None else {"class": top, "ms_per_step": prof[top][0] / args.steps,
+                                                           "frac_f64_mfma_peak": classes[top].get("frac_f64_mfma_peak")})}
     elif top is not None:
         ms, launches = prof[top]
         achieved = flops.get(top, 0) * args.steps / (ms * 1e-3) / 1e12      # = flops per launch / average launch duration
@@ -496,11 +533,15 @@ def main():
                                    "edit_weight refactors the four 3072 x 3072 matrices on the side stream under the forward"},
         "first_call_ms": first_s * 1e3,
         "host_phases_ms_per_call": host_phases,
-        "forward_gemm": {"this_run": "emcid_linear_f32 (own fp32-MFMA GEMM, fused bias / activation / residual)" if own_gemm
+        "forward_gemm": {"this_run": ("emcid_linear_sp16_f32 (split-fp16 MFMA GEMM at fp32 accuracy, fused bias / activation / residual, "
+                                       "native layer runner)" if split_gemm else
+                                       "emcid_linear_f32 (own fp32-MFMA GEMM, fused bias / activation / residual)") if own_gemm
                          else "torch F.linear (hipBLASLt)",
                          "other_path_ms_per_step": other_gemm_ms,
-                         "other_path": "torch F.linear (hipBLASLt, library-default selection) + separate element-wise passes"
+                         "other_path": ("emcid_linear_f32 (exact-f32 MFMA GEMM, EMCID_SPLIT_GEMM=0)" if split_gemm else
+                                        "torch F.linear (hipBLASLt, library-default selection) + separate element-wise passes")
                          if own_gemm else "emcid_linear_f32",
+                         "paths": dict(clip_forward.LAST_PATHS),
                          "note": "replay calls (same 1 000 requests); compare with replay_ms_per_call"},
         "host_prepare_ms": statistics.median(prep_ms),
         "device_ms_per_step": device_ms,
