@@ -440,6 +440,20 @@ def default_noise_scheduler():
         return DDPMNoiseSchedule()
 
 
+FIM_FILE = "data/fim_stats/text_encoder/ccs_filtered_stats/text_model.encoder.layers.10.mlp.fc2_float32_mean_step10_3000.npz"
+
+
+def load_fim(device, path: Optional[str] = None) -> torch.Tensor:
+    """The Fisher diagonal Stage 1's EWC term weighs ``delta ** 2`` with (reference: emcid/compute_z.py:478-486 — a ``Mean``
+    statistic that emcid/fim_cal.py wrote, read from the same cwd-relative path; ``EMCID_FIM_FILE`` or ``path`` override it)."""
+    from .runningstats import CombinedStat, Mean
+    file_path = path or os.environ.get("EMCID_FIM_FILE") or FIM_FILE
+    stat = CombinedStat(**{"mean": Mean()})
+    with np.load(file_path, allow_pickle=True) as data:
+        stat.load_state_dict(data)
+    return torch.from_numpy(stat.mean.state_dict()["mean"]).to(device)
+
+
 def compute_z_text_encoder(pipe, request: Dict, hparams, layer: int, device=None, noise_scheduler=None,
                            resolution: int = 512, rng_device=None) -> torch.Tensor:
     """v* of one concept: the hidden state of ``layer_module_tmp.format(layer)`` at the last subject token of the first
@@ -457,10 +471,9 @@ def compute_z_text_encoder(pipe, request: Dict, hparams, layer: int, device=None
     "cpu": everything from the host generator, then moved (reproduces a CPU run on the GPU to fp32 rounding)."""
     from PIL import Image
     hp = hparams
-    if getattr(hp, "use_ewc", False):
-        raise NotImplementedError("use_ewc needs the Fisher statistics of emcid/fim_cal.py (Stage-1 option outside the shipped hparams)")
     te = pipe.text_encoder
     dev = next(te.parameters()).device
+    fim = load_fim(dev) if getattr(hp, "use_ewc", False) else None          # :478-486 (two shipped hparams files set use_ewc)
     rdev = torch.device(rng_device) if rng_device is not None else dev
     tok = pipe.tokenizer
     sched = noise_scheduler if noise_scheduler is not None else default_noise_scheduler()
@@ -506,10 +519,14 @@ def compute_z_text_encoder(pipe, request: Dict, hparams, layer: int, device=None
         if state["source_init"] is None:
             state["source_init"] = h[0, src_lookup[0]].detach().clone()
         h = h.clone()
-        if hp.replace_repr:
-            h[ar, src_idx, :] = delta
-        else:
-            h[ar, src_idx, :] = h[ar, src_idx, :] + delta
+        # one prompt after the other like the reference's hook (:353-373: cur_out[0][i, idx, :] += delta): autograd then sums
+        # delta's gradient over the prompts in the reference's order — a vectorised add reduces them in another order, a
+        # last-bit difference that 200 Adam steps amplify to 8e-5 of |v*| (tests/test_oracle_golden.py, toy_stage1_more)
+        for i, idx in enumerate(src_lookup):
+            if hp.replace_repr:
+                h[i, idx, :] = delta
+            else:
+                h[i, idx, :] += delta
         return (h,) + tuple(out[1:]) if isinstance(out, tuple) else h
 
     def edited(inp):
@@ -563,7 +580,10 @@ def compute_z_text_encoder(pipe, request: Dict, hparams, layer: int, device=None
                 edit_pred = pipe.unet(noisy, timesteps, edit_repr).sample
                 with torch.no_grad():
                     pred_dest = pipe.unet(noisy, timesteps, dest_repr).sample
-            reg = hp.v_weight_decay * (torch.norm(delta) / torch.norm(source_init) ** 2)
+            if fim is not None and "ablate" in objective:        # EWC instead of the weight decay (:547-549; esd keeps the decay, :553)
+                reg = torch.sum(float(hp.ewc_lambda) * fim * delta ** 2) / (2 * torch.norm(source_init) ** 2)
+            else:
+                reg = hp.v_weight_decay * (torch.norm(delta) / torch.norm(source_init) ** 2)
             if "ablate" in objective:
                 if getattr(hp, "use_sampled_noise", False) or request.get("use_real_noise", False):
                     loss = F.mse_loss(noise, edit_pred, reduction="mean") + reg
@@ -962,10 +982,9 @@ def compute_z_text_encoder_batched(pipe, requests: Sequence[Dict], hparams, laye
     concepts whose tokenized prompts have the same padded lengths (the UNet sees every position of the sequence)."""
     from PIL import Image
     hp = hparams
-    if getattr(hp, "use_ewc", False):
-        raise NotImplementedError("use_ewc needs the Fisher statistics of emcid/fim_cal.py (Stage-1 option outside the shipped hparams)")
     te = pipe.text_encoder
     dev = next(te.parameters()).device
+    fim = load_fim(dev) if getattr(hp, "use_ewc", False) else None
     rdev = torch.device(rng_device) if rng_device is not None else dev
     host_draw = rdev.type == "cpu" and dev.type != "cpu"
     tok = pipe.tokenizer
@@ -1053,7 +1072,7 @@ def compute_z_text_encoder_batched(pipe, requests: Sequence[Dict], hparams, laye
             for c in ctxs:
                 groups.setdefault((c["src_inp"]["input_ids"].shape[1], c["dest_repr"].shape[1]), []).append(c)
             for members in groups.values():
-                _stage1_optimise_group(pipe, te, mod, hp, members, steps, dev)
+                _stage1_optimise_group(pipe, te, mod, hp, members, steps, dev, fim)
                 for c in members:
                     results[c["ri"]] = c["v_star"]
     finally:
@@ -1062,7 +1081,7 @@ def compute_z_text_encoder_batched(pipe, requests: Sequence[Dict], hparams, laye
     return results
 
 
-def _stage1_optimise_group(pipe, te, mod, hp, members, steps, dev):
+def _stage1_optimise_group(pipe, te, mod, hp, members, steps, dev, fim=None):
     """The Adam loop of compute_z_text_encoder for several concepts at once (rows of concept c: [off[c], off[c + 1]))."""
     objective = hp.objective
     B = len(members)
@@ -1120,7 +1139,10 @@ def _stage1_optimise_group(pipe, te, mod, hp, members, steps, dev):
                 edit_pred = pipe.unet(noisy, timesteps, edit_repr).sample
                 with torch.no_grad():
                     pred_dest = pipe.unet(noisy, timesteps, dest_repr).sample
-            reg = hp.v_weight_decay * (torch.norm(delta, dim=1) / torch.norm(source_init, dim=1) ** 2)       # (B,)
+            if fim is not None and "ablate" in objective:        # EWC instead of the weight decay, per concept (:547-549)
+                reg = torch.sum(float(hp.ewc_lambda) * fim * delta ** 2, dim=1) / (2 * torch.norm(source_init, dim=1) ** 2)
+            else:
+                reg = hp.v_weight_decay * (torch.norm(delta, dim=1) / torch.norm(source_init, dim=1) ** 2)       # (B,)
             if "ablate" in objective:
                 if getattr(hp, "use_sampled_noise", False):
                     loss = per_concept_mse(noise, edit_pred) + reg

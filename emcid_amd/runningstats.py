@@ -183,6 +183,59 @@ class SecondMoment(Stat):
         self._lower, self._stage, self._staged = None, None, 0
 
 
+class Mean(Stat):
+    """Running mean of the rows fed to ``add`` (reference: util/runningstats.py:234-291, Chan-style batch update) with the
+    reference's npz keys (count, batchcount, data_shape, mean).  Stage 1's EWC term reads the Fisher diagonal that
+    emcid/fim_cal.py stored through this class (emcid/compute_z.py:478-486); host-side torch, no kernel."""
+
+    def __init__(self, state=None):
+        if state is not None:
+            return super().__init__(state)
+        self.count = 0
+        self.batchcount = 0
+        self._mean = None
+        self.data_shape = None
+
+    def add(self, a):
+        a = self._normalize_add_shape(a)
+        if len(a) == 0:
+            return
+        batch_count = a.shape[0]
+        batch_mean = a.sum(0) / batch_count
+        self.batchcount += 1
+        if self._mean is None:
+            self.count = batch_count
+            self._mean = batch_mean
+            return
+        self.count += batch_count
+        self._mean.add_(batch_mean.sub_(self._mean).mul_(float(batch_count) / self.count))
+
+    def size(self):
+        return self.count
+
+    def mean(self):
+        return self._mean
+
+    def to_(self, device):
+        if self._mean is not None:
+            self._mean = self._mean.to(device)
+
+    def load_state_dict(self, state):
+        self.count = int(state["count"])
+        self.batchcount = int(state["batchcount"])
+        self._mean = torch.from_numpy(numpy.asarray(state["mean"]))
+        ds = state["data_shape"]
+        if ds is None or is_null_numpy_value(ds) or (isinstance(ds, numpy.ndarray) and ds.dtype == object and ds.item() is None):
+            self.data_shape = None
+        else:
+            self.data_shape = tuple(int(v) for v in numpy.asarray(ds).reshape(-1))
+
+    def state_dict(self):
+        return dict(constructor="util.runningstats.Mean()", count=self.count,
+                    data_shape=self.data_shape and tuple(self.data_shape), batchcount=self.batchcount,
+                    mean=self._mean.cpu().numpy())
+
+
 class CombinedStat(Stat):
     """Bundle of named stats sharing one ``add`` / one npz (keys are ``<name>.<key>``)."""
 

@@ -337,6 +337,10 @@ def compute_z_sdxl_text_encoders(pipe, request: Dict, hparams: Dict, layers, res
     return (state["source_init"] + delta).detach(), (state["source_init_2"] + deltas_2).detach()
 
 
+# the path the reference reads its Fisher statistics from, relative to the cwd (compute_z.py:482); tests point it at a fixture
+FIM_FILE = "data/fim_stats/text_encoder/ccs_filtered_stats/text_model.encoder.layers.10.mlp.fc2_float32_mean_step10_3000.npz"
+
+
 def compute_z_text_encoder(pipe, request: Dict, hparams: Dict, layer: int, noise_scheduler, resolution: int = 512) -> torch.Tensor:
     """Per-concept Adam optimisation of v* through the UNet (compute_z.py:315-649), op for op: deep copy of the encoder
     with a hook that adds ``delta`` at each prompt's last subject token in ``layer_module_tmp.format(layer)``'s output,
@@ -347,9 +351,12 @@ def compute_z_text_encoder(pipe, request: Dict, hparams: Dict, layer: int, noise
     from copy import deepcopy
     import torch.nn.functional as F
     hp = lambda k, d=None: hparams.get(k, d)
-    if hp("use_ewc", False):
-        raise NotImplementedError("use_ewc needs the Fisher statistics file (Stage-1 option outside the shipped hparams)")
     device = next(pipe.text_encoder.parameters()).device
+    fim = None
+    if hp("use_ewc", False):
+        # compute_z.py:478-486: the Fisher diagonal as a CombinedStat(mean=Mean()) npz at a cwd-relative path (FIM_FILE here)
+        with np.load(FIM_FILE, allow_pickle=True) as data:
+            fim = torch.from_numpy(np.asarray(data["mean.mean"])).to(device)
     te_edit = deepcopy(pipe.text_encoder).to(device)
     source_prompts = [p.format(request["source"]) for p in request["prompts"]]
     objective = hp("objective")
@@ -433,7 +440,10 @@ def compute_z_text_encoder(pipe, request: Dict, hparams: Dict, layer: int, noise
                 edit_pred = pipe.unet(noisy, timesteps, edit_repr).sample
                 pred_dest = pipe.unet(noisy, timesteps, dest_repr).sample
             source_init = state["source_init"]
-            reg = hp("v_weight_decay") * (torch.norm(delta) / torch.norm(source_init) ** 2)
+            if fim is not None and "ablate" in objective:       # :547-549 (the esd branch keeps the weight decay, :553)
+                reg = torch.sum(float(hp("ewc_lambda", 1e4)) * fim * delta ** 2) / (2 * torch.norm(source_init) ** 2)
+            else:
+                reg = hp("v_weight_decay") * (torch.norm(delta) / torch.norm(source_init) ** 2)
             if "ablate" in objective:
                 if hp("use_sampled_noise", False) or request.get("use_real_noise", False):
                     mse = F.mse_loss(noise, edit_pred, reduction="mean")

@@ -217,6 +217,61 @@ def golden_stage1(cz, EMCIDHyperParams, scratch, tag="toy_stage1"):
     print(f"[golden] {tag}: wrote {len(out)} arrays: " + ", ".join(f"{k}: |v*| {np.linalg.norm(out[k + '/v_star']):.4f}" for k in STAGE1_CASES))
 
 
+STAGE1_MORE_CASES = {
+    # hparams/dest_s-200_c-1.5_ly-11_lr-0.1_ewc-1e7_txt-align-0.01.json: EWC instead of the weight decay (compute_z.py:478-486,
+    # :547-549), a synthetic Fisher file written through the reference's own Mean / CombinedStat
+    "ewc": dict(hp=dict(objective="ablate-dest", cal_text_repr_loss=True, text_repr_loss_scale_factor=0.01, v_lr=0.1,
+                        v_weight_decay=5e-4, use_ewc=True, ewc_lambda=1e7, clamp_norm_factor=1.5, v_num_grad_steps=12),
+                layer=4, seed=4321, req={}),
+    # the shipped SD settings at 50 / 100 / 150 / 200 Adam steps (v_num_grad_steps = 200 is what every shipped file sets): the
+    # random draws of a shorter run are the first draws of a longer one, so the four fixtures are one trajectory sampled four times
+    **{f"steps{n}": dict(hp=dict(objective="ablate-dest", cal_text_repr_loss=True, text_repr_loss_scale_factor=0.01, v_lr=0.2,
+                                 v_weight_decay=5e-4, clamp_norm_factor=1.5, v_num_grad_steps=n), layer=3, seed=1234, req={})
+       for n in (50, 100, 150, 200)},
+}
+FIM_REL = "data/fim_stats/text_encoder/ccs_filtered_stats/text_model.encoder.layers.10.mlp.fc2_float32_mean_step10_3000.npz"
+
+
+def golden_stage1_more(cz, EMCIDHyperParams, scratch, tag="toy_stage1_more"):
+    """More of the REAL reference's compute_z_text_encoder on the toy pipe: use_ewc (the Fisher file is written into the scratch
+    cwd by the reference's own runningstats classes, the way emcid/fim_cal.py does) and the shipped step count."""
+    from util.runningstats import CombinedStat, Mean
+    out, meta = {}, {"cases": {}, "resolution": STAGE1_RESOLUTION, "fim_file": FIM_REL}
+    g = torch.Generator().manual_seed(99)
+    grads_sq = (torch.randn(40, 32, generator=g) * 1e-3) ** 2             # 40 squared-gradient samples over the toy hidden size
+    stat = CombinedStat(**{"mean": Mean()})
+    for chunk in grads_sq.split(10):
+        stat.add(chunk)
+    fim_path = Path(scratch) / FIM_REL
+    fim_path.parent.mkdir(parents=True, exist_ok=True)
+    stat.save(str(fim_path))
+    with np.load(fim_path, allow_pickle=True) as npz:
+        for k in npz.files:
+            out[f"fim/{k}"] = npz[k]
+    for name, c in STAGE1_MORE_CASES.items():
+        pipe = syn.add_diffusion(syn.build_pipe("toy", "cpu"))
+        as_transformers_427(pipe.text_encoder)
+        hp_d = syn.sd_hparams_dict(layers=(1, 2, 3, 4), prefix="")
+        hp_d.update(c["hp"])
+        hp = EMCIDHyperParams(**hp_d)
+        request = {"source": "tocife" if name == "ewc" else "c0042", "dest": "a realist artist",
+                   "prompts": list(syn.ARTIST_TEMPLATES), "seed_train": 2024}
+        request.update(c["req"])
+        imgs = syn.make_images(len(request["prompts"]) * hp.samples_per_prompt, STAGE1_RESOLUTION, seed=31 + c["seed"])
+        torch.manual_seed(c["seed"])
+        with contextlib.redirect_stdout(io.StringIO()):
+            v = cz.compute_z_text_encoder(pipe, dict(request, images=imgs), hp, c["layer"], device="cpu")
+        out[f"{name}/v_star"] = v.detach().numpy()
+        if name in ("ewc", "steps50"):
+            out[f"{name}/images"] = np.stack([np.asarray(im) for im in imgs])
+        meta["cases"][name] = {"hparams": hp_d, "layer": c["layer"], "seed": c["seed"], "request": request,
+                               "images": name if name in ("ewc", "steps50") else "steps50"}
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump(meta, f, indent=1)
+    print(f"[golden] {tag}: wrote {len(out)} arrays: " + ", ".join(f"{k}: |v*| {np.linalg.norm(out[k + '/v_star']):.4f}" for k in STAGE1_MORE_CASES))
+
+
 STAGE1_XL_CASES = {
     # the shipped SDXL hparams' Stage-1 settings (hparams/sdxl-dest_s-100_c-1.2_ly-8-11_ly2-26-31_lr-0.1_wd-8e-03_txt-align-0.01.json), fewer steps
     "shipped_xl": dict(hp=dict(objective="ablate-dest", cal_text_repr_loss=True, text_repr_loss_scale_factor=0.005, v_lr=0.1,
@@ -849,6 +904,8 @@ def main():
                 golden_stage1(cz, HP, scratch)
             elif which == "toy_stage1_sdxl":
                 golden_stage1_sdxl(cz, XLHP, scratch)
+            elif which == "toy_stage1_more":
+                golden_stage1_more(cz, HP, scratch)
             elif which == "toy_multi_token":
                 golden_multi_token(em, HP, scratch)
             else:
@@ -865,6 +922,7 @@ def main():
         golden_toy_extras(cz, ls, scratch)
         golden_stage1(cz, HP, scratch)
         golden_stage1_sdxl(cz, XLHP, scratch)
+        golden_stage1_more(cz, HP, scratch)
         golden_multi_token(em, HP, scratch)
         if "--skip-real" not in sys.argv:
             golden_sd(em, HP, scratch, "real_sd_summary", "sd-v1.4", n_req=24, layers=(7, 8, 9, 10), lam=4000,
