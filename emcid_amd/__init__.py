@@ -24,6 +24,11 @@ def __getattr__(name):
     if name in ("edit_text_encoder_uce", "edit_model_uce"):
         from . import uce_train
         return getattr(uce_train, name)
+    if name == "LAST_PATHS":
+        # which forward / GEMM path this process's calls took (counters; clip_forward.LAST_PATHS): tests and bench.py assert
+        # "own kernels" on it instead of inferring that from a profiler's kernel table
+        from . import clip_forward
+        return clip_forward.LAST_PATHS
     raise AttributeError(name)
 
 

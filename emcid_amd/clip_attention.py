@@ -60,12 +60,48 @@ def _swap_quick_gelu(text_encoder):
     return undo
 
 
+def _own_linear_forward(lin: torch.nn.Linear):
+    """``lin.forward`` on the library's GEMM (clip_forward.linear: the exact-f32 MFMA kernel for fp32 HBM operands with
+    K % 16 == 0, else torch — counted in LAST_PATHS either way)."""
+    from . import clip_forward
+
+    def forward(x):
+        if x.is_cuda and x.dtype == torch.float32 and lin.weight.dtype == torch.float32:
+            x2 = x.reshape(-1, x.shape[-1])
+            if not x2.is_contiguous():
+                x2 = x2.contiguous()
+            return clip_forward.linear(x2, lin.weight, lin.bias).reshape(*x.shape[:-1], lin.out_features)
+        return torch.nn.functional.linear(x, lin.weight, lin.bias)
+    return forward
+
+
+def _swap_linears(text_encoder):
+    """Instance-level ``forward`` of every nn.Linear of the encoder -> the library's GEMM; returns the modules to undo."""
+    from . import clip_forward
+    undo = []
+    if not clip_forward.OWN_GEMM:
+        return undo
+    for mod in text_encoder.modules():
+        if type(mod) is torch.nn.Linear and "forward" not in mod.__dict__:
+            mod.forward = _own_linear_forward(mod)
+            undo.append(mod)
+    return undo
+
+
 @contextlib.contextmanager
-def hip_attention(text_encoder, enabled=True):
-    """Within the block the encoder's attention (and quick_gelu) run on the hand-written HIP kernels."""
+def hip_attention(text_encoder, enabled=True, linears=True):
+    """Within the block the encoder's attention and quick_gelu run on the hand-written HIP kernels, and (``linears``) its
+    nn.Linear projections on the library's GEMM instead of torch's F.linear: the hooked HF forward — what an encoder the trie
+    forward does not take, ``num_edit_tokens > 1`` and the cross-attention sibling use — leaves the library's kernels nowhere."""
     cfg = getattr(text_encoder, "config", None)
+    on_gpu = next((p.is_cuda for p in text_encoder.parameters()), False)
+    swapped = _swap_linears(text_encoder) if (enabled and linears and on_gpu) else []
     if not (enabled and cfg is not None and hasattr(cfg, "_attn_implementation") and register()):
-        yield False
+        try:
+            yield False
+        finally:
+            for mod in swapped:
+                del mod.forward
         return
     prev = cfg._attn_implementation
     cfg._attn_implementation = NAME
@@ -76,3 +112,5 @@ def hip_attention(text_encoder, enabled=True):
         cfg._attn_implementation = prev
         for mod, name, orig in undo:
             setattr(mod, name, orig)
+        for mod in swapped:
+            del mod.forward

@@ -38,7 +38,24 @@ OWN_GEMM = os.environ.get("EMCID_OWN_GEMM", "1") != "0"     # 0: torch's F.linea
 # 1 (default): the projections run on the split-fp16 kernel (csrc/gemm_sp16.hip: fp32 operands as hi + lo fp16 planes, three f16
 # MFMAs per k-step, fp32 accumulate — fp32-level accuracy at 3/16 of the f32-MFMA issue time); 0: the exact-f32 MFMA kernel
 SPLIT_GEMM = os.environ.get("EMCID_SPLIT_GEMM", "1") != "0"
-LAST_PATHS = {"linear_sp16": 0, "linear_f32": 0, "linear_torch": 0}     # which GEMM path the projections of this process took
+# Which path ran (counters of this process; ``emcid_amd.LAST_PATHS`` is this dict): projections on the split-fp16 kernel / the
+# exact-f32 kernel / torch's F.linear; layers issued by the native runner; forwards that took the trie / the hooked HF encoder;
+# trie forwards that had to FALL BACK to the hooked HF encoder (each one is also logged once per reason).
+LAST_PATHS = {"linear_sp16": 0, "linear_f32": 0, "linear_torch": 0, "native_layers": 0, "forward_trie": 0, "forward_hf": 0,
+              "forward_hf_fallback": 0}
+_FALLBACK_SEEN = set()
+
+
+def note_fallback(where: str, why: Exception):
+    """A trie forward that could not run and took the hooked HF forward instead: counted, and logged once per (place, reason)."""
+    import logging
+    LAST_PATHS["forward_hf_fallback"] += 1
+    key = (where, type(why).__name__, str(why))
+    if key not in _FALLBACK_SEEN:
+        _FALLBACK_SEEN.add(key)
+        logging.getLogger("emcid_amd").warning("%s: the prefix-trie forward is not available (%s: %s); using the hooked HF "
+                                               "forward (its projections still run on the library's GEMM)", where,
+                                               type(why).__name__, why)
 
 
 def split_ok(w: torch.Tensor) -> bool:
@@ -692,7 +709,7 @@ def run_prefix(graph: ClipTextGraph, trie: TokenTrie, stop: int):
                         nxt = None
                     hip.clip_layers(nat.array, 0, stop, hs.shape[0], nat.h, nat.d, nat.heads, nat.scale, trie.anc, trie.depth,
                                     hs, x_ln1, nxt)
-                    LAST_PATHS["native_layers"] = LAST_PATHS.get("native_layers", 0) + stop
+                    LAST_PATHS["native_layers"] += stop
                     return hs, (x_ln1 if nxt is not None else None)
             else:
                 hs, x_ln1 = hip.embed_layernorm(te.weight, pe.weight, trie.token, trie.depth, ln0)
@@ -753,7 +770,7 @@ def run_layers_multi(graph: ClipTextGraph, tries: Sequence[TokenTrie], states, s
                     # attention block + fc1 in ONE C call (csrc/clip_layers.hip)
                     mid, x = hip.clip_layer_head(nat.array, i, hs.shape[0], nat.h, nat.d, nat.heads, nat.scale, trie.anc,
                                                  trie.depth, rows, hs, x_ln1, want_f32=on_fc2 is not None)
-                    LAST_PATHS["native_layers"] = LAST_PATHS.get("native_layers", 0) + 1
+                    LAST_PATHS["native_layers"] += 1
                     xs.append(x)
                     mids.append(mid)
                     continue

@@ -26,9 +26,12 @@ def text_embedding_at_lookup(pipe, batch: PromptBatch, layer_module_tmp: Optiona
             graph = clip_forward.discover(te, layer_module_tmp)
             trie = clip_forward.build_trie(batch.ids_host, batch.lookup_host, batch.lookup.device)
             with torch.no_grad():
-                return clip_forward.last_hidden_at_lookup(graph, trie)
-        except (clip_forward.UnsupportedEncoder, IndexError, LookupError):
-            pass
+                out = clip_forward.last_hidden_at_lookup(graph, trie)
+            clip_forward.LAST_PATHS["forward_trie"] += 1
+            return out
+        except (clip_forward.UnsupportedEncoder, IndexError, LookupError) as e:
+            clip_forward.note_fallback("text_embedding_at_lookup", e)       # counted and logged, never silent
+    clip_forward.LAST_PATHS["forward_hf"] += 1
     with torch.no_grad(), hip_attention(te):
         rep = te(**batch.inputs)[0]
     return rep[torch.arange(rep.shape[0], device=rep.device), batch.lookup]
@@ -63,5 +66,6 @@ def get_layers_input_output_at_words_cross_attn(pipe, requests: List[Dict], modu
         for name in module_names:
             mod = get_module(pipe.unet, name)
             ins[name] = keys
-            outs[name] = request_means(F.linear(rows, mod.weight, mod.bias).contiguous())
+            # one GEMM per projection on the lookup rows, on the library's kernel (clip_forward.linear counts the path it took)
+            outs[name] = request_means(clip_forward.linear(rows, mod.weight, mod.bias).contiguous())
     return ins, outs

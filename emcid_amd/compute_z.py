@@ -689,6 +689,7 @@ def compute_z_text_encoder_v2(pipe, request: Dict, hparams, layer: int, device=N
         return t
 
     src_idx, dst_idx = lookup_rows(src_inp, request["source"]), lookup_rows(dst_inp, request["dest"])
+    src_rows = src_idx.tolist()
     if not (len(src_inp["input_ids"]) == len(dst_inp["input_ids"]) == len(pixels)):
         raise AssertionError("The number of prompts and images should be the same.")
     ar = torch.arange(bsz, device=dev)[:, None]
@@ -706,10 +707,12 @@ def compute_z_text_encoder_v2(pipe, request: Dict, hparams, layer: int, device=N
         if state["inits"] is None:
             state["inits"] = h[0, src_idx[0]].detach().clone()           # (k, hidden): the rows of the FIRST prompt
         h = h.clone()
-        if hp.replace_repr:
-            h[ar, src_idx, :] = deltas.unsqueeze(0).expand(bsz, -1, -1)
-        else:
-            h[ar, src_idx, :] = h[ar, src_idx, :] + deltas
+        for i in range(bsz):                 # prompt by prompt, row by row: the reference's order (:1135-1141), see compute_z_text_encoder
+            for j in range(k):
+                if hp.replace_repr:
+                    h[i, src_rows[i][j], :] = deltas[j, :]
+                else:
+                    h[i, src_rows[i][j], :] += deltas[j, :]
         return (h,) + tuple(out[1:]) if isinstance(out, tuple) else h
 
     def edited(inp):
@@ -855,7 +858,11 @@ def compute_z_sdxl_text_encoders(pipe, request: Dict, hparams, layers, device=No
             if state["init"][k] is None:
                 state["init"][k] = h[0, first].detach().clone()
             h = h.clone()
-            h[ar, idx, :] = dvec if hp.replace_repr else h[ar, idx, :] + dvec
+            for i in range(h.shape[0]):          # prompt by prompt: the reference's order (:706-728), see compute_z_text_encoder
+                if hp.replace_repr:
+                    h[i, idx[i], :] = dvec
+                else:
+                    h[i, idx[i], :] += dvec
             return (h,) + tuple(out[1:]) if isinstance(out, tuple) else h
         return hook
 
@@ -867,8 +874,8 @@ def compute_z_sdxl_text_encoders(pipe, request: Dict, hparams, layers, device=No
     def last_layer(te):
         return get_module(te, hp.layer_module_tmp.format(te.config.num_hidden_layers - 1))
 
-    handles = [get_module(te1, hp.layer_module_tmp.format(layer)).register_forward_hook(edit_hook(0, idx1, src_lookup[0], delta)),
-               get_module(te2, hp.layer_module_tmp.format(layer_2)).register_forward_hook(edit_hook(1, idx2, src_lookup_2[0], deltas_2)),
+    handles = [get_module(te1, hp.layer_module_tmp.format(layer)).register_forward_hook(edit_hook(0, [int(i) for i in src_lookup], src_lookup[0], delta)),
+               get_module(te2, hp.layer_module_tmp.format(layer_2)).register_forward_hook(edit_hook(1, [int(i) for i in src_lookup_2], src_lookup_2[0], deltas_2)),
                last_layer(te1).register_forward_pre_hook(penult_hook(0), with_kwargs=True),
                last_layer(te2).register_forward_pre_hook(penult_hook(1), with_kwargs=True)]
 
@@ -1090,7 +1097,9 @@ def _stage1_optimise_group(pipe, te, mod, hp, members, steps, dev, fim=None):
     rows = int(off[-1])
     owner = torch.tensor(np.repeat(np.arange(B), sizes), device=dev)                   # concept of every stacked row
     ar = torch.arange(rows, device=dev)
-    src_idx = torch.tensor([i for c in members for i in c["src_lookup"]], device=dev)
+    src_idx_host = [int(i) for c in members for i in c["src_lookup"]]
+    owner_host = np.repeat(np.arange(B), sizes).tolist()
+    src_idx = torch.tensor(src_idx_host, device=dev)
     dst_idx = torch.tensor([i for c in members for i in c["dst_lookup"]], device=dev)
     cat = lambda key: {k: torch.cat([c[key][k] for c in members], dim=0) for k in members[0][key]}
     src_inp = cat("src_inp")
@@ -1110,8 +1119,12 @@ def _stage1_optimise_group(pipe, te, mod, hp, members, steps, dev, fim=None):
             first = torch.tensor(off[:-1], device=dev)
             state["source_init"] = h[first, src_idx[first]].detach().clone()
         h = h.clone()
-        per_row = delta.index_select(0, owner)
-        h[ar, src_idx, :] = per_row if hp.replace_repr else h[ar, src_idx, :] + per_row
+        for r in range(rows):                # row by row in every concept's own prompt order: delta_c's gradient is summed over its
+            c = owner_host[r]                # prompts in the order a sequential call sums it (see compute_z_text_encoder)
+            if hp.replace_repr:
+                h[r, src_idx_host[r], :] = delta[c]
+            else:
+                h[r, src_idx_host[r], :] += delta[c]
         return (h,) + tuple(out[1:]) if isinstance(out, tuple) else h
 
     def edited(inp):

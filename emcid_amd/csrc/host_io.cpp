@@ -128,22 +128,34 @@ extern "C" int64_t emcid_read_npz_rows_f32(const char* paths, const int64_t* off
     if (n == 0) return 0;
     int nt = n_threads < 1 ? 1 : n_threads > 64 ? 64 : n_threads;
     if ((int64_t)nt > (n + 63) / 64) nt = (int)((n + 63) / 64);      // at least 64 files per thread
-    auto work = [&](int64_t lo, int64_t hi) {
-        std::vector<unsigned char> buf;
-        std::string path;
-        for (int64_t i = lo; i < hi; ++i) {
-            path.assign(paths + off[i], (size_t)(off[i + 1] - off[i]));
-            status[i] = (uint8_t)read_one(path.c_str(), member, width, out + i * ld, buf);
+    // no exception leaves a worker (std::terminate would take the whole Python process down) or the calling thread while workers
+    // are joinable: a failed allocation marks the rest of that thread's files "not served" (status 2: they take the numpy path)
+    auto work = [&](int64_t lo, int64_t hi) noexcept {
+        int64_t i = lo;
+        try {
+            std::vector<unsigned char> buf;
+            std::string path;
+            for (; i < hi; ++i) {
+                path.assign(paths + off[i], (size_t)(off[i + 1] - off[i]));
+                status[i] = (uint8_t)read_one(path.c_str(), member, width, out + i * ld, buf);
+            }
+        } catch (...) {
+            for (; i < hi; ++i) status[i] = 2;
         }
     };
     if (nt == 1) {
         work(0, n);
     } else {
         std::vector<std::thread> pool;
-        pool.reserve((size_t)nt - 1);
-        for (int t = 1; t < nt; ++t) pool.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+        int started = 0;
+        try {
+            pool.reserve((size_t)nt - 1);
+            for (int t = 1; t < nt; ++t, ++started) pool.emplace_back(work, n * t / nt, n * (t + 1) / nt);
+        } catch (...) {
+        }
         work(0, n / nt);
         for (auto& th : pool) th.join();
+        for (int t = started + 1; t < nt; ++t) work(n * t / nt, n * (t + 1) / nt);      // threads that could not be started
     }
     int64_t bad = 0;
     for (int64_t i = 0; i < n; ++i) bad += status[i] != 0;

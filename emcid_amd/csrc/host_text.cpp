@@ -323,20 +323,58 @@ int64_t emcid_bpe_encode_templated(emcid_bpe* m, const char* pre, const int64_t*
     }
     std::atomic<int> arrived{0};
     std::vector<int64_t> n_fb((size_t)nt, 0);
-    auto work = [&](int w) {
-        std::string low_t;
-        for (int64_t k = n_names * w / nt; k < n_names * (w + 1) / nt; ++k) {
-            Piece& pc = Nm[(size_t)k];
-            pc.state = encode_text(m, names + name_off[k], (size_t)(name_off[k + 1] - name_off[k]), low_t, pc.ids, budget, false) ? 1 : 2;
+    // No exception leaves a worker (std::terminate would take the whole Python process down) and every worker reaches the
+    // rendezvous: a failed allocation marks that thread's names "not encoded" and its rows "fallback" (the caller re-encodes
+    // those through the public tokenizer).  `from`: the first share this thread has to do (threads that could not be started
+    // have theirs done by the caller's thread afterwards, without a rendezvous: every name is encoded or marked by then).
+    auto encode_share = [&](int w, std::string& low_t) noexcept {
+        int64_t k = n_names * w / nt;
+        const int64_t k_hi = n_names * (w + 1) / nt;
+        try {
+            for (; k < k_hi; ++k) {
+                Piece& pc = Nm[(size_t)k];
+                pc.state = encode_text(m, names + name_off[k], (size_t)(name_off[k + 1] - name_off[k]), low_t, pc.ids, budget, false) ? 1 : 2;
+            }
+        } catch (...) {
+            for (; k < k_hi; ++k) Nm[(size_t)k].state = 2;
         }
+    };
+    auto assemble_share = [&](int w, std::string& low_t) noexcept {
+        const int64_t lo = n * w / nt, hi = n * (w + 1) / nt;
+        try {
+            n_fb[(size_t)w] = assemble(lo, hi, false, low_t);
+        } catch (...) {
+            for (int64_t i = lo; i < hi; ++i) fallback[i] = 1;
+            n_fb[(size_t)w] = hi - lo;
+        }
+    };
+    auto work = [&](int w) noexcept {
+        std::string low_t;
+        encode_share(w, low_t);
         arrived.fetch_add(1, std::memory_order_acq_rel);
         while (arrived.load(std::memory_order_acquire) < nt) std::this_thread::yield();
-        n_fb[(size_t)w] = assemble(n * w / nt, n * (w + 1) / nt, false, low_t);
+        assemble_share(w, low_t);
     };
     std::vector<std::thread> pool;
-    for (int w = 1; w < nt; ++w) pool.emplace_back(work, w);
+    int started = 1;
+    try {
+        pool.reserve((size_t)nt - 1);
+        for (; started < nt; ++started) pool.emplace_back(work, started);
+    } catch (...) {
+    }
+    {
+        std::string low_t;
+        for (int w = started; w < nt; ++w) {          // shares of threads that could not be started: their names first
+            encode_share(w, low_t);
+            arrived.fetch_add(1, std::memory_order_acq_rel);
+        }
+    }
     work(0);
     for (auto& th : pool) th.join();
+    {
+        std::string low_t;
+        for (int w = started; w < nt; ++w) assemble_share(w, low_t);
+    }
     int64_t n_fallback = 0;
     for (int64_t v : n_fb) n_fallback += v;
     return n_fallback;

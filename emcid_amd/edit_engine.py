@@ -220,8 +220,12 @@ def factor_cache_key(covs: Sequence[torch.Tensor], lam: float, edit_weight: floa
     reference's most common sweep, experiments/emcid_test.py:924-930, ablation.py:80-83) reuses the factors and hands the
     library the ratio (include/emcid_hip.h, "lam_ratio").  edit_weight stays in the key: C' = fl32(fl32(C (1 - e_w)) / 0.5)
     is rounded per entry in fp32 (reference :1037), which a scalar cannot reproduce.  The statistics are identified by the
-    identity and version counter of the HBM-resident C tensors (the entries of emcid_main's covariance cache)."""
-    return (tuple((c.device.index, c.data_ptr(), c._version, tuple(c.shape)) for c in covs), float(edit_weight))
+    identity and version counter of the HBM-resident C tensors (the entries of emcid_main's covariance cache).
+    Reusing a factor across lam changes the weights at fp64-rounding level against a process that factors lam C' itself;
+    EMCID_FACTOR_KEY_LAM=1 puts lam back into the key where bit-stable output across processes is wanted (every new lam then
+    refactors, ~6 ms)."""
+    key_lam = float(lam) if os.environ.get("EMCID_FACTOR_KEY_LAM", "0") == "1" else None
+    return (tuple((c.device.index, c.data_ptr(), c._version, tuple(c.shape)) for c in covs), float(edit_weight), key_lam)
 
 
 def clear_engine_caches():
@@ -300,7 +304,8 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
                         raise clip_forward.UnsupportedEncoder("rewrite_module_tmp is not the layer's mlp.fc2")
                 if sorted(layers) != list(layers):
                     raise clip_forward.UnsupportedEncoder("layers not in forward order")
-        except (clip_forward.UnsupportedEncoder, IndexError, LookupError):
+        except (clip_forward.UnsupportedEncoder, IndexError, LookupError) as e:
+            clip_forward.note_fallback("prepare_encoder_edit", e)
             graph = None
     plan = EncoderEditPlan(text_encoder, list(layers), rewrite_module_tmp, float(lam), float(edit_weight), None,
                            None, covs, len(requests) * k, shard, tokenizer=tokenizer, local_requests=local, num_edit_tokens=k)
@@ -342,7 +347,8 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
                                                     zs_t, covs, shard, layer_module_tmp, forward_mode, num_edit_tokens,
                                                     _defer_checks=False)
             plan.graph, plan.chunks = graph, chunks
-        except (clip_forward.UnsupportedEncoder, IndexError):
+        except (clip_forward.UnsupportedEncoder, IndexError) as e:
+            clip_forward.note_fallback("prepare_encoder_edit (prompt batch)", e)
             plan.graph = plan.chunks = None
     if plan.chunks is None:
         with phase("tokenize+lookup"):
@@ -633,6 +639,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                 else:
                     states.append(clip_forward.run_prefix(plan.graph, ch.trie, first_edit))
                 ch.state = None         # single use: the residual stream below belongs to the weights of this very call
+            clip_forward.LAST_PATHS["forward_trie"] += 1
             clip_forward.run_layers_multi(plan.graph, [ch.trie for ch in chunks], states, first_edit, last, on_fc2,
                                           fc2_by_callback=order, callback_adds_residual=True, split_aware=True)
     else:
@@ -642,9 +649,11 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                 solve(i, layer, gather_request_means(x, plan.ensure_batch()), gather_request_means(output, plan.ensure_batch()))
                 if layer == last:
                     raise StopForward()
-                return F.linear(x, mod.weight, mod.bias)
+                return clip_forward.linear(x.reshape(-1, x.shape[-1]), mod.weight, mod.bias).reshape(*x.shape[:-1], -1) \
+                    if x.is_cuda and x.dtype == torch.float32 else F.linear(x, mod.weight, mod.bias)
             return hook
 
+        clip_forward.LAST_PATHS["forward_hf"] += 1
         for i, l in enumerate(plan.layers):
             handles.append(mods[l].register_forward_hook(make_hook(i, l)))
         try:

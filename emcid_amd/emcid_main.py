@@ -282,7 +282,11 @@ def load_v_stars(requests: Sequence[Dict], hparams, cache_name: Optional[str], s
     file :903-904, Stage 1 on a miss :905-969)."""
     names = [vstar_cache_name(cache_name, request, hparams, idx, suffix) for idx, request in enumerate(requests)]
     native = _native_vstar_rows(names, int(width), pin) if (width and cache_name is not None and len(names)) else None
-    if native is not None and not native[1].any():
+    new_z = bool(getattr(hparams, "use_new_compute_z", False))
+    k_tok = int(getattr(hparams, "num_edit_tokens", 1) or 1)
+    if native is not None and not native[1].any() and not (new_z and k_tok > 1):
+        # every file was read natively: (width,) or (1, width) rows, which is all a one-token edit can hold — a k-token edit's
+        # files are (k, width) and take the per-file path below with its shape check (the native reader does not serve them)
         return native[0]
     rows: List[Optional[np.ndarray]] = [None] * len(requests)
     missing: List[int] = []

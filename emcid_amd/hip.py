@@ -538,12 +538,20 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     ws = None
     if (cfg >= 128 or (cfg < 0 and K >= 2048 and -(-M // 128) * -(-N // 128) <= 128)) and not torch.cuda.is_current_stream_capturing():
         ws = _linear_workspace(x.device)
-    _check(load().emcid_linear_ws_f32(_ptr(x, torch.float32, "x"), x.stride(0), _ptr(w, torch.float32, "w"), w.stride(0),
-                                      _ptr(bias, torch.float32, "bias"), _ptr(residual, torch.float32, "residual"),
-                                      residual.stride(0) if residual is not None else 0, _ptr(out, torch.float32, "out"),
-                                      out.stride(0), M, N, K, int(act), int(cfg),
-                                      C.c_void_p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0,
-                                      _stream(x)), "emcid_linear_ws_f32")
+    try:
+        _check(load().emcid_linear_ws_f32(_ptr(x, torch.float32, "x"), x.stride(0), _ptr(w, torch.float32, "w"), w.stride(0),
+                                          _ptr(bias, torch.float32, "bias"), _ptr(residual, torch.float32, "residual"),
+                                          residual.stride(0) if residual is not None else 0, _ptr(out, torch.float32, "out"),
+                                          out.stride(0), M, N, K, int(act), int(cfg),
+                                          C.c_void_p(ws.data_ptr()) if ws is not None else None, ws.numel() if ws is not None else 0,
+                                          _stream(x)), "emcid_linear_ws_f32")
+    except EmcidHipError:
+        # the split-K form relies on its ticket counters being zero on entry; a launch that did not complete may have left
+        # some behind — later launches on this stream would then never see a "last arriver".  Start from a fresh workspace.
+        if ws is not None:
+            _LINEAR_WS.pop((x.device.index if x.device.index is not None else torch.cuda.current_device(),
+                            torch.cuda.current_stream(x.device).cuda_stream), None)
+        raise
     return out
 
 

@@ -116,8 +116,8 @@ def _encode_rows(pipe, ids: torch.Tensor, flat_sets: Sequence[np.ndarray], tap_m
             out = _encode_rows_packed(pipe, ids, flat_sets, tap_module)
             LAST_RUN["forward"] = "packed-trie"
             return out
-        except clip_forward.UnsupportedEncoder:
-            pass
+        except clip_forward.UnsupportedEncoder as e:
+            clip_forward.note_fallback("uce_train", e)
     LAST_RUN["forward"] = "hooked"
     return _encode_rows_hooked(pipe, ids, flat_sets, tap_module)
 
