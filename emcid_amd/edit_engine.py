@@ -375,14 +375,55 @@ def _staged(group) -> bool:
     return dist.get_backend(group) == "gloo"
 
 
+# Per-rank phase times of a sharded edit (bench.py --gpus N reports them for every rank, so that a bad scaling curve can be read):
+# EMCID_DIST_TIMING=1 (or DIST_TIMING["enabled"] = True) brackets the collectives and every layer's solve with event pairs on
+# the launch stream; dist_timing_collect() synchronises and returns {phase: (total ms, count)}.
+DIST_TIMING = {"enabled": os.environ.get("EMCID_DIST_TIMING", "0") == "1", "events": []}
+
+
+class _dist_phase:
+    def __init__(self, name: str, dev):
+        self.name, self.dev = name, dev
+        self.on = DIST_TIMING["enabled"] and torch.device(dev).type == "cuda"
+
+    def __enter__(self):
+        if self.on:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream(self.dev))
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record(torch.cuda.current_stream(self.dev))
+            DIST_TIMING["events"].append((self.name, self.a, b))
+        return False
+
+
+def dist_timing_collect() -> Dict[str, tuple]:
+    """{phase: (milliseconds in total, number of brackets)} since the last collect (synchronises the device)."""
+    out: Dict[str, list] = {}
+    evs, DIST_TIMING["events"] = DIST_TIMING["events"], []
+    if evs:
+        torch.cuda.synchronize()
+    for name, a, b in evs:
+        rec = out.setdefault(name, [0.0, 0])
+        rec[0] += a.elapsed_time(b)
+        rec[1] += 1
+    return {k: (v[0], v[1]) for k, v in out.items()}
+
+
 def _all_reduce_sum(t: torch.Tensor, group):
     import torch.distributed as dist
-    if t.is_cuda and _staged(group):
-        host = t.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-        t.copy_(host)
-    else:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    # the two all-reduces of the column-sharded solve: the N x N partial S (square) and the h x d partial U
+    name = "all_reduce_S" if t.dim() == 2 and t.shape[0] == t.shape[1] else "all_reduce_U"
+    with _dist_phase(name, t.device):
+        if t.is_cuda and _staged(group):
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
@@ -393,6 +434,11 @@ def _all_gather_rows(local: torch.Tensor, plan: EncoderEditPlan) -> torch.Tensor
         return local
     import torch.distributed as dist
 
+    with _dist_phase("k_all_gather", local.device):
+        return _all_gather_rows_timed(local, plan, sh, dist)
+
+
+def _all_gather_rows_timed(local, plan, sh, dist):
     sizes = [b - a for a, b in (sh.bounds(plan.n_total, r) for r in range(sh.world))]
     nmax = max(sizes)
     padded = local
@@ -512,7 +558,8 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
         """All-gather the shard's K/Zc rows, run the closed form, leave W0 + dW in the live weight.  ``Zc_local`` may be
         a callable K -> Zc (fc2 applied to the gathered keys): then only K crosses the links."""
         try:
-            _solve(i, layer, K_local, Zc_local)
+            with _dist_phase("solve (incl. its collectives)", dev):
+                _solve(i, layer, K_local, Zc_local)
         finally:
             _touch(weights[layer])
 

@@ -389,3 +389,9 @@ def test_bench_self_launch_two_ranks_gloo(tmp_path):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["config"]["backend"] == "gloo"
     assert out["value"] > 0 and out["ms_per_step"] > 0 and out["scaling"] == "strong" and out["unit"] == "concept-edits/s"
     assert out["config"]["parallelism"] == "concept-shard x2" and out["roofline"] is not None
+    # per-rank phase times, so that a scaling curve can be read: both ranks report, with the collectives of the sharded solve
+    assert out["config"]["world_size_seen"] == 2 and [r["rank"] for r in out["per_rank"]] == [0, 1]
+    for r in out["per_rank"]:
+        ph = r["phases_ms_per_call"]
+        assert {"k_all_gather", "all_reduce_S", "all_reduce_U", "solve (incl. its collectives)"} <= set(ph)
+        assert r["collectives_ms_per_call"] > 0 and r["ms_per_call"] > ph["solve (incl. its collectives)"]["ms_per_call"] > 0
