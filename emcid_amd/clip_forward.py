@@ -152,8 +152,8 @@ class ClipLayer:
         if hit is not None and hit[0] == sig:
             return hit[1]
         b = self.qkv_b if name == "qkv" else getattr(self, name).bias
-        with torch.no_grad():
-            sp = hip.split_rows(w.detach(), b if b is not None and b.is_contiguous() else None, want_bound=True)
+        with torch.no_grad():        # the (max row norm, max |bias|) pair only where a LayerNorm turns it into an output scale: fc1
+            sp = hip.split_rows(w.detach(), b if b is not None and b.is_contiguous() else None, want_bound=name == "fc1")
         self.splits[name] = (sig, sp)
         return sp
 
@@ -201,7 +201,7 @@ class NativeLayers:
         lns = [layer.ln1.weight, layer.ln1.bias, layer.ln2.weight, layer.ln2.bias]
         if any(t.dtype != torch.float32 or not t.is_contiguous() for t in lns):
             return False
-        sig = tuple((sp.planes.data_ptr(), sp.inv_scale.data_ptr(), sp.bound.data_ptr()) for sp in sps) + \
+        sig = tuple((sp.planes.data_ptr(), sp.inv_scale.data_ptr(), sp.bound.data_ptr() if sp.bound is not None else 0) for sp in sps) + \
             tuple(t.data_ptr() if t is not None else 0 for t in biases + lns) + (layer.act_code,)
         if self.sigs[i] == sig:
             return True
@@ -801,7 +801,17 @@ def run_layers_multi(graph: ClipTextGraph, tries: Sequence[TokenTrie], states, s
             if on_fc2 is not None:
                 cb_xs = xs if split_aware else [x.float() if isinstance(x, hip.SplitRows) else x for x in xs]
                 if callback_adds_residual and not summed:
-                    outs = on_fc2(i, cb_xs, outs, mids)
+                    if split_aware:
+                        # a split-aware callback may also take the next layer's LN1 off our hands (fc2 + residual + LN1 in
+                        # one C call): it then returns (hs, LN1 planes) pairs instead of the fc2 outputs
+                        nl = nxt if nxt is not None and _fusable(nxt) and _sp_ln_ok(nxt) and \
+                            graph.layers[i + 1].qkv_w is not None and graph.layers[i + 1].split_of("qkv") is not None else None
+                        outs = on_fc2(i, cb_xs, outs, mids, nl)
+                        if outs is not None and len(outs) and isinstance(outs[0], tuple):
+                            tail_states = [(hs, x if nl is not None else _next_ln1(graph, i + 1, hs, nxt)) for hs, x in outs]
+                            outs = [hs for hs, _ in outs]
+                    else:
+                        outs = on_fc2(i, cb_xs, outs, mids)
                     summed = outs is not None and i in by_cb
                 else:
                     outs = on_fc2(i, cb_xs, outs)

@@ -30,6 +30,9 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
+#ifndef SP16_ONE_SLOT
+#define SP16_ONE_SLOT 0
+#endif
 constexpr int SPK = 32;            // k per stage and wave group (a stage is 32 KS deep)
 // LDS bytes per tile row and stage: 128 KS + 16.  KS = 1: 36 dwords, the 16 lanes of every b128 lane group fall on 16 distinct
 // 4-bank groups (36 r mod 64 = 4 (9 r mod 16)); KS = 2: 68 dwords (68 r mod 64 = 4 r).
@@ -131,7 +134,7 @@ __device__ __forceinline__ void sp_accumulate(const SpArgs& a, int m0, int n0, i
     // fragments: lane (row l31, half l5) of k16-step t reads group 2 t + l5 of its row: hi at +0, lo at +16
     const int fx_off = (wm0 + l31) * SPROW + 32 * l5 + 128 * grp;
     const int fw_off = (BM + wn0 + l31) * SPROW + 32 * l5 + 128 * grp;
-    constexpr int NSLOT = MJ * NI > 4 ? 1 : 2;
+    constexpr int NSLOT = (MJ * NI > 4 && SP16_ONE_SLOT) ? 1 : 2;
     v8h xh[NSLOT][MJ], xl[NSLOT][MJ], wh[NSLOT][NI], wl[NSLOT][NI];
     auto fread = [&](const unsigned char* stage, int t, int slot) __attribute__((always_inline)) {
 #pragma unroll
@@ -168,7 +171,7 @@ __device__ __forceinline__ void sp_accumulate(const SpArgs& a, int m0, int n0, i
     gload(min(1, T - 1), SpIC<1 % PF>{});
     if constexpr (PF > 1) gload(min(2, T - 1), SpIC<2 % PF>{});
     __syncthreads();
-    constexpr bool ONE_SLOT = MJ * NI > 4;       // five blocks per wave: a second set of fragments would not fit in 256 registers
+    constexpr bool ONE_SLOT = MJ * NI > 4 && SP16_ONE_SLOT;       // five blocks per wave: a second set of fragments would not fit in 256 registers
     if constexpr (!ONE_SLOT) fread(smem, 0, 0);
     if constexpr (DBG >= 3) fread(smem, 1, 1);
     auto body = [&](auto rc, int it) __attribute__((always_inline)) {
@@ -365,6 +368,131 @@ __device__ __forceinline__ void sp_finish(const SpArgs& a, int m0, int n0, unsig
     else epilogue([](float x) { return x; });
 }
 
+// ---- "ping-pong": two 128 x 128 tiles per workgroup, their K loops interleaved by barriers ------------------------------------
+// Two independent workgroups of a compute unit share its matrix pipes by chance: both in their MFMAs (one waits), both in their
+// loads (the pipe idles) — 0.34 busy in the counters of the 4-wave kernel.  Here ONE workgroup of eight waves holds two tiles,
+// waves 0-3 one and waves 4-7 the other (one wave of each group per SIMD), and the groups alternate at workgroup barriers:
+// while a group issues the 24 MFMAs of its stage from registers, the other does ALL of its memory work for later stages — the
+// fragment reads of its next stage (both k16 steps: 64 registers), the LDS stores of the stage after it and the global loads
+// of the one after that — and nothing else; then they swap.  Group 1 runs one phase behind group 0 (an extra barrier before
+// its loop, one after group 0's).  Each group owns its own two LDS stage buffers, so only its own program order and the
+// barriers between a store and the reads of it matter:
+//     mem phase after MFMA(s):  fread(s+1) <- buf[(s+1)&1] (stored two phases ago) | lstore(s+2) -> buf[s&1] (last read two phases
+//     ago, consumed by MFMA(s)) | gload(s+3) into the one register set the store has just emptied (in flight for two phases).
+template <int DBG>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_sp16_pp_kernel(SpArgs a) {
+    constexpr int MJ = 2, NI = 2, WN = 2, BM = 128, BN = 128, NT = 256, SPROW = 144, VA = BM * 8 / NT, VB = BN * 8 / NT;
+    constexpr int STAGE = (BM + BN) * SPROW, GROUP = 2 * STAGE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_all[2 * GROUP];
+    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, l5 = lane >> 5;
+    const int wm0 = (wave / WN) * (32 * MJ), wn0 = (wave % WN) * (32 * NI);
+    unsigned char* smem = smem_all + grp * GROUP;
+    // XCD x takes the tile PAIRS [x per, (x + 1) per) of the super-row order; a pair = two consecutive tiles
+    const int pairs = (a.tiles + 1) / 2, per = (pairs + 7) / 8;
+    const int pair = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (pair >= pairs || (int)(blockIdx.x >> 3) >= per) return;
+    const int tile_raw = 2 * pair + grp;
+    const bool ghost = tile_raw >= a.tiles;            // odd tile count: the last pair's second group computes a copy, stores nothing
+    int bm, bn;
+    sp_tile_of(a, ghost ? a.tiles - 1 : tile_raw, bm, bn);
+    const int m0 = bm * BM, n0 = bn * BN, T = a.K / SPK;
+
+    const uint32_t* pa[VA];
+    const uint32_t* pb[VB];
+    int wa[VA], wb[VB];
+#pragma unroll
+    for (int s = 0; s < VA; ++s) {
+        const int v = tid + NT * s, row = v >> 3;
+        pa[s] = a.X + (int64_t)min(m0 + row, a.M - 1) * a.ldx + 4 * (v & 7);
+        wa[s] = row * SPROW + 16 * (v & 7);
+    }
+#pragma unroll
+    for (int s = 0; s < VB; ++s) {
+        const int v = tid + NT * s, row = v >> 3;
+        pb[s] = a.W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + 4 * (v & 7);
+        wb[s] = (BM + row) * SPROW + 16 * (v & 7);
+    }
+    v4u ga[VA], gb[VB];
+    auto gload = [&](int it) __attribute__((always_inline)) {
+        const int k0 = min(it, T - 1) * SPK;
+#pragma unroll
+        for (int s = 0; s < VA; ++s) ga[s] = *reinterpret_cast<const v4u*>(pa[s] + k0);
+#pragma unroll
+        for (int s = 0; s < VB; ++s) gb[s] = *reinterpret_cast<const v4u*>(pb[s] + k0);
+    };
+    auto lstore = [&](unsigned char* stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < VA; ++s) *reinterpret_cast<v4u*>(stage + wa[s]) = ga[s];
+#pragma unroll
+        for (int s = 0; s < VB; ++s) *reinterpret_cast<v4u*>(stage + wb[s]) = gb[s];
+    };
+    const int fx_off = (wm0 + l31) * SPROW + 32 * l5;
+    const int fw_off = (BM + wn0 + l31) * SPROW + 32 * l5;
+    v8h xh[2][MJ], xl[2][MJ], wh[2][NI], wl[2][NI];
+    auto fread = [&](const unsigned char* stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) {
+                xh[t][j] = *reinterpret_cast<const v8h*>(stage + fx_off + j * 32 * SPROW + 64 * t);
+                xl[t][j] = *reinterpret_cast<const v8h*>(stage + fx_off + j * 32 * SPROW + 64 * t + 16);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                wh[t][i] = *reinterpret_cast<const v8h*>(stage + fw_off + i * 32 * SPROW + 64 * t);
+                wl[t][i] = *reinterpret_cast<const v8h*>(stage + fw_off + i * 32 * SPROW + 64 * t + 16);
+            }
+        }
+    };
+    v16f acc[NI][MJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mfmas = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p == 0 ? wl[t][i] : wh[t][i], p == 1 ? xl[t][j] : xh[t][j],
+                                                                           acc[i][j], 0, 0, 0);
+    };
+
+    gload(0);
+    lstore(smem);
+    gload(1);
+    __syncthreads();
+    fread(smem);
+    lstore(smem + STAGE);
+    gload(2);
+    if (grp == 1) __syncthreads();                 // group 1 runs one phase behind
+    for (int s = 0; s < T; ++s) {
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DBG < 4) {
+            __builtin_amdgcn_s_setprio(1);
+            mfmas();
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DBG < 3) fread(smem + ((s + 1) & 1) * STAGE);
+        if constexpr (DBG < 2) lstore(smem + (s & 1) * STAGE);
+        if constexpr (DBG < 1) gload(s + 3);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (grp == 0) __syncthreads();
+    if (!ghost) sp_finish<MJ, NI, 2, WN, 1>(a, m0, n0, smem, acc);
+}
+
 template <int MJ, int NI, int WM, int WN, int PF, int WPE, int DBG, int KS>
 __global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void linear_sp16_kernel(SpArgs a) {
@@ -442,7 +570,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 }
 
 struct SpCfg { int bm, bn; };
-static const SpCfg kSpCfgs[] = {{128, 128}, {256, 128}, {64, 64}, {160, 128}};
+static const SpCfg kSpCfgs[] = {{128, 128}, {128, 128}, {64, 64}, {160, 128}};
 
 }  // namespace emcid
 
@@ -504,12 +632,20 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
         if (pf == 1) EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 1, WPE_, 0, KS_);      \
         else EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 2, WPE_, 0, KS_);              \
     } while (0)
-    if (dbg == 1) EMCID_SP_LAUNCH(2, 2, 2, 2, 2, 2, 1, 1);
+    if (dbg && tile_sel == 3) {
+        if (dbg == 1) EMCID_SP_LAUNCH(5, 1, 1, 4, 1, 2, 1, 2);
+        else if (dbg == 2) EMCID_SP_LAUNCH(5, 1, 1, 4, 1, 2, 2, 2);
+        else EMCID_SP_LAUNCH(5, 1, 1, 4, 1, 2, 3, 2);
+    } else if (dbg == 1) EMCID_SP_LAUNCH(2, 2, 2, 2, 2, 2, 1, 1);
     else if (dbg == 2) EMCID_SP_LAUNCH(2, 2, 2, 2, 2, 2, 2, 1);
     else if (dbg == 3) EMCID_SP_LAUNCH(2, 2, 2, 2, 2, 2, 3, 1);
     else switch (tile_sel) {
         case 0: EMCID_SP_PF(2, 2, 2, 2, 2, 1); break;
-        case 1: EMCID_SP_PF(2, 2, 4, 2, 2, 1); break;
+        case 1: {       // ping-pong: two 128 x 128 tiles per 512-thread workgroup
+            const int pairs = (tiles + 1) / 2, pper = (pairs + 7) / 8;
+            hipLaunchKernelGGL((linear_sp16_pp_kernel<0>), dim3((unsigned)(pper * 8)), dim3(512), 0, st, a);
+            break;
+        }
         case 2: EMCID_SP_PF(1, 1, 2, 2, 4, 1); break;
         default: EMCID_SP_LAUNCH(5, 1, 1, 4, 1, 2, 0, 2); break;     // a 64-deep stage ahead; two register sets would spill
     }

@@ -656,9 +656,10 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
 
         zc_from_keys = os.environ.get("EMCID_ZC_FROM_KEYS", "1") != "0"      # 0: fc2 over every node + gather (A/B switch)
 
-        def on_fc2(li, xs, outs, mids=None):
+        def on_fc2(li, xs, outs, mids=None, next_ln=None):
             """fc2 of an edited layer: keys -> closed form -> the projection with the NEW weight.  ``mids`` (the residual
-            streams): the callback returns fc2(x) + mid, the add riding in the GEMM's epilogue."""
+            streams): the callback returns fc2(x) + mid, the add riding in the GEMM's epilogue; with the native layer runner
+            (hs, LN1 planes of the next layer) pairs from ONE C call (``next_ln``: that LayerNorm, or None)."""
             if li not in order:
                 return outs
             m = mods[li]
@@ -673,6 +674,10 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
             if li == last:
                 return None
             wsp = plan.graph.layers[li].split_of("fc2")          # of the NEW weight (solve() bumped its version counter)
+            if mids is not None and wsp is not None and all(isinstance(x, hip.SplitRows) for x in xs):
+                nats = [clip_forward.native_of(plan.graph, ch.trie, li, li + 1) for ch in chunks]
+                if all(n is not None for n in nats):       # fc2 + residual add + the next layer's LN1: one C call per slice
+                    return [hip.clip_layer_tail(n.array, li, n.h, n.d, x, mid, next_ln) for n, x, mid in zip(nats, xs, mids)]
             if mids is None:
                 return [lin(x, m.weight, m.bias, wsp=wsp) for x in xs]
             return [lin(x, m.weight, m.bias, residual=mid, wsp=wsp) for x, mid in zip(xs, mids)]

@@ -46,10 +46,11 @@ for M, K, N, name in shapes:
     line.append(f"f32 {t:7.1f} us {fl / t / 1e6:6.1f} TF")
     t = timeit(lambda: hip.split_rows(x))
     line.append(f"split(x) {t:6.1f} us")
-    names = {0: "128x128", 1: "256x128", 2: "64x64", 3: "160x128k2"}
+    names = {0: "128x128", 1: "pp2x128x128", 2: "64x64", 3: "160x128k2"}
     cfgs = [(-1, "auto")] + [(tile + 4 * (pf - 1), f"{names[tile]}/pf{pf}") for tile in (0, 1, 2, 3) for pf in (1, 2)]
     if os.environ.get("MB_DBG", "0") == "1":       # timing-only variants (wrong results)
         cfgs += [(4 + 16, "128x128/noload"), (4 + 32, "128x128/noload-nostore"), (4 + 48, "128x128/mfma-only")]
+        cfgs += [(3 + 16, "160x128k2/noload"), (3 + 32, "160x128k2/noload-nostore"), (3 + 48, "160x128k2/mfma-only")]
     for cfg, cn in cfgs:
         t = timeit(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=cfg))
         line.append(f"{cn} {t:6.1f} us {fl / t / 1e6:5.1f} TF")
