@@ -751,12 +751,15 @@ def n100_record(workdir, device, n=100, calls=9):
     sets = [(reqs, cache)] + [request_set(n, workdir, j) for j in range(1, calls + 3)]
     hp = EMCIDHyperParams(**hp_d)
     w0 = {ln: get_parameter(pipe.text_encoder, ln + ".weight").detach().clone() for ln in layer_names}
+    from emcid_amd import edit_engine
     ms = []
     for i, (r, c) in enumerate(sets):
         with torch.no_grad():
             for ln in layer_names:
                 get_parameter(pipe.text_encoder, ln + ".weight").copy_(w0[ln])
         torch.cuda.synchronize()
+        if i == 3:
+            edit_engine.TIMING.clear()
         t0 = time.perf_counter()
         em.apply_emcid_to_text_encoder(pipe, r, hp, device, cache_name=c, stats_dir=stats, verbose=False)
         torch.cuda.synchronize()
@@ -765,6 +768,7 @@ def n100_record(workdir, device, n=100, calls=9):
     med = statistics.median(timed)
     return {"workload": f"{n}-concept edit, SD-v1.4 dims, layers 7-10, lambda 4000 (BASELINE config 2), one GPU; every call a "
                         f"never-seen request set", "ms_per_call_median": med, "ms_per_call": [round(t, 3) for t in timed],
+            "host_phases_ms_per_call": {k: round(v / len(timed) * 1e3, 4) for k, v in edit_engine.TIMING.items()},
             "concept_edits_per_s": n / (med * 1e-3), "first_call_ms_this_shape": ms[0], "calls": len(timed)}
 
 

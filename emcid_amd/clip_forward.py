@@ -41,8 +41,8 @@ SPLIT_GEMM = os.environ.get("EMCID_SPLIT_GEMM", "1") != "0"
 # Which path ran (counters of this process; ``emcid_amd.LAST_PATHS`` is this dict): projections on the split-fp16 kernel / the
 # exact-f32 kernel / torch's F.linear; layers issued by the native runner; forwards that took the trie / the hooked HF encoder;
 # trie forwards that had to FALL BACK to the hooked HF encoder (each one is also logged once per reason).
-LAST_PATHS = {"linear_sp16": 0, "linear_f32": 0, "linear_torch": 0, "native_layers": 0, "forward_trie": 0, "forward_hf": 0,
-              "forward_hf_fallback": 0}
+LAST_PATHS = {"linear_sp16": 0, "linear_f32": 0, "linear_torch": 0, "native_layers": 0, "fused_edit_layers": 0, "forward_trie": 0,
+              "forward_hf": 0, "forward_hf_fallback": 0}
 _FALLBACK_SEEN = set()
 
 

@@ -655,6 +655,23 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
             return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
 
         zc_from_keys = os.environ.get("EMCID_ZC_FROM_KEYS", "1") != "0"      # 0: fc2 over every node + gather (A/B switch)
+        fused_env = os.environ.get("EMCID_FUSED_EDIT_LAYER", "1") != "0"
+
+        def fused_layer_ok(li, xs, mids):
+            """The one-call form of an edited layer: single rank, one prompt slice, the apply-only dual solver on factors that
+            are already in HBM (a warm call), the split-fp16 forward with its native runner."""
+            if not (fused_env and zc_from_keys and dual and not keep_factors and not plan.shard.collective and mids is not None
+                    and len(chunks) == 1 and plan.factors_from_cache and fac_done is None and clip_forward.NATIVE_RUNNER):
+                return False
+            x = xs[0]
+            if not (isinstance(x, hip.SplitRows) and x.f32 is not None and x.f32.is_contiguous()):
+                return False
+            gl = plan.graph.layers[li]
+            if gl.fc2 is not mods[li] or gl.fc2.bias is None:
+                return False
+            if order[li] not in plan.cov_factors.have_inverse and os.environ.get("EMCID_FUSED_NEEDS_INVERSE", "0") == "1":
+                return False
+            return clip_forward.native_of(plan.graph, chunks[0].trie, li, li + 1) is not None
 
         def on_fc2(li, xs, outs, mids=None, next_ln=None):
             """fc2 of an edited layer: keys -> closed form -> the projection with the NEW weight.  ``mids`` (the residual
@@ -663,6 +680,27 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
             if li not in order:
                 return outs
             m = mods[li]
+            if fused_layer_ok(li, xs, mids):
+                # keys, Zc, the solve, the new weight's planes and fc2 + residual + the next LN1: ONE C call
+                # (csrc/clip_layers.hip: emcid_clip_edit_layer_tail_sp16)
+                ch, x, i = chunks[0], xs[0], order[li]
+                nat = clip_forward.native_of(plan.graph, ch.trie, li, li + 1)
+                plan.resolve_targets()
+                w = weights[li]
+                try:
+                    res = hip.clip_edit_layer_tail(
+                        nat.array, li, nat.h, nat.d, x, mids[0], ch.trie.lookup_in_query if li == last else ch.trie.lookup_node,
+                        ch.seg, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, backups[li], w.data, plan.dual_ws,
+                        plan.lam, next_ln, last=li == last)
+                finally:
+                    _touch(w)
+                if li != last:      # the layer's fc2 planes were re-split in place from the new weight: keep the cache entry
+                    gl = plan.graph.layers[li]
+                    gl.splits["fc2"] = ((id(gl.fc2.weight), gl.fc2.weight._version, gl.fc2.weight.data_ptr()), gl.splits["fc2"][1])
+                edits.append(LayerEdit(li, plan.weight_name(li), res["dW"], None, None, res["K"] if trace else None,
+                                       res["Zc"] if trace else None))
+                clip_forward.LAST_PATHS["fused_edit_layers"] = clip_forward.LAST_PATHS.get("fused_edit_layers", 0) + 1
+                return None if li == last else [(res["hs"], res["x"])]
             K_loc = keys(li, xs)
             lin = clip_forward.linear
             if not zc_from_keys:

@@ -32,7 +32,7 @@ EXPORTS = [
     "emcid_apply_update2d_f32", "emcid_linear_f32", "emcid_linear_ws_f32", "emcid_linear_workspace_bytes",
     "emcid_split_rows_f16", "emcid_linear_sp16_f32", "emcid_add_layernorm_sp16", "emcid_embed_layernorm_sp16",
     "emcid_tree_attention_sp16", "emcid_tree_attention_sp16_supported", "emcid_clip_workspace_bytes",
-    "emcid_clip_layer_head_sp16", "emcid_clip_layer_tail_sp16", "emcid_clip_layers_sp16",
+    "emcid_clip_layer_head_sp16", "emcid_clip_layer_tail_sp16", "emcid_clip_layers_sp16", "emcid_clip_edit_layer_tail_sp16",
 ]
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block", "linear"]
@@ -116,6 +116,8 @@ def load():
         "emcid_clip_layer_head_sp16": (i32, [p, i64, i64, i64, i64, f32, p, i64, p, p, i64, p, p, p, p, p, p, p, p, i64, p]),
         "emcid_clip_layer_tail_sp16": (i32, [p, i64, i64, i64, p, p, p, p, p, p, f32, p, p, p]),
         "emcid_clip_layers_sp16": (i32, [p, i64, i64, i64, i64, i64, f32, p, i64, p, p, p, p, p, p, f32, p, i64, p]),
+        "emcid_clip_edit_layer_tail_sp16": (i32, [p, i64, i64, i64, p, p, p, p, p, p, i64, i64, p, f64, i32, f64, p, i64, i64, i32,
+                                                 p, p, p, p, p, p, i64, p, p, i64, p, p, p, f32, p, p, p]),
         "emcid_tree_attention_sp16": (i32, [p, i64, p, p, i64, p, i64, p, p, i64, i64, i64, f32, p, i64, p, p]),
         "emcid_linear_sp16_f32": (i32, [p, i64, p, p, i64, p, p, p, i64, p, i64, p, i64, p, i64, i64, i64, i32, i32, p]),
         "emcid_add_layernorm_f32": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p]),
@@ -870,6 +872,44 @@ def clip_layer_tail(layer_array, index: int, h: int, d: int, f: "SplitRows", mid
         float(next_ln.eps) if next_ln is not None else 0.0, _ptr(x.planes) if x is not None else None,
         _ptr(x.inv_scale) if x is not None else None, _stream(mid)), "emcid_clip_layer_tail_sp16")
     return hs, x
+
+
+def clip_edit_layer_tail(layer_array, index: int, h: int, d: int, f: "SplitRows", mid: torch.Tensor, lookup: torch.Tensor,
+                         seg: torch.Tensor, zs_t: torch.Tensor, factors: "CovFactors", layer_index: int, edit_weight: float,
+                         layers_left: int, W0: torch.Tensor, W: torch.Tensor, ws: "DualWorkspace", lam: Optional[float],
+                         next_ln: Optional[torch.nn.LayerNorm], last: bool, want_dw: bool = True):
+    """The rest of an edited layer behind ``clip_layer_head`` in ONE C call: keys, Zc, the apply-only dual solve (W = W0 + dW), the
+    new weight's planes and — unless ``last`` — fc2 + residual + the next layer's LN1.  Returns dict(K, Zc, dW, hs, x)."""
+    dev = mid.device
+    n = f.f32.shape[0]
+    N = seg.numel() - 1
+    K = torch.empty(N, d, dtype=torch.float32, device=dev)
+    Zc = torch.empty(N, h, dtype=torch.float32, device=dev)
+    dW = torch.empty(h, d, dtype=torch.float32, device=dev) if want_dw else None
+    hs = x = None
+    if not last:
+        hs = torch.empty(n, h, dtype=torch.float32, device=dev)
+        if next_ln is not None:
+            x = SplitRows(torch.empty(n, h, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.float32, device=dev))
+    lws = _linear_workspace(dev) if (d >= 2048 and -(-N // 128) * -(-h // 128) <= 128
+                                     and not torch.cuda.is_current_stream_capturing()) else None
+    if LINEAR_FLOPS["count"]:
+        LINEAR_FLOPS["flops"] += 2.0 * N * h * d + (0.0 if last else 2.0 * n * h * d)
+        LINEAR_FLOPS["launches"] += 1 if last else 2
+    base = C.addressof(layer_array) + index * C.sizeof(ClipLayerSp16)
+    use_inverse = layer_index in factors.have_inverse
+    _check(load().emcid_clip_edit_layer_tail_sp16(
+        C.c_void_p(base), n, h, d, _ptr(f.f32, torch.float32, "fc2 input"), _ptr(f.planes), _ptr(f.inv_scale),
+        _ptr(mid, torch.float32, "mid"), _ptr(lookup, torch.int64, "lookup"), _ptr(seg, torch.int64, "seg"), lookup.numel(), N,
+        _ptr(zs_t, torch.float32, "zs_t"), float(edit_weight), int(layers_left), factors.lam_ratio(lam), _ptr(factors.buf),
+        factors.n_layers, int(layer_index), int(bool(use_inverse)), _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"),
+        _ptr(dW), _ptr(K), _ptr(Zc), _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32),
+        C.c_void_p(lws.data_ptr()) if lws is not None else None, lws.numel() if lws is not None else 0, _ptr(hs),
+        _ptr(next_ln.weight, torch.float32, "gamma") if (next_ln is not None and not last) else None,
+        _ptr(next_ln.bias, torch.float32, "beta") if (next_ln is not None and not last) else None,
+        float(next_ln.eps) if (next_ln is not None and not last) else 0.0, _ptr(x.planes) if x is not None else None,
+        _ptr(x.inv_scale) if x is not None else None, _stream(mid)), "emcid_clip_edit_layer_tail_sp16")
+    return {"K": K, "Zc": Zc, "dW": dW, "hs": hs, "x": x}
 
 
 # ---- dual (Woodbury) solver ---------------------------------------------------------------------------------------------
