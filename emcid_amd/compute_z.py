@@ -624,6 +624,152 @@ def compute_z_text_encoder(pipe, request: Dict, hparams, layer: int, device=None
     return (state["source_init"] + delta).detach()
 
 
+SLD_SAFE_WORDS = ("hate, harassment, violence, suffering, humiliation, harm, suicide, sexual, nudity, bodily fluids, blood, "
+                  "obscene gestures, illegal activity, drug use, theft, vandalism, weapons, child abuse, brutality, cruelty")
+SLD_PRESETS = {     # reference :2448-2466 (the "max" / "strong" configurations of safe latent diffusion)
+    "max": dict(sld_guidance_scale=5000, sld_warmup_steps=0, sld_threshold=1.0, sld_momentum_scale=0.5, sld_mom_beta=0.7),
+    "strong": dict(sld_guidance_scale=2000, sld_warmup_steps=7, sld_threshold=0.025, sld_momentum_scale=0.5, sld_mom_beta=0.7),
+}
+
+
+def compute_z_unet_x_kv(pipe, request: Dict, hparams, device=None, noise_scheduler=None, resolution: int = 512,
+                        rng_device=None) -> Dict[str, torch.Tensor]:
+    """Stage 1 of the cross-attention sibling: the target vector of EVERY ``attn2.to_k`` / ``to_v`` projection of the UNet (16
+    blocks x 2 for SD-v1.x) for one concept — the projection's output at the last subject token of the first prompt plus a
+    delta found by ONE Adam over all of them on the denoising objective: MSE between the edited UNet's prediction and a
+    supervision built from the clean UNet's predictions (safe-latent-diffusion guidance away from the ``safe words``, or the esd
+    form), plus the mean weight decay, each delta projected onto its own L2 ball (reference: emcid/compute_z.py:2407-2645; same
+    arguments, same return: {layer name: (out_features,) tensor}; called on a v* miss at emcid_main.py:398).
+
+    Results-identical restructuring as in ``compute_z_text_encoder``: the UNet is hooked in place instead of deep-copied (its
+    clean passes run with the hook switched off), the hook adds delta prompt by prompt like the reference's edit_output_fn
+    (:2482-2492) so that autograd sums delta's gradient in the reference's order; no loss log file.  Random draws in the
+    reference's order (image flips; per step sample indices, VAE posterior noise, latent noise, timesteps).  The reference
+    defines ``samples_per_prompt`` only when it samples the training images from the pipeline (:2503-2510; with
+    ``training_img_paths`` it stops at a NameError): here hparams.samples_per_prompt in every case, and ``request["images"]``
+    is accepted like in the other Stage-1 forms."""
+    from PIL import Image
+    hp = hparams
+    te, unet = pipe.text_encoder, pipe.unet
+    dev = next(unet.parameters()).device
+    rdev = torch.device(rng_device) if rng_device is not None else dev
+    host_draw = rdev.type == "cpu" and dev.type != "cpu"
+    tok = pipe.tokenizer
+    sched = noise_scheduler if noise_scheduler is not None else default_noise_scheduler()
+    if not hp.sld_supervision and hp.objective != "esd":
+        raise ValueError("compute_z_unet_x_kv needs sld_supervision or objective == 'esd' (reference :2566-2590 defines no "
+                         "supervision otherwise)")
+    source_prompts = [p.format(request["source"]) for p in request["prompts"]]
+    src_inp = tokenize_prompts(source_prompts, tok, dev)
+    finder = finder_for(tok)
+    src_lookup = [finder(ids, request["source"])[-1] - 1 for ids in src_inp["input_ids"].tolist()]
+    bsz = len(source_prompts)
+    sld = None
+    if hp.sld_supervision:
+        safe_words = SLD_SAFE_WORDS if hp.all_safe else request["safe words"]
+        if hp.sld_type not in SLD_PRESETS:
+            raise ValueError(f"sld_type {hp.sld_type} not supported")
+        sld = {k: torch.tensor(v).to(dev) for k, v in SLD_PRESETS[hp.sld_type].items()}
+    from .layer_stats import get_all_cross_attn_kv_layer_names
+    names = get_all_cross_attn_kv_layer_names(pipe)            # the reference's order (down, up, mid; to_k then to_v per block)
+    mods = dict(unet.named_modules())
+    frozen = [prm for m in (unet, pipe.vae, te) for prm in m.parameters() if prm.requires_grad]
+    for prm in frozen:
+        prm.requires_grad_(False)
+    deltas = {n: torch.zeros((mods[n].out_features,), requires_grad=True, device=dev) for n in names}
+    inits: Dict[str, Optional[torch.Tensor]] = {n: None for n in names}
+    state = {"edit": False}
+
+    def make_hook(name):
+        def hook(mod, args, out):
+            if not state["edit"]:
+                return out
+            if inits[name] is None:
+                inits[name] = out[0, src_lookup[0]].detach().clone()
+            out = out.clone()
+            for i, idx in enumerate(src_lookup):
+                if hp.replace_repr:
+                    out[i, idx, :] = deltas[name]
+                else:
+                    out[i, idx, :] += deltas[name]
+            return out
+        return hook
+
+    opt = torch.optim.Adam([deltas[n] for n in names], lr=hp.v_lr)
+    spp = hp.samples_per_prompt
+    if "training_img_paths" in request:
+        images = [Image.open(path) for path in request["training_img_paths"]]
+    elif "images" in request:
+        images = request["images"]
+    else:
+        gen = torch.Generator(dev).manual_seed(int(request["seed_train"]))
+        images = []
+        for _ in range(spp):
+            images.extend(pipe(source_prompts, guidance_scale=7.5, generator=gen).images)
+    if len(images) % bsz:
+        raise AssertionError(f"len(img_batch) {len(images)} should be n times of batch size {bsz}")
+    pixels = preprocess_img(images, resolution)
+    pixels = pixels.reshape(spp, bsz, *pixels.shape[1:]).transpose(0, 1)              # "(s b) c h w -> b s c h w"
+    handles = [mods[n].register_forward_hook(make_hook(n)) for n in names]
+    try:
+        with torch.no_grad():
+            source_repr = te(**src_inp)[0]
+            safe_repr = te(**tokenize_prompts([safe_words] * bsz, tok, dev))[0] if sld is not None else None
+            uncond_repr = te(**tokenize_prompts([""] * bsz, tok, dev))[0]
+        posteriors = {}
+        for it in range(hp.v_num_grad_steps):
+            opt.zero_grad()
+            sample_indices = torch.randint(0, spp, (bsz,))
+            key = tuple(sample_indices.tolist())
+            if key not in posteriors:
+                with torch.no_grad():
+                    posteriors[key] = pipe.vae.encode(pixels[torch.arange(bsz), sample_indices].to(dev)).latent_dist
+            with torch.no_grad():
+                latents = posteriors[key].sample(torch.default_generator) if host_draw else posteriors[key].sample()
+                latents = latents * pipe.vae.config.scaling_factor
+            if host_draw:
+                noise = torch.randn(latents.shape, dtype=latents.dtype).to(dev)
+                timesteps = torch.randint(0, sched.config.num_train_timesteps, (bsz,)).long().to(dev)
+            else:
+                noise = torch.randn_like(latents, device=dev)
+                timesteps = torch.randint(0, sched.config.num_train_timesteps, (bsz,), device=dev).long()
+            noisy = sched.add_noise(latents, noise, timesteps)
+            with torch.no_grad():
+                pred_source = unet(noisy, timesteps, source_repr).sample
+                pred_uncond = unet(noisy, timesteps, uncond_repr).sample
+                if sld is not None:      # the safe-latent-diffusion guidance of StableDiffusionPipelineSafe (:2566-2584)
+                    pred_safety = unet(noisy, timesteps, safe_repr).sample
+                    scale = torch.clamp(torch.abs(pred_source - pred_safety) * sld["sld_guidance_scale"], max=1.0)
+                    concept_scale = torch.where((pred_source - pred_safety) >= sld["sld_threshold"], torch.zeros_like(scale), scale)
+                    supervision = pred_source - torch.mul(pred_safety - pred_uncond, concept_scale)
+                else:
+                    supervision = pred_uncond - hp.esd_mu * (pred_source - pred_uncond)
+            state["edit"] = True
+            try:
+                edit_pred = unet(noisy, timesteps, source_repr).sample
+            finally:
+                state["edit"] = False
+            mse = F.mse_loss(edit_pred, supervision, reduction="mean")
+            decay = 0
+            for n in names:
+                decay += hp.v_weight_decay * (torch.norm(deltas[n]) / torch.norm(inits[n]) ** 2)
+            loss = mse + decay / len(names)
+            loss.backward()
+            opt.step()
+            for n in names:
+                max_norm = hp.clamp_norm_factor * inits[n].norm()
+                if deltas[n].norm() > max_norm:
+                    with torch.no_grad():
+                        deltas[n][...] = deltas[n] * max_norm / deltas[n].norm()
+    finally:
+        for hd in handles:
+            hd.remove()
+        for prm in frozen:
+            prm.requires_grad_(True)
+    with torch.no_grad():
+        return {n: inits[n] + deltas[n] for n in names}
+
+
 def compute_z_text_encoder_v2(pipe, request: Dict, hparams, layer: int, device=None, noise_scheduler=None,
                               resolution: int = 512, rng_device=None) -> torch.Tensor:
     """The ``use_new_compute_z`` Stage 1: ``hparams.num_edit_tokens`` vectors per concept, (k, hidden) — row 0 for the last

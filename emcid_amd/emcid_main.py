@@ -583,9 +583,9 @@ def load_v_stars_cross_attn(requests: Sequence[Dict], cache_name: Optional[str],
         if got is None:
             if stage1 is None:
                 raise NotImplementedError(
-                    f"no cached cross-attention v* for request {idx} ([{request['source']}]) at {f}: Stage 1 "
-                    f"(compute_z_unet_x_kv, needs the SD UNet and its noise-prediction loss) is out of scope of this "
-                    f"build — pass cache_name pointing at the reference's npz files or a stage1= callable")
+                    f"no cached cross-attention v* for request {idx} ([{request['source']}]) at {f} and no way to compute it: "
+                    f"Stage 1 (compute_z_unet_x_kv) needs a pipeline with a UNet and a VAE — pass cache_name pointing at "
+                    f"the reference's npz files or a stage1= callable")
             got = {n: v.detach().float().cpu().numpy() for n, v in stage1(request).items()}
             if f is not None:
                 f.parent.mkdir(exist_ok=True, parents=True)
@@ -610,6 +610,11 @@ def _edit_cross_attn(pipe, requests, hparams, cache_name, stats_dir, keep_factor
     for n, w in weights.items():
         if not (w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()):
             raise hip.EmcidHipError(f"{n}.weight must be a contiguous fp32 tensor in HBM (got {w.dtype} on {w.device})")
+    if stage1 is None and getattr(pipe, "unet", None) is not None and getattr(pipe, "vae", None) is not None:
+        # a v* miss runs Stage 1 of this sibling on the caller's UNet / VAE, like the reference (:398)
+        from .compute_z import compute_z_unet_x_kv
+        device = next(pipe.unet.parameters()).device
+        stage1 = lambda request: compute_z_unet_x_kv(pipe, request, hparams, device)
     zs = load_v_stars_cross_attn(requests, cache_name, names, stage1)
     covs = {n: get_cov_cross_attn(pipe, n, hparams.mom2_dataset, hparams.mom2_n_samples, hparams.mom2_dtype,
                                   verbose=verbose, stats_dir=stats_dir) for n in names}

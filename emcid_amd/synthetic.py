@@ -139,6 +139,14 @@ class SyntheticPipe(SimpleNamespace):
     def device(self):
         return next(self.text_encoder.parameters()).device
 
+    def __call__(self, prompts, guidance_scale: float = 7.5, generator=None, **kw):
+        """Stand-in for image generation (the reference samples Stage-1 training images with ``pipe(prompts, ...).images``,
+        emcid/compute_z.py:2503-2510): one deterministic image per prompt, seeded by a draw from ``generator``."""
+        res = int(getattr(self, "image_resolution", 32))
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,), generator=generator,
+                                 device=generator.device if generator is not None else "cpu").item())
+        return SimpleNamespace(images=make_images(len(prompts), res, seed=seed))
+
     def to(self, device):
         self.text_encoder.to(device)
         if getattr(self, "text_encoder_2", None) is not None:

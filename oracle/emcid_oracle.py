@@ -947,6 +947,116 @@ def layer_stats_cross_attn_kv(pipe, layer_name: str, captions: List[str], sample
     return stat
 
 
+def compute_z_unet_x_kv(pipe, request: Dict, hparams: Dict, noise_scheduler, resolution: int = 512) -> Dict[str, torch.Tensor]:
+    """Stage 1 of the cross-attention sibling (compute_z.py:2407-2645), op for op: a deep copy of the UNet whose attn2.to_k /
+    to_v outputs get their delta added in place at every prompt's last subject token (the TraceDict edit_output of :2482-2492,
+    here forward hooks on the copy), per step one VAE encode + sample, the clean UNet's source / unconditional (/ safety)
+    predictions, the safe-latent-diffusion or esd supervision, MSE + mean weight decay, one Adam over all deltas, projection of
+    every delta onto its L2 ball.  Randomness: the global torch generators, consumed in the reference's order."""
+    from copy import deepcopy
+    import torch.nn.functional as F
+    hp = lambda k, d=None: hparams.get(k, d)
+    device = pipe.device
+    unet_to_edit = deepcopy(pipe.unet).to(device)
+    tok = pipe.tokenizer
+    source_prompts = [p.format(request["source"]) for p in request["prompts"]]
+    src_inp = tokenize_prompts(source_prompts, tok, device)
+    src_lookup = [find_token_range(tok, ids, request["source"])[-1] - 1 for ids in src_inp["input_ids"]]
+    if hp("sld_supervision", False):
+        if hp("all_safe", False):
+            safe_words = ('hate, harassment, violence, suffering, humiliation, harm, suicide, '
+                          'sexual, nudity, bodily fluids, blood, obscene gestures, illegal activity, '
+                          'drug use, theft, vandalism, weapons, child abuse, brutality, cruelty')
+        else:
+            safe_words = request["safe words"]
+        if hp("sld_type", "max") == "max":
+            sld = {"sld_guidance_scale": 5000, "sld_warmup_steps": 0, "sld_threshold": 1.0, "sld_momentum_scale": 0.5, "sld_mom_beta": 0.7}
+        elif hp("sld_type") == "strong":
+            sld = {"sld_guidance_scale": 2000, "sld_warmup_steps": 7, "sld_threshold": 0.025, "sld_momentum_scale": 0.5, "sld_mom_beta": 0.7}
+        else:
+            raise ValueError(f"sld_type {hp('sld_type')} not supported")
+        sld = {k: torch.tensor(v).to(device) for k, v in sld.items()}
+    layer_names = get_all_cross_attn_kv_layer_names(pipe.unet)
+    delta_dict = {n: torch.zeros((get_module(pipe.unet, n).out_features,), requires_grad=True, device=device) for n in layer_names}
+    init_dict = {n: None for n in layer_names}
+
+    def make_hook(name):
+        def hook(mod, args, cur_out):
+            if init_dict[name] is None:
+                init_dict[name] = cur_out[0, src_lookup[0]].detach().clone()
+            for i, idx in enumerate(src_lookup):
+                if hp("replace_repr", False):
+                    cur_out[i, idx, :] = delta_dict[name]
+                else:
+                    cur_out[i, idx, :] += delta_dict[name]
+            return cur_out
+        return hook
+
+    opt = torch.optim.Adam([delta_dict[n] for n in layer_names], lr=hp("v_lr"))
+    for m in (unet_to_edit, pipe.vae, pipe.unet, pipe.text_encoder):
+        for prm in m.parameters():
+            prm.requires_grad = False
+    spp = hp("samples_per_prompt", 1)
+    if "images" in request:                    # (not in the reference: lets a GPU run use the images a CPU run generated)
+        all_imgs = request["images"]
+    else:
+        generator = torch.Generator(pipe.device).manual_seed(int(request["seed_train"]))
+        all_imgs = []
+        for _ in range(spp):
+            all_imgs.extend(pipe(source_prompts, guidance_scale=7.5, generator=generator).images)
+    bsz = len(source_prompts)
+    assert len(all_imgs) % bsz == 0
+    all_imgs = preprocess_img(all_imgs, resolution)
+    all_imgs = all_imgs.reshape(spp, bsz, *all_imgs.shape[1:]).transpose(0, 1)       # "(s b) c h w -> b s c h w"
+    with torch.no_grad():
+        source_repr = pipe.text_encoder(**src_inp)[0]
+        if hp("sld_supervision", False):
+            safe_repr = pipe.text_encoder(**tokenize_prompts([safe_words] * bsz, tok, device))[0]
+        uncond_repr = pipe.text_encoder(**tokenize_prompts([""] * bsz, tok, device))[0]
+    copy_mods = dict(unet_to_edit.named_modules())
+    for it in range(hp("v_num_grad_steps")):
+        opt.zero_grad()
+        sample_indices = torch.randint(0, spp, (bsz,))
+        imgs = all_imgs[torch.arange(bsz), sample_indices].to(device)
+        with torch.no_grad():
+            latents = pipe.vae.encode(imgs).latent_dist.sample()
+            latents = latents * pipe.vae.config.scaling_factor
+        handles = [copy_mods[n].register_forward_hook(make_hook(n)) for n in layer_names]
+        try:
+            noise = torch.randn_like(latents, device=device)
+            timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (bsz,), device=device).long()
+            noisy = noise_scheduler.add_noise(latents, noise, timesteps)
+            with torch.no_grad():
+                pred_source = pipe.unet(noisy, timesteps, source_repr).sample
+                pred_uncond = pipe.unet(noisy, timesteps, uncond_repr).sample
+                if hp("sld_supervision", False):
+                    pred_safety = pipe.unet(noisy, timesteps, safe_repr).sample
+                    scale = torch.clamp(torch.abs((pred_source - pred_safety)) * sld["sld_guidance_scale"], max=1.0)
+                    concept_scale = torch.where((pred_source - pred_safety) >= sld["sld_threshold"], torch.zeros_like(scale), scale)
+                    guidance = torch.mul((pred_safety - pred_uncond), concept_scale)
+                    supervision = pred_source - guidance
+                elif hp("objective") == "esd":
+                    supervision = pred_uncond - hp("esd_mu") * (pred_source - pred_uncond)
+            edit_pred = unet_to_edit(noisy, timesteps, source_repr).sample
+            mse = F.mse_loss(edit_pred, supervision, reduction="mean")
+            weight_decay = 0
+            for n in layer_names:
+                weight_decay += hp("v_weight_decay") * (torch.norm(delta_dict[n]) / torch.norm(init_dict[n]) ** 2)
+            loss = mse + weight_decay / len(layer_names)
+            loss.backward()
+            opt.step()
+            for n in layer_names:
+                max_norm = hp("clamp_norm_factor") * init_dict[n].norm()
+                if delta_dict[n].norm() > max_norm:
+                    with torch.no_grad():
+                        delta_dict[n][...] = delta_dict[n] * max_norm / delta_dict[n].norm()
+        finally:
+            for hd in handles:
+                hd.remove()
+    with torch.no_grad():
+        return {n: init_dict[n] + delta_dict[n] for n in layer_names}
+
+
 def load_cov_cross_attn(stats_dir, layer_name, n_samples, precision="float32") -> torch.Tensor:
     """emcid_main.py:2217-2232 with the statistics already cached on disk (layer_stats.py:361: model_name "unet")."""
     with np.load(stats_path(stats_dir, layer_name, n_samples, precision, model_name="unet")) as z:

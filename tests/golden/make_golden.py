@@ -272,6 +272,50 @@ def golden_stage1_more(cz, EMCIDHyperParams, scratch, tag="toy_stage1_more"):
     print(f"[golden] {tag}: wrote {len(out)} arrays: " + ", ".join(f"{k}: |v*| {np.linalg.norm(out[k + '/v_star']):.4f}" for k in STAGE1_MORE_CASES))
 
 
+XATTN_STAGE1_CASES = {
+    # safe-latent-diffusion supervision with the request's own safe words ("max" preset), the esd supervision with replace_repr,
+    # and the "strong" preset over the built-in list of safety concepts
+    "sld_max": dict(hp=dict(sld_supervision=True, sld_type="max", v_lr=0.05, v_weight_decay=5e-4, clamp_norm_factor=1.5,
+                            v_num_grad_steps=8, samples_per_prompt=2), seed=611, req={"safe words": "tocife, bamilo"}),
+    "esd_replace": dict(hp=dict(objective="esd", esd_mu=1.0, replace_repr=True, v_lr=0.02, v_weight_decay=1e-3, clamp_norm_factor=0.8,
+                                v_num_grad_steps=6, samples_per_prompt=1), seed=77, req={}),
+    "sld_strong_all_safe": dict(hp=dict(sld_supervision=True, sld_type="strong", all_safe=True, v_lr=0.1, v_weight_decay=5e-4,
+                                        clamp_norm_factor=1.2, v_num_grad_steps=7, samples_per_prompt=2), seed=5, req={}),
+}
+
+
+def golden_xattn_stage1(cz, EMCIDHyperParams, scratch, tag="toy_xattn_stage1"):
+    """Stage 1 of the cross-attention sibling: the REAL reference's compute_z_unet_x_kv (compute_z.py:2407-2645) on the synthetic
+    pipe (UNet stand-in with the 32 attn2.to_k / to_v projections under their real names, VAE stand-in, DDPM schedule stub; the
+    training images come from ``pipe(prompts, ...)`` like in the reference: the synthetic pipe draws them from the generator)."""
+    (scratch / "log").mkdir(exist_ok=True)
+    out, meta = {}, {"cases": {}, "resolution": STAGE1_RESOLUTION}
+    for name, c in XATTN_STAGE1_CASES.items():
+        pipe = syn.add_diffusion(syn.build_pipe("toy", "cpu"))
+        pipe.image_resolution = STAGE1_RESOLUTION
+        hp_d = syn.sd_hparams_dict(layers=(1, 2, 3, 4), prefix="")
+        hp_d.update(c["hp"])
+        hp = EMCIDHyperParams(**hp_d)
+        request = {"source": "c0042", "dest": "a realist artist", "prompts": list(syn.ARTIST_TEMPLATES), "seed_train": 2024}
+        request.update(c["req"])
+        # the images the reference is about to sample (same generator, same calls), kept for runs on another device
+        gen = torch.Generator("cpu").manual_seed(int(request["seed_train"]))
+        src = [p.format(request["source"]) for p in request["prompts"]]
+        imgs = [im for _ in range(hp.samples_per_prompt) for im in pipe(src, guidance_scale=7.5, generator=gen).images]
+        torch.manual_seed(c["seed"])
+        with contextlib.redirect_stdout(io.StringIO()):
+            vs = cz.compute_z_unet_x_kv(pipe, dict(request), hp, "cpu")
+        for ln, v in vs.items():
+            out[f"{name}/v_star/{ln}"] = v.detach().numpy()
+        out[f"{name}/images"] = np.stack([np.asarray(im) for im in imgs])
+        meta["cases"][name] = {"hparams": hp_d, "seed": c["seed"], "request": request, "layer_names": list(vs)}
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump(meta, f, indent=1)
+    print(f"[golden] {tag}: wrote {len(out)} arrays; " + ", ".join(
+        f"{k}: mean |v*| {np.mean([np.linalg.norm(out[a]) for a in out if a.startswith(k + '/v_star/')]):.4f}" for k in XATTN_STAGE1_CASES))
+
+
 STAGE1_XL_CASES = {
     # the shipped SDXL hparams' Stage-1 settings (hparams/sdxl-dest_s-100_c-1.2_ly-8-11_ly2-26-31_lr-0.1_wd-8e-03_txt-align-0.01.json), fewer steps
     "shipped_xl": dict(hp=dict(objective="ablate-dest", cal_text_repr_loss=True, text_repr_loss_scale_factor=0.005, v_lr=0.1,
@@ -906,6 +950,8 @@ def main():
                 golden_stage1_sdxl(cz, XLHP, scratch)
             elif which == "toy_stage1_more":
                 golden_stage1_more(cz, HP, scratch)
+            elif which == "toy_xattn_stage1":
+                golden_xattn_stage1(cz, HP, scratch)
             elif which == "toy_multi_token":
                 golden_multi_token(em, HP, scratch)
             else:
@@ -923,6 +969,7 @@ def main():
         golden_stage1(cz, HP, scratch)
         golden_stage1_sdxl(cz, XLHP, scratch)
         golden_stage1_more(cz, HP, scratch)
+        golden_xattn_stage1(cz, HP, scratch)
         golden_multi_token(em, HP, scratch)
         if "--skip-real" not in sys.argv:
             golden_sd(em, HP, scratch, "real_sd_summary", "sd-v1.4", n_req=24, layers=(7, 8, 9, 10), lam=4000,

@@ -519,3 +519,28 @@ def test_stage1_ewc_batched_equals_sequential(tmp_path, monkeypatch):
                                             resolution=meta["resolution"])
     for a, b in zip(seq, bat):
         assert (a - b).abs().max().item() <= 2e-6 * a.abs().max().item()
+
+
+@pytest.mark.parametrize("name", ["sld_max", "esd_replace", "sld_strong_all_safe"])
+def test_cross_attn_stage1_matches_reference(name):
+    """Stage 1 of the cross-attention sibling (compute_z_unet_x_kv, compute_z.py:2407-2645; run on a v* miss at
+    emcid_main.py:398): one Adam over the deltas of all 32 attn2.to_k / to_v outputs against the safe-latent-diffusion (or esd)
+    supervision.  The oracle's op-for-op restatement and the product's restructured loop (UNet hooked in place, clean passes
+    with the hook off) both reproduce the REAL reference's 32 target vectors bit for bit on the CPU (fixture toy_xattn_stage1;
+    the training images are sampled from ``pipe(prompts, ...)`` like in the reference)."""
+    from emcid_amd.compute_z import compute_z_unet_x_kv
+    z, meta = load_golden("toy_xattn_stage1")
+    c = meta["cases"][name]
+    for which in ("oracle", "product"):
+        pipe = syn.add_diffusion(syn.build_pipe("toy", "cpu"))
+        pipe.image_resolution = meta["resolution"]
+        torch.manual_seed(c["seed"])
+        if which == "oracle":
+            vs = orc.compute_z_unet_x_kv(pipe, dict(c["request"]), c["hparams"], syn.DDPMNoiseSchedule(), meta["resolution"])
+        else:
+            vs = compute_z_unet_x_kv(pipe, dict(c["request"]), EMCIDHyperParams(**c["hparams"]), "cpu",
+                                     noise_scheduler=syn.DDPMNoiseSchedule(), resolution=meta["resolution"])
+        assert list(vs) == c["layer_names"] and len(vs) == 32
+        for ln, v in vs.items():
+            np.testing.assert_array_equal(v.numpy(), z[f"{name}/v_star/{ln}"], err_msg=f"{which} {ln}")
+        assert all(p.requires_grad is False for p in pipe.unet.parameters())          # the synthetic UNet is frozen: left as found
