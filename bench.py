@@ -334,22 +334,11 @@ def main():
         rank_elapsed, elapsed = elapsed, float(tmax.item())
         # per-rank phase times (a few more calls OUTSIDE the timed region, with event brackets around the collectives and the
         # solves): what a scaling curve is read with
-        edit_engine.DIST_TIMING["enabled"] = True
-        edit_engine.dist_timing_collect()
-        k_diag = max(2, min(5, args.steps))
-        diag_s, _ = timed_calls(k_diag, first_set=1 + args.warmup)
-        phases = {k: {"ms_per_call": v[0] / k_diag, "brackets_per_call": v[1] / k_diag}
-                  for k, v in edit_engine.dist_timing_collect().items()}
-        edit_engine.DIST_TIMING["enabled"] = False
-        coll = sum(v["ms_per_call"] for k, v in phases.items() if k.startswith(("all_reduce", "k_all_gather")))
-        mine = {"rank": rank, "device": str(device), "timed_region_s": rank_elapsed, "ms_per_call": diag_s / k_diag * 1e3,
-                "phases_ms_per_call": phases, "collectives_ms_per_call": coll,
-                "forward_and_host_ms_per_call": diag_s / k_diag * 1e3 - phases.get("solve (incl. its collectives)", {}).get("ms_per_call", 0.0),
-                "host_phases_ms_per_call": host_phases, "concepts_of_this_rank": shard.bounds(args.concepts)[1] - shard.bounds(args.concepts)[0]
-                if hasattr(shard, "bounds") else None}
-        gathered = [None] * world
-        dist.all_gather_object(gathered, mine)
-        per_rank = gathered
+        try:
+            per_rank = _per_rank_phases(edit_engine, dist, timed_calls, args, rank, world, device, shard, rank_elapsed, host_phases)
+        except Exception as e:         # diagnostics must never cost the line
+            edit_engine.DIST_TIMING["enabled"] = False
+            per_rank = {"error": repr(e)}
     value = args.concepts * args.steps / elapsed
 
     # ---- the same 1 000 requests again and again (what rounds 1-2 reported as the step) ------------------------------------
@@ -597,6 +586,26 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _per_rank_phases(edit_engine, dist, timed_calls, args, rank, world, device, shard, rank_elapsed, host_phases):
+    """A few more calls OUTSIDE the timed region with event brackets around the collectives and the solves, gathered from every rank."""
+    edit_engine.DIST_TIMING["enabled"] = True
+    edit_engine.dist_timing_collect()
+    k_diag = max(2, min(5, args.steps))
+    diag_s, _ = timed_calls(k_diag, first_set=1 + args.warmup)
+    phases = {k: {"ms_per_call": v[0] / k_diag, "brackets_per_call": v[1] / k_diag}
+              for k, v in edit_engine.dist_timing_collect().items()}
+    edit_engine.DIST_TIMING["enabled"] = False
+    coll = sum(v["ms_per_call"] for k, v in phases.items() if k.startswith(("all_reduce", "k_all_gather")))
+    lo, hi = shard.bounds(args.concepts)
+    mine = {"rank": rank, "device": str(device), "timed_region_s": rank_elapsed, "ms_per_call": diag_s / k_diag * 1e3,
+            "phases_ms_per_call": phases, "collectives_ms_per_call": coll,
+            "forward_and_host_ms_per_call": diag_s / k_diag * 1e3 - phases.get("solve (incl. its collectives)", {}).get("ms_per_call", 0.0),
+            "host_phases_ms_per_call": host_phases, "concepts_of_this_rank": hi - lo}
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    return gathered
 
 
 def cpu_model():

@@ -1208,7 +1208,7 @@ def test_cross_attn_stage1_on_gpu_matches_reference_golden(name):
         ref = z[f"{name}/v_star/{ln}"]
         worst = max(worst, np.abs(v.cpu().numpy() - ref).max() / np.abs(ref).max())
     print(f"cross-attention stage 1 on the GPU, {name}: worst of 32 projections {worst:.2e}")
-    assert worst <= 2e-4
+    assert worst <= 2e-5           # measured on MI355X: 7e-7 .. 8e-7
 
 
 def test_cross_attn_cache_miss_runs_stage1_then_edits(tmp_path):
