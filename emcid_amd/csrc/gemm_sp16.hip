@@ -134,7 +134,7 @@ __device__ __forceinline__ void sp_accumulate(const SpArgs& a, int m0, int n0, i
     // fragments: lane (row l31, half l5) of k16-step t reads group 2 t + l5 of its row: hi at +0, lo at +16
     const int fx_off = (wm0 + l31) * SPROW + 32 * l5 + 128 * grp;
     const int fw_off = (BM + wn0 + l31) * SPROW + 32 * l5 + 128 * grp;
-    constexpr int NSLOT = (MJ * NI > 4 && SP16_ONE_SLOT) ? 1 : 2;
+    constexpr int NSLOT = ((MJ * NI > 4 && SP16_ONE_SLOT) || MJ * NI > 5) ? 1 : 2;
     v8h xh[NSLOT][MJ], xl[NSLOT][MJ], wh[NSLOT][NI], wl[NSLOT][NI];
     auto fread = [&](const unsigned char* stage, int t, int slot) __attribute__((always_inline)) {
 #pragma unroll
@@ -171,7 +171,7 @@ __device__ __forceinline__ void sp_accumulate(const SpArgs& a, int m0, int n0, i
     gload(min(1, T - 1), SpIC<1 % PF>{});
     if constexpr (PF > 1) gload(min(2, T - 1), SpIC<2 % PF>{});
     __syncthreads();
-    constexpr bool ONE_SLOT = MJ * NI > 4 && SP16_ONE_SLOT;       // five blocks per wave: a second set of fragments would not fit in 256 registers
+    constexpr bool ONE_SLOT = (MJ * NI > 4 && SP16_ONE_SLOT) || MJ * NI > 5;       // five blocks per wave: a second set of fragments would not fit in 256 registers
     if constexpr (!ONE_SLOT) fread(smem, 0, 0);
     if constexpr (DBG >= 3) fread(smem, 1, 1);
     auto body = [&](auto rc, int it) __attribute__((always_inline)) {
@@ -598,7 +598,10 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
     EMCID_CHECK_ARG(M < (1 << 24) && N < (1 << 24) && K < (1 << 24) && (residual == nullptr || ldr >= N) && (Y == nullptr || ldy >= N));
     EMCID_CHECK_ARG(Yp == nullptr || (N % 8 == 0 && ldp >= N && ldp % 4 == 0 && aligned16(Yp)));
     EMCID_CHECK_ARG(act >= SP_ACT_NONE && act <= SP_ACT_GELU_ERF && cfg >= -1 && cfg < 64);
-    // cfg: bits 0-1 tile (0: 128 x 128 on 4 waves, 1: 256 x 128 on 8 waves, 2: 64 x 64 on 4 waves, 3: 160 x 128 on 8 waves with
+    // (A 256 x 256 tile on eight waves — 128 x 64 per wave, the vendor library's choice for the q | k | v shape: 225 tiles — needs
+    // 128 accumulator + 48 fragment + 32 staging registers plus addresses: hipcc spills at the 256 two waves per SIMD allow, 423 us on
+    // the qkv shape; removed.)
+    // cfg: bits 0-1 tile (0: 128 x 128 on 4 waves, 1: two 128 x 128 tiles ping-pong on 8 waves, 2: 64 x 64 on 4 waves, 3: 160 x 128 on 8 waves with
     // the K range of a 64-deep stage split between two wave groups), bits 2-3: prefetch distance - 1, bits 4-5: timing
     // experiments (tile 0, prefetch 2; results wrong); -1: auto
     const int dbg = cfg < 0 ? 0 : (cfg >> 4) & 3;
