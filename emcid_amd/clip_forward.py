@@ -289,6 +289,21 @@ def _graph_signature(graph: ClipTextGraph) -> tuple:
     return tuple(sig)
 
 
+def invalidate_weight_caches(text_encoder=None):
+    """Forget everything derived from an encoder's weights — the stacked q | k | v snapshots, the split-fp16 planes and the native
+    runner's structs (all encoders when ``text_encoder`` is None).  The caches follow a weight by tensor identity, address and
+    torch's in-place version counter; code that rewrites a weight in a way the counter does not see (``param.data.add_(...)``, a raw
+    pointer) calls this afterwards — or bumps the counter itself (``torch.autograd.graph.increment_version``), as the edit
+    engine does for the weights its kernels write."""
+    if text_encoder is None:
+        _GRAPHS.clear()
+        return
+    try:
+        _GRAPHS.pop(text_encoder, None)
+    except TypeError:
+        pass
+
+
 def discover_cached(text_encoder, layer_module_tmp: str) -> ClipTextGraph:
     """``discover`` once per encoder object: the module walk and the stacked q|k|v copies are reused by later edits as long
     as the q/k/v parameters are the same tensors and have not been written in place (their version counters)."""

@@ -955,3 +955,17 @@ def test_host_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert host_text.load().emcid_host_abi_version() == host_text.ABI_VERSION
     assert lib.emcid_read_npz_rows_f32(None, None, 1, b"v_star", 4, None, 4, None, 1) == -1
+
+
+def test_invalidate_weight_caches_forgets_the_graph():
+    """clip_forward.invalidate_weight_caches drops the per-encoder graph (snapshots, planes, native structs) so that the next
+    call re-derives them — the hook for code that rewrites weights behind the version counter's back."""
+    from emcid_amd import clip_forward as cf, synthetic as syn
+    pipe = syn.build_pipe("toy", "cpu")
+    g1 = cf.discover_cached(pipe.text_encoder, "text_model.encoder.layers.{}")
+    assert cf.discover_cached(pipe.text_encoder, "text_model.encoder.layers.{}") is g1
+    cf.invalidate_weight_caches(pipe.text_encoder)
+    g2 = cf.discover_cached(pipe.text_encoder, "text_model.encoder.layers.{}")
+    assert g2 is not g1
+    cf.invalidate_weight_caches()
+    assert cf.discover_cached(pipe.text_encoder, "text_model.encoder.layers.{}") is not g2
