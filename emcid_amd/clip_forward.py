@@ -602,10 +602,18 @@ def build_trie_packed(seqs: Sequence[Sequence[int]], device, bucket: int = ROW_B
         depth = np.concatenate([depth, np.zeros(pad, dtype=np.int32)])
         anc[n_real:, 0] = np.arange(n_real, U)
     empty64 = torch.zeros(0, dtype=torch.int64, device=device)
-    trie = TokenTrie(torch.from_numpy(token).to(device), torch.from_numpy(depth.astype(np.int32)).to(device),
-                     torch.from_numpy(anc).to(device), empty64, torch.zeros(0, dtype=torch.int32, device=device), empty64,
-                     n_real, n * lmax)
-    count_t = torch.from_numpy(count.astype(np.float32)).to(device)
+
+    def up(a):
+        # through page-locked memory, asynchronously: a pageable upload makes the host wait for everything already queued on the
+        # stream — the previous pool's forward and Gram launches, under which the host is meant to prepare this pool
+        t = torch.from_numpy(np.ascontiguousarray(a))
+        if torch.device(device).type == "cuda":
+            return t.pin_memory().to(device, non_blocking=True)
+        return t.to(device)
+
+    trie = TokenTrie(up(token), up(depth.astype(np.int32)), up(anc), empty64, torch.zeros(0, dtype=torch.int32, device=device),
+                     empty64, n_real, n * lmax)
+    count_t = up(count.astype(np.float32))
     return (trie, count_t, nodes) if return_nodes else (trie, count_t)
 
 

@@ -107,7 +107,7 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
         # tokenized pool by pool, inside the loop: the GPU works on pool i (launches are asynchronous) while the host
         # tokenizes pool i+1 — tokenizing all captions up front kept the GPU idle for the first ~2.5 s of a 100k-caption job
         for g in range(0, len(sample), pool):
-            ids = tokenizer([ds.data[i] for i in sample[g:g + pool]], truncation=True, max_length=ds.maxlen)["input_ids"]
+            ids = tokenize_ragged(tokenizer, [ds.data[i] for i in sample[g:g + pool]], ds.maxlen)
             yield collate_token_lists(ids, max(batch_tokens, device_batch_tokens))
 
     packed = _packed_plan(model, todo, mods_of=None) if (forward in ("auto", "trie") and feature == "input") else None
@@ -207,6 +207,26 @@ def _packed_plan(model, layer_names, mods_of=None):
     return None
 
 
+def tokenize_ragged(tokenizer, texts, max_length):
+    """``tokenizer(texts, truncation=True, max_length=max_length)["input_ids"]`` (ragged lists, what the reference's
+    TokenizedDataset feeds Stage 0: dsets/stat_dataset.py:71-103) without transformers' per-caption Python conversion of every
+    encoding (1.0 of the 3.1 s of a 100 000-caption pass): a ONE-caption public call configures the backend's truncation exactly
+    as transformers does for these arguments, then the backend encodes the batch without offsets; the longest caption is checked
+    against the public call every time, anything unexpected takes the public call."""
+    bt = getattr(tokenizer, "_tokenizer", None)
+    if bt is not None and hasattr(bt, "encode_batch_fast") and len(texts) > 8:
+        try:
+            longest = max(range(len(texts)), key=lambda i: len(texts[i]))
+            want = tokenizer([texts[longest]], truncation=True, max_length=max_length)["input_ids"][0]
+            encs = bt.encode_batch_fast(list(texts), add_special_tokens=True)
+            ids = [e.ids for e in encs]
+            if len(ids) == len(texts) and ids[longest] == want and max(len(r) for r in ids) <= (max_length or 1 << 30):
+                return ids
+        except Exception:
+            pass
+    return tokenizer(list(texts), truncation=True, max_length=max_length)["input_ids"]
+
+
 def _collect_packed(model, tokenizer, ds, sample, pool, packed, todo, stats, files, args, shard, group, device, progress,
                     device_batch_tokens, stat_dtypes=(torch.float32, torch.float32, torch.float32)):
     """Stage 0 on the packed prefix trie: the captions of a pool share their common prefixes ("<bos> a photo of ...") and
@@ -231,7 +251,7 @@ def _collect_packed(model, tokenizer, ds, sample, pool, packed, todo, stats, fil
     LAST_RUN.update(forward="packed-trie", tokens=0, rows=0)
     with torch.no_grad():
         for g in wrap(pools, total=len(pools)):
-            ids = tokenizer([ds.data[i] for i in sample[g:g + pool]], truncation=True, max_length=ds.maxlen)["input_ids"]
+            ids = tokenize_ragged(tokenizer, [ds.data[i] for i in sample[g:g + pool]], ds.maxlen)
             trie, cnt = clip_forward.build_trie_packed(ids, device)
             n_real, tokens = trie.n_nodes, int(sum(len(s) for s in ids))
             LAST_RUN["tokens"] += tokens
