@@ -569,6 +569,113 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     }
 }
 
+// ---- Stage-0 Gram on the same matrix path:  lower(G) += X^T X  for a chunk of token rows X [t][d] ---------------------------------
+// (reference: util/runningstats.py:469-511, mom2 += a.t().mm(a) over the caption tokens.)  The contraction runs over the TOKENS,
+// so the operand is X^T [d][t] and the scale is per COLUMN of X (per feature, over the chunk): gram_colmax_kernel finds the
+// column maxima, gram_transpose_split_kernel writes X^T as split planes (rows = features, K = tokens, zero-padded to a multiple
+// of 32), and gram_sp16_kernel is the projection kernel's K loop over the LOWER 128 x 128 tiles with the token range of every
+// tile cut into `ks` parts (300 lower tiles at d = 3072 do not fill 512 workgroup slots): a part's tile is scaled back by
+// 2^-(e_i + e_j) and added into G with fp32 atomics — G is an accumulator, like the exact-f32 SYRK's multi-slab mode.
+__global__ __launch_bounds__(256) void gram_colmax_kernel(const float* __restrict__ X, int64_t ldx, int t, int d, int rows_per_wg,
+                                                           unsigned* __restrict__ cmax) {
+    const int c4 = blockIdx.x * 256 + threadIdx.x;                 // float4 column group
+    if (4 * c4 >= d) return;
+    const int r0 = blockIdx.y * rows_per_wg, r1 = min(t, r0 + rows_per_wg);
+    v4f m = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < r1; ++r) {
+        const v4f x = *reinterpret_cast<const v4f*>(X + (int64_t)r * ldx + 4 * c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], fabsf(x[e]));
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicMax(cmax + 4 * c4 + e, __float_as_uint(m[e]));      // non-negative floats order like their bits
+}
+
+// one workgroup: 64 tokens x 64 features through LDS; thread -> (feature, group of 8 tokens): 32 contiguous bytes of planes
+__global__ __launch_bounds__(256) void gram_transpose_split_kernel(const float* __restrict__ X, int64_t ldx, int t, int d,
+                                                                    const unsigned* __restrict__ cmax, uint32_t* __restrict__ P,
+                                                                    int64_t ldp, float* __restrict__ inv_scale) {
+    __shared__ float tile[64][65];
+    const int t0 = blockIdx.x * 64, d0 = blockIdx.y * 64, tid = threadIdx.x;
+    for (int v = tid; v < 64 * 16; v += 256) {                    // 64 rows x 16 float4
+        const int r = v >> 4, c = (v & 15) * 4;
+        v4f x = {0.f, 0.f, 0.f, 0.f};
+        if (t0 + r < t && d0 + c < d) x = *reinterpret_cast<const v4f*>(X + (int64_t)(t0 + r) * ldx + d0 + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[r][c + e] = x[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int w = tid + 256 * u, f = w >> 3, g = w & 7;       // feature 0..63, token group 0..7
+        if (d0 + f >= d) continue;
+        float s, inv;
+        sp_scale_of(__uint_as_float(cmax[d0 + f]), s, inv);
+        if (blockIdx.x == 0 && g == 0) inv_scale[d0 + f] = inv;
+        v4f a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = tile[8 * g + e][f], b[e] = tile[8 * g + 4 + e][f];
+        v4u hi, lo;
+        sp_split8(a, b, s, hi, lo);
+        uint32_t* dst = P + (int64_t)(d0 + f) * ldp + t0 + 8 * g;
+        *reinterpret_cast<v4u*>(dst) = hi;
+        *reinterpret_cast<v4u*>(dst + 4) = lo;
+    }
+}
+
+struct GramSpArgs {
+    const uint32_t* XT; int64_t ld; const float* inv; float* G; int64_t ldg; int d, K, tiles_side, ks;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_sp16_kernel(GramSpArgs g) {
+    constexpr int MJ = 2, NI = 2, WM = 2, WN = 2, PF = 2;
+    using Geo = SpGeom<MJ, NI, WM, WN, PF, 1>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Geo::SMEM];
+    const int n_lower = g.tiles_side * (g.tiles_side + 1) / 2, items = n_lower * g.ks, per = (items + 7) / 8;
+    const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (item >= items || (int)(blockIdx.x >> 3) >= per) return;
+    const int tile = item / g.ks, part = item - tile * g.ks;
+    int bm = (int)((sqrtf(8.f * (float)tile + 1.f) - 1.f) * 0.5f);          // row of the lower triangle holding `tile`
+    while (bm * (bm + 1) / 2 > tile) --bm;
+    while ((bm + 1) * (bm + 2) / 2 <= tile) ++bm;
+    const int bn = tile - bm * (bm + 1) / 2;
+    const int T = g.K / SPK, it_lo = (int)((int64_t)part * T / g.ks), it_hi = (int)((int64_t)(part + 1) * T / g.ks);
+    if (it_hi <= it_lo) return;
+    // the projection kernel's K loop: "X" rows = features of the tile's rows, "W" rows = features of its columns
+    SpArgs a{};
+    a.X = g.XT + (int64_t)it_lo * SPK; a.ldx = g.ld; a.W = g.XT + (int64_t)it_lo * SPK; a.ldw = g.ld;
+    a.M = g.d; a.N = g.d; a.K = g.K;
+    v16f acc[NI][MJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // lane side of the accumulators = the tile's COLUMNS (features of block bn), register side = its rows (block bm): one atomic
+    // wave-instruction then adds to two runs of 32 consecutive floats in two rows of G (MI355X_MICROARCH.md, global float atomics:
+    // the full-rate shape; 64 lanes in 64 rows would be ~17x slower)
+    const int c0 = bn * Geo::BM, r0 = bm * Geo::BN;
+    sp_accumulate<MJ, NI, WM, WN, PF, 0, 1>(a, c0, r0, it_hi - it_lo, smem, acc);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, l5 = lane >> 5;
+    const int wm0 = (wave / WN) * (32 * MJ), wn0 = (wave % WN) * (32 * NI);
+#pragma unroll
+    for (int j = 0; j < MJ; ++j) {
+        const int col = c0 + wm0 + 32 * j + l31;
+        const float sc = g.inv[min(col, g.d - 1)];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = r0 + wn0 + 32 * i + 8 * q + 4 * l5 + e;
+                    if (row < g.d && col < g.d)
+                        unsafeAtomicAdd(g.G + (int64_t)row * g.ldg + col, acc[i][j][4 * q + e] * (sc * g.inv[row]));
+                }
+    }
+}
+
 struct SpCfg { int bm, bn; };
 static const SpCfg kSpCfgs[] = {{128, 128}, {128, 128}, {64, 64}, {160, 128}};
 
@@ -585,6 +692,50 @@ int emcid_split_rows_f16(const float* X, int64_t ldx, int64_t rows, int64_t K, v
     ScopedProf sp(KC_MISC, (hipStream_t)stream);
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, X, ldx, (int)rows,
                        (int)K, (uint32_t*)planes, ldp, inv_scale, max_row_norm);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+int64_t emcid_gram_sp16_workspace_bytes(int64_t d) {
+    // planes of one chunk of X^T [d][32768] + the chunk's column maxima and inverse scales
+    return round_up(d, 64) * 32768 * 4 + 2 * round_up(d, 64) * 4 + 256;
+}
+
+int emcid_gram_accumulate_sp16_f32(const float* X, int64_t t, int64_t d, int64_t ldx, float* G, int64_t ldg, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+    EMCID_CHECK_ARG(X && G && workspace && t >= 0 && d > 0 && ldx >= d && ldg >= d && d % 4 == 0 && ldx % 4 == 0 && aligned16(X));
+    EMCID_CHECK_ARG(workspace_bytes >= emcid_gram_sp16_workspace_bytes(d) && aligned16(workspace) && d < (1 << 20) && t < (1LL << 31));
+    if (t == 0) return EMCID_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t dr = round_up(d, 64);
+    uint32_t* P = (uint32_t*)workspace;
+    unsigned* cmax = (unsigned*)((char*)workspace + dr * 32768 * 4);
+    float* inv = (float*)(cmax + dr);
+    const int side = (int)((d + 127) / 128), n_lower = side * (side + 1) / 2;
+    ScopedProf sp(KC_GRAM, st);
+    for (int64_t c0 = 0; c0 < t; c0 += 32768) {
+        const int tc = (int)std::min<int64_t>(32768, t - c0), tpad = (int)round_up(tc, 64);
+        const float* Xc = X + c0 * ldx;
+        if (hipMemsetAsync(cmax, 0, dr * sizeof(unsigned), st) != hipSuccess) return fail(EMCID_ERR_HIP, __func__, "hipMemsetAsync");
+        const int rows_per_wg = 256;
+        hipLaunchKernelGGL(gram_colmax_kernel, dim3((unsigned)((d / 4 + 255) / 256), (unsigned)((tc + rows_per_wg - 1) / rows_per_wg)),
+                           dim3(256), 0, st, Xc, ldx, tc, (int)d, rows_per_wg, cmax);
+        hipLaunchKernelGGL(gram_transpose_split_kernel, dim3((unsigned)(tpad / 64), (unsigned)(dr / 64)), dim3(256), 0, st, Xc, ldx, tc,
+                           (int)d, cmax, P, (int64_t)tpad, inv);
+        // parts per tile: enough work items for ~3 rounds of the 512 workgroup slots, a last round as full as possible
+        const int T = tpad / SPK;
+        int ks = 1;
+        double best = 0.0;
+        for (int k = 1; k <= 16 && T / k >= 16; ++k) {
+            const int items = n_lower * k;
+            const double fill = (double)items / (512.0 * ((items + 511) / 512));
+            const double score = fill - 0.01 * k + (items >= 1024 ? 0.0 : -0.5);
+            if (score > best) best = score, ks = k;
+        }
+        GramSpArgs ga{P, (int64_t)tpad, inv, G, ldg, (int)d, tpad, side, ks};
+        const int items = n_lower * ks;
+        hipLaunchKernelGGL(gram_sp16_kernel, dim3((unsigned)(((items + 7) / 8) * 8)), dim3(256), 0, st, ga);
+    }
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }

@@ -30,7 +30,7 @@ EXPORTS = [
     "emcid_edit_lu_workspace_bytes", "emcid_edit_layer_lu_f64", "emcid_lu_solve_f64",
     "emcid_edit_dual_cols_stage1_f64", "emcid_edit_dual_s", "emcid_edit_dual_u", "emcid_edit_dual_cols_stage2_f64",
     "emcid_apply_update2d_f32", "emcid_linear_f32", "emcid_linear_ws_f32", "emcid_linear_workspace_bytes",
-    "emcid_split_rows_f16", "emcid_linear_sp16_f32", "emcid_add_layernorm_sp16", "emcid_embed_layernorm_sp16",
+    "emcid_split_rows_f16", "emcid_linear_sp16_f32", "emcid_gram_sp16_workspace_bytes", "emcid_gram_accumulate_sp16_f32", "emcid_add_layernorm_sp16", "emcid_embed_layernorm_sp16",
     "emcid_tree_attention_sp16", "emcid_tree_attention_sp16_supported", "emcid_clip_workspace_bytes",
     "emcid_clip_layer_head_sp16", "emcid_clip_layer_tail_sp16", "emcid_clip_layers_sp16", "emcid_clip_edit_layer_tail_sp16",
 ]
@@ -109,6 +109,8 @@ def load():
         "emcid_linear_ws_f32": (i32, [p, i64, p, i64, p, p, i64, p, i64, i64, i64, i64, i32, i32, p, i64, p]),
         "emcid_linear_workspace_bytes": (i64, []),
         "emcid_split_rows_f16": (i32, [p, i64, i64, i64, p, i64, p, p, p]),
+        "emcid_gram_sp16_workspace_bytes": (i64, [i64]),
+        "emcid_gram_accumulate_sp16_f32": (i32, [p, i64, i64, i64, p, i64, p, i64, p]),
         "emcid_add_layernorm_sp16": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p, i64, p, p, p, p]),
         "emcid_embed_layernorm_sp16": (i32, [p, i64, i64, p, i64, i64, p, p, p, p, C.c_float, i64, i64, p, p, p, i64, p, p]),
         "emcid_tree_attention_sp16_supported": (i32, [i64, i64, i64]),
@@ -174,11 +176,32 @@ def _stream(t: torch.Tensor):
 
 # ---- Stage 0 -----------------------------------------------------------------------------------------
 
+GRAM_SPLIT = os.environ.get("EMCID_GRAM_SPLIT", "1") != "0"      # 0: always the exact-f32 MFMA SYRK
+_GRAM_WS = {}
+
+
 def gram_accumulate_(G: torch.Tensor, X: torch.Tensor, ksplit: int = 0):
-    """G (d,d) fp32 lower triangle += X^T X, X (t,d) fp32 with row stride multiple of 4 (runningstats.py:493)."""
+    """G (d,d) fp32 lower triangle += X^T X, X (t,d) fp32 with row stride multiple of 4 (runningstats.py:493).  Long batches
+    (>= 2048 tokens, ``ksplit != 1``) run on the split-fp16 path (csrc/gemm_sp16.hip: three f16 MFMAs per k-step on X^T planes
+    under per-feature scales, fp32 atomics into G); ``ksplit == 1`` — the deterministic mode — and short batches on the exact-f32
+    SYRK (csrc/gram_f32.hip)."""
     assert X.dim() == 2 and G.dim() == 2 and G.shape[0] == G.shape[1] == X.shape[1]
     assert X.stride(1) == 1 and G.stride(1) == 1
     if X.shape[0] == 0:
+        return G
+    d = X.shape[1]
+    if GRAM_SPLIT and ksplit != 1 and X.shape[0] >= 2048 and d % 4 == 0 and d >= 256 and X.stride(0) % 4 == 0 \
+            and X.data_ptr() % 16 == 0 and X.dtype == torch.float32 and G.dtype == torch.float32:
+        key = (X.device.index if X.device.index is not None else torch.cuda.current_device(),
+               torch.cuda.current_stream(X.device).cuda_stream, d)
+        ws = _GRAM_WS.get(key)
+        if ws is None:
+            if len(_GRAM_WS) >= 8:
+                _GRAM_WS.clear()
+            ws = _GRAM_WS[key] = torch.empty(int(load().emcid_gram_sp16_workspace_bytes(d)), dtype=torch.uint8, device=X.device)
+        _check(load().emcid_gram_accumulate_sp16_f32(_ptr(X, torch.float32, "X"), X.shape[0], d, X.stride(0),
+                                                     _ptr(G, torch.float32, "G"), G.stride(0), C.c_void_p(ws.data_ptr()),
+                                                     ws.numel(), _stream(G)), "emcid_gram_accumulate_sp16_f32")
         return G
     _check(load().emcid_gram_accumulate_f32(_ptr(X, torch.float32, "X"), X.shape[0], X.shape[1], X.stride(0),
                                             _ptr(G, torch.float32, "G"), G.stride(0), ksplit, _stream(G)),

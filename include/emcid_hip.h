@@ -139,6 +139,15 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
                           void* Yp, int64_t ldp, const float* y_scale, int64_t M, int64_t N, int64_t K, int act, int cfg,
                           void* stream);
 
+/* Stage 0 on the same matrix path: lower(G) += X^T X for token rows X [t, d] fp32 (reference: util/runningstats.py:469-511,
+ * mom2 += a.t().mm(a)) like emcid_gram_accumulate_f32, with X^T carried as split-fp16 planes under per-FEATURE scales (the
+ * contraction runs over the tokens; scales per 32 768-token chunk) and three f16 MFMAs per k-step; the lower 128 x 128 tiles, the
+ * token range of a tile cut into parts whose scaled results are added into G with fp32 atomics (G is an accumulator: sums in no
+ * fixed order, like the exact-f32 kernel's multi-slab mode).  d % 4 == 0; workspace: emcid_gram_sp16_workspace_bytes(d). */
+int64_t emcid_gram_sp16_workspace_bytes(int64_t d);
+int emcid_gram_accumulate_sp16_f32(const float* X, int64_t t, int64_t d, int64_t ldx, float* G, int64_t ldg, void* workspace,
+                                   int64_t workspace_bytes, void* stream);
+
 /* Producers that write their result straight as a split-fp16 matrix for the projection that consumes it (no fp32 round trip
  * through HBM, no separate split pass):
  *  - emcid_add_layernorm_sp16 / emcid_embed_layernorm_sp16: emcid_add_layernorm_f32 / emcid_embed_layernorm_f32 with z as planes

@@ -815,3 +815,34 @@ def test_producers_write_split_rows_directly():
         ref = hip.tree_attention(q[rows_sel.long()], k, v, anc_d, depth_d, H, rows=rows_sel)
         sp = hip.tree_attention_sp(q[rows_sel.long()], k, v, anc_d, depth_d, H, rows=rows_sel)
         assert torch.equal(sp.planes, hip.split_rows(ref).planes)
+
+
+@pytest.mark.parametrize("t,d", [(2048, 256), (3000, 328), (40000, 3072), (33000, 1280)])
+def test_gram_accumulate_split_fp16_path(t, d):
+    """emcid_gram_accumulate_sp16_f32 (what gram_accumulate_ takes for long batches): X^T as split-fp16 planes under per-feature
+    scales per 32 768-token chunk, lower tiles, fp32 atomics — against the fp64 Gram at the exact-f32 kernel's tolerance; features
+    on very different scales, a zero feature, a ragged token count crossing a chunk boundary; accumulation over two batches; and
+    the exact-f32 SYRK (ksplit = 1) agrees."""
+    g = torch.Generator().manual_seed(t + d)
+    X1 = torch.randn(t, d, generator=g)
+    X1 *= torch.exp2(torch.randint(-12, 12, (1, d), generator=g).float())        # features on very different scales
+    X1[:, 7] = 0.0
+    X1[::5, 11] *= 1e-5
+    X2 = torch.randn(t // 2 + 3, d, generator=g)
+    X2[:, 7] = 0.0
+    G = torch.zeros(d, d, dtype=torch.float32, device=DEV)
+    hip.gram_accumulate_(G, X1.to(DEV), 0)
+    hip.gram_accumulate_(G, X2.to(DEV), 0)
+    hip.symmetrize_lower_(G)
+    ref = X1.double().t() @ X1.double() + X2.double().t() @ X2.double()
+    # per entry: relative to the two features' own scales (sqrt of the diagonal), like a correlation
+    dd = ref.diagonal().clamp_min(1e-300).sqrt()
+    rel = ((G.cpu().double() - ref).abs() / (dd[:, None] * dd[None, :] + 1e-300)).max().item()
+    assert rel <= 2e-6 * np.sqrt(t / 100 + 1), rel
+    assert torch.equal(G, G.t()) and bool((G[7] == 0).all())
+    G1 = torch.zeros(d, d, dtype=torch.float32, device=DEV)
+    hip.gram_accumulate_(G1, X1.to(DEV), 1)
+    hip.gram_accumulate_(G1, X2.to(DEV), 1)
+    hip.symmetrize_lower_(G1)
+    rel1 = ((G1.cpu().double() - ref).abs() / (dd[:, None] * dd[None, :] + 1e-300)).max().item()
+    print(f"gram t={t} d={d}: split-fp16 {rel:.2e}, exact-f32 {rel1:.2e} (relative to the features' scales)")
