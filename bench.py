@@ -352,6 +352,19 @@ def main():
     ew_list = [0.35, 0.4, 0.45, 0.55, 0.6]
     new_lam_ms = each_synced(len(lam_list), lambda i: call(0, copy.deepcopy(hp), mom2_weight=lam_list[i]))
     new_ew_ms = each_synced(len(ew_list), lambda i: call(0, copy.deepcopy(hp), edit_weight=ew_list[i]))
+    # the same sweep under EMCID_EDIT_WEIGHT_SCALAR=1 (C' taken as the scalar multiple of C it is up to one fp32 rounding per
+    # entry: the workload's factors serve every edit_weight), and how far its weights are from the exact form's
+    def edited():
+        return [get_parameter(pipe.text_encoder, n + ".weight").detach().clone() for n in layer_names]
+    exact_w = edited()                                 # exact form at ew_list[-1] (the sweep's last call)
+    os.environ["EMCID_EDIT_WEIGHT_SCALAR"] = "1"
+    try:
+        call(0)                                        # the workload's own (lam, e_w) into the scalar-keyed cache slot
+        ew_scalar_ms = each_synced(len(ew_list), lambda i: call(0, copy.deepcopy(hp), edit_weight=ew_list[i]))
+        ew_scalar_err = max(float((a - b).abs().max() / (b - o).abs().max().clamp_min(1e-30))
+                            for a, b, o in zip(edited(), exact_w, (originals[n] for n in layer_names)))
+    finally:
+        os.environ.pop("EMCID_EDIT_WEIGHT_SCALAR", None)
     call(0)        # (lam, e_w) of the workload again (its factors are still cached)
 
     log("GEMM A/B, host/device split, roofline pass")
@@ -538,6 +551,12 @@ def main():
                            "new_lambda_ms_all": [round(t, 3) for t in new_lam_ms],
                            "new_edit_weight_ms_per_call": statistics.median(new_ew_ms), "edit_weights": ew_list,
                            "new_edit_weight_ms_all": [round(t, 3) for t in new_ew_ms],
+                           "new_edit_weight_scalar_ms_per_call": statistics.median(ew_scalar_ms),
+                           "new_edit_weight_scalar_ms_all": [round(t, 3) for t in ew_scalar_ms],
+                           "new_edit_weight_scalar_dw_rel_err_vs_exact": ew_scalar_err,
+                           "scalar_note": "EMCID_EDIT_WEIGHT_SCALAR=1 (off by default): lam C'(e_w) = [lam (1 - e_w)/(1 - e_w0)] C'(e_w0) "
+                                          "up to one fp32 rounding per entry of C'; error = max |W_scalar - W_exact| / max |dW| over the "
+                                          "edited layers at the sweep's last edit_weight",
                            "note": "same requests as the replay; a new lambda reuses the cached factor of C' (lam_ratio), a new "
                                    "edit_weight refactors the four 3072 x 3072 matrices on the side stream under the forward"},
         "first_call_ms": first_s * 1e3,

@@ -225,7 +225,28 @@ def factor_cache_key(covs: Sequence[torch.Tensor], lam: float, edit_weight: floa
     EMCID_FACTOR_KEY_LAM=1 puts lam back into the key where bit-stable output across processes is wanted (every new lam then
     refactors, ~6 ms)."""
     key_lam = float(lam) if os.environ.get("EMCID_FACTOR_KEY_LAM", "0") == "1" else None
-    return (tuple((c.device.index, c.data_ptr(), c._version, tuple(c.shape)) for c in covs), float(edit_weight), key_lam)
+    key_ew = None if edit_weight_is_scalar() else float(edit_weight)
+    return (tuple((c.device.index, c.data_ptr(), c._version, tuple(c.shape)) for c in covs), key_ew, key_lam)
+
+
+def edit_weight_is_scalar() -> bool:
+    """EMCID_EDIT_WEIGHT_SCALAR=1 (default 0 = the exact form): treat C' as the scalar multiple (1 - e_w)/0.5 of C, so a new
+    edit_weight reuses the factors like a new lam does (lam C'(e_w) = [lam (1 - e_w)/(1 - e_w0)] C'(e_w0) up to one fp32
+    rounding per entry of C' — the rounding the reference's own `cov * (1 - edit_weight) / 0.5` commits, :1037).  The weights
+    then differ from the exact form by cond(lam C' + K K^T) * 6e-8; tests/test_e2e_gpu.py measures it on statistics of
+    condition 1e2 ... 1e8."""
+    return os.environ.get("EMCID_EDIT_WEIGHT_SCALAR", "0") == "1"
+
+
+def solve_lam(plan) -> float:
+    """The lam handed to the dual stages: the call's own, times (1 - e_w)/(1 - e_w0) when the factors in use were built for
+    another edit_weight (only under EMCID_EDIT_WEIGHT_SCALAR=1 — otherwise the cache never pairs them)."""
+    f = plan.cov_factors
+    if f is None or f.edit_weight is None or float(f.edit_weight) == float(plan.edit_weight):
+        return plan.lam
+    if not (plan.edit_weight < 1.0 and f.edit_weight < 1.0):
+        raise ValueError(f"edit_weight must be < 1 to rescale the factors (got {plan.edit_weight}, factored {f.edit_weight})")
+    return plan.lam * (1.0 - plan.edit_weight) / (1.0 - f.edit_weight)
 
 
 def clear_engine_caches():
@@ -592,7 +613,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                     res = hip.edit_layer_dual_cols(
                         K, Zc, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, backups[layer], weights[layer].data,
                         hip.column_tiles(plan.shard.rank, plan.shard.world, n_tiles),
-                        lambda t: _all_reduce_sum(t, plan.shard.group), ws=plan.dual_ws, lam=plan.lam)
+                        lambda t: _all_reduce_sum(t, plan.shard.group), ws=plan.dual_ws, lam=solve_lam(plan))
                     edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], None, None,
                                            K if trace else None, Zc if trace else None))
                     return
@@ -603,7 +624,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                     K, Zc, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, backups[layer], weights[layer].data,
                     ws=plan.dual_ws, rows=plan.shard.bounds(plan.n_total) if split else None,
                     gather_yt=(lambda rows_: _all_gather_rows(rows_.contiguous(), plan)) if split else None,
-                    on_factor_start=lazy_inverse if ahead else None, lam=plan.lam)
+                    on_factor_start=lazy_inverse if ahead else None, lam=solve_lam(plan))
                 edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], None, None,
                                        K if trace else None, Zc if trace else None))
                 return
@@ -611,7 +632,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                 K, Zc, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, W0=backups[layer], W=weights[layer].data,
                 want_factors=keep_factors, ws=plan.dual_ws,
                 rows=plan.shard.bounds(plan.n_total) if sharded else None,
-                gather_pt=(lambda rows_: _all_gather_rows(rows_.contiguous(), plan)) if sharded else None, lam=plan.lam)
+                gather_pt=(lambda rows_: _all_gather_rows(rows_.contiguous(), plan)) if sharded else None, lam=solve_lam(plan))
             xt = res["adj_k"].t() if res["adj_k"] is not None else None
             edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], xt, res["Rt"],
                                    K if trace else None, Zc if trace else None))
@@ -691,7 +712,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                     res = hip.clip_edit_layer_tail(
                         nat.array, li, nat.h, nat.d, x, mids[0], ch.trie.lookup_in_query if li == last else ch.trie.lookup_node,
                         ch.seg, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, backups[li], w.data, plan.dual_ws,
-                        plan.lam, next_ln, last=li == last)
+                        solve_lam(plan), next_ln, last=li == last)
                 finally:
                     _touch(w)
                 if li != last:      # the layer's fc2 planes were re-split in place from the new weight: keep the cache entry
