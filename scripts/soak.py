@@ -17,10 +17,12 @@ def call():
 for _ in range(5): call()
 ref = {n: get_parameter(pipe.text_encoder, n + ".weight").detach().clone() for n in names}
 m0 = torch.cuda.memory_allocated(); r0 = torch.cuda.memory_reserved()
-ts = []
+ts, differ = [], 0
 for i in range(400):
     t = time.perf_counter(); call(); ts.append((time.perf_counter() - t) * 1e3)
-same = all(torch.equal(ref[n], get_parameter(pipe.text_encoder, n + ".weight")) for n in names)
+    if i % 4 == 0 and not all(torch.equal(ref[n], get_parameter(pipe.text_encoder, n + ".weight")) for n in names):
+        differ += 1          # every fourth call is compared (the comparison synchronises)
+same = differ == 0 and all(torch.equal(ref[n], get_parameter(pipe.text_encoder, n + ".weight")) for n in names)
 print("calls 400 median", round(statistics.median(ts), 2), "p95", round(sorted(ts)[380], 2), "max", round(max(ts), 2),
       "first100", round(statistics.median(ts[:100]), 2), "last100", round(statistics.median(ts[-100:]), 2))
-print("bit-identical weights after 400 calls:", same, "alloc delta MB", (torch.cuda.memory_allocated() - m0) / 1e6, "reserved delta MB", (torch.cuda.memory_reserved() - r0) / 1e6)
+print("bit-identical weights in 100 checked calls of 400:", same, "calls that differed", differ, "alloc delta MB", (torch.cuda.memory_allocated() - m0) / 1e6, "reserved delta MB", (torch.cuda.memory_reserved() - r0) / 1e6)
