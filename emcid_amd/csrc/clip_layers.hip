@@ -89,7 +89,7 @@ int emcid_clip_layer_head_sp16(const emcid_clip_layer_sp16* L, int64_t rows, int
                                const float* hs, const void* x_planes, const float* x_inv_scale, float* mid, void* f_planes,
                                float* f_scale, float* f_f32, void* workspace, int64_t workspace_bytes, void* stream) {
     EMCID_CHECK_ARG(L && rows > 0 && h > 0 && d > 0 && heads > 0 && h % heads == 0 && anc && depth && hs && x_planes && x_inv_scale);
-    EMCID_CHECK_ARG(mid && f_planes && f_scale && n_sel > 0 && (rows_sel != nullptr || n_sel == rows) && h % 32 == 0 && d % 32 == 0);
+    EMCID_CHECK_ARG(mid && f_planes && f_scale && n_sel > 0 && n_sel <= rows && (rows_sel != nullptr || n_sel == rows) && h % 32 == 0 && d % 32 == 0);
     ClipWs w;
     if (!clip_ws_carve(workspace, workspace_bytes, rows, h, d, w)) return fail(EMCID_ERR_BAD_ARG, __func__, "workspace too small or misaligned");
     hipStream_t st = (hipStream_t)stream;

@@ -9,6 +9,7 @@
 #include <mutex>
 #include <string>
 #include <atomic>
+#include <cstdlib>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -315,7 +316,8 @@ int64_t emcid_bpe_encode_templated(emcid_bpe* m, const char* pre, const int64_t*
     // (without the cache: names of a request set are not expected back; a replayed set costs the same again), meet, and then
     // assemble the rows, each its share.
     const unsigned hw = std::thread::hardware_concurrency();
-    const int nt = n_names >= 256 ? (int)std::min<int64_t>(std::min<int64_t>(4, hw ? hw : 1), n_names / 128) : 1;
+    static const int max_threads = [] { const char* e = getenv("EMCID_TOK_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 32 ? 32 : v); }();
+    const int nt = n_names >= 256 ? (int)std::min<int64_t>(std::min<int64_t>(max_threads, hw ? hw : 1), n_names / 128) : 1;
     if (nt <= 1) return assemble(0, n, true, low);
     for (int64_t t = 0; t < n_templates; ++t) {          // the few template pieces: here, through the cache
         piece(P[(size_t)t], pre, pre_off, t);
