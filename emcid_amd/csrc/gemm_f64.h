@@ -1020,7 +1020,12 @@ inline void launch_gemm_f64_streamk2_bk(GemmShape p, EpiAxpby epi, hipStream_t s
     static const int syrk_tile = [] { const char* v = getenv("EMCID_STREAMK_SYRK_TILE"); return v ? atoi(v) : 2; }();
     if constexpr (BK == 16) {
         if (tile == 1 && !p.lower_only) { launch_gemm_f64_streamk2_tile<KCA, KCB, BK, 64, 128, 2, 2>(p, epi, stream, wgs, 2, work, diag_add); return; }
-        if (tile == 2 || (p.lower_only && syrk_tile == 2)) { launch_gemm_f64_streamk2_tile<KCA, KCB, BK, 64, 64, 2, 2>(p, epi, stream, wgs, 3, work, diag_add); return; }
+        // a product with at most 128 rows (a 100-concept edit: ONE row of 128 x 128 tiles, every tile cut over ~10 workgroups) also
+        // takes the 64 x 64 tiles: inv_apply 0.575 -> 0.509 ms per 100-concept call (EMCID_STREAMK_TILE=3: 128 x 128 there too)
+        if (tile == 2 || (p.lower_only && syrk_tile == 2) || (tile == 0 && !p.lower_only && p.M <= 128)) {
+            launch_gemm_f64_streamk2_tile<KCA, KCB, BK, 64, 64, 2, 2>(p, epi, stream, wgs, 3, work, diag_add);
+            return;
+        }
     }
     launch_gemm_f64_streamk2_tile<KCA, KCB, BK, 128, 128, 2, 4>(p, epi, stream, wgs, 1, work, diag_add);
 }
