@@ -154,7 +154,8 @@ int emcid_clip_layer_tail_sp16(const emcid_clip_layer_sp16* L, int64_t n, int64_
 
 /* Everything of an edited layer behind its attention block + fc1 (emcid_clip_layer_head_sp16 with the fp32 twin), from ONE call:
  * keys = per-request means of the twin at the prompts' lookup rows (emcid_gather_mean_f32), Zc = fc2(keys) with the layer's
- * CURRENT weight on the exact-f32 kernel, the dual solver's apply-only form against the cached factors
+ * CURRENT weight (k_planes / k_inv_scale given: scratch for the keys as a split matrix, and the product runs on the split-fp16
+ * kernel against the layer's fc2 planes; NULL: on the exact-f32 kernel against W), the dual solver's apply-only form against the cached factors
  * (emcid_edit_dual_apply_stage1_f64 / _stage2_f64: W = W0 + float(U), dW), the NEW weight split into the layer's own fc2 planes
  * (in place: the struct stays valid), and — hs_out != NULL — fc2 + residual + the next layer's LN1 (emcid_clip_layer_tail_sp16).
  * The reference's layer loop body (emcid/emcid_main.py:981-1073) as one launch sequence; single rank, factors in HBM.
@@ -164,13 +165,23 @@ int emcid_clip_edit_layer_tail_sp16(const emcid_clip_layer_sp16* L, int64_t n_ro
                                     const int64_t* seg, int64_t B, int64_t N, const float* zs_t, double edit_weight,
                                     int layers_left, double lam_ratio, const void* cov_factor_ws, int64_t n_layers,
                                     int64_t layer_index, int use_inverse, const float* W0, float* W, float* dW, float* K_out,
-                                    float* Zc_out, void* dual_ws, int64_t dual_ws_bytes, int* info_dev, void* linear_ws,
-                                    int64_t linear_ws_bytes, float* hs_out, const float* next_ln_gamma, const float* next_ln_beta,
-                                    float next_ln_eps, void* x_planes, float* x_inv_scale, void* stream) {
+                                    float* Zc_out, void* k_planes, float* k_inv_scale, void* dual_ws, int64_t dual_ws_bytes,
+                                    int* info_dev, void* linear_ws, int64_t linear_ws_bytes, float* hs_out,
+                                    const float* next_ln_gamma, const float* next_ln_beta, float next_ln_eps, void* x_planes,
+                                    float* x_inv_scale, void* stream) {
     EMCID_CHECK_ARG(L && n_rows > 0 && h % 32 == 0 && d % 32 == 0 && f_f32 && lookup && seg && B > 0 && N > 0 && zs_t);
     EMCID_CHECK_ARG(cov_factor_ws && W0 && W && K_out && Zc_out && dual_ws && info_dev && (hs_out == nullptr || (f_planes && f_inv_scale && mid)));
     EMCID_TRY(emcid_gather_mean_f32(f_f32, B, n_rows, d, 0, d, lookup, seg, N, K_out, d, stream));
-    EMCID_TRY(emcid_linear_ws_f32(K_out, d, W, d, L->fc2_bias, nullptr, 0, Zc_out, h, N, h, d, 0, -1, linear_ws, linear_ws_bytes, stream));
+    EMCID_CHECK_ARG((k_planes == nullptr) == (k_inv_scale == nullptr));
+    if (k_planes != nullptr) {
+        // Zc on the split-fp16 kernel against the layer's own fc2 planes (they are the planes of the CURRENT weight: the caller
+        // splits a weight once per version, and this layer's has not been touched yet in this call)
+        EMCID_TRY(emcid_split_rows_f16(K_out, d, N, d, k_planes, d, k_inv_scale, nullptr, stream));
+        EMCID_TRY(emcid_linear_sp16_f32(k_planes, d, k_inv_scale, L->fc2_planes, d, L->fc2_inv_scale, L->fc2_bias, nullptr, 0, Zc_out, h,
+                                        nullptr, 0, nullptr, N, h, d, 0, -1, stream));
+    } else {
+        EMCID_TRY(emcid_linear_ws_f32(K_out, d, W, d, L->fc2_bias, nullptr, 0, Zc_out, h, N, h, d, 0, -1, linear_ws, linear_ws_bytes, stream));
+    }
     EMCID_TRY(emcid_edit_dual_apply_stage1_f64(K_out, Zc_out, zs_t, N, d, h, edit_weight, layers_left, lam_ratio, cov_factor_ws,
                                                n_layers, layer_index, 0, N, use_inverse, dual_ws, dual_ws_bytes, stream));
     EMCID_TRY(emcid_edit_dual_apply_stage2_f64(N, d, h, cov_factor_ws, n_layers, layer_index, use_inverse, 0, W0, W, dW, dual_ws,

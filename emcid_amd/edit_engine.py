@@ -729,7 +729,8 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
             else:
                 # fc2 is affine, so the mean over a request's prompts of its output at the lookup rows IS fc2 of the mean
                 # key: Zc = K W^T + b on N rows (to fp32 rounding) instead of fc2 over every node followed by a gather
-                solve(order[li], li, K_loc, lambda K_all: lin(K_all, m.weight, m.bias))
+                # (on the split-fp16 kernel against the planes of the weight as it is now, like the fused call above)
+                solve(order[li], li, K_loc, lambda K_all: lin(K_all, m.weight, m.bias, wsp=plan.graph.layers[li].split_of("fc2")))
             if li == last:
                 return None
             wsp = plan.graph.layers[li].split_of("fc2")          # of the NEW weight (solve() bumped its version counter)

@@ -37,7 +37,7 @@ EXPORTS = [
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block", "linear"]
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 NB = 128      # Cholesky block (csrc/common.h)
 NPAD = 64     # concept padding of the f64 stacks (csrc/common.h)
 
@@ -119,7 +119,7 @@ def load():
         "emcid_clip_layer_tail_sp16": (i32, [p, i64, i64, i64, p, p, p, p, p, p, f32, p, p, p]),
         "emcid_clip_layers_sp16": (i32, [p, i64, i64, i64, i64, i64, f32, p, i64, p, p, p, p, p, p, f32, p, i64, p]),
         "emcid_clip_edit_layer_tail_sp16": (i32, [p, i64, i64, i64, p, p, p, p, p, p, i64, i64, p, f64, i32, f64, p, i64, i64, i32,
-                                                 p, p, p, p, p, p, i64, p, p, i64, p, p, p, f32, p, p, p]),
+                                                 p, p, p, p, p, p, p, p, i64, p, p, i64, p, p, p, f32, p, p, p]),
         "emcid_tree_attention_sp16": (i32, [p, i64, p, p, i64, p, i64, p, p, i64, i64, i64, f32, p, i64, p, p]),
         "emcid_linear_sp16_f32": (i32, [p, i64, p, p, i64, p, p, p, i64, p, i64, p, i64, p, i64, i64, i64, i32, i32, p]),
         "emcid_add_layernorm_f32": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p]),
@@ -900,7 +900,7 @@ def clip_layer_tail(layer_array, index: int, h: int, d: int, f: "SplitRows", mid
 def clip_edit_layer_tail(layer_array, index: int, h: int, d: int, f: "SplitRows", mid: torch.Tensor, lookup: torch.Tensor,
                          seg: torch.Tensor, zs_t: torch.Tensor, factors: "CovFactors", layer_index: int, edit_weight: float,
                          layers_left: int, W0: torch.Tensor, W: torch.Tensor, ws: "DualWorkspace", lam: Optional[float],
-                         next_ln: Optional[torch.nn.LayerNorm], last: bool, want_dw: bool = True):
+                         next_ln: Optional[torch.nn.LayerNorm], last: bool, want_dw: bool = True, zc_split: bool = True):
     """The rest of an edited layer behind ``clip_layer_head`` in ONE C call: keys, Zc, the apply-only dual solve (W = W0 + dW), the
     new weight's planes and — unless ``last`` — fc2 + residual + the next layer's LN1.  Returns dict(K, Zc, dW, hs, x)."""
     dev = mid.device
@@ -909,6 +909,10 @@ def clip_edit_layer_tail(layer_array, index: int, h: int, d: int, f: "SplitRows"
     K = torch.empty(N, d, dtype=torch.float32, device=dev)
     Zc = torch.empty(N, h, dtype=torch.float32, device=dev)
     dW = torch.empty(h, d, dtype=torch.float32, device=dev) if want_dw else None
+    # Zc = fc2(keys) on the split-fp16 kernel against the layer's own fc2 planes (scratch for the keys' planes): the caller
+    # says so with zc_split — the planes in ``layer_array`` must then be those of W as it is now
+    kp = torch.empty(N, d, dtype=torch.int32, device=dev) if zc_split else None
+    ks = torch.empty(N, dtype=torch.float32, device=dev) if zc_split else None
     hs = x = None
     if not last:
         hs = torch.empty(n, h, dtype=torch.float32, device=dev)
@@ -926,7 +930,7 @@ def clip_edit_layer_tail(layer_array, index: int, h: int, d: int, f: "SplitRows"
         _ptr(mid, torch.float32, "mid"), _ptr(lookup, torch.int64, "lookup"), _ptr(seg, torch.int64, "seg"), lookup.numel(), N,
         _ptr(zs_t, torch.float32, "zs_t"), float(edit_weight), int(layers_left), factors.lam_ratio(lam), _ptr(factors.buf),
         factors.n_layers, int(layer_index), int(bool(use_inverse)), _ptr(W0, torch.float32, "W0"), _ptr(W, torch.float32, "W"),
-        _ptr(dW), _ptr(K), _ptr(Zc), _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32),
+        _ptr(dW), _ptr(K), _ptr(Zc), _ptr(kp), _ptr(ks), _ptr(ws.buf), ws.nbytes, _ptr(ws.info, torch.int32),
         C.c_void_p(lws.data_ptr()) if lws is not None else None, lws.numel() if lws is not None else 0, _ptr(hs),
         _ptr(next_ln.weight, torch.float32, "gamma") if (next_ln is not None and not last) else None,
         _ptr(next_ln.bias, torch.float32, "beta") if (next_ln is not None and not last) else None,

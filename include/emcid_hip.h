@@ -28,7 +28,7 @@ extern "C" {
 #define EMCID_ERR_HIP (-2)
 #define EMCID_ERR_WORKSPACE (-3)
 
-#define EMCID_ABI_VERSION 11
+#define EMCID_ABI_VERSION 12
 
 /* ABI version of the loaded library (host-only, no GPU needed). */
 int emcid_abi_version(void);
@@ -210,7 +210,9 @@ int emcid_clip_layer_tail_sp16(const emcid_clip_layer_sp16* L, int64_t n, int64_
 /* Everything of an edited layer behind emcid_clip_layer_head_sp16 from one call — the body of the reference's layer loop
  * (emcid/emcid_main.py:981-1073) as one launch sequence, single rank, lam C' factored and in HBM (emcid_factor_cov_f64): keys
  * K_out [N, d] = per-request means of f_f32 [n_rows, d] at the prompts' lookup rows (lookup [B], seg [N + 1]); Zc_out [N, h] =
- * fc2(K_out) with the CURRENT weight W (exact-f32 kernel; linear_ws as emcid_linear_ws_f32, may be NULL); the dual solver's
+ * fc2(K_out) with the CURRENT weight: k_planes [N, d] / k_inv_scale [N] given (scratch) = on the split-fp16 kernel against the
+ * layer's own fc2 planes, which must then be the planes of W as it is; both NULL = on the exact-f32 kernel against W (linear_ws
+ * as emcid_linear_ws_f32, may be NULL); the dual solver's
  * apply-only form (arguments as emcid_edit_dual_apply_stage1_f64 / _stage2_f64): W = W0 + float(U), dW (may be NULL); then, if
  * hs_out != NULL, the new W split into the layer's OWN fc2 planes (in place) and fc2 + residual + the next layer's LN1 as in
  * emcid_clip_layer_tail_sp16.  hs_out == NULL (the last edited layer): nothing after the weight update. */
@@ -219,9 +221,10 @@ int emcid_clip_edit_layer_tail_sp16(const emcid_clip_layer_sp16* L, int64_t n_ro
                                     const int64_t* seg, int64_t B, int64_t N, const float* zs_t, double edit_weight,
                                     int layers_left, double lam_ratio, const void* cov_factor_ws, int64_t n_layers,
                                     int64_t layer_index, int use_inverse, const float* W0, float* W, float* dW, float* K_out,
-                                    float* Zc_out, void* dual_ws, int64_t dual_ws_bytes, int* info_dev, void* linear_ws,
-                                    int64_t linear_ws_bytes, float* hs_out, const float* next_ln_gamma, const float* next_ln_beta,
-                                    float next_ln_eps, void* x_planes, float* x_inv_scale, void* stream);
+                                    float* Zc_out, void* k_planes, float* k_inv_scale, void* dual_ws, int64_t dual_ws_bytes,
+                                    int* info_dev, void* linear_ws, int64_t linear_ws_bytes, float* hs_out,
+                                    const float* next_ln_gamma, const float* next_ln_beta, float next_ln_eps, void* x_planes,
+                                    float* x_inv_scale, void* stream);
 
 /* n_layers whole layers on every node, hs in place; x_planes / x_inv_scale: LN1 of hs for layers[0] in, LN1 of the result under
  * next_ln_* out (next_ln_gamma == NULL: not computed). */
