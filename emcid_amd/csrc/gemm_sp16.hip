@@ -527,9 +527,9 @@ void linear_sp16_kernel(SpArgs a) {
 // SOURCE address of the DMA (lane -> which 16 bytes of which row it fetches) and on the fragment read, never on the destination.
 // Two stage buffers; per stage: wait for the own DMA (vmcnt(0)), barrier (everybody's stage has landed and everybody is done
 // reading the other buffer), issue the next stage's DMA into the other buffer, contract this one.
-template <int MJ, int DBG>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_sp16_dma_kernel(SpArgs a) {
-    constexpr int NI = 2, WM = 2, WN = 4, NWV = 8, BM = 32 * MJ * WM, BN = 32 * NI * WN;
+template <int MJ, int NI, int WM, int WN, int DBG>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_sp16_dma_kernel(SpArgs a) {
+    constexpr int NWV = WM * WN, BM = 32 * MJ * WM, BN = 32 * NI * WN;
     constexpr int STAGE = (BM + BN) * 128, PIECES = STAGE / 1024, PPW = PIECES / NWV;
     static_assert(PIECES % NWV == 0 && BM % 8 == 0, "pieces per wave");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 struct SpCfg { int bm, bn; };
-static const SpCfg kSpCfgs[] = {{128, 128}, {128, 128}, {64, 64}, {160, 128}, {256, 256}};
+static const SpCfg kSpCfgs[] = {{128, 128}, {128, 128}, {64, 64}, {160, 128}, {256, 256}, {128, 128}};
 
 }  // namespace emcid
 
@@ -887,7 +887,7 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
     // bit 6: the LDS-DMA kernel (256 x 256 on eight waves)
     const int dbg = cfg < 0 ? 0 : (cfg >> 4) & 3;
     int tile_sel = cfg < 0 ? -1 : (cfg >> 6) ? 3 + (cfg >> 6) : (cfg & 3);
-    EMCID_CHECK_ARG(tile_sel <= 4);
+    EMCID_CHECK_ARG(tile_sel <= 5);      // cfg 64: LDS-DMA 256 x 256 on eight waves, 128: LDS-DMA 128 x 128 on four
     int pf = cfg < 0 ? 2 : ((cfg >> 2) & 3) + 1;
     EMCID_CHECK_ARG(pf >= 1 && pf <= 2);
     if (tile_sel < 0) {
@@ -897,6 +897,15 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
         const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128), t160 = ((M + 159) / 160) * ((N + 127) / 128);
         if (K % 64 == 0 && t160 >= 160 && t160 <= 256 && t128 > 256) tile_sel = 3;
         else tile_sel = (t128 >= 256 && (K >= 2048 || t128 >= 640)) ? 0 : 2;
+        // The LDS-DMA forms of the 128 x 128 tile (the same bits): short contractions only (at K = 3072 / 5120 the register-staged
+        // loop is ahead, profiles/r04_mb_linear_sp16_dma.txt); 256 x 256 tiles where they fill their last round of 256 workgroups
+        // to 85 % (q | k | v at 6 250 rows: 225 tiles, 92 against 102 us; bigG fc1: 500 tiles, 248 against 279), else 128 x 128 on
+        // four waves, two workgroups per compute unit (fc1: 118 against 127 us; bigG q | k | v 207 against 214).  EMCID_SP16_DMA=0: off.
+        static const int dma_env = [] { const char* e = getenv("EMCID_SP16_DMA"); return e ? atoi(e) : 1; }();
+        if (dma_env && tile_sel == 0 && K <= 1536 && ldx < (1 << 20) && ldw < (1 << 20)) {
+            const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), rounds = (t256 + 255) / 256;
+            tile_sel = (t256 * 100 >= rounds * 256 * 85) ? 4 : 5;
+        }
     }
     if (tile_sel == 3 && K % 64 != 0) tile_sel = 0;
     const int bm = kSpCfgs[tile_sel].bm, bn = kSpCfgs[tile_sel].bn;
@@ -918,8 +927,9 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
         else EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 2, WPE_, 0, KS_);              \
     } while (0)
     if (tile_sel >= 4) {
-        if (tile_sel == 4 && dbg) hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 1>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 0>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
+        if (tile_sel == 5) hipLaunchKernelGGL((linear_sp16_dma_kernel<2, 2, 2, 2, 0>), dim3((unsigned)(per * 8)), dim3(256), 0, st, a);
+        else if (dbg) hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 2, 2, 4, 1>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 2, 2, 4, 0>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
     } else if (dbg && tile_sel == 3) {
         if (dbg == 1) EMCID_SP_LAUNCH(5, 1, 1, 4, 1, 2, 1, 2);
         else if (dbg == 2) EMCID_SP_LAUNCH(5, 1, 1, 4, 1, 2, 2, 2);

@@ -14,6 +14,7 @@ rows = int(sys.argv[1]) if len(sys.argv) > 1 else 6400
 shapes = [(rows, 768, 2304, "qkv"), (rows, 768, 768, "out"), (rows, 768, 3072, "fc1"), (rows, 3072, 768, "fc2"),
           (3072, 768, 768, "out@query"), (3072, 768, 3072, "fc1@query"), (1000, 3072, 768, "fc2(K)"), (640, 768, 2304, "qkv@n100"),
           (640, 3072, 768, "fc2@n100"), (1000, 5120, 1280, "fc2(K)-bigG"),
+          (36335, 768, 2304, "qkv-36k"), (36335, 768, 3072, "fc1-36k"), (2048, 768, 3072, "fc1-2k"), (12000, 768, 2304, "qkv-12k"), (12000, 768, 3072, "fc1-12k"),
           (rows, 1280, 3840, "qkv-bigG"), (rows, 1280, 5120, "fc1-bigG"), (rows, 5120, 1280, "fc2-bigG")]
 
 
@@ -55,7 +56,7 @@ for M, K, N, name in shapes:
     if os.environ.get("MB_DBG", "0") == "1":       # timing-only variants (wrong results)
         cfgs += [(4 + 16, "128x128/noload"), (4 + 32, "128x128/noload-nostore"), (4 + 48, "128x128/mfma-only")]
         cfgs += [(3 + 16, "160x128k2/noload"), (3 + 32, "160x128k2/noload-nostore"), (3 + 48, "160x128k2/mfma-only")]
-    cfgs += [(64, "dma256x256")]
+    cfgs += [(64, "dma256x256"), (128, "dma128x128")]
     if os.environ.get("MB_DBG", "0") == "1":
         cfgs += [(64 + 16, "dma256x256/noload")]
     yauto = hip.linear_sp(xs, ws, b)
