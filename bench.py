@@ -203,10 +203,11 @@ KERNEL_OF_CLASS = {
     "inv_build": "gemm_f64_kernel<KC,!KC,*,*,16,*> launched as recursive-halving build of X = inv(L)",
     "linear": "linear_f32_kernel (csrc/gemm_f32.hip): the forward's projections Y = act(X W^T + b) + residual on v_mfma_f32_32x32x2_f32, "
               "128 x 128 tiles on 4 waves or 160 x 128 on 8 waves (K split inside the workgroup) by the launch's fill of the chip",
-    "linear_sp16": "linear_sp16_kernel (csrc/gemm_sp16.hip): the forward's projections Y = act(X W^T + b) + residual at fp32 accuracy on "
-                   "v_mfma_f32_32x32x16_f16 — operands as hi + lo fp16 planes under per-row power-of-two scales, three MFMAs per "
-                   "k-step (hi.hi + hi.lo + lo.hi), fp32 accumulate; 128 x 128 tiles on 4 waves, 160 x 128 on 8 waves (K split "
-                   "inside the workgroup) or 64 x 64 by the launch's fill of the chip",
+    "linear_sp16": "linear_sp16_kernel / linear_sp16_dma_kernel (csrc/gemm_sp16.hip): the forward's projections Y = act(X W^T + b) + residual at "
+                   "fp32 accuracy on v_mfma_f32_32x32x16_f16 — operands as hi + lo fp16 planes under per-row power-of-two scales, three "
+                   "MFMAs per k-step (hi.hi + hi.lo + lo.hi), fp32 accumulate; by the launch's shape: 256 x 256 tiles on 8 waves or "
+                   "128 x 128 on 4 with both operands staged by LDS-DMA (K <= 1536: q|k|v, fc1), 160 x 128 on 8 waves with the K range "
+                   "split inside the workgroup (out, fc2), 128 x 128 register-staged or 64 x 64",
 }
 FP64_CLASSES = ["assemble", "chol_leaf", "chol_panel", "chol_trail", "chol_inner", "chol_fused", "inv_block", "trsm_diag",
                 "trsm_update", "delta_w", "inv_build", "inv_apply"]
