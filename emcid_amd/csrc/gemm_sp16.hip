@@ -527,51 +527,63 @@ void linear_sp16_kernel(SpArgs a) {
 // SOURCE address of the DMA (lane -> which 16 bytes of which row it fetches) and on the fragment read, never on the destination.
 // Two stage buffers; per stage: wait for the own DMA (vmcnt(0)), barrier (everybody's stage has landed and everybody is done
 // reading the other buffer), issue the next stage's DMA into the other buffer, contract this one.
-template <int MJ, int NI, int WM, int WN, int DBG>
-__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_sp16_dma_kernel(SpArgs a) {
-    constexpr int NWV = WM * WN, BM = 32 * MJ * WM, BN = 32 * NI * WN;
-    constexpr int STAGE = (BM + BN) * 128, PIECES = STAGE / 1024, PPW = PIECES / NWV;
-    static_assert(PIECES % NWV == 0 && BM % 8 == 0, "pieces per wave");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+// KS = 2 (the 160 x 128 tile's scheme): a stage is 64 deep, 256 bytes per row, two wave groups contract its two halves over the
+// whole tile and meet through LDS at the end (sp_finish).  A 1-KiB piece is then 4 rows of 16 chunks and the swizzle key is
+// r & 15 (a row is a whole bank line; the 16 rows of a ds_read_b128 lane group have 16 different keys).
+template <int MJ, int NI, int WM, int WN, int KS, int DBG>
+__global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_sp16_dma_kernel(SpArgs a) {
+    constexpr int NW = WM * WN, NWV = NW * KS, BM = 32 * MJ * WM, BN = 32 * NI * WN;
+    constexpr int ROWB = 128 * KS, RPP = 1024 / ROWB, CPR = 8 * KS;          // bytes per row and stage, rows per piece, chunks per row
+    constexpr int STAGE = (BM + BN) * ROWB, PIECES = STAGE / 1024, PPW = PIECES / NWV;
+    constexpr int RED = KS == 2 ? NW * MJ * NI * 4 * 64 * 16 : 0;
+    static_assert(PIECES % NWV == 0 && BM % RPP == 0 && BN % RPP == 0, "pieces per wave");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE > RED ? 2 * STAGE : RED];
     const int per = (a.tiles + 7) / 8;
     const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (tile >= a.tiles || (int)(blockIdx.x >> 3) >= per) return;
     int bm, bn;
     sp_tile_of(a, tile, bm, bn);
-    const int m0 = bm * BM, n0 = bn * BN, T = a.K / SPK;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, l5 = lane >> 5;
+    const int m0 = bm * BM, n0 = bn * BN, T = a.K / (SPK * KS);
+    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, wave = wave_all % NW, grp = wave_all / NW;
+    const int l31 = lane & 31, l5 = lane >> 5;
     const int wm0 = (wave / WN) * (32 * MJ), wn0 = (wave % WN) * (32 * NI);
 
-    // DMA: piece p = wave PPW + s holds image rows 8 p .. 8 p + 7 (rows < BM: X rows, then W rows; a wave's pieces are all of one
-    // operand); lane -> row 8 p + lane / 8, slot lane % 8, fetching chunk slot ^ ((row >> 1) & 7) of that row's 128-byte line of
-    // the stage.  Address = wave-uniform base (SGPRs, advanced by 128 bytes per stage) + a 32-bit byte offset per lane and piece.
-    static_assert(BM % (8 * PPW) == 0, "a wave loads one operand");
-    const bool is_x = wave * PPW * 8 < BM;
-    const int64_t ld4 = (is_x ? a.ldx : a.ldw) * 4;
-    const int row_lo = is_x ? m0 : n0, row_hi = (is_x ? a.M : a.N) - 1;
-    const unsigned char* base_v = reinterpret_cast<const unsigned char*>(is_x ? a.X : a.W) + (int64_t)row_lo * ld4;
-    const uint64_t base_u = (uint64_t)__builtin_amdgcn_readfirstlane((int)(reinterpret_cast<uint64_t>(base_v) & 0xffffffffu)) & 0xffffffffu;
-    const uint64_t base_h = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(reinterpret_cast<uint64_t>(base_v) >> 32));
-    const unsigned char* base = reinterpret_cast<const unsigned char*>(base_u | (base_h << 32));
+    // DMA: piece p = wave_all PPW + s holds image rows RPP p .. RPP p + RPP - 1 (rows < BM: X rows, then W rows); lane -> row
+    // RPP p + lane / CPR, slot lane % CPR, fetching chunk slot ^ key(row) of that row's line of the stage.  Address = a uniform
+    // base per operand (SGPRs, advanced by ROWB bytes per stage) + a 32-bit byte offset per lane and piece.
+    auto uniform_ptr = [](const void* ptr) __attribute__((always_inline)) {
+        const uint64_t v = reinterpret_cast<uint64_t>(ptr);
+        const uint64_t lo = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffu));
+        const uint64_t hi = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+        return reinterpret_cast<const unsigned char*>(lo | (hi << 32));
+    };
+    const unsigned char* base_x = uniform_ptr(a.X + (int64_t)m0 * a.ldx);
+    const unsigned char* base_w = uniform_ptr(a.W + (int64_t)n0 * a.ldw);
     unsigned off[PPW];
 #pragma unroll
     for (int s = 0; s < PPW; ++s) {
-        const int r = 8 * (wave * PPW + s) + (lane >> 3), c = (lane & 7) ^ ((r >> 1) & 7);
-        const int rr = min(row_lo + (is_x ? r : r - BM), row_hi) - row_lo;           // rows past the end: a valid row, never stored
-        off[s] = (unsigned)(rr * (int)ld4 + 16 * c);
+        const int r = RPP * (wave_all * PPW + s) + lane / CPR;
+        const int c = (lane % CPR) ^ (KS == 2 ? (r & 15) : ((r >> 1) & 7));
+        const bool is_x = r < BM;
+        const int rr = is_x ? min(m0 + r, a.M - 1) - m0 : min(n0 + r - BM, a.N - 1) - n0;      // rows past the end: a valid row, never stored
+        off[s] = (unsigned)(rr * (int)(4 * (is_x ? a.ldx : a.ldw)) + 16 * c);
     }
-    const int lds_w = __builtin_amdgcn_readfirstlane(wave * PPW * 1024);
+    const int lds_w = __builtin_amdgcn_readfirstlane(wave_all * PPW * 1024);
+    const int piece0 = __builtin_amdgcn_readfirstlane(wave_all * PPW);
     auto issue = [&](int it, unsigned char* stage) __attribute__((always_inline)) {
-        const unsigned char* b = base + (int64_t)it * 128;
+        const int64_t adv = (int64_t)it * ROWB;
 #pragma unroll
-        for (int s = 0; s < PPW; ++s)
+        for (int s = 0; s < PPW; ++s) {
+            const unsigned char* b = ((piece0 + s) * RPP < BM ? base_x : base_w) + adv;      // uniform select
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + off[s]),
                                              (__attribute__((address_space(3))) void*)(stage + lds_w + s * 1024), 16, 0, 0);
+        }
     };
-    // fragments: lane (row l31 of a 32-row block, k half l5) of k16 step t reads chunks 4 t + 2 l5 (hi) and + 1 (lo) of its row
-    const int q = (l31 >> 1) & 7;
-    const int ch0 = 16 * ((2 * l5) ^ q), ch1 = 16 * ((4 + 2 * l5) ^ q);
-    const int fx = (wm0 + l31) * 128, fw = (BM + wn0 + l31) * 128;
+    // fragments: lane (row l31 of a 32-row block, k half l5) of k16 step t of its group's half reads chunks 8 grp + 4 t + 2 l5 (hi)
+    // and + 1 (lo) of its row
+    const int q = KS == 2 ? (l31 & 15) : ((l31 >> 1) & 7);
+    const int ch0 = 16 * ((8 * grp * (KS - 1) + 2 * l5) ^ q), ch1 = 16 * ((8 * grp * (KS - 1) + 4 + 2 * l5) ^ q);
+    const int fx = (wm0 + l31) * ROWB, fw = (BM + wn0 + l31) * ROWB;
     v16f acc[NI][MJ];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -584,13 +596,13 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     auto fread = [&](const unsigned char* stage, int ch, auto sc) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value;
 #pragma unroll
-        for (int j = 0; j < MJ; ++j) xh[S][j] = *reinterpret_cast<const v8h*>(stage + fx + j * 32 * 128 + ch);
+        for (int j = 0; j < MJ; ++j) xh[S][j] = *reinterpret_cast<const v8h*>(stage + fx + j * 32 * ROWB + ch);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) wl[S][i] = *reinterpret_cast<const v8h*>(stage + fw + i * 32 * 128 + (ch ^ 16));
+        for (int i = 0; i < NI; ++i) wl[S][i] = *reinterpret_cast<const v8h*>(stage + fw + i * 32 * ROWB + (ch ^ 16));
 #pragma unroll
-        for (int i = 0; i < NI; ++i) wh[S][i] = *reinterpret_cast<const v8h*>(stage + fw + i * 32 * 128 + ch);
+        for (int i = 0; i < NI; ++i) wh[S][i] = *reinterpret_cast<const v8h*>(stage + fw + i * 32 * ROWB + ch);
 #pragma unroll
-        for (int j = 0; j < MJ; ++j) xl[S][j] = *reinterpret_cast<const v8h*>(stage + fx + j * 32 * 128 + (ch ^ 16));
+        for (int j = 0; j < MJ; ++j) xl[S][j] = *reinterpret_cast<const v8h*>(stage + fx + j * 32 * ROWB + (ch ^ 16));
     };
     auto mfmas = [&](auto sc) __attribute__((always_inline)) {
         constexpr int S = decltype(sc)::value;
@@ -641,7 +653,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
             __builtin_amdgcn_sched_barrier(0);       // next iteration's MFMAs do not wait for the reads issued just before them
         }
     }
-    sp_finish<MJ, NI, WM, WN, 1>(a, m0, n0, smem, acc);
+    sp_finish<MJ, NI, WM, WN, KS>(a, m0, n0, smem, acc);
 }
 
 // ---- fp32 rows -> planes ------------------------------------------------------------------------------------------------------
@@ -806,7 +818,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 struct SpCfg { int bm, bn; };
-static const SpCfg kSpCfgs[] = {{128, 128}, {128, 128}, {64, 64}, {160, 128}, {256, 256}, {128, 128}};
+static const SpCfg kSpCfgs[] = {{128, 128}, {128, 128}, {64, 64}, {160, 128}, {256, 256}, {128, 128}, {160, 128}};
 
 }  // namespace emcid
 
@@ -887,7 +899,7 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
     // bit 6: the LDS-DMA kernel (256 x 256 on eight waves)
     const int dbg = cfg < 0 ? 0 : (cfg >> 4) & 3;
     int tile_sel = cfg < 0 ? -1 : (cfg >> 6) ? 3 + (cfg >> 6) : (cfg & 3);
-    EMCID_CHECK_ARG(tile_sel <= 5);      // cfg 64: LDS-DMA 256 x 256 on eight waves, 128: LDS-DMA 128 x 128 on four
+    EMCID_CHECK_ARG(tile_sel <= 6);      // cfg 64: LDS-DMA 256 x 256 on eight waves, 128: 128 x 128 on four, 192: 160 x 128 with the K split
     int pf = cfg < 0 ? 2 : ((cfg >> 2) & 3) + 1;
     EMCID_CHECK_ARG(pf >= 1 && pf <= 2);
     if (tile_sel < 0) {
@@ -901,13 +913,15 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
         // loop is ahead, profiles/r04_mb_linear_sp16_dma.txt); 256 x 256 tiles where they fill their last round of 256 workgroups
         // to 85 % (q | k | v at 6 250 rows: 225 tiles, 92 against 102 us; bigG fc1: 500 tiles, 248 against 279), else 128 x 128 on
         // four waves, two workgroups per compute unit (fc1: 118 against 127 us; bigG q | k | v 207 against 214).  EMCID_SP16_DMA=0: off.
-        static const int dma_env = [] { const char* e = getenv("EMCID_SP16_DMA"); return e ? atoi(e) : 1; }();
+        static const int dma_env = [] { const char* e = getenv("EMCID_SP16_DMA"); return e ? atoi(e) : 2; }();
         if (dma_env && tile_sel == 0 && K <= 1536 && ldx < (1 << 20) && ldw < (1 << 20)) {
             const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), rounds = (t256 + 255) / 256;
             tile_sel = (t256 * 100 >= rounds * 256 * 85) ? 4 : 5;
+        } else if (dma_env >= 2 && tile_sel == 3 && ldx < (1 << 20) && ldw < (1 << 20)) {
+            tile_sel = 6;       // the 160 x 128 tile with the K range split in the workgroup, staged by LDS-DMA: out 32 against 34 us, fc2 94 against 102
         }
     }
-    if (tile_sel == 3 && K % 64 != 0) tile_sel = 0;
+    if ((tile_sel == 3 || tile_sel == 6) && K % 64 != 0) tile_sel = 0;
     const int bm = kSpCfgs[tile_sel].bm, bn = kSpCfgs[tile_sel].bn;
     const int tiles_m = (int)((M + bm - 1) / bm), tiles_n = (int)((N + bn - 1) / bn);
     const int tiles = tiles_m * tiles_n;
@@ -927,9 +941,10 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
         else EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 2, WPE_, 0, KS_);              \
     } while (0)
     if (tile_sel >= 4) {
-        if (tile_sel == 5) hipLaunchKernelGGL((linear_sp16_dma_kernel<2, 2, 2, 2, 0>), dim3((unsigned)(per * 8)), dim3(256), 0, st, a);
-        else if (dbg) hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 2, 2, 4, 1>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 2, 2, 4, 0>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
+        if (tile_sel == 6) hipLaunchKernelGGL((linear_sp16_dma_kernel<5, 1, 1, 4, 2, 0>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
+        else if (tile_sel == 5) hipLaunchKernelGGL((linear_sp16_dma_kernel<2, 2, 2, 2, 1, 0>), dim3((unsigned)(per * 8)), dim3(256), 0, st, a);
+        else if (dbg) hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 2, 2, 4, 1, 1>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 2, 2, 4, 1, 0>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
     } else if (dbg && tile_sel == 3) {
         if (dbg == 1) EMCID_SP_LAUNCH(5, 1, 1, 4, 1, 2, 1, 2);
         else if (dbg == 2) EMCID_SP_LAUNCH(5, 1, 1, 4, 1, 2, 2, 2);

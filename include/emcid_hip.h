@@ -133,10 +133,11 @@ int emcid_split_rows_f16(const float* X, int64_t ldx, int64_t rows, int64_t K, v
  * under the CALLER's per-row scale y_scale[m] = 2^e (a bound on the row's magnitude is enough: |Y[m][n]| y_scale[m] < 2^15
  * must hold; NULL = 1); N % 8 == 0 for Yp.  cfg: -1 auto; bits 0-1 tile (0: 128 x 128, 1: two 128 x 128 tiles per
  * eight-wave workgroup ("ping-pong"), 2: 64 x 64, 3: 160 x 128 with the K range split between two wave groups, K % 64 == 0),
- * bits 2-3 prefetch distance - 1; 64 / 128: both operands staged by LDS-DMA (global_load_lds_dwordx4 into an XOR-swizzled
- * image, no staging registers, no LDS stores; the same bits as tile 0) on 256 x 256 tiles / eight waves, or 128 x 128 tiles / four
- * waves.  cfg = -1 takes them for K <= 1536 where it would take tile 0: 256 x 256 when those tiles fill their last round of 256
- * workgroups to 85 %, else 128 x 128 (EMCID_SP16_DMA=0: never). */
+ * bits 2-3 prefetch distance - 1; 64 / 128 / 192: both operands staged by LDS-DMA (global_load_lds_dwordx4 into an XOR-swizzled
+ * image, no staging registers, no LDS stores) on 256 x 256 tiles / eight waves, 128 x 128 tiles / four waves (both: the same bits
+ * as tile 0), or the 160 x 128 tile with the K split (the same bits as tile 3; K % 64 == 0).  cfg = -1 takes them where it would
+ * take tile 0 at K <= 1536 (256 x 256 when those tiles fill their last round of 256 workgroups to 85 %, else 128 x 128) and
+ * wherever it would take tile 3 (EMCID_SP16_DMA=1: not there; 0: never). */
 int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale, const void* Wp, int64_t ldw,
                           const float* w_inv_scale, const float* bias, const float* residual, int64_t ldr, float* Y, int64_t ldy,
                           void* Yp, int64_t ldp, const float* y_scale, int64_t M, int64_t N, int64_t K, int act, int cfg,

@@ -56,14 +56,14 @@ for M, K, N, name in shapes:
     if os.environ.get("MB_DBG", "0") == "1":       # timing-only variants (wrong results)
         cfgs += [(4 + 16, "128x128/noload"), (4 + 32, "128x128/noload-nostore"), (4 + 48, "128x128/mfma-only")]
         cfgs += [(3 + 16, "160x128k2/noload"), (3 + 32, "160x128k2/noload-nostore"), (3 + 48, "160x128k2/mfma-only")]
-    cfgs += [(64, "dma256x256"), (128, "dma128x128")]
+    cfgs += [(64, "dma256x256"), (128, "dma128x128"), (192, "dma160x128k2")]
     if os.environ.get("MB_DBG", "0") == "1":
         cfgs += [(64 + 16, "dma256x256/noload")]
     yauto = hip.linear_sp(xs, ws, b)
     for cfg, cn in cfgs:
         t = timeit(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=cfg))
         line.append(f"{cn} {t:6.1f} us {fl / t / 1e6:5.1f} TF")
-        if cfg in (64, 128):        # the LDS-DMA kernels contract in another order than the register-staged ones: compare, do not equate
+        if cfg in (64, 128, 192):        # the LDS-DMA kernels contract in another order than the register-staged ones: compare, do not equate
             d = (hip.linear_sp(xs, ws, b, cfg=cfg) - yauto).abs().max().item() / top
             line.append(f"(vs auto {d:.1e})")
     print(" | ".join(line), flush=True)

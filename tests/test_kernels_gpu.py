@@ -738,7 +738,7 @@ def test_split_rows_keeps_22_bits_under_a_per_row_scale():
     assert (sp2.float() - wide[:, :128]).abs().max().item() <= wide.abs().max().item() * 2.0 ** -21
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 4, 1, 5, 2, 6, 3, 7, 64, 128])
+@pytest.mark.parametrize("cfg", [-1, 0, 4, 1, 5, 2, 6, 3, 7, 64, 128, 192])
 @pytest.mark.parametrize("M,K,N", [(6400, 768, 2304), (6400, 3072, 768), (1000, 3072, 768), (640, 768, 3072), (300, 1280, 1280),
                                    (129, 96, 257), (37, 2048, 200), (256, 32, 32), (330, 192, 130)])
 def test_linear_sp16_vs_torch(M, K, N, cfg):
@@ -761,6 +761,8 @@ def test_linear_sp16_vs_torch(M, K, N, cfg):
     assert (y - F.linear(x, w, b)).abs().max().item() <= 2 * tol
     if cfg in (64, 128):       # the LDS-DMA kernels contract every element in the order of the register-staged ones: the same bits
         assert torch.equal(y, hip.linear_sp(xs, ws_, b, cfg=0))
+    if cfg == 192 and K % 64 == 0:
+        assert torch.equal(y, hip.linear_sp(xs, ws_, b, cfg=3))
     assert torch.equal(hip.linear_sp(xs, ws_, b, cfg=cfg), y)                   # the same bits call after call
     y0 = hip.linear_sp(xs, ws_, None, cfg=cfg)
     assert (y0.double() - F.linear(x.double(), w.double())).abs().max().item() <= tol
