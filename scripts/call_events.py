@@ -50,6 +50,9 @@ def wrap(mod, name, label):
 
 w_prefix = wrap(clip_forward, "run_prefix", "prefix")
 w_solve = wrap(hip, "edit_layer_dual_apply", "solve")
+w_fused = wrap(hip, "clip_edit_layer_tail", "edit layer (one C call)")          # the warm single-rank path
+w_head = wrap(hip, "clip_layer_head", "attention + fc1")
+w_join = wrap(edit_engine.EncoderEditPlan, "resolve_targets", "v* rows")
 
 
 def call():
@@ -66,7 +69,7 @@ table = {}
 walls = []
 for _ in range(n_calls):
     marks.clear()
-    w_prefix.count[0] = w_solve.count[0] = 0
+    w_prefix.count[0] = w_solve.count[0] = w_fused.count[0] = w_head.count[0] = w_join.count[0] = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     mark("call start")
