@@ -533,6 +533,18 @@ struct ShadowJob {
     int nofast;                       // GemmShape.nofast for the shadow tiles (EMCID_GEMM_FAST=0)
     int fuse_pair;                    // both tiles of a pair through one software pipeline (EMCID_SHADOW_FUSE, default 1)
 };
+
+// The explicit inverse of the factor, built ROW BLOCK BY ROW BLOCK inside the factorization's own launches (dual solver: XS =
+// inv(LS) is what turns Z = S^-1 R into two GEMMs).  Stored transposed, Xt[n][k] = X[k][n], so that both products of a step are
+// K-contiguous on both sides:
+//     leaf launch j  (j >= 1):  Tt [128 j, 128] = Xt[0:128j, 0:128j] L[j, 0:j]^T        (X of the leading j blocks is complete)
+//     spine launch j (j >= 0):  Xt[0:128j, j]  = -Tt inv(L_jj)^T,   Xt[j, j] = inv(L_jj)^T
+// i.e. X[j, 0:j] = -inv(L_jj) L[j, 0:j] X[0:j, 0:j].  Behind the last leaf only that block row's second product is left (one
+// small launch) where the recursive-halving build took six dependent ones (~70 us per layer at N = 1000).
+struct XrowJob {
+    double* Xt; int64_t ldx;      // [n, n] transposed inverse (every entry the consumers read is written here)
+    double* Tt;                   // [n, 128] scratch, leading dimension 128
+};
 inline long long* g_step_stamps = nullptr;      // set by emcid_debug_step_stamps
 constexpr int SH_BM = 64, SH_BN = 128;
 
@@ -740,7 +752,8 @@ __device__ __forceinline__ void shadow_pair(const ShadowJob& sh, int s_, int sli
 __global__ __launch_bounds__(LEAF_T) void chol_step_leaf_kernel(const double* __restrict__ A, int64_t lda, double* __restrict__ L,
                                                                  int64_t ldl, double* __restrict__ inv, int64_t ldinv, int* info,
                                                                  int col0, GemmShape trail, EpiAxpby trail_epi, int ntrail,
-                                                                 ShadowJob sh, int slice, int nslices) {
+                                                                 ShadowJob sh, int slice, int nslices, GemmShape xr, EpiAxpby xr_epi,
+                                                                 int nxr) {
     __shared__ __attribute__((aligned(16))) double lds[LEAF_LDS];
     long long* stamp = (sh.stamps && blockIdx.x < 512) ? sh.stamps + ((int64_t)slice * 512 + blockIdx.x) * 4 : nullptr;
     if (stamp && threadIdx.x == 0) stamp[0] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -757,6 +770,16 @@ __global__ __launch_bounds__(LEAF_T) void chol_step_leaf_kernel(const double* __
         if (stamp && threadIdx.x == 0) { stamp[2] = (long long)__builtin_amdgcn_s_memrealtime(); stamp[3] = 2; }
         return;
     }
+    if ((int)blockIdx.x <= ntrail + nxr) {      // a 32 x 64 tile of Tt = Xt L[j, 0:j]^T (XrowJob) on the workgroup's first four waves
+        // (a 128 x 128 tile of it contracts up to 896 deep on ONE compute unit: ~100 us, three leaf launches long; the small tiles
+        // finish under the leaf, and 8 j of them still leave every shadow workgroup a compute unit of its own)
+        if (threadIdx.x >= 256) return;
+        const int t = (int)blockIdx.x - 1 - ntrail;
+        gemm_f64_tile<true, true, 32, 64, 16, 2, 2, EpiAxpby>(xr, xr_epi, t / 2, t % 2, 0, lds);
+        if (stamp && threadIdx.x == 0) { stamp[2] = (long long)__builtin_amdgcn_s_memrealtime(); stamp[3] = 6; }
+        return;
+    }
+    ntrail += nxr;
     int s_ = (int)blockIdx.x - 1 - ntrail;
     if (sh.skip_xcd0) {
         // workgroups go to the 8 XCDs round-robin by linear id: those that would land on the leaf's XCD (id % 8 == 0) leave at
@@ -923,7 +946,9 @@ __global__ __launch_bounds__(SP_T) void chol_spine_kernel(const double* __restri
 // inv(L_jj)^T): both need leaf j only, neither needs the other.
 __global__ __launch_bounds__(SP_T) void chol_step_spine_kernel(const double* __restrict__ Ablk, int64_t lda, const double* __restrict__ inv,
                                                                 int64_t ldi, double* __restrict__ Lout, int64_t ldl, double* __restrict__ D,
-                                                                GemmShape panel, EpiAxpby panel_epi, long long* stamps, int step) {
+                                                                GemmShape panel, EpiAxpby panel_epi, long long* stamps, int step,
+                                                                int npanel, GemmShape xs, EpiAxpby xs_epi, int nxs, double* xdiag,
+                                                                int64_t ldxd) {
     __shared__ __attribute__((aligned(16))) double lds[SP_LDS];
     // diagnostic (stamps usually null): [start, -, end, kind] per workgroup behind the leaf launches' table (kind 4 spine, 5 panel)
     long long* stamp = (stamps && blockIdx.x < 512) ? stamps + ((int64_t)(16 + step) * 512 + blockIdx.x) * 4 : nullptr;
@@ -933,9 +958,32 @@ __global__ __launch_bounds__(SP_T) void chol_step_spine_kernel(const double* __r
         if (stamp && threadIdx.x == 0) { stamp[2] = (long long)__builtin_amdgcn_s_memrealtime(); stamp[3] = 4; }
         return;
     }
-    const int t = (int)blockIdx.x - 36;
-    gemm_f64_tile<true, true, 32, 64, 16, 2, 2, EpiAxpby>(panel, panel_epi, t / 2, t % 2, 0, lds);
-    if (stamp && threadIdx.x == 0) { stamp[2] = (long long)__builtin_amdgcn_s_memrealtime(); stamp[3] = 5; }
+    int t = (int)blockIdx.x - 36;
+    if (t < npanel) {
+        gemm_f64_tile<true, true, 32, 64, 16, 2, 2, EpiAxpby>(panel, panel_epi, t / 2, t % 2, 0, lds);
+        if (stamp && threadIdx.x == 0) { stamp[2] = (long long)__builtin_amdgcn_s_memrealtime(); stamp[3] = 5; }
+        return;
+    }
+    t -= npanel;
+    if (t < nxs) {                              // XrowJob: Xt[0:128j, j] = -Tt inv(L_jj)^T
+        gemm_f64_tile<true, true, 32, 64, 16, 2, 2, EpiAxpby>(xs, xs_epi, t / 2, t % 2, 0, lds);
+        if (stamp && threadIdx.x == 0) { stamp[2] = (long long)__builtin_amdgcn_s_memrealtime(); stamp[3] = 7; }
+        return;
+    }
+    if (xdiag != nullptr)                       // XrowJob: Xt[j, j] = inv(L_jj)^T, zeros below its diagonal
+        for (int v = threadIdx.x; v < NB * NB; v += SP_T) {
+            const int r = v / NB, c = v % NB;
+            xdiag[(int64_t)r * ldxd + c] = (r <= c) ? inv[(int64_t)c * ldi + r] : 0.0;
+        }
+}
+
+// the same transposed copy as a launch of its own (behind the last leaf there is no spine launch)
+__global__ __launch_bounds__(256) void copy_inverse_transposed_kernel(const double* __restrict__ inv, int64_t ldi, double* __restrict__ xdiag,
+                                                                       int64_t ldxd) {
+    for (int v = blockIdx.x * 256 + threadIdx.x; v < NB * NB; v += gridDim.x * 256) {
+        const int r = v / NB, c = v % NB;
+        xdiag[(int64_t)r * ldxd + c] = (r <= c) ? inv[(int64_t)c * ldi + r] : 0.0;
+    }
 }
 
 // ---- host orchestration -------------------------------------------------------------------------------
@@ -1201,7 +1249,7 @@ static int cholesky_lookahead(double* A, double* L, int64_t n, int64_t lda, doub
 // per step is leaf + spine step + two kernel boundaries (~48 us) instead of leaf + panel + trailing update + three (~65 us) — with
 // one stream, i.e. without the parallel graph branches that sank cholesky_lookahead.
 static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, double* invw, int* info, hipStream_t st,
-                                const ShadowJob* shadow = nullptr) {
+                                const ShadowJob* shadow = nullptr, const XrowJob* xrow = nullptr) {
     const int nb = (int)(n / NB);
     hipLaunchKernelGGL(zero_f64_kernel, dim3(1024), dim3(256), 0, st, invw, inv_doubles(n));
     for (int j = 0; j < nb; ++j) {
@@ -1238,11 +1286,33 @@ static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, do
             }
             // with skip_xcd0 one id in eight is a no-op: enough ids that sh.wgs of them are not multiples of 8
             const int shadow_ids = (sh.wgs && skip0) ? (sh.wgs * 8 + 6) / 7 + 8 : sh.wgs;
+            // XrowJob: Tt = Xt[0:o, 0:o] L[j, 0:j]^T on 32 x 64 tiles (K range from the tile's own first row on: X is lower
+            // triangular, Xt upper)
+            GemmShape xr{L, lda, L, lda, 0, 0, NB, 0};
+            EpiAxpby xe{A, lda, 1.0, 0.0};
+            int nxr = 0;
+            if (xrow && j >= 1) {
+                xr = GemmShape{xrow->Xt, xrow->ldx, L + o * lda, lda, (int)o, NB, (int)o, 0};
+                xr.tri = 8;
+                xr.pf = 1;
+                xe = EpiAxpby{xrow->Tt, NB, 1.0, 0.0};
+                nxr = (int)(o / 32) * 2;
+            }
             ScopedProf sp(KC_CHOL_LEAF, st);
-            hipLaunchKernelGGL(chol_step_leaf_kernel, dim3(1 + ntiles + shadow_ids), dim3(LEAF_T), 0, st, A + o * lda + o, lda,
-                               L + o * lda + o, lda, inv, (int64_t)OB, info, (int)o, tr, te, ntiles, sh, j, nb);
+            hipLaunchKernelGGL(chol_step_leaf_kernel, dim3(1 + ntiles + nxr + shadow_ids), dim3(LEAF_T), 0, st, A + o * lda + o, lda,
+                               L + o * lda + o, lda, inv, (int64_t)OB, info, (int)o, tr, te, ntiles, sh, j, nb, xr, xe, nxr);
         }
-        if (j == nb - 1) break;
+        if (j == nb - 1) {
+            if (xrow) {     // the last block row of X: its second product and its diagonal block, no spine launch to ride in
+                ScopedProf sp(KC_INV_BLOCK, st);
+                GemmShape g{xrow->Tt, NB, inv, OB, (int)o, NB, NB, 0};
+                g.tri = 1;      // B(k, n) = inv[n][k], zero for k > n
+                launch_gemm_f64<true, true>(g, EpiAxpby{xrow->Xt + o, xrow->ldx, -1.0, 0.0}, st, 2);
+                hipLaunchKernelGGL(copy_inverse_transposed_kernel, dim3(16), dim3(256), 0, st, inv, (int64_t)OB,
+                                   xrow->Xt + o * xrow->ldx + o, xrow->ldx);
+            }
+            break;
+        }
         {   // B_j
             const int m2 = (int)(n - o - 2 * NB);
             GemmShape ps{A, lda, inv, OB, 0, NB, NB, 0};
@@ -1255,12 +1325,29 @@ static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, do
                 pe.C = L + (o + 2 * NB) * lda + o;
                 npanel = (m2 / 32) * 2;
             }
+            // XrowJob: Xt[0:o, j] = -Tt inv(L_jj)^T on 32 x 64 tiles, and one workgroup for Xt[j, j] = inv(L_jj)^T
+            GemmShape xs{A, lda, inv, OB, 0, NB, NB, 0};
+            EpiAxpby xse{L, lda, -1.0, 0.0};
+            int nxs = 0;
+            double* xdiag = nullptr;
+            if (xrow) {
+                if (j >= 1) {
+                    xs = GemmShape{xrow->Tt, NB, inv, OB, (int)o, NB, NB, 0};
+                    xs.tri = 1;      // B(k, n) = inv[n][k], zero for k > n
+                    xs.pf = 1;
+                    xse.C = xrow->Xt + o;
+                    xse.ldc = xrow->ldx;
+                    nxs = (int)(o / 32) * 2;
+                }
+                xdiag = xrow->Xt + o * xrow->ldx + o;
+            }
             ScopedProf sp(KC_CHOL_PANEL, st);
-            hipLaunchKernelGGL(chol_step_spine_kernel, dim3(36 + npanel), dim3(SP_T), 0, st, A + (o + NB) * lda + o, lda, inv,
-                               (int64_t)OB, L + (o + NB) * lda + o, lda, A + (o + NB) * lda + o + NB, ps, pe, g_step_stamps, j);
+            hipLaunchKernelGGL(chol_step_spine_kernel, dim3(36 + npanel + nxs + (xdiag ? 1 : 0)), dim3(SP_T), 0, st,
+                               A + (o + NB) * lda + o, lda, inv, (int64_t)OB, L + (o + NB) * lda + o, lda, A + (o + NB) * lda + o + NB,
+                               ps, pe, g_step_stamps, j, npanel, xs, xse, nxs, xdiag, xrow ? xrow->ldx : 0);
         }
     }
-    build_block_inverses(L, n, lda, invw, st);
+    if (!xrow) build_block_inverses(L, n, lda, invw, st);      // (with an XrowJob the consumers read Xt, not the 512-block inverses)
     return check_launch("emcid_cholesky_f64");
 }
 
@@ -1273,15 +1360,15 @@ static inline bool cholesky_takes_shadow(int64_t dp) {      // the schedule whos
 }
 
 static int cholesky_impl(double* A, double* L, int64_t dp, int64_t lda, double* invw, int* info, hipStream_t st,
-                         const ShadowJob* shadow = nullptr) {
+                         const ShadowJob* shadow = nullptr, const XrowJob* xrow = nullptr) {
     // Off by default: measured on MI355X / ROCm 7.2 (bench.py device step, 4 layers, N = 1000): 13.3 ms serial -> 22.3 ms with the
     // look-ahead schedule inside the captured graph — every fork/join between the two capture streams costs ~70 us of graph
     // execution — and 14.2 ms with both run eagerly (host-launch bound).  Kept for the day parallel graph branches are cheap.
     static const int lookahead = env_flag("EMCID_CHOL_LOOKAHEAD", 0);
     if (lookahead && dp <= 2048 && dp >= 2 * NB) return cholesky_lookahead(A, L, dp, lda, invw, info, st);
     static const int fused = env_flag("EMCID_CHOL_FUSED", 1);
-    if (fused && dp <= 2048 && dp >= 2 * NB) return cholesky_fused_steps(A, L, dp, lda, invw, info, st, shadow);
-    if (shadow) return fail(EMCID_ERR_BAD_ARG, "cholesky_impl", "shadow job without the fused schedule");
+    if (fused && dp <= 2048 && dp >= 2 * NB) return cholesky_fused_steps(A, L, dp, lda, invw, info, st, shadow, xrow);
+    if (shadow || xrow) return fail(EMCID_ERR_BAD_ARG, "cholesky_impl", "shadow / inverse job without the fused schedule");
     return cholesky_serial(A, L, dp, lda, invw, info, st);
 }
 
@@ -2181,9 +2268,12 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
     // (61 + ~15 us instead of ~20 + 155 per layer).  EMCID_P_FIRST=0: the h-side form.
     static const int p_first_env = env_flag("EMCID_P_FIRST", 1);
     const bool p_first = p_first_env && !shadow && use_inverse && Np < h;
+    static const int s_inverse = env_flag("EMCID_S_INVERSE", 1);
+    static const int xrow_env = env_flag("EMCID_XROW", 1);
+    const bool xrow = xrow_env && shadow && s_inverse && cholesky_takes_shadow(Np) && Np * Np <= hp * dp && Np * NB <= hp * dp;
     EMCID_TRY(with_graph(make_key(6, {Yt, R, S, LS, RT, V, U, info_dev},
                                   {dp, Np, N, hp, (int64_t)(uintptr_t)Lb,
-                                   use_inverse + 2 * (assembled != 0) + 4 * (int)shadow + 8 * h + ((int64_t)p_first << 31) + (d << 32)}),
+                                   use_inverse + 2 * (assembled != 0) + 4 * (int)shadow + 8 * h + ((int64_t)p_first << 31) + ((int64_t)xrow << 30) + (d << 32)}),
                          st,
                          [&](hipStream_t q) {
         if (!assembled) {
@@ -2192,15 +2282,26 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
         if (p_first) apply_inverse_backward(X, dp, Yt, (int)Np, (int)dp, P, dp, q, base + ws.off_SK);       // P = Yt X
         ShadowJob job{Yt, dp, X, dp, P, dp, (int)Np, (int)dp, (int)dp, 0, 0, nullptr, 0, 0, 0};
         job.wgs = (int)((Np + SH_BM - 1) / SH_BM) * (int)(((dp + SH_BN - 1) / SH_BN + 1) / 2);
-        EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q, shadow ? &job : nullptr));
+        // XS = inv(LS) rides in the factorization's launches (XrowJob), transposed, in the V | U buffers the shadow form leaves unused
+        const XrowJob xj{V, Np, U};
+        EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q, shadow ? &job : nullptr, xrow ? &xj : nullptr));
         // RT[h, Np] = Rt^T ; Z^T = RT S^-1 (two solves with h rows)
         hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)((hp + 31) / 32), (unsigned)(Np / 32)), dim3(256), 0, q, R, hp, RT,
                            Np, (int)Np, (int)hp);
         // Z^T = RT S^-1.  As block substitution this is 6 dependent launches on h rows (~140 us at N = 1000, latency-bound); with
         // XS = inv(LS) made explicit (one more halving level on top of the 512-block inverses, into S, which the factorization has
         // consumed) it is two GEMMs against a triangle:  Z^T = (RT XS^T) XS.   EMCID_S_INVERSE=0 keeps the substitution.
-        static const int s_inverse = env_flag("EMCID_S_INVERSE", 1);
-        if (s_inverse && Np <= 4096) {
+        if (xrow) {
+            ScopedProf sp(KC_TRSM_DIAG, q);
+            GemmShape f{RT, Np, V, Np, (int)h, (int)Np, (int)Np, 0};
+            f.tri = 1;       // B(k, n) = XS[n][k] = Xt[k][n], zero for k > n
+            f.pair = 1;
+            launch_gemm_f64<true, false>(f, EpiAxpby{Y2, Np, 1.0, 0.0}, q);
+            GemmShape b{Y2, Np, V, Np, (int)h, (int)Np, (int)Np, 0};
+            b.tri = 2;       // B(k, n) = XS[k][n] = Xt[n][k], zero for k < n
+            b.pair = 1;
+            launch_gemm_f64<true, true>(b, EpiAxpby{RT, Np, 1.0, 0.0}, q);
+        } else if (s_inverse && Np <= 4096) {
             EMCID_TRY(build_full_inverse(LS, Np, Np, invS, S, Y2, 1, 0, 0, q));
             ScopedProf sp(KC_TRSM_DIAG, q);
             GemmShape f{RT, Np, S, Np, (int)h, (int)Np, (int)Np, 0};

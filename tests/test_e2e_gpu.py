@@ -1117,9 +1117,14 @@ def test_forward_paths_agree(tmp_path, kind, layers, n_req, monkeypatch):
     if hidden % 32 == 0 and inter % 32 == 0:
         assert paths["native"].get("native_layers", 0) >= max(layers) and paths["launches"].get("native_layers", 0) == 0
         assert paths["launches"]["linear_sp16"] > 0 and paths["f32"]["linear_sp16"] == 0 and paths["f32"]["linear_f32"] > 0
-    for en, el, ef in zip(results["native"][0], results["launches"][0], results["f32"][0]):
-        assert torch.equal(en.K, el.K) and torch.equal(en.Zc, el.Zc)
-        assert (en.dW - el.dW).abs().max().item() <= 1e-7 * el.dW.abs().max().item()
+    for i, (en, el, ef) in enumerate(zip(results["native"][0], results["launches"][0], results["f32"][0])):
+        if i == 0:      # nothing upstream of the first edited layer has been solved: the same kernels on the same inputs
+            assert torch.equal(en.K, el.K) and torch.equal(en.Zc, el.Zc)
+        else:           # downstream of a cold solve (reproducible to fp64 rounding only, see above): the keys may move in their last bits
+            assert (en.K - el.K).abs().max().item() <= 1e-6 * el.K.abs().max().item()
+            assert (en.Zc - el.Zc).abs().max().item() <= 1e-6 * el.Zc.abs().max().item()
+        # (a one-ulp flip in a weight of the layer before moves this layer's keys by ~1e-7 and its update by a few times that)
+        assert (en.dW - el.dW).abs().max().item() <= (1e-7 if i == 0 else 2e-6) * el.dW.abs().max().item()
         torch.testing.assert_close(en.K, ef.K, rtol=2e-4, atol=2e-5)
         assert (en.dW - ef.dW).abs().max().item() <= 2e-5 * ef.dW.abs().max().item()
     for n in names:
