@@ -1574,7 +1574,7 @@ struct GraphKey {
     bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
 };
 struct GraphSlot { GraphKey key; hipGraphExec_t exec; hipGraph_t graph; uint64_t used; };
-constexpr int GRAPH_SLOTS = 32;
+constexpr int GRAPH_SLOTS = 64;     // (32 was one bench process short: its SDXL record re-captured graphs in every call once the other records had filled the cache)
 GraphSlot g_graphs[GRAPH_SLOTS];
 int g_graph_n = 0;
 uint64_t g_graph_clock = 0;
@@ -1729,8 +1729,11 @@ struct DualWorkspace {
         off_V = o; o += hp * dp;
         off_U = o; o += hp * dp;
         off_SK = o; o += streamk_workspace_doubles(kStreamKWgs);      // partial-tile slots + ticket counters (zero between launches)
+        off_XT = o; o += Np * Np;                                     // XrowJob: inv(LS)^T ...
+        off_TT = o; o += Np * NB;                                     // ... and its per-step scratch
         total = o;
     }
+    int64_t off_XT, off_TT;
 };
 
 struct EditWorkspace {
@@ -2270,7 +2273,8 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
     const bool p_first = p_first_env && !shadow && use_inverse && Np < h;
     static const int s_inverse = env_flag("EMCID_S_INVERSE", 1);
     static const int xrow_env = env_flag("EMCID_XROW", 1);
-    const bool xrow = xrow_env && shadow && s_inverse && cholesky_takes_shadow(Np) && Np * Np <= hp * dp && Np * NB <= hp * dp;
+    const bool xrow = xrow_env && s_inverse && cholesky_takes_shadow(Np);       // (= the fused leaf / spine schedule runs)
+    double *XT = base + ws.off_XT, *TT = base + ws.off_TT;
     EMCID_TRY(with_graph(make_key(6, {Yt, R, S, LS, RT, V, U, info_dev},
                                   {dp, Np, N, hp, (int64_t)(uintptr_t)Lb,
                                    use_inverse + 2 * (assembled != 0) + 4 * (int)shadow + 8 * h + ((int64_t)p_first << 31) + ((int64_t)xrow << 30) + (d << 32)}),
@@ -2282,8 +2286,8 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
         if (p_first) apply_inverse_backward(X, dp, Yt, (int)Np, (int)dp, P, dp, q, base + ws.off_SK);       // P = Yt X
         ShadowJob job{Yt, dp, X, dp, P, dp, (int)Np, (int)dp, (int)dp, 0, 0, nullptr, 0, 0, 0};
         job.wgs = (int)((Np + SH_BM - 1) / SH_BM) * (int)(((dp + SH_BN - 1) / SH_BN + 1) / 2);
-        // XS = inv(LS) rides in the factorization's launches (XrowJob), transposed, in the V | U buffers the shadow form leaves unused
-        const XrowJob xj{V, Np, U};
+        // XS = inv(LS) rides in the factorization's launches (XrowJob), transposed
+        const XrowJob xj{XT, Np, TT};
         EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q, shadow ? &job : nullptr, xrow ? &xj : nullptr));
         // RT[h, Np] = Rt^T ; Z^T = RT S^-1 (two solves with h rows)
         hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)((hp + 31) / 32), (unsigned)(Np / 32)), dim3(256), 0, q, R, hp, RT,
@@ -2293,11 +2297,11 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
         // consumed) it is two GEMMs against a triangle:  Z^T = (RT XS^T) XS.   EMCID_S_INVERSE=0 keeps the substitution.
         if (xrow) {
             ScopedProf sp(KC_TRSM_DIAG, q);
-            GemmShape f{RT, Np, V, Np, (int)h, (int)Np, (int)Np, 0};
+            GemmShape f{RT, Np, XT, Np, (int)h, (int)Np, (int)Np, 0};
             f.tri = 1;       // B(k, n) = XS[n][k] = Xt[k][n], zero for k > n
             f.pair = 1;
             launch_gemm_f64<true, false>(f, EpiAxpby{Y2, Np, 1.0, 0.0}, q);
-            GemmShape b{Y2, Np, V, Np, (int)h, (int)Np, (int)Np, 0};
+            GemmShape b{Y2, Np, XT, Np, (int)h, (int)Np, (int)Np, 0};
             b.tri = 2;       // B(k, n) = XS[k][n] = Xt[n][k], zero for k < n
             b.pair = 1;
             launch_gemm_f64<true, true>(b, EpiAxpby{RT, Np, 1.0, 0.0}, q);
@@ -2421,12 +2425,27 @@ int emcid_edit_dual_cols_stage2_f64(int64_t N, int64_t d, int64_t h, const void*
     const int64_t dp = ws.dp, Np = ws.Np, hp = ws.hp;
     const double* X = cov_inverse(cov_factor_ws, n_layers, dp, layer_index);
     const int w = n_tiles * NB;
-    EMCID_TRY(with_graph(make_key(8, {Yc, R, S, LS, RT, V, U, info_dev}, {dp, Np, N, hp, (int64_t)w}), st, [&](hipStream_t q) {
+    static const int xrow_env = env_flag("EMCID_XROW", 1);
+    const bool xrow = xrow_env && cholesky_takes_shadow(Np);
+    EMCID_TRY(with_graph(make_key(8, {Yc, R, S, LS, RT, V, U, info_dev}, {dp, Np, N, hp, (int64_t)w + ((int64_t)xrow << 40)}), st, [&](hipStream_t q) {
         hipLaunchKernelGGL(add_identity_f64_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, q, S, (int)Np);
-        EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q));
+        const XrowJob xj{base + ws.off_XT, Np, base + ws.off_TT};
+        EMCID_TRY(cholesky_impl(S, LS, Np, Np, invS, info_dev, q, nullptr, xrow ? &xj : nullptr));
         hipLaunchKernelGGL(transpose_f64_kernel, dim3((unsigned)((hp + 31) / 32), (unsigned)(Np / 32)), dim3(256), 0, q, R, hp, RT,
                            Np, (int)Np, (int)hp);
-        EMCID_TRY(cholesky_solve_impl(LS, Np, Np, invS, RT, Y2, h, Np, q));      // RT := Z^T
+        if (xrow) {     // Z^T = (RT XS^T) XS against the inverse that rode in the factorization (as emcid_edit_dual_apply_stage2_f64)
+            ScopedProf sp(KC_TRSM_DIAG, q);
+            GemmShape f{RT, Np, xj.Xt, Np, (int)h, (int)Np, (int)Np, 0};
+            f.tri = 1;
+            f.pair = 1;
+            launch_gemm_f64<true, false>(f, EpiAxpby{Y2, Np, 1.0, 0.0}, q);
+            GemmShape b{Y2, Np, xj.Xt, Np, (int)h, (int)Np, (int)Np, 0};
+            b.tri = 2;
+            b.pair = 1;
+            launch_gemm_f64<true, true>(b, EpiAxpby{RT, Np, 1.0, 0.0}, q);
+        } else {
+            EMCID_TRY(cholesky_solve_impl(LS, Np, Np, invS, RT, Y2, h, Np, q));      // RT := Z^T
+        }
         {
             ScopedProf sp(KC_DELTA_W, q);       // V[h, w] = Z^T Yc
             GemmShape g{RT, Np, Yc, dp, (int)h, w, (int)Np, 0};
