@@ -126,13 +126,10 @@ int emcid_clip_layer_head_sp16(const emcid_clip_layer_sp16* L, int64_t rows, int
     EMCID_TRY(emcid_linear_sp16_f32(w.ctx_p, h, w.ctx_s, L->out_planes, h, L->out_inv_scale, L->out_bias, res, h, mid, h, nullptr,
                                     0, nullptr, n_sel, h, h, 0, -1, stream));
     EMCID_TRY(emcid_add_layernorm_sp16(mid, h, nullptr, 0, L->ln2_gamma, L->ln2_beta, L->ln2_eps, n_sel, h, nullptr, nullptr, w.z_p,
-                                       h, w.z_s, L->fc1_bound, w.f_scale, stream));
-    // the LayerNorm kernel writes scale / inverse scale at [0, n) and [n, 2n) of ITS row count: hand them on in the caller's layout
-    if (f_scale != w.f_scale)
-        if (hipMemcpyAsync(f_scale, w.f_scale, 2 * n_sel * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return fail(EMCID_ERR_HIP, __func__, "hipMemcpyAsync");
+                                       h, w.z_s, L->fc1_bound, f_scale, stream));
+    // (the LayerNorm kernel writes the scales at [0, n_sel) and their inverses at [n_sel, 2 n_sel): the caller's [2, n_sel] layout)
     EMCID_TRY(emcid_linear_sp16_f32(w.z_p, h, w.z_s, L->fc1_planes, h, L->fc1_inv_scale, L->fc1_bias, nullptr, 0, f_f32, d,
-                                    f_planes, d, w.f_scale, n_sel, d, h, L->act, -1, stream));
+                                    f_planes, d, f_scale, n_sel, d, h, L->act, -1, stream));
     return EMCID_OK;
 }
 
