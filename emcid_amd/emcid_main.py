@@ -403,6 +403,57 @@ def _any_vstar_missing(requests: Sequence[Dict], hparams, cache_name: Optional[s
     return not names.issuperset(pre_base + t for t in tails) if pre_base else not names.issuperset(tails)
 
 
+_VSTAR_READER = None          # one helper thread for the whole process (created at first use)
+
+
+class _EarlyVstars:
+    """The v* rows of a request list, read by the native batch reader ON A HELPER THREAD from the moment prepare has launched the
+    unedited leading layers: the reader is one ctypes call that does not hold the interpreter lock, so it runs beside the host's
+    remaining preparation and is (nearly) done when the first solve asks — with the GPU twice as fast as in round 3 the read had
+    moved onto the critical path (profiles/r04_g_call_events.txt: the host reached the first solve 0.2 ms before the device).
+    Anything the native reader does not serve (a miss, a file for numpy, k-token files) falls back to load_v_stars at result()."""
+
+    def __init__(self, args, kwargs, future, rows, keep):
+        self.args, self.kwargs, self.future, self.rows, self.keep = args, kwargs, future, rows, keep
+
+    @classmethod
+    def start(cls, requests, hparams, cache_name, suffix, stage1, width=None, pin=False):
+        from . import host_text
+        if (not width or cache_name is None or not len(requests) or os.environ.get("EMCID_NATIVE_VSTAR", "1") == "0"
+                or os.environ.get("EMCID_EARLY_VSTAR", "1") == "0" or not host_text.available()):
+            return None
+        if bool(getattr(hparams, "use_new_compute_z", False)) and int(getattr(hparams, "num_edit_tokens", 1) or 1) > 1:
+            return None
+        names = [vstar_cache_name(cache_name, request, hparams, idx, suffix) for idx, request in enumerate(requests)]
+        if any(n is None for n in names):
+            return None
+        global _VSTAR_READER
+        if _VSTAR_READER is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _VSTAR_READER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="emcid-vstar")
+        lib = host_text.load()
+        n = len(names)
+        blob, off = host_text.pack_strings(names)
+        rows = torch.empty((n, int(width)), dtype=torch.float32, pin_memory=bool(pin))
+        status = np.empty(n, dtype=np.uint8)
+        threads = _read_threads()
+        fut = _VSTAR_READER.submit(lib.emcid_read_npz_rows_f32, blob, off.ctypes.data, n, b"v_star", int(width), rows.data_ptr(),
+                                   int(width), status.ctypes.data, threads)
+        return cls((requests, hparams, cache_name, suffix, stage1), dict(width=width, pin=pin), fut, rows, (blob, off, status))
+
+    def wait(self):
+        try:
+            return self.future.result()
+        except Exception:
+            return -1
+
+    def result(self):
+        rc = self.wait()
+        if rc is not None and rc >= 0 and not self.keep[2].any():
+            return self.rows
+        return load_v_stars(*self.args, **self.kwargs)
+
+
 class _LazyVstars:
     """The v* rows of a request list, read when first asked for.  prepare hands this to the engine, which asks at the first
     edited layer's solve — by then the encoder forward up to that layer is queued on the GPU, so the file-system calls of
@@ -426,11 +477,15 @@ def prepare_text_encoder_edit(text_encoder, tokenizer, requests, hparams, layers
     how = dict(width=int(w.shape[0]) if w is not None and w.dim() == 2 else None, pin=bool(w is not None and w.is_cuda))
 
     def targets():
+        # the files start coming in on the helper thread at once; whether one is missing is looked up meanwhile
+        early = _EarlyVstars.start(requests, hparams, cache_name, suffix, stage1, **how)
         # a cache miss is handled FIRST, as the reference does (:873-969 come before the layer loop's covariance reads): Stage 1
         # runs (or the miss is reported) before statistics are read or computed
         if _any_vstar_missing(requests, hparams, cache_name, suffix):
+            if early is not None:
+                early.wait()            # its buffers stay alive until the reader is out of them
             return load_v_stars(requests, hparams, cache_name, suffix, stage1, **how)
-        return _LazyVstars(requests, hparams, cache_name, suffix, stage1, **how)
+        return early if early is not None else _LazyVstars(requests, hparams, cache_name, suffix, stage1, **how)
 
     def statistics():
         return {layer: get_cov_text_encoder(text_encoder, tokenizer, hparams.rewrite_module_tmp.format(layer),
