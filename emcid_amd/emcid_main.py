@@ -437,8 +437,14 @@ class _EarlyVstars:
         rows = torch.empty((n, int(width)), dtype=torch.float32, pin_memory=bool(pin))
         status = np.empty(n, dtype=np.uint8)
         threads = _read_threads()
-        fut = _VSTAR_READER.submit(lib.emcid_read_npz_rows_f32, blob, off.ctypes.data, n, b"v_star", int(width), rows.data_ptr(),
-                                   int(width), status.ctypes.data, threads)
+
+        def read(blob=blob, off=off, rows=rows, status=status):
+            # (the buffers belong to this task, not to the object that waits for it: a plan that is dropped unrun must not free
+            #  memory the reader is still writing)
+            return lib.emcid_read_npz_rows_f32(blob, off.ctypes.data, n, b"v_star", int(width), rows.data_ptr(), int(width),
+                                               status.ctypes.data, threads)
+
+        fut = _VSTAR_READER.submit(read)
         return cls((requests, hparams, cache_name, suffix, stage1), dict(width=width, pin=pin), fut, rows, (blob, off, status))
 
     def wait(self):
