@@ -858,6 +858,28 @@ def test_native_vstar_reader_equals_numpy_reader(tmp_path, monkeypatch):
     assert torch.equal(em.load_v_stars(reqs, hp, cache), ref)
 
 
+def test_early_vstar_reader_survives_dropped_plans_and_falls_back(tmp_path):
+    """emcid_main._EarlyVstars: the native read runs on a helper thread from the moment it is started; a handle that is dropped
+    unconsumed (a plan prepared and never run) must not free the buffers under the reader (they belong to the reader's task), the
+    rows equal load_v_stars's, and whatever the native reader does not serve (a miss, a file for numpy) takes load_v_stars at
+    result()."""
+    import gc
+    em, reqs, cache, vs, hp = _vstar_setup(tmp_path, n=400, width=64)
+    ref = em.load_v_stars(reqs, hp, cache, width=64)
+    for _ in range(30):                                   # started and dropped at once, many times over
+        em._EarlyVstars.start(reqs, hp, cache, "", None, width=64, pin=False)
+    gc.collect()
+    early = em._EarlyVstars.start(reqs, hp, cache, "", None, width=64, pin=False)
+    assert early is not None and torch.equal(early.result(), ref)
+    name = lambda i: em.vstar_cache_name(cache, reqs[i], hp, i)
+    np.savez_compressed(name(3), v_star=vs[3])            # not served natively: the whole list goes through load_v_stars
+    Path(name(7)).unlink()
+    early = em._EarlyVstars.start(reqs, hp, cache, "", lambda r, sfx: torch.full((64,), 7.0), width=64, pin=False)
+    got = early.result()
+    assert torch.equal(got[3], ref[3]) and torch.equal(got[7], torch.full((64,), 7.0)) and torch.equal(got[8:], ref[8:])
+    assert em._EarlyVstars.start(reqs, hp, None, "", None, width=64) is None          # nothing to read early without a cache
+
+
 def test_vstar_memo_is_bounded(tmp_path, monkeypatch):
     em, reqs, cache, vs, hp = _vstar_setup(tmp_path, n=12)
     monkeypatch.setattr(em, "_VSTAR_CACHE_MAX", 5)
