@@ -403,7 +403,7 @@ def _any_vstar_missing(requests: Sequence[Dict], hparams, cache_name: Optional[s
     return not names.issuperset(pre_base + t for t in tails) if pre_base else not names.issuperset(tails)
 
 
-_VSTAR_READER = None          # one helper thread for the whole process (created at first use)
+_VSTAR_READER = None          # (pid, executor): one helper thread per process, created at first use
 
 
 class _EarlyVstars:
@@ -428,9 +428,9 @@ class _EarlyVstars:
         if any(n is None for n in names):
             return None
         global _VSTAR_READER
-        if _VSTAR_READER is None:
+        if _VSTAR_READER is None or _VSTAR_READER[0] != os.getpid():      # (a forked child does not inherit the worker thread)
             from concurrent.futures import ThreadPoolExecutor
-            _VSTAR_READER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="emcid-vstar")
+            _VSTAR_READER = (os.getpid(), ThreadPoolExecutor(max_workers=1, thread_name_prefix="emcid-vstar"))
         lib = host_text.load()
         n = len(names)
         blob, off = host_text.pack_strings(names)
@@ -444,7 +444,7 @@ class _EarlyVstars:
             return lib.emcid_read_npz_rows_f32(blob, off.ctypes.data, n, b"v_star", int(width), rows.data_ptr(), int(width),
                                                status.ctypes.data, threads)
 
-        fut = _VSTAR_READER.submit(read)
+        fut = _VSTAR_READER[1].submit(read)
         return cls((requests, hparams, cache_name, suffix, stage1), dict(width=width, pin=pin), fut, rows, (blob, off, status))
 
     def wait(self):
