@@ -1512,7 +1512,8 @@ static inline bool pairs_fill_the_chip(int rows, int64_t dp, bool backward) {
     static const int enabled = env_flag("EMCID_TRI_PAIRS", 1);
     if (!enabled) return false;
     const int64_t wgs = (int64_t)((rows + 31) / 32) * (((dp + 63) / 64 + 1) / 2);
-    if (backward && rows <= 256) return true;
+    // (at most 128 rows: the stream-K form on 64 x 64 tiles is ahead — P = Yt X of a 100-concept edit 75 -> 54 us, inv_apply 0.51 -> 0.42 ms per call)
+    if (backward && rows <= 256 && rows > 128) return true;
     if (wgs <= 768) return wgs >= 614;          // one round at >= 80 % of the slots (d = 5120, 1024 rows: 640 -> 515 vs 542 us)
     const int64_t tail = wgs % 768;
     return tail == 0 || tail >= 700;
