@@ -28,7 +28,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import hip, nethook
+from . import edit_engine, hip, nethook
 from .edit_engine import (ConceptShard, EncoderEditPlan, LayerEdit, check_info, phase, prepare_encoder_edit,
                           run_checked, run_encoder_edit)
 from .emcid_hparams import EMCIDHyperParams, EMCIDXLHyperParams
@@ -795,15 +795,26 @@ def _sdxl_split(shard: ConceptShard):
     return {"which": which, "shard": ConceptShard(sub_rank, g1 if which == 1 else g2, grp), "roots": (0, g1)}
 
 
+def _axpy_weight_(w: torch.Tensor, dW: torch.Tensor):
+    """``w += dW`` on an encoder weight (the kernel writes through the raw pointer) with the in-place version counter of the
+    PARAMETER bumped: the caches derived from a weight (split-fp16 planes, native layer structs) follow that counter, and a
+    write through ``w.data`` alone leaves it where it was (``.data`` has a counter of its own)."""
+    hip.axpy_(w.data, dW)
+    edit_engine._touch(w)
+
+
 def _broadcast_(t: torch.Tensor, src: int):
-    """In-place broadcast over the default group (RCCL on device buffers; gloo stages HBM tensors through the host)."""
+    """In-place broadcast over the default group (RCCL on device buffers; gloo stages HBM tensors through the host).  ``t`` may
+    be a Parameter: the bytes go through ``t.data`` and the parameter's version counter is bumped (see ``_axpy_weight_``)."""
     import torch.distributed as dist
-    if t.is_cuda and dist.get_backend() == "gloo":
-        host = t.detach().cpu()
+    raw = t.data
+    if raw.is_cuda and dist.get_backend() == "gloo":
+        host = raw.cpu()
         dist.broadcast(host, src=src)
-        t.copy_(host)
+        raw.copy_(host)
     else:
-        dist.broadcast(t, src=src)
+        dist.broadcast(raw, src=src)
+    edit_engine._touch(t)
 
 
 def _sdxl_plans(pipe, requests, hparams, cache_name, stat_dir, stat_dir_2, verbose, shard, stage1):
@@ -858,13 +869,13 @@ def apply_emcid_to_sdxl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
             edits = run_checked(plan, keep_factors=False, restore=False)
             if SDXL_TE2_DOUBLE_APPLY:   # execute left TE2 edited, apply adds the update once more (:93-99)
                 for e in edits:
-                    hip.axpy_(nethook.get_parameter(pipe.text_encoder_2, e.weight_name).data, e.dW)
+                    _axpy_weight_(nethook.get_parameter(pipe.text_encoder_2, e.weight_name), e.dW)
         names = []
         for enc, layers, root in ((pipe.text_encoder, hparams.layers, split["roots"][0]),
                                   (pipe.text_encoder_2, hparams.layers_2, split["roots"][1])):
             for layer in layers:
                 name = f"{hparams.rewrite_module_tmp.format(layer)}.weight"
-                _broadcast_(nethook.get_parameter(enc, name).data, root)
+                _broadcast_(nethook.get_parameter(enc, name), root)
                 names.append(name)
         if verbose:
             print(f"New weights successfully inserted into {names}")
@@ -884,13 +895,13 @@ def apply_emcid_to_sdxl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
         e2 = run_encoder_edit(p2, keep_factors=False, restore=False)
         if SDXL_TE2_DOUBLE_APPLY:   # execute left TE2 edited, apply adds the update once more (:93-99)
             for e in e2:
-                hip.axpy_(nethook.get_parameter(pipe.text_encoder_2, e.weight_name).data, e.dW)
+                _axpy_weight_(nethook.get_parameter(pipe.text_encoder_2, e.weight_name), e.dW)
     if two_streams:
         torch.cuda.current_stream(dev2).wait_stream(s2)
 
     def double_apply(edits):
         for e in edits:
-            hip.axpy_(nethook.get_parameter(pipe.text_encoder_2, e.weight_name).data, e.dW)
+            _axpy_weight_(nethook.get_parameter(pipe.text_encoder_2, e.weight_name), e.dW)
 
     for plan, redo in ((p1, None), (p2, double_apply if SDXL_TE2_DOUBLE_APPLY else None)):
         try:

@@ -358,6 +358,73 @@ def test_sdxl_real_dims_apply_vs_oracle(tmp_path):
             assert err < 1e-4 and err <= 1e-4 * ref.abs().max().item(), (tag, n, err, ref.abs().max().item())
 
 
+def test_sdxl_apply_twice_on_one_pipe_vs_oracle(tmp_path):
+    """Sequential editing (reference: experiments/sequential_editing.py:98-165 applies edit after edit to ONE pipe): the second
+    `apply_emcid_to_sdxl_text_encoders` call on the same pipe must see TE2's weights as the first call left them (W + 2 dW, the
+    double-apply quirk) — the split-fp16 planes and native layer structs cached from the first call are stale at that point
+    unless every raw write to a weight bumps its version counter (round-4 advisor finding)."""
+    reqs_a = syn.make_requests(8, names="syllable")
+    reqs_b = syn.make_requests(8, names="syllable", name_seed=11)
+    hp_d = syn.sdxl_hparams_dict()
+    n1 = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers"]]
+    n2 = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers_2"]]
+    cache = str(tmp_path / "cache") + "/"
+    for reqs, seed in ((reqs_a, 1), (reqs_b, 3)):
+        syn.write_vstar_cache(cache, reqs, 768, seed=seed, scale=0.5)
+        syn.write_vstar_cache(cache, reqs, 1280, seed=seed + 4, scale=0.5, suffix="_2")
+    syn.write_stats_cache(tmp_path / "s1", n1, 3072, hp_d["mom2_n_samples"], seed=2, t=6144)
+    syn.write_stats_cache(tmp_path / "s2", n2, 5120, hp_d["mom2_n_samples"], seed=7, t=10240)
+    cpu = syn.build_pipe("sd-v1.4", "cpu", sdxl=True, syllables=True)
+    w0 = {("1", n): orc.get_parameter(cpu.text_encoder, n + ".weight").clone() for n in n1}
+    w0.update({("2", n): orc.get_parameter(cpu.text_encoder_2, n + ".weight").clone() for n in n2})
+    gpu = syn.build_pipe("sd-v1.4", DEV, sdxl=True, syllables=True)
+    for reqs in (reqs_a, reqs_b):
+        orc.apply_emcid_to_sdxl_text_encoders(cpu, reqs, copy.deepcopy(hp_d), cache_name=cache, stat_dir=str(tmp_path / "s1"),
+                                              stat_dir_2=str(tmp_path / "s2"))
+        em.apply_emcid_to_sdxl_text_encoders(gpu, reqs, EMCIDXLHyperParams(**hp_d), DEV, cache_name=cache,
+                                             stat_dir=str(tmp_path / "s1"), stat_dir_2=str(tmp_path / "s2"), verbose=False)
+    for tag, names, ce, ge in (("1", n1, cpu.text_encoder, gpu.text_encoder), ("2", n2, cpu.text_encoder_2, gpu.text_encoder_2)):
+        for n in names:
+            ref = orc.get_parameter(ce, n + ".weight").double() - w0[(tag, n)].double()
+            got = get_parameter(ge, n + ".weight").cpu().double() - w0[(tag, n)].double()
+            err = (got - ref).abs().max().item()
+            assert err < 1e-4 and err <= 1e-4 * ref.abs().max().item(), (tag, n, err, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("own_gemm", [True, False])
+def test_non_contiguous_layer_list_vs_oracle(tmp_path, monkeypatch, own_gemm):
+    """`hparams.layers = [7, 9, 10]`: layer 8 sits between two edited layers and is NOT edited — its fc2 output takes the
+    unedited path inside a forward whose callback adds the residual for the edited ones (clip_forward.run_layers, the
+    `summed = outs is not None and i in by_cb` line; round-3 advisor bug).  Default path (native layer runner, split-fp16 GEMM)
+    and `EMCID_OWN_GEMM=0` (torch F.linear), SD-v1.4 dims, vs the oracle."""
+    from emcid_amd import clip_forward
+    monkeypatch.setattr(clip_forward, "OWN_GEMM", own_gemm)
+    layers = (7, 9, 10)
+    reqs = syn.make_requests(20, ragged=True, names="syllable")
+    hp_d = syn.sd_hparams_dict(layers=layers)
+    names = [hp_d["rewrite_module_tmp"].format(l) for l in layers]
+    cache = str(tmp_path / "cache") + "/"
+    syn.write_vstar_cache(cache, reqs, 768, seed=1, scale=0.5)
+    syn.write_stats_cache(tmp_path / "stats", names, 3072, hp_d["mom2_n_samples"], seed=2, t=6144)
+    cpu = syn.build_pipe("sd-v1.4", "cpu", syllables=True)
+    w0 = {n: orc.get_parameter(cpu.text_encoder, n + ".weight").clone() for n in names}
+    orc.apply_emcid_to_text_encoder(cpu, reqs, copy.deepcopy(hp_d), cache_name=cache, stats_dir=str(tmp_path / "stats"))
+    gpu = syn.build_pipe("sd-v1.4", DEV, syllables=True)
+    untouched = get_parameter(gpu.text_encoder, hp_d["rewrite_module_tmp"].format(8) + ".weight").clone()
+    for _ in range(2):          # the second call runs on the caches of the first (factors, planes, graph)
+        em.apply_emcid_to_text_encoder(gpu, reqs, EMCIDHyperParams(**hp_d), DEV, cache_name=cache,
+                                       stats_dir=str(tmp_path / "stats"), verbose=False)
+        for n in names:
+            ref = orc.get_parameter(cpu.text_encoder, n + ".weight").double() - w0[n].double()
+            got = get_parameter(gpu.text_encoder, n + ".weight").cpu().double() - w0[n].double()
+            err = (got - ref).abs().max().item()
+            assert err < 1e-4 and err <= 1e-4 * ref.abs().max().item(), (n, err, ref.abs().max().item())
+        assert torch.equal(get_parameter(gpu.text_encoder, hp_d["rewrite_module_tmp"].format(8) + ".weight"), untouched)
+        with torch.no_grad():
+            for n in names:
+                get_parameter(gpu.text_encoder, n + ".weight").copy_(w0[n].to(DEV))
+
+
 def test_eleven_layer_edit_vs_oracle(tmp_path):
     """The shipped `ly-11` hparams edit layers 0..10 (L = 11): batched factorization of eleven lam*C' matrices,
     residual split over 11 layers — HIP path vs the oracle at SD-v1.4 dims."""
