@@ -222,7 +222,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage0", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the n100 / sdxl / cold_process records")
-    ap.add_argument("--no-cpu-full", action="store_true", help="skip the full 1 000-concept run of the CPU baseline (~1 min)")
+    ap.add_argument("--no-cpu-full", action="store_true", help="skip the full 1 000-concept runs of the CPU baseline (~1 min each)")
+    ap.add_argument("--cpu-full-runs", type=int, default=3, help="full-size runs of the CPU baseline (median reported)")
     ap.add_argument("--no-gemm-ab", action="store_true", help="skip the calls on the OTHER forward-GEMM path (keeps a profiler trace "
                                                               "of this run free of that path's kernels)")
     ap.add_argument("--cold-child", default=None, help=argparse.SUPPRESS)
@@ -341,6 +342,35 @@ def main():
             edit_engine.DIST_TIMING["enabled"] = False
             per_rank = {"error": repr(e)}
     value = args.concepts * args.steps / elapsed
+    # ---- companion record for N > 1: the SAME call as G independent replicas (every rank edits its own 1 000-concept request
+    # sets on its own GPU, no collective on the data path — SURVEY.md §8e: what actually uses 8 GPUs when there are 8 lists to
+    # edit), beside the strong-scaling number above (ONE list cut across the ranks, whose replicated N x N chain and per-layer
+    # all-reduces do not divide) -------------------------------------------------------------------------------------------
+    weak = None
+    if world > 1:
+        try:
+            solo = ConceptShard(0, 1, None)
+
+            def replica_call(i):
+                r, c = sets[(1 + args.warmup + rank * 5 + i) % len(sets)]
+                restore_weights()
+                em.apply_emcid_to_text_encoder(pipe, r, hp, device, cache_name=c, stats_dir=stats, verbose=False, shard=solo)
+
+            for i in range(2):
+                replica_call(i)
+            sync()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                replica_call(2 + i)
+            sync()
+            wt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(wt, op=dist.ReduceOp.MAX)
+            weak = {"scaling": "weak", "value": world * args.concepts * args.steps / float(wt.item()), "unit": "concept-edits/s",
+                    "ms_per_step": float(wt.item()) / args.steps * 1e3, "steps": args.steps,
+                    "note": f"{world} replicas, one process per GPU, each editing its own {args.concepts}-concept request sets with no "
+                            f"collective on the data path; barrier + synchronize on both sides, max over ranks"}
+        except Exception as e:         # diagnostics must never cost the line
+            weak = {"error": repr(e)}
 
     # ---- the same 1 000 requests again and again (what rounds 1-2 reported as the step) ------------------------------------
     log(f"{elapsed / args.steps * 1e3:.2f} ms per step; replay / new-weight variants")
@@ -523,7 +553,8 @@ def main():
     out = {
         "metric": "concept-edits/sec (1 000-concept batch, SD-v1.4)", "value": value, "unit": "concept-edits/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": ("f32 forward (2 x fp16 split MFMA, fp32 accumulate) + f64 solve" if split_gemm else "f32 forward + f64 solve"), "data": "synthetic",
         "config": {"workload": f"{args.concepts}-concept edit, SD-v1.4 text-encoder dims (768/3072/12L), layers 7-10, "
                                f"lambda 4000, 3 prompts/concept; one step = one apply_emcid_to_text_encoder call, timer "
                                f"around the call (v* npz on disk, C_l in the covariance cache, model in HBM); every step "
@@ -579,11 +610,16 @@ def main():
         "solve": solve,
         "kernel_classes": classes,
         "per_rank": per_rank,
+        "weak_replicas": weak,
     }
 
     if rank == 0 and world == 1 and not args.no_variants:
-        log("secondary records: n100, sdxl, stage1, cold_process")
+        log("secondary records: n100, latency, realistic_names, n1500, no_shared_prefix, sdxl, stage1, cold_process")
         for name, fn in (("n100", lambda: n100_record(workdir, device)),
+                         ("latency_n1000", lambda: latency_record(workdir, device, args.concepts)),
+                         ("latency_n100", lambda: latency_record(workdir, device, 100)),
+                         ("realistic_names", lambda: realistic_names_record(workdir, device)),
+                         ("n1500", lambda: n1500_record(workdir, device)),
                          ("no_shared_prefix", lambda: no_shared_prefix_record(workdir, device)),
                          ("sdxl", lambda: sdxl_record(workdir, device)),
                          ("stage1", lambda: stage1_record(device)),
@@ -595,7 +631,8 @@ def main():
             log(f"{name} done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("cpu_baseline (oracle on the host cores)")
-        out.update(cpu_baseline_and_error(workdir, device, full_n=0 if args.no_cpu_full else args.concepts))
+        out.update(cpu_baseline_and_error(workdir, device, full_n=0 if args.no_cpu_full else args.concepts,
+                                          full_runs=max(1, args.cpu_full_runs)))
     if rank == 0 and world == 1 and not args.no_stage0:
         log("stage0")
         try:
@@ -639,7 +676,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline_and_error(workdir, device, n_sample=100, budget_s=40.0, full_n=0):
+def cpu_baseline_and_error(workdir, device, n_sample=100, budget_s=40.0, full_n=0, full_runs=3, full_budget_s=200.0):
     """Oracle on the host cores over a 100-concept sample of the workload (median of up to 3 runs inside `budget_s`) +
     dW error of the HIP path on the same sample; with `full_n`, ONE more run on the full request set of the GPU number
     ("same request sets"; about a minute).  host_s = tokenizer, subject search, v*/C reads inside the call."""
@@ -718,15 +755,19 @@ def cpu_baseline_and_error(workdir, device, n_sample=100, budget_s=40.0, full_n=
     out = {"cpu_baseline": rec, "dw_max_abs_err": err_abs, "dw_max_rel_err": err_rel}
     if full_n and full_n != n_sample:
         log(f"cpu_baseline: full {full_n}-concept run (about {cpu_s * full_n / n_sample:.0f} s)")
-        runs_f, ctx_f = oracle_runs(full_n, 1, 0.0)
+        # median of 3 runs after a warm-up (the sample runs above are the warm-up); a third run is dropped
+        # when the first two already took more than `full_budget_s` (a slow host must not push the bench past its minutes)
+        runs_f, ctx_f = oracle_runs(full_n, full_runs, full_budget_s)
         fa, fr = dw_error(ctx_f)
-        full = {"value": full_n / runs_f[0][0], "unit": "concept-edits/s", "seconds": runs_f[0][0], "host_s": runs_f[0][1],
-                "sample": f"the full {full_n}-concept request set of the GPU number (set 0), one run",
+        med_s, med_host = runs_f[len(runs_f) // 2]
+        full = {"value": full_n / med_s, "unit": "concept-edits/s", "seconds": med_s, "host_s": med_host,
+                "runs": len(runs_f), "seconds_per_run": [r[0] for r in runs_f],
+                "sample": f"the full {full_n}-concept request set of the GPU number (set 0), median of {len(runs_f)} run(s)",
                 "dw_max_abs_err": fa, "dw_max_rel_err": fr}
         # the like-for-like figure leads: `value` is the full request set of the GPU number; the bounded sample moves below it
         rec["sample_run"] = {k: rec[k] for k in ("value", "runs", "seconds_per_run", "host_s", "compute_s", "sample")}
-        rec.update(value=full["value"], sample=full["sample"], seconds=full["seconds"], host_s=full["host_s"], runs=1,
-                   seconds_per_run=[full["seconds"]], compute_s=full["seconds"] - full["host_s"])
+        rec.update(value=full["value"], sample=full["sample"], seconds=full["seconds"], host_s=full["host_s"], runs=len(runs_f),
+                   seconds_per_run=full["seconds_per_run"], compute_s=full["seconds"] - full["host_s"])
         rec["full"] = full
     return out
 
@@ -798,6 +839,121 @@ def n100_record(workdir, device, n=100, calls=9):
     return {"workload": f"{n}-concept edit, SD-v1.4 dims, layers 7-10, lambda 4000 (BASELINE config 2), one GPU; every call a "
                         f"never-seen request set", "ms_per_call_median": med, "ms_per_call": [round(t, 3) for t in timed],
             "host_phases_ms_per_call": {k: round(v / len(timed) * 1e3, 4) for k, v in edit_engine.TIMING.items()},
+            "concept_edits_per_s": n / (med * 1e-3), "first_call_ms_this_shape": ms[0], "calls": len(timed)}
+
+
+def percentiles(ms):
+    """p50 / p95 / p99 / max of a list of per-call milliseconds (nearest-rank on the sorted list)."""
+    v = sorted(ms)
+    def q(p):
+        return v[min(len(v) - 1, max(0, int(round(p * (len(v) - 1)))))]
+    return {"calls": len(v), "p50": q(0.50), "p95": q(0.95), "p99": q(0.99), "max": v[-1], "min": v[0],
+            "over_1p3x_median": sum(1 for t in v if t > 1.3 * q(0.50))}
+
+
+def latency_record(workdir, device, n, calls=200, kind="syllable"):
+    """Per-call wall-clock distribution of `calls` warm apply_emcid_to_text_encoder calls on `n`-concept request sets (cycled over
+    the distinct sets on disk; each call synchronised, weights restored before it, as in the headline)."""
+    import torch
+    from emcid_amd import emcid_main as em
+    from emcid_amd.emcid_hparams import EMCIDHyperParams
+    from emcid_amd.nethook import get_parameter
+
+    pipe, reqs, hp_d, cache, stats, layer_names = build_inputs(n, device, workdir)
+    sets = [(reqs, cache)] + [request_set(n, workdir, j) for j in range(1, 12)]
+    hp = EMCIDHyperParams(**hp_d)
+    w0 = {ln: get_parameter(pipe.text_encoder, ln + ".weight").detach().clone() for ln in layer_names}
+    ms = []
+    for i in range(calls + 5):
+        r, c = sets[i % len(sets)]
+        with torch.no_grad():
+            for ln in layer_names:
+                get_parameter(pipe.text_encoder, ln + ".weight").copy_(w0[ln])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        em.apply_emcid_to_text_encoder(pipe, r, hp, device, cache_name=c, stats_dir=stats, verbose=False)
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) * 1e3)
+    rec = percentiles(ms[5:])
+    rec["workload"] = f"{n}-concept edit, SD-v1.4 dims, layers 7-10: {calls} warm calls over {len(sets)} request sets, each between two synchronisations"
+    return rec
+
+
+def realistic_names_record(workdir, device, n=1000, calls=7):
+    """The headline edit on a request list with the first-word statistics of the reference's artist lists
+    (data/artists/info/erased-1000artists-....txt: two-word names of 3-5 tokens, ~650 distinct first words of 1 000, the
+    commonest ~21 times) instead of the 3-syllable names drawn from 90 syllables (which share first tokens 11-fold): how many trie
+    rows the three shared templates leave, and what the call costs.  Synthetic names of that shape (emcid_amd.synthetic.
+    artist_names, `syllables="wide"` vocabulary: its own model object, same dims); the list itself is not shipped."""
+    import torch
+    from emcid_amd import emcid_main as em, synthetic as syn
+    from emcid_amd.emcid_hparams import EMCIDHyperParams
+    from emcid_amd.nethook import get_parameter
+
+    pipe = syn.build_pipe(KIND, device, syllables="wide")
+    hp_d = syn.sd_hparams_dict(layers=LAYERS, mom2_update_weight=LAM, edit_weight=EW)
+    hp = EMCIDHyperParams(**hp_d)
+    layer_names = [hp_d["rewrite_module_tmp"].format(l) for l in LAYERS]
+    _, _, _, _, stats, _ = build_inputs(n, "cpu", workdir)
+    w0 = {ln: get_parameter(pipe.text_encoder, ln + ".weight").detach().clone() for ln in layer_names}
+    ms, rows, tok_hist = [], None, None
+    for j in range(calls + 2):
+        reqs = syn.make_requests(n, names="artist", name_seed=3 + 101 * j)
+        cache = str(Path(workdir) / f"cache_artist_{n}_set{j}") + "/"
+        if not (Path(cache) / ".complete").exists():
+            syn.write_vstar_cache(cache, reqs, syn.ENCODER_DIMS[KIND][0], seed=1 + j, scale=0.5)
+            (Path(cache) / ".complete").touch()
+        with torch.no_grad():
+            for ln in layer_names:
+                get_parameter(pipe.text_encoder, ln + ".weight").copy_(w0[ln])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        em.apply_emcid_to_text_encoder(pipe, reqs, hp, device, cache_name=cache, stats_dir=stats, verbose=False)
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) * 1e3)
+        if rows is None:
+            plan = em.prepare_text_encoder_edit(pipe.text_encoder, pipe.tokenizer, reqs, hp, hp.layers, hp.mom2_update_weight,
+                                                stats, cache, "", verbose=False)
+            rows = list(plan.trie_rows) if getattr(plan, "trie_rows", None) else None
+            torch.cuda.synchronize()
+            lens = [len(pipe.tokenizer(r["source"])["input_ids"]) - 2 for r in reqs]
+            firsts = len({r["source"].split()[0] for r in reqs})
+            tok_hist = {"tokens_per_name_mean": sum(lens) / len(lens), "tokens_per_name_min_max": [min(lens), max(lens)],
+                        "distinct_first_words": firsts}
+    timed = ms[2:]
+    med = statistics.median(timed)
+    return {"workload": f"{n}-concept edit, SD-v1.4 dims, layers 7-10, lambda 4000, the three shared templates, two-word names with "
+                        f"the first-word sharing of the reference's 1 000-artist list (synthetic names of that shape); every call a "
+                        f"never-seen name list", "names": tok_hist, "trie_rows_of_tokens": rows, "ms_per_call_median": med,
+            "ms_per_call": [round(t, 3) for t in timed], "concept_edits_per_s": n / (med * 1e-3), "calls": len(timed)}
+
+
+def n1500_record(workdir, device, n=1500, calls=7):
+    """The reference's largest shipped request list (data/artists/info/erased-1500artists-....txt through
+    dsets/artist_requests.py:27-46): 1 500 concepts, Np = 1536 — other tile / stream-K / shadow-fit decisions than Np = 1024."""
+    import torch
+    from emcid_amd import emcid_main as em
+    from emcid_amd.emcid_hparams import EMCIDHyperParams
+    from emcid_amd.nethook import get_parameter
+
+    pipe, reqs, hp_d, cache, stats, layer_names = build_inputs(n, device, workdir)
+    sets = [(reqs, cache)] + [request_set(n, workdir, j) for j in range(1, calls + 2)]
+    hp = EMCIDHyperParams(**hp_d)
+    w0 = {ln: get_parameter(pipe.text_encoder, ln + ".weight").detach().clone() for ln in layer_names}
+    ms = []
+    for r, c in sets:
+        with torch.no_grad():
+            for ln in layer_names:
+                get_parameter(pipe.text_encoder, ln + ".weight").copy_(w0[ln])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        em.apply_emcid_to_text_encoder(pipe, r, hp, device, cache_name=c, stats_dir=stats, verbose=False)
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) * 1e3)
+    timed = ms[2:]
+    med = statistics.median(timed)
+    return {"workload": f"{n}-concept edit (the reference's largest shipped list size), SD-v1.4 dims, layers 7-10, lambda 4000, one GPU; "
+                        f"every call a never-seen request set", "ms_per_call_median": med, "ms_per_call": [round(t, 3) for t in timed],
             "concept_edits_per_s": n / (med * 1e-3), "first_call_ms_this_shape": ms[0], "calls": len(timed)}
 
 

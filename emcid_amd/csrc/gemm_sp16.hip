@@ -51,6 +51,7 @@ struct SpArgs {
     float* Y; int64_t ldy;                                // fp32 result (may be null when only the planes are wanted)
     uint32_t* P; int64_t ldp; const float* ps;            // planes of the result under the caller's per-row scale 2^e (or null)
     int M, N, K, act, tiles_n, tiles, rb;
+    long long* stamps;                                    // diagnostic builds only (emcid_debug_linear_sp16_stamps); else null
 };
 
 // Tile order as in gemm_f32.hip: super-rows of `rb` row tiles, column-major inside a super-row.
@@ -634,6 +635,11 @@ __global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_sched_barrier(0);
+        long long t_clk = 0, t_real = 0;
+        if constexpr (DBG == 2) {
+            t_clk = (long long)__builtin_amdgcn_s_memtime();
+            t_real = (long long)__builtin_amdgcn_s_memrealtime();
+        }
         for (int it = 0; it < T; ++it) {
             unsigned char* cur = smem + (it & 1) * STAGE;
             unsigned char* oth = smem + ((it + 1) & 1) * STAGE;
@@ -644,7 +650,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_
             __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): stage it + 1 (own share) landed, step-1 fragments in registers
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (DBG < 1 && it + 2 < T) issue(it + 2, cur);
+            if (DBG != 1 && it + 2 < T) issue(it + 2, cur);
             if (it + 1 < T) fread(oth, ch0, SpIC<0>{});
             __builtin_amdgcn_sched_barrier(0);
             mfmas(SpIC<1>{});
@@ -652,8 +658,285 @@ __global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_
             __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the step-0 fragments landed long ago; said here so that the
             __builtin_amdgcn_sched_barrier(0);       // next iteration's MFMAs do not wait for the reads issued just before them
         }
+        if constexpr (DBG == 2) {        // diagnostic build: shader-clock and 100 MHz stamps around the K loop, one record per workgroup
+            const long long e_clk = (long long)__builtin_amdgcn_s_memtime(), e_real = (long long)__builtin_amdgcn_s_memrealtime();
+            if (a.stamps != nullptr && tid == 0) {
+                long long* st = a.stamps + 4 * (int64_t)blockIdx.x;
+                st[0] = t_clk; st[1] = e_clk; st[2] = t_real; st[3] = e_real;
+            }
+        }
     }
     sp_finish<MJ, NI, WM, WN, KS>(a, m0, n0, smem, acc);
+}
+
+// ---- the same LDS-DMA structure on v_mfma_f32_16x16x32_f16 ---------------------------------------------------------------------
+// MI355X_MICROARCH.md, DVFS give-back item 7: at about equal cycles per FLOP the chip holds a higher clock on the 16x16x32 shape
+// than on 32x32x16 (1.12-1.15x the FLOP/s in bare loops on random data).  Same planes, same stage image (32 k of a row = one
+// 128-byte line, 1-KiB DMA pieces of 8 rows), but a lane now holds row l & 15 and the k group l >> 4 of a 16-row block — chunk
+// 2 (l >> 4) (hi) / + 1 (lo) of its row: ONE k32 step per stage.  A ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) is then
+// rows {0-3, 12-15} at chunk c and rows {4-11} at chunk c ^ 2, so the swizzle key of the 32-row kernel, (r >> 1) & 7, would put
+// rows 4-11 on the slots of rows 0-3 / 12-15 (two-way conflicts); the key here flips bit 1 for rows 4-11 of every 16:
+// key16(r) = ((r >> 1) & 7) ^ ((((r >> 2) ^ (r >> 3)) & 1) << 1) — conflict-free for this read (checked exhaustively).
+// The MFMA runs transposed like the others (A = W rows, B = X rows): a lane of a 16 x 16 result holds row m = l & 15 and the
+// four consecutive columns n = 4 (l >> 4) .. + 3.
+// NSLOT = 2: both fragment sets of a stage pair in registers (wave tile 64 x 64: 64 + 2 x 64 registers), the reads of stage
+// it + 1 run under the MFMAs of stage it.  NSLOT = 1 (wave tile 128 x 64: 128 accumulator + 96 fragment registers, no room for
+// a second set): the fragments are reloaded PROGRESSIVELY — the barrier sits in the middle of a stage; behind it the registers
+// of every m block go back to LDS for the next stage as soon as the block's last MFMA is issued, the W fragments one by one
+// inside the last m block (each has >= 9 MFMAs = 144 cycles before the next stage wants it).
+__device__ __forceinline__ int sp_key16(int r) { return ((r >> 1) & 7) ^ ((((r >> 2) ^ (r >> 3)) & 1) << 1); }
+
+// Epilogue of the 16 x 16 blocks.  acc[i][j][e] = element (m, n): m = m0 + wm0 + 16 j + (l & 15), n = n0 + wn0 + 16 i + 4 (l >> 4) + e.
+template <int MJ, int NI, int WM, int WN>
+__device__ __forceinline__ void sp_finish16(const SpArgs& a, int m0, int n0, v4f (&acc)[NI][MJ]) {
+    constexpr int BM = 16 * MJ * WM, BN = 16 * NI * WN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int wm0 = (wave / WN) * (16 * MJ), wn0 = (wave % WN) * (16 * NI);
+    const float* __restrict__ bias = a.bias;
+    const float* __restrict__ res = a.res;
+    const float* __restrict__ ws = a.ws;
+    float* __restrict__ Y = a.Y;
+    uint32_t* __restrict__ P = a.P;
+    const int M = a.M, N = a.N;
+    const int64_t ldr = a.ldr, ldy = a.ldy, ldp = a.ldp;
+    const bool vec_ok = (N & 3) == 0 && (Y == nullptr || ((ldy & 3) == 0 && sp_al16(Y))) &&
+                        (res == nullptr || ((ldr & 3) == 0 && sp_al16(res))) && (bias == nullptr || sp_al16(bias)) && sp_al16(ws);
+    const bool interior = m0 + BM <= M && n0 + BN <= N && vec_ok;
+    auto epilogue = [&](auto actfn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) {
+            const int m = m0 + wm0 + 16 * j + l15;
+            const bool m_ok = m < M;
+            const float sx = a.xs[min(m, M - 1)];
+            const float sp = a.ps != nullptr ? a.ps[min(m, M - 1)] : 1.f;
+            if (interior) {
+                v4f rv[NI];
+                if (res != nullptr) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) rv[i] = *reinterpret_cast<const v4f*>(res + (int64_t)m * ldr + n0 + wn0 + 16 * i + 4 * l4);
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int n = n0 + wn0 + 16 * i + 4 * l4;
+                    const v4f w4 = *reinterpret_cast<const v4f*>(ws + n);
+                    v4f b4 = {0.f, 0.f, 0.f, 0.f};
+                    if (bias != nullptr) b4 = *reinterpret_cast<const v4f*>(bias + n);
+                    v4f v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = actfn(acc[i][j][e] * (sx * w4[e]) + b4[e]);
+                        if (res != nullptr) v[e] += rv[i][e];
+                    }
+                    if (Y != nullptr) *reinterpret_cast<v4f*>(Y + (int64_t)m * ldy + n) = v;
+                    if (P != nullptr) sp_store4(P + (int64_t)m * ldp, n, v[0], v[1], v[2], v[3], sp);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = n0 + wn0 + 16 * i + 4 * l4 + e;
+                        if (m_ok && n < N) {
+                            float v = actfn(acc[i][j][e] * (sx * ws[n]) + (bias != nullptr ? bias[n] : 0.f));
+                            if (res != nullptr) v += res[(int64_t)m * ldr + n];
+                            if (Y != nullptr) Y[(int64_t)m * ldy + n] = v;
+                            if (P != nullptr) {
+                                const float t = v * sp;
+                                const _Float16 h = (_Float16)t, l = (_Float16)(t - (float)h);
+                                _Float16* dst = reinterpret_cast<_Float16*>(reinterpret_cast<unsigned char*>(P + (int64_t)m * ldp) +
+                                                                           (n >> 3) * 32) + (n & 7);
+                                dst[0] = h;
+                                dst[8] = l;
+                            }
+                        }
+                    }
+            }
+        }
+    };
+    if (a.act == SP_ACT_QUICK_GELU) epilogue([](float x) { return x / (1.0f + __expf(-1.702f * x)); });
+    else if (a.act == SP_ACT_GELU_ERF) epilogue([](float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); });
+    else epilogue([](float x) { return x; });
+}
+
+// DBG (timing / diagnosis only): 1 = no DMA inside the loop (results wrong), 2 = shader-clock and 100 MHz stamps around the K
+// loop into a.stamps (results right), 3 = MFMAs only: no DMA and no fragment reads inside the loop (results wrong)
+template <int MJ, int NI, int WM, int WN, int NSLOT, int DBG>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_sp16_dma16_kernel(SpArgs a) {
+    constexpr int NWV = WM * WN, BM = 16 * MJ * WM, BN = 16 * NI * WN;
+    constexpr int ROWB = 128, RPP = 8, CPR = 8;
+    constexpr int STAGE = (BM + BN) * ROWB, PIECES = STAGE / 1024, PPW = PIECES / NWV;
+    static_assert(PIECES % NWV == 0 && BM % RPP == 0 && BN % RPP == 0 && PPW < 16, "pieces per wave");
+    static_assert(NSLOT == 2 || MJ % 2 == 0, "progressive reload halves the m blocks");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+    const int per = (a.tiles + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile >= a.tiles || (int)(blockIdx.x >> 3) >= per) return;
+    int bm, bn;
+    sp_tile_of(a, tile, bm, bn);
+    const int m0 = bm * BM, n0 = bn * BN, T = a.K / SPK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int wm0 = (wave / WN) * (16 * MJ), wn0 = (wave % WN) * (16 * NI);
+
+    // DMA through a buffer resource (cdna_hip_programming.md T8 / T20): a wave's PPW pieces are all X rows or all W rows
+    // (BM / RPP % PPW == 0), so ONE descriptor per wave — base = the tile's first row of that operand, made from readfirstlane'd
+    // halves so that the compiler keeps it in SGPRs — a loop-invariant 32-bit byte offset per lane and piece, and the stage's
+    // advance (128 bytes per stage) as the instruction's scalar offset: no vector address arithmetic inside the loop.
+    static_assert((BM / RPP) % PPW == 0, "a wave's pieces must not straddle the operands");
+    const bool is_x = wave * PPW * RPP < BM;
+    const unsigned char* base = reinterpret_cast<const unsigned char*>(is_x ? a.X + (int64_t)m0 * a.ldx : a.W + (int64_t)n0 * a.ldw);
+    const uint64_t bv = reinterpret_cast<uint64_t>(base);
+    const uint64_t b_lo = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bv & 0xffffffffu));
+    const uint64_t b_hi = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bv >> 32));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(b_lo | (b_hi << 32)), 0, 0x7fffffff, 0x00020000);
+    unsigned off[PPW];
+#pragma unroll
+    for (int s = 0; s < PPW; ++s) {
+        const int r = RPP * (wave * PPW + s) + lane / CPR;
+        const int c = (lane % CPR) ^ sp_key16(r);
+        const int rr = is_x ? min(m0 + r, a.M - 1) - m0 : min(n0 + r - BM, a.N - 1) - n0;      // rows past the end: a valid row, never stored
+        off[s] = (unsigned)(rr * (int)(4 * (is_x ? a.ldx : a.ldw)) + 16 * c);
+    }
+    const int lds_w = __builtin_amdgcn_readfirstlane(wave * PPW * 1024);
+    auto issue = [&](int it, unsigned char* stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < PPW; ++s)
+            // ((int) cast: an argument of template-dependent type makes hipcc's HOST pass drop the kernel's instantiation without
+            // a diagnostic — the launch stub stays an undefined symbol of the library)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(stage + lds_w + s * 1024), 16,
+                                                     (int)off[s], (int)(it * ROWB), 0, 0);
+    };
+    const int ch = 16 * ((2 * l4) ^ sp_key16(l15));                        // hi chunk; lo = ch ^ 16
+    const int fx = (wm0 + l15) * ROWB, fw = (BM + wn0 + l15) * ROWB;
+    v4f acc[NI][MJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    v8h xh[NSLOT][MJ], xl[NSLOT][MJ], wh[NSLOT][NI], wl[NSLOT][NI];
+    auto fread_x = [&](const unsigned char* stage, int j, auto sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+        xh[S][j] = *reinterpret_cast<const v8h*>(stage + fx + j * 16 * ROWB + ch);
+        xl[S][j] = *reinterpret_cast<const v8h*>(stage + fx + j * 16 * ROWB + (ch ^ 16));
+    };
+    auto fread_w = [&](const unsigned char* stage, int i, auto sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+        wh[S][i] = *reinterpret_cast<const v8h*>(stage + fw + i * 16 * ROWB + ch);
+        wl[S][i] = *reinterpret_cast<const v8h*>(stage + fw + i * 16 * ROWB + (ch ^ 16));
+    };
+    auto fread = [&](const unsigned char* stage, auto sc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < MJ; ++j) fread_x(stage, j, sc);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) fread_w(stage, i, sc);
+    };
+    // the two small products first, then hi x hi (as in the 32-row kernels)
+    auto mfma3 = [&](int i, int j, auto sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[S][i], xh[S][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[S][i], xl[S][j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[S][i], xh[S][j], acc[i][j], 0, 0, 0);
+    };
+    auto mfmas = [&](auto sc) __attribute__((always_inline)) {
+        constexpr int S = decltype(sc)::value;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 0 ? wl[S][i] : wh[S][i], p == 1 ? xl[S][j] : xh[S][j],
+                                                                       acc[i][j], 0, 0, 0);
+    };
+
+    issue(0, smem);
+    if (T > 1) issue(1, smem + STAGE);
+    if (T > 1) __builtin_amdgcn_s_waitcnt(0x0f70 | PPW);              // vmcnt(PPW): stage 0 has landed
+    else __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                               // the prologue's scalar loads (see the 32-row kernel)
+    __builtin_amdgcn_sched_barrier(0);
+    fread(smem, SpIC<0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_sched_barrier(0);
+    long long t_clk = 0, t_real = 0;
+    if constexpr (DBG == 2) {
+        t_clk = (long long)__builtin_amdgcn_s_memtime();
+        t_real = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+    if constexpr (NSLOT == 2) {
+        // stage `it` is in registers (slot it & 1).  Barrier: every wave's share of stage it + 1 has landed and every wave is
+        // done reading stage it (its buffer takes the DMA of stage it + 2); the reads of stage it + 1 run under the MFMAs.
+        auto body = [&](int it, auto sc) __attribute__((always_inline)) {
+            constexpr int S = decltype(sc)::value;
+            unsigned char* cur = smem + (it & 1) * STAGE;
+            unsigned char* oth = smem + ((it + 1) & 1) * STAGE;
+            __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (DBG != 1 && DBG != 3 && it + 2 < T) issue(it + 2, cur);
+            if (DBG != 3 && it + 1 < T) fread(oth, SpIC<S ^ 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(sc);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int it = 0;
+        for (; it + 1 < T; it += 2) {
+            body(it, SpIC<0>{});
+            body(it + 1, SpIC<1>{});
+        }
+        if (it < T) body(it, SpIC<0>{});
+    } else {
+        for (int it = 0; it < T; ++it) {
+            unsigned char* cur = smem + (it & 1) * STAGE;
+            unsigned char* oth = smem + ((it + 1) & 1) * STAGE;
+            const bool more = DBG != 3 && it + 1 < T;
+#pragma unroll
+            for (int j = 0; j < MJ / 2; ++j)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) mfma3(i, j, SpIC<0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0070);          // vmcnt(0) lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (DBG != 1 && DBG != 3 && it + 2 < T) issue(it + 2, cur);
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < MJ / 2; ++j) fread_x(oth, j, SpIC<0>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = MJ / 2; j < MJ - 1; ++j) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) mfma3(i, j, SpIC<0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) fread_x(oth, j, SpIC<0>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                mfma3(i, MJ - 1, SpIC<0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) fread_w(oth, i, SpIC<0>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) fread_x(oth, MJ - 1, SpIC<0>{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if constexpr (DBG == 2) {
+        const long long e_clk = (long long)__builtin_amdgcn_s_memtime(), e_real = (long long)__builtin_amdgcn_s_memrealtime();
+        if (a.stamps != nullptr && tid == 0) {
+            long long* st = a.stamps + 4 * (int64_t)blockIdx.x;
+            st[0] = t_clk; st[1] = e_clk; st[2] = t_real; st[3] = e_real;
+        }
+    }
+    sp_finish16<MJ, NI, WM, WN>(a, m0, n0, acc);
 }
 
 // ---- fp32 rows -> planes ------------------------------------------------------------------------------------------------------
@@ -818,7 +1101,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 struct SpCfg { int bm, bn; };
-static const SpCfg kSpCfgs[] = {{128, 128}, {128, 128}, {64, 64}, {160, 128}, {256, 256}, {128, 128}, {160, 128}};
+static const SpCfg kSpCfgs[] = {{128, 128}, {128, 128}, {64, 64}, {160, 128}, {256, 256}, {128, 128}, {160, 128}, {128, 128}, {256, 256}};
+inline long long* g_sp16_stamps = nullptr;      // set by emcid_debug_linear_sp16_stamps
 
 }  // namespace emcid
 
@@ -881,6 +1165,14 @@ int emcid_gram_accumulate_sp16_f32(const float* X, int64_t t, int64_t d, int64_t
     return EMCID_OK;
 }
 
+/* Diagnostic: until called again with NULL, the LDS-DMA projection launches (cfg 64 / 128 / 256 / 320) run their stamped build:
+ * per workgroup {shader clock at loop start, at loop end, 100 MHz clock at loop start, at loop end} at stamps_dev[4 * blockIdx.x]
+ * (in-kernel clock = delta s_memtime / delta s_memrealtime x 100 MHz, MI355X_MICROARCH.md DVFS item 6). */
+int emcid_debug_linear_sp16_stamps(long long* stamps_dev) {
+    g_sp16_stamps = stamps_dev;
+    return EMCID_OK;
+}
+
 int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale, const void* Wp, int64_t ldw,
                           const float* w_inv_scale, const float* bias, const float* residual, int64_t ldr, float* Y, int64_t ldy,
                           void* Yp, int64_t ldp, const float* y_scale, int64_t M, int64_t N, int64_t K, int act, int cfg,
@@ -889,7 +1181,7 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
     EMCID_CHECK_ARG(K % SPK == 0 && ldx % 4 == 0 && ldw % 4 == 0 && aligned16(Xp) && aligned16(Wp));
     EMCID_CHECK_ARG(M < (1 << 24) && N < (1 << 24) && K < (1 << 24) && (residual == nullptr || ldr >= N) && (Y == nullptr || ldy >= N));
     EMCID_CHECK_ARG(Yp == nullptr || (N % 8 == 0 && ldp >= N && ldp % 4 == 0 && aligned16(Yp)));
-    EMCID_CHECK_ARG(act >= SP_ACT_NONE && act <= SP_ACT_GELU_ERF && cfg >= -1 && cfg < 256);
+    EMCID_CHECK_ARG(act >= SP_ACT_NONE && act <= SP_ACT_GELU_ERF && cfg >= -1 && cfg < 512);
     // (A 256 x 256 tile on eight waves — 128 x 64 per wave, the vendor library's choice for the q | k | v shape: 225 tiles — needs
     // 128 accumulator + 48 fragment + 32 staging registers plus addresses: hipcc spills at the 256 two waves per SIMD allow, 423 us on
     // the qkv shape; removed.)
@@ -899,7 +1191,8 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
     // bit 6: the LDS-DMA kernel (256 x 256 on eight waves)
     const int dbg = cfg < 0 ? 0 : (cfg >> 4) & 3;
     int tile_sel = cfg < 0 ? -1 : (cfg >> 6) ? 3 + (cfg >> 6) : (cfg & 3);
-    EMCID_CHECK_ARG(tile_sel <= 6);      // cfg 64: LDS-DMA 256 x 256 on eight waves, 128: 128 x 128 on four, 192: 160 x 128 with the K split
+    EMCID_CHECK_ARG(tile_sel <= 8);      // cfg 64: LDS-DMA 256 x 256 on eight waves, 128: 128 x 128 on four, 192: 160 x 128 with the K split,
+                                         // 256 / 320: the 16x16x32 forms of 128 x 128 on four waves / 256 x 256 on eight
     int pf = cfg < 0 ? 2 : ((cfg >> 2) & 3) + 1;
     EMCID_CHECK_ARG(pf >= 1 && pf <= 2);
     if (tile_sel < 0) {
@@ -922,6 +1215,7 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
         }
     }
     if ((tile_sel == 3 || tile_sel == 6) && K % 64 != 0) tile_sel = 0;
+    if ((tile_sel == 7 || tile_sel == 8) && (ldx >= (1 << 20) || ldw >= (1 << 20))) tile_sel = 0;      // 32-bit buffer offsets
     const int bm = kSpCfgs[tile_sel].bm, bn = kSpCfgs[tile_sel].bn;
     const int tiles_m = (int)((M + bm - 1) / bm), tiles_n = (int)((N + bn - 1) / bn);
     const int tiles = tiles_m * tiles_n;
@@ -930,7 +1224,7 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
     static const int rb_env = [] { const char* e = getenv("EMCID_SP16_RB"); return e ? atoi(e) : 4; }();
     const int rb = rb_env >= 1 ? rb_env : 1;
     const SpArgs a{(const uint32_t*)Xp, ldx, x_inv_scale, (const uint32_t*)Wp, ldw, w_inv_scale, bias, residual, ldr, Y, ldy,
-                   (uint32_t*)Yp, ldp, y_scale, (int)M, (int)N, (int)K, act, tiles_n, tiles, rb};
+                   (uint32_t*)Yp, ldp, y_scale, (int)M, (int)N, (int)K, act, tiles_n, tiles, rb, g_sp16_stamps};
     ScopedProf sp(KC_LINEAR, st);
 #define EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, PF_, WPE_, DBG_, KS_)                                                               \
     hipLaunchKernelGGL((linear_sp16_kernel<MJ_, NI_, WM_, WN_, PF_, WPE_, DBG_, KS_>), dim3((unsigned)(per * 8)),               \
@@ -940,8 +1234,19 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
         if (pf == 1) EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 1, WPE_, 0, KS_);      \
         else EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 2, WPE_, 0, KS_);              \
     } while (0)
-    if (tile_sel >= 4) {
-        if (tile_sel == 6) hipLaunchKernelGGL((linear_sp16_dma_kernel<5, 1, 1, 4, 2, 0>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
+#define EMCID_SP_DMA16(MJ_, NI_, WM_, WN_, NS_)                                                                                      \
+    do {                                                                                                                         \
+        if (dbg == 1) hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 1>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a);      \
+        else if (dbg == 3) hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 3>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a); \
+        else if (a.stamps) hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 2>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a); \
+        else hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 0>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a);               \
+    } while (0)
+    if (tile_sel == 7) EMCID_SP_DMA16(4, 4, 2, 2, 2);
+    else if (tile_sel == 8) EMCID_SP_DMA16(8, 4, 2, 4, 1);
+    else if (tile_sel >= 4) {
+        if (a.stamps && tile_sel == 4) hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 2, 2, 4, 1, 2>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
+        else if (a.stamps && tile_sel == 5) hipLaunchKernelGGL((linear_sp16_dma_kernel<2, 2, 2, 2, 1, 2>), dim3((unsigned)(per * 8)), dim3(256), 0, st, a);
+        else if (tile_sel == 6) hipLaunchKernelGGL((linear_sp16_dma_kernel<5, 1, 1, 4, 2, 0>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
         else if (tile_sel == 5) hipLaunchKernelGGL((linear_sp16_dma_kernel<2, 2, 2, 2, 1, 0>), dim3((unsigned)(per * 8)), dim3(256), 0, st, a);
         else if (dbg) hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 2, 2, 4, 1, 1>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
         else hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 2, 2, 4, 1, 0>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
@@ -964,6 +1269,7 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
     }
 #undef EMCID_SP_PF
 #undef EMCID_SP_LAUNCH
+#undef EMCID_SP_DMA16
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }

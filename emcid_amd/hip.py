@@ -19,7 +19,7 @@ _lib = None
 EXPORTS = [
     "emcid_abi_version", "emcid_last_error", "emcid_gram_accumulate_f32", "emcid_symmetrize_lower_f32",
     "emcid_gather_mean_f32", "emcid_edit_workspace_bytes", "emcid_edit_layer_f64", "emcid_assemble_spd_f64",
-    "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_dgemm_ex_f64", "emcid_dgemm_batched_f64", "emcid_streamk_workspace_bytes", "emcid_dgemm_streamk_f64", "emcid_debug_streamk_stamps", "emcid_debug_step_stamps", "emcid_axpy_f32",
+    "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_dgemm_ex_f64", "emcid_dgemm_batched_f64", "emcid_streamk_workspace_bytes", "emcid_dgemm_streamk_f64", "emcid_debug_streamk_stamps", "emcid_debug_step_stamps", "emcid_debug_linear_sp16_stamps", "emcid_axpy_f32",
     "emcid_profile_enable", "emcid_profile_collect", "emcid_attention_f32", "emcid_edit_layer_shard_f64",
     "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32", "emcid_add_layernorm_f32", "emcid_embed_layernorm_f32", "emcid_tree_attention_f32", "emcid_debug_leaf_stamps",
     "emcid_cov_factor_workspace_bytes", "emcid_factor_cov_f64", "emcid_cov_inverse_f64",
@@ -37,7 +37,7 @@ EXPORTS = [
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block", "linear"]
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 NB = 128      # Cholesky block (csrc/common.h)
 NPAD = 64     # concept padding of the f64 stacks (csrc/common.h)
 
@@ -101,6 +101,7 @@ def load():
         "emcid_dgemm_batched_f64": (i32, [i32, i32, i64, i64, i64, f64, p, i64, i64, p, i64, i64, f64, p, i64, i64, i64, p]),
         "emcid_streamk_workspace_bytes": (i64, [i32]),
         "emcid_debug_streamk_stamps": (i32, [p]),
+        "emcid_debug_linear_sp16_stamps": (i32, [p]),
         "emcid_debug_step_stamps": (i32, [p]),
         "emcid_dgemm_streamk_f64": (i32, [i32, i64, i64, i64, f64, p, i64, p, i64, p, i64, i32, i32, f64, p, i64, p]),
         "emcid_axpy_f32": (i32, [p, p, i64, p]),

@@ -50,11 +50,13 @@ VOWELS = "aeiou"
 SYLLABLES = [c + v for c in CONSONANTS for v in VOWELS]          # 90 consonant-vowel syllables
 
 
-def synthetic_vocab(words: Sequence[str] = TEMPLATE_WORDS, syllables: bool = False
+def synthetic_vocab(words: Sequence[str] = TEMPLATE_WORDS, syllables=False
                     ) -> Tuple[Dict[str, int], List[Tuple[str, str]]]:
     """Character vocabulary plus left-to-right merge chains for ``words``.  ``syllables=True`` (the benchmark
     vocabulary) also merges every consonant-vowel pair, so a name such as ``kazumi`` is 3 tokens — the token
-    count real CLIP BPE gives a typical artist name (the golden fixtures keep the plain vocabulary)."""
+    count real CLIP BPE gives a typical artist name (the golden fixtures keep the plain vocabulary).
+    ``syllables="wide"`` adds the 1 620 consonant-vowel-consonant syllables behind those (``kaz``, ``kaz</w>``): enough
+    distinct one-token words for name lists with the first-word statistics of real artist lists (``artist_names``)."""
     chars = list(string.ascii_lowercase + string.digits + ".,'-")
     vocab: Dict[str, int] = {}
     for c in chars:
@@ -79,9 +81,45 @@ def synthetic_vocab(words: Sequence[str] = TEMPLATE_WORDS, syllables: bool = Fal
                         merges.append((c, v + tail))
                     if c + v + tail not in vocab:
                         vocab[c + v + tail] = len(vocab)
+    if syllables == "wide":      # consonant-vowel-consonant, ranked behind every consonant-vowel merge
+        for c in CONSONANTS:
+            for v in VOWELS:
+                for c2 in CONSONANTS:
+                    for tail in ("", "</w>"):
+                        if (c + v, c2 + tail) not in merges:
+                            merges.append((c + v, c2 + tail))
+                        if c + v + c2 + tail not in vocab:
+                            vocab[c + v + c2 + tail] = len(vocab)
     vocab["<|startoftext|>"] = len(vocab)
     vocab["<|endoftext|>"] = len(vocab)
     return vocab, merges
+
+
+def artist_names(n: int, seed: int = 3) -> List[str]:
+    """n distinct two-word names with the shape of the reference's artist lists (data/artists/info/erased-1000artists-….txt:
+    1 000 names, 86 % of two words, 655 distinct first words, the commonest one 21 times, ~14 characters): a first word that is
+    ONE token of the ``syllables="wide"`` vocabulary (a consonant-vowel-consonant syllable, drawn from a Zipf-like pool: common
+    first names are single CLIP BPE tokens and are shared) and a last word of 2-4 tokens nobody shares — 3-5 tokens per name.
+    Synthetic: the reference's list itself is not shipped."""
+    rng = np.random.default_rng(seed)
+    cvc = [c + v + c2 for c in CONSONANTS for v in VOWELS for c2 in CONSONANTS]
+    pool = [cvc[i] for i in rng.permutation(len(cvc))]
+    # a quarter of the names take one of 60 common first words (p ~ 1 / (rank + 3)), the rest any of the others: on n = 1000
+    # ~650 distinct first words, the commonest ~21, 15, 12, 12, 11, 11 times (the reference's list: 655; 21, 12, 11, 11, 9, 9)
+    head = 1.0 / (np.arange(1, 61, dtype=np.float64) + 3.0)
+    p = np.concatenate([0.25 * head / head.sum(), np.full(len(pool) - 60, 0.75 / (len(pool) - 60))])
+    names, seen = [], set()
+    while len(names) < n:
+        first = pool[int(rng.choice(len(pool), p=p))]
+        k = int(rng.choice([2, 3, 4], p=[0.45, 0.4, 0.15]))
+        parts = []
+        for _ in range(k):
+            parts.append(SYLLABLES[int(rng.integers(0, len(SYLLABLES)))] if rng.random() < 0.7 else cvc[int(rng.integers(0, len(cvc)))])
+        nm = first + " " + "".join(parts)
+        if nm not in seen:
+            seen.add(nm)
+            names.append(nm)
+    return names
 
 
 def syllable_names(n: int, seed: int = 3, syllables_per_name: int = 3) -> List[str]:
@@ -159,7 +197,7 @@ class SyntheticPipe(SimpleNamespace):
 
 
 def build_pipe(kind: str = "toy", device: str = "cpu", sdxl: bool = False, seed: int = 0,
-               syllables: bool = False, projection_dim: Optional[int] = None) -> SyntheticPipe:
+               syllables=False, projection_dim: Optional[int] = None) -> SyntheticPipe:
     vocab, merges = synthetic_vocab(syllables=syllables)
     tok = build_tokenizer(vocab, merges)
     if not sdxl:
@@ -391,7 +429,8 @@ def make_requests(n: int, dest: str = "a realist artist", templates: Sequence[st
     draws another set of names: 729 000 possible, so two seeds share about one name in a thousand).
     ``ragged`` gives requests differing prompt counts (1..len(templates))."""
     reqs = []
-    sources = syllable_names(n, seed=name_seed) if names == "syllable" else [f"c{i:04d}" for i in range(n)]
+    sources = (syllable_names(n, seed=name_seed) if names == "syllable" else
+               artist_names(n, seed=name_seed) if names == "artist" else [f"c{i:04d}" for i in range(n)])
     for i in range(n):
         k = len(templates) if not ragged else 1 + (i % len(templates))
         reqs.append({

@@ -28,7 +28,7 @@ extern "C" {
 #define EMCID_ERR_HIP (-2)
 #define EMCID_ERR_WORKSPACE (-3)
 
-#define EMCID_ABI_VERSION 12
+#define EMCID_ABI_VERSION 13
 
 /* ABI version of the loaded library (host-only, no GPU needed). */
 int emcid_abi_version(void);
@@ -137,7 +137,8 @@ int emcid_split_rows_f16(const float* X, int64_t ldx, int64_t rows, int64_t K, v
  * image, no staging registers, no LDS stores) on 256 x 256 tiles / eight waves, 128 x 128 tiles / four waves (both: the same bits
  * as tile 0), or the 160 x 128 tile with the K split (the same bits as tile 3; K % 64 == 0).  cfg = -1 takes them where it would
  * take tile 0 at K <= 1536 (256 x 256 when those tiles fill their last round of 256 workgroups to 85 %, else 128 x 128) and
- * wherever it would take tile 3 (EMCID_SP16_DMA=1: not there; 0: never). */
+ * wherever it would take tile 3 (EMCID_SP16_DMA=1: not there; 0: never).  256 / 320 (ABI 13): the LDS-DMA structure on
+ * v_mfma_f32_16x16x32_f16 — 128 x 128 tiles on four waves / 256 x 256 on eight (another summation order: compare, do not equate). */
 int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale, const void* Wp, int64_t ldw,
                           const float* w_inv_scale, const float* bias, const float* residual, int64_t ldr, float* Y, int64_t ldy,
                           void* Yp, int64_t ldp, const float* y_scale, int64_t M, int64_t N, int64_t K, int act, int cfg,
@@ -148,6 +149,10 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
  * contraction runs over the tokens; scales per 32 768-token chunk) and three f16 MFMAs per k-step; the lower 128 x 128 tiles, the
  * token range of a tile cut into parts whose scaled results are added into G with fp32 atomics (G is an accumulator: sums in no
  * fixed order, like the exact-f32 kernel's multi-slab mode).  d % 4 == 0; workspace: emcid_gram_sp16_workspace_bytes(d). */
+/* Diagnostic (ABI 13): until called again with NULL, the LDS-DMA projection launches (cfg 64 / 128 / 256 / 320) run a stamped
+ * build: per workgroup {shader clock at the K loop's start, at its end, 100 MHz clock at its start, at its end} at
+ * stamps_dev[4 * blockIdx.x] — the in-kernel clock under load (scripts/mb_linear_sp16_r5.py). */
+int emcid_debug_linear_sp16_stamps(long long* stamps_dev);
 int64_t emcid_gram_sp16_workspace_bytes(int64_t d);
 int emcid_gram_accumulate_sp16_f32(const float* X, int64_t t, int64_t d, int64_t ldx, float* G, int64_t ldg, void* workspace,
                                    int64_t workspace_bytes, void* stream);

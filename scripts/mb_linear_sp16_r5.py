@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Round 5: the LDS-DMA forms of the split-fp16 projection kernel on v_mfma_f32_32x32x16_f16 (cfg 64 / 128) against the same
+structure on v_mfma_f32_16x16x32_f16 (cfg 256: 128 x 128 on four waves, both fragment sets in registers; cfg 320: 256 x 256 on
+eight waves, progressive fragment reload), interleaved rounds in one process (cdna_hip_programming.md rule 24), with
+ * the error of each form against the fp64 product,
+ * the timing-only builds (no DMA / MFMAs only) of each,
+ * the IN-KERNEL clock of each form: delta s_memtime / delta s_memrealtime x 100 MHz around the K loop of every workgroup after
+   >= 2 s of back-to-back launches on random data (MI355X_MICROARCH.md, DVFS give-back item 6), and from it the cycles per MFMA
+   the loop actually takes (loop cycles x SIMD share / MFMAs per wave).
+One line per shape and form."""
+import ctypes as C
+import os, sys, time
+from pathlib import Path
+import torch
+import torch.nn.functional as F
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from emcid_amd import hip
+
+dev = "cuda"
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 6292
+shapes = [(rows, 768, 2304, "qkv"), (rows, 768, 3072, "fc1"), (rows, 768, 768, "out"), (rows, 3072, 768, "fc2"),
+          (36335, 768, 2304, "qkv-36k"), (36335, 768, 3072, "fc1-36k"),
+          (rows, 1280, 3840, "qkv-bigG"), (rows, 1280, 5120, "fc1-bigG")]
+if os.environ.get("MB_SHAPES"):
+    shapes = [sh for sh in shapes if sh[3] in os.environ["MB_SHAPES"].split(",")]
+lib = hip.load()
+lib.emcid_debug_linear_sp16_stamps.restype = C.c_int
+lib.emcid_debug_linear_sp16_stamps.argtypes = [C.c_void_p]
+
+# (cfg, name, tile rows, tile cols, waves per workgroup, MFMAs per wave and 32-deep stage, nominal cycles per MFMA)
+FORMS = [(64, "32x32x16 256x256/8w", 256, 256, 8, 48, 32), (128, "32x32x16 128x128/4w", 128, 128, 4, 24, 32),
+         (256, "16x16x32 128x128/4w", 128, 128, 4, 48, 16), (320, "16x16x32 256x256/8w", 256, 256, 8, 96, 16)]
+
+
+def rounds(fns, n_rounds=7, n=20):
+    """interleaved timing: every form once per round; returns the per-form list of per-round means (us)"""
+    for f in fns:
+        for _ in range(3):
+            f()
+    torch.cuda.synchronize()
+    out = [[] for _ in fns]
+    for _ in range(n_rounds):
+        for i, f in enumerate(fns):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                f()
+            torch.cuda.synchronize()
+            out[i].append((time.perf_counter() - t0) / n * 1e6)
+    return out
+
+
+def med(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+for M, K, N, name in shapes:
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(M, K, device=dev, generator=g)
+    w = torch.randn(N, K, device=dev, generator=g) * 0.05
+    b = torch.randn(N, device=dev, generator=g)
+    y = torch.empty(M, N, device=dev)
+    fl = 2.0 * M * N * K
+    ref = F.linear(x.double(), w.double(), b.double())
+    top = ref.abs().max().item()
+    xs, ws = hip.split_rows(x), hip.split_rows(w)
+    yauto = hip.linear_sp(xs, ws, b)
+    print(f"== {name}: {M} x {K} -> {N}   ({fl * 3 / 1e9:.1f} GF of f16 MFMA work)", flush=True)
+    errs = {}
+    for cfg, cn, *_ in FORMS:
+        yy = hip.linear_sp(xs, ws, b, cfg=cfg)
+        e = (yy.double() - ref).abs()
+        errs[cfg] = (e.max().item() / top, e.pow(2).mean().sqrt().item() / top, (yy - yauto).abs().max().item() / top)
+    fns = [(lambda c=cfg: hip.linear_sp(xs, ws, b, out=y, cfg=c)) for cfg, *_ in FORMS]
+    fns.append(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=-1))
+    tt = rounds(fns)
+    t_auto = med(tt[-1])
+    print(f"   auto                      {t_auto:7.1f} us  {fl / t_auto / 1e6:6.1f} TF-equivalent", flush=True)
+    dbg = {}
+    if os.environ.get("MB_DBG", "1") == "1":
+        dfns, keys = [], []
+        for cfg, *_ in FORMS:
+            for d, dn in ((16, "no-dma"), (48, "mfma-only")):
+                if cfg in (64, 128) and d == 48:
+                    continue            # the 32-row DMA kernels have no MFMA-only build
+                dfns.append(lambda c=cfg + d: hip.linear_sp(xs, ws, b, out=y, cfg=c))
+                keys.append((cfg, dn))
+        for k, v in zip(keys, rounds(dfns, n_rounds=3)):
+            dbg[k] = med(v)
+    for (cfg, cn, bm, bn, waves, mfma_per_stage, nominal), t in zip(FORMS, tt):
+        tm = med(t)
+        # in-kernel clock: >= 2 s of back-to-back launches, then the stamps of the last one
+        tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
+        nwg = ((tiles + 7) // 8) * 8
+        stamps = torch.zeros(nwg * 4, dtype=torch.int64, device=dev)
+        lib.emcid_debug_linear_sp16_stamps(C.c_void_p(stamps.data_ptr()))
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 2.0:
+            for _ in range(50):
+                hip.linear_sp(xs, ws, b, out=y, cfg=cfg)
+            torch.cuda.synchronize()
+        stamps.zero_()
+        hip.linear_sp(xs, ws, b, out=y, cfg=cfg)
+        torch.cuda.synchronize()
+        lib.emcid_debug_linear_sp16_stamps(None)
+        st = stamps.view(-1, 4).cpu()
+        st = st[st[:, 3] > st[:, 2]]
+        clk = ((st[:, 1] - st[:, 0]).double() / (st[:, 3] - st[:, 2]).double() * 0.1)      # GHz
+        loop_cycles = (st[:, 1] - st[:, 0]).double().median().item()
+        stages = K // 32
+        # a SIMD carries waves / 4 waves of the workgroup (and as many of the other resident workgroup for the 4-wave tiles:
+        # two workgroups per compute unit); cycles per MFMA if this workgroup had the SIMD to itself:
+        per_mfma = loop_cycles / (stages * mfma_per_stage * (waves / 4))
+        e = errs[cfg]
+        extra = "".join(f" | {dn} {dbg[(cfg, dn)]:6.1f} us" for dn in ("no-dma", "mfma-only") if (cfg, dn) in dbg)
+        print(f"   {cn:24s} {tm:7.1f} us  {fl / tm / 1e6:6.1f} TF-eq = {3 * fl / tm / 1e9:6.3f} PF executed (min {min(t):6.1f}) | err max {e[0]:.1e} rms {e[1]:.1e}"
+              f" vs auto {e[2]:.1e} | clock {clk.median().item():.3f} GHz (p10 {clk.quantile(0.1).item():.3f}) loop {loop_cycles:8.0f} cyc ="
+              f" {per_mfma:5.1f} cyc/MFMA at the workgroup's SIMD share (nominal {nominal}){extra}", flush=True)

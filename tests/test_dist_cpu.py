@@ -59,7 +59,9 @@ def _worker(rank, world, port, n_total, tmp):
                 st2.load_state_dict({"mom2.count": 0, "mom2.mom2": np.zeros((1, 1), np.float32)})
             cur = st2.mom2
             cur.load_state_dict({"count": cur.count + b.shape[0], "mom2": (cur.mom2 + b.t() @ b).numpy()})
-        assert sum(t.shape[0] for t in seen) == 10
+        counts = [None] * world
+        dist.all_gather_object(counts, sum(t.shape[0] for t in seen))
+        assert sum(counts) == 20 and max(counts) - min(counts) <= 1          # every item once, shards even to within one
         dist.barrier()
         with np.load(cache) as z:
             assert int(z["mom2.count"]) == 20 and float(z["mom2.mom2"][0, 0]) == float((data ** 2).sum())
@@ -70,6 +72,11 @@ def _worker(rank, world, port, n_total, tmp):
 @pytest.mark.parametrize("n_total", [7, 8])
 def test_world2_gloo(tmp_path, n_total):
     mp.spawn(_worker, args=(2, _free_port(), n_total, str(tmp_path)), nprocs=2, join=True)
+
+
+def test_world8_gloo_uneven_shards(tmp_path):
+    """The skeleton at the node's size: 8 ranks, 1 003 concepts (shards of 126 / 125), caption shards, the reduce."""
+    mp.spawn(_worker, args=(8, _free_port(), 1003, str(tmp_path)), nprocs=8, join=True)
 
 
 def test_concept_shard_bounds_cover_all():
@@ -119,7 +126,8 @@ def _cols_worker(rank, world, port):
         from emcid_amd.emcid_main import _sdxl_split, _broadcast_, sdxl_rank_split
         from emcid_amd.edit_engine import ConceptShard
         from oracle import emcid_oracle as orc
-        N, d, h, lam, ew, left = 24, 512, 16, 40.0, 0.6, 2
+        torch.set_num_threads(1)
+        N, d, h, lam, ew, left = 24, (3072 if world == 8 else 512), 16, 40.0, 0.6, 2      # world 8: 24 column tiles over 8 ranks
         g = torch.Generator().manual_seed(5)                      # identical inputs on every rank (after the K all-gather)
         K = torch.randn(N, d, generator=g) * 0.3
         Zc = torch.randn(N, h, generator=g)
@@ -161,7 +169,7 @@ def _cols_worker(rank, world, port):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_column_sharded_solve_and_sdxl_groups_gloo(world):
     """The column-sharded layer solve (partial S and U summed over the ranks) equals the single-process closed form and
     leaves bit-identical weights on every rank; the SDXL TE1 / TE2 rank groups and their weight broadcasts."""
