@@ -24,6 +24,12 @@ def __getattr__(name):
     if name in ("edit_text_encoder_uce", "edit_model_uce"):
         from . import uce_train
         return getattr(uce_train, name)
+    if name in ("invalidate_weight_caches", "StaleWeightCacheError"):
+        # after rewriting an encoder weight through ``param.data`` (which torch's version counter does not see) call
+        # ``emcid_amd.invalidate_weight_caches(text_encoder)``; without it the content guard catches dense rewrites at the next
+        # edit call and that call is redone ("weights written behind the caches")
+        from . import clip_forward
+        return getattr(clip_forward, name)
     if name == "LAST_PATHS":
         # which forward / GEMM path this process's calls took (counters; clip_forward.LAST_PATHS): tests and bench.py assert
         # "own kernels" on it instead of inferring that from a profiler's kernel table

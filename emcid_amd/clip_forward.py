@@ -110,6 +110,59 @@ def _sp_ln_ok(ln) -> bool:
     return ln.normalized_shape[0] % 32 == 0 and ln.normalized_shape[0] <= 2048
 
 
+class StaleWeightCacheError(RuntimeError):
+    """An encoder weight was rewritten behind the caches' back (``param.data.copy_(...)``, a raw-pointer write): the planes
+    the forward just ran on were stale.  The edit engine restores the edited weights, drops the encoder's caches and raises
+    this; the public entry points of ``emcid_main`` catch it once and redo the call (single process)."""
+
+
+WEIGHT_GUARD = os.environ.get("EMCID_WEIGHT_GUARD", "1") != "0"
+GUARD_SLOTS = 6            # per layer: q, k, v (the stacked snapshot is cut from them), out, fc1, fc2
+_GUARD_SLOT = {"q": 0, "k": 1, "v": 2, "out": 3, "fc1": 4, "fc2": 5}
+
+
+class WeightGuard:
+    """Content guard of the weight-derived caches of ONE encoder (include/emcid_hip.h, "stale-cache guard"): a device table with
+    one {address, bytes, fingerprint} entry per cached weight, written when a cache entry is made (``store``), and a device flag
+    that ``check`` raises when a cached weight's BYTES no longer match — torch's version counter, which the caches are keyed by,
+    does not see ``param.data`` writes.  The check is one launch per edit call; the flag is read back with the call's final
+    synchronisation (``edit_engine.check_info``).  Host side: the address and size every slot was stored with, so that a slot
+    whose tensor has since been replaced is emptied instead of dereferenced."""
+
+    def __init__(self, n_layers: int, device):
+        self.n = n_layers * GUARD_SLOTS
+        self.table = torch.zeros(self.n, 4, dtype=torch.int64, device=device)
+        self.flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = [None] * self.n          # (data_ptr, bytes) per filled slot
+
+    def store(self, layer: int, name: str, w: torch.Tensor):
+        nbytes = w.numel() * w.element_size()
+        slot = layer * GUARD_SLOTS + _GUARD_SLOT[name]
+        if not (w.is_cuda and w.is_contiguous() and nbytes % 16 == 0 and w.data_ptr() % 16 == 0 and w.device == self.table.device):
+            if self.host[slot] is not None:
+                self.table[slot].zero_()
+                self.host[slot] = None
+            return
+        hip.fingerprint_store(w.detach(), self.table, slot)
+        self.host[slot] = (w.data_ptr(), nbytes)
+
+    def check(self, layers, hi: int):
+        """Zero the flag and launch the comparison for the filled slots of layers [0, hi).  A slot whose tensor is no longer the
+        one it was stored from (another address or size) is emptied first: its cache entry misses on identity anyway."""
+        self.flag.zero_()
+        for i in range(min(hi, len(layers))):
+            l = layers[i]
+            for name, m in (("q", l.q), ("k", l.k), ("v", l.v), ("out", l.out), ("fc1", l.fc1), ("fc2", l.fc2)):
+                slot = i * GUARD_SLOTS + _GUARD_SLOT[name]
+                h = self.host[slot]
+                if h is not None:
+                    w = m._parameters["weight"]
+                    if w.data_ptr() != h[0] or w.numel() * w.element_size() != h[1]:
+                        self.table[slot].zero_()
+                        self.host[slot] = None
+        hip.fingerprint_check(self.table, 0, min(hi, len(layers)) * GUARD_SLOTS, self.flag)
+
+
 @dataclass
 class ClipLayer:
     ln1: torch.nn.LayerNorm
@@ -127,6 +180,8 @@ class ClipLayer:
     qkv_b: Optional[torch.Tensor] = None
     act_code: Optional[int] = None         # hip.ACT_* when the activation can ride in the fc1 GEMM's epilogue
     splits: Optional[dict] = None          # name -> (weight id, version, data_ptr, hip.SplitRows): the weights as split-fp16 planes
+    guard: Optional[object] = None         # WeightGuard of the encoder + this layer's index: every cache entry made from a
+    index: int = -1                        # weight leaves the fingerprint of the weight's bytes there
 
     def fuse_qkv(self):
         """Snapshot q/k/v into one stacked weight (they are never edited by this path; call again if they change)."""
@@ -136,6 +191,9 @@ class ClipLayer:
                 self.qkv_b = torch.cat([self.q.bias, self.k.bias, self.v.bias], 0).contiguous()
         if self.splits is not None:
             self.splits.pop("qkv", None)
+        if self.guard is not None:
+            for name in ("q", "k", "v"):
+                self.guard.store(self.index, name, getattr(self, name).weight)
 
     def split_of(self, name: str) -> Optional["hip.SplitRows"]:
         """The weight ``name`` (qkv | q | k | v | out | fc1 | fc2) as a split-fp16 matrix, made once per weight version: the
@@ -155,6 +213,8 @@ class ClipLayer:
         with torch.no_grad():        # the (max row norm, max |bias|) pair only where a LayerNorm turns it into an output scale: fc1
             sp = hip.split_rows(w.detach(), b if b is not None and b.is_contiguous() else None, want_bound=name == "fc1")
         self.splits[name] = (sig, sp)
+        if self.guard is not None and name in ("out", "fc1", "fc2"):
+            self.guard.store(self.index, name, w)
         return sp
 
 
@@ -165,6 +225,7 @@ class ClipTextGraph:
     layers: List[ClipLayer]
     final_layer_norm: Optional[torch.nn.LayerNorm] = None
     native: Optional[object] = None        # NativeLayers: the layers as the C structs of the layer runner (csrc/clip_layers.hip)
+    guard: Optional[WeightGuard] = None    # content guard of everything cached from this encoder's weights
 
 
 NATIVE_RUNNER = os.environ.get("EMCID_NATIVE_LAYERS", "1") != "0"     # 0: one ctypes call per launch (the A/B path)
@@ -277,10 +338,15 @@ def discover(text_encoder, layer_module_tmp: str) -> ClipTextGraph:
             for m in (l.q, l.k, l.v, l.out, l.fc1, l.fc2):
                 if not isinstance(m, torch.nn.Linear):
                     raise UnsupportedEncoder("projection is not nn.Linear")
+        guard = None
+        if WEIGHT_GUARD and layers and layers[0].q.weight.is_cuda:
+            guard = WeightGuard(n_layers, layers[0].q.weight.device)
+            for i, l in enumerate(layers):
+                l.guard, l.index = guard, i
         for l in layers:
             if (l.q.bias is None) == (l.k.bias is None) == (l.v.bias is None) and l.q.weight.is_cuda:
                 l.fuse_qkv()
-        return ClipTextGraph(tok_e, pos_e, layers, getattr(root, "final_layer_norm", None))
+        return ClipTextGraph(tok_e, pos_e, layers, getattr(root, "final_layer_norm", None), guard=guard)
     except (AttributeError, LookupError, TypeError) as e:
         raise UnsupportedEncoder(str(e))
 

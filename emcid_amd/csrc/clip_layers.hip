@@ -35,6 +35,57 @@ __global__ __launch_bounds__(256) void gather_f32_kernel(const float* __restrict
     if (i < n) dst[i] = src[idx[i]];
 }
 
+// ---- stale-cache guard: a sampled fingerprint of a weight tensor ------------------------------------------------------------------
+// Everything the forward derives from a weight (the stacked q | k | v snapshot, the split-fp16 planes, the native layer structs)
+// is cached by tensor identity + torch's in-place version counter, which a write through `param.data` or a raw pointer does not
+// move.  So every cached weight also leaves a fingerprint of its BYTES in a per-encoder device table when the cache entry is made,
+// and every edit call recomputes the fingerprints of the entries it is about to trust (one small launch, no host
+// synchronisation): a mismatch raises a device flag that the call's one final read-back (edit_engine.check_info) sees.
+// Fingerprint: up to 4 096 16-byte vectors spaced evenly over the tensor (64 KB read of a 9.4 MB weight), each mixed with its
+// index, XOR-combined: any dense rewrite (a restore loop, a LoRA merge, an optimizer step, `.data.copy_`) changes it; a write
+// that touches only a few rows can slip between the samples.  Table entry = {pointer, bytes, fingerprint, 0} (4 x int64).
+__device__ __forceinline__ unsigned long long fp_mix(unsigned long long x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    return x;
+}
+
+__device__ __forceinline__ unsigned long long fingerprint_of(const unsigned char* data, long long bytes, unsigned long long* lds) {
+    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+    const long long nvec = bytes / 16, ns = nvec < 4096 ? nvec : 4096;
+    unsigned long long h = 0;
+    for (long long i = threadIdx.x; i < ns; i += 256) {
+        const long long v = ns == nvec ? i : i * nvec / ns;                 // i < 4 096, nvec < 2^40
+        const v2u64 x = *reinterpret_cast<const v2u64*>(data + 16 * v);
+        h ^= fp_mix(x[0] + 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * i + 1)) ^ fp_mix(x[1] + 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * i + 2));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)(h & 0xffffffffu), o, 64), hi = __shfl_xor((unsigned)(h >> 32), o, 64);
+        h ^= ((unsigned long long)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = h;
+    __syncthreads();
+    return lds[0] ^ lds[1] ^ lds[2] ^ lds[3];
+}
+
+__global__ __launch_bounds__(256) void fingerprint_store_kernel(const unsigned char* data, long long bytes, long long* table, long long slot) {
+    __shared__ unsigned long long lds[4];
+    const unsigned long long h = fingerprint_of(data, bytes, lds);
+    if (threadIdx.x == 0) {
+        long long* e = table + 4 * slot;
+        e[0] = (long long)reinterpret_cast<uintptr_t>(data); e[1] = bytes; e[2] = (long long)h; e[3] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void fingerprint_check_kernel(const long long* table, long long first_slot, int* flag) {
+    __shared__ unsigned long long lds[4];
+    const long long* e = table + 4 * (first_slot + blockIdx.x);
+    const long long bytes = e[1];
+    if (bytes <= 0) return;                                    // an empty slot (uniform: the whole workgroup leaves)
+    const unsigned long long h = fingerprint_of(reinterpret_cast<const unsigned char*>((uintptr_t)e[0]), bytes, lds);
+    if (threadIdx.x == 0 && h != (unsigned long long)e[2]) atomicOr(flag, 1);
+}
+
 struct ClipWs {
     float* qkv;            // [rows, 3h]
     float* mid;            // [rows, h]
@@ -78,6 +129,27 @@ inline bool clip_ws_carve(void* base, int64_t bytes, int64_t rows, int64_t h, in
 using namespace emcid;
 
 extern "C" {
+
+/* include/emcid_hip.h, "stale-cache guard".  Stores {data, bytes, fingerprint} of a weight's bytes in slot `slot` of the table. */
+int emcid_fingerprint_store(const void* data, int64_t bytes, void* table, int64_t table_slots, int64_t slot, void* stream) {
+    EMCID_CHECK_ARG(data && table && bytes > 0 && bytes % 16 == 0 && aligned16(data) && slot >= 0 && slot < table_slots);
+    hipLaunchKernelGGL(fingerprint_store_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)data,
+                       (long long)bytes, (long long*)table, (long long)slot);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
+
+/* Recomputes the fingerprints of slots [first_slot, first_slot + n_slots) (empty slots skipped) and ORs 1 into *flag where the
+ * bytes no longer match.  Every non-empty slot in the range must still point at live memory of that size: the caller checks
+ * tensor identity and address on the host first (clip_forward.NativeLayers / discover_cached). */
+int emcid_fingerprint_check(const void* table, int64_t table_slots, int64_t first_slot, int64_t n_slots, int* flag, void* stream) {
+    EMCID_CHECK_ARG(table && flag && first_slot >= 0 && n_slots >= 0 && first_slot + n_slots <= table_slots && n_slots < (1 << 20));
+    if (n_slots == 0) return EMCID_OK;
+    hipLaunchKernelGGL(fingerprint_check_kernel, dim3((unsigned)n_slots), dim3(256), 0, (hipStream_t)stream, (const long long*)table,
+                       (long long)first_slot, flag);
+    EMCID_CHECK_LAUNCH();
+    return EMCID_OK;
+}
 
 int64_t emcid_clip_workspace_bytes(int64_t rows, int64_t h, int64_t d) { return clip_ws_bytes(rows, h, d); }
 

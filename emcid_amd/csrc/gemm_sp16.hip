@@ -544,6 +544,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_
     if (tile >= a.tiles || (int)(blockIdx.x >> 3) >= per) return;
     int bm, bn;
     sp_tile_of(a, tile, bm, bn);
+    long long t_begin = 0;
+    if constexpr (DBG == 2) t_begin = (long long)__builtin_amdgcn_s_memrealtime();
     const int m0 = bm * BM, n0 = bn * BN, T = a.K / (SPK * KS);
     const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, wave = wave_all % NW, grp = wave_all / NW;
     const int l31 = lane & 31, l5 = lane >> 5;
@@ -661,12 +663,15 @@ __global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_
         if constexpr (DBG == 2) {        // diagnostic build: shader-clock and 100 MHz stamps around the K loop, one record per workgroup
             const long long e_clk = (long long)__builtin_amdgcn_s_memtime(), e_real = (long long)__builtin_amdgcn_s_memrealtime();
             if (a.stamps != nullptr && tid == 0) {
-                long long* st = a.stamps + 4 * (int64_t)blockIdx.x;
-                st[0] = t_clk; st[1] = e_clk; st[2] = t_real; st[3] = e_real;
+                long long* st = a.stamps + 8 * (int64_t)blockIdx.x;
+                st[0] = t_clk; st[1] = e_clk; st[2] = t_real; st[3] = e_real; st[4] = t_begin;
             }
         }
     }
     sp_finish<MJ, NI, WM, WN, KS>(a, m0, n0, smem, acc);
+    if constexpr (DBG == 2) {
+        if (a.stamps != nullptr && tid == 0) a.stamps[8 * (int64_t)blockIdx.x + 5] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ---- the same LDS-DMA structure on v_mfma_f32_16x16x32_f16 ---------------------------------------------------------------------
@@ -687,9 +692,17 @@ __global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_
 __device__ __forceinline__ int sp_key16(int r) { return ((r >> 1) & 7) ^ ((((r >> 2) ^ (r >> 3)) & 1) << 1); }
 
 // Epilogue of the 16 x 16 blocks.  acc[i][j][e] = element (m, n): m = m0 + wm0 + 16 j + (l & 15), n = n0 + wn0 + 16 i + 4 (l >> 4) + e.
+// Interior tiles go THROUGH LDS: straight from the accumulators a store instruction would write 16 rows x 64 bytes (the 32-row
+// kernels: 32 rows x 32 bytes) — a row-per-lane store tail that is issue-bound (cdna_hip_programming.md T21; the K loop was
+// HALF of a launch's duration with it, profiles/r05_mb_linear_sp16_dbg.txt).  Each wave owns an 8-KiB LDS region and moves its
+// tile through it 32 rows at a time: scaled / biased / activated values in (16 rows x 16 bytes per ds_write_b128, the
+// 16-byte slot c of row r at c ^ (r & 15): conflict-free both ways), whole rows out — a wave-instruction then reads, adds the
+// residual to and stores 4 rows x 256 contiguous bytes (fp32) and 4 x 256 bytes of planes.  LDS operations of one wave execute
+// in order and nobody else touches the region, so one workgroup barrier (everybody is out of the stage buffers) is all.
 template <int MJ, int NI, int WM, int WN>
-__device__ __forceinline__ void sp_finish16(const SpArgs& a, int m0, int n0, v4f (&acc)[NI][MJ]) {
+__device__ __forceinline__ void sp_finish16(const SpArgs& a, int m0, int n0, unsigned char* smem, v4f (&acc)[NI][MJ]) {
     constexpr int BM = 16 * MJ * WM, BN = 16 * NI * WN;
+    static_assert(NI == 4 && MJ % 2 == 0, "the LDS pass moves 32 rows x 64 columns per wave and step");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int wm0 = (wave / WN) * (16 * MJ), wn0 = (wave % WN) * (16 * NI);
     const float* __restrict__ bias = a.bias;
@@ -702,55 +715,73 @@ __device__ __forceinline__ void sp_finish16(const SpArgs& a, int m0, int n0, v4f
     const bool vec_ok = (N & 3) == 0 && (Y == nullptr || ((ldy & 3) == 0 && sp_al16(Y))) &&
                         (res == nullptr || ((ldr & 3) == 0 && sp_al16(res))) && (bias == nullptr || sp_al16(bias)) && sp_al16(ws);
     const bool interior = m0 + BM <= M && n0 + BN <= N && vec_ok;
+    __syncthreads();                                   // uniform: every wave has left the stage buffers
     auto epilogue = [&](auto actfn) __attribute__((always_inline)) {
+        if (interior) {
+            unsigned char* region = smem + wave * 8192;
+            v4f w4[NI], b4[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int n = n0 + wn0 + 16 * i + 4 * l4;
+                w4[i] = *reinterpret_cast<const v4f*>(ws + n);
+                b4[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+                if (bias != nullptr) b4[i] = *reinterpret_cast<const v4f*>(bias + n);
+            }
+            const int ncol = n0 + wn0 + 4 * l15;       // this lane's four columns on the way OUT
+#pragma unroll
+            for (int c = 0; c < MJ / 2; ++c) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * c + jj;
+                    const float sx = a.xs[m0 + wm0 + 16 * j + l15];
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        v4f v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = actfn(acc[i][j][e] * (sx * w4[i][e]) + b4[i][e]);
+                        *reinterpret_cast<v4f*>(region + (16 * jj + l15) * 256 + 16 * ((4 * i + l4) ^ l15)) = v;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int row = 4 * t + l4, m = m0 + wm0 + 32 * c + row;
+                    v4f v = *reinterpret_cast<const v4f*>(region + row * 256 + 16 * (l15 ^ (row & 15)));
+                    if (res != nullptr) {
+                        const v4f r = *reinterpret_cast<const v4f*>(res + (int64_t)m * ldr + ncol);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += r[e];
+                    }
+                    if (Y != nullptr) *reinterpret_cast<v4f*>(Y + (int64_t)m * ldy + ncol) = v;
+                    if (P != nullptr) sp_store4(P + (int64_t)m * ldp, ncol, v[0], v[1], v[2], v[3], a.ps != nullptr ? a.ps[m] : 1.f);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
             const int m = m0 + wm0 + 16 * j + l15;
             const bool m_ok = m < M;
             const float sx = a.xs[min(m, M - 1)];
             const float sp = a.ps != nullptr ? a.ps[min(m, M - 1)] : 1.f;
-            if (interior) {
-                v4f rv[NI];
-                if (res != nullptr) {
 #pragma unroll
-                    for (int i = 0; i < NI; ++i) rv[i] = *reinterpret_cast<const v4f*>(res + (int64_t)m * ldr + n0 + wn0 + 16 * i + 4 * l4);
-                }
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int n = n0 + wn0 + 16 * i + 4 * l4;
-                    const v4f w4 = *reinterpret_cast<const v4f*>(ws + n);
-                    v4f b4 = {0.f, 0.f, 0.f, 0.f};
-                    if (bias != nullptr) b4 = *reinterpret_cast<const v4f*>(bias + n);
-                    v4f v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = actfn(acc[i][j][e] * (sx * w4[e]) + b4[e]);
-                        if (res != nullptr) v[e] += rv[i][e];
-                    }
-                    if (Y != nullptr) *reinterpret_cast<v4f*>(Y + (int64_t)m * ldy + n) = v;
-                    if (P != nullptr) sp_store4(P + (int64_t)m * ldp, n, v[0], v[1], v[2], v[3], sp);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int n = n0 + wn0 + 16 * i + 4 * l4 + e;
-                        if (m_ok && n < N) {
-                            float v = actfn(acc[i][j][e] * (sx * ws[n]) + (bias != nullptr ? bias[n] : 0.f));
-                            if (res != nullptr) v += res[(int64_t)m * ldr + n];
-                            if (Y != nullptr) Y[(int64_t)m * ldy + n] = v;
-                            if (P != nullptr) {
-                                const float t = v * sp;
-                                const _Float16 h = (_Float16)t, l = (_Float16)(t - (float)h);
-                                _Float16* dst = reinterpret_cast<_Float16*>(reinterpret_cast<unsigned char*>(P + (int64_t)m * ldp) +
-                                                                           (n >> 3) * 32) + (n & 7);
-                                dst[0] = h;
-                                dst[8] = l;
-                            }
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + wn0 + 16 * i + 4 * l4 + e;
+                    if (m_ok && n < N) {
+                        float v = actfn(acc[i][j][e] * (sx * ws[n]) + (bias != nullptr ? bias[n] : 0.f));
+                        if (res != nullptr) v += res[(int64_t)m * ldr + n];
+                        if (Y != nullptr) Y[(int64_t)m * ldy + n] = v;
+                        if (P != nullptr) {
+                            const float t = v * sp;
+                            const _Float16 h = (_Float16)t, l = (_Float16)(t - (float)h);
+                            _Float16* dst = reinterpret_cast<_Float16*>(reinterpret_cast<unsigned char*>(P + (int64_t)m * ldp) +
+                                                                       (n >> 3) * 32) + (n & 7);
+                            dst[0] = h;
+                            dst[8] = l;
                         }
                     }
-            }
+                }
         }
     };
     if (a.act == SP_ACT_QUICK_GELU) epilogue([](float x) { return x / (1.0f + __expf(-1.702f * x)); });
@@ -773,6 +804,8 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     if (tile >= a.tiles || (int)(blockIdx.x >> 3) >= per) return;
     int bm, bn;
     sp_tile_of(a, tile, bm, bn);
+    long long t_begin = 0;
+    if constexpr (DBG == 2) t_begin = (long long)__builtin_amdgcn_s_memrealtime();
     const int m0 = bm * BM, n0 = bn * BN, T = a.K / SPK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int wm0 = (wave / WN) * (16 * MJ), wn0 = (wave % WN) * (16 * NI);
@@ -932,11 +965,14 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     if constexpr (DBG == 2) {
         const long long e_clk = (long long)__builtin_amdgcn_s_memtime(), e_real = (long long)__builtin_amdgcn_s_memrealtime();
         if (a.stamps != nullptr && tid == 0) {
-            long long* st = a.stamps + 4 * (int64_t)blockIdx.x;
-            st[0] = t_clk; st[1] = e_clk; st[2] = t_real; st[3] = e_real;
+            long long* st = a.stamps + 8 * (int64_t)blockIdx.x;
+            st[0] = t_clk; st[1] = e_clk; st[2] = t_real; st[3] = e_real; st[4] = t_begin;
         }
     }
-    sp_finish16<MJ, NI, WM, WN>(a, m0, n0, acc);
+    sp_finish16<MJ, NI, WM, WN>(a, m0, n0, smem, acc);
+    if constexpr (DBG == 2) {
+        if (a.stamps != nullptr && tid == 0) a.stamps[8 * (int64_t)blockIdx.x + 5] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
 }
 
 // ---- fp32 rows -> planes ------------------------------------------------------------------------------------------------------
@@ -1166,8 +1202,9 @@ int emcid_gram_accumulate_sp16_f32(const float* X, int64_t t, int64_t d, int64_t
 }
 
 /* Diagnostic: until called again with NULL, the LDS-DMA projection launches (cfg 64 / 128 / 256 / 320) run their stamped build:
- * per workgroup {shader clock at loop start, at loop end, 100 MHz clock at loop start, at loop end} at stamps_dev[4 * blockIdx.x]
- * (in-kernel clock = delta s_memtime / delta s_memrealtime x 100 MHz, MI355X_MICROARCH.md DVFS item 6). */
+ * per workgroup {shader clock at loop start, at loop end, 100 MHz clock at loop start, at loop end, 100 MHz clock at kernel entry,
+ * at kernel exit, -, -} at stamps_dev[8 * blockIdx.x] (in-kernel clock = delta s_memtime / delta s_memrealtime x 100 MHz,
+ * MI355X_MICROARCH.md DVFS item 6; prologue / K loop / epilogue of every workgroup in 10-ns ticks). */
 int emcid_debug_linear_sp16_stamps(long long* stamps_dev) {
     g_sp16_stamps = stamps_dev;
     return EMCID_OK;

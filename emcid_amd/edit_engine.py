@@ -498,6 +498,11 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                                     f"(got {w.dtype} on {w.device})")
     backups = {l: w.detach().clone() for l, w in weights.items()}
     plan.backups = backups
+    guard = plan.graph.guard if plan.graph is not None else None
+    if guard is not None:
+        # the caches this pass runs on (stacked q | k | v, split planes, layer structs) against the BYTES of the live weights:
+        # one launch, read back by check_info with the solver's flags (clip_forward.WeightGuard)
+        guard.check(plan.graph.layers, plan.layers[-1] + 1)
     d, h = weights[plan.layers[0]].shape[1], weights[plan.layers[0]].shape[0]
     dev = weights[plan.layers[0]].device
     dual = _use_dual(plan, d)
@@ -718,6 +723,8 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                 if li != last:      # the layer's fc2 planes were re-split in place from the new weight: keep the cache entry
                     gl = plan.graph.layers[li]
                     gl.splits["fc2"] = ((id(gl.fc2.weight), gl.fc2.weight._version, gl.fc2.weight.data_ptr()), gl.splits["fc2"][1])
+                    if gl.guard is not None:
+                        gl.guard.store(gl.index, "fc2", gl.fc2.weight)
                 edits.append(LayerEdit(li, plan.weight_name(li), res["dW"], None, None, res["K"] if trace else None,
                                        res["Zc"] if trace else None))
                 clip_forward.LAST_PATHS["fused_edit_layers"] = clip_forward.LAST_PATHS.get("fused_edit_layers", 0) + 1
@@ -801,6 +808,14 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
 def solver_info(plan: EncoderEditPlan) -> int:
     """One host sync: 0, or 1 + the column of the first non-positive pivot any factorization of the last run met."""
     infos = [holder.info for holder in (plan.ws, plan.dual_ws, plan.cov_factors) if holder is not None]
+    guard = plan.graph.guard if getattr(plan, "graph", None) is not None else None
+    plan.stale_weights = False
+    if guard is not None:
+        if infos and infos[0].is_cuda and infos[0].device == guard.flag.device:
+            infos = infos + [guard.flag]          # the stale-cache flag rides in the same read-back
+        else:
+            plan.stale_weights = bool(int(guard.flag.item()))
+            guard = None
     if not infos:
         return 0
     if len(infos) == 1 or not infos[0].is_cuda:
@@ -812,6 +827,8 @@ def solver_info(plan: EncoderEditPlan) -> int:
             host[i:i + 1].copy_(t.reshape(-1)[:1], non_blocking=True)
         torch.cuda.current_stream(dev).synchronize()
         vals = [int(v) for v in host.tolist()]
+    if guard is not None:
+        plan.stale_weights = bool(vals.pop())
     return next((v for v in vals if v != 0), 0)
 
 
@@ -839,6 +856,19 @@ def check_info(plan: EncoderEditPlan, restore_on_failure: bool = True):
     retry — emcid_main — catch it and rerun with the pivoted-LU solver, the reference's own semantics)."""
     code = solver_info(plan)          # (a host synchronisation: nothing of this plan's run is still using its workspaces)
     _release_workspaces(plan)
+    if getattr(plan, "stale_weights", False):
+        # a weight was rewritten without its version counter moving: this pass ran on planes of the OLD bytes
+        if plan.backups is not None:
+            with torch.no_grad():
+                for l, w0 in plan.backups.items():
+                    get_parameter(plan.text_encoder, plan.weight_name(l)).copy_(w0)
+        clip_forward.invalidate_weight_caches(plan.text_encoder)
+        plan.factor_key, plan.graph = None, None
+        raise clip_forward.StaleWeightCacheError(
+            "an encoder weight was written in a way torch's version counter does not see (param.data.copy_/add_, a raw pointer) "
+            "after the forward's caches were made from it; the edited weights have been put back and the caches dropped — call "
+            "again (emcid_main's entry points do so by themselves), and bump the counter or call "
+            "emcid_amd.invalidate_weight_caches(text_encoder) after such writes")
     if code != 0 and plan.solver == "lu":
         if restore_on_failure and plan.backups is not None:
             with torch.no_grad():

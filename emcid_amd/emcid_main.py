@@ -20,6 +20,8 @@ per-request progress prints obey ``verbose``; a v* cache miss runs Stage 1 (comp
 pipeline carries a UNet and a VAE (SDXL: compute_z.compute_z_sdxl_text_encoders, both vectors in one optimisation), and raises
 otherwise.
 """
+import functools
+import logging
 import os
 from copy import deepcopy
 from pathlib import Path
@@ -28,7 +30,7 @@ from typing import Callable, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import edit_engine, hip, nethook
+from . import clip_forward, edit_engine, hip, nethook
 from .edit_engine import (ConceptShard, EncoderEditPlan, LayerEdit, check_info, phase, prepare_encoder_edit,
                           run_checked, run_encoder_edit)
 from .emcid_hparams import EMCIDHyperParams, EMCIDXLHyperParams
@@ -543,8 +545,29 @@ def _announce(requests, verbose):
             print(f"EMCID request sample: [{request['source']}] -> [{request['dest']}]")
 
 
+def _retry_if_stale(fn):
+    """The forward's weight-derived caches carry a content guard (clip_forward.WeightGuard): when an edit finds that a weight was
+    rewritten behind them (``param.data.copy_(...)`` between two calls), the engine puts the edited weights back, drops the caches
+    and raises ``StaleWeightCacheError`` — the call is redone once, from the live weights.  A multi-rank job raises instead: one
+    rank redoing its call alone would leave the others inside their collectives."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        try:
+            return fn(*args, **kwargs)
+        except clip_forward.StaleWeightCacheError as e:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                raise
+            logging.getLogger("emcid_amd").warning("%s: %s; redoing the call from the live weights", fn.__name__, e)
+            clip_forward.invalidate_weight_caches(None)
+            clip_forward.LAST_PATHS["stale_cache_retries"] = clip_forward.LAST_PATHS.get("stale_cache_retries", 0) + 1
+            return fn(*args, **kwargs)
+    return wrapper
+
+
 # ---- SD ------------------------------------------------------------------------------------------------
 
+@_retry_if_stale
 def execute_emcid_text_encoder(pipe, requests: List[Dict], hparams: EMCIDHyperParams, cache_name: Optional[str] = None,
                                mom2_weight: Optional[int] = None, edit_weight: Optional[float] = None,
                                verbose: bool = True, stat_dir=STATS_DIR, shard=None, stage1=None
@@ -562,6 +585,7 @@ def execute_emcid_text_encoder(pipe, requests: List[Dict], hparams: EMCIDHyperPa
     return _deltas_to_host(edits)
 
 
+@_retry_if_stale
 def apply_emcid_to_text_encoder(pipe, requests: List[Dict], hparams: EMCIDHyperParams, device: str,
                                 mom2_weight: Optional[int] = None, edit_weight: Optional[float] = None,
                                 return_orig_text_encoder=False, cache_name: Optional[str] = None,
@@ -583,6 +607,7 @@ def apply_emcid_to_text_encoder(pipe, requests: List[Dict], hparams: EMCIDHyperP
     return pipe, origin_text_encoder
 
 
+@_retry_if_stale
 def cal_insert_deltas(pipe, weights: Dict[str, torch.Tensor], hparams: EMCIDHyperParams, requests: List[Dict],
                       zs: torch.Tensor, verbose: bool = True, stat_dir=STATS_DIR, shard=None):
     """The Stage-2 layer loop for targets the caller already has (reference: :1969-2052, used by the debias driver):
@@ -827,6 +852,7 @@ def _sdxl_plans(pipe, requests, hparams, cache_name, stat_dir, stat_dir_2, verbo
     return p1, p2
 
 
+@_retry_if_stale
 def execute_emcid_sd_xl_text_encoders(pipe, requests: List[Dict], hparams: EMCIDXLHyperParams,
                                       cache_name: Optional[str] = None, mom2_weight: Optional[int] = None,
                                       mom2_weight_2: Optional[int] = None, edit_weight: Optional[float] = None,
@@ -842,6 +868,7 @@ def execute_emcid_sd_xl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
     return _deltas_to_host(e1), _deltas_to_host(e2)
 
 
+@_retry_if_stale
 def apply_emcid_to_sdxl_text_encoders(pipe, requests: List[Dict], hparams: EMCIDXLHyperParams, device: str,
                                       mom2_weight: Optional[int] = None, mom2_weight_2: Optional[int] = None,
                                       edit_weight: Optional[float] = None, return_orig_text_encoder=False,
@@ -903,9 +930,12 @@ def apply_emcid_to_sdxl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
         for e in edits:
             _axpy_weight_(nethook.get_parameter(pipe.text_encoder_2, e.weight_name), e.dW)
 
+    stale = None
     for plan, redo in ((p1, None), (p2, double_apply if SDXL_TE2_DOUBLE_APPLY else None)):
         try:
             check_info(plan)                       # restores the encoder's weights if a factorization failed
+        except clip_forward.StaleWeightCacheError as e:
+            stale = e                              # (this encoder's weights are back; the other one's follow below)
         except FloatingPointError:
             if os.environ.get("EMCID_LU_FALLBACK", "1") == "0":
                 raise
@@ -914,6 +944,12 @@ def apply_emcid_to_sdxl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
             check_info(plan)
             if redo is not None:
                 redo(again)
+    if stale is not None:      # one encoder ran on stale planes: put BOTH back (TE2 sits at W + 2 dW) and let the call be redone
+        with torch.no_grad():
+            for plan in (p1, p2):
+                for l, w0 in (plan.backups or {}).items():
+                    nethook.get_parameter(plan.text_encoder, plan.weight_name(l)).copy_(w0)
+        raise stale
     if verbose:
         print(f"New weights successfully inserted into {[e.weight_name for e in e1 + e2]}")
     return pipe, o1, o2

@@ -19,7 +19,7 @@ _lib = None
 EXPORTS = [
     "emcid_abi_version", "emcid_last_error", "emcid_gram_accumulate_f32", "emcid_symmetrize_lower_f32",
     "emcid_gather_mean_f32", "emcid_edit_workspace_bytes", "emcid_edit_layer_f64", "emcid_assemble_spd_f64",
-    "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_dgemm_ex_f64", "emcid_dgemm_batched_f64", "emcid_streamk_workspace_bytes", "emcid_dgemm_streamk_f64", "emcid_debug_streamk_stamps", "emcid_debug_step_stamps", "emcid_debug_linear_sp16_stamps", "emcid_axpy_f32",
+    "emcid_cholesky_f64", "emcid_cholesky_solve_f64", "emcid_delta_w_f64", "emcid_dgemm_f64", "emcid_dgemm_ex_f64", "emcid_dgemm_batched_f64", "emcid_streamk_workspace_bytes", "emcid_dgemm_streamk_f64", "emcid_debug_streamk_stamps", "emcid_debug_step_stamps", "emcid_debug_linear_sp16_stamps", "emcid_fingerprint_store", "emcid_fingerprint_check", "emcid_axpy_f32",
     "emcid_profile_enable", "emcid_profile_collect", "emcid_attention_f32", "emcid_edit_layer_shard_f64",
     "emcid_apply_update_f32", "emcid_inverse_workspace_doubles", "emcid_quick_gelu_f32", "emcid_add_layernorm_f32", "emcid_embed_layernorm_f32", "emcid_tree_attention_f32", "emcid_debug_leaf_stamps",
     "emcid_cov_factor_workspace_bytes", "emcid_factor_cov_f64", "emcid_cov_inverse_f64",
@@ -102,6 +102,8 @@ def load():
         "emcid_streamk_workspace_bytes": (i64, [i32]),
         "emcid_debug_streamk_stamps": (i32, [p]),
         "emcid_debug_linear_sp16_stamps": (i32, [p]),
+        "emcid_fingerprint_store": (i32, [p, i64, p, i64, i64, p]),
+        "emcid_fingerprint_check": (i32, [p, i64, i64, i64, p, p]),
         "emcid_debug_step_stamps": (i32, [p]),
         "emcid_dgemm_streamk_f64": (i32, [i32, i64, i64, i64, f64, p, i64, p, i64, p, i64, i32, i32, f64, p, i64, p]),
         "emcid_axpy_f32": (i32, [p, p, i64, p]),
@@ -409,6 +411,18 @@ def dgemm_batched(ta: int, tb: int, A, B, Cm, alpha=1.0, beta=0.0):
                                           _ptr(Cm, torch.float64), Cm.stride(1), Cm.stride(0), nb, _stream(Cm)),
            "emcid_dgemm_batched_f64")
     return Cm
+
+
+def fingerprint_store(t: torch.Tensor, table: torch.Tensor, slot: int):
+    """Stale-cache guard (include/emcid_hip.h): leave {address, bytes, fingerprint of the bytes} of ``t`` in ``table[slot]``."""
+    _check(load().emcid_fingerprint_store(_ptr(t), t.numel() * t.element_size(), _ptr(table, torch.int64, "table"), table.shape[0],
+                                          int(slot), _stream(t)), "emcid_fingerprint_store")
+
+
+def fingerprint_check(table: torch.Tensor, first_slot: int, n_slots: int, flag: torch.Tensor):
+    """Recompute the fingerprints of ``table[first_slot : first_slot + n_slots]`` (empty slots skipped); ``flag |= 1`` on a mismatch."""
+    _check(load().emcid_fingerprint_check(_ptr(table, torch.int64, "table"), table.shape[0], int(first_slot), int(n_slots),
+                                          _ptr(flag, torch.int32, "flag"), _stream(table)), "emcid_fingerprint_check")
 
 
 def axpy_(W: torch.Tensor, dW: torch.Tensor):

@@ -150,8 +150,9 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
  * token range of a tile cut into parts whose scaled results are added into G with fp32 atomics (G is an accumulator: sums in no
  * fixed order, like the exact-f32 kernel's multi-slab mode).  d % 4 == 0; workspace: emcid_gram_sp16_workspace_bytes(d). */
 /* Diagnostic (ABI 13): until called again with NULL, the LDS-DMA projection launches (cfg 64 / 128 / 256 / 320) run a stamped
- * build: per workgroup {shader clock at the K loop's start, at its end, 100 MHz clock at its start, at its end} at
- * stamps_dev[4 * blockIdx.x] — the in-kernel clock under load (scripts/mb_linear_sp16_r5.py). */
+ * build: per workgroup {shader clock at the K loop's start, at its end, 100 MHz clock at its start, at its end, 100 MHz clock at
+ * kernel entry, at kernel exit, -, -} at stamps_dev[8 * blockIdx.x] — the in-kernel clock under load and the split of a
+ * workgroup's life into prologue / K loop / epilogue (scripts/mb_linear_sp16_r5.py). */
 int emcid_debug_linear_sp16_stamps(long long* stamps_dev);
 int64_t emcid_gram_sp16_workspace_bytes(int64_t d);
 int emcid_gram_accumulate_sp16_f32(const float* X, int64_t t, int64_t d, int64_t ldx, float* G, int64_t ldg, void* workspace,
@@ -178,6 +179,17 @@ int emcid_tree_attention_sp16_supported(int64_t anc_ld, int64_t H, int64_t D);
 int emcid_tree_attention_sp16(const float* q, int64_t ldq, const float* k, const float* v, int64_t ld, const int* anc,
                               int64_t anc_ld, const int* depth, const int* rows, int64_t n_rows, int64_t H, int64_t D, float scale,
                               void* planes, int64_t ldp, float* inv_scale, void* stream);
+
+/* ---- stale-cache guard (ABI 13; csrc/clip_layers.hip) ------------------------------------------------------------------------------
+ * The forward's weight-derived caches (stacked q | k | v, split-fp16 planes, native layer structs) follow torch's in-place version
+ * counter, which a write through `param.data` or a raw pointer does not move.  emcid_fingerprint_store leaves {pointer, bytes,
+ * fingerprint} of a weight's BYTES (up to 4 096 evenly spaced 16-byte vectors, each mixed with its index) in slot `slot` of a
+ * device table of table_slots x 4 int64 when a cache entry is made; emcid_fingerprint_check recomputes the fingerprints of a
+ * slot range (empty slots skipped) and ORs 1 into *flag on a mismatch — read back with the call's one final synchronisation.
+ * bytes % 16 == 0.  Every non-empty slot of a checked range must still point at live memory (the host checks tensor identity
+ * and address first).  No reference counterpart: the reference reads every weight live in every forward. */
+int emcid_fingerprint_store(const void* data, int64_t bytes, void* table, int64_t table_slots, int64_t slot, void* stream);
+int emcid_fingerprint_check(const void* table, int64_t table_slots, int64_t first_slot, int64_t n_slots, int* flag, void* stream);
 
 /* ---- native layer runner of the trie forward (csrc/clip_layers.hip) ---------------------------------------------------------------
  * One C call issues all launches of a run of CLIP text-encoder layers on the split-fp16 projections (the forward the reference

@@ -93,7 +93,7 @@ for M, K, N, name in shapes:
         # in-kernel clock: >= 2 s of back-to-back launches, then the stamps of the last one
         tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
         nwg = ((tiles + 7) // 8) * 8
-        stamps = torch.zeros(nwg * 4, dtype=torch.int64, device=dev)
+        stamps = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
         lib.emcid_debug_linear_sp16_stamps(C.c_void_p(stamps.data_ptr()))
         t0 = time.perf_counter()
         while time.perf_counter() - t0 < 2.0:
@@ -104,8 +104,14 @@ for M, K, N, name in shapes:
         hip.linear_sp(xs, ws, b, out=y, cfg=cfg)
         torch.cuda.synchronize()
         lib.emcid_debug_linear_sp16_stamps(None)
-        st = stamps.view(-1, 4).cpu()
+        st = stamps.view(-1, 8).cpu()
         st = st[st[:, 3] > st[:, 2]]
+        # a workgroup's life in microseconds (100 MHz ticks): entry -> loop start, loop, loop end -> exit; and the launch's span
+        pro = ((st[:, 2] - st[:, 4]).double() * 0.01).median().item()
+        lp = ((st[:, 3] - st[:, 2]).double() * 0.01).median().item()
+        epi = ((st[:, 5] - st[:, 3]).double() * 0.01).median().item()
+        span = (st[:, 5].max() - st[:, 4].min()).item() * 0.01
+        last_start = (st[:, 4].max() - st[:, 4].min()).item() * 0.01
         clk = ((st[:, 1] - st[:, 0]).double() / (st[:, 3] - st[:, 2]).double() * 0.1)      # GHz
         loop_cycles = (st[:, 1] - st[:, 0]).double().median().item()
         stages = K // 32
@@ -116,4 +122,5 @@ for M, K, N, name in shapes:
         extra = "".join(f" | {dn} {dbg[(cfg, dn)]:6.1f} us" for dn in ("no-dma", "mfma-only") if (cfg, dn) in dbg)
         print(f"   {cn:24s} {tm:7.1f} us  {fl / tm / 1e6:6.1f} TF-eq = {3 * fl / tm / 1e9:6.3f} PF executed (min {min(t):6.1f}) | err max {e[0]:.1e} rms {e[1]:.1e}"
               f" vs auto {e[2]:.1e} | clock {clk.median().item():.3f} GHz (p10 {clk.quantile(0.1).item():.3f}) loop {loop_cycles:8.0f} cyc ="
-              f" {per_mfma:5.1f} cyc/MFMA at the workgroup's SIMD share (nominal {nominal}){extra}", flush=True)
+              f" {per_mfma:5.1f} cyc/MFMA at the workgroup's SIMD share (nominal {nominal}) | workgroup: prologue {pro:5.1f} + loop {lp:5.1f} + epilogue {epi:5.1f} us,"
+              f" launch span {span:6.1f} us, last workgroup starts at {last_start:5.1f}{extra}", flush=True)

@@ -425,6 +425,59 @@ def test_non_contiguous_layer_list_vs_oracle(tmp_path, monkeypatch, own_gemm):
                 get_parameter(gpu.text_encoder, n + ".weight").copy_(w0[n].to(DEV))
 
 
+def test_weights_rewritten_through_data_are_caught_and_the_call_redone(tmp_path, caplog):
+    """A restore loop in the `param.data.copy_(...)` idiom (diffusers / LoRA code, user scripts) does not move torch's version
+    counter, which the split-fp16 planes and native layer structs are keyed by.  The content guard (clip_forward.WeightGuard:
+    sampled fingerprints of the cached weights' bytes, checked by one launch per call, read back with the call's final sync)
+    notices, the engine puts the weights back and drops the caches, and the entry point redoes the call: the result equals the
+    oracle's on the weights as they ARE.  Also: an un-edited layer's fc1 rewritten the same way."""
+    import logging
+    import emcid_amd
+    from emcid_amd import clip_forward
+    reqs = syn.make_requests(16, names="syllable")
+    hp_d = syn.sd_hparams_dict()
+    names = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers"]]
+    fc1_name = hp_d["rewrite_module_tmp"].format(3).replace("fc2", "fc1")
+    cache = str(tmp_path / "cache") + "/"
+    syn.write_vstar_cache(cache, reqs, 768, seed=1, scale=0.5)
+    syn.write_stats_cache(tmp_path / "stats", names, 3072, hp_d["mom2_n_samples"], seed=2, t=6144)
+    gpu = syn.build_pipe("sd-v1.4", DEV, syllables=True)
+    cpu = syn.build_pipe("sd-v1.4", "cpu", syllables=True)
+    em.apply_emcid_to_text_encoder(gpu, reqs, EMCIDHyperParams(**hp_d), DEV, cache_name=cache, stats_dir=str(tmp_path / "stats"),
+                                   verbose=False)                      # caches made: planes of W0 (fc1 ...) and of W0 + dW (fc2)
+    # behind the caches' back: every edited fc2 and one early fc1 get new values through .data (version counters do not move)
+    g = torch.Generator().manual_seed(9)
+    new = {n: (orc.get_parameter(cpu.text_encoder, n + ".weight") + 0.01 * torch.randn(768, 3072, generator=g)).clone() for n in names}
+    new[fc1_name] = (orc.get_parameter(cpu.text_encoder, fc1_name + ".weight") * 1.05).clone()
+    with torch.no_grad():
+        for n, w in new.items():
+            p = get_parameter(gpu.text_encoder, n + ".weight")
+            v = p._version
+            p.data.copy_(w.to(DEV))
+            assert p._version == v
+            orc.get_parameter(cpu.text_encoder, n + ".weight").copy_(w)
+    orc.apply_emcid_to_text_encoder(cpu, reqs, copy.deepcopy(hp_d), cache_name=cache, stats_dir=str(tmp_path / "stats"))
+    before = clip_forward.LAST_PATHS.get("stale_cache_retries", 0)
+    with caplog.at_level(logging.WARNING, logger="emcid_amd"):
+        em.apply_emcid_to_text_encoder(gpu, reqs, EMCIDHyperParams(**hp_d), DEV, cache_name=cache,
+                                       stats_dir=str(tmp_path / "stats"), verbose=False)
+    assert clip_forward.LAST_PATHS.get("stale_cache_retries", 0) == before + 1
+    assert any("redoing the call" in r.getMessage() for r in caplog.records)
+    for n in names:
+        ref = orc.get_parameter(cpu.text_encoder, n + ".weight").double() - new[n].double()
+        got = get_parameter(gpu.text_encoder, n + ".weight").cpu().double() - new[n].double()
+        err = (got - ref).abs().max().item()
+        assert err < 1e-4 and err <= 1e-4 * ref.abs().max().item(), (n, err, ref.abs().max().item())
+    # the documented alternative: say so, and nothing has to be caught
+    with torch.no_grad():
+        for n in names:
+            get_parameter(gpu.text_encoder, n + ".weight").data.copy_(new[n].to(DEV))
+    emcid_amd.invalidate_weight_caches(gpu.text_encoder)
+    em.apply_emcid_to_text_encoder(gpu, reqs, EMCIDHyperParams(**hp_d), DEV, cache_name=cache, stats_dir=str(tmp_path / "stats"),
+                                   verbose=False)
+    assert clip_forward.LAST_PATHS.get("stale_cache_retries", 0) == before + 1
+
+
 def test_eleven_layer_edit_vs_oracle(tmp_path):
     """The shipped `ly-11` hparams edit layers 0..10 (L = 11): batched factorization of eleven lam*C' matrices,
     residual split over 11 layers — HIP path vs the oracle at SD-v1.4 dims."""
