@@ -133,34 +133,39 @@ class WeightGuard:
         self.n = n_layers * GUARD_SLOTS
         self.table = torch.zeros(self.n, 4, dtype=torch.int64, device=device)
         self.flag = torch.zeros(1, dtype=torch.int32, device=device)
-        self.host = [None] * self.n          # (data_ptr, bytes) per filled slot
+        self.host = [None] * self.n          # (data_ptr, bytes, version counter) of the tensor each filled slot was stored from
 
     def store(self, layer: int, name: str, w: torch.Tensor):
         nbytes = w.numel() * w.element_size()
         slot = layer * GUARD_SLOTS + _GUARD_SLOT[name]
         if not (w.is_cuda and w.is_contiguous() and nbytes % 16 == 0 and w.data_ptr() % 16 == 0 and w.device == self.table.device):
-            if self.host[slot] is not None:
-                self.table[slot].zero_()
-                self.host[slot] = None
+            self.host[slot] = None
             return
         hip.fingerprint_store(w.detach(), self.table, slot)
-        self.host[slot] = (w.data_ptr(), nbytes)
+        self.host[slot] = (w.data_ptr(), nbytes, w._version)
 
     def check(self, layers, hi: int):
-        """Zero the flag and launch the comparison for the filled slots of layers [0, hi).  A slot whose tensor is no longer the
-        one it was stored from (another address or size) is emptied first: its cache entry misses on identity anyway."""
+        """Zero the flag and launch the comparison for the slots of layers [0, hi) whose cache entries this call will TRUST: the
+        tensor a slot was stored from is still the live parameter, at the same address, with the same version counter.  Any other
+        slot is masked out — its cache entry misses on the counter (or identity) anyway and is rebuilt, with a fresh
+        fingerprint, before it is used; its table entry may point at memory that is no longer there and is never looked at."""
         self.flag.zero_()
+        n = min(hi, len(layers)) * GUARD_SLOTS
+        skip = []
         for i in range(min(hi, len(layers))):
             l = layers[i]
-            for name, m in (("q", l.q), ("k", l.k), ("v", l.v), ("out", l.out), ("fc1", l.fc1), ("fc2", l.fc2)):
-                slot = i * GUARD_SLOTS + _GUARD_SLOT[name]
+            for k, m in enumerate((l.q, l.k, l.v, l.out, l.fc1, l.fc2)):
+                slot = i * GUARD_SLOTS + k
                 h = self.host[slot]
-                if h is not None:
-                    w = m._parameters["weight"]
-                    if w.data_ptr() != h[0] or w.numel() * w.element_size() != h[1]:
-                        self.table[slot].zero_()
-                        self.host[slot] = None
-        hip.fingerprint_check(self.table, 0, min(hi, len(layers)) * GUARD_SLOTS, self.flag)
+                if h is None:
+                    skip.append(slot)
+                    continue
+                w = m._parameters["weight"]
+                if w.data_ptr() != h[0] or w.numel() * w.element_size() != h[1] or w._version != h[2]:
+                    skip.append(slot)
+        for first in range(0, n, 256):
+            cnt = min(256, n - first)
+            hip.fingerprint_check(self.table, first, cnt, self.flag, [s - first for s in skip if first <= s < first + cnt])
 
 
 @dataclass

@@ -77,11 +77,14 @@ __global__ __launch_bounds__(256) void fingerprint_store_kernel(const unsigned c
     }
 }
 
-__global__ __launch_bounds__(256) void fingerprint_check_kernel(const long long* table, long long first_slot, int* flag) {
+struct FpSkip { unsigned long long m[4]; };                   // bit b of word w: slot first_slot + 64 w + b is not to be looked at
+
+__global__ __launch_bounds__(256) void fingerprint_check_kernel(const long long* table, long long first_slot, FpSkip skip, int* flag) {
     __shared__ unsigned long long lds[4];
+    if ((skip.m[blockIdx.x >> 6] >> (blockIdx.x & 63)) & 1ull) return;      // (uniform: the whole workgroup leaves)
     const long long* e = table + 4 * (first_slot + blockIdx.x);
     const long long bytes = e[1];
-    if (bytes <= 0) return;                                    // an empty slot (uniform: the whole workgroup leaves)
+    if (bytes <= 0) return;                                    // an empty slot
     const unsigned long long h = fingerprint_of(reinterpret_cast<const unsigned char*>((uintptr_t)e[0]), bytes, lds);
     if (threadIdx.x == 0 && h != (unsigned long long)e[2]) atomicOr(flag, 1);
 }
@@ -139,14 +142,19 @@ int emcid_fingerprint_store(const void* data, int64_t bytes, void* table, int64_
     return EMCID_OK;
 }
 
-/* Recomputes the fingerprints of slots [first_slot, first_slot + n_slots) (empty slots skipped) and ORs 1 into *flag where the
- * bytes no longer match.  Every non-empty slot in the range must still point at live memory of that size: the caller checks
- * tensor identity and address on the host first (clip_forward.NativeLayers / discover_cached). */
-int emcid_fingerprint_check(const void* table, int64_t table_slots, int64_t first_slot, int64_t n_slots, int* flag, void* stream) {
-    EMCID_CHECK_ARG(table && flag && first_slot >= 0 && n_slots >= 0 && first_slot + n_slots <= table_slots && n_slots < (1 << 20));
+/* Recomputes the fingerprints of slots [first_slot, first_slot + n_slots) (n_slots <= 256; empty slots and the slots whose bit is
+ * set in skip_mask — 4 host uint64, may be NULL — are skipped) and ORs 1 into *flag where the bytes no longer match.  Every slot
+ * that is looked at must still point at live memory of that size: the caller compares tensor identity, address and version on the
+ * host first and masks what it will not trust anyway (clip_forward.WeightGuard). */
+int emcid_fingerprint_check(const void* table, int64_t table_slots, int64_t first_slot, int64_t n_slots, const uint64_t* skip_mask,
+                            int* flag, void* stream) {
+    EMCID_CHECK_ARG(table && flag && first_slot >= 0 && n_slots >= 0 && first_slot + n_slots <= table_slots && n_slots <= 256);
     if (n_slots == 0) return EMCID_OK;
+    FpSkip skip{};
+    if (skip_mask != nullptr)
+        for (int w = 0; w < 4; ++w) skip.m[w] = skip_mask[w];
     hipLaunchKernelGGL(fingerprint_check_kernel, dim3((unsigned)n_slots), dim3(256), 0, (hipStream_t)stream, (const long long*)table,
-                       (long long)first_slot, flag);
+                       (long long)first_slot, skip, flag);
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }

@@ -702,7 +702,8 @@ __device__ __forceinline__ int sp_key16(int r) { return ((r >> 1) & 7) ^ ((((r >
 template <int MJ, int NI, int WM, int WN>
 __device__ __forceinline__ void sp_finish16(const SpArgs& a, int m0, int n0, unsigned char* smem, v4f (&acc)[NI][MJ]) {
     constexpr int BM = 16 * MJ * WM, BN = 16 * NI * WN;
-    static_assert(NI == 4 && MJ % 2 == 0, "the LDS pass moves 32 rows x 64 columns per wave and step");
+    static_assert(NI == 4 || NI == 2, "the LDS pass moves 32 rows x 64 or 32 columns per wave and step");
+    constexpr int SLOTS = 4 * NI, ROWBYTES = 16 * SLOTS, RPI = 64 / SLOTS;      // 16-byte slots per row, rows per wave-instruction on the way out
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int wm0 = (wave / WN) * (16 * MJ), wn0 = (wave % WN) * (16 * NI);
     const float* __restrict__ bias = a.bias;
@@ -718,7 +719,7 @@ __device__ __forceinline__ void sp_finish16(const SpArgs& a, int m0, int n0, uns
     __syncthreads();                                   // uniform: every wave has left the stage buffers
     auto epilogue = [&](auto actfn) __attribute__((always_inline)) {
         if (interior) {
-            unsigned char* region = smem + wave * 8192;
+            unsigned char* region = smem + wave * (32 * ROWBYTES);
             v4f w4[NI], b4[NI];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -727,25 +728,30 @@ __device__ __forceinline__ void sp_finish16(const SpArgs& a, int m0, int n0, uns
                 b4[i] = (v4f){0.f, 0.f, 0.f, 0.f};
                 if (bias != nullptr) b4[i] = *reinterpret_cast<const v4f*>(bias + n);
             }
-            const int ncol = n0 + wn0 + 4 * l15;       // this lane's four columns on the way OUT
+            const int oslot = lane % SLOTS, orow = lane / SLOTS;      // on the way OUT: this lane's 16-byte slot and row inside a wave-instruction
+            const int ncol = n0 + wn0 + 4 * oslot;
 #pragma unroll
-            for (int c = 0; c < MJ / 2; ++c) {
+            for (int c = 0; c < (MJ + 1) / 2; ++c) {
+                constexpr int KEY = SLOTS - 1;
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     const int j = 2 * c + jj;
+                    if (j >= MJ) continue;
                     const float sx = a.xs[m0 + wm0 + 16 * j + l15];
 #pragma unroll
                     for (int i = 0; i < NI; ++i) {
                         v4f v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = actfn(acc[i][j][e] * (sx * w4[i][e]) + b4[i][e]);
-                        *reinterpret_cast<v4f*>(region + (16 * jj + l15) * 256 + 16 * ((4 * i + l4) ^ l15)) = v;
+                        *reinterpret_cast<v4f*>(region + (16 * jj + l15) * ROWBYTES + 16 * ((4 * i + l4) ^ (l15 & KEY))) = v;
                     }
                 }
+                const int rows = (2 * c + 1 < MJ) ? 32 : 16;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int row = 4 * t + l4, m = m0 + wm0 + 32 * c + row;
-                    v4f v = *reinterpret_cast<const v4f*>(region + row * 256 + 16 * (l15 ^ (row & 15)));
+                for (int t = 0; t < 32 / RPI; ++t) {
+                    if (t * RPI >= rows) continue;
+                    const int row = RPI * t + orow, m = m0 + wm0 + 32 * c + row;
+                    v4f v = *reinterpret_cast<const v4f*>(region + row * ROWBYTES + 16 * (oslot ^ (row & KEY)));
                     if (res != nullptr) {
                         const v4f r = *reinterpret_cast<const v4f*>(res + (int64_t)m * ldr + ncol);
 #pragma unroll
@@ -795,9 +801,9 @@ template <int MJ, int NI, int WM, int WN, int NSLOT, int DBG>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_sp16_dma16_kernel(SpArgs a) {
     constexpr int NWV = WM * WN, BM = 16 * MJ * WM, BN = 16 * NI * WN;
     constexpr int ROWB = 128, RPP = 8, CPR = 8;
-    constexpr int STAGE = (BM + BN) * ROWB, PIECES = STAGE / 1024, PPW = PIECES / NWV;
-    static_assert(PIECES % NWV == 0 && BM % RPP == 0 && BN % RPP == 0 && PPW < 16, "pieces per wave");
-    static_assert(NSLOT == 2 || MJ % 2 == 0, "progressive reload halves the m blocks");
+    constexpr int STAGE = (BM + BN) * ROWB;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "whole pieces per operand");
+    static_assert(2 * STAGE >= NWV * 2048 * NI, "the epilogue's LDS regions");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
     const int per = (a.tiles + 7) / 8;
     const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
@@ -810,33 +816,45 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int wm0 = (wave / WN) * (16 * MJ), wn0 = (wave % WN) * (16 * NI);
 
-    // DMA through a buffer resource (cdna_hip_programming.md T8 / T20): a wave's PPW pieces are all X rows or all W rows
-    // (BM / RPP % PPW == 0), so ONE descriptor per wave — base = the tile's first row of that operand, made from readfirstlane'd
-    // halves so that the compiler keeps it in SGPRs — a loop-invariant 32-bit byte offset per lane and piece, and the stage's
-    // advance (128 bytes per stage) as the instruction's scalar offset: no vector address arithmetic inside the loop.
-    static_assert((BM / RPP) % PPW == 0, "a wave's pieces must not straddle the operands");
-    const bool is_x = wave * PPW * RPP < BM;
-    const unsigned char* base = reinterpret_cast<const unsigned char*>(is_x ? a.X + (int64_t)m0 * a.ldx : a.W + (int64_t)n0 * a.ldw);
-    const uint64_t bv = reinterpret_cast<uint64_t>(base);
-    const uint64_t b_lo = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bv & 0xffffffffu));
-    const uint64_t b_hi = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bv >> 32));
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(b_lo | (b_hi << 32)), 0, 0x7fffffff, 0x00020000);
-    unsigned off[PPW];
+    // DMA through buffer resources (cdna_hip_programming.md T8 / T20): one descriptor per operand — base = the tile's first row,
+    // made from readfirstlane'd halves so that the compiler keeps it in SGPRs — a loop-invariant 32-bit byte offset per lane and
+    // piece, and the stage's advance (128 bytes per stage) as the instruction's scalar offset: no vector address arithmetic inside
+    // the loop.  Wave w stages the X pieces w, w + NWV, ... and the W pieces w, w + NWV, ... of the image (X rows first); a
+    // tile whose piece count is no multiple of the wave count leaves the last slot of some waves empty (a wave-uniform test).
+    auto make_rsrc = [](const void* ptr) __attribute__((always_inline)) {
+        const uint64_t v = reinterpret_cast<uint64_t>(ptr);
+        const uint64_t lo = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffu));
+        const uint64_t hi = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(lo | (hi << 32)), 0, 0x7fffffff, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(a.X + (int64_t)m0 * a.ldx);
+    const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.W + (int64_t)n0 * a.ldw);
+    constexpr int NPX = BM / RPP, NPW = BN / RPP, PXW = (NPX + NWV - 1) / NWV, PWW = (NPW + NWV - 1) / NWV;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned off_x[PXW], off_w[PWW];
 #pragma unroll
-    for (int s = 0; s < PPW; ++s) {
-        const int r = RPP * (wave * PPW + s) + lane / CPR;
-        const int c = (lane % CPR) ^ sp_key16(r);
-        const int rr = is_x ? min(m0 + r, a.M - 1) - m0 : min(n0 + r - BM, a.N - 1) - n0;      // rows past the end: a valid row, never stored
-        off[s] = (unsigned)(rr * (int)(4 * (is_x ? a.ldx : a.ldw)) + 16 * c);
+    for (int s = 0; s < PXW; ++s) {
+        const int r = RPP * min(wave + NWV * s, NPX - 1) + lane / CPR;
+        off_x[s] = (unsigned)((min(m0 + r, a.M - 1) - m0) * (int)(4 * a.ldx) + 16 * ((lane % CPR) ^ sp_key16(r)));      // rows past the end: a valid row, never stored
     }
-    const int lds_w = __builtin_amdgcn_readfirstlane(wave * PPW * 1024);
-    auto issue = [&](int it, unsigned char* stage) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < PPW; ++s)
-            // ((int) cast: an argument of template-dependent type makes hipcc's HOST pass drop the kernel's instantiation without
-            // a diagnostic — the launch stub stays an undefined symbol of the library)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(stage + lds_w + s * 1024), 16,
-                                                     (int)off[s], (int)(it * ROWB), 0, 0);
+    for (int s = 0; s < PWW; ++s) {
+        const int r = RPP * min(wave + NWV * s, NPW - 1) + lane / CPR;
+        off_w[s] = (unsigned)((min(n0 + r, a.N - 1) - n0) * (int)(4 * a.ldw) + 16 * ((lane % CPR) ^ sp_key16(r)));
+    }
+    auto issue = [&](int it, unsigned char* stage) __attribute__((always_inline)) {
+        // ((int) casts: an argument of template-dependent type makes hipcc's HOST pass drop the kernel's instantiation without a
+        // diagnostic — the launch stub stays an undefined symbol of the library)
+#pragma unroll
+        for (int s = 0; s < PXW; ++s)
+            if (NPX % NWV == 0 || s + 1 < PXW || wave_u + NWV * s < NPX)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(stage + (wave_u + NWV * s) * 1024), 16,
+                                                         (int)off_x[s], (int)(it * ROWB), 0, 0);
+#pragma unroll
+        for (int s = 0; s < PWW; ++s)
+            if (NPW % NWV == 0 || s + 1 < PWW || wave_u + NWV * s < NPW)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(stage + (NPX + wave_u + NWV * s) * 1024), 16,
+                                                         (int)off_w[s], (int)(it * ROWB), 0, 0);
     };
     const int ch = 16 * ((2 * l4) ^ sp_key16(l15));                        // hi chunk; lo = ch ^ 16
     const int fx = (wm0 + l15) * ROWB, fw = (BM + wn0 + l15) * ROWB;
@@ -885,8 +903,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
 
     issue(0, smem);
     if (T > 1) issue(1, smem + STAGE);
-    if (T > 1) __builtin_amdgcn_s_waitcnt(0x0f70 | PPW);              // vmcnt(PPW): stage 0 has landed
-    else __builtin_amdgcn_s_waitcnt(0x0f70);
+    __builtin_amdgcn_s_waitcnt(0x0f70);                               // vmcnt(0) (waves stage different numbers of pieces)
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xc07f);                               // the prologue's scalar loads (see the 32-row kernel)
@@ -1137,7 +1154,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 struct SpCfg { int bm, bn; };
-static const SpCfg kSpCfgs[] = {{128, 128}, {128, 128}, {64, 64}, {160, 128}, {256, 256}, {128, 128}, {160, 128}, {128, 128}, {256, 256}};
+static const SpCfg kSpCfgs[] = {{128, 128}, {128, 128}, {64, 64}, {160, 128}, {256, 256}, {128, 128}, {160, 128}, {128, 128}, {256, 256},
+                                {160, 128}, {80, 128}};
 inline long long* g_sp16_stamps = nullptr;      // set by emcid_debug_linear_sp16_stamps
 
 }  // namespace emcid
@@ -1228,8 +1246,9 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
     // bit 6: the LDS-DMA kernel (256 x 256 on eight waves)
     const int dbg = cfg < 0 ? 0 : (cfg >> 4) & 3;
     int tile_sel = cfg < 0 ? -1 : (cfg >> 6) ? 3 + (cfg >> 6) : (cfg & 3);
-    EMCID_CHECK_ARG(tile_sel <= 8);      // cfg 64: LDS-DMA 256 x 256 on eight waves, 128: 128 x 128 on four, 192: 160 x 128 with the K split,
-                                         // 256 / 320: the 16x16x32 forms of 128 x 128 on four waves / 256 x 256 on eight
+    EMCID_CHECK_ARG(tile_sel <= 10);     // cfg 64: LDS-DMA 256 x 256 on eight waves, 128: 128 x 128 on four, 192: 160 x 128 with the K split,
+                                         // 256 / 320 / 384 / 448: the 16x16x32 forms: 128 x 128 on four waves, 256 x 256 on eight,
+                                         // 160 x 128 on four, 80 x 128 on four (waves side by side: 80 x 32 each)
     int pf = cfg < 0 ? 2 : ((cfg >> 2) & 3) + 1;
     EMCID_CHECK_ARG(pf >= 1 && pf <= 2);
     if (tile_sel < 0) {
@@ -1246,13 +1265,18 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
         static const int dma_env = [] { const char* e = getenv("EMCID_SP16_DMA"); return e ? atoi(e) : 2; }();
         if (dma_env && tile_sel == 0 && K <= 1536 && ldx < (1 << 20) && ldw < (1 << 20)) {
             const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), rounds = (t256 + 255) / 256;
-            tile_sel = (t256 * 100 >= rounds * 256 * 85) ? 4 : 5;
+            // round 5 (profiles/r05_mb_linear_sp16_epi.txt): the same structure on v_mfma_f32_16x16x32_f16 with the epilogue through
+            // LDS — 128 x 128 on four waves (q | k | v at 6 292 rows 73.6 against 96.4 us, fc1 92.0 against 102.4); 256 x 256 on
+            // eight waves only where those tiles run for four rounds or more and fill the last one (36 335 rows: 364 against 398)
+            static const int mfma16_env = [] { const char* e = getenv("EMCID_SP16_MFMA16"); return e ? atoi(e) : 1; }();
+            if (mfma16_env) tile_sel = (rounds >= 4 && t256 * 100 >= rounds * 256 * 85) ? 8 : 7;
+            else tile_sel = (t256 * 100 >= rounds * 256 * 85) ? 4 : 5;
         } else if (dma_env >= 2 && tile_sel == 3 && ldx < (1 << 20) && ldw < (1 << 20)) {
             tile_sel = 6;       // the 160 x 128 tile with the K range split in the workgroup, staged by LDS-DMA: out 32 against 34 us, fc2 94 against 102
         }
     }
     if ((tile_sel == 3 || tile_sel == 6) && K % 64 != 0) tile_sel = 0;
-    if ((tile_sel == 7 || tile_sel == 8) && (ldx >= (1 << 20) || ldw >= (1 << 20))) tile_sel = 0;      // 32-bit buffer offsets
+    if (tile_sel >= 7 && (ldx >= (1 << 20) || ldw >= (1 << 20))) tile_sel = 0;      // 32-bit buffer offsets
     const int bm = kSpCfgs[tile_sel].bm, bn = kSpCfgs[tile_sel].bn;
     const int tiles_m = (int)((M + bm - 1) / bm), tiles_n = (int)((N + bn - 1) / bn);
     const int tiles = tiles_m * tiles_n;
@@ -1280,6 +1304,8 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
     } while (0)
     if (tile_sel == 7) EMCID_SP_DMA16(4, 4, 2, 2, 2);
     else if (tile_sel == 8) EMCID_SP_DMA16(8, 4, 2, 4, 1);
+    else if (tile_sel == 9) EMCID_SP_DMA16(5, 4, 2, 2, 1);      // (two fragment sets spill: 56 registers)
+    else if (tile_sel == 10) EMCID_SP_DMA16(5, 2, 1, 4, 2);
     else if (tile_sel >= 4) {
         if (a.stamps && tile_sel == 4) hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 2, 2, 4, 1, 2>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
         else if (a.stamps && tile_sel == 5) hipLaunchKernelGGL((linear_sp16_dma_kernel<2, 2, 2, 2, 1, 2>), dim3((unsigned)(per * 8)), dim3(256), 0, st, a);

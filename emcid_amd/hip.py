@@ -103,7 +103,7 @@ def load():
         "emcid_debug_streamk_stamps": (i32, [p]),
         "emcid_debug_linear_sp16_stamps": (i32, [p]),
         "emcid_fingerprint_store": (i32, [p, i64, p, i64, i64, p]),
-        "emcid_fingerprint_check": (i32, [p, i64, i64, i64, p, p]),
+        "emcid_fingerprint_check": (i32, [p, i64, i64, i64, p, p, p]),
         "emcid_debug_step_stamps": (i32, [p]),
         "emcid_dgemm_streamk_f64": (i32, [i32, i64, i64, i64, f64, p, i64, p, i64, p, i64, i32, i32, f64, p, i64, p]),
         "emcid_axpy_f32": (i32, [p, p, i64, p]),
@@ -419,9 +419,13 @@ def fingerprint_store(t: torch.Tensor, table: torch.Tensor, slot: int):
                                           int(slot), _stream(t)), "emcid_fingerprint_store")
 
 
-def fingerprint_check(table: torch.Tensor, first_slot: int, n_slots: int, flag: torch.Tensor):
-    """Recompute the fingerprints of ``table[first_slot : first_slot + n_slots]`` (empty slots skipped); ``flag |= 1`` on a mismatch."""
-    _check(load().emcid_fingerprint_check(_ptr(table, torch.int64, "table"), table.shape[0], int(first_slot), int(n_slots),
+def fingerprint_check(table: torch.Tensor, first_slot: int, n_slots: int, flag: torch.Tensor, skip=()):
+    """Recompute the fingerprints of ``table[first_slot : first_slot + n_slots]`` (empty slots and the slot offsets in ``skip``
+    are not looked at); ``flag |= 1`` on a mismatch."""
+    mask = (C.c_uint64 * 4)()
+    for k in skip:
+        mask[k >> 6] |= 1 << (k & 63)
+    _check(load().emcid_fingerprint_check(_ptr(table, torch.int64, "table"), table.shape[0], int(first_slot), int(n_slots), mask,
                                           _ptr(flag, torch.int32, "flag"), _stream(table)), "emcid_fingerprint_check")
 
 

@@ -185,11 +185,13 @@ int emcid_tree_attention_sp16(const float* q, int64_t ldq, const float* k, const
  * counter, which a write through `param.data` or a raw pointer does not move.  emcid_fingerprint_store leaves {pointer, bytes,
  * fingerprint} of a weight's BYTES (up to 4 096 evenly spaced 16-byte vectors, each mixed with its index) in slot `slot` of a
  * device table of table_slots x 4 int64 when a cache entry is made; emcid_fingerprint_check recomputes the fingerprints of a
- * slot range (empty slots skipped) and ORs 1 into *flag on a mismatch — read back with the call's one final synchronisation.
+ * slot range of at most 256 slots (empty slots and those whose bit is set in the 4 host words of skip_mask are skipped) and ORs
+ * 1 into *flag on a mismatch — read back with the call's one final synchronisation.
  * bytes % 16 == 0.  Every non-empty slot of a checked range must still point at live memory (the host checks tensor identity
  * and address first).  No reference counterpart: the reference reads every weight live in every forward. */
 int emcid_fingerprint_store(const void* data, int64_t bytes, void* table, int64_t table_slots, int64_t slot, void* stream);
-int emcid_fingerprint_check(const void* table, int64_t table_slots, int64_t first_slot, int64_t n_slots, int* flag, void* stream);
+int emcid_fingerprint_check(const void* table, int64_t table_slots, int64_t first_slot, int64_t n_slots, const uint64_t* skip_mask,
+                            int* flag, void* stream);
 
 /* ---- native layer runner of the trie forward (csrc/clip_layers.hip) ---------------------------------------------------------------
  * One C call issues all launches of a run of CLIP text-encoder layers on the split-fp16 projections (the forward the reference

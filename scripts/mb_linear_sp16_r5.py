@@ -19,7 +19,9 @@ from emcid_amd import hip
 dev = "cuda"
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 6292
 shapes = [(rows, 768, 2304, "qkv"), (rows, 768, 3072, "fc1"), (rows, 768, 768, "out"), (rows, 3072, 768, "fc2"),
-          (36335, 768, 2304, "qkv-36k"), (36335, 768, 3072, "fc1-36k"),
+          (36335, 768, 2304, "qkv-36k"), (36335, 768, 3072, "fc1-36k"), (36335, 768, 768, "out-36k"), (36335, 3072, 768, "fc2-36k"),
+          (10500, 768, 2304, "qkv-10k"), (10500, 768, 3072, "fc1-10k"), (10500, 768, 768, "out-10k"), (10500, 3072, 768, "fc2-10k"),
+          (rows, 5120, 1280, "fc2-bigG"), (rows, 1280, 1280, "out-bigG"),
           (rows, 1280, 3840, "qkv-bigG"), (rows, 1280, 5120, "fc1-bigG")]
 if os.environ.get("MB_SHAPES"):
     shapes = [sh for sh in shapes if sh[3] in os.environ["MB_SHAPES"].split(",")]
@@ -29,7 +31,10 @@ lib.emcid_debug_linear_sp16_stamps.argtypes = [C.c_void_p]
 
 # (cfg, name, tile rows, tile cols, waves per workgroup, MFMAs per wave and 32-deep stage, nominal cycles per MFMA)
 FORMS = [(64, "32x32x16 256x256/8w", 256, 256, 8, 48, 32), (128, "32x32x16 128x128/4w", 128, 128, 4, 24, 32),
-         (256, "16x16x32 128x128/4w", 128, 128, 4, 48, 16), (320, "16x16x32 256x256/8w", 256, 256, 8, 96, 16)]
+         (256, "16x16x32 128x128/4w", 128, 128, 4, 48, 16), (320, "16x16x32 256x256/8w", 256, 256, 8, 96, 16),
+         (384, "16x16x32 160x128/4w", 160, 128, 4, 60, 16), (448, "16x16x32 80x128/4w", 80, 128, 4, 30, 16)]
+if os.environ.get("MB_FORMS"):
+    FORMS = [f for f in FORMS if str(f[0]) in os.environ["MB_FORMS"].split(",")]
 
 
 def rounds(fns, n_rounds=7, n=20):
@@ -73,15 +78,20 @@ for M, K, N, name in shapes:
         e = (yy.double() - ref).abs()
         errs[cfg] = (e.max().item() / top, e.pow(2).mean().sqrt().item() / top, (yy - yauto).abs().max().item() / top)
     fns = [(lambda c=cfg: hip.linear_sp(xs, ws, b, out=y, cfg=c)) for cfg, *_ in FORMS]
+    fns.append(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=4))
+    fns.append(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=192))
     fns.append(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=-1))
     tt = rounds(fns)
     t_auto = med(tt[-1])
-    print(f"   auto                      {t_auto:7.1f} us  {fl / t_auto / 1e6:6.1f} TF-equivalent", flush=True)
+    print(f"   auto                      {t_auto:7.1f} us  {fl / t_auto / 1e6:6.1f} TF-equivalent | register-staged 128x128/pf2 {med(tt[-3]):7.1f} us | "
+          f"32x32x16 160x128 K-split (LDS-DMA) {med(tt[-2]):7.1f} us", flush=True)
     dbg = {}
     if os.environ.get("MB_DBG", "1") == "1":
         dfns, keys = [], []
         for cfg, *_ in FORMS:
             for d, dn in ((16, "no-dma"), (48, "mfma-only")):
+                if os.environ.get("MB_DBG_FORMS", "1") != "1":
+                    continue
                 if cfg in (64, 128) and d == 48:
                     continue            # the 32-row DMA kernels have no MFMA-only build
                 dfns.append(lambda c=cfg + d: hip.linear_sp(xs, ws, b, out=y, cfg=c))

@@ -738,7 +738,7 @@ def test_split_rows_keeps_22_bits_under_a_per_row_scale():
     assert (sp2.float() - wide[:, :128]).abs().max().item() <= wide.abs().max().item() * 2.0 ** -21
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 4, 1, 5, 2, 6, 3, 7, 64, 128, 192, 256, 320])
+@pytest.mark.parametrize("cfg", [-1, 0, 4, 1, 5, 2, 6, 3, 7, 64, 128, 192, 256, 320, 384, 448])
 @pytest.mark.parametrize("M,K,N", [(6400, 768, 2304), (6400, 3072, 768), (1000, 3072, 768), (640, 768, 3072), (300, 1280, 1280),
                                    (129, 96, 257), (37, 2048, 200), (256, 32, 32), (330, 192, 130)])
 def test_linear_sp16_vs_torch(M, K, N, cfg):
