@@ -797,8 +797,8 @@ __device__ __forceinline__ void sp_finish16(const SpArgs& a, int m0, int n0, uns
 
 // DBG (timing / diagnosis only): 1 = no DMA inside the loop (results wrong), 2 = shader-clock and 100 MHz stamps around the K
 // loop into a.stamps (results right), 3 = MFMAs only: no DMA and no fragment reads inside the loop (results wrong)
-template <int MJ, int NI, int WM, int WN, int NSLOT, int DBG>
-__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_sp16_dma16_kernel(SpArgs a) {
+template <int MJ, int NI, int WM, int WN, int NSLOT, int DBG, int WPE = 2>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void linear_sp16_dma16_kernel(SpArgs a) {
     constexpr int NWV = WM * WN, BM = 16 * MJ * WM, BN = 16 * NI * WN;
     constexpr int ROWB = 128, RPP = 8, CPR = 8;
     constexpr int STAGE = (BM + BN) * ROWB;
@@ -1155,7 +1155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 struct SpCfg { int bm, bn; };
 static const SpCfg kSpCfgs[] = {{128, 128}, {128, 128}, {64, 64}, {160, 128}, {256, 256}, {128, 128}, {160, 128}, {128, 128}, {256, 256},
-                                {160, 128}, {80, 128}};
+                                {160, 128}, {80, 128}, {64, 64}};
 inline long long* g_sp16_stamps = nullptr;      // set by emcid_debug_linear_sp16_stamps
 
 }  // namespace emcid
@@ -1236,7 +1236,7 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
     EMCID_CHECK_ARG(K % SPK == 0 && ldx % 4 == 0 && ldw % 4 == 0 && aligned16(Xp) && aligned16(Wp));
     EMCID_CHECK_ARG(M < (1 << 24) && N < (1 << 24) && K < (1 << 24) && (residual == nullptr || ldr >= N) && (Y == nullptr || ldy >= N));
     EMCID_CHECK_ARG(Yp == nullptr || (N % 8 == 0 && ldp >= N && ldp % 4 == 0 && aligned16(Yp)));
-    EMCID_CHECK_ARG(act >= SP_ACT_NONE && act <= SP_ACT_GELU_ERF && cfg >= -1 && cfg < 512);
+    EMCID_CHECK_ARG(act >= SP_ACT_NONE && act <= SP_ACT_GELU_ERF && cfg >= -1 && cfg < 1024);
     // (A 256 x 256 tile on eight waves — 128 x 64 per wave, the vendor library's choice for the q | k | v shape: 225 tiles — needs
     // 128 accumulator + 48 fragment + 32 staging registers plus addresses: hipcc spills at the 256 two waves per SIMD allow, 423 us on
     // the qkv shape; removed.)
@@ -1246,9 +1246,10 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
     // bit 6: the LDS-DMA kernel (256 x 256 on eight waves)
     const int dbg = cfg < 0 ? 0 : (cfg >> 4) & 3;
     int tile_sel = cfg < 0 ? -1 : (cfg >> 6) ? 3 + (cfg >> 6) : (cfg & 3);
-    EMCID_CHECK_ARG(tile_sel <= 10);     // cfg 64: LDS-DMA 256 x 256 on eight waves, 128: 128 x 128 on four, 192: 160 x 128 with the K split,
+    EMCID_CHECK_ARG(tile_sel <= 11);     // cfg 64: LDS-DMA 256 x 256 on eight waves, 128: 128 x 128 on four, 192: 160 x 128 with the K split,
                                          // 256 / 320 / 384 / 448: the 16x16x32 forms: 128 x 128 on four waves, 256 x 256 on eight,
-                                         // 160 x 128 on four, 80 x 128 on four (waves side by side: 80 x 32 each)
+                                         // 160 x 128 on four, 80 x 128 on four (waves side by side: 80 x 32 each); 512: 64 x 64 on four, four
+                                         // workgroups per compute unit
     int pf = cfg < 0 ? 2 : ((cfg >> 2) & 3) + 1;
     EMCID_CHECK_ARG(pf >= 1 && pf <= 2);
     if (tile_sel < 0) {
@@ -1263,16 +1264,28 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
         // to 85 % (q | k | v at 6 250 rows: 225 tiles, 92 against 102 us; bigG fc1: 500 tiles, 248 against 279), else 128 x 128 on
         // four waves, two workgroups per compute unit (fc1: 118 against 127 us; bigG q | k | v 207 against 214).  EMCID_SP16_DMA=0: off.
         static const int dma_env = [] { const char* e = getenv("EMCID_SP16_DMA"); return e ? atoi(e) : 2; }();
+        static const int mfma16_env = [] { const char* e = getenv("EMCID_SP16_MFMA16"); return e ? atoi(e) : 2; }();
         if (dma_env && tile_sel == 0 && K <= 1536 && ldx < (1 << 20) && ldw < (1 << 20)) {
             const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), rounds = (t256 + 255) / 256;
             // round 5 (profiles/r05_mb_linear_sp16_epi.txt): the same structure on v_mfma_f32_16x16x32_f16 with the epilogue through
             // LDS — 128 x 128 on four waves (q | k | v at 6 292 rows 73.6 against 96.4 us, fc1 92.0 against 102.4); 256 x 256 on
             // eight waves only where those tiles run for four rounds or more and fill the last one (36 335 rows: 364 against 398)
-            static const int mfma16_env = [] { const char* e = getenv("EMCID_SP16_MFMA16"); return e ? atoi(e) : 1; }();
-            if (mfma16_env) tile_sel = (rounds >= 4 && t256 * 100 >= rounds * 256 * 85) ? 8 : 7;
+            if (mfma16_env == 1) tile_sel = (rounds >= 4 && t256 * 100 >= rounds * 256 * 85) ? 8 : 7;
             else tile_sel = (t256 * 100 >= rounds * 256 * 85) ? 4 : 5;
         } else if (dma_env >= 2 && tile_sel == 3 && ldx < (1 << 20) && ldw < (1 << 20)) {
             tile_sel = 6;       // the 160 x 128 tile with the K range split in the workgroup, staged by LDS-DMA: out 32 against 34 us, fc2 94 against 102
+        }
+        // round 5, second half (profiles/r05_mb_linear_sp16_forms.txt: six LDS-DMA forms on sixteen shapes): the 16x16x32 forms on
+        // four waves, two workgroups per compute unit, are ahead of every 32x32x16 form on every shape.  128 x 128 by default;
+        // 80 x 128 (waves side by side) where 128 x 128 tiles would not give every compute unit two workgroups (N = 768 at 6 292
+        // rows: 300 tiles -> 474: out 30.7 against 35.1 us for the K-split tile, fc2 82.3 against 97.6); 160 x 128 for operands
+        // far beyond the L2 and many rounds of tiles (36 335 rows: 339 against 369 us); 64 x 64 below 128 tiles of 80 rows.
+        if (mfma16_env >= 2 && ldx < (1 << 20) && ldw < (1 << 20)) {
+            const int64_t t80 = ((M + 79) / 80) * ((N + 127) / 128);
+            if (t80 < 128) tile_sel = 11;
+            else if (t128 < 400) tile_sel = 10;
+            else if (t128 >= 1600 && M >= 16384) tile_sel = 9;
+            else tile_sel = 7;
         }
     }
     if ((tile_sel == 3 || tile_sel == 6) && K % 64 != 0) tile_sel = 0;
@@ -1295,17 +1308,18 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
         if (pf == 1) EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 1, WPE_, 0, KS_);      \
         else EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 2, WPE_, 0, KS_);              \
     } while (0)
-#define EMCID_SP_DMA16(MJ_, NI_, WM_, WN_, NS_)                                                                                      \
+#define EMCID_SP_DMA16(MJ_, NI_, WM_, WN_, NS_, WPE_)                                                                                \
     do {                                                                                                                         \
-        if (dbg == 1) hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 1>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a);      \
-        else if (dbg == 3) hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 3>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a); \
-        else if (a.stamps) hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 2>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a); \
-        else hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 0>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a);               \
+        if (dbg == 1) hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 1, WPE_>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a);      \
+        else if (dbg == 3) hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 3, WPE_>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a); \
+        else if (a.stamps) hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 2, WPE_>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a); \
+        else hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 0, WPE_>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a);               \
     } while (0)
-    if (tile_sel == 7) EMCID_SP_DMA16(4, 4, 2, 2, 2);
-    else if (tile_sel == 8) EMCID_SP_DMA16(8, 4, 2, 4, 1);
-    else if (tile_sel == 9) EMCID_SP_DMA16(5, 4, 2, 2, 1);      // (two fragment sets spill: 56 registers)
-    else if (tile_sel == 10) EMCID_SP_DMA16(5, 2, 1, 4, 2);
+    if (tile_sel == 7) EMCID_SP_DMA16(4, 4, 2, 2, 2, 2);
+    else if (tile_sel == 8) EMCID_SP_DMA16(8, 4, 2, 4, 1, 2);
+    else if (tile_sel == 9) EMCID_SP_DMA16(5, 4, 2, 2, 1, 2);      // (two fragment sets spill: 56 registers)
+    else if (tile_sel == 10) EMCID_SP_DMA16(5, 2, 1, 4, 2, 2);
+    else if (tile_sel == 11) EMCID_SP_DMA16(2, 2, 2, 2, 2, 4);     // 64 x 64: 32 KB of LDS, 128 registers: four workgroups per compute unit
     else if (tile_sel >= 4) {
         if (a.stamps && tile_sel == 4) hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 2, 2, 4, 1, 2>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
         else if (a.stamps && tile_sel == 5) hipLaunchKernelGGL((linear_sp16_dma_kernel<2, 2, 2, 2, 1, 2>), dim3((unsigned)(per * 8)), dim3(256), 0, st, a);

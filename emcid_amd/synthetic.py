@@ -143,10 +143,41 @@ def build_tokenizer(vocab: Optional[Dict[str, int]] = None, merges=None, model_m
     return CLIPTokenizer(vocab=dict(vocab), merges=merges, model_max_length=model_max_length)
 
 
+def add_trained_like_outliers(model, seed: int = 5) -> None:
+    """In place: give a random-init CLIP text encoder the weight statistics a TRAINED one is known for and a Gaussian init lacks —
+    a few hidden channels whose LayerNorm gains are 10^2-10^3 times the median (and their biases off zero), matching outlier
+    rows in fc1 / columns in fc2 and in the out projection (the residual stream's massive channels), and two attention heads
+    per layer that sink on the start token (one key direction scaled up).  The split-fp16 forward's accuracy argument (per-row
+    power-of-two scales, the Cauchy-Schwarz bound of fc1's output planes) is exercised on these; seeded, so the reference and
+    the product build the same model."""
+    g = torch.Generator().manual_seed(seed)
+    root = getattr(model, "text_model", model)
+    h = root.config.hidden_size if hasattr(root, "config") else model.config.hidden_size
+    n_out = 6
+    chans = torch.randperm(h, generator=g)[:n_out]
+    mags = 10.0 ** (2.0 + torch.rand(n_out, generator=g))            # 10^2 .. 10^3
+    with torch.no_grad():
+        for li, layer in enumerate(root.encoder.layers):
+            for ln in (layer.layer_norm1, layer.layer_norm2):
+                ln.weight[chans] *= mags * (0.5 + torch.rand(n_out, generator=g))
+                ln.bias[chans] += (torch.rand(n_out, generator=g) - 0.5) * 4.0
+            mlp, at = layer.mlp, layer.self_attn
+            rows = torch.randperm(mlp.fc1.out_features, generator=g)[:8]
+            mlp.fc1.weight[rows] *= 10.0 ** (1.0 + torch.rand(8, 1, generator=g))       # heavy rows of fc1 (and their fc2 columns)
+            mlp.fc1.bias[rows] += torch.randn(8, generator=g) * 2.0
+            mlp.fc2.weight[:, rows] *= 10.0 ** (0.5 * torch.rand(1, 8, generator=g))
+            at.out_proj.weight[chans] *= 3.0                                            # the residual stream's massive channels
+            hd = h // at.num_heads
+            for head in torch.randperm(at.num_heads, generator=g)[:2].tolist():          # start-token sinks
+                at.k_proj.weight[head * hd:(head + 1) * hd] *= 4.0
+                at.q_proj.bias[head * hd:(head + 1) * hd] += 1.5
+        root.final_layer_norm.weight[chans] *= mags.sqrt()
+
+
 def build_text_encoder(kind: str = "toy", vocab_size: Optional[int] = None, seed: int = 0,
-                       name_or_path: str = "synthetic/clip-text", projection_dim: Optional[int] = None):
+                       name_or_path: str = "synthetic/clip-text", projection_dim: Optional[int] = None, outliers: bool = False):
     """Seeded random-init CLIPTextModel (fp32, eval, no grad); with ``projection_dim`` a CLIPTextModelWithProjection (SDXL's
-    second encoder: ``.text_embeds``, what Stage 1 of the SDXL pair reads)."""
+    second encoder: ``.text_embeds``, what Stage 1 of the SDXL pair reads); ``outliers``: ``add_trained_like_outliers``."""
     from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
 
     hidden, inter, layers, heads, act = ENCODER_DIMS[kind]
@@ -164,6 +195,8 @@ def build_text_encoder(kind: str = "toy", vocab_size: Optional[int] = None, seed
     torch.random.set_rng_state(gen_state)
     for p in model.parameters():
         p.requires_grad_(False)
+    if outliers:
+        add_trained_like_outliers(model, seed=seed + 5)
     model.config._name_or_path = name_or_path
     return model
 
@@ -197,11 +230,11 @@ class SyntheticPipe(SimpleNamespace):
 
 
 def build_pipe(kind: str = "toy", device: str = "cpu", sdxl: bool = False, seed: int = 0,
-               syllables=False, projection_dim: Optional[int] = None) -> SyntheticPipe:
+               syllables=False, projection_dim: Optional[int] = None, outliers: bool = False) -> SyntheticPipe:
     vocab, merges = synthetic_vocab(syllables=syllables)
     tok = build_tokenizer(vocab, merges)
     if not sdxl:
-        te = build_text_encoder(kind, len(vocab), seed=seed)
+        te = build_text_encoder(kind, len(vocab), seed=seed, outliers=outliers)
         return SyntheticPipe(text_encoder=te.to(device), tokenizer=tok)
     kind1, kind2 = ("toy", "toy2") if kind.startswith("toy") else ("sdxl-te1", "sdxl-te2")
     te1 = build_text_encoder(kind1, len(vocab), seed=seed, name_or_path="synthetic/clip-text-1")

@@ -22,6 +22,9 @@ shapes = [(rows, 768, 2304, "qkv"), (rows, 768, 3072, "fc1"), (rows, 768, 768, "
           (36335, 768, 2304, "qkv-36k"), (36335, 768, 3072, "fc1-36k"), (36335, 768, 768, "out-36k"), (36335, 3072, 768, "fc2-36k"),
           (10500, 768, 2304, "qkv-10k"), (10500, 768, 3072, "fc1-10k"), (10500, 768, 768, "out-10k"), (10500, 3072, 768, "fc2-10k"),
           (rows, 5120, 1280, "fc2-bigG"), (rows, 1280, 1280, "out-bigG"),
+          (640, 768, 2304, "qkv-n100"), (640, 768, 3072, "fc1-n100"), (640, 768, 768, "out-n100"), (640, 3072, 768, "fc2-n100"),
+          (1000, 3072, 768, "fc2-keys"), (3072, 768, 768, "out-query"), (3072, 768, 3072, "fc1-query"), (3072, 3072, 768, "fc2-query"),
+          (1000, 5120, 1280, "fc2-keys-bigG"), (2100, 768, 2304, "qkv-2k"), (2100, 3072, 768, "fc2-2k"),
           (rows, 1280, 3840, "qkv-bigG"), (rows, 1280, 5120, "fc1-bigG")]
 if os.environ.get("MB_SHAPES"):
     shapes = [sh for sh in shapes if sh[3] in os.environ["MB_SHAPES"].split(",")]
@@ -32,7 +35,8 @@ lib.emcid_debug_linear_sp16_stamps.argtypes = [C.c_void_p]
 # (cfg, name, tile rows, tile cols, waves per workgroup, MFMAs per wave and 32-deep stage, nominal cycles per MFMA)
 FORMS = [(64, "32x32x16 256x256/8w", 256, 256, 8, 48, 32), (128, "32x32x16 128x128/4w", 128, 128, 4, 24, 32),
          (256, "16x16x32 128x128/4w", 128, 128, 4, 48, 16), (320, "16x16x32 256x256/8w", 256, 256, 8, 96, 16),
-         (384, "16x16x32 160x128/4w", 160, 128, 4, 60, 16), (448, "16x16x32 80x128/4w", 80, 128, 4, 30, 16)]
+         (384, "16x16x32 160x128/4w", 160, 128, 4, 60, 16), (448, "16x16x32 80x128/4w", 80, 128, 4, 30, 16),
+         (512, "16x16x32 64x64/4w", 64, 64, 4, 12, 16)]
 if os.environ.get("MB_FORMS"):
     FORMS = [f for f in FORMS if str(f[0]) in os.environ["MB_FORMS"].split(",")]
 
@@ -80,11 +84,12 @@ for M, K, N, name in shapes:
     fns = [(lambda c=cfg: hip.linear_sp(xs, ws, b, out=y, cfg=c)) for cfg, *_ in FORMS]
     fns.append(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=4))
     fns.append(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=192))
+    fns.append(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=6))
     fns.append(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=-1))
     tt = rounds(fns)
     t_auto = med(tt[-1])
-    print(f"   auto                      {t_auto:7.1f} us  {fl / t_auto / 1e6:6.1f} TF-equivalent | register-staged 128x128/pf2 {med(tt[-3]):7.1f} us | "
-          f"32x32x16 160x128 K-split (LDS-DMA) {med(tt[-2]):7.1f} us", flush=True)
+    print(f"   auto                      {t_auto:7.1f} us  {fl / t_auto / 1e6:6.1f} TF-equivalent | register-staged 128x128/pf2 {med(tt[-4]):7.1f} us | "
+          f"32x32x16 160x128 K-split (LDS-DMA) {med(tt[-3]):7.1f} us | register-staged 64x64/pf2 {med(tt[-2]):7.1f} us", flush=True)
     dbg = {}
     if os.environ.get("MB_DBG", "1") == "1":
         dfns, keys = [], []

@@ -392,11 +392,11 @@ def unrecord_kz(em, orig, cks):
 
 
 def golden_sd(em, EMCIDHyperParams, scratch, tag, kind, n_req, layers, lam, ew, ragged, full, syllables=False,
-              store_vstar=True):
+              store_vstar=True, outliers=False):
     """Reference execute_emcid_text_encoder + apply_emcid_to_text_encoder on a synthetic pipe.  ``syllables``: bench.py's
     workload (syllable vocabulary, 3-syllable names); ``store_vstar=False``: the v* rows are a seeded function of the
     request list (syn.write_vstar_cache(seed=1, scale=0.5)), only their checksum goes into the fixture."""
-    pipe = syn.build_pipe(kind, "cpu", syllables=syllables)
+    pipe = syn.build_pipe(kind, "cpu", syllables=syllables, outliers=outliers)
     hidden, inter = syn.ENCODER_DIMS[kind][:2]
     reqs = syn.make_requests(n_req, ragged=ragged, names="syllable" if syllables else "index")
     hp_d = syn.sd_hparams_dict(layers=layers, mom2_update_weight=lam + 1, edit_weight=0.5, mom2_n_samples=1000, prefix="")
@@ -424,7 +424,7 @@ def golden_sd(em, EMCIDHyperParams, scratch, tag, kind, n_req, layers, lam, ew, 
     assert hp2.mom2_update_weight == lam  # in-place mutation quirk
     out = {"vstar": vs} if store_vstar else {"vstar_sum": np.array(vs.astype(np.float64).sum()),
                                              "vstar_row0": vs[0]}
-    meta = {"kind": kind, "requests": reqs if store_vstar else None, "n_requests": n_req, "syllables": syllables,
+    meta = {"kind": kind, "requests": reqs if store_vstar else None, "n_requests": n_req, "syllables": syllables, "outliers": outliers,
             "hparams": hp_d, "layers": list(layers), "lam": lam, "ew": ew, "layer_names": layer_names,
             "stats": {"seed": 2, "t": max(2 * inter, 512), "n_samples": 1000}, "vstar": {"seed": 1, "scale": 0.5}}
     g = torch.Generator().manual_seed(123)
@@ -936,6 +936,9 @@ def main():
             if which == "real_sd_n1000_summary":
                 golden_sd(em, HP, scratch, which, "sd-v1.4", n_req=1000, layers=(7, 8, 9, 10), lam=4000, ew=0.5,
                           ragged=False, full=False, syllables=True, store_vstar=False)
+            elif which == "real_sd_outliers_summary":     # trained-weight-like statistics (syn.add_trained_like_outliers), N = 100
+                golden_sd(em, HP, scratch, which, "sd-v1.4", n_req=100, layers=(7, 8, 9, 10), lam=4000, ew=0.5,
+                          ragged=False, full=False, syllables=True, store_vstar=False, outliers=True)
             elif which == "real_sdxl_summary":
                 golden_sdxl_real(em, XLHP, scratch)
             elif which == "real_sdxl_n1000_summary":     # BASELINE config 4 at its full size (N = 1000: the solver's

@@ -478,6 +478,33 @@ def test_weights_rewritten_through_data_are_caught_and_the_call_redone(tmp_path,
     assert clip_forward.LAST_PATHS.get("stale_cache_retries", 0) == before + 1
 
 
+def test_n1500_apply_vs_oracle(tmp_path):
+    """The reference's largest shipped request list has 1 500 artists (data/artists/info/erased-1500artists-....txt through
+    dsets/artist_requests.py:27-46): Np = 1536 takes other tile / stream-K / shadow-fit decisions than the headline's Np = 1024.
+    The whole `apply_emcid_to_text_encoder` call at SD-v1.4 dims against the oracle's op-for-op CPU restatement."""
+    reqs = syn.make_requests(1500, names="syllable", name_seed=17)
+    hp_d = syn.sd_hparams_dict()
+    names = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers"]]
+    cache = str(tmp_path / "cache") + "/"
+    syn.write_vstar_cache(cache, reqs, 768, seed=1, scale=0.5)
+    syn.write_stats_cache(tmp_path / "stats", names, 3072, hp_d["mom2_n_samples"], seed=2, t=6144)
+    cpu = syn.build_pipe("sd-v1.4", "cpu", syllables=True)
+    w0 = {n: orc.get_parameter(cpu.text_encoder, n + ".weight").clone() for n in names}
+    orc.apply_emcid_to_text_encoder(cpu, reqs, copy.deepcopy(hp_d), cache_name=cache, stats_dir=str(tmp_path / "stats"))
+    gpu = syn.build_pipe("sd-v1.4", DEV, syllables=True)
+    for _ in range(2):          # cold (factorization inside the call) and warm (cached factors, fused edited layers)
+        with torch.no_grad():
+            for n in names:
+                get_parameter(gpu.text_encoder, n + ".weight").copy_(w0[n].to(DEV))
+        em.apply_emcid_to_text_encoder(gpu, reqs, EMCIDHyperParams(**hp_d), DEV, cache_name=cache,
+                                       stats_dir=str(tmp_path / "stats"), verbose=False)
+        for n in names:
+            ref = orc.get_parameter(cpu.text_encoder, n + ".weight").double() - w0[n].double()
+            got = get_parameter(gpu.text_encoder, n + ".weight").cpu().double() - w0[n].double()
+            err = (got - ref).abs().max().item()
+            assert err < 1e-4 and err <= 1e-4 * ref.abs().max().item(), (n, err, ref.abs().max().item())
+
+
 def test_eleven_layer_edit_vs_oracle(tmp_path):
     """The shipped `ly-11` hparams edit layers 0..10 (L = 11): batched factorization of eleven lam*C' matrices,
     residual split over 11 layers — HIP path vs the oracle at SD-v1.4 dims."""
@@ -743,6 +770,42 @@ def test_headline_n1000_edit_matches_reference_summary(tmp_path):
     for li, ln in enumerate(meta["layer_names"]):
         dw = get_parameter(pipe.text_encoder, ln + ".weight").cpu().double() - w0[ln].double()
         _summary_close(dw, z, li, "", probe)
+
+
+def test_trained_like_outlier_statistics_match_reference_summary(tmp_path):
+    """The split-fp16 forward under weight statistics a TRAINED CLIP is known for (a Gaussian init has none of them): LayerNorm
+    gains with 10^2-10^3 outlier channels, heavy fc1 rows / fc2 columns, start-token attention sinks
+    (`synthetic.add_trained_like_outliers`).  100 concepts, SD-v1.4 dims, held to the summaries the REAL reference produced for
+    the same model (tests/golden/make_golden.py --only real_sd_outliers_summary) at the UNCHANGED 1e-4 bar, first call and
+    cached-factor call; and the worst dW error against the oracle-free summary is printed for bench comparison."""
+    z, meta = load_golden("real_sd_outliers_summary")
+    assert meta["outliers"] and meta["syllables"]
+    kind = meta["kind"]
+    hidden, inter = syn.ENCODER_DIMS[kind][:2]
+    reqs = syn.make_requests(meta["n_requests"], names="syllable")
+    cache = str(tmp_path / "cache") + "/"
+    vs = syn.write_vstar_cache(cache, reqs, hidden, seed=meta["vstar"]["seed"], scale=meta["vstar"]["scale"])
+    np.testing.assert_array_equal(vs[0], z["vstar_row0"])
+    st = meta["stats"]
+    syn.write_stats_cache(tmp_path / "stats", meta["layer_names"], inter, st["n_samples"], seed=st["seed"], t=st["t"])
+    probe = torch.randn(inter, 8, generator=torch.Generator().manual_seed(123), dtype=torch.float64)
+    pipe = syn.build_pipe(kind, DEV, syllables=True, outliers=True)
+    # the model really has the outliers: some LayerNorm gains are >= 100 x the median gain
+    g1 = get_parameter(pipe.text_encoder, meta["layer_names"][0].replace("mlp.fc2", "layer_norm2") + ".weight").abs()
+    assert (g1.max() / g1.median()).item() >= 100
+    w0 = {ln: get_parameter(pipe.text_encoder, ln + ".weight").detach().clone() for ln in meta["layer_names"]}
+    from emcid_amd import clip_forward
+    before = dict(clip_forward.LAST_PATHS)
+    for route in ("first call", "cached factors"):
+        em.apply_emcid_to_text_encoder(pipe, reqs, EMCIDHyperParams(**meta["hparams"]), DEV, mom2_weight=meta["lam"],
+                                       edit_weight=meta["ew"], cache_name=cache, stats_dir=str(tmp_path / "stats"), verbose=False)
+        for li, ln in enumerate(meta["layer_names"]):
+            dw = get_parameter(pipe.text_encoder, ln + ".weight").cpu().double() - w0[ln].cpu().double()
+            _summary_close(dw, z, li, "", probe)
+            with torch.no_grad():
+                get_parameter(pipe.text_encoder, ln + ".weight").copy_(w0[ln])
+    assert clip_forward.LAST_PATHS["linear_sp16"] > before["linear_sp16"]          # it was the split-fp16 path that was held to the bar
+    assert clip_forward.LAST_PATHS["forward_hf_fallback"] == before["forward_hf_fallback"]
 
 
 def test_headline_n1000_first_call_path_and_cached_path_match_reference_summary(tmp_path):

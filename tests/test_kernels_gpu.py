@@ -91,7 +91,9 @@ def _edit_inputs(N, d, h, seed):
                                               (50, 1400, 96, 300.0, 0.5, 2),     # dp = 1408: short last 512-block
                                               (100, 3072, 768, 4000.0, 0.5, 4), (1000, 3072, 768, 4000.0, 0.5, 2),
                                               (1, 3072, 768, 4000.0, 0.5, 1), (130, 5120, 1280, 10000.0, 0.5, 5),
-                                              (1000, 5120, 1280, 10000.0, 0.5, 5)])      # BASELINE config 4 (SDXL TE2) at its full size
+                                              (1000, 5120, 1280, 10000.0, 0.5, 5),       # BASELINE config 4 (SDXL TE2) at its full size
+                                              (1500, 3072, 768, 4000.0, 0.5, 3),         # the reference's largest shipped list (Np = 1536)
+                                              (2000, 3072, 768, 4000.0, 0.5, 1)])        # Np = 2048: the last size the fused steps take
 def test_edit_layer_vs_oracle(N, d, h, lam, ew, left):
     """The whole per-layer closed form against the oracle's fp64 LU restatement on identical inputs.
     Bar (BASELINE.json): dW max-abs error < 1e-4 and <= 1e-4 relative; observed ~1e-12."""
@@ -267,8 +269,10 @@ def test_tree_attention_vs_dense_reference(U, H, D, max_depth):
                                               (50, 1400, 96, 300.0, 0.5, 2),     # dp = 1408: short last 512-block
                                               (100, 3072, 768, 4000.0, 0.5, 4), (1000, 3072, 768, 4000.0, 0.5, 2),
                                               (300, 5120, 1280, 10000.0, 0.5, 5),
-                                              (1000, 5120, 1280, 10000.0, 0.5, 5)])      # config 4 full size: Np = 1024 at dp = 5120 (no shadow
+                                              (1000, 5120, 1280, 10000.0, 0.5, 5),       # config 4 full size: Np = 1024 at dp = 5120 (no shadow
                                                                                          # product: two rounds of stream-K / paired tiles)
+                                              (1500, 3072, 768, 4000.0, 0.5, 3),         # data/artists/info/erased-1500artists-...: Np = 1536
+                                              (2000, 3072, 768, 4000.0, 0.5, 1)])
 def test_dual_solver_vs_oracle(N, d, h, lam, ew, left):
     """The Woodbury form (batched factor of lam*C', N x N system per layer) against the oracle's fp64 LU."""
     K, Zc, zs, Cov, W0 = _edit_inputs(N, d, h, seed=N + d)
@@ -738,7 +742,7 @@ def test_split_rows_keeps_22_bits_under_a_per_row_scale():
     assert (sp2.float() - wide[:, :128]).abs().max().item() <= wide.abs().max().item() * 2.0 ** -21
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 4, 1, 5, 2, 6, 3, 7, 64, 128, 192, 256, 320, 384, 448])
+@pytest.mark.parametrize("cfg", [-1, 0, 4, 1, 5, 2, 6, 3, 7, 64, 128, 192, 256, 320, 384, 448, 512])
 @pytest.mark.parametrize("M,K,N", [(6400, 768, 2304), (6400, 3072, 768), (1000, 3072, 768), (640, 768, 3072), (300, 1280, 1280),
                                    (129, 96, 257), (37, 2048, 200), (256, 32, 32), (330, 192, 130)])
 def test_linear_sp16_vs_torch(M, K, N, cfg):
@@ -790,6 +794,51 @@ def test_linear_sp16_vs_torch(M, K, N, cfg):
         assert bool(((back - yq).abs() <= torch.maximum(yq.abs() * 2.0 ** -21, (2.0 ** -24 / ps)[:, None])).all())
         yp2 = hip.linear_sp(xs, ws_, b, act=hip.ACT_QUICK_GELU, planes_scale=ps2, want_f32=False, cfg=cfg)
         assert yp2.f32 is None and torch.equal(yp2.planes, yp.planes)
+
+
+@pytest.mark.parametrize("cfg", [-1, 256, 448, 2])
+def test_linear_sp16_heavy_tailed_operands(cfg):
+    """Operands with the statistics of a trained encoder rather than a Gaussian init: a few channels 10^3 times the rest, rows with
+    Cauchy tails, outlier weight rows.  The split keeps 22-23 bits relative to each ROW's largest magnitude, so the error of an
+    output element is bounded by 2^-23 (max|x_m| ||w_n||_1 + max|w_n| ||x_m||_1) plus the fp32 accumulation — held with a factor
+    of two; and the per-row output scale the LayerNorm hands to fc1 (LnPlanes.out_scale, a Cauchy-Schwarz bound) stays within
+    2^10 of the row's true maximum, i.e. the output planes keep >= 12 of their 22 bits even on these rows."""
+    g = torch.Generator().manual_seed(77)
+    M, K, N = 1500, 768, 3072
+    x = torch.randn(M, K, generator=g)
+    x[:, torch.randperm(K, generator=g)[:6]] *= 1000.0                        # massive channels
+    x[::7] *= torch.distributions.Cauchy(0.0, 1.0).sample((x[::7].shape[0], 1)).abs().clamp(0.1, 500.0)
+    w = torch.randn(N, K, generator=g) * 0.05
+    w[torch.randperm(N, generator=g)[:8]] *= 50.0
+    b = torch.randn(N, generator=g)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    ref = F.linear(xd.double(), wd.double(), bd.double())
+    xs, ws_ = hip.split_rows(xd), hip.split_rows(wd)
+    y = hip.linear_sp(xs, ws_, bd, cfg=cfg)
+    bound = 2.0 ** -23 * (xd.abs().amax(1, keepdim=True).double() * wd.abs().sum(1).double()[None, :] +
+                          wd.abs().amax(1).double()[None, :] * xd.abs().sum(1, keepdim=True).double()) + \
+        2.0 ** -23 * (xd.abs().double() @ wd.abs().double().t()) + 1e-6
+    err = (y.double() - ref).abs()
+    assert bool((err <= 2.0 * bound).all()), float((err / bound).max())
+    # the exact-f32 kernel is held to the same bound (it rounds every accumulate; the split drops 2^-23 of a row's maximum)
+    assert bool(((hip.linear(xd, wd, bd).double() - ref).abs() <= 2.0 * bound).all())
+    if cfg == -1:
+        # LayerNorm with outlier gains writing x as planes + the fc1 output scale: |act(z W^T + b)| * 2^e < 2^15 (no overflow of
+        # the planes) and >= 2^5 on every row (the bound is within 2^10 of the row's true maximum)
+        ln = torch.nn.LayerNorm(K).to(DEV)
+        with torch.no_grad():
+            ln.weight.copy_((torch.rand(K, generator=g) + 0.5).to(DEV))
+            ln.weight[torch.randperm(K, generator=g)[:6].to(DEV)] *= 300.0
+            ln.bias.copy_((torch.randn(K, generator=g) * 0.2).to(DEV))
+        wsp = hip.split_rows(wd, bd, want_bound=True)
+        _, zsp = hip.add_layernorm_sp(xd, None, ln, want_f32=True, bound=wsp.bound)
+        out = F.linear(zsp.f32, wd, bd)
+        top = out.abs().amax(1) * zsp.out_scale[0]
+        assert bool((top < 2.0 ** 15).all()) and bool((top >= 2.0 ** 5).all()), (top.min().item(), top.max().item())
+        hq = hip.linear_sp(zsp, wsp, bd, act=hip.ACT_QUICK_GELU, planes_scale=zsp.out_scale)
+        back = hip.SplitRows(hq.planes, hq.inv_scale).float()
+        rowmax = hq.f32.abs().amax(1, keepdim=True)
+        assert bool(((back - hq.f32).abs() <= rowmax * 2.0 ** -11 * 2.0 ** -10 + hq.f32.abs() * 2.0 ** -21).all())
 
 
 def test_producers_write_split_rows_directly():

@@ -120,6 +120,30 @@ def test_real_dims_summary(tmp_path):
         np.testing.assert_allclose(dw.norm().item(), float(z[f"dw_fro/{li}"]), rtol=1e-6)
 
 
+def test_outlier_statistics_summary(tmp_path):
+    """The oracle against the reference on an encoder with trained-weight-like outliers (synthetic.add_trained_like_outliers;
+    fixture real_sd_outliers_summary: N = 100, SD-v1.4 dims): the same model on both sides, the same numbers."""
+    z, meta = load_golden("real_sd_outliers_summary")
+    pipe = syn.build_pipe(meta["kind"], "cpu", syllables=True, outliers=True)
+    reqs = syn.make_requests(meta["n_requests"], names="syllable")
+    hidden, inter = syn.ENCODER_DIMS[meta["kind"]][:2]
+    cache = str(tmp_path / "cache") + "/"
+    vs = syn.write_vstar_cache(cache, reqs, hidden, seed=meta["vstar"]["seed"], scale=meta["vstar"]["scale"])
+    np.testing.assert_array_equal(vs[0], z["vstar_row0"])
+    st = meta["stats"]
+    syn.write_stats_cache(tmp_path / "stats", meta["layer_names"], inter, st["n_samples"], seed=st["seed"], t=st["t"])
+    w0 = {ln: orc.get_parameter(pipe.text_encoder, ln + ".weight").clone() for ln in meta["layer_names"]}
+    hp = copy.deepcopy(meta["hparams"])
+    orc.apply_emcid_to_text_encoder(pipe, reqs, hp, mom2_weight=meta["lam"], edit_weight=meta["ew"], cache_name=cache,
+                                    stats_dir=str(tmp_path / "stats"))
+    probe = torch.randn(inter, 8, generator=torch.Generator().manual_seed(123), dtype=torch.float64)
+    for li, ln in enumerate(meta["layer_names"]):
+        dw = orc.get_parameter(pipe.text_encoder, ln + ".weight").double() - w0[ln].double()
+        ref = z[f"dw_probe/{li}"]
+        np.testing.assert_allclose((dw @ probe).numpy(), ref, rtol=0, atol=1e-6 * np.abs(ref).max())
+        np.testing.assert_allclose(dw.norm().item(), float(z[f"dw_fro/{li}"]), rtol=1e-6)
+
+
 def test_fact_tokens_and_float64_statistics_match_reference():
     """Two reference behaviours outside the shipped hparams: num_fact_token > 1 (compute_z.py:2329-2382) and
     --precision float64 statistics (layer_stats.py:161, :218) — the oracle's restatements against the reference's outputs."""
