@@ -262,8 +262,7 @@ def main():
     shard = ConceptShard(rank, world, None)
 
     # the forward's projections run on the library's own GEMM (no selection step); under EMCID_OWN_GEMM=0 they are torch's
-    # F.linear with library-default selection (EMCID_TUNE_GEMM=1 would time hipBLASLt's solutions in the first call)
-    os.environ.setdefault("EMCID_TUNE_GEMM", "auto")
+    # F.linear with library-default selection
     os.environ.setdefault("EMCID_MANAGE_THREADS", "1")      # an editing process of its own: thread pools sized to the CPU quota
     os.environ.setdefault("EMCID_FACTOR_CACHE", "8")        # the edit_weight sweep below must not evict the workload's own factors
     workdir = Path(tempfile.gettempdir()) / f"emcid_bench_{os.getuid()}"
@@ -383,19 +382,6 @@ def main():
     ew_list = [0.35, 0.4, 0.45, 0.55, 0.6]
     new_lam_ms = each_synced(len(lam_list), lambda i: call(0, copy.deepcopy(hp), mom2_weight=lam_list[i]))
     new_ew_ms = each_synced(len(ew_list), lambda i: call(0, copy.deepcopy(hp), edit_weight=ew_list[i]))
-    # the same sweep under EMCID_EDIT_WEIGHT_SCALAR=1 (C' taken as the scalar multiple of C it is up to one fp32 rounding per
-    # entry: the workload's factors serve every edit_weight), and how far its weights are from the exact form's
-    def edited():
-        return [get_parameter(pipe.text_encoder, n + ".weight").detach().clone() for n in layer_names]
-    exact_w = edited()                                 # exact form at ew_list[-1] (the sweep's last call)
-    os.environ["EMCID_EDIT_WEIGHT_SCALAR"] = "1"
-    try:
-        call(0)                                        # the workload's own (lam, e_w) into the scalar-keyed cache slot
-        ew_scalar_ms = each_synced(len(ew_list), lambda i: call(0, copy.deepcopy(hp), edit_weight=ew_list[i]))
-        ew_scalar_err = max(float((a - b).abs().max() / (b - o).abs().max().clamp_min(1e-30))
-                            for a, b, o in zip(edited(), exact_w, (originals[n] for n in layer_names)))
-    finally:
-        os.environ.pop("EMCID_EDIT_WEIGHT_SCALAR", None)
     call(0)        # (lam, e_w) of the workload again (its factors are still cached)
 
     log("GEMM A/B, host/device split, roofline pass")
@@ -456,7 +442,7 @@ def main():
     N, L = args.concepts, len(LAYERS)
     dual = plan.dual_ws is not None
     flops = step_flops(N, N, d, h, L, dual, True, plan.factors_from_cache,
-                       min(L, max(0, int(os.environ.get("EMCID_INVERSE_FROM", "1")))))
+                       min(L, 1))
     classes = {}
     for c, (ms, launches) in prof.items():
         rec = {"ms_per_step": ms / args.steps, "launches_per_step": launches / args.steps}
@@ -583,12 +569,6 @@ def main():
                            "new_lambda_ms_all": [round(t, 3) for t in new_lam_ms],
                            "new_edit_weight_ms_per_call": statistics.median(new_ew_ms), "edit_weights": ew_list,
                            "new_edit_weight_ms_all": [round(t, 3) for t in new_ew_ms],
-                           "new_edit_weight_scalar_ms_per_call": statistics.median(ew_scalar_ms),
-                           "new_edit_weight_scalar_ms_all": [round(t, 3) for t in ew_scalar_ms],
-                           "new_edit_weight_scalar_dw_rel_err_vs_exact": ew_scalar_err,
-                           "scalar_note": "EMCID_EDIT_WEIGHT_SCALAR=1 (off by default): lam C'(e_w) = [lam (1 - e_w)/(1 - e_w0)] C'(e_w0) "
-                                          "up to one fp32 rounding per entry of C'; error = max |W_scalar - W_exact| / max |dW| over the "
-                                          "edited layers at the sweep's last edit_weight",
                            "note": "same requests as the replay; a new lambda reuses the cached factor of C' (lam_ratio), a new "
                                    "edit_weight refactors the four 3072 x 3072 matrices on the side stream under the forward"},
         "first_call_ms": first_s * 1e3,
@@ -605,7 +585,6 @@ def main():
                          "note": "replay calls (same 1 000 requests); compare with replay_ms_per_call"},
         "host_prepare_ms": statistics.median(prep_ms),
         "device_ms_per_step": device_ms,
-        "gemm_tuning_ms": clip_forward.TUNING_SECONDS_TOTAL * 1e3,     # inside first_call_ms
         "roofline": roofline,
         "solve": solve,
         "kernel_classes": classes,
@@ -1065,7 +1044,7 @@ def sdxl_record(workdir, device, n=1000, calls=5):
         return (time.perf_counter() - t) / k * 1e3
 
     t1, t2 = alone(p1), alone(p2)
-    first_x = max(0, int(os.environ.get("EMCID_INVERSE_FROM", "1")))
+    first_x = 1
     f1 = step_flops(n, n, 3072, 768, len(hp.layers), p1.dual_ws is not None, True, p1.factors_from_cache, min(len(hp.layers), first_x))
     f2 = step_flops(n, n, 5120, 1280, len(hp.layers_2), p2.dual_ws is not None, True, p2.factors_from_cache,
                     min(len(hp.layers_2), first_x))
@@ -1136,7 +1115,6 @@ def cold_child(workdir, n):
     call one at a time.  Prints one JSON line."""
     t_start = time.perf_counter()
     os.environ.setdefault("EMCID_MANAGE_THREADS", "1")
-    os.environ["EMCID_TUNE_GEMM"] = "auto"          # load an existing table, never tune
     import torch
     t_torch = time.perf_counter()
     from emcid_amd import edit_engine, emcid_main as em, hip, host_text
@@ -1180,7 +1158,6 @@ def cold_child(workdir, n):
     warm_ms = statistics.median(warm)
     print(json.dumps({
         "cold_process_ms": first_ms, "host_phases_ms_first_call": first_phases,
-        "tunable_table_loaded": bool(clip_forward._TUNED["done"]),
         "before_the_call_ms": {"import_torch": (t_torch - t_start) * 1e3, "import_package_and_load_libraries": (t_lib - t_torch) * 1e3,
                                "gpu_context": (t_ctx - t_lib) * 1e3, "synthetic_model_to_hbm": (t_model - t_ctx) * 1e3},
         "second_to_fourth_call_ms": [round(t, 3) for t in warm], "warm_call_ms": warm_ms,
@@ -1206,7 +1183,6 @@ def cold_process_record(workdir, device):
     except Exception:
         pass
     env = dict(os.environ)
-    env.pop("EMCID_TUNE_GEMM", None)
     r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--cold-child", str(workdir)], env=env,
                        capture_output=True, text=True, timeout=600)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -134,21 +134,32 @@ class WeightGuard:
         self.table = torch.zeros(self.n, 4, dtype=torch.int64, device=device)
         self.flag = torch.zeros(1, dtype=torch.int32, device=device)
         self.host = [None] * self.n          # (data_ptr, bytes, version counter) of the tensor each filled slot was stored from
+        self.pending = {}                    # slot -> tensor: fingerprints still to be taken (``flush``)
 
     def store(self, layer: int, name: str, w: torch.Tensor):
+        """Note that a cache entry was just made from ``w``.  The fingerprint itself is taken by ``flush`` — ONE launch for
+        everything noted since the last one, at the end of the forward / edit that made the entries (an edited layer's fc2
+        is noted twice per call, before and after its edit: the later note wins, and the bytes are read after both)."""
         nbytes = w.numel() * w.element_size()
         slot = layer * GUARD_SLOTS + _GUARD_SLOT[name]
+        self.pending.pop(slot, None)
         if not (w.is_cuda and w.is_contiguous() and nbytes % 16 == 0 and w.data_ptr() % 16 == 0 and w.device == self.table.device):
             self.host[slot] = None
             return
-        hip.fingerprint_store(w.detach(), self.table, slot)
+        self.pending[slot] = w
         self.host[slot] = (w.data_ptr(), nbytes, w._version)
+
+    def flush(self):
+        if self.pending:
+            hip.fingerprint_store([(w.detach(), slot) for slot, w in self.pending.items()], self.table)
+            self.pending.clear()
 
     def check(self, layers, hi: int):
         """Zero the flag and launch the comparison for the slots of layers [0, hi) whose cache entries this call will TRUST: the
         tensor a slot was stored from is still the live parameter, at the same address, with the same version counter.  Any other
         slot is masked out — its cache entry misses on the counter (or identity) anyway and is rebuilt, with a fresh
         fingerprint, before it is used; its table entry may point at memory that is no longer there and is never looked at."""
+        self.flush()        # (entries made earlier in this very call, by the leading layers' launches)
         self.flag.zero_()
         n = min(hi, len(layers)) * GUARD_SLOTS
         skip = []
@@ -512,123 +523,15 @@ def build_trie_numpy(tok: np.ndarray, lk: np.ndarray, device, bucket: int = ROW_
 
 
 class tuned_gemms:
-    """Context: route torch's fp32 GEMMs through TunableOp's table (results of ``tune_projections``) for the duration
-    of the forward, and put the process-wide switches back afterwards.  No tuning happens inside the context."""
+    """(Rounds 2-3 routed torch's fp32 GEMMs through TunableOp's table here; the projections run on the library's own kernels
+    since round 3 and the `EMCID_OWN_GEMM=0` comparison path takes torch's default selection: a no-op context, kept so that
+    the two forward drivers read the same.)"""
 
     def __enter__(self):
-        self.prev = None
-        if OWN_GEMM:                 # nothing of torch's GEMM selection is touched on the default path
-            return self
-        t = torch.cuda.tunable
-        self.prev = (t.is_enabled(), t.tuning_is_enabled())
-        if _TUNED["done"]:
-            t.enable(True)
-            t.tuning_enable(False)
         return self
 
     def __exit__(self, *exc):
-        if self.prev is not None:
-            t = torch.cuda.tunable
-            t.tuning_enable(self.prev[1])
-            t.enable(self.prev[0])
         return False
-
-
-_TUNED = {"done": False, "shapes": set()}
-
-
-def _tunable_file(dev) -> str:
-    """TunableOp results file: per user (0700 directory under ~/.cache, or $EMCID_CACHE_DIR), per device and rank —
-    processes of a multi-GPU job must not write the same file at exit, and nobody else can plant one."""
-    import os
-    root = os.environ.get("EMCID_CACHE_DIR") or os.path.join(os.path.expanduser("~"), ".cache", "emcid_amd")
-    os.makedirs(root, mode=0o700, exist_ok=True)
-    return os.path.join(root, f"tunableop_gpu{dev.index or 0}_r{os.environ.get('RANK', '0')}.csv")
-
-
-def _own_regular_file(path: str) -> bool:
-    import os
-    import stat
-    try:
-        st = os.lstat(path)
-    except OSError:
-        return False
-    return stat.S_ISREG(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & 0o022)
-
-
-TUNING_SECONDS_TOTAL = 0.0     # seconds this process has spent inside TunableOp tuning (bench.py reports it)
-
-
-def tune_projections(graph: ClipTextGraph, trie: TokenTrie, upto: int, mode: str = "auto") -> float:
-    """Let TunableOp time the GEMM libraries' solutions for the projection shapes this trie produces (rows are
-    bucketed, so a handful of shapes per encoder) and keep the fastest: on MI355X the default heuristic leaves
-    10-35 % on the table for (rows x 768) @ (768 x {768, 2304, 3072}).
-
-    ``mode``: "1" tunes shapes not seen yet (seconds per encoder, once; results also go to TunableOp's file under the
-    user's cache directory) — what a long-running editing service or the benchmark wants; "auto" (the library default) only LOADS
-    that file if an earlier process left one, so a one-off call never pays for tuning; "0" leaves torch alone.
-    Returns the seconds spent."""
-    import time
-    if mode == "0" or OWN_GEMM:      # the library's own GEMM needs no selection; torch's switches are left alone
-        return 0.0
-    layer = graph.layers[upto]
-    dev = layer.fc2.weight.device
-    t = torch.cuda.tunable
-    fname = _tunable_file(dev)
-    t0 = time.perf_counter()
-    if mode != "1":
-        if not _TUNED["done"] and _own_regular_file(fname):
-            prev = (t.is_enabled(), t.tuning_is_enabled(), t.get_filename())
-            try:
-                t.enable(True)
-                t.tuning_enable(False)
-                t.set_filename(fname)
-                _TUNED["done"] = bool(t.read_file(fname))
-            finally:
-                t.set_filename(prev[2])
-                t.tuning_enable(prev[1])
-                t.enable(prev[0])
-        return time.perf_counter() - t0
-    rows_all, rows_q = int(trie.token.numel()), int(trie.query_rows.numel())
-    todo = []
-    for rows in {rows_all, rows_q}:
-        mods = [layer.out, layer.fc1, layer.fc2, layer.q, layer.k]
-        for m in mods:
-            todo.append((rows, m.in_features, m.out_features, m.bias is not None))
-        if layer.qkv_w is not None:
-            todo.append((rows, layer.qkv_w.shape[1], layer.qkv_w.shape[0], layer.qkv_b is not None))
-    todo = [s for s in dict.fromkeys(todo) if s not in _TUNED["shapes"]]
-    if not todo:
-        return 0.0
-    global TUNING_SECONDS_TOTAL
-    prev = (t.is_enabled(), t.tuning_is_enabled())
-    try:
-        t.enable(True)
-        t.tuning_enable(True)
-        t.set_filename(fname)
-        t.set_max_tuning_duration(30)
-        t.set_max_tuning_iterations(10)
-        # Timing every library solution of a shape normally takes ~0.5 s per shape; on a box whose page cache has never seen
-        # the GEMM libraries' code objects it was measured at 70-130 s in total.  Past the budget (EMCID_TUNE_BUDGET_S, default
-        # 150 s per process) the remaining shapes keep the library's own choice (a few per cent slower) and are not retried.
-        budget = float(os.environ.get("EMCID_TUNE_BUDGET_S", "150"))
-        with torch.no_grad():
-            for rows, k, n, has_bias in todo:
-                if TUNING_SECONDS_TOTAL + (time.perf_counter() - t0) > budget:
-                    break
-                x = torch.randn(rows, k, device=dev)
-                w = torch.randn(n, k, device=dev)
-                b = torch.randn(n, device=dev) if has_bias else None
-                F.linear(x, w, b)
-                torch.cuda.synchronize(dev)
-        torch.cuda.synchronize(dev)
-        _TUNED["shapes"].update(todo)
-        _TUNED["done"] = True
-    finally:
-        t.tuning_enable(prev[1])
-        t.enable(prev[0])
-    TUNING_SECONDS_TOTAL += time.perf_counter() - t0
-    return time.perf_counter() - t0
 
 
 def build_trie_packed(seqs: Sequence[Sequence[int]], device, bucket: int = ROW_BUCKET, return_nodes: bool = False):
@@ -789,6 +692,8 @@ def run_layers(graph: ClipTextGraph, trie: TokenTrie, upto: int, on_fc2=None, la
             out = on_fc2(i, xs[0], outs[0])
             return None if out is None else [out]
     res = run_layers_multi(graph, [trie], None, 0, upto, cb, last_rows_only, fc2_by_callback)
+    if graph.guard is not None:
+        graph.guard.flush()
     return None if res is None else res[0][0]
 
 

@@ -315,7 +315,7 @@ static void launch_tree_attention_short(const TreeAttnArgs& a, int rounds, hipSt
 
 /* 1 when emcid_tree_attention_sp16 serves chains of up to anc_ld nodes with H heads (the short-chain kernel), else 0 */
 extern "C" int emcid_tree_attention_sp16_supported(int64_t anc_ld, int64_t H, int64_t D) {
-    static const int short_ok = [] { const char* e = getenv("EMCID_TREE_ATTN_SHORT"); return e ? atoi(e) : 1; }();
+    constexpr int short_ok = 1;
     return short_ok && anc_ld >= 1 && anc_ld <= 16 && (H + 3) / 4 <= 5 && D <= 64 && D % 8 == 0 ? 1 : 0;
 }
 
@@ -345,7 +345,7 @@ extern "C" int emcid_tree_attention_f32(const float* q, int64_t ldq, const float
     EMCID_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(out) && n_rows < (1LL << 31));
     TreeAttnArgs a{q, ldq, k, v, ld, anc, anc_ld, depth, rows, (int)n_rows, (int)H, (int)D, scale, out, ldo, nullptr, 0, nullptr};
     ScopedProf sp(KC_MISC, (hipStream_t)stream);
-    static const int short_ok = [] { const char* e = getenv("EMCID_TREE_ATTN_SHORT"); return e ? atoi(e) : 1; }();
+    constexpr int short_ok = 1;
     const int rounds = (int)((H + 3) / 4);
     if (short_ok && anc_ld <= 16 && rounds <= 5) {      // every chain has at most anc_ld nodes
         if (anc_ld <= 8) launch_tree_attention_short<2, false>(a, rounds, (hipStream_t)stream);
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void add_layernorm_wave_kernel(const float* __
 static void launch_add_layernorm(const float* a, int64_t lda, const float* b, int64_t ldb, const float* gamma, const float* beta,
                                  float eps, int64_t rows, int64_t cols, float* y, float* z, const int64_t* ia, const int* ib,
                                  hipStream_t st, LnPlanes sp = LnPlanes{nullptr, 0, nullptr, nullptr, nullptr}) {
-    static const int wave_rows = [] { const char* e = getenv("EMCID_LN_WAVE"); return e ? atoi(e) : 1; }();
+    constexpr int wave_rows = 1;
     if ((wave_rows || sp.P != nullptr) && cols <= LN_MAX_V4 * 64 * 4)
         hipLaunchKernelGGL(add_layernorm_wave_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a, lda, b, ldb, gamma, beta,
                            eps, (int)cols, (int)rows, y, z, ia, ib, sp);

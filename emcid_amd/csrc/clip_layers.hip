@@ -16,6 +16,8 @@
 // (sel = all rows, or the query rows of the last edited layer: k | v for every node, q / attention / MLP for the selected ones).
 #include "common.h"
 
+#include <algorithm>
+
 namespace emcid {
 
 // dst[r] = src[idx[r]] for rows of `row_bytes` bytes (a multiple of 16); one workgroup per destination row
@@ -53,10 +55,18 @@ __device__ __forceinline__ unsigned long long fingerprint_of(const unsigned char
     typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
     const long long nvec = bytes / 16, ns = nvec < 4096 ? nvec : 4096;
     unsigned long long h = 0;
-    for (long long i = threadIdx.x; i < ns; i += 256) {
+    v2u64 x[16];                                                            // a thread's (up to) 16 samples: every load in flight at once
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const long long i = threadIdx.x + 256 * u;
         const long long v = ns == nvec ? i : i * nvec / ns;                 // i < 4 096, nvec < 2^40
-        const v2u64 x = *reinterpret_cast<const v2u64*>(data + 16 * v);
-        h ^= fp_mix(x[0] + 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * i + 1)) ^ fp_mix(x[1] + 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * i + 2));
+        x[u] = i < ns ? *reinterpret_cast<const v2u64*>(data + 16 * v) : (v2u64){0ull, 0ull};
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const long long i = threadIdx.x + 256 * u;
+        if (i < ns)
+            h ^= fp_mix(x[u][0] + 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * i + 1)) ^ fp_mix(x[u][1] + 0x9E3779B97F4A7C15ull * (unsigned long long)(2 * i + 2));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -68,11 +78,15 @@ __device__ __forceinline__ unsigned long long fingerprint_of(const unsigned char
     return lds[0] ^ lds[1] ^ lds[2] ^ lds[3];
 }
 
-__global__ __launch_bounds__(256) void fingerprint_store_kernel(const unsigned char* data, long long bytes, long long* table, long long slot) {
+struct FpBatch { const unsigned char* data[32]; long long bytes[32]; long long slot[32]; };      // one workgroup per entry
+
+__global__ __launch_bounds__(256) void fingerprint_store_kernel(FpBatch b, long long* table) {
     __shared__ unsigned long long lds[4];
+    const unsigned char* data = b.data[blockIdx.x];
+    const long long bytes = b.bytes[blockIdx.x];
     const unsigned long long h = fingerprint_of(data, bytes, lds);
     if (threadIdx.x == 0) {
-        long long* e = table + 4 * slot;
+        long long* e = table + 4 * b.slot[blockIdx.x];
         e[0] = (long long)reinterpret_cast<uintptr_t>(data); e[1] = bytes; e[2] = (long long)h; e[3] = 0;
     }
 }
@@ -133,11 +147,21 @@ using namespace emcid;
 
 extern "C" {
 
-/* include/emcid_hip.h, "stale-cache guard".  Stores {data, bytes, fingerprint} of a weight's bytes in slot `slot` of the table. */
-int emcid_fingerprint_store(const void* data, int64_t bytes, void* table, int64_t table_slots, int64_t slot, void* stream) {
-    EMCID_CHECK_ARG(data && table && bytes > 0 && bytes % 16 == 0 && aligned16(data) && slot >= 0 && slot < table_slots);
-    hipLaunchKernelGGL(fingerprint_store_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)data,
-                       (long long)bytes, (long long*)table, (long long)slot);
+/* include/emcid_hip.h, "stale-cache guard".  Stores {data, bytes, fingerprint} of n weights' bytes in their slots of the table:
+ * one launch per 32 entries, one workgroup per entry (host arrays). */
+int emcid_fingerprint_store(int64_t n, const void* const* data, const int64_t* bytes, const int64_t* slots, void* table,
+                            int64_t table_slots, void* stream) {
+    EMCID_CHECK_ARG(n >= 0 && table && (n == 0 || (data && bytes && slots)));
+    for (int64_t i0 = 0; i0 < n; i0 += 32) {
+        FpBatch b{};
+        const int cnt = (int)std::min<int64_t>(32, n - i0);
+        for (int i = 0; i < cnt; ++i) {
+            EMCID_CHECK_ARG(data[i0 + i] && bytes[i0 + i] > 0 && bytes[i0 + i] % 16 == 0 && aligned16(data[i0 + i]) &&
+                            slots[i0 + i] >= 0 && slots[i0 + i] < table_slots);
+            b.data[i] = (const unsigned char*)data[i0 + i]; b.bytes[i] = bytes[i0 + i]; b.slot[i] = slots[i0 + i];
+        }
+        hipLaunchKernelGGL(fingerprint_store_kernel, dim3((unsigned)cnt), dim3(256), 0, (hipStream_t)stream, b, (long long*)table);
+    }
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }

@@ -466,9 +466,8 @@ int emcid_linear_ws_f32(const float* X, int64_t ldx, const float* W, int64_t ldw
     int parts = cfg < 0 ? 0 : (cfg >> 7) & 15;
     if (cfg >= 0) cfg &= 127;
     int tile_sel = cfg < 0 ? -1 : (cfg & 3);
-    static const int pf_env = [] { const char* e = getenv("EMCID_LINEAR_PF"); return e ? atoi(e) : 1; }();
-    static const int ks_env = [] { const char* e = getenv("EMCID_LINEAR_KS"); return e ? atoi(e) : 2; }();
-    int pf = cfg < 0 ? (pf_env >= 1 && pf_env <= 3 ? pf_env : 1) : ((cfg >> 2) & 3) + 1;
+    constexpr int ks_env = 2;
+    int pf = cfg < 0 ? 1 : ((cfg >> 2) & 3) + 1;
     const int dbg = cfg < 0 ? 0 : (cfg >> 4) & 3;
     int ks = cfg < 0 ? (ks_env == 1 ? 1 : 2) : ((cfg >> 6) & 1) ? 1 : 2;
     if (K % (2 * LBK) != 0) ks = 1;
@@ -477,8 +476,7 @@ int emcid_linear_ws_f32(const float* X, int64_t ldx, const float* W, int64_t ldw
     const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128);
     EMCID_CHECK_ARG(parts == 0 || (parts >= 2 && parts <= 8 && tile_sel == 1 && ks == 1 && dbg == 0 && workspace != nullptr &&
                                    t128 <= kSplitTiles && t128 * parts <= kSplitItems && K / LBK >= parts));
-    static const int split_env = [] { const char* e = getenv("EMCID_LINEAR_SPLITK"); return e ? atoi(e) : 1; }();
-    if (tile_sel < 0 && workspace != nullptr && split_env && t128 <= 128 && K >= 2048) {
+    if (tile_sel < 0 && workspace != nullptr && t128 <= 128 && K >= 2048) {
         // at most half the compute units would get a 128 x 128 tile: cut K so that about one workgroup per compute unit runs.
         // Measured (scripts/mb_linear.py, profiles/r03_mb_linear_splitk.txt; us, 64 x 64 tiles -> split-K; hipBLASLt beside it):
         // 640 x 3072 -> 768 61.7 -> 43.2 (8 parts; 30), 1 000 x 5120 -> 1280 173.8 -> 123.0 (6) / 131.1 (3; 107), 1 000 x 3072 ->
@@ -510,8 +508,7 @@ int emcid_linear_ws_f32(const float* X, int64_t ldx, const float* W, int64_t ldw
     const int tiles = tiles_m * tiles_n;
     const int per = (tiles + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
-    static const int rb_env = [] { const char* e = getenv("EMCID_LINEAR_RB"); return e ? atoi(e) : 4; }();
-    const int rb = rb_env >= 1 ? rb_env : 1;
+    const int rb = 4;        // row tiles per super-row of the tile order (profiles/r03_ab_linear_tile_order.txt)
     const LinearArgs a{X, ldx, W, ldw, bias, residual, ldr, Y, ldy, (int)M, (int)N, (int)K, act, tiles_n, tiles, rb};
     ScopedProf sp(KC_LINEAR, st);
     if (parts >= 2) {

@@ -692,9 +692,9 @@ struct EpiDeltaW {
 // With a triangular operand the K depth of an output tile grows linearly along one tile dimension, so "one tile per
 // workgroup" leaves the chip waiting for the deepest tiles, and small tiles (for balance) give up the efficiency of the
 // 128x128 configuration.  Here the (tile, K-step) space is linearised — column tile major, 16-deep K steps — and cut into
-// equal runs, one per workgroup: a run covers the tail of one tile, some whole tiles, the head of another.  Whole tiles
-// are stored directly; the two partial ones are added with f64 atomics into C, which the caller zeroes first.  No
-// workgroup waits for another.  Only B-side triangles (tri = 1 or 2) and the f64 EpiAxpby epilogue.
+// equal runs, one per workgroup: a run covers the tail of one tile, some whole tiles, the head of another.  (Round 1 added
+// the partial tiles into a zeroed C with f64 atomics; that form is gone: the two-phase form below is faster and
+// bit-reproducible.)  Only B-side triangles (tri = 1 or 2) and the f64 EpiAxpby epilogue.
 __device__ __forceinline__ int streamk_depth(const GemmShape& p, int bn, int BN, int BK) {
     const int KT = (p.K + BK - 1) / BK;
     if (p.tri & 1) return min(KT, (min(p.K, (bn + 1) * BN) + BK - 1) / BK);
@@ -702,83 +702,7 @@ __device__ __forceinline__ int streamk_depth(const GemmShape& p, int bn, int BN,
     return KT;
 }
 
-template <bool KCA, bool KCB, int BM, int BN, int BK, int WGM, int WGN>
-__global__ __launch_bounds__(WGM* WGN * 64) void gemm_f64_streamk_kernel(GemmShape p, EpiAxpby epi, long long total_units,
-                                                                           long long units_per_wg) {
-    using TA = OpTile<KCA, BM, BK>;
-    using TB = OpTile<KCB, BN, BK>;
-    __shared__ __attribute__((aligned(16))) double smem[2 * (TA::SIZE + TB::SIZE)];
-    const int MT = (p.M + BM - 1) / BM, NTL = (p.N + BN - 1) / BN;
-    long long u = (long long)blockIdx.x * units_per_wg;
-    const long long u1 = min(total_units, u + units_per_wg);
-    if (p.lower_only) {
-        // SYRK-like: the lower tiles (bn <= bm) of a square output, every tile the full K deep, numbered row by row;
-        // C holds a start value (the caller's), so every run ADDS its part
-        const int KT = (p.K + BK - 1) / BK;
-        GemmShape q = p;
-        q.lower_only = 0;
-        while (u < u1) {
-            const long long t = u / KT;
-            int bm = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-            while ((long long)(bm + 1) * (bm + 2) / 2 <= t) ++bm;
-            while ((long long)bm * (bm + 1) / 2 > t) --bm;
-            const int bn = (int)(t - (long long)bm * (bm + 1) / 2);
-            const int k_begin = (int)(u - t * KT);
-            const int k_end = (int)min((long long)KT, k_begin + (u1 - u));
-            EpiAxpby e = epi;
-            e.atomic = 1;
-            gemm_f64_tile<KCA, KCB, BM, BN, BK, WGM, WGN>(q, e, bm, bn, 0, smem, k_begin, k_end);
-            u += k_end - k_begin;
-        }
-        return;
-    }
-    // locate the column tile of unit u: prefix sums of MT * depth(bn)
-    int bn = 0;
-    long long base = 0;     // first unit of column tile bn
-    while (bn < NTL) {
-        const long long span = (long long)MT * streamk_depth(p, bn, BN, BK);
-        if (u < base + span) break;
-        base += span;
-        ++bn;
-    }
-    while (u < u1 && bn < NTL) {
-        const int depth = streamk_depth(p, bn, BN, BK);
-        const long long span = (long long)MT * depth;
-        if (depth == 0 || u >= base + span) { base += span; ++bn; continue; }
-        const int bm = (int)((u - base) / depth);
-        const int k_begin = (int)((u - base) % depth);
-        const int k_end = (int)min((long long)depth, k_begin + (u1 - u));
-        EpiAxpby e = epi;
-        e.atomic = (k_begin != 0 || k_end != depth) ? 1 : 0;
-        gemm_f64_tile<KCA, KCB, BM, BN, BK, WGM, WGN>(p, e, bm, bn, 0, smem, k_begin, k_end);
-        u += k_end - k_begin;
-    }
-}
-
-// C must be zero on entry (partial tiles accumulate atomically); alpha is applied, beta is ignored.
-// lower_only (M == N): every run adds into C, whose content on entry is the start value (e.g. the identity).
-template <bool KCA, bool KCB>
-inline void launch_gemm_f64_streamk(GemmShape p, EpiAxpby epi, hipStream_t stream, int wgs) {
-    constexpr int BM = 128, BN = 128, BK = 16;
-    const int MT = (p.M + BM - 1) / BM, NTL = (p.N + BN - 1) / BN, KT = (p.K + BK - 1) / BK;
-    long long total = 0;
-    if (p.lower_only) total = (long long)MT * (MT + 1) / 2 * KT;      // square output, lower tiles, full K
-    else for (int bn = 0; bn < NTL; ++bn) {
-        int depth = KT;
-        if (p.tri & 1) { const int ke = p.K < (bn + 1) * BN ? p.K : (bn + 1) * BN; depth = (ke + BK - 1) / BK; if (depth > KT) depth = KT; }
-        else if (p.tri & 2) { const int kb = bn * BN < p.K ? bn * BN : p.K; depth = KT - kb / BK; }
-        total += (long long)MT * depth;
-    }
-    if (total <= 0) return;
-    long long per = (total + wgs - 1) / wgs;
-    if (per < 8) per = 8;                                   // never less than half a 128-deep step per workgroup
-    const unsigned grid = (unsigned)((total + per - 1) / per);
-    epi.beta = 0.0;
-    hipLaunchKernelGGL((gemm_f64_streamk_kernel<KCA, KCB, BM, BN, BK, 2, 4>), dim3(grid), dim3(512), 0, stream, p, epi, total, per);
-}
-
-
-// ---- stream-K, second form: no atomics, no zero fill, bit-reproducible ---------------------------------------------------
+// ---- stream-K: no atomics, no zero fill, bit-reproducible ---------------------------------------------------
 // Same partition as above (the (tile, K-step) space cut into equal runs), but a run's partial tiles go to a workspace slot
 // (lane-linear image of the accumulators, 16-byte write-through stores) instead of being added into C with f64 atomics:
 //   * a run holds at most two partial segments: its first (the tail of a tile an earlier run started) and its last (the
@@ -990,39 +914,28 @@ inline void launch_gemm_f64_streamk2_tile(GemmShape p, EpiAxpby epi, hipStream_t
     long long per = (total + wgs - 1) / wgs;
     if (per < 128 / BK) per = 128 / BK;                      // never less than a 128-deep run per workgroup
     unsigned grid = (unsigned)((total + per - 1) / per);
-    static const int xcd_map = [] { const char* v = getenv("EMCID_STREAMK_XCD"); return v ? atoi(v) : 1; }();
-    int map = xcd_map;
+    int map = 1;
     if (grid % 8) {                    // keep the XCD dealing exact: round the grid up (trailing runs are empty)
         const unsigned g8 = (grid + 7) / 8 * 8;
         if ((int)g8 <= wgs) grid = g8; else map = 0;
     }
     // the ticket counters sit behind the slot area of the ALLOCATION (fixed place, whatever tile shape a launch uses)
     StreamKWork w{work, reinterpret_cast<unsigned*>(work + (int64_t)2 * wgs_alloc * 128 * 128), diag_add, g_streamk_stamps};
-    static const int fast = [] { const char* v = getenv("EMCID_GEMM_FAST"); return v ? atoi(v) : 1; }();
-    p.nofast = !fast;
+    p.nofast = 0;
     // 11: one K tile of global loads in flight + LDS fragments of the next k8 step fetched ahead.  With the interior fast path
     // this instantiation runs the SYRK 20 % faster than the plain one (80 vs 100 us) and the triangular GEMMs 1-2 % faster
-    static const int pf = [] { const char* v = getenv("EMCID_STREAMK_PF"); return v ? atoi(v) : 11; }();
     constexpr int NTH = WGM * WGN * 64;
-    if (pf == 11) hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, WGM, WGN, 11>), dim3(grid), dim3(NTH), 0, stream, p, epi, w, total, per, map);
-    else if (pf <= 1) hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, WGM, WGN, 1>), dim3(grid), dim3(NTH), 0, stream, p, epi, w, total, per, map);
-    else hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, WGM, WGN, 2>), dim3(grid), dim3(NTH), 0, stream, p, epi, w, total, per, map);
+    hipLaunchKernelGGL((gemm_f64_streamk2_kernel<KCA, KCB, BM, BN, BK, WGM, WGN, 11>), dim3(grid), dim3(NTH), 0, stream, p, epi, w, total, per, map);
 }
 
 template <bool KCA, bool KCB, int BK>
 inline void launch_gemm_f64_streamk2_bk(GemmShape p, EpiAxpby epi, hipStream_t stream, int wgs, double* work, double diag_add) {
-    // EMCID_STREAMK_TILE (experiment): 1 = 64 x 128 tiles on 4-wave workgroups, two per compute unit with independent barriers
-    // (triangular GEMMs only: the SYRK numbering wants square tiles); 2 = 64 x 64 tiles, 4 waves, three per compute unit
     // Measured (scripts/mb_tri.py, us: Yt = Kt X^T / U = G X / S = I + Yt Yt^T): 128 x 128 214 / 168 / 81, 64 x 128 270 / 222 / -,
-    // 64 x 64 243 / 217 / 74: independent barriers do not make up for the smaller tiles' operand traffic, except on the SYRK's 36
-    // big tiles -> the SYRK takes 64 x 64 by default (EMCID_STREAMK_SYRK_TILE=0: 128 x 128)
-    static const int tile = [] { const char* v = getenv("EMCID_STREAMK_TILE"); return v ? atoi(v) : 0; }();
-    static const int syrk_tile = [] { const char* v = getenv("EMCID_STREAMK_SYRK_TILE"); return v ? atoi(v) : 2; }();
+    // 64 x 64 243 / 217 / 74: the smaller tiles' independent barriers do not make up for their operand traffic, except on the
+    // SYRK's 36 big tiles and on products with at most 128 rows (a 100-concept edit: ONE row of 128 x 128 tiles, every tile cut
+    // over ~10 workgroups: inv_apply 0.575 -> 0.509 ms per 100-concept call): those take 64 x 64.
     if constexpr (BK == 16) {
-        if (tile == 1 && !p.lower_only) { launch_gemm_f64_streamk2_tile<KCA, KCB, BK, 64, 128, 2, 2>(p, epi, stream, wgs, 2, work, diag_add); return; }
-        // a product with at most 128 rows (a 100-concept edit: ONE row of 128 x 128 tiles, every tile cut over ~10 workgroups) also
-        // takes the 64 x 64 tiles: inv_apply 0.575 -> 0.509 ms per 100-concept call (EMCID_STREAMK_TILE=3: 128 x 128 there too)
-        if (tile == 2 || (p.lower_only && syrk_tile == 2) || (tile == 0 && !p.lower_only && p.M <= 128)) {
+        if (p.lower_only || p.M <= 128) {
             launch_gemm_f64_streamk2_tile<KCA, KCB, BK, 64, 64, 2, 2>(p, epi, stream, wgs, 3, work, diag_add);
             return;
         }
@@ -1035,13 +948,8 @@ inline void launch_gemm_f64_streamk2_bk(GemmShape p, EpiAxpby epi, hipStream_t s
 template <bool KCA, bool KCB>
 inline void launch_gemm_f64_streamk2(GemmShape p, EpiAxpby epi, hipStream_t stream, int wgs, double* work, double diag_add = 0.0) {
     const int MT = (p.M + 127) / 128, NTL = (p.N + 127) / 128;
-    if ((long long)MT * NTL > 16384) {      // more tiles than ticket counters: the atomic form (needs C zeroed / preset by the caller)
-        launch_gemm_f64_streamk<KCA, KCB>(p, epi, stream, wgs);
-        return;
-    }
-    static const int bk = [] { const char* v = getenv("EMCID_STREAMK_BK"); return v ? atoi(v) : 16; }();
-    if (bk == 32) launch_gemm_f64_streamk2_bk<KCA, KCB, 32>(p, epi, stream, wgs, work, diag_add);
-    else launch_gemm_f64_streamk2_bk<KCA, KCB, 16>(p, epi, stream, wgs, work, diag_add);
+    if ((long long)MT * NTL > 16384) return;      // more tiles than ticket counters: refused by every caller before it gets here
+    launch_gemm_f64_streamk2_bk<KCA, KCB, 16>(p, epi, stream, wgs, work, diag_add);
 }
 
 // ---- launcher ----------------------------------------------------------------------------------
@@ -1066,12 +974,8 @@ inline void launch_gemm_f64(GemmShape p, Epi epi, hipStream_t stream, int force_
     // measured on the M ~ 1000 solve shapes (scripts/mb_shapes.py): 32x64 beats 64x64 whenever 128x128 cannot fill the chip
     // (re-measured with the prefetch ring in the small-tile kernels: 32x64 also wins between 224 and 512 big tiles, e.g.
     // the batched Cholesky trailing updates: chol_trail 0.93 -> 0.86 ms per step)
-    static const int big_min = [] { const char* v = getenv("EMCID_GEMM_BIG"); return v ? atoi(v) : 512; }();      // experiments
-    int cfg = (big_tiles >= big_min) ? 0 : (KCA ? 2 : 1);
+    int cfg = (big_tiles >= 512) ? 0 : (KCA ? 2 : 1);
     if (force_cfg >= 0) cfg = force_cfg;
-    static const int env_cfg = [] { const char* v = getenv("EMCID_GEMM_CFG"); return v ? atoi(v) : -1; }();      // experiments
-    static const int env_split = [] { const char* v = getenv("EMCID_GEMM_KSPLIT"); return v ? atoi(v) : -1; }();
-    if (env_cfg >= 0) cfg = env_cfg;
     if (cfg == 2 && !KCA) cfg = 1;
     // too few workgroups to hide the global->LDS latency of a shallow tile: split K (accumulating epilogues only)
     const int64_t wgs = cfg == 0 ? big_tiles : cfg == 1 ? mid_tiles : tiles(32, 64);
@@ -1081,7 +985,6 @@ inline void launch_gemm_f64(GemmShape p, Epi epi, hipStream_t stream, int force_
         p.ksplit = (int)(want < cap ? want : cap);
         if (p.ksplit < 1) p.ksplit = 1;
     }
-    if (env_split >= 0 && epi_accumulates(epi)) p.ksplit = env_split > 0 ? env_split : 1;
     if (p.kchunk > 0) {   // fixed-length runs: as many z-slices as the longest K range needs
         p.ksplit = epi_accumulates(epi) ? (ktiles + p.kchunk - 1) / p.kchunk : 1;
         if (p.ksplit == 1) p.kchunk = 0;
@@ -1089,15 +992,11 @@ inline void launch_gemm_f64(GemmShape p, Epi epi, hipStream_t stream, int force_
     if (p.ksplit > 1) epi_set_atomic(epi);
     const unsigned gz = (unsigned)(p.batch * p.batch2 * p.ksplit);
     if (p.pair && (p.tri == 0 || p.lower_only)) p.pair = 0;
-    static const int env_xcd_rows = [] { const char* v = getenv("EMCID_GEMM_XCD_ROWS"); return v ? atoi(v) : 1; }();
-    p.xcd_rows = (env_xcd_rows && (p.tri & 3) && !(p.tri & 12) && !p.lower_only && !p.pair) ? 1 : 0;
+    p.xcd_rows = ((p.tri & 3) && !(p.tri & 12) && !p.lower_only && !p.pair) ? 1 : 0;
     // prefetch ring for the small-tile configurations: needs an even extent along each operand's contiguous dimension
-    static const int env_pf = [] { const char* v = getenv("EMCID_GEMM_PF"); return v ? atoi(v) : 1; }();
-    p.pf = (env_pf && cfg != 0 && ((KCA ? p.K : p.M) % 2 == 0) && ((KCB ? p.K : p.N) % 2 == 0)) ? 1 : 0;
-    static const int env_fast = [] { const char* v = getenv("EMCID_GEMM_FAST"); return v ? atoi(v) : 1; }();
-    p.nofast = !env_fast;
-    static const int env_lo = [] { const char* v = getenv("EMCID_GEMM_LO_ENUM"); return v ? atoi(v) : 1; }();
-    if (env_lo && p.lower_only && !p.pair && p.tri == 0 && p.M == p.N && p.lower_shift == 0) {
+    p.pf = (cfg != 0 && ((KCA ? p.K : p.M) % 2 == 0) && ((KCB ? p.K : p.N) % 2 == 0)) ? 1 : 0;
+    p.nofast = 0;
+    if (p.lower_only && !p.pair && p.tri == 0 && p.M == p.N && p.lower_shift == 0) {
         const int bm_ = cfg == 0 ? 128 : cfg == 1 ? 64 : 32, r_ = (cfg == 0 ? 128 : 64) / bm_;
         const int gy_ = (p.M + bm_ - 1) / bm_, q_ = gy_ / r_, s_ = gy_ % r_;
         p.lo_total = r_ * q_ * (q_ + 1) / 2 + s_ * (q_ + 1);

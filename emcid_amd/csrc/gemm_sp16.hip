@@ -1280,12 +1280,16 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
         // 80 x 128 (waves side by side) where 128 x 128 tiles would not give every compute unit two workgroups (N = 768 at 6 292
         // rows: 300 tiles -> 474: out 30.7 against 35.1 us for the K-split tile, fc2 82.3 against 97.6); 160 x 128 for operands
         // far beyond the L2 and many rounds of tiles (36 335 rows: 339 against 369 us); 64 x 64 below 128 tiles of 80 rows.
+        // The largest of 128 x 128, 80 x 128, 64 x 64 that still gives ~400 workgroups (3 072 x 3 072 -> 768: 64 x 64 51.8 against
+        // 60.2 / 68.9 us; 2 100 x 768 -> 2 304: 80 x 128 28.0 against 44.5).  Below one 64 x 64 tile per compute unit a launch is
+        // latency-bound and the register-staged 64 x 64 loop with its two stages of loads in flight stays ahead on a long K
+        // (640 x 3 072 -> 768: 28 against 45 us): those keep the selection above (profiles/r05_mb_linear_sp16_small.txt).
         if (mfma16_env >= 2 && ldx < (1 << 20) && ldw < (1 << 20)) {
-            const int64_t t80 = ((M + 79) / 80) * ((N + 127) / 128);
-            if (t80 < 128) tile_sel = 11;
-            else if (t128 < 400) tile_sel = 10;
-            else if (t128 >= 1600 && M >= 16384) tile_sel = 9;
-            else tile_sel = 7;
+            const int64_t t80 = ((M + 79) / 80) * ((N + 127) / 128), t64 = ((M + 63) / 64) * ((N + 63) / 64);
+            if (t128 >= 1600 && M >= 16384) tile_sel = 9;
+            else if (t128 >= 400) tile_sel = 7;
+            else if (t80 >= 400) tile_sel = 10;
+            else if (t64 >= 256) tile_sel = 11;
         }
     }
     if ((tile_sel == 3 || tile_sel == 6) && K % 64 != 0) tile_sel = 0;

@@ -527,7 +527,6 @@ struct ShadowJob {
     double* C; int64_t ldc;           // [M][N]
     int M, N, K;
     int wgs;                          // workgroups per launch: ceil(M / 64) * ceil(ceil(N / 128) / 2); 0 = no job
-    int skip_xcd0;                    // keep the shadow workgroups off the XCD the leaf runs on
     long long* stamps;                // diagnostic (usually null): per launch slice and workgroup [start, mid, end, kind]
     int xcd_gx;                       // > 0: XCD-blocked tile assignment, the 8 XCDs as a xcd_gx x (8 / xcd_gx) grid (set by the launcher)
     int nofast;                       // GemmShape.nofast for the shadow tiles (EMCID_GEMM_FAST=0)
@@ -781,14 +780,6 @@ __global__ __launch_bounds__(LEAF_T) void chol_step_leaf_kernel(const double* __
     }
     ntrail += nxr;
     int s_ = (int)blockIdx.x - 1 - ntrail;
-    if (sh.skip_xcd0) {
-        // workgroups go to the 8 XCDs round-robin by linear id: those that would land on the leaf's XCD (id % 8 == 0) leave at
-        // once, so that XCD runs the leaf (and a few trailing tiles) alone, at its own clock, while the other seven carry the
-        // shadow product (the grid is enlarged by 8/7 accordingly)
-        if ((blockIdx.x & 7) == 0) return;
-        s_ -= (int)((blockIdx.x + 7) / 8) - (1 + ntrail + 7) / 8;
-        if (s_ >= sh.wgs) return;
-    }
     // (K-tile depth 32, 6 or 8 K tiles of loads in flight and LDS fragment prefetch were measured here as template variants:
     //  none moved the launch time by more than 1 us)
     shadow_pair<16, 3>(sh, s_, slice, nslices, lds);
@@ -936,12 +927,6 @@ __device__ __forceinline__ void chol_spine_body(const double* __restrict__ Ablk,
     }
 }
 
-__global__ __launch_bounds__(SP_T) void chol_spine_kernel(const double* __restrict__ Ablk, int64_t lda, const double* __restrict__ inv,
-                                                           int64_t ldi, double* __restrict__ Lout, int64_t ldl, double* __restrict__ D) {
-    __shared__ __attribute__((aligned(16))) double lds[SP_LDS];
-    chol_spine_body(Ablk, lda, inv, ldi, Lout, ldl, D, (int)blockIdx.x, lds);
-}
-
 // One launch = the spine step of block j (workgroups 0..35) AND the rest of panel j (32 x 64 tiles of L[j+2.., j] = A[j+2.., j]
 // inv(L_jj)^T): both need leaf j only, neither needs the other.
 __global__ __launch_bounds__(SP_T) void chol_step_spine_kernel(const double* __restrict__ Ablk, int64_t lda, const double* __restrict__ inv,
@@ -1017,8 +1002,7 @@ static void build_block_inverses(const double* L, int64_t dp, int64_t lda, doubl
     // level a: 256-blocks from pairs of 128-inverses.  u selects the pair inside an OB block.  ONE matrix with whole OB blocks
     // only (the N x N system of the dual solver at N = 1000): its second batch dimension is free, so the two pairs of every
     // block share a launch (two launches instead of four on the tail behind the last leaf, ~8 us each).
-    static const int pair_batch = env_flag("EMCID_INV_PAIR_BATCH", 1);
-    if (pair_batch && nmat == 1 && rem == 0 && nfull > 0) {
+    if (nmat == 1 && rem == 0 && nfull > 0) {
         const int64_t hopL = 2 * NB * (lda + 1), hopI = 2 * NB * (int64_t)(OB + 1), hopT = (int64_t)NB * TB;
         const double* Cb = L + (int64_t)NB * lda;
         double* Ai = inv_block(invw, 0);
@@ -1137,111 +1121,6 @@ static int cholesky_serial(double* A, double* L, int64_t dp, int64_t lda, double
 }
 
 
-// ---- small Cholesky with look-ahead (n <= 2048: the N x N system of the dual solver) -----------------------------------------------
-// The serial spine of a right-looking factorization is leaf -> (panel block + diagonal update of the NEXT block) -> leaf; everything
-// else of step j — the rest of the panel, the rest of the trailing update, the 512-block inverses the triangular solves want —
-// only has to be done before step j+2 reads it.  Here the spine runs on the caller's stream (leaf + chol_spine_kernel, ~45 us per
-// 128 columns) and the rest on a second stream, ordered by events; inside a captured graph the two become parallel branches.
-// (For the d x d statistics matrices this schedule lost: their bulk GEMMs fill the chip and the leaf, which wants a whole CU's
-// LDS, cannot start underneath them — see the note at cholesky_impl.  At n = 1024 the bulk is a handful of workgroups.)
-namespace {
-hipStream_t g_side_stream[MAX_DEVICES] = {};
-constexpr int EV_POOL = 96;
-hipEvent_t g_events[MAX_DEVICES][EV_POOL] = {};
-int side_stream_init(int dev, hipStream_t* out) {
-    if (dev < 0 || dev >= MAX_DEVICES) return fail(EMCID_ERR_BAD_ARG, "emcid side stream", "device ordinal out of range");
-    if (!g_side_stream[dev] && hipStreamCreateWithFlags(&g_side_stream[dev], hipStreamNonBlocking) != hipSuccess)
-        return fail(EMCID_ERR_HIP, "emcid side stream", "hipStreamCreateWithFlags");
-    for (int i = 0; i < EV_POOL; ++i)
-        if (!g_events[dev][i] && hipEventCreateWithFlags(&g_events[dev][i], hipEventDisableTiming) != hipSuccess)
-            return fail(EMCID_ERR_HIP, "emcid side stream", "hipEventCreateWithFlags");
-    *out = g_side_stream[dev];
-    return EMCID_OK;
-}
-}  // namespace
-
-static int cholesky_lookahead(double* A, double* L, int64_t n, int64_t lda, double* invw, int* info, hipStream_t st) {
-    const int nb = (int)(n / NB);
-    const int dev = current_device();
-    hipStream_t side = nullptr;
-    EMCID_TRY(side_stream_init(dev, &side));
-    int next_ev = 0;
-    auto signal = [&](hipStream_t from, hipStream_t to) {        // everything queued on `from` so far happens before what `to` gets next
-        hipEvent_t e = g_events[dev][next_ev++ % EV_POOL];
-        (void)hipEventRecord(e, from);
-        (void)hipStreamWaitEvent(to, e, 0);
-    };
-    hipLaunchKernelGGL(zero_f64_kernel, dim3(1024), dim3(256), 0, st, invw, inv_doubles(n));
-    signal(st, side);
-    double* tmp = invw + ((n + OB - 1) / OB) * (int64_t)OB * OB;
-    auto product = [&](const double* Am, int64_t ldA, bool b_lower, const double* Bm, int64_t ldB, double* Cm, int64_t ldC, int M,
-                       int N, int K, double alpha, hipStream_t q) {
-        GemmShape p{Am, ldA, Bm, ldB, M, N, K, 0};
-        p.tri = b_lower ? 2 : 0;
-        ScopedProf sp(KC_INV_BLOCK, q);
-        launch_gemm_f64<true, false>(p, EpiAxpby{Cm, ldC, alpha, 0.0}, q, 2);
-    };
-    auto level_a = [&](int J, int u, hipStream_t q) {         // the 256-block inverse from the pair (4J + 2u, 4J + 2u + 1) of 128-inverses
-        const double* Cb = L + ((int64_t)(J * 4 + 2 * u + 1) * NB) * lda + (int64_t)(J * 4 + 2 * u) * NB;
-        double* Ai = inv_block(invw, J) + (2 * u * NB) * (int64_t)(OB + 1);
-        double* Bi = inv_block(invw, J) + ((2 * u + 1) * NB) * (int64_t)(OB + 1);
-        double* X = inv_block(invw, J) + ((2 * u + 1) * NB) * (int64_t)OB + 2 * u * NB;
-        double* T = tmp + (int64_t)J * TB * TB;
-        product(Cb, lda, true, Ai, OB, T, TB, NB, NB, NB, 1.0, q);
-        product(Bi, OB, false, T, TB, X, OB, NB, NB, NB, -1.0, q);
-    };
-    auto level_b = [&](int J, int mrows, hipStream_t q) {     // the 512-block inverse from its two 256-halves (the lower may be short)
-        const double* Cb = L + ((int64_t)(J * 4 + 2) * NB) * lda + (int64_t)(J * 4) * NB;
-        double* Ai = inv_block(invw, J);
-        double* Bi = inv_block(invw, J) + (2 * NB) * (int64_t)(OB + 1);
-        double* X = inv_block(invw, J) + (2 * NB) * (int64_t)OB;
-        double* T = tmp + (int64_t)J * TB * TB;
-        product(Cb, lda, true, Ai, OB, T, TB, mrows, 2 * NB, 2 * NB, 1.0, q);
-        product(Bi, OB, false, T, TB, X, OB, mrows, 2 * NB, mrows, -1.0, q);
-    };
-    auto inverses_ready_after_block = [&](int j, hipStream_t q) {   // j: a block whose leaf and whose row of L are complete
-        const int J = j / 4, r = j % 4;
-        if (r == 1 || r == 3) level_a(J, r / 2, q);
-        const int last_in_J = (4 * J + 3 < nb) ? 4 * J + 3 : nb - 1;
-        if (j == last_in_J && last_in_J - 4 * J >= 2) level_b(J, (last_in_J - 4 * J - 1) * NB, q);
-    };
-    for (int j = 0; j < nb; ++j) {
-        const int64_t o = (int64_t)j * NB;
-        double* inv = inv_block(invw, j / 4) + ((j % 4) * NB) * (int64_t)(OB + 1);
-        {
-            ScopedProf sp(KC_CHOL_LEAF, st);
-            hipLaunchKernelGGL(chol_leaf_kernel, dim3(1), dim3(LEAF_T), 0, st, A + o * lda + o, lda, L + o * lda + o, lda, inv,
-                               (int64_t)OB, info, (int)o, (long long*)nullptr, (int64_t)0, (int64_t)0);
-        }
-        if (j == nb - 1) break;
-        if (j > 0) signal(side, st);            // bulk j-1 has brought block column j+1 up to date through column j-1
-        {
-            ScopedProf sp(KC_CHOL_PANEL, st);
-            hipLaunchKernelGGL(chol_spine_kernel, dim3(36), dim3(SP_T), 0, st, A + (o + NB) * lda + o, lda, inv, (int64_t)OB,
-                               L + (o + NB) * lda + o, lda, A + (o + NB) * lda + o + NB);
-        }
-        signal(st, side);                       // leaf j and L[j+1, j] are there
-        inverses_ready_after_block(j, side);    // block j's own row of L was finished by step j-1
-        const int m2 = (int)(n - o - 2 * NB);
-        if (m2 > 0) {
-            GemmShape ps{A + (o + 2 * NB) * lda + o, lda, inv, OB, m2, NB, NB, 0};
-            ps.tri = 1;
-            {
-                ScopedProf sp(KC_CHOL_PANEL, side);
-                launch_gemm_f64<true, true>(ps, EpiAxpby{L + (o + 2 * NB) * lda + o, lda, 1.0, 0.0}, side);
-            }
-            // A[r, c] -= L[r, j] L[c, j]^T for rows r >= j+2, columns j+1 <= c <= r (block (j+1, j+1) was the spine's)
-            GemmShape ts{L + (o + 2 * NB) * lda + o, lda, L + (o + NB) * lda + o, lda, m2, m2 + NB, NB, 1};
-            ts.lower_shift = NB;
-            ScopedProf sp(KC_CHOL_INNER, side);
-            launch_gemm_f64<true, true>(ts, EpiAxpby{A + (o + 2 * NB) * lda + o + NB, lda, -1.0, 1.0}, side);
-        }
-    }
-    signal(side, st);
-    inverses_ready_after_block(nb - 1, st);
-    return check_launch("emcid_cholesky_f64");
-}
-
 // ---- small Cholesky, two heterogeneous launches per 128 columns (n <= 2048) -------------------------------------------------------
 // Step j:   launch A_j = { leaf j }  +  { trailing update of step j-1 minus the block the leaf needs }
 //           launch B_j = { spine step j: L[j+1, j] and the next diagonal block }  +  { the rest of panel j }
@@ -1269,23 +1148,17 @@ static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, do
             }
             ShadowJob sh{};
             if (shadow) sh = *shadow;
-            static const int skip0 = env_flag("EMCID_SHADOW_SKIP_XCD0", 0);
-            sh.skip_xcd0 = skip0;
             sh.stamps = g_step_stamps;
             sh.xcd_gx = 0;
-            static const int gemm_fast = env_flag("EMCID_GEMM_FAST", 1);
-            sh.nofast = !gemm_fast;
-            static const int fuse_pair = env_flag("EMCID_SHADOW_FUSE", 1);
-            sh.fuse_pair = fuse_pair;
-            static const int xcd_block = env_flag("EMCID_SHADOW_XCD_BLOCK", 1);
-            if (xcd_block && sh.wgs && !skip0 && sh.wgs % 8 == 0) {
+            sh.nofast = 0;
+            sh.fuse_pair = 1;
+            if (sh.wgs && sh.wgs % 8 == 0) {
                 const int mb = (sh.M + SH_BM - 1) / SH_BM, np_ = ((sh.N + SH_BN - 1) / SH_BN + 1) / 2;
                 // (shadow ids with the same s_ % 8 land on the same XCD whatever the id of the first one is)
                 for (int gx : {4, 2, 8, 1})
                     if (mb % gx == 0 && np_ % (8 / gx) == 0) { sh.xcd_gx = gx; break; }
             }
-            // with skip_xcd0 one id in eight is a no-op: enough ids that sh.wgs of them are not multiples of 8
-            const int shadow_ids = (sh.wgs && skip0) ? (sh.wgs * 8 + 6) / 7 + 8 : sh.wgs;
+            const int shadow_ids = sh.wgs;
             // XrowJob: Tt = Xt[0:o, 0:o] L[j, 0:j]^T on 32 x 64 tiles (K range from the tile's own first row on: X is lower
             // triangular, Xt upper)
             GemmShape xr{L, lda, L, lda, 0, 0, NB, 0};
@@ -1355,19 +1228,15 @@ static int cholesky_fused_steps(double* A, double* L, int64_t n, int64_t lda, do
 // panel/trailing on a side stream — was built and measured 6-11 % SLOWER, eager and as a graph: the leaf needs a
 // whole CU's LDS, so it cannot start while the bulk GEMM keeps every CU populated.  Kept serial.)
 static inline bool cholesky_takes_shadow(int64_t dp) {      // the schedule whose leaf launches can carry a ShadowJob
-    static const int lookahead = env_flag("EMCID_CHOL_LOOKAHEAD", 0), fused = env_flag("EMCID_CHOL_FUSED", 1);
-    return !lookahead && fused && dp <= 2048 && dp >= 2 * NB;
+    return dp <= 2048 && dp >= 2 * NB;
 }
 
 static int cholesky_impl(double* A, double* L, int64_t dp, int64_t lda, double* invw, int* info, hipStream_t st,
                          const ShadowJob* shadow = nullptr, const XrowJob* xrow = nullptr) {
-    // Off by default: measured on MI355X / ROCm 7.2 (bench.py device step, 4 layers, N = 1000): 13.3 ms serial -> 22.3 ms with the
-    // look-ahead schedule inside the captured graph — every fork/join between the two capture streams costs ~70 us of graph
-    // execution — and 14.2 ms with both run eagerly (host-launch bound).  Kept for the day parallel graph branches are cheap.
-    static const int lookahead = env_flag("EMCID_CHOL_LOOKAHEAD", 0);
-    if (lookahead && dp <= 2048 && dp >= 2 * NB) return cholesky_lookahead(A, L, dp, lda, invw, info, st);
-    static const int fused = env_flag("EMCID_CHOL_FUSED", 1);
-    if (fused && dp <= 2048 && dp >= 2 * NB) return cholesky_fused_steps(A, L, dp, lda, invw, info, st, shadow, xrow);
+    // (A look-ahead schedule on two streams — spine on the caller's, bulk on a side stream — was built in rounds 1-2 and lost:
+    // 13.3 -> 22.3 ms per device step inside the captured graph, every fork / join between capture streams costing ~70 us;
+    // removed in round 5, DESIGN.md "measured and dropped".)
+    if (cholesky_takes_shadow(dp)) return cholesky_fused_steps(A, L, dp, lda, invw, info, st, shadow, xrow);
     if (shadow || xrow) return fail(EMCID_ERR_BAD_ARG, "cholesky_impl", "shadow / inverse job without the fused schedule");
     return cholesky_serial(A, L, dp, lda, invw, info, st);
 }
@@ -1458,8 +1327,7 @@ static int build_full_inverse(const double* L, int64_t dp, int64_t lda, const do
     const int nob = (int)((dp + OB - 1) / OB);
     // 32x64 tiles in mirrored pairs: 1.06 ms for 4 x 3072^2 vs 1.30 ms with the launcher's own choice
     // (scripts/inverse_alone.py sweeps these)
-    static const int cfg_a = env_flag("EMCID_INV_CFG_A", 2), cfg_b = env_flag("EMCID_INV_CFG_B", 2);
-    static const int pair_ = env_flag("EMCID_INV_PAIR", 1);
+    constexpr int cfg_a = 2, cfg_b = 2, pair_ = 1;
     // Recursion over block ranges [b0, b1).  When the two halves of a range are the same problem (equal block counts, no
     // short last block) they are solved ONCE with the copy count doubled: `reps` copies of the range sit `stride` blocks
     // apart on the diagonal and share every launch through the GEMM's second batch dimension.
@@ -1501,7 +1369,6 @@ static int build_full_inverse(const double* L, int64_t dp, int64_t lda, const do
 // into a zeroed output.  Measured for 1024 x 3072 x 3072: 218 us (zeroing included) against 253 us for mirrored 32x64
 // tile pairs and 306 us for plain 64x64 tiles; 768 rows: 188 / 238 / 299 us (scripts/mb_tri.py).
 static const int kStreamKWgs = 256;
-static const int kStreamKForm = env_flag("EMCID_STREAMK_V", 2);      // 2: two-phase, reproducible; 1: f64 atomics into a zeroed C
 
 // With the interior fast path of the small-tile ring, mirrored PAIRS of 32 x 64 tiles (every workgroup contracts over the same
 // total depth, three 4-wave workgroups per compute unit, no split, no fix-up) beat the stream-K form whenever their count fills
@@ -1509,8 +1376,6 @@ static const int kStreamKForm = env_flag("EMCID_STREAMK_V", 2);      // 2: two-p
 // rows 146 / 161; 512 rows 104 / 118), and for very few rows on the backward product (128 rows: 114 / 80; 256: 98 / 81), where a
 // stream-K run is mostly fix-up.  EMCID_TRI_PAIRS=0 keeps stream-K everywhere.
 static inline bool pairs_fill_the_chip(int rows, int64_t dp, bool backward) {
-    static const int enabled = env_flag("EMCID_TRI_PAIRS", 1);
-    if (!enabled) return false;
     const int64_t wgs = (int64_t)((rows + 31) / 32) * (((dp + 63) / 64 + 1) / 2);
     // (at most 128 rows: the stream-K form on 64 x 64 tiles is ahead — P = Yt X of a 100-concept edit 75 -> 54 us, inv_apply 0.51 -> 0.42 ms per call)
     if (backward && rows <= 256 && rows > 128) return true;
@@ -1530,12 +1395,12 @@ static void apply_inverse_forward(const double* X, int64_t dp, const double* Kt,
         launch_gemm_f64<true, true>(g, EpiAxpby{Yt, dp, 1.0, 0.0}, st, 2);
         return;
     }
-    if (sk_work && kStreamKForm == 2) {
+    if (sk_work) {
         launch_gemm_f64_streamk2<true, true>(g, EpiAxpby{Yt, dp, 1.0, 0.0}, st, kStreamKWgs, sk_work);
         return;
     }
-    hipLaunchKernelGGL(zero2d_f64_kernel, dim3((unsigned)rows, 1u), dim3(256), 0, st, Yt, dp, (int64_t)0, (int)dp);
-    launch_gemm_f64_streamk<true, true>(g, EpiAxpby{Yt, dp, 1.0, 0.0}, st, kStreamKWgs);
+    g.pair = 1;      // (no stream-K workspace: mirrored tile pairs)
+    launch_gemm_f64<true, true>(g, EpiAxpby{Yt, dp, 1.0, 0.0}, st, 2);
 }
 
 // C[rows, ncols] (f64, leading dimension ldc) = V[rows, dp] * X  (= V L^-1: the backward substitution as one GEMM)
@@ -1549,12 +1414,12 @@ static void apply_inverse_backward(const double* X, int64_t dp, const double* V,
         launch_gemm_f64<true, false>(g, EpiAxpby{C, ldc, 1.0, 0.0}, st, 2);
         return;
     }
-    if (sk_work && kStreamKForm == 2) {
+    if (sk_work) {
         launch_gemm_f64_streamk2<true, false>(g, EpiAxpby{C, ldc, 1.0, 0.0}, st, kStreamKWgs, sk_work);
         return;
     }
-    hipLaunchKernelGGL(zero2d_f64_kernel, dim3((unsigned)rows, 1u), dim3(256), 0, st, C, ldc, (int64_t)0, ncols);
-    launch_gemm_f64_streamk<true, false>(g, EpiAxpby{C, ldc, 1.0, 0.0}, st, kStreamKWgs);
+    g.pair = ncols == (int)dp ? 1 : 0;      // (no stream-K workspace: mirrored tile pairs where the output is the whole width)
+    launch_gemm_f64<true, false>(g, EpiAxpby{C, ldc, 1.0, 0.0}, st, 2);
 }
 
 // layout of the covariance-factor workspace (emcid_factor_cov_f64): [M | L | 512-block inverses | X = inv(L)] x n_layers
@@ -1604,8 +1469,6 @@ static int with_graph(const GraphKey& key_in, hipStream_t st, F&& body) {
     for (int i = 0; i < g_graph_n; ++i)
         if (g_graphs[i].key == key) { slot = &g_graphs[i]; break; }
     if (!slot) {
-        static const int trace = env_flag("EMCID_GRAPH_TRACE", 0);
-        if (trace) fprintf(stderr, "[emcid graph] capture tag %lld (cached %d of %d)\n", (long long)key.num[5], g_graph_n, GRAPH_SLOTS);
         hipStream_t cap = nullptr;
         EMCID_TRY(capture_stream_init((int)key.dev, &cap));
         if (hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) != hipSuccess)
@@ -1683,16 +1546,11 @@ static void assemble_dual_system(const double* P, const double* Q, int64_t dp, d
                                  double* sk_work = nullptr) {
     ScopedProf sp(KC_ASSEMBLE, st);
     GemmShape g{P, dp, Q, dp, Np, Np, (int)dp, 1};
-    static const int streamk = env_flag("EMCID_SYRK_STREAMK", 1);
-    if (streamk && Np >= 512 && sk_work && kStreamKForm == 2) {    // S = I + P Q^T written once per tile, no identity pass
+    if (Np >= 512 && sk_work) {    // S = I + P Q^T written once per tile, no identity pass
         launch_gemm_f64_streamk2<true, true>(g, EpiAxpby{S, Np, 1.0, 0.0}, st, kStreamKWgs, sk_work, 1.0);
         return;
     }
     hipLaunchKernelGGL(eye_f64_kernel, dim3((unsigned)Np), dim3(256), 0, st, S, Np);
-    if (streamk && Np >= 512) {   // lower 128x128 tiles x K cut into 256 equal runs, added atomically into the identity
-        launch_gemm_f64_streamk<true, true>(g, EpiAxpby{S, Np, 1.0, 1.0}, st, 256);
-        return;
-    }
     const int kt = (int)(dp / 16);
     g.ksplit = kt >= 64 ? 4 : kt >= 32 ? 2 : 1;
     launch_gemm_f64<true, true>(g, EpiAxpby{S, Np, 1.0, 1.0}, st, Np >= 512 ? 1 : 2);
@@ -1825,14 +1683,6 @@ int emcid_dgemm_ex_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double a
     if (ksplit < 0) p.kchunk = -ksplit;
     EpiAxpby e{C, ldc, alpha, beta};
     ScopedProf sp(KC_DGEMM, st);
-    if (cfg == 4) {   // stream-K over a B-side triangle: ksplit = number of workgroups (0: 512); C is zeroed here
-        EMCID_CHECK_ARG(ta == 0 && (p.tri == 1 || p.tri == 2) && !p.lower_only);
-        hipLaunchKernelGGL(zero2d_f64_kernel, dim3((unsigned)M, 1u), dim3(256), 0, st, C, ldc, (int64_t)0, (int)N);
-        if (tb == 0) launch_gemm_f64_streamk<true, true>(p, e, st, ksplit > 0 ? ksplit : 512);
-        else launch_gemm_f64_streamk<true, false>(p, e, st, ksplit > 0 ? ksplit : 512);
-        EMCID_CHECK_LAUNCH();
-        return EMCID_OK;
-    }
     if (ta == 0 && tb == 0) launch_gemm_f64<true, true>(p, e, st, cfg);
     else if (ta == 0 && tb == 1) launch_gemm_f64<true, false>(p, e, st, cfg);
     else if (ta == 1 && tb == 0) launch_gemm_f64<false, true>(p, e, st, cfg);
@@ -1851,6 +1701,7 @@ int emcid_dgemm_streamk_f64(int tb, int64_t M, int64_t N, int64_t K, double alph
     EMCID_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30) && (flags & ~19) == 0);
     const int tri = flags & 3, lower = (flags >> 4) & 1;
     EMCID_CHECK_ARG((lower && M == N && tri == 0) || (!lower && (tri == 1 || tri == 2)));
+    EMCID_CHECK_ARG(((M + 127) / 128) * ((N + 127) / 128) <= 16384);      // one ticket counter per 128 x 128 tile
     if (workspace_bytes < emcid_streamk_workspace_bytes(wgs)) return fail(EMCID_ERR_WORKSPACE, __func__, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
     GemmShape p{A, lda, B, ldb, (int)M, (int)N, (int)K, lower};
@@ -2270,8 +2121,7 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
     // Few concepts (a 100-concept edit: Np = 128, no chain of leaves to ride in): U = Z^T (Yt X) with the triangle multiplied on the
     // Np-row side as a launch of its own, instead of U = (Z^T Yt) X on the h-row side — 128 rows against 768 at SD dims
     // (61 + ~15 us instead of ~20 + 155 per layer).  EMCID_P_FIRST=0: the h-side form.
-    static const int p_first_env = env_flag("EMCID_P_FIRST", 1);
-    const bool p_first = p_first_env && !shadow && use_inverse && Np < h;
+    const bool p_first = !shadow && use_inverse && Np < h;
     static const int s_inverse = env_flag("EMCID_S_INVERSE", 1);
     static const int xrow_env = env_flag("EMCID_XROW", 1);
     const bool xrow = xrow_env && s_inverse && cholesky_takes_shadow(Np);       // (= the fused leaf / spine schedule runs)
@@ -2285,7 +2135,7 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
             assemble_dual_system(Yt, Yt, dp, S, (int)Np, q, base + ws.off_SK);      // S = I + Yt Yt^T (lower tiles)
         }
         if (p_first) apply_inverse_backward(X, dp, Yt, (int)Np, (int)dp, P, dp, q, base + ws.off_SK);       // P = Yt X
-        ShadowJob job{Yt, dp, X, dp, P, dp, (int)Np, (int)dp, (int)dp, 0, 0, nullptr, 0, 0, 0};
+        ShadowJob job{Yt, dp, X, dp, P, dp, (int)Np, (int)dp, (int)dp, 0, nullptr, 0, 0, 0};
         job.wgs = (int)((Np + SH_BM - 1) / SH_BM) * (int)(((dp + SH_BN - 1) / SH_BN + 1) / 2);
         // XS = inv(LS) rides in the factorization's launches (XrowJob), transposed
         const XrowJob xj{XT, Np, TT};
@@ -2333,8 +2183,7 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
         // W0 / W / dW are the caller's tensors and change from layer to layer and call to call)
         ScopedProf sp(KC_DELTA_W, st);
         GemmShape g{RT, Np, P, dp, (int)h, (int)d, (int)Np, 0};
-        static const int u_cfg = env_flag("EMCID_U_GEMM_CFG", -1);      // -1: the launcher's choice (32 x 64 tiles); 1: 64 x 64; 0: 128 x 128
-        launch_gemm_f64<true, false>(g, EpiDeltaW{W0, W, d, dW_out, d, nullptr, 0}, st, u_cfg);
+        launch_gemm_f64<true, false>(g, EpiDeltaW{W0, W, d, dW_out, d, nullptr, 0}, st, -1);      // the launcher's choice: 32 x 64 tiles
         EMCID_CHECK_LAUNCH();
         return EMCID_OK;
     }

@@ -101,7 +101,6 @@ class EncoderEditPlan:
     tokenizer: object = None
     local_requests: Optional[List[Dict]] = None
     zs_pending: object = None
-    gemm_tuning_s: float = 0.0           # one-off TunableOp time spent in prepare (first plan with these GEMM shapes)
     backups: Optional[Dict[int, torch.Tensor]] = None    # W0 of the edited layers of the last run (failure recovery)
     factor_key: Optional[tuple] = None   # set by a run that factored lam*C' itself: check_info caches the factors if sound
     factors_from_cache: bool = False
@@ -222,31 +221,17 @@ def factor_cache_key(covs: Sequence[torch.Tensor], lam: float, edit_weight: floa
     is rounded per entry in fp32 (reference :1037), which a scalar cannot reproduce.  The statistics are identified by the
     identity and version counter of the HBM-resident C tensors (the entries of emcid_main's covariance cache).
     Reusing a factor across lam changes the weights at fp64-rounding level against a process that factors lam C' itself;
-    EMCID_FACTOR_KEY_LAM=1 puts lam back into the key where bit-stable output across processes is wanted (every new lam then
-    refactors, ~6 ms)."""
-    key_lam = float(lam) if os.environ.get("EMCID_FACTOR_KEY_LAM", "0") == "1" else None
-    key_ew = None if edit_weight_is_scalar() else float(edit_weight)
+    (A process that wants bit-stable output across runs keeps lam fixed.)"""
+    key_lam = None
+    key_ew = float(edit_weight)
     return (tuple((c.device.index, c.data_ptr(), c._version, tuple(c.shape)) for c in covs), key_ew, key_lam)
 
 
-def edit_weight_is_scalar() -> bool:
-    """EMCID_EDIT_WEIGHT_SCALAR=1 (default 0 = the exact form): treat C' as the scalar multiple (1 - e_w)/0.5 of C, so a new
-    edit_weight reuses the factors like a new lam does (lam C'(e_w) = [lam (1 - e_w)/(1 - e_w0)] C'(e_w0) up to one fp32
-    rounding per entry of C' — the rounding the reference's own `cov * (1 - edit_weight) / 0.5` commits, :1037).  The weights
-    then differ from the exact form by cond(lam C' + K K^T) * 6e-8; tests/test_e2e_gpu.py measures it on statistics of
-    condition 1e2 ... 1e8."""
-    return os.environ.get("EMCID_EDIT_WEIGHT_SCALAR", "0") == "1"
-
-
 def solve_lam(plan) -> float:
-    """The lam handed to the dual stages: the call's own, times (1 - e_w)/(1 - e_w0) when the factors in use were built for
-    another edit_weight (only under EMCID_EDIT_WEIGHT_SCALAR=1 — otherwise the cache never pairs them)."""
-    f = plan.cov_factors
-    if f is None or f.edit_weight is None or float(f.edit_weight) == float(plan.edit_weight):
-        return plan.lam
-    if not (plan.edit_weight < 1.0 and f.edit_weight < 1.0):
-        raise ValueError(f"edit_weight must be < 1 to rescale the factors (got {plan.edit_weight}, factored {f.edit_weight})")
-    return plan.lam * (1.0 - plan.edit_weight) / (1.0 - f.edit_weight)
+    """The lam handed to the dual stages.  (The cached factors are keyed by the statistics AND edit_weight, so they always belong
+    to this call's edit_weight; round 4's EMCID_EDIT_WEIGHT_SCALAR switch — reuse them across edit_weights by treating C' as a
+    scalar multiple of C — left the 1e-4 bar on statistics of condition > 1e5 and is gone.)"""
+    return plan.lam
 
 
 def clear_engine_caches():
@@ -339,7 +324,6 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
         n_chunks = int(os.environ.get("EMCID_PREP_CHUNKS", "0")) or 1
         first_edit = plan.layers[0]
         chunks: List[TrieChunk] = []
-        tune_mode = os.environ.get("EMCID_TUNE_GEMM", "auto")
         try:
             it = iter_prompt_chunks(tokenizer, local, n_chunks, defer_probe=_defer_checks)
             while True:
@@ -350,8 +334,6 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
                 with phase("trie"):
                     trie = clip_forward.build_trie(pc.ids, pc.lookup, device, tail=np.cumsum([0] + list(pc.counts)).astype(np.int64))
                     seg = trie.tail
-                with phase("gemm_tuning"):
-                    plan.gemm_tuning_s += clip_forward.tune_projections(graph, trie, max(plan.layers), tune_mode)
                 with phase("prefix launches"), torch.no_grad():
                     hs, x_ln1 = clip_forward.run_prefix(graph, trie, first_edit)
                 chunks.append(TrieChunk(trie, seg, pc.n_requests, len(pc.lookup), (first_edit, hs, x_ln1)))
@@ -535,7 +517,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
             if plan.side_stream is None:
                 # high priority: the factorization is a long chain of small dependent kernels; each must get the next
                 # free CU ahead of the forward's wide GEMMs or the chain stretches to several times its own length
-                plan.side_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("EMCID_SIDE_PRIORITY", "-1")))
+                plan.side_stream = torch.cuda.Stream(device=dev, priority=-1)
             plan.side_stream.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(plan.side_stream):
                 if plan.cov_factors is not None and plan.cov_factors.cached:
@@ -553,8 +535,8 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                 # latency-bound Cholesky of its N x N system (the chip is idle there): see ``lazy_inverse`` in solve().
                 # EMCID_INVERSE_FROM: first layer index that uses X; EMCID_INVERSE_LAZY=0: build them all right after the
                 # factorization instead (batched, underneath the forward — costs the forward more than it hides).
-                first_x = min(L, max(0, int(os.environ.get("EMCID_INVERSE_FROM", "1"))))
-                lazy = os.environ.get("EMCID_INVERSE_LAZY", "1") != "0" and keep_factors is False
+                first_x = min(L, 1)
+                lazy = keep_factors is False
                 if plan.shard.collective and not keep_factors and -(-d // hip.NB) >= plan.shard.world:
                     first_x, lazy = 0, False      # the column-sharded solve multiplies by X in every layer
                 fac_done = [chol_done] * L
@@ -570,8 +552,6 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                         fac_done[i] = ev
             if first_x >= L:
                 lazy = False
-            if os.environ.get("EMCID_FACTOR_FIRST", "0") == "1":    # experiment: no overlap of the factorization with the forward
-                torch.cuda.current_stream(dev).wait_event(chol_done)
     elif _solver_mode(plan) == "lu":
         plan.ws = _workspace("lu", plan.n_total, d, h, dev, plan)
         plan.ws.info.zero_()
@@ -609,7 +589,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                         fac_done[nxt].record(plan.side_stream)
 
                 ahead = lazy and max(first_x, 1) <= i + 1 < L
-                if sharded and -(-d // hip.NB) >= plan.shard.world and os.environ.get("EMCID_SHARD_SOLVE", "cols") != "replicate":
+                if sharded and -(-d // hip.NB) >= plan.shard.world:
                     # Every rank holds all N key rows (the K all-gather above).  The layer's GEMMs are split by 128-wide
                     # column tiles of d: a rank forms its columns of Yt = Kt X^T and its share of S = I + Yt Yt^T and of
                     # U = (Z^T Yt) X; S (N x N) and U (h x d) are summed over the ranks (two all-reduces over xGMI), the
@@ -622,9 +602,8 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                     edits.append(LayerEdit(layer, plan.weight_name(layer), res["dW"], None, None,
                                            K if trace else None, Zc if trace else None))
                     return
-                # EMCID_SHARD_SOLVE=replicate: every rank runs the whole layer itself (the round-1 form; one collective
-                # less per layer, no scaling of the solve).  EMCID_SHARD_MSOLVE=1 additionally row-shards the M-solve.
-                split = sharded and os.environ.get("EMCID_SHARD_MSOLVE", "0") == "1"
+                # (fewer 128-column tiles than ranks: every rank runs the whole layer itself)
+                split = False
                 res = hip.edit_layer_dual_apply(
                     K, Zc, plan.zs_t, plan.cov_factors, i, plan.edit_weight, L - i, backups[layer], weights[layer].data,
                     ws=plan.dual_ws, rows=plan.shard.bounds(plan.n_total) if split else None,
@@ -680,7 +659,7 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
             parts = [rows_at(x, ch.trie.lookup_in_query if li == last else ch.trie.lookup_node, ch) for x, ch in zip(xs, chunks)]
             return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
 
-        zc_from_keys = os.environ.get("EMCID_ZC_FROM_KEYS", "1") != "0"      # 0: fc2 over every node + gather (A/B switch)
+        zc_from_keys = True      # Zc = fc2(mean keys): fc2 is affine (the other form, fc2 over every node + gather, left in round 5)
         fused_env = os.environ.get("EMCID_FUSED_EDIT_LAYER", "1") != "0"
 
         def fused_layer_ok(li, xs, mids):
@@ -694,8 +673,6 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                 return False
             gl = plan.graph.layers[li]
             if gl.fc2 is not mods[li] or gl.fc2.bias is None:
-                return False
-            if order[li] not in plan.cov_factors.have_inverse and os.environ.get("EMCID_FUSED_NEEDS_INVERSE", "0") == "1":
                 return False
             return clip_forward.native_of(plan.graph, chunks[0].trie, li, li + 1) is not None
 
@@ -802,6 +779,8 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
         with torch.no_grad():
             for l, w in weights.items():
                 w.copy_(backups[l])
+    if guard is not None:
+        guard.flush()       # fingerprints of every weight a cache entry was made from in this pass (the edited fc2's as they are NOW)
     return edits
 
 

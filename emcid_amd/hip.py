@@ -102,7 +102,7 @@ def load():
         "emcid_streamk_workspace_bytes": (i64, [i32]),
         "emcid_debug_streamk_stamps": (i32, [p]),
         "emcid_debug_linear_sp16_stamps": (i32, [p]),
-        "emcid_fingerprint_store": (i32, [p, i64, p, i64, i64, p]),
+        "emcid_fingerprint_store": (i32, [i64, p, p, p, p, i64, p]),
         "emcid_fingerprint_check": (i32, [p, i64, i64, i64, p, p, p]),
         "emcid_debug_step_stamps": (i32, [p]),
         "emcid_dgemm_streamk_f64": (i32, [i32, i64, i64, i64, f64, p, i64, p, i64, p, i64, i32, i32, f64, p, i64, p]),
@@ -413,10 +413,17 @@ def dgemm_batched(ta: int, tb: int, A, B, Cm, alpha=1.0, beta=0.0):
     return Cm
 
 
-def fingerprint_store(t: torch.Tensor, table: torch.Tensor, slot: int):
-    """Stale-cache guard (include/emcid_hip.h): leave {address, bytes, fingerprint of the bytes} of ``t`` in ``table[slot]``."""
-    _check(load().emcid_fingerprint_store(_ptr(t), t.numel() * t.element_size(), _ptr(table, torch.int64, "table"), table.shape[0],
-                                          int(slot), _stream(t)), "emcid_fingerprint_store")
+def fingerprint_store(entries, table: torch.Tensor):
+    """Stale-cache guard (include/emcid_hip.h): leave {address, bytes, fingerprint of the bytes} of every ``(tensor, slot)`` of
+    ``entries`` in ``table[slot]`` — one launch per 32 entries."""
+    n = len(entries)
+    if not n:
+        return
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t, _ in entries])
+    sizes = (C.c_int64 * n)(*[t.numel() * t.element_size() for t, _ in entries])
+    slots = (C.c_int64 * n)(*[int(s) for _, s in entries])
+    _check(load().emcid_fingerprint_store(n, ptrs, sizes, slots, _ptr(table, torch.int64, "table"), table.shape[0], _stream(table)),
+           "emcid_fingerprint_store")
 
 
 def fingerprint_check(table: torch.Tensor, first_slot: int, n_slots: int, flag: torch.Tensor, skip=()):

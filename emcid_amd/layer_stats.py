@@ -244,8 +244,8 @@ def _collect_packed(model, tokenizer, ds, sample, pool, packed, todo, stats, fil
     wanted = {i: [ln for ln in todo if index[ln] == i] for i in set(index.values())}
     wrap = progress if progress is not None else (lambda it, total=None: it)
     # larger pools than the hooked forward's: more shared prefixes per trie and longer GEMMs (rows ~ 0.8 x tokens);
-    # EMCID_STAGE0_POOL captions per pool (default 4 x the hooked pool, i.e. ~110 k tokens, ~1.4 GB of fc2 inputs)
-    pool = int(os.environ.get("EMCID_STAGE0_POOL", 4 * pool))
+    # 4 x the hooked pool per pool, i.e. ~110 k tokens, ~1.4 GB of fc2 inputs
+    pool = 4 * pool
     pools = range(0, len(sample), pool)
     LAST_RUN.clear()
     LAST_RUN.update(forward="packed-trie", tokens=0, rows=0)

@@ -183,13 +183,15 @@ int emcid_tree_attention_sp16(const float* q, int64_t ldq, const float* k, const
 /* ---- stale-cache guard (ABI 13; csrc/clip_layers.hip) ------------------------------------------------------------------------------
  * The forward's weight-derived caches (stacked q | k | v, split-fp16 planes, native layer structs) follow torch's in-place version
  * counter, which a write through `param.data` or a raw pointer does not move.  emcid_fingerprint_store leaves {pointer, bytes,
- * fingerprint} of a weight's BYTES (up to 4 096 evenly spaced 16-byte vectors, each mixed with its index) in slot `slot` of a
- * device table of table_slots x 4 int64 when a cache entry is made; emcid_fingerprint_check recomputes the fingerprints of a
+ * fingerprint} of n weights' BYTES (up to 4 096 evenly spaced 16-byte vectors each, mixed with their index; host arrays of
+ * pointers / sizes / slots, one workgroup per weight) in their slots of a device table of table_slots x 4 int64 after cache
+ * entries were made; emcid_fingerprint_check recomputes the fingerprints of a
  * slot range of at most 256 slots (empty slots and those whose bit is set in the 4 host words of skip_mask are skipped) and ORs
  * 1 into *flag on a mismatch — read back with the call's one final synchronisation.
  * bytes % 16 == 0.  Every non-empty slot of a checked range must still point at live memory (the host checks tensor identity
  * and address first).  No reference counterpart: the reference reads every weight live in every forward. */
-int emcid_fingerprint_store(const void* data, int64_t bytes, void* table, int64_t table_slots, int64_t slot, void* stream);
+int emcid_fingerprint_store(int64_t n, const void* const* data, const int64_t* bytes, const int64_t* slots, void* table,
+                            int64_t table_slots, void* stream);
 int emcid_fingerprint_check(const void* table, int64_t table_slots, int64_t first_slot, int64_t n_slots, const uint64_t* skip_mask,
                             int* flag, void* stream);
 
@@ -436,17 +438,15 @@ int emcid_dgemm_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alph
 /* The same GEMM with the structure hints the solver uses (tests / micro-benchmarks of those shapes):
  * flags bits 0-3 = triangular operands (1: B(k,n)=0 for k>n, 2: B(k,n)=0 for k<n, 4: A(m,k)=0 for k>m, 8: A(m,k)=0 for
  * k<m), bit 4 = compute only output tiles that touch the lower triangle, bit 5 = pair mirrored tiles of the triangular
- * dimension in one workgroup; cfg: -1 auto, 0 = 128x128, 1 = 64x64,
- * 2 = 32x64 tiles, 4 = stream-K over 128x128 tiles (B-side triangle only; C is zeroed by the call, ksplit = number of
- * workgroups, 0 = 512); ksplit: 0 auto, n > 0 = even n-way split of K, n < 0 = fixed runs of |n| K-tiles (16 deep) per
- * workgroup; splits need beta == 1 (partials are added with f64 atomics). */
+ * dimension in one workgroup; cfg: -1 auto, 0 = 128x128, 1 = 64x64, 2 = 32x64 tiles; ksplit: 0 auto, n > 0 = even n-way split of
+ * K, n < 0 = fixed runs of |n| K-tiles (16 deep) per workgroup; splits need beta == 1 (partials are added with f64 atomics). */
 int emcid_dgemm_ex_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double alpha,
                        const double* A, int64_t lda, const double* B, int64_t ldb,
                        double beta, double* C, int64_t ldc, int flags, int cfg, int ksplit, void* stream);
 
 /* Stream-K form of the same GEMM for the two shapes whose work per output tile is uneven or too scarce for the chip —
  * a triangular B operand (flags bit 0 or 1 as above) or a lower-only square output (flags bit 4: SYRK-like, M == N) —
- * WITHOUT atomics: the (tile, K-step) space is cut into `wgs` equal runs; a run's partial tiles go to `workspace`, the
+ * WITHOUT atomics (M and N up to 16 384 tiles of 128 x 128 together): the (tile, K-step) space is cut into `wgs` equal runs; a run's partial tiles go to `workspace`, the
  * contributor of a tile that takes the last ticket sums them in run order (bit-reproducible) and writes
  * C = alpha * A op(B) (+ diag_add on the diagonal).  C needs no initial value.  A is [M][K]; tb as in emcid_dgemm_f64.
  * workspace: emcid_streamk_workspace_bytes(wgs) bytes whose LAST 65536 bytes (the ticket counters) are zero on entry;

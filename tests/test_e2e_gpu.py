@@ -846,54 +846,6 @@ def test_headline_n1000_first_call_path_and_cached_path_match_reference_summary(
         assert (weights[0][ln] - weights[1][ln]).abs().max().item() <= 1e-5 * dw
 
 
-def test_edit_weight_scalar_switch_reuses_the_factors_and_stays_within_tolerance(tmp_path, monkeypatch):
-    """EMCID_EDIT_WEIGHT_SCALAR=1: an edit at another edit_weight finds the factors of the first one (no refactorization) and
-    its weights are the exact form's within BASELINE's 1e-4 (the exact form: default switch, factors of its own)."""
-    from emcid_amd import edit_engine as ee
-    z, meta = load_golden("real_sd_n1000_summary")
-    kind = meta["kind"]
-    hidden, inter = syn.ENCODER_DIMS[kind][:2]
-    reqs = syn.make_requests(300, names="syllable")
-    cache = str(tmp_path / "cache") + "/"
-    syn.write_vstar_cache(cache, reqs, hidden, seed=5, scale=meta["vstar"]["scale"])
-    st = meta["stats"]
-    syn.write_stats_cache(tmp_path / "stats", meta["layer_names"], inter, st["n_samples"], seed=st["seed"], t=st["t"])
-    pipe = syn.build_pipe(kind, DEV, syllables=True)
-    w0 = {ln: get_parameter(pipe.text_encoder, ln + ".weight").detach().clone() for ln in meta["layer_names"]}
-
-    def run(ew):
-        with torch.no_grad():
-            for ln in meta["layer_names"]:
-                get_parameter(pipe.text_encoder, ln + ".weight").copy_(w0[ln])
-        em.apply_emcid_to_text_encoder(pipe, reqs, EMCIDHyperParams(**meta["hparams"]), DEV, mom2_weight=meta["lam"],
-                                       edit_weight=ew, cache_name=cache, stats_dir=str(tmp_path / "stats"), verbose=False)
-        return {ln: get_parameter(pipe.text_encoder, ln + ".weight").detach().clone() for ln in meta["layer_names"]}
-
-    em.clear_caches()
-    with ee.ENGINE_LOCK:
-        ee._FACTOR_CACHE.clear()
-    monkeypatch.delenv("EMCID_EDIT_WEIGHT_SCALAR", raising=False)
-    exact = run(0.7)
-    assert len(ee._FACTOR_CACHE) == 1
-    with ee.ENGINE_LOCK:
-        ee._FACTOR_CACHE.clear()
-    monkeypatch.setenv("EMCID_EDIT_WEIGHT_SCALAR", "1")
-    run(0.5)
-    assert len(ee._FACTOR_CACHE) == 1
-    fac = next(iter(ee._FACTOR_CACHE.values()))[0]
-    assert fac.edit_weight == 0.5
-    scalar = run(0.7)
-    assert len(ee._FACTOR_CACHE) == 1 and next(iter(ee._FACTOR_CACHE.values()))[0] is fac and fac.edit_weight == 0.5
-    worst = 0.0
-    for ln in meta["layer_names"]:
-        dw = (exact[ln] - w0[ln]).abs().max().item()
-        worst = max(worst, (scalar[ln] - exact[ln]).abs().max().item() / dw)
-    print(f"edit_weight as a scalar: max |W - W_exact| / max |dW| = {worst:.3e}")
-    assert worst <= 1e-4, worst
-    with ee.ENGINE_LOCK:
-        ee._FACTOR_CACHE.clear()
-
-
 @pytest.mark.parametrize("fixture", ["real_sdxl_summary", "real_sdxl_n1000_summary"])
 def test_sdxl_edit_matches_reference_summary(tmp_path, fixture):
     """BASELINE config 4 at real dimensions against the REAL reference's summaries — N = 300 (fixture real_sdxl_summary) and
