@@ -155,14 +155,14 @@ def step_flops(N, n_rows, d, h, L, dual, apply_only, factors_cached, first_x):
     add(chol_flops(Np), L)                               # the N x N system S = I + Yt Yt^T
     f["assemble"] += L * N * N * d                       # SYRK count of S
     if apply_only:
-        if os.environ.get("EMCID_S_INVERSE", "1") != "0" and Np <= 4096:
+        if Np <= 4096:
             # Z^T = (Rt^T XS^T) XS with XS = inv(LS) explicit: two triangular GEMMs on h rows + the halving level(s) above 512
             f["trsm_diag"] += L * 2 * h * Np * Np
             f["inv_build"] += L * (Np ** 3 // 3 - (Np // 512) * 512 ** 3 // 3)
         else:
             add(trsm_flops(h, Np, 2), L)                 # Z = S^-1 Rt by block substitution: h right-hand sides
         f["delta_w"] += L * 2 * h * N * d                # V = Z^T Yt
-        shadow = (os.environ.get("EMCID_SHADOW_P", "1") != "0" and os.environ.get("EMCID_CHOL_FUSED", "1") != "0"
+        shadow = (os.environ.get("EMCID_SHADOW_P", "1") != "0"
                   and 256 <= Np <= 2048)
         if shadow and os.environ.get("EMCID_SHADOW_P", "1") == "1":      # the library's own fit estimate (emcid_edit_dual_apply_stage2_f64)
             ntl, nb = -(-d // 128), Np // 128

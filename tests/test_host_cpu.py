@@ -901,22 +901,6 @@ def test_factor_cache_key_ignores_lambda_but_not_edit_weight():
     assert k2 != factor_cache_key(c, 4000.0, 0.5)
 
 
-def test_edit_weight_scalar_switch_drops_it_from_the_key_and_folds_it_into_lam(monkeypatch):
-    from types import SimpleNamespace
-    from emcid_amd.edit_engine import factor_cache_key, solve_lam
-    c = [torch.zeros(4, 4)]
-    monkeypatch.delenv("EMCID_EDIT_WEIGHT_SCALAR", raising=False)
-    assert factor_cache_key(c, 4000.0, 0.5) != factor_cache_key(c, 4000.0, 0.6)
-    monkeypatch.setenv("EMCID_EDIT_WEIGHT_SCALAR", "1")
-    assert factor_cache_key(c, 4000.0, 0.5) == factor_cache_key(c, 4000.0, 0.6)
-    fac = SimpleNamespace(edit_weight=0.5)
-    assert solve_lam(SimpleNamespace(cov_factors=fac, edit_weight=0.5, lam=4000.0)) == 4000.0
-    assert solve_lam(SimpleNamespace(cov_factors=fac, edit_weight=0.75, lam=4000.0)) == 2000.0
-    assert solve_lam(SimpleNamespace(cov_factors=None, edit_weight=0.75, lam=4000.0)) == 4000.0
-    with pytest.raises(ValueError):
-        solve_lam(SimpleNamespace(cov_factors=fac, edit_weight=1.0, lam=4000.0))
-
-
 def test_lam_ratio_rules():
     f = hip.CovFactors.__new__(hip.CovFactors)
     f.lam = 4000.0
