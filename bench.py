@@ -203,11 +203,12 @@ KERNEL_OF_CLASS = {
     "inv_build": "gemm_f64_kernel<KC,!KC,*,*,16,*> launched as recursive-halving build of X = inv(L)",
     "linear": "linear_f32_kernel (csrc/gemm_f32.hip): the forward's projections Y = act(X W^T + b) + residual on v_mfma_f32_32x32x2_f32, "
               "128 x 128 tiles on 4 waves or 160 x 128 on 8 waves (K split inside the workgroup) by the launch's fill of the chip",
-    "linear_sp16": "linear_sp16_kernel / linear_sp16_dma_kernel (csrc/gemm_sp16.hip): the forward's projections Y = act(X W^T + b) + residual at "
-                   "fp32 accuracy on v_mfma_f32_32x32x16_f16 — operands as hi + lo fp16 planes under per-row power-of-two scales, three "
-                   "MFMAs per k-step (hi.hi + hi.lo + lo.hi), fp32 accumulate; by the launch's shape: 256 x 256 tiles on 8 waves or "
-                   "128 x 128 on 4 with both operands staged by LDS-DMA (K <= 1536: q|k|v, fc1), 160 x 128 on 8 waves with the K range "
-                   "split inside the workgroup (out, fc2), 128 x 128 register-staged or 64 x 64",
+    "linear_sp16": "linear_sp16_dma16_kernel (csrc/gemm_sp16.hip): the forward's projections Y = act(X W^T + b) + residual at fp32 accuracy on "
+                   "v_mfma_f32_16x16x32_f16 — operands as hi + lo fp16 planes under per-row power-of-two scales, three MFMAs per k-step "
+                   "(hi.hi + hi.lo + lo.hi), fp32 accumulate; operands staged by LDS-DMA (buffer_load ... lds, XOR-swizzled image), "
+                   "epilogue through LDS (whole-row stores); four waves per workgroup, two workgroups per compute unit; by the launch's "
+                   "shape 128 x 128 tiles (q|k|v, fc1 at ~6 300 rows), 80 x 128 (out, fc2), 64 x 64 or 160 x 128; launches of less than one "
+                   "tile per compute unit on the register-staged 64 x 64 kernel (linear_sp16_kernel, v_mfma_f32_32x32x16_f16)",
 }
 FP64_CLASSES = ["assemble", "chol_leaf", "chol_panel", "chol_trail", "chol_inner", "chol_fused", "inv_block", "trsm_diag",
                 "trsm_update", "delta_w", "inv_build", "inv_apply"]
@@ -487,12 +488,13 @@ def main():
             peak = F16_MFMA_PEAK_TFLOPS / 3.0
             lin["frac_f16_mfma_peak"] = lin["tflops"] / peak
             lin["mfma_tflops_executed"] = 3.0 * lin["tflops"]
-            pmc = REPO / "profiles" / "r04_pmc_linear_sp16.json"
+            pmc = REPO / "profiles" / "r05_pmc_linear_sp16.json"
             traffic = traffic_note = None
             if pmc.exists():
                 with open(pmc) as fh:
                     rec = json.load(fh)
-                traffic, traffic_note = rec.get("traffic_bytes_per_launch"), rec.get("note")
+                traffic = rec.get("traffic_bytes_per_launch")
+                traffic_note = f"STORED value from {pmc.relative_to(REPO)} (counter passes of the same kernels, not of this run): " + str(rec.get("note"))
             roofline = {"bound": "mfma", "kernel": KERNEL_OF_CLASS["linear_sp16"], "class": "linear", "achieved": lin["tflops"],
                         "peak": peak, "unit": "TFLOP/s", "frac": lin["tflops"] / peak,
                         "dtype": "f32 (2 x fp16 split: 3 f16 MFMAs per k-step, fp32 accumulate)",

@@ -11,12 +11,15 @@
 //
 // Storage of a split matrix ("planes", one 4-byte unit per element like the fp32 matrix it stands for, so row views and row
 // gathers work on it as on an int32 matrix): per row, groups of 8 consecutive k: [hi k..k+7 (16 B)][lo k..k+7 (16 B)].  A lane's
-// MFMA fragment (v_mfma_f32_32x32x16_f16: 8 consecutive k of one row) is then ONE ds_read_b128 per plane, and a stage's 32 k of
-// a row are one whole 128-byte line in global memory.
+// MFMA fragment (8 consecutive k of one row, for v_mfma_f32_16x16x32_f16 and v_mfma_f32_32x32x16_f16 alike) is then ONE
+// ds_read_b128 per plane, and a stage's 32 k of a row are one whole 128-byte line in global memory.
 //
 // The MFMA runs "transposed": A operand = W rows (n), B operand = X rows (m), so a lane of the result holds ONE row m and four
-// consecutive n per register quad: 16-byte stores / residual loads in the epilogue, and the fp16 planes of the OUTPUT (when the
-// consumer is the next projection: quick_gelu(fc1) -> fc2) are written 8 bytes per plane per quad straight from the registers.
+// consecutive n per register quad.
+//
+// Kernels: `linear_sp16_dma16_kernel` — the default: operands by LDS-DMA, 16x16x32 MFMAs, epilogue through LDS, four tile forms
+// (round 5) — and `linear_sp16_kernel` — register-staged operands, 32x32x16 MFMAs (round 4): kept for launches of less than one
+// 64 x 64 tile per compute unit, and its K loop (`sp_accumulate`) for the Stage-0 Gram.
 #include "common.h"
 #include "sp16.h"
 
@@ -369,131 +372,6 @@ __device__ __forceinline__ void sp_finish(const SpArgs& a, int m0, int n0, unsig
     else epilogue([](float x) { return x; });
 }
 
-// ---- "ping-pong": two 128 x 128 tiles per workgroup, their K loops interleaved by barriers ------------------------------------
-// Two independent workgroups of a compute unit share its matrix pipes by chance: both in their MFMAs (one waits), both in their
-// loads (the pipe idles) — 0.34 busy in the counters of the 4-wave kernel.  Here ONE workgroup of eight waves holds two tiles,
-// waves 0-3 one and waves 4-7 the other (one wave of each group per SIMD), and the groups alternate at workgroup barriers:
-// while a group issues the 24 MFMAs of its stage from registers, the other does ALL of its memory work for later stages — the
-// fragment reads of its next stage (both k16 steps: 64 registers), the LDS stores of the stage after it and the global loads
-// of the one after that — and nothing else; then they swap.  Group 1 runs one phase behind group 0 (an extra barrier before
-// its loop, one after group 0's).  Each group owns its own two LDS stage buffers, so only its own program order and the
-// barriers between a store and the reads of it matter:
-//     mem phase after MFMA(s):  fread(s+1) <- buf[(s+1)&1] (stored two phases ago) | lstore(s+2) -> buf[s&1] (last read two phases
-//     ago, consumed by MFMA(s)) | gload(s+3) into the one register set the store has just emptied (in flight for two phases).
-template <int DBG>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_sp16_pp_kernel(SpArgs a) {
-    constexpr int MJ = 2, NI = 2, WN = 2, BM = 128, BN = 128, NT = 256, SPROW = 144, VA = BM * 8 / NT, VB = BN * 8 / NT;
-    constexpr int STAGE = (BM + BN) * SPROW, GROUP = 2 * STAGE;
-    __shared__ __attribute__((aligned(16))) unsigned char smem_all[2 * GROUP];
-    const int grp = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, l5 = lane >> 5;
-    const int wm0 = (wave / WN) * (32 * MJ), wn0 = (wave % WN) * (32 * NI);
-    unsigned char* smem = smem_all + grp * GROUP;
-    // XCD x takes the tile PAIRS [x per, (x + 1) per) of the super-row order; a pair = two consecutive tiles
-    const int pairs = (a.tiles + 1) / 2, per = (pairs + 7) / 8;
-    const int pair = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (pair >= pairs || (int)(blockIdx.x >> 3) >= per) return;
-    const int tile_raw = 2 * pair + grp;
-    const bool ghost = tile_raw >= a.tiles;            // odd tile count: the last pair's second group computes a copy, stores nothing
-    int bm, bn;
-    sp_tile_of(a, ghost ? a.tiles - 1 : tile_raw, bm, bn);
-    const int m0 = bm * BM, n0 = bn * BN, T = a.K / SPK;
-
-    const uint32_t* pa[VA];
-    const uint32_t* pb[VB];
-    int wa[VA], wb[VB];
-#pragma unroll
-    for (int s = 0; s < VA; ++s) {
-        const int v = tid + NT * s, row = v >> 3;
-        pa[s] = a.X + (int64_t)min(m0 + row, a.M - 1) * a.ldx + 4 * (v & 7);
-        wa[s] = row * SPROW + 16 * (v & 7);
-    }
-#pragma unroll
-    for (int s = 0; s < VB; ++s) {
-        const int v = tid + NT * s, row = v >> 3;
-        pb[s] = a.W + (int64_t)min(n0 + row, a.N - 1) * a.ldw + 4 * (v & 7);
-        wb[s] = (BM + row) * SPROW + 16 * (v & 7);
-    }
-    v4u ga[VA], gb[VB];
-    auto gload = [&](int it) __attribute__((always_inline)) {
-        const int k0 = min(it, T - 1) * SPK;
-#pragma unroll
-        for (int s = 0; s < VA; ++s) ga[s] = *reinterpret_cast<const v4u*>(pa[s] + k0);
-#pragma unroll
-        for (int s = 0; s < VB; ++s) gb[s] = *reinterpret_cast<const v4u*>(pb[s] + k0);
-    };
-    auto lstore = [&](unsigned char* stage) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < VA; ++s) *reinterpret_cast<v4u*>(stage + wa[s]) = ga[s];
-#pragma unroll
-        for (int s = 0; s < VB; ++s) *reinterpret_cast<v4u*>(stage + wb[s]) = gb[s];
-    };
-    const int fx_off = (wm0 + l31) * SPROW + 32 * l5;
-    const int fw_off = (BM + wn0 + l31) * SPROW + 32 * l5;
-    v8h xh[2][MJ], xl[2][MJ], wh[2][NI], wl[2][NI];
-    auto fread = [&](const unsigned char* stage) __attribute__((always_inline)) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int j = 0; j < MJ; ++j) {
-                xh[t][j] = *reinterpret_cast<const v8h*>(stage + fx_off + j * 32 * SPROW + 64 * t);
-                xl[t][j] = *reinterpret_cast<const v8h*>(stage + fx_off + j * 32 * SPROW + 64 * t + 16);
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                wh[t][i] = *reinterpret_cast<const v8h*>(stage + fw_off + i * 32 * SPROW + 64 * t);
-                wl[t][i] = *reinterpret_cast<const v8h*>(stage + fw_off + i * 32 * SPROW + 64 * t + 16);
-            }
-        }
-    };
-    v16f acc[NI][MJ];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < MJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    auto mfmas = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int j = 0; j < MJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p == 0 ? wl[t][i] : wh[t][i], p == 1 ? xl[t][j] : xh[t][j],
-                                                                           acc[i][j], 0, 0, 0);
-    };
-
-    gload(0);
-    lstore(smem);
-    gload(1);
-    __syncthreads();
-    fread(smem);
-    lstore(smem + STAGE);
-    gload(2);
-    if (grp == 1) __syncthreads();                 // group 1 runs one phase behind
-    for (int s = 0; s < T; ++s) {
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (DBG < 4) {
-            __builtin_amdgcn_s_setprio(1);
-            mfmas();
-            __builtin_amdgcn_s_setprio(0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (DBG < 3) fread(smem + ((s + 1) & 1) * STAGE);
-        if constexpr (DBG < 2) lstore(smem + (s & 1) * STAGE);
-        if constexpr (DBG < 1) gload(s + 3);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (grp == 0) __syncthreads();
-    if (!ghost) sp_finish<MJ, NI, 2, WN, 1>(a, m0, n0, smem, acc);
-}
-
 template <int MJ, int NI, int WM, int WN, int PF, int WPE, int DBG, int KS>
 __global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 void linear_sp16_kernel(SpArgs a) {
@@ -516,165 +394,12 @@ void linear_sp16_kernel(SpArgs a) {
     sp_finish<MJ, NI, WM, WN, KS>(a, bm * G::BM, bn * G::BN, smem, acc);
 }
 
-// ---- 256-column tiles on eight waves, operands by LDS-DMA --------------------------------------------------------------------
-// The register-staged kernels above spend 54 % of the LDS's time on ds_write_b128 (79 B/clk) and a third on fragment reads
-// (MI355X_MICROARCH.md, LDS): with loads and stores removed the 128 x 128 loop runs 1.3-1.45x faster.  Here a stage (32 k of
-// (BM + BN) rows, 128 bytes per row) is written by `global_load_lds_dwordx4` — no staging registers, no LDS store instructions —
-// and a wave owns 32 MJ x 64 of the tile, so a k16 step is 2 (MJ + 2) ds_read_b128 for 6 MJ MFMAs (0.5 reads per MFMA at MJ = 4
-// against 0.67 on the 64 x 64 wave tile).  One LDS-DMA wave-instruction writes 1 KiB = 8 whole rows, lane-linear, so the image
-// cannot be padded; it is XOR-swizzled instead: the 16-byte chunk c of row r sits at slot c ^ ((r >> 1) & 7).  The lanes of a
-// ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) are 16 rows with the same c: (r >> 1) & 7 takes every value twice, once
-// per row parity (a row is half the 256-byte bank line): 16 distinct slots, conflict-free.  The swizzle is applied on the
-// SOURCE address of the DMA (lane -> which 16 bytes of which row it fetches) and on the fragment read, never on the destination.
-// Two stage buffers; per stage: wait for the own DMA (vmcnt(0)), barrier (everybody's stage has landed and everybody is done
-// reading the other buffer), issue the next stage's DMA into the other buffer, contract this one.
-// KS = 2 (the 160 x 128 tile's scheme): a stage is 64 deep, 256 bytes per row, two wave groups contract its two halves over the
-// whole tile and meet through LDS at the end (sp_finish).  A 1-KiB piece is then 4 rows of 16 chunks and the swizzle key is
-// r & 15 (a row is a whole bank line; the 16 rows of a ds_read_b128 lane group have 16 different keys).
-template <int MJ, int NI, int WM, int WN, int KS, int DBG>
-__global__ __launch_bounds__(64 * WM * WN * KS) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_sp16_dma_kernel(SpArgs a) {
-    constexpr int NW = WM * WN, NWV = NW * KS, BM = 32 * MJ * WM, BN = 32 * NI * WN;
-    constexpr int ROWB = 128 * KS, RPP = 1024 / ROWB, CPR = 8 * KS;          // bytes per row and stage, rows per piece, chunks per row
-    constexpr int STAGE = (BM + BN) * ROWB, PIECES = STAGE / 1024, PPW = PIECES / NWV;
-    constexpr int RED = KS == 2 ? NW * MJ * NI * 4 * 64 * 16 : 0;
-    static_assert(PIECES % NWV == 0 && BM % RPP == 0 && BN % RPP == 0, "pieces per wave");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE > RED ? 2 * STAGE : RED];
-    const int per = (a.tiles + 7) / 8;
-    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (tile >= a.tiles || (int)(blockIdx.x >> 3) >= per) return;
-    int bm, bn;
-    sp_tile_of(a, tile, bm, bn);
-    long long t_begin = 0;
-    if constexpr (DBG == 2) t_begin = (long long)__builtin_amdgcn_s_memrealtime();
-    const int m0 = bm * BM, n0 = bn * BN, T = a.K / (SPK * KS);
-    const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6, wave = wave_all % NW, grp = wave_all / NW;
-    const int l31 = lane & 31, l5 = lane >> 5;
-    const int wm0 = (wave / WN) * (32 * MJ), wn0 = (wave % WN) * (32 * NI);
-
-    // DMA: piece p = wave_all PPW + s holds image rows RPP p .. RPP p + RPP - 1 (rows < BM: X rows, then W rows); lane -> row
-    // RPP p + lane / CPR, slot lane % CPR, fetching chunk slot ^ key(row) of that row's line of the stage.  Address = a uniform
-    // base per operand (SGPRs, advanced by ROWB bytes per stage) + a 32-bit byte offset per lane and piece.
-    auto uniform_ptr = [](const void* ptr) __attribute__((always_inline)) {
-        const uint64_t v = reinterpret_cast<uint64_t>(ptr);
-        const uint64_t lo = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffu));
-        const uint64_t hi = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
-        return reinterpret_cast<const unsigned char*>(lo | (hi << 32));
-    };
-    const unsigned char* base_x = uniform_ptr(a.X + (int64_t)m0 * a.ldx);
-    const unsigned char* base_w = uniform_ptr(a.W + (int64_t)n0 * a.ldw);
-    unsigned off[PPW];
-#pragma unroll
-    for (int s = 0; s < PPW; ++s) {
-        const int r = RPP * (wave_all * PPW + s) + lane / CPR;
-        const int c = (lane % CPR) ^ (KS == 2 ? (r & 15) : ((r >> 1) & 7));
-        const bool is_x = r < BM;
-        const int rr = is_x ? min(m0 + r, a.M - 1) - m0 : min(n0 + r - BM, a.N - 1) - n0;      // rows past the end: a valid row, never stored
-        off[s] = (unsigned)(rr * (int)(4 * (is_x ? a.ldx : a.ldw)) + 16 * c);
-    }
-    const int lds_w = __builtin_amdgcn_readfirstlane(wave_all * PPW * 1024);
-    const int piece0 = __builtin_amdgcn_readfirstlane(wave_all * PPW);
-    auto issue = [&](int it, unsigned char* stage) __attribute__((always_inline)) {
-        const int64_t adv = (int64_t)it * ROWB;
-#pragma unroll
-        for (int s = 0; s < PPW; ++s) {
-            const unsigned char* b = ((piece0 + s) * RPP < BM ? base_x : base_w) + adv;      // uniform select
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b + off[s]),
-                                             (__attribute__((address_space(3))) void*)(stage + lds_w + s * 1024), 16, 0, 0);
-        }
-    };
-    // fragments: lane (row l31 of a 32-row block, k half l5) of k16 step t of its group's half reads chunks 8 grp + 4 t + 2 l5 (hi)
-    // and + 1 (lo) of its row
-    const int q = KS == 2 ? (l31 & 15) : ((l31 >> 1) & 7);
-    const int ch0 = 16 * ((8 * grp * (KS - 1) + 2 * l5) ^ q), ch1 = 16 * ((8 * grp * (KS - 1) + 4 + 2 * l5) ^ q);
-    const int fx = (wm0 + l31) * ROWB, fw = (BM + wn0 + l31) * ROWB;
-    v16f acc[NI][MJ];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < MJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    constexpr int NSLOT = 2;
-    v8h xh[NSLOT][MJ], xl[NSLOT][MJ], wh[NSLOT][NI], wl[NSLOT][NI];
-    auto fread = [&](const unsigned char* stage, int ch, auto sc) __attribute__((always_inline)) {
-        constexpr int S = decltype(sc)::value;
-#pragma unroll
-        for (int j = 0; j < MJ; ++j) xh[S][j] = *reinterpret_cast<const v8h*>(stage + fx + j * 32 * ROWB + ch);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) wl[S][i] = *reinterpret_cast<const v8h*>(stage + fw + i * 32 * ROWB + (ch ^ 16));
-#pragma unroll
-        for (int i = 0; i < NI; ++i) wh[S][i] = *reinterpret_cast<const v8h*>(stage + fw + i * 32 * ROWB + ch);
-#pragma unroll
-        for (int j = 0; j < MJ; ++j) xl[S][j] = *reinterpret_cast<const v8h*>(stage + fx + j * 32 * ROWB + (ch ^ 16));
-    };
-    auto mfmas = [&](auto sc) __attribute__((always_inline)) {
-        constexpr int S = decltype(sc)::value;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < MJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p == 0 ? wl[S][i] : wh[S][i], p == 1 ? xl[S][j] : xh[S][j],
-                                                                       acc[i][j], 0, 0, 0);
-    };
-    {
-        // The barrier sits in the MIDDLE of a stage's contraction: by then every wave has read both k16 steps of the stage
-        // (its buffer is free for the DMA of stage it + 2) and its own share of stage it + 1 has landed; the fragment reads of a
-        // k16 step always run underneath the 24 MFMAs of the step before.
-        issue(0, smem);
-        if (T > 1) issue(1, smem + STAGE);
-        static_assert(PPW < 16, "vmcnt encoding");
-        if (T > 1) __builtin_amdgcn_s_waitcnt(0x0f70 | PPW);              // vmcnt(PPW): stage 0 has landed
-        else __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
-        // (every scalar load of the prologue retired before the first fragment read: with one possibly pending, hipcc treats the
-        // LGKM counter as out of order for the whole loop and waits lgkmcnt(0) before every MFMA block)
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_sched_barrier(0);
-        fread(smem, ch0, SpIC<0>{});
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_sched_barrier(0);
-        long long t_clk = 0, t_real = 0;
-        if constexpr (DBG == 2) {
-            t_clk = (long long)__builtin_amdgcn_s_memtime();
-            t_real = (long long)__builtin_amdgcn_s_memrealtime();
-        }
-        for (int it = 0; it < T; ++it) {
-            unsigned char* cur = smem + (it & 1) * STAGE;
-            unsigned char* oth = smem + ((it + 1) & 1) * STAGE;
-            fread(cur, ch1, SpIC<1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(SpIC<0>{});
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): stage it + 1 (own share) landed, step-1 fragments in registers
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            if (DBG != 1 && it + 2 < T) issue(it + 2, cur);
-            if (it + 1 < T) fread(oth, ch0, SpIC<0>{});
-            __builtin_amdgcn_sched_barrier(0);
-            mfmas(SpIC<1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the step-0 fragments landed long ago; said here so that the
-            __builtin_amdgcn_sched_barrier(0);       // next iteration's MFMAs do not wait for the reads issued just before them
-        }
-        if constexpr (DBG == 2) {        // diagnostic build: shader-clock and 100 MHz stamps around the K loop, one record per workgroup
-            const long long e_clk = (long long)__builtin_amdgcn_s_memtime(), e_real = (long long)__builtin_amdgcn_s_memrealtime();
-            if (a.stamps != nullptr && tid == 0) {
-                long long* st = a.stamps + 8 * (int64_t)blockIdx.x;
-                st[0] = t_clk; st[1] = e_clk; st[2] = t_real; st[3] = e_real; st[4] = t_begin;
-            }
-        }
-    }
-    sp_finish<MJ, NI, WM, WN, KS>(a, m0, n0, smem, acc);
-    if constexpr (DBG == 2) {
-        if (a.stamps != nullptr && tid == 0) a.stamps[8 * (int64_t)blockIdx.x + 5] = (long long)__builtin_amdgcn_s_memrealtime();
-    }
-}
-
-// ---- the same LDS-DMA structure on v_mfma_f32_16x16x32_f16 ---------------------------------------------------------------------
+// ---- operands by LDS-DMA, v_mfma_f32_16x16x32_f16 ---------------------------------------------------------------------------------
+// (Round 4 built this structure on v_mfma_f32_32x32x16_f16 — 256 x 256 tiles on eight waves, 128 x 128 on four, 160 x 128 with the K
+// range split inside the workgroup — after measuring that the register-staged loop spends 54 % of the LDS's time on ds_write_b128:
+// a stage (32 k of the tile's rows, 128 bytes per row) written by `buffer_load ... lds`, no staging registers, no LDS stores, the
+// image XOR-swizzled on the DMA's SOURCE address and on the fragment read, two stage buffers.  Round 5 measured every one of those
+// forms behind the 16x16x32 forms below on every shape (profiles/r05_mb_linear_sp16_forms.txt) and removed them.)
 // MI355X_MICROARCH.md, DVFS give-back item 7: at about equal cycles per FLOP the chip holds a higher clock on the 16x16x32 shape
 // than on 32x32x16 (1.12-1.15x the FLOP/s in bare loops on random data).  Same planes, same stage image (32 k of a row = one
 // 128-byte line, 1-KiB DMA pieces of 8 rows), but a lane now holds row l & 15 and the k group l >> 4 of a 16-row block — chunk
@@ -1154,8 +879,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 struct SpCfg { int bm, bn; };
-static const SpCfg kSpCfgs[] = {{128, 128}, {128, 128}, {64, 64}, {160, 128}, {256, 256}, {128, 128}, {160, 128}, {128, 128}, {256, 256},
-                                {160, 128}, {80, 128}, {64, 64}};
+static const SpCfg kSpCfgs[] = {{128, 128}, {80, 128}, {64, 64}, {160, 128}, {64, 64}};
 inline long long* g_sp16_stamps = nullptr;      // set by emcid_debug_linear_sp16_stamps
 
 }  // namespace emcid
@@ -1236,120 +960,57 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
     EMCID_CHECK_ARG(K % SPK == 0 && ldx % 4 == 0 && ldw % 4 == 0 && aligned16(Xp) && aligned16(Wp));
     EMCID_CHECK_ARG(M < (1 << 24) && N < (1 << 24) && K < (1 << 24) && (residual == nullptr || ldr >= N) && (Y == nullptr || ldy >= N));
     EMCID_CHECK_ARG(Yp == nullptr || (N % 8 == 0 && ldp >= N && ldp % 4 == 0 && aligned16(Yp)));
-    EMCID_CHECK_ARG(act >= SP_ACT_NONE && act <= SP_ACT_GELU_ERF && cfg >= -1 && cfg < 1024);
-    // (A 256 x 256 tile on eight waves — 128 x 64 per wave, the vendor library's choice for the q | k | v shape: 225 tiles — needs
-    // 128 accumulator + 48 fragment + 32 staging registers plus addresses: hipcc spills at the 256 two waves per SIMD allow, 423 us on
-    // the qkv shape; removed.)
-    // cfg: bits 0-1 tile (0: 128 x 128 on 4 waves, 1: two 128 x 128 tiles ping-pong on 8 waves, 2: 64 x 64 on 4 waves, 3: 160 x 128 on 8 waves with
-    // the K range of a 64-deep stage split between two wave groups), bits 2-3: prefetch distance - 1, bits 4-5: timing
-    // experiments (tile 0, prefetch 2; results wrong); -1: auto
-    // bit 6: the LDS-DMA kernel (256 x 256 on eight waves)
+    EMCID_CHECK_ARG(act >= SP_ACT_NONE && act <= SP_ACT_GELU_ERF && cfg >= -1 && cfg < 64);
+    // cfg: -1 auto; 0: 128 x 128 (two waves by two, 64 x 64 each, both fragment sets in registers); 1: 80 x 128 (four waves side
+    // by side, 80 x 32 each); 2: 64 x 64 (four workgroups per compute unit); 3: 160 x 128 (80 x 64 per wave, fragments reloaded
+    // progressively) — all four: operands by LDS-DMA, v_mfma_f32_16x16x32_f16, epilogue through LDS —; 4: 64 x 64 with
+    // register-staged operands on v_mfma_f32_32x32x16_f16, two stages of loads in flight (latency-bound launches); + 16 / + 48
+    // with cfg 0: timing-only builds (no DMA inside the loop / MFMAs only; results wrong).
+    EMCID_CHECK_ARG(ldx < (1 << 20) && ldw < (1 << 20));      // 32-bit buffer offsets of a tile's rows
     const int dbg = cfg < 0 ? 0 : (cfg >> 4) & 3;
-    int tile_sel = cfg < 0 ? -1 : (cfg >> 6) ? 3 + (cfg >> 6) : (cfg & 3);
-    EMCID_CHECK_ARG(tile_sel <= 11);     // cfg 64: LDS-DMA 256 x 256 on eight waves, 128: 128 x 128 on four, 192: 160 x 128 with the K split,
-                                         // 256 / 320 / 384 / 448: the 16x16x32 forms: 128 x 128 on four waves, 256 x 256 on eight,
-                                         // 160 x 128 on four, 80 x 128 on four (waves side by side: 80 x 32 each); 512: 64 x 64 on four, four
-                                         // workgroups per compute unit
-    int pf = cfg < 0 ? 2 : ((cfg >> 2) & 3) + 1;
-    EMCID_CHECK_ARG(pf >= 1 && pf <= 2);
+    int tile_sel = cfg < 0 ? -1 : (cfg & 15);
+    EMCID_CHECK_ARG(tile_sel <= 4 && (dbg == 0 || tile_sel == 0) && dbg != 2);
     if (tile_sel < 0) {
-        // scripts/mb_linear_sp16.py.  A compute unit works through ceil(tiles / 256) tiles: 160 x 128 (one workgroup of eight
-        // waves per compute unit) where 128 x 128 tiles would leave the second round nearly empty (N = 768 at 6 400 rows: 300
-        // tiles = two rounds for 1.17 tiles per compute unit; 160 x 128: 240 tiles, one round).
-        const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128), t160 = ((M + 159) / 160) * ((N + 127) / 128);
-        if (K % 64 == 0 && t160 >= 160 && t160 <= 256 && t128 > 256) tile_sel = 3;
-        else tile_sel = (t128 >= 256 && (K >= 2048 || t128 >= 640)) ? 0 : 2;
-        // The LDS-DMA forms of the 128 x 128 tile (the same bits): short contractions only (at K = 3072 / 5120 the register-staged
-        // loop is ahead, profiles/r04_mb_linear_sp16_dma.txt); 256 x 256 tiles where they fill their last round of 256 workgroups
-        // to 85 % (q | k | v at 6 250 rows: 225 tiles, 92 against 102 us; bigG fc1: 500 tiles, 248 against 279), else 128 x 128 on
-        // four waves, two workgroups per compute unit (fc1: 118 against 127 us; bigG q | k | v 207 against 214).  EMCID_SP16_DMA=0: off.
-        static const int dma_env = [] { const char* e = getenv("EMCID_SP16_DMA"); return e ? atoi(e) : 2; }();
-        static const int mfma16_env = [] { const char* e = getenv("EMCID_SP16_MFMA16"); return e ? atoi(e) : 2; }();
-        if (dma_env && tile_sel == 0 && K <= 1536 && ldx < (1 << 20) && ldw < (1 << 20)) {
-            const int64_t t256 = ((M + 255) / 256) * ((N + 255) / 256), rounds = (t256 + 255) / 256;
-            // round 5 (profiles/r05_mb_linear_sp16_epi.txt): the same structure on v_mfma_f32_16x16x32_f16 with the epilogue through
-            // LDS — 128 x 128 on four waves (q | k | v at 6 292 rows 73.6 against 96.4 us, fc1 92.0 against 102.4); 256 x 256 on
-            // eight waves only where those tiles run for four rounds or more and fill the last one (36 335 rows: 364 against 398)
-            if (mfma16_env == 1) tile_sel = (rounds >= 4 && t256 * 100 >= rounds * 256 * 85) ? 8 : 7;
-            else tile_sel = (t256 * 100 >= rounds * 256 * 85) ? 4 : 5;
-        } else if (dma_env >= 2 && tile_sel == 3 && ldx < (1 << 20) && ldw < (1 << 20)) {
-            tile_sel = 6;       // the 160 x 128 tile with the K range split in the workgroup, staged by LDS-DMA: out 32 against 34 us, fc2 94 against 102
-        }
-        // round 5, second half (profiles/r05_mb_linear_sp16_forms.txt: six LDS-DMA forms on sixteen shapes): the 16x16x32 forms on
-        // four waves, two workgroups per compute unit, are ahead of every 32x32x16 form on every shape.  128 x 128 by default;
-        // 80 x 128 (waves side by side) where 128 x 128 tiles would not give every compute unit two workgroups (N = 768 at 6 292
-        // rows: 300 tiles -> 474: out 30.7 against 35.1 us for the K-split tile, fc2 82.3 against 97.6); 160 x 128 for operands
-        // far beyond the L2 and many rounds of tiles (36 335 rows: 339 against 369 us); 64 x 64 below 128 tiles of 80 rows.
-        // The largest of 128 x 128, 80 x 128, 64 x 64 that still gives ~400 workgroups (3 072 x 3 072 -> 768: 64 x 64 51.8 against
-        // 60.2 / 68.9 us; 2 100 x 768 -> 2 304: 80 x 128 28.0 against 44.5).  Below one 64 x 64 tile per compute unit a launch is
-        // latency-bound and the register-staged 64 x 64 loop with its two stages of loads in flight stays ahead on a long K
-        // (640 x 3 072 -> 768: 28 against 45 us): those keep the selection above (profiles/r05_mb_linear_sp16_small.txt).
-        if (mfma16_env >= 2 && ldx < (1 << 20) && ldw < (1 << 20)) {
-            const int64_t t80 = ((M + 79) / 80) * ((N + 127) / 128), t64 = ((M + 63) / 64) * ((N + 63) / 64);
-            if (t128 >= 1600 && M >= 16384) tile_sel = 9;
-            else if (t128 >= 400) tile_sel = 7;
-            else if (t80 >= 400) tile_sel = 10;
-            else if (t64 >= 256) tile_sel = 11;
-        }
+        // profiles/r05_mb_linear_sp16_forms.txt, r05_mb_linear_sp16_small.txt (six LDS-DMA forms and the register-staged ones on
+        // 27 shapes, interleaved rounds in one process).  The largest of 128 x 128, 80 x 128, 64 x 64 that still gives ~400
+        // workgroups — two resident workgroups for every compute unit: q | k | v at 6 292 rows 128 x 128 (69 us; 96 on round 4's
+        // 256 x 256 tile of 32x32x16 MFMAs), N = 768 at 6 292 rows 80 x 128 (300 tiles -> 474: out 30.7 against 35.1 us for round 4's
+        // K-split tile, fc2 82.3 against 97.6), 3 072 x 3 072 -> 768 64 x 64 (51.8 against 60.2 / 68.9); 160 x 128 for operands far
+        // beyond the L2 and many rounds of tiles (36 335 rows: 339 against 369 us).  Below one 64 x 64 tile per compute unit a launch
+        // is latency-bound and the register-staged loop stays ahead on a long K (640 x 3 072 -> 768: 28 against 45 us).
+        const int64_t t128 = ((M + 127) / 128) * ((N + 127) / 128), t80 = ((M + 79) / 80) * ((N + 127) / 128);
+        const int64_t t64 = ((M + 63) / 64) * ((N + 63) / 64);
+        if (t128 >= 1600 && M >= 16384) tile_sel = 3;
+        else if (t128 >= 400) tile_sel = 0;
+        else if (t80 >= 400) tile_sel = 1;
+        else if (t64 >= 256) tile_sel = 2;
+        else tile_sel = 4;
     }
-    if ((tile_sel == 3 || tile_sel == 6) && K % 64 != 0) tile_sel = 0;
-    if (tile_sel >= 7 && (ldx >= (1 << 20) || ldw >= (1 << 20))) tile_sel = 0;      // 32-bit buffer offsets
     const int bm = kSpCfgs[tile_sel].bm, bn = kSpCfgs[tile_sel].bn;
     const int tiles_m = (int)((M + bm - 1) / bm), tiles_n = (int)((N + bn - 1) / bn);
     const int tiles = tiles_m * tiles_n;
     const int per = (tiles + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
-    static const int rb_env = [] { const char* e = getenv("EMCID_SP16_RB"); return e ? atoi(e) : 4; }();
-    const int rb = rb_env >= 1 ? rb_env : 1;
+    const int rb = 4;       // row tiles per super-row of the tile order
     const SpArgs a{(const uint32_t*)Xp, ldx, x_inv_scale, (const uint32_t*)Wp, ldw, w_inv_scale, bias, residual, ldr, Y, ldy,
                    (uint32_t*)Yp, ldp, y_scale, (int)M, (int)N, (int)K, act, tiles_n, tiles, rb, g_sp16_stamps};
     ScopedProf sp(KC_LINEAR, st);
-#define EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, PF_, WPE_, DBG_, KS_)                                                               \
-    hipLaunchKernelGGL((linear_sp16_kernel<MJ_, NI_, WM_, WN_, PF_, WPE_, DBG_, KS_>), dim3((unsigned)(per * 8)),               \
-                       dim3(64 * WM_ * WN_ * KS_), 0, st, a)
-#define EMCID_SP_PF(MJ_, NI_, WM_, WN_, WPE_, KS_)                              \
-    do {                                                                        \
-        if (pf == 1) EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 1, WPE_, 0, KS_);      \
-        else EMCID_SP_LAUNCH(MJ_, NI_, WM_, WN_, 2, WPE_, 0, KS_);              \
-    } while (0)
-#define EMCID_SP_DMA16(MJ_, NI_, WM_, WN_, NS_, WPE_)                                                                                \
-    do {                                                                                                                         \
-        if (dbg == 1) hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 1, WPE_>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a);      \
-        else if (dbg == 3) hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 3, WPE_>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a); \
-        else if (a.stamps) hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 2, WPE_>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a); \
-        else hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, 0, WPE_>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a);               \
-    } while (0)
-    if (tile_sel == 7) EMCID_SP_DMA16(4, 4, 2, 2, 2, 2);
-    else if (tile_sel == 8) EMCID_SP_DMA16(8, 4, 2, 4, 1, 2);
-    else if (tile_sel == 9) EMCID_SP_DMA16(5, 4, 2, 2, 1, 2);      // (two fragment sets spill: 56 registers)
-    else if (tile_sel == 10) EMCID_SP_DMA16(5, 2, 1, 4, 2, 2);
-    else if (tile_sel == 11) EMCID_SP_DMA16(2, 2, 2, 2, 2, 4);     // 64 x 64: 32 KB of LDS, 128 registers: four workgroups per compute unit
-    else if (tile_sel >= 4) {
-        if (a.stamps && tile_sel == 4) hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 2, 2, 4, 1, 2>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
-        else if (a.stamps && tile_sel == 5) hipLaunchKernelGGL((linear_sp16_dma_kernel<2, 2, 2, 2, 1, 2>), dim3((unsigned)(per * 8)), dim3(256), 0, st, a);
-        else if (tile_sel == 6) hipLaunchKernelGGL((linear_sp16_dma_kernel<5, 1, 1, 4, 2, 0>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
-        else if (tile_sel == 5) hipLaunchKernelGGL((linear_sp16_dma_kernel<2, 2, 2, 2, 1, 0>), dim3((unsigned)(per * 8)), dim3(256), 0, st, a);
-        else if (dbg) hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 2, 2, 4, 1, 1>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((linear_sp16_dma_kernel<4, 2, 2, 4, 1, 0>), dim3((unsigned)(per * 8)), dim3(512), 0, st, a);
-    } else if (dbg && tile_sel == 3) {
-        if (dbg == 1) EMCID_SP_LAUNCH(5, 1, 1, 4, 1, 2, 1, 2);
-        else if (dbg == 2) EMCID_SP_LAUNCH(5, 1, 1, 4, 1, 2, 2, 2);
-        else EMCID_SP_LAUNCH(5, 1, 1, 4, 1, 2, 3, 2);
-    } else if (dbg == 1) EMCID_SP_LAUNCH(2, 2, 2, 2, 2, 2, 1, 1);
-    else if (dbg == 2) EMCID_SP_LAUNCH(2, 2, 2, 2, 2, 2, 2, 1);
-    else if (dbg == 3) EMCID_SP_LAUNCH(2, 2, 2, 2, 2, 2, 3, 1);
-    else switch (tile_sel) {
-        case 0: EMCID_SP_PF(2, 2, 2, 2, 2, 1); break;
-        case 1: {       // ping-pong: two 128 x 128 tiles per 512-thread workgroup
-            const int pairs = (tiles + 1) / 2, pper = (pairs + 7) / 8;
-            hipLaunchKernelGGL((linear_sp16_pp_kernel<0>), dim3((unsigned)(pper * 8)), dim3(512), 0, st, a);
+#define EMCID_SP_DMA16(MJ_, NI_, WM_, WN_, NS_, WPE_, DBG_)                                                                        \
+    hipLaunchKernelGGL((linear_sp16_dma16_kernel<MJ_, NI_, WM_, WN_, NS_, DBG_, WPE_>), dim3((unsigned)(per * 8)), dim3(64 * WM_ * WN_), 0, st, a)
+    switch (tile_sel) {
+        case 0:
+            if (dbg == 1) EMCID_SP_DMA16(4, 4, 2, 2, 2, 2, 1);
+            else if (dbg == 3) EMCID_SP_DMA16(4, 4, 2, 2, 2, 2, 3);
+            else if (a.stamps) EMCID_SP_DMA16(4, 4, 2, 2, 2, 2, 2);
+            else EMCID_SP_DMA16(4, 4, 2, 2, 2, 2, 0);
             break;
-        }
-        case 2: EMCID_SP_PF(1, 1, 2, 2, 4, 1); break;
-        default: EMCID_SP_LAUNCH(5, 1, 1, 4, 1, 2, 0, 2); break;     // a 64-deep stage ahead; two register sets would spill
+        case 1: EMCID_SP_DMA16(5, 2, 1, 4, 2, 2, 0); break;
+        case 2: EMCID_SP_DMA16(2, 2, 2, 2, 2, 4, 0); break;      // 32 KB of LDS, 128 registers: four workgroups per compute unit
+        case 3: EMCID_SP_DMA16(5, 4, 2, 2, 1, 2, 0); break;      // (two fragment sets would spill: 56 registers)
+        default:
+            hipLaunchKernelGGL((linear_sp16_kernel<1, 1, 2, 2, 2, 4, 0, 1>), dim3((unsigned)(per * 8)), dim3(256), 0, st, a);
+            break;
     }
-#undef EMCID_SP_PF
-#undef EMCID_SP_LAUNCH
 #undef EMCID_SP_DMA16
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;

@@ -144,34 +144,41 @@ def build_tokenizer(vocab: Optional[Dict[str, int]] = None, merges=None, model_m
 
 
 def add_trained_like_outliers(model, seed: int = 5) -> None:
-    """In place: give a random-init CLIP text encoder the weight statistics a TRAINED one is known for and a Gaussian init lacks —
-    a few hidden channels whose LayerNorm gains are 10^2-10^3 times the median (and their biases off zero), matching outlier
-    rows in fc1 / columns in fc2 and in the out projection (the residual stream's massive channels), and two attention heads
-    per layer that sink on the start token (one key direction scaled up).  The split-fp16 forward's accuracy argument (per-row
-    power-of-two scales, the Cauchy-Schwarz bound of fc1's output planes) is exercised on these; seeded, so the reference and
-    the product build the same model."""
+    """In place: give a random-init CLIP text encoder the TENSOR statistics a trained one is known for and a Gaussian init lacks,
+    the way trained networks carry them — large activations met by small weights, so that the function stays well-conditioned
+    (a gain of 10^3 in front of Gaussian q / k projections would saturate every softmax: the fp32 reference itself is then
+    only good to 5e-3, measured) while the intermediate tensors are heavy-tailed:
+      * six hidden channels whose LayerNorm gains are 10^2-10^3 times the median (biases off zero), with the matching input
+        columns of q | k | v (LN1) and fc1 (LN2) scaled down by the same factor (up to a jitter of 1-2): every LayerNorm
+        output row has a few entries a thousand times the rest — the case a per-row scale is worst at;
+      * two "massive activation" channels of the residual stream (a constant 25-40 in the position embeddings);
+      * eight heavy fc1 rows (x 10-40, biases shifted) with their fc2 columns scaled down: heavy-tailed rows of the fc2 input;
+      * two heads per layer that lean on the start token (a bias on their queries, keys x 2).
+    Seeded, so the reference and the product build the same model."""
     g = torch.Generator().manual_seed(seed)
     root = getattr(model, "text_model", model)
-    h = root.config.hidden_size if hasattr(root, "config") else model.config.hidden_size
+    h = root.final_layer_norm.weight.numel()
     n_out = 6
     chans = torch.randperm(h, generator=g)[:n_out]
-    mags = 10.0 ** (2.0 + torch.rand(n_out, generator=g))            # 10^2 .. 10^3
     with torch.no_grad():
-        for li, layer in enumerate(root.encoder.layers):
-            for ln in (layer.layer_norm1, layer.layer_norm2):
-                ln.weight[chans] *= mags * (0.5 + torch.rand(n_out, generator=g))
-                ln.bias[chans] += (torch.rand(n_out, generator=g) - 0.5) * 4.0
+        root.embeddings.position_embedding.weight[:, chans[:2]] += 25.0 + 15.0 * torch.rand(2, generator=g)
+        for layer in root.encoder.layers:
             mlp, at = layer.mlp, layer.self_attn
+            for ln, consumers in ((layer.layer_norm1, (at.q_proj, at.k_proj, at.v_proj)), (layer.layer_norm2, (mlp.fc1,))):
+                m = 10.0 ** (2.0 + torch.rand(n_out, generator=g))            # 10^2 .. 10^3
+                ln.weight[chans] *= m
+                ln.bias[chans] += (torch.rand(n_out, generator=g) - 0.5) * 2.0 * m.sqrt()
+                for lin in consumers:
+                    lin.weight[:, chans] *= (1.0 + torch.rand(n_out, generator=g)) / m
             rows = torch.randperm(mlp.fc1.out_features, generator=g)[:8]
-            mlp.fc1.weight[rows] *= 10.0 ** (1.0 + torch.rand(8, 1, generator=g))       # heavy rows of fc1 (and their fc2 columns)
-            mlp.fc1.bias[rows] += torch.randn(8, generator=g) * 2.0
-            mlp.fc2.weight[:, rows] *= 10.0 ** (0.5 * torch.rand(1, 8, generator=g))
-            at.out_proj.weight[chans] *= 3.0                                            # the residual stream's massive channels
+            r = 10.0 + 30.0 * torch.rand(8, generator=g)
+            mlp.fc1.weight[rows] *= r[:, None]
+            mlp.fc1.bias[rows] += torch.randn(8, generator=g)
+            mlp.fc2.weight[:, rows] /= r[None, :]
             hd = h // at.num_heads
-            for head in torch.randperm(at.num_heads, generator=g)[:2].tolist():          # start-token sinks
-                at.k_proj.weight[head * hd:(head + 1) * hd] *= 4.0
-                at.q_proj.bias[head * hd:(head + 1) * hd] += 1.5
-        root.final_layer_norm.weight[chans] *= mags.sqrt()
+            for head in torch.randperm(at.num_heads, generator=g)[:2].tolist():
+                at.k_proj.weight[head * hd:(head + 1) * hd] *= 2.0
+                at.q_proj.bias[head * hd:(head + 1) * hd] += 0.5
 
 
 def build_text_encoder(kind: str = "toy", vocab_size: Optional[int] = None, seed: int = 0,

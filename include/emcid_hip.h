@@ -127,18 +127,16 @@ int emcid_split_rows_f16(const float* X, int64_t ldx, int64_t rows, int64_t K, v
                          float* max_row_norm, void* stream);
 
 /* Y[M,N] = act(X W^T + bias) + residual like emcid_linear_f32 (the same nn.Linear calls of CLIPTextModel.forward,
- * emcid/compute_z.py:2296-2316), with X [M,K] and W [N,K] given as split matrices: three v_mfma_f32_32x32x16_f16 per k-step
+ * emcid/compute_z.py:2296-2316), with X [M,K] and W [N,K] given as split matrices: three f16 MFMAs per k-step
  * (hi.hi + hi.lo + lo.hi, fp32 accumulate; the dropped lo.lo term is <= 2^-22 of a product), scales undone exactly in the
  * epilogue.  K % 32 == 0.  Outputs: Y fp32 (may be NULL) and / or Yp = the result as a split matrix for the next projection,
  * under the CALLER's per-row scale y_scale[m] = 2^e (a bound on the row's magnitude is enough: |Y[m][n]| y_scale[m] < 2^15
- * must hold; NULL = 1); N % 8 == 0 for Yp.  cfg: -1 auto; bits 0-1 tile (0: 128 x 128, 1: two 128 x 128 tiles per
- * eight-wave workgroup ("ping-pong"), 2: 64 x 64, 3: 160 x 128 with the K range split between two wave groups, K % 64 == 0),
- * bits 2-3 prefetch distance - 1; 64 / 128 / 192: both operands staged by LDS-DMA (global_load_lds_dwordx4 into an XOR-swizzled
- * image, no staging registers, no LDS stores) on 256 x 256 tiles / eight waves, 128 x 128 tiles / four waves (both: the same bits
- * as tile 0), or the 160 x 128 tile with the K split (the same bits as tile 3; K % 64 == 0).  cfg = -1 takes them where it would
- * take tile 0 at K <= 1536 (256 x 256 when those tiles fill their last round of 256 workgroups to 85 %, else 128 x 128) and
- * wherever it would take tile 3 (EMCID_SP16_DMA=1: not there; 0: never).  256 / 320 (ABI 13): the LDS-DMA structure on
- * v_mfma_f32_16x16x32_f16 — 128 x 128 tiles on four waves / 256 x 256 on eight (another summation order: compare, do not equate). */
+ * must hold; NULL = 1); N % 8 == 0 for Yp.  ldx, ldw < 2^20.  cfg: -1 auto (by the number of tiles each form would give); 0:
+ * 128 x 128 tiles, 1: 80 x 128, 2: 64 x 64, 3: 160 x 128 — four waves, operands by LDS-DMA (buffer_load ... lds into an
+ * XOR-swizzled image, no staging registers, no LDS stores), three v_mfma_f32_16x16x32_f16 per k-step and accumulator block,
+ * epilogue through LDS (whole-row stores); 4: 64 x 64 with register-staged operands on v_mfma_f32_32x32x16_f16 (launches of less
+ * than one tile per compute unit); + 16 / + 48 with cfg 0: timing-only builds (results wrong).  The forms sum in different
+ * orders: compare, do not equate. */
 int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale, const void* Wp, int64_t ldw,
                           const float* w_inv_scale, const float* bias, const float* residual, int64_t ldr, float* Y, int64_t ldy,
                           void* Yp, int64_t ldp, const float* y_scale, int64_t M, int64_t N, int64_t K, int act, int cfg,
@@ -149,7 +147,7 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
  * contraction runs over the tokens; scales per 32 768-token chunk) and three f16 MFMAs per k-step; the lower 128 x 128 tiles, the
  * token range of a tile cut into parts whose scaled results are added into G with fp32 atomics (G is an accumulator: sums in no
  * fixed order, like the exact-f32 kernel's multi-slab mode).  d % 4 == 0; workspace: emcid_gram_sp16_workspace_bytes(d). */
-/* Diagnostic (ABI 13): until called again with NULL, the LDS-DMA projection launches (cfg 64 / 128 / 256 / 320) run a stamped
+/* Diagnostic (ABI 13): until called again with NULL, the 128 x 128 projection launches (cfg 0) run a stamped
  * build: per workgroup {shader clock at the K loop's start, at its end, 100 MHz clock at its start, at its end, 100 MHz clock at
  * kernel entry, at kernel exit, -, -} at stamps_dev[8 * blockIdx.x] — the in-kernel clock under load and the split of a
  * workgroup's life into prologue / K loop / epilogue (scripts/mb_linear_sp16_r5.py). */

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Round 5: the LDS-DMA forms of the split-fp16 projection kernel on v_mfma_f32_32x32x16_f16 (cfg 64 / 128) against the same
-structure on v_mfma_f32_16x16x32_f16 (cfg 256: 128 x 128 on four waves, both fragment sets in registers; cfg 320: 256 x 256 on
-eight waves, progressive fragment reload), interleaved rounds in one process (cdna_hip_programming.md rule 24), with
+"""Round 5: the tile forms of the split-fp16 projection kernel (cfg 0-3: 128 x 128, 80 x 128, 64 x 64, 160 x 128 on
+v_mfma_f32_16x16x32_f16 with LDS-DMA operands; cfg 4: the register-staged 64 x 64 kernel), interleaved rounds in one process
+(cdna_hip_programming.md rule 24) — profiles/r05_mb_linear_sp16_{dbg,epi,forms,small}.txt were taken with this script at earlier
+commits of the round, when the 32x32x16 LDS-DMA forms (since removed) were still in the library — with
  * the error of each form against the fp64 product,
  * the timing-only builds (no DMA / MFMAs only) of each,
  * the IN-KERNEL clock of each form: delta s_memtime / delta s_memrealtime x 100 MHz around the K loop of every workgroup after
@@ -33,10 +34,8 @@ lib.emcid_debug_linear_sp16_stamps.restype = C.c_int
 lib.emcid_debug_linear_sp16_stamps.argtypes = [C.c_void_p]
 
 # (cfg, name, tile rows, tile cols, waves per workgroup, MFMAs per wave and 32-deep stage, nominal cycles per MFMA)
-FORMS = [(64, "32x32x16 256x256/8w", 256, 256, 8, 48, 32), (128, "32x32x16 128x128/4w", 128, 128, 4, 24, 32),
-         (256, "16x16x32 128x128/4w", 128, 128, 4, 48, 16), (320, "16x16x32 256x256/8w", 256, 256, 8, 96, 16),
-         (384, "16x16x32 160x128/4w", 160, 128, 4, 60, 16), (448, "16x16x32 80x128/4w", 80, 128, 4, 30, 16),
-         (512, "16x16x32 64x64/4w", 64, 64, 4, 12, 16)]
+FORMS = [(0, "128x128", 128, 128, 4, 48, 16), (1, "80x128", 80, 128, 4, 30, 16), (2, "64x64", 64, 64, 4, 12, 16),
+         (3, "160x128", 160, 128, 4, 60, 16)]
 if os.environ.get("MB_FORMS"):
     FORMS = [f for f in FORMS if str(f[0]) in os.environ["MB_FORMS"].split(",")]
 
@@ -83,13 +82,10 @@ for M, K, N, name in shapes:
         errs[cfg] = (e.max().item() / top, e.pow(2).mean().sqrt().item() / top, (yy - yauto).abs().max().item() / top)
     fns = [(lambda c=cfg: hip.linear_sp(xs, ws, b, out=y, cfg=c)) for cfg, *_ in FORMS]
     fns.append(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=4))
-    fns.append(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=192))
-    fns.append(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=6))
     fns.append(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=-1))
     tt = rounds(fns)
     t_auto = med(tt[-1])
-    print(f"   auto                      {t_auto:7.1f} us  {fl / t_auto / 1e6:6.1f} TF-equivalent | register-staged 128x128/pf2 {med(tt[-4]):7.1f} us | "
-          f"32x32x16 160x128 K-split (LDS-DMA) {med(tt[-3]):7.1f} us | register-staged 64x64/pf2 {med(tt[-2]):7.1f} us", flush=True)
+    print(f"   auto                      {t_auto:7.1f} us  {fl / t_auto / 1e6:6.1f} TF-equivalent | register-staged 64x64 {med(tt[-2]):7.1f} us", flush=True)
     dbg = {}
     if os.environ.get("MB_DBG", "1") == "1":
         dfns, keys = [], []
@@ -97,14 +93,18 @@ for M, K, N, name in shapes:
             for d, dn in ((16, "no-dma"), (48, "mfma-only")):
                 if os.environ.get("MB_DBG_FORMS", "1") != "1":
                     continue
-                if cfg in (64, 128) and d == 48:
-                    continue            # the 32-row DMA kernels have no MFMA-only build
+                if cfg != 0:
+                    continue            # timing-only builds exist for the 128 x 128 form
                 dfns.append(lambda c=cfg + d: hip.linear_sp(xs, ws, b, out=y, cfg=c))
                 keys.append((cfg, dn))
         for k, v in zip(keys, rounds(dfns, n_rounds=3)):
             dbg[k] = med(v)
     for (cfg, cn, bm, bn, waves, mfma_per_stage, nominal), t in zip(FORMS, tt):
         tm = med(t)
+        if cfg != 0:           # the stamped build exists for the 128 x 128 form
+            e = errs[cfg]
+            print(f"   {cn:24s} {tm:7.1f} us  {fl / tm / 1e6:6.1f} TF-eq = {3 * fl / tm / 1e9:6.3f} PF executed (min {min(t):6.1f}) | err max {e[0]:.1e} rms {e[1]:.1e} vs auto {e[2]:.1e}", flush=True)
+            continue
         # in-kernel clock: >= 2 s of back-to-back launches, then the stamps of the last one
         tiles = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
         nwg = ((tiles + 7) // 8) * 8

@@ -727,14 +727,14 @@ def test_split_rows_keeps_22_bits_under_a_per_row_scale():
     assert (sp2.float() - wide[:, :128]).abs().max().item() <= wide.abs().max().item() * 2.0 ** -21
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 4, 1, 5, 2, 6, 3, 7, 64, 128, 192, 256, 320, 384, 448, 512])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])      # auto; 128 x 128, 80 x 128, 64 x 64, 160 x 128 (LDS-DMA, 16x16x32); register-staged 64 x 64
 @pytest.mark.parametrize("M,K,N", [(6400, 768, 2304), (6400, 3072, 768), (1000, 3072, 768), (640, 768, 3072), (300, 1280, 1280),
                                    (129, 96, 257), (37, 2048, 200), (256, 32, 32), (330, 192, 130)])
 def test_linear_sp16_vs_torch(M, K, N, cfg):
     """emcid_linear_sp16_f32 against the fp64 product at the UNCHANGED tolerance of the exact-f32 kernel's test
     (test_linear_f32_vs_torch): every tile form, ragged edges, the fused epilogues, the split-fp16 output for the next
     projection."""
-    if cfg >= 0 and M * N * K > 6400 * 768 * 2304 // 2 and (cfg & 3) == 2:
+    if cfg in (2, 4) and M * N * K > 6400 * 768 * 2304 // 2:
         pytest.skip("64 x 64 tiles on the large shapes: covered by the smaller ones")
     g = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K + 4, generator=g).to(DEV)[:, :K]
@@ -748,10 +748,8 @@ def test_linear_sp16_vs_torch(M, K, N, cfg):
     y = hip.linear_sp(xs, ws_, b, cfg=cfg)
     assert (y.double() - ref).abs().max().item() <= tol
     assert (y - F.linear(x, w, b)).abs().max().item() <= 2 * tol
-    if cfg in (64, 128):       # the LDS-DMA kernels contract every element in the order of the register-staged ones: the same bits
+    if cfg in (1, 2, 3):       # the LDS-DMA forms contract every element over k in the same order whatever the tile: the same bits
         assert torch.equal(y, hip.linear_sp(xs, ws_, b, cfg=0))
-    if cfg == 192 and K % 64 == 0:
-        assert torch.equal(y, hip.linear_sp(xs, ws_, b, cfg=3))
     assert torch.equal(hip.linear_sp(xs, ws_, b, cfg=cfg), y)                   # the same bits call after call
     y0 = hip.linear_sp(xs, ws_, None, cfg=cfg)
     assert (y0.double() - F.linear(x.double(), w.double())).abs().max().item() <= tol
@@ -781,7 +779,7 @@ def test_linear_sp16_vs_torch(M, K, N, cfg):
         assert yp2.f32 is None and torch.equal(yp2.planes, yp.planes)
 
 
-@pytest.mark.parametrize("cfg", [-1, 256, 448, 2])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 4])
 def test_linear_sp16_heavy_tailed_operands(cfg):
     """Operands with the statistics of a trained encoder rather than a Gaussian init: a few channels 10^3 times the rest, rows with
     Cauchy tails, outlier weight rows.  The split keeps 22-23 bits relative to each ROW's largest magnitude, so the error of an
