@@ -370,10 +370,13 @@ def test_rccl_column_sharded_solve_at_headline_size(tmp_path):
         np.testing.assert_allclose(np.abs(got[n]).max(), scale, rtol=1e-4)
 
 
-def test_bench_self_launch_two_ranks_gloo(tmp_path):
-    """`python bench.py --gpus 2` without a launcher: the script starts its own torch.distributed.run child before touching the
-    GPU and the two ranks (sharing this box's GPU, EMCID_BENCH_BACKEND=gloo: collectives staged through the host) produce ONE
-    JSON line with the contract's fields — the path the driver's N > 1 runs take, kept from rotting on a one-GPU box."""
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_self_launch_gloo(tmp_path, ranks):
+    """`python bench.py --gpus N` without a launcher: the script starts its own torch.distributed.run child before touching the
+    GPU and the ranks (sharing this box's GPU, EMCID_BENCH_BACKEND=gloo: collectives staged through the host) produce ONE
+    JSON line with the contract's fields — the path the driver's N > 1 runs take, kept from rotting on a one-GPU box.  Four ranks
+    (the box allows six processes on its card, this test runner being one): 50-concept shards and 24 column tiles over four ranks, every
+    rank in `per_rank`, and the companion record of N independent replicas (`weak_replicas`)."""
     import json
     import subprocess
     import sys
@@ -381,16 +384,18 @@ def test_bench_self_launch_two_ranks_gloo(tmp_path):
     env = dict(os.environ, EMCID_BENCH_BACKEND="gloo", TMPDIR=str(tmp_path))
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--concepts", "200",
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--concepts", "200",
                         "--no-cpu-baseline", "--no-stage0", "--no-variants"], env=env, capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["config"]["backend"] == "gloo"
+    assert out["n_gpus"] == ranks and out["steps"] == 2 and out["warmup"] == 1 and out["config"]["backend"] == "gloo"
     assert out["value"] > 0 and out["ms_per_step"] > 0 and out["scaling"] == "strong" and out["unit"] == "concept-edits/s"
-    assert out["config"]["parallelism"] == "concept-shard x2" and out["roofline"] is not None
+    assert out["config"]["parallelism"] == f"concept-shard x{ranks}" and out["roofline"] is not None
     # per-rank phase times, so that a scaling curve can be read: both ranks report, with the collectives of the sharded solve
-    assert out["config"]["world_size_seen"] == 2 and [r["rank"] for r in out["per_rank"]] == [0, 1]
+    assert out["config"]["world_size_seen"] == ranks and [r["rank"] for r in out["per_rank"]] == list(range(ranks))
+    weak = out["weak_replicas"]
+    assert weak["scaling"] == "weak" and weak["value"] > 0 and weak["steps"] == 2
     for r in out["per_rank"]:
         ph = r["phases_ms_per_call"]
         assert {"k_all_gather", "all_reduce_S", "all_reduce_U", "solve (incl. its collectives)"} <= set(ph)
