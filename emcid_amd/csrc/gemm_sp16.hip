@@ -425,7 +425,7 @@ __device__ __forceinline__ int sp_key16(int r) { return ((r >> 1) & 7) ^ ((((r >
 // residual to and stores 4 rows x 256 contiguous bytes (fp32) and 4 x 256 bytes of planes.  LDS operations of one wave execute
 // in order and nobody else touches the region, so one workgroup barrier (everybody is out of the stage buffers) is all.
 template <int MJ, int NI, int WM, int WN>
-__device__ __forceinline__ void sp_finish16(const SpArgs& a, int m0, int n0, unsigned char* smem, v4f (&acc)[NI][MJ]) {
+__device__ __forceinline__ void sp_finish16(const SpArgs& a, int m0, int n0, unsigned char* smem, const float* side, v4f (&acc)[NI][MJ]) {
     constexpr int BM = 16 * MJ * WM, BN = 16 * NI * WN;
     static_assert(NI == 4 || NI == 2, "the LDS pass moves 32 rows x 64 or 32 columns per wave and step");
     constexpr int SLOTS = 4 * NI, ROWBYTES = 16 * SLOTS, RPI = 64 / SLOTS;      // 16-byte slots per row, rows per wave-instruction on the way out
@@ -445,13 +445,11 @@ __device__ __forceinline__ void sp_finish16(const SpArgs& a, int m0, int n0, uns
     auto epilogue = [&](auto actfn) __attribute__((always_inline)) {
         if (interior) {
             unsigned char* region = smem + wave * (32 * ROWBYTES);
-            v4f w4[NI], b4[NI];
+            v4f w4[NI], b4[NI];         // from the side area the prologue filled: [xs BM | ps BM | ws BN | bias BN]
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int n = n0 + wn0 + 16 * i + 4 * l4;
-                w4[i] = *reinterpret_cast<const v4f*>(ws + n);
-                b4[i] = (v4f){0.f, 0.f, 0.f, 0.f};
-                if (bias != nullptr) b4[i] = *reinterpret_cast<const v4f*>(bias + n);
+                w4[i] = *reinterpret_cast<const v4f*>(side + 2 * BM + wn0 + 16 * i + 4 * l4);
+                b4[i] = *reinterpret_cast<const v4f*>(side + 2 * BM + BN + wn0 + 16 * i + 4 * l4);
             }
             const int oslot = lane % SLOTS, orow = lane / SLOTS;      // on the way OUT: this lane's 16-byte slot and row inside a wave-instruction
             const int ncol = n0 + wn0 + 4 * oslot;
@@ -462,7 +460,7 @@ __device__ __forceinline__ void sp_finish16(const SpArgs& a, int m0, int n0, uns
                 for (int jj = 0; jj < 2; ++jj) {
                     const int j = 2 * c + jj;
                     if (j >= MJ) continue;
-                    const float sx = a.xs[m0 + wm0 + 16 * j + l15];
+                    const float sx = side[wm0 + 16 * j + l15];
 #pragma unroll
                     for (int i = 0; i < NI; ++i) {
                         v4f v;
@@ -483,7 +481,7 @@ __device__ __forceinline__ void sp_finish16(const SpArgs& a, int m0, int n0, uns
                         for (int e = 0; e < 4; ++e) v[e] += r[e];
                     }
                     if (Y != nullptr) *reinterpret_cast<v4f*>(Y + (int64_t)m * ldy + ncol) = v;
-                    if (P != nullptr) sp_store4(P + (int64_t)m * ldp, ncol, v[0], v[1], v[2], v[3], a.ps != nullptr ? a.ps[m] : 1.f);
+                    if (P != nullptr) sp_store4(P + (int64_t)m * ldp, ncol, v[0], v[1], v[2], v[3], side[BM + wm0 + 32 * c + row]);
                 }
             }
             return;
@@ -529,7 +527,11 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WP
     constexpr int STAGE = (BM + BN) * ROWB;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "whole pieces per operand");
     static_assert(2 * STAGE >= NWV * 2048 * NI, "the epilogue's LDS regions");
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+    // behind the two stage buffers: the tile's epilogue vectors — 2^-e of its X rows, the caller's plane scale of those rows, 2^-e
+    // and bias of its W rows — fetched in the prologue underneath the first stages' DMA, so that the epilogue starts from LDS
+    // instead of from three dependent global loads (a workgroup's epilogue was 4.4 us of its 27.7, profiles/r05_mb_linear_sp16_epi.txt)
+    constexpr int SIDE = 4 * (2 * BM + 2 * BN);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + SIDE];
     const int per = (a.tiles + 7) / 8;
     const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (tile >= a.tiles || (int)(blockIdx.x >> 3) >= per) return;
@@ -628,7 +630,30 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WP
 
     issue(0, smem);
     if (T > 1) issue(1, smem + STAGE);
-    __builtin_amdgcn_s_waitcnt(0x0f70);                               // vmcnt(0) (waves stage different numbers of pieces)
+    {
+        float* side = reinterpret_cast<float*>(smem + 2 * STAGE);      // [xs BM | ps BM | ws BN | bias BN]
+        constexpr int NSV = (BM + BN + 64 * NWV - 1) / (64 * NWV);
+        float sv0[NSV], sv1[NSV];
+#pragma unroll
+        for (int q = 0; q < NSV; ++q) {
+            const int e = tid + q * 64 * NWV;
+            sv0[q] = sv1[q] = 0.f;
+            if (e < BM) {
+                sv0[q] = a.xs[min(m0 + e, a.M - 1)];
+                sv1[q] = a.ps != nullptr ? a.ps[min(m0 + e, a.M - 1)] : 1.f;
+            } else if (e < BM + BN) {
+                sv0[q] = a.ws[min(n0 + e - BM, a.N - 1)];
+                sv1[q] = a.bias != nullptr ? a.bias[min(n0 + e - BM, a.N - 1)] : 0.f;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);                           // vmcnt(0): the stages (waves stage different numbers of pieces) and these
+#pragma unroll
+        for (int q = 0; q < NSV; ++q) {
+            const int e = tid + q * 64 * NWV;
+            if (e < BM) side[e] = sv0[q], side[BM + e] = sv1[q];
+            else if (e < BM + BN) side[2 * BM + e - BM] = sv0[q], side[2 * BM + BN + e - BM] = sv1[q];
+        }
+    }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xc07f);                               // the prologue's scalar loads (see the 32-row kernel)
@@ -711,7 +736,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WP
             st[0] = t_clk; st[1] = e_clk; st[2] = t_real; st[3] = e_real; st[4] = t_begin;
         }
     }
-    sp_finish16<MJ, NI, WM, WN>(a, m0, n0, smem, acc);
+    sp_finish16<MJ, NI, WM, WN>(a, m0, n0, smem, reinterpret_cast<const float*>(smem + 2 * STAGE), acc);
     if constexpr (DBG == 2) {
         if (a.stamps != nullptr && tid == 0) a.stamps[8 * (int64_t)blockIdx.x + 5] = (long long)__builtin_amdgcn_s_memrealtime();
     }
