@@ -27,6 +27,9 @@ shapes = [(rows, 768, 2304, "qkv"), (rows, 768, 3072, "fc1"), (rows, 768, 768, "
           (1000, 3072, 768, "fc2-keys"), (3072, 768, 768, "out-query"), (3072, 768, 3072, "fc1-query"), (3072, 3072, 768, "fc2-query"),
           (1000, 5120, 1280, "fc2-keys-bigG"), (2100, 768, 2304, "qkv-2k"), (2100, 3072, 768, "fc2-2k"),
           (rows, 1280, 3840, "qkv-bigG"), (rows, 1280, 5120, "fc1-bigG")]
+# whole rounds of 128 x 128 tiles on 512 workgroup slots (tile-quantisation check): 504 / 1008 / 1512 tiles
+shapes += [(3584, 768, 2304, "qkv-504t"), (7168, 768, 2304, "qkv-1008t"), (2688, 768, 3072, "fc1-504t"), (5376, 768, 3072, "fc1-1008t"),
+           (8064, 768, 3072, "fc1-1512t")]
 if os.environ.get("MB_SHAPES"):
     shapes = [sh for sh in shapes if sh[3] in os.environ["MB_SHAPES"].split(",")]
 lib = hip.load()
@@ -101,6 +104,18 @@ for M, K, N, name in shapes:
             dbg[k] = med(v)
     for (cfg, cn, bm, bn, waves, mfma_per_stage, nominal), t in zip(FORMS, tt):
         tm = med(t)
+        if os.environ.get("MB_RB") or os.environ.get("MB_STAGGER"):
+            # the tile order's super-row height (row tiles) and the first round's stagger (mode:sleeps of 2 048 cycles),
+            # interleaved rounds; "0" / "1:0" = what the library does.  Needs the diagnostic entry of
+            # profiles/r05_linear_stagger_dropped.patch (measured: no gain from either, profiles/r05_mb_linear_sp16_order.txt)
+            knobs = [(int(v), 0, 1) for v in os.environ.get("MB_RB", "").split(",") if v]
+            knobs += [(0, int(v.split(":")[1]), int(v.split(":")[0])) for v in os.environ.get("MB_STAGGER", "").split(",") if v]
+            def with_knob(kn, c=cfg):
+                lib.emcid_debug_linear_sp16_order(*kn)
+                hip.linear_sp(xs, ws, b, out=y, cfg=c)
+            res = rounds([(lambda kn=kn: with_knob(kn)) for kn in knobs], n_rounds=5)
+            lib.emcid_debug_linear_sp16_order(0, -1, 1)
+            print(f"      {cn}: (super-row, stagger, mode) -> us: " + " ".join(f"{kn}:{med(v):.1f}" for kn, v in zip(knobs, res)), flush=True)
         if cfg != 0:           # the stamped build exists for the 128 x 128 form
             e = errs[cfg]
             print(f"   {cn:24s} {tm:7.1f} us  {fl / tm / 1e6:6.1f} TF-eq = {3 * fl / tm / 1e9:6.3f} PF executed (min {min(t):6.1f}) | err max {e[0]:.1e} rms {e[1]:.1e} vs auto {e[2]:.1e}", flush=True)
@@ -139,3 +154,18 @@ for M, K, N, name in shapes:
               f" vs auto {e[2]:.1e} | clock {clk.median().item():.3f} GHz (p10 {clk.quantile(0.1).item():.3f}) loop {loop_cycles:8.0f} cyc ="
               f" {per_mfma:5.1f} cyc/MFMA at the workgroup's SIMD share (nominal {nominal}) | workgroup: prologue {pro:5.1f} + loop {lp:5.1f} + epilogue {epi:5.1f} us,"
               f" launch span {span:6.1f} us, last workgroup starts at {last_start:5.1f}{extra}", flush=True)
+        if os.environ.get("MB_TIMELINE"):
+            # workgroups alive (and inside their K loop) every 4 us of the launch, and a workgroup's lifetime by start order
+            t_in = (st[:, 4] - st[:, 4].min()).double() * 0.01
+            t_l0 = (st[:, 2] - st[:, 4].min()).double() * 0.01
+            t_l1 = (st[:, 3] - st[:, 4].min()).double() * 0.01
+            t_out = (st[:, 5] - st[:, 4].min()).double() * 0.01
+            line = []
+            for t in range(0, int(span) + 4, 4):
+                line.append(f"{t}:{int(((t_in <= t) & (t_out > t)).sum())}/{int(((t_l0 <= t) & (t_l1 > t)).sum())}")
+            print("      alive/in-loop at t us: " + " ".join(line))
+            order = torch.argsort(t_in)
+            life = (t_out - t_in)[order]
+            q = len(life) // 8
+            print("      lifetime (us) by start order, eighths: " + " ".join(f"{life[i * q:(i + 1) * q].mean().item():.1f}" for i in range(8))
+                  + f" | starts (us) eighth means: " + " ".join(f"{t_in[order][i * q:(i + 1) * q].mean().item():.1f}" for i in range(8)), flush=True)
