@@ -1227,8 +1227,9 @@ def stage0_record(workdir, device, n_captions):
     exe = float(rows) * d * d * len(names)
     split = bool(hip.GRAM_SPLIT)
     peak = F16_MFMA_PEAK_TFLOPS / 3.0 if split else F32_MFMA_PEAK_TFLOPS
-    kernel = ("gram_sp16_kernel (csrc/gemm_sp16.hip: v_mfma_f32_32x32x16_f16 on X^T planes under per-feature scales, lower tiles, "
-              "fp32 atomics) + gram_colmax_kernel + gram_transpose_split_kernel") if split else \
+    kernel = ("gram_sp16_kernel (csrc/gemm_sp16.hip: the projection kernel's K loop — v_mfma_f32_16x16x32_f16, operands by LDS-DMA — on "
+              "X^T planes under per-feature scales, lower 128 x 128 tiles, fp32 atomics) + gram_colmax_kernel + "
+              "gram_transpose_split_kernel (both apply the packed forward's row weights as they read the rows)") if split else \
         "gram_f32_kernel (v_mfma_f32_32x32x2_f32 SYRK)"
     shutil.rmtree(tmp / "stats", ignore_errors=True)
     return {"workload": f"{n_captions} synthetic captions, SD-v1.4 dims, 12 layers in one pass (BASELINE config 5, one GPU), "

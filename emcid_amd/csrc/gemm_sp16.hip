@@ -518,28 +518,24 @@ __device__ __forceinline__ void sp_finish16(const SpArgs& a, int m0, int n0, uns
     else epilogue([](float x) { return x; });
 }
 
-// DBG (timing / diagnosis only): 1 = no DMA inside the loop (results wrong), 2 = shader-clock and 100 MHz stamps around the K
-// loop into a.stamps (results right), 3 = MFMAs only: no DMA and no fragment reads inside the loop (results wrong)
-template <int MJ, int NI, int WM, int WN, int NSLOT, int DBG, int WPE = 2>
-__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void linear_sp16_dma16_kernel(SpArgs a) {
+// The K loop of a tile on v_mfma_f32_16x16x32_f16 with its operands by LDS-DMA: `Xt` / `Wt` = the tile's first row of either
+// operand's planes, `mrows` / `nrows` = how many of its rows exist (>= 1; the others re-read the last one and are never stored), T
+// stages of 32 k from the pointers on.  `pre.load()` runs between the first stages' DMA and the wait for them, `pre.store()` behind
+// that wait and in front of the first barrier (the projection's epilogue vectors go to LDS there; SpNoPre: nothing).
+// DBG (timing / diagnosis only): 1 = no DMA inside the loop (results wrong), 2 = shader clock and 100 MHz clock at the loop's start
+// into clk[0..1] (results right), 3 = MFMAs only: no DMA and no fragment reads inside the loop (results wrong)
+struct SpNoPre {
+    __device__ __forceinline__ void load() {}
+    __device__ __forceinline__ void store() {}
+};
+
+template <int MJ, int NI, int WM, int WN, int NSLOT, int DBG, bool ILV, class Pre>
+__device__ __forceinline__ void sp_accumulate16(const uint32_t* Xt, int64_t ldx, int mrows, const uint32_t* Wt, int64_t ldw, int nrows, int T,
+                                                unsigned char* smem, v4f (&acc)[NI][MJ], Pre& pre, long long (&clk)[2]) {
     constexpr int NWV = WM * WN, BM = 16 * MJ * WM, BN = 16 * NI * WN;
     constexpr int ROWB = 128, RPP = 8, CPR = 8;
     constexpr int STAGE = (BM + BN) * ROWB;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "whole pieces per operand");
-    static_assert(2 * STAGE >= NWV * 2048 * NI, "the epilogue's LDS regions");
-    // behind the two stage buffers: the tile's epilogue vectors — 2^-e of its X rows, the caller's plane scale of those rows, 2^-e
-    // and bias of its W rows — fetched in the prologue underneath the first stages' DMA, so that the epilogue starts from LDS
-    // instead of from three dependent global loads (a workgroup's epilogue was 4.4 us of its 27.7, profiles/r05_mb_linear_sp16_epi.txt)
-    constexpr int SIDE = 4 * (2 * BM + 2 * BN);
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + SIDE];
-    const int per = (a.tiles + 7) / 8;
-    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (tile >= a.tiles || (int)(blockIdx.x >> 3) >= per) return;
-    int bm, bn;
-    sp_tile_of(a, tile, bm, bn);
-    long long t_begin = 0;
-    if constexpr (DBG == 2) t_begin = (long long)__builtin_amdgcn_s_memrealtime();
-    const int m0 = bm * BM, n0 = bn * BN, T = a.K / SPK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const int wm0 = (wave / WN) * (16 * MJ), wn0 = (wave % WN) * (16 * NI);
 
@@ -554,20 +550,20 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WP
         const uint64_t hi = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
         return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(lo | (hi << 32)), 0, 0x7fffffff, 0x00020000);
     };
-    const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(a.X + (int64_t)m0 * a.ldx);
-    const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(a.W + (int64_t)n0 * a.ldw);
+    const __amdgpu_buffer_rsrc_t rsrc_x = make_rsrc(Xt);
+    const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc(Wt);
     constexpr int NPX = BM / RPP, NPW = BN / RPP, PXW = (NPX + NWV - 1) / NWV, PWW = (NPW + NWV - 1) / NWV;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     unsigned off_x[PXW], off_w[PWW];
 #pragma unroll
     for (int s = 0; s < PXW; ++s) {
         const int r = RPP * min(wave + NWV * s, NPX - 1) + lane / CPR;
-        off_x[s] = (unsigned)((min(m0 + r, a.M - 1) - m0) * (int)(4 * a.ldx) + 16 * ((lane % CPR) ^ sp_key16(r)));      // rows past the end: a valid row, never stored
+        off_x[s] = (unsigned)(min(r, mrows - 1) * (int)(4 * ldx) + 16 * ((lane % CPR) ^ sp_key16(r)));      // rows past the end: a valid row, never stored
     }
 #pragma unroll
     for (int s = 0; s < PWW; ++s) {
         const int r = RPP * min(wave + NWV * s, NPW - 1) + lane / CPR;
-        off_w[s] = (unsigned)((min(n0 + r, a.N - 1) - n0) * (int)(4 * a.ldw) + 16 * ((lane % CPR) ^ sp_key16(r)));
+        off_w[s] = (unsigned)(min(r, nrows - 1) * (int)(4 * ldw) + 16 * ((lane % CPR) ^ sp_key16(r)));
     }
     auto issue = [&](int it, unsigned char* stage) __attribute__((always_inline)) {
         // ((int) casts: an argument of template-dependent type makes hipcc's HOST pass drop the kernel's instantiation without a
@@ -585,7 +581,6 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WP
     };
     const int ch = 16 * ((2 * l4) ^ sp_key16(l15));                        // hi chunk; lo = ch ^ 16
     const int fx = (wm0 + l15) * ROWB, fw = (BM + wn0 + l15) * ROWB;
-    v4f acc[NI][MJ];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -630,30 +625,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WP
 
     issue(0, smem);
     if (T > 1) issue(1, smem + STAGE);
-    {
-        float* side = reinterpret_cast<float*>(smem + 2 * STAGE);      // [xs BM | ps BM | ws BN | bias BN]
-        constexpr int NSV = (BM + BN + 64 * NWV - 1) / (64 * NWV);
-        float sv0[NSV], sv1[NSV];
-#pragma unroll
-        for (int q = 0; q < NSV; ++q) {
-            const int e = tid + q * 64 * NWV;
-            sv0[q] = sv1[q] = 0.f;
-            if (e < BM) {
-                sv0[q] = a.xs[min(m0 + e, a.M - 1)];
-                sv1[q] = a.ps != nullptr ? a.ps[min(m0 + e, a.M - 1)] : 1.f;
-            } else if (e < BM + BN) {
-                sv0[q] = a.ws[min(n0 + e - BM, a.N - 1)];
-                sv1[q] = a.bias != nullptr ? a.bias[min(n0 + e - BM, a.N - 1)] : 0.f;
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0x0f70);                           // vmcnt(0): the stages (waves stage different numbers of pieces) and these
-#pragma unroll
-        for (int q = 0; q < NSV; ++q) {
-            const int e = tid + q * 64 * NWV;
-            if (e < BM) side[e] = sv0[q], side[BM + e] = sv1[q];
-            else if (e < BM + BN) side[2 * BM + e - BM] = sv0[q], side[2 * BM + BN + e - BM] = sv1[q];
-        }
-    }
+    pre.load();
+    __builtin_amdgcn_s_waitcnt(0x0f70);                               // vmcnt(0): the stages (waves stage different numbers of pieces) and pre's loads
+    pre.store();
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xc07f);                               // the prologue's scalar loads (see the 32-row kernel)
@@ -662,10 +636,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WP
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_sched_barrier(0);
-    long long t_clk = 0, t_real = 0;
     if constexpr (DBG == 2) {
-        t_clk = (long long)__builtin_amdgcn_s_memtime();
-        t_real = (long long)__builtin_amdgcn_s_memrealtime();
+        clk[0] = (long long)__builtin_amdgcn_s_memtime();
+        clk[1] = (long long)__builtin_amdgcn_s_memrealtime();
     }
     if constexpr (NSLOT == 2) {
         // stage `it` is in registers (slot it & 1).  Barrier: every wave's share of stage it + 1 has landed and every wave is
@@ -685,7 +658,48 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WP
             __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
             __builtin_amdgcn_sched_barrier(0);
         };
+        // the same step for it + 2 < T, as ONE basic block whose order is prescribed: the DMA of stage it + 2 and the fragment
+        // reads of stage it + 1 go out between the MFMAs of stage it (two MFMAs, one ds_read_b128, and after each of the first
+        // ones one buffer_load ... lds) instead of in front of them.  Two resident workgroups hide each other's issue gaps
+        // either way (33.6 cycles per MFMA and workgroup = 95 % of the pipe); a workgroup that has its compute unit to itself —
+        // the tail of every round of tiles, launches of about one tile per compute unit — ran at 30 cycles per MFMA, the matrix
+        // pipe idle while its one wave per SIMD issued 16 ds_reads and 8 DMAs (profiles/r05_mb_linear_sp16_rounds.txt).
+        auto body_full = [&](int it, auto sc) __attribute__((always_inline)) {
+            constexpr int S = decltype(sc)::value;
+            constexpr int NREAD = 2 * (MJ + NI), NMFMA = 3 * MJ * NI, MPG = (2 * MJ * NI) / NREAD < 1 ? 1 : (2 * MJ * NI) / NREAD;
+            static_assert(NMFMA >= PXW + PWW + MPG * NREAD, "MFMAs to hide the issue under");
+            constexpr int NDMA = PXW + PWW;
+            unsigned char* cur = smem + (it & 1) * STAGE;
+            unsigned char* oth = smem + ((it + 1) & 1) * STAGE;
+            __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (DBG != 1 && DBG != 3) issue(it + 2, cur);
+            if (DBG != 3) fread(oth, SpIC<S ^ 1>{});
+            mfmas(sc);
+            // (the compiler orders the fragment reads behind the DMAs — both touch LDS —, so the DMAs go first)
+#pragma unroll
+            for (int g = 0; g < NDMA; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            // VMEM read
+            }
+#pragma unroll
+            for (int g = 0; g < NREAD; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MPG, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);            // DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMFMA - NDMA - MPG * NREAD, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+            __builtin_amdgcn_sched_barrier(0);
+        };
         int it = 0;
+        if constexpr (ILV) {
+            for (; it + 3 < T; it += 2) {
+                body_full(it, SpIC<0>{});
+                body_full(it + 1, SpIC<1>{});
+            }
+        }
         for (; it + 1 < T; it += 2) {
             body(it, SpIC<0>{});
             body(it + 1, SpIC<1>{});
@@ -729,16 +743,75 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WP
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+}
+
+// the projection's epilogue vectors — 2^-e of the tile's X rows, the caller's plane scale of those rows, 2^-e and bias of its W rows
+// — fetched underneath the first stages' DMA into an LDS side area [xs BM | ps BM | ws BN | bias BN], so that the epilogue starts
+// from LDS instead of from three dependent global loads (a workgroup's epilogue was 4.4 us of its 27.7,
+// profiles/r05_mb_linear_sp16_epi.txt)
+template <int BM, int BN, int NT>
+struct SpSidePre {
+    static constexpr int NSV = (BM + BN + NT - 1) / NT;
+    const SpArgs& a;
+    int m0, n0;
+    float* side;
+    float sv0[NSV], sv1[NSV];
+    __device__ __forceinline__ void load() {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int q = 0; q < NSV; ++q) {
+            const int e = tid + q * NT;
+            sv0[q] = sv1[q] = 0.f;
+            if (e < BM) {
+                sv0[q] = a.xs[min(m0 + e, a.M - 1)];
+                sv1[q] = a.ps != nullptr ? a.ps[min(m0 + e, a.M - 1)] : 1.f;
+            } else if (e < BM + BN) {
+                sv0[q] = a.ws[min(n0 + e - BM, a.N - 1)];
+                sv1[q] = a.bias != nullptr ? a.bias[min(n0 + e - BM, a.N - 1)] : 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store() {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int q = 0; q < NSV; ++q) {
+            const int e = tid + q * NT;
+            if (e < BM) side[e] = sv0[q], side[BM + e] = sv1[q];
+            else if (e < BM + BN) side[2 * BM + e - BM] = sv0[q], side[2 * BM + BN + e - BM] = sv1[q];
+        }
+    }
+};
+
+template <int MJ, int NI, int WM, int WN, int NSLOT, int DBG, int WPE = 2, bool ILV = (NSLOT == 2)>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void linear_sp16_dma16_kernel(SpArgs a) {
+    constexpr int NWV = WM * WN, BM = 16 * MJ * WM, BN = 16 * NI * WN;
+    constexpr int STAGE = (BM + BN) * 128;
+    static_assert(2 * STAGE >= NWV * 2048 * NI, "the epilogue's LDS regions");
+    constexpr int SIDE = 4 * (2 * BM + 2 * BN);
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE + SIDE];
+    const int per = (a.tiles + 7) / 8;
+    const int tile = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (tile >= a.tiles || (int)(blockIdx.x >> 3) >= per) return;
+    int bm, bn;
+    sp_tile_of(a, tile, bm, bn);
+    long long t_begin = 0;
+    if constexpr (DBG == 2) t_begin = (long long)__builtin_amdgcn_s_memrealtime();
+    const int m0 = bm * BM, n0 = bn * BN;
+    v4f acc[NI][MJ];
+    long long clk[2] = {0, 0};
+    SpSidePre<BM, BN, 64 * NWV> pre{a, m0, n0, reinterpret_cast<float*>(smem + 2 * STAGE)};
+    sp_accumulate16<MJ, NI, WM, WN, NSLOT, DBG, ILV>(a.X + (int64_t)m0 * a.ldx, a.ldx, a.M - m0, a.W + (int64_t)n0 * a.ldw, a.ldw, a.N - n0,
+                                                     a.K / SPK, smem, acc, pre, clk);
     if constexpr (DBG == 2) {
         const long long e_clk = (long long)__builtin_amdgcn_s_memtime(), e_real = (long long)__builtin_amdgcn_s_memrealtime();
-        if (a.stamps != nullptr && tid == 0) {
+        if (a.stamps != nullptr && threadIdx.x == 0) {
             long long* st = a.stamps + 8 * (int64_t)blockIdx.x;
-            st[0] = t_clk; st[1] = e_clk; st[2] = t_real; st[3] = e_real; st[4] = t_begin;
+            st[0] = clk[0]; st[1] = e_clk; st[2] = clk[1]; st[3] = e_real; st[4] = t_begin;
         }
     }
     sp_finish16<MJ, NI, WM, WN>(a, m0, n0, smem, reinterpret_cast<const float*>(smem + 2 * STAGE), acc);
     if constexpr (DBG == 2) {
-        if (a.stamps != nullptr && tid == 0) a.stamps[8 * (int64_t)blockIdx.x + 5] = (long long)__builtin_amdgcn_s_memrealtime();
+        if (a.stamps != nullptr && threadIdx.x == 0) a.stamps[8 * (int64_t)blockIdx.x + 5] = (long long)__builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -800,36 +873,41 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 // (reference: util/runningstats.py:469-511, mom2 += a.t().mm(a) over the caption tokens.)  The contraction runs over the TOKENS,
 // so the operand is X^T [d][t] and the scale is per COLUMN of X (per feature, over the chunk): gram_colmax_kernel finds the
 // column maxima, gram_transpose_split_kernel writes X^T as split planes (rows = features, K = tokens, zero-padded to a multiple
-// of 32), and gram_sp16_kernel is the projection kernel's K loop over the LOWER 128 x 128 tiles with the token range of every
+// of 32), and gram_sp16_kernel is the projection kernel's K loop (sp_accumulate16) over the LOWER 128 x 128 tiles with the token range of every
 // tile cut into `ks` parts (300 lower tiles at d = 3072 do not fill 512 workgroup slots): a part's tile is scaled back by
 // 2^-(e_i + e_j) and added into G with fp32 atomics — G is an accumulator, like the exact-f32 SYRK's multi-slab mode.
-__global__ __launch_bounds__(256) void gram_colmax_kernel(const float* __restrict__ X, int64_t ldx, int t, int d, int rows_per_wg,
-                                                           unsigned* __restrict__ cmax) {
+__global__ __launch_bounds__(256) void gram_colmax_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ rw, int t,
+                                                           int d, int rows_per_wg, unsigned* __restrict__ cmax) {
     const int c4 = blockIdx.x * 256 + threadIdx.x;                 // float4 column group
     if (4 * c4 >= d) return;
     const int r0 = blockIdx.y * rows_per_wg, r1 = min(t, r0 + rows_per_wg);
     v4f m = {0.f, 0.f, 0.f, 0.f};
     for (int r = r0; r < r1; ++r) {
         const v4f x = *reinterpret_cast<const v4f*>(X + (int64_t)r * ldx + 4 * c4);
+        const float w = rw != nullptr ? rw[r] : 1.f;               // (a uniform load per row)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], fabsf(x[e]));
+        for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], fabsf(x[e] * w));
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) atomicMax(cmax + 4 * c4 + e, __float_as_uint(m[e]));      // non-negative floats order like their bits
 }
 
 // one workgroup: 64 tokens x 64 features through LDS; thread -> (feature, group of 8 tokens): 32 contiguous bytes of planes
-__global__ __launch_bounds__(256) void gram_transpose_split_kernel(const float* __restrict__ X, int64_t ldx, int t, int d,
-                                                                    const unsigned* __restrict__ cmax, uint32_t* __restrict__ P,
-                                                                    int64_t ldp, float* __restrict__ inv_scale) {
+__global__ __launch_bounds__(256) void gram_transpose_split_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ rw,
+                                                                    int t, int d, const unsigned* __restrict__ cmax,
+                                                                    uint32_t* __restrict__ P, int64_t ldp, float* __restrict__ inv_scale) {
     __shared__ float tile[64][65];
     const int t0 = blockIdx.x * 64, d0 = blockIdx.y * 64, tid = threadIdx.x;
     for (int v = tid; v < 64 * 16; v += 256) {                    // 64 rows x 16 float4
         const int r = v >> 4, c = (v & 15) * 4;
         v4f x = {0.f, 0.f, 0.f, 0.f};
-        if (t0 + r < t && d0 + c < d) x = *reinterpret_cast<const v4f*>(X + (int64_t)(t0 + r) * ldx + d0 + c);
+        float w = 1.f;
+        if (t0 + r < t && d0 + c < d) {
+            x = *reinterpret_cast<const v4f*>(X + (int64_t)(t0 + r) * ldx + d0 + c);
+            if (rw != nullptr) w = rw[t0 + r];
+        }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tile[r][c + e] = x[e];
+        for (int e = 0; e < 4; ++e) tile[r][c + e] = x[e] * w;    // fl32(x w): the fp32 product the caller would have formed
     }
     __syncthreads();
 #pragma unroll
@@ -855,9 +933,9 @@ struct GramSpArgs {
 };
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gram_sp16_kernel(GramSpArgs g) {
-    constexpr int MJ = 2, NI = 2, WM = 2, WN = 2, PF = 2;
-    using Geo = SpGeom<MJ, NI, WM, WN, PF, 1>;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[Geo::SMEM];
+    // the projection's 128 x 128 form (two waves by two, 64 x 64 each, v_mfma_f32_16x16x32_f16, operands by LDS-DMA)
+    constexpr int MJ = 4, NI = 4, WM = 2, WN = 2, BT = 128;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * (2 * BT) * 128];
     const int n_lower = g.tiles_side * (g.tiles_side + 1) / 2, items = n_lower * g.ks, per = (items + 7) / 8;
     const int item = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if (item >= items || (int)(blockIdx.x >> 3) >= per) return;
@@ -868,38 +946,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int bn = tile - bm * (bm + 1) / 2;
     const int T = g.K / SPK, it_lo = (int)((int64_t)part * T / g.ks), it_hi = (int)((int64_t)(part + 1) * T / g.ks);
     if (it_hi <= it_lo) return;
-    // the projection kernel's K loop: "X" rows = features of the tile's rows, "W" rows = features of its columns
-    SpArgs a{};
-    a.X = g.XT + (int64_t)it_lo * SPK; a.ldx = g.ld; a.W = g.XT + (int64_t)it_lo * SPK; a.ldw = g.ld;
-    a.M = g.d; a.N = g.d; a.K = g.K;
-    v16f acc[NI][MJ];
+    // the K loop's "X" rows = the features of the tile's COLUMNS (block bn), its "W" rows = those of the tile's rows (block bm):
+    // a register of the accumulators then holds, per wave, 16 consecutive columns in each of 4 rows of G — one atomic
+    // wave-instruction = four 64-byte runs, the size an atomic request leaves the L2 with (MI355X_MICROARCH.md, global float
+    // atomics; 64 lanes in 64 rows would be ~17x slower)
+    const int c0 = bn * BT, r0 = bm * BT;
+    const uint32_t* base = g.XT + (int64_t)it_lo * SPK;
+    v4f acc[NI][MJ];
+    long long clk[2];
+    SpNoPre pre;
+    sp_accumulate16<MJ, NI, WM, WN, 2, 0, true>(base + (int64_t)c0 * g.ld, g.ld, g.d - c0, base + (int64_t)r0 * g.ld, g.ld, g.d - r0,
+                                                it_hi - it_lo, smem, acc, pre, clk);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const int wm0 = (wave / WN) * (16 * MJ), wn0 = (wave % WN) * (16 * NI);
+    float rinv[NI][4];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < MJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // lane side of the accumulators = the tile's COLUMNS (features of block bn), register side = its rows (block bm): one atomic
-    // wave-instruction then adds to two runs of 32 consecutive floats in two rows of G (MI355X_MICROARCH.md, global float atomics:
-    // the full-rate shape; 64 lanes in 64 rows would be ~17x slower)
-    const int c0 = bn * Geo::BM, r0 = bm * Geo::BN;
-    sp_accumulate<MJ, NI, WM, WN, PF, 0, 1>(a, c0, r0, it_hi - it_lo, smem, acc);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, l5 = lane >> 5;
-    const int wm0 = (wave / WN) * (32 * MJ), wn0 = (wave % WN) * (32 * NI);
+        for (int e = 0; e < 4; ++e) rinv[i][e] = g.inv[min(r0 + wn0 + 16 * i + 4 * l4 + e, g.d - 1)];
 #pragma unroll
     for (int j = 0; j < MJ; ++j) {
-        const int col = c0 + wm0 + 32 * j + l31;
+        const int col = c0 + wm0 + 16 * j + l15;
         const float sc = g.inv[min(col, g.d - 1)];
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int row = r0 + wn0 + 32 * i + 8 * q + 4 * l5 + e;
-                    if (row < g.d && col < g.d)
-                        unsafeAtomicAdd(g.G + (int64_t)row * g.ldg + col, acc[i][j][4 * q + e] * (sc * g.inv[row]));
-                }
+            for (int e = 0; e < 4; ++e) {
+                const int row = r0 + wn0 + 16 * i + 4 * l4 + e;
+                if (row < g.d && col < g.d) unsafeAtomicAdd(g.G + (int64_t)row * g.ldg + col, acc[i][j][e] * (sc * rinv[i][e]));
+            }
     }
 }
 
@@ -929,8 +1004,8 @@ int64_t emcid_gram_sp16_workspace_bytes(int64_t d) {
     return round_up(d, 64) * 32768 * 4 + 2 * round_up(d, 64) * 4 + 256;
 }
 
-int emcid_gram_accumulate_sp16_f32(const float* X, int64_t t, int64_t d, int64_t ldx, float* G, int64_t ldg, void* workspace,
-                                   int64_t workspace_bytes, void* stream) {
+int emcid_gram_accumulate_sp16_f32(const float* X, const float* row_weight, int64_t t, int64_t d, int64_t ldx, float* G, int64_t ldg,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
     EMCID_CHECK_ARG(X && G && workspace && t >= 0 && d > 0 && ldx >= d && ldg >= d && d % 4 == 0 && ldx % 4 == 0 && aligned16(X));
     EMCID_CHECK_ARG(workspace_bytes >= emcid_gram_sp16_workspace_bytes(d) && aligned16(workspace) && d < (1 << 20) && t < (1LL << 31));
     if (t == 0) return EMCID_OK;
@@ -944,12 +1019,13 @@ int emcid_gram_accumulate_sp16_f32(const float* X, int64_t t, int64_t d, int64_t
     for (int64_t c0 = 0; c0 < t; c0 += 32768) {
         const int tc = (int)std::min<int64_t>(32768, t - c0), tpad = (int)round_up(tc, 64);
         const float* Xc = X + c0 * ldx;
+        const float* rwc = row_weight != nullptr ? row_weight + c0 : nullptr;
         if (hipMemsetAsync(cmax, 0, dr * sizeof(unsigned), st) != hipSuccess) return fail(EMCID_ERR_HIP, __func__, "hipMemsetAsync");
         const int rows_per_wg = 256;
         hipLaunchKernelGGL(gram_colmax_kernel, dim3((unsigned)((d / 4 + 255) / 256), (unsigned)((tc + rows_per_wg - 1) / rows_per_wg)),
-                           dim3(256), 0, st, Xc, ldx, tc, (int)d, rows_per_wg, cmax);
-        hipLaunchKernelGGL(gram_transpose_split_kernel, dim3((unsigned)(tpad / 64), (unsigned)(dr / 64)), dim3(256), 0, st, Xc, ldx, tc,
-                           (int)d, cmax, P, (int64_t)tpad, inv);
+                           dim3(256), 0, st, Xc, ldx, rwc, tc, (int)d, rows_per_wg, cmax);
+        hipLaunchKernelGGL(gram_transpose_split_kernel, dim3((unsigned)(tpad / 64), (unsigned)(dr / 64)), dim3(256), 0, st, Xc, ldx, rwc,
+                           tc, (int)d, cmax, P, (int64_t)tpad, inv);
         // parts per tile: enough work items for ~3 rounds of the 512 workgroup slots, a last round as full as possible
         const int T = tpad / SPK;
         int ks = 1;

@@ -37,7 +37,7 @@ EXPORTS = [
 PROF_CLASSES = ["prep", "assemble", "chol_leaf", "chol_panel", "chol_trail", "trsm_diag", "trsm_update", "delta_w",
                 "gram", "gather", "dgemm", "misc", "inv_build", "chol_inner", "inv_apply", "inv_block", "linear"]
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 NB = 128      # Cholesky block (csrc/common.h)
 NPAD = 64     # concept padding of the f64 stacks (csrc/common.h)
 
@@ -113,7 +113,7 @@ def load():
         "emcid_linear_workspace_bytes": (i64, []),
         "emcid_split_rows_f16": (i32, [p, i64, i64, i64, p, i64, p, p, p]),
         "emcid_gram_sp16_workspace_bytes": (i64, [i64]),
-        "emcid_gram_accumulate_sp16_f32": (i32, [p, i64, i64, i64, p, i64, p, i64, p]),
+        "emcid_gram_accumulate_sp16_f32": (i32, [p, p, i64, i64, i64, p, i64, p, i64, p]),
         "emcid_add_layernorm_sp16": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p, i64, p, p, p, p]),
         "emcid_embed_layernorm_sp16": (i32, [p, i64, i64, p, i64, i64, p, p, p, p, C.c_float, i64, i64, p, p, p, i64, p, p]),
         "emcid_tree_attention_sp16_supported": (i32, [i64, i64, i64]),
@@ -183,16 +183,28 @@ GRAM_SPLIT = os.environ.get("EMCID_GRAM_SPLIT", "1") != "0"      # 0: always the
 _GRAM_WS = {}
 
 
-def gram_accumulate_(G: torch.Tensor, X: torch.Tensor, ksplit: int = 0):
+def gram_takes_row_weight(X: torch.Tensor, ksplit: int = 0) -> bool:
+    """whether gram_accumulate_ would run this batch on the split-fp16 path (which applies a per-row weight as it reads the rows)"""
+    d = X.shape[1]
+    return bool(GRAM_SPLIT and ksplit != 1 and X.shape[0] >= 2048 and d % 4 == 0 and d >= 256 and X.stride(0) % 4 == 0
+                and X.stride(1) == 1 and X.data_ptr() % 16 == 0 and X.dtype == torch.float32)
+
+
+def gram_accumulate_(G: torch.Tensor, X: torch.Tensor, ksplit: int = 0, row_weight: Optional[torch.Tensor] = None):
     """G (d,d) fp32 lower triangle += X^T X, X (t,d) fp32 with row stride multiple of 4 (runningstats.py:493).  Long batches
     (>= 2048 tokens, ``ksplit != 1``) run on the split-fp16 path (csrc/gemm_sp16.hip: three f16 MFMAs per k-step on X^T planes
     under per-feature scales, fp32 atomics into G); ``ksplit == 1`` — the deterministic mode — and short batches on the exact-f32
-    SYRK (csrc/gram_f32.hip)."""
+    SYRK (csrc/gram_f32.hip).  ``row_weight`` (t,) fp32: row r enters as fl32(row_weight[r] * X[r]) — on the split path inside the
+    kernels that read the rows, otherwise by a multiplication here."""
     assert X.dim() == 2 and G.dim() == 2 and G.shape[0] == G.shape[1] == X.shape[1]
     assert X.stride(1) == 1 and G.stride(1) == 1
     if X.shape[0] == 0:
         return G
     d = X.shape[1]
+    if row_weight is not None:
+        assert row_weight.shape == (X.shape[0],) and row_weight.dtype == torch.float32 and row_weight.is_contiguous()
+        if not (gram_takes_row_weight(X, ksplit) and G.dtype == torch.float32):
+            X, row_weight = X * row_weight.unsqueeze(1), None
     if GRAM_SPLIT and ksplit != 1 and X.shape[0] >= 2048 and d % 4 == 0 and d >= 256 and X.stride(0) % 4 == 0 \
             and X.data_ptr() % 16 == 0 and X.dtype == torch.float32 and G.dtype == torch.float32:
         key = (X.device.index if X.device.index is not None else torch.cuda.current_device(),
@@ -202,7 +214,9 @@ def gram_accumulate_(G: torch.Tensor, X: torch.Tensor, ksplit: int = 0):
             if len(_GRAM_WS) >= 8:
                 _GRAM_WS.clear()
             ws = _GRAM_WS[key] = torch.empty(int(load().emcid_gram_sp16_workspace_bytes(d)), dtype=torch.uint8, device=X.device)
-        _check(load().emcid_gram_accumulate_sp16_f32(_ptr(X, torch.float32, "X"), X.shape[0], d, X.stride(0),
+        _check(load().emcid_gram_accumulate_sp16_f32(_ptr(X, torch.float32, "X"),
+                                                     _ptr(row_weight, torch.float32, "row_weight") if row_weight is not None else None,
+                                                     X.shape[0], d, X.stride(0),
                                                      _ptr(G, torch.float32, "G"), G.stride(0), C.c_void_p(ws.data_ptr()),
                                                      ws.numel(), _stream(G)), "emcid_gram_accumulate_sp16_f32")
         return G

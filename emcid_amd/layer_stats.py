@@ -154,6 +154,12 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
     finally:
         for h in handles:
             h.remove()
+    _finish_layers(todo, stats, files, args, shard, group)
+    return stats
+
+
+def _finish_layers(todo, stats, files, args, shard, group):
+    """all-reduce (caption-sharded runs), read-out and npz write of every collected layer"""
     for ln in todo:
         if shard is not None and shard[1] > 1:
             stats[ln].all_reduce_(group)
@@ -181,7 +187,6 @@ def layer_stats_text_encoder_multi(model, tokenizer, layer_names: Sequence[str],
     else:
         for ln in todo:
             finish(ln)
-    return stats
 
 
 LAST_RUN = {}   # bookkeeping of the most recent Stage-0 pass (rows actually pushed through the Gram kernel vs tokens they stand for)
@@ -256,22 +261,19 @@ def _collect_packed(model, tokenizer, ds, sample, pool, packed, todo, stats, fil
             n_real, tokens = trie.n_nodes, int(sum(len(s) for s in ids))
             LAST_RUN["tokens"] += tokens
             LAST_RUN["rows"] += n_real
-            root = cnt.to(stat_dtype).sqrt().unsqueeze(1)
+            root = cnt.to(stat_dtype).sqrt()
 
             def on_fc2(i, x, out):
                 if i in wanted:
-                    feats = x[:n_real].to(round_dtype).to(stat_dtype) * root
+                    # the rows and their weights: the Gram's kernels form fl(root * row) as they read a long fp32 batch (one pass
+                    # over ~1 GB per layer less than multiplying here); SecondMoment.add multiplies where that does not apply
+                    feats = x[:n_real].to(round_dtype).to(stat_dtype)
                     for ln in wanted[i]:
-                        stats[ln].add(feats, count=tokens)
+                        stats[ln].add(feats, count=tokens, row_weight=root)
                 return None if i == deepest else out
 
             clip_forward.run_layers(graph, trie, deepest, on_fc2, last_rows_only=False, fc2_by_callback={deepest})
-    for ln in todo:
-        if shard is not None and shard[1] > 1:
-            stats[ln].all_reduce_(group)
-        stats[ln].to_(device="cpu")
-        if shard is None or shard[0] == 0:
-            save_cached_state(files[ln], stats[ln], args)
+    _finish_layers(todo, stats, files, args, shard, group)
     return stats
 
 

@@ -76,12 +76,20 @@ class SecondMoment(Stat):
             super().__init__(state)
 
     # -- accumulation --------------------------------------------------------------------------------
-    def add(self, a: torch.Tensor, count: Optional[int] = None):
+    def add(self, a: torch.Tensor, count: Optional[int] = None, row_weight: Optional[torch.Tensor] = None):
         """mom2 += a^T a; ``count`` (default: the rows of ``a``) is what the rows stand for — the packed Stage-0 forward
-        hands in each distinct prefix once, scaled by the square root of its multiplicity."""
+        hands in each distinct prefix once, scaled by the square root of its multiplicity: either already multiplied in, or as
+        ``row_weight`` (rows,) — row r then enters as fl(row_weight[r] * a[r]), the product formed inside the Gram's own
+        kernels when the batch goes straight to the split-fp16 path, and here otherwise."""
         a = self._normalize_add_shape(a)
         if len(a) == 0:
             return
+        if row_weight is not None:
+            direct = (a.is_cuda and a.dtype == torch.float32 and a.shape[0] >= self.stage_tokens and a.is_contiguous()
+                      and row_weight.dtype == torch.float32 and hip.gram_takes_row_weight(a, self.ksplit)
+                      and (self._lower is None or self._lower.dtype == torch.float32))
+            if not direct:
+                a, row_weight = a * row_weight.to(a.dtype).reshape(-1, 1), None
         if not a.is_cuda:
             raise hip.EmcidHipError("SecondMoment.add needs a tensor in HBM (no CPU path in emcid_amd)")
         if a.dtype not in (torch.float32, torch.float64):
@@ -101,7 +109,7 @@ class SecondMoment(Stat):
         self.count += a.shape[0] if count is None else int(count)
         if a.shape[0] >= self.stage_tokens:
             self.flush()
-            self._accumulate(a.contiguous())
+            self._accumulate(a.contiguous(), None if row_weight is None else row_weight.reshape(-1).contiguous())
             return
         if self._stage is None:
             self._stage = torch.empty(self.stage_tokens, d, dtype=a.dtype, device=a.device)
@@ -110,12 +118,13 @@ class SecondMoment(Stat):
         self._stage[self._staged:self._staged + a.shape[0]].copy_(a)
         self._staged += a.shape[0]
 
-    def _accumulate(self, x: torch.Tensor):
+    def _accumulate(self, x: torch.Tensor, row_weight: Optional[torch.Tensor] = None):
         """lower(mom2) += x^T x on the matrix cores: fp32 SYRK (csrc/gram_f32.hip) or the fp64 MFMA GEMM restricted to the
         lower tiles (csrc/gemm_f64.h: A = x stored [K = tokens][rows = d] for both operands)."""
         if x.dtype == torch.float32:
-            hip.gram_accumulate_(self._lower, x, self.ksplit)
+            hip.gram_accumulate_(self._lower, x, self.ksplit, row_weight=row_weight)
         else:
+            assert row_weight is None
             hip.dgemm_ex(1, 1, x, x, self._lower, alpha=1.0, beta=1.0, flags=16, ksplit=1 if self.ksplit == 1 else 0)
 
     def flush(self):
@@ -250,9 +259,17 @@ class CombinedStat(Stat):
             return objs[k]
         raise AttributeError(k)
 
-    def add(self, d, *args, **kwargs):
+    def add(self, d, *args, row_weight=None, **kwargs):
+        scaled = None
         for obj in self._objs.values():
-            obj.add(d, *args, **kwargs)
+            if row_weight is None:
+                obj.add(d, *args, **kwargs)
+            elif isinstance(obj, SecondMoment):
+                obj.add(d, *args, row_weight=row_weight, **kwargs)      # applied inside the Gram's kernels where it can be
+            else:
+                if scaled is None:
+                    scaled = d * row_weight.to(d.dtype).reshape(-1, 1)
+                obj.add(scaled, *args, **kwargs)
 
     def load_state_dict(self, state):
         for prefix, obj in self._objs.items():

@@ -28,7 +28,7 @@ extern "C" {
 #define EMCID_ERR_HIP (-2)
 #define EMCID_ERR_WORKSPACE (-3)
 
-#define EMCID_ABI_VERSION 13
+#define EMCID_ABI_VERSION 14
 
 /* ABI version of the loaded library (host-only, no GPU needed). */
 int emcid_abi_version(void);
@@ -142,19 +142,21 @@ int emcid_linear_sp16_f32(const void* Xp, int64_t ldx, const float* x_inv_scale,
                           void* Yp, int64_t ldp, const float* y_scale, int64_t M, int64_t N, int64_t K, int act, int cfg,
                           void* stream);
 
-/* Stage 0 on the same matrix path: lower(G) += X^T X for token rows X [t, d] fp32 (reference: util/runningstats.py:469-511,
- * mom2 += a.t().mm(a)) like emcid_gram_accumulate_f32, with X^T carried as split-fp16 planes under per-FEATURE scales (the
- * contraction runs over the tokens; scales per 32 768-token chunk) and three f16 MFMAs per k-step; the lower 128 x 128 tiles, the
- * token range of a tile cut into parts whose scaled results are added into G with fp32 atomics (G is an accumulator: sums in no
- * fixed order, like the exact-f32 kernel's multi-slab mode).  d % 4 == 0; workspace: emcid_gram_sp16_workspace_bytes(d). */
 /* Diagnostic (ABI 13): until called again with NULL, the 128 x 128 projection launches (cfg 0) run a stamped
  * build: per workgroup {shader clock at the K loop's start, at its end, 100 MHz clock at its start, at its end, 100 MHz clock at
  * kernel entry, at kernel exit, -, -} at stamps_dev[8 * blockIdx.x] — the in-kernel clock under load and the split of a
  * workgroup's life into prologue / K loop / epilogue (scripts/mb_linear_sp16_r5.py). */
 int emcid_debug_linear_sp16_stamps(long long* stamps_dev);
+/* Stage 0 on the same matrix path: lower(G) += X^T X for token rows X [t, d] fp32 (reference: util/runningstats.py:469-511,
+ * mom2 += a.t().mm(a)) like emcid_gram_accumulate_f32, with X^T carried as split-fp16 planes under per-FEATURE scales (the
+ * contraction runs over the tokens; scales per 32 768-token chunk) and three f16 MFMAs per k-step; the lower 128 x 128 tiles, the
+ * token range of a tile cut into parts whose scaled results are added into G with fp32 atomics (G is an accumulator: sums in no
+ * fixed order, like the exact-f32 kernel's multi-slab mode).  d % 4 == 0; workspace: emcid_gram_sp16_workspace_bytes(d).
+ * row_weight (ABI 14; [t] fp32 or NULL): row r enters as fl32(row_weight[r] * X[r, :]) — the packed Stage-0 forward's
+ * square-root multiplicities (emcid_amd/layer_stats.py), applied where the rows are read instead of in a pass of their own. */
 int64_t emcid_gram_sp16_workspace_bytes(int64_t d);
-int emcid_gram_accumulate_sp16_f32(const float* X, int64_t t, int64_t d, int64_t ldx, float* G, int64_t ldg, void* workspace,
-                                   int64_t workspace_bytes, void* stream);
+int emcid_gram_accumulate_sp16_f32(const float* X, const float* row_weight, int64_t t, int64_t d, int64_t ldx, float* G, int64_t ldg,
+                                   void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Producers that write their result straight as a split-fp16 matrix for the projection that consumes it (no fp32 round trip
  * through HBM, no separate split pass):

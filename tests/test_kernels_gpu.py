@@ -913,3 +913,51 @@ def test_gram_accumulate_split_fp16_path(t, d):
     hip.symmetrize_lower_(G1)
     rel1 = ((G1.cpu().double() - ref).abs() / (dd[:, None] * dd[None, :] + 1e-300)).max().item()
     print(f"gram t={t} d={d}: split-fp16 {rel:.2e}, exact-f32 {rel1:.2e} (relative to the features' scales)")
+
+
+@pytest.mark.parametrize("t,d", [(2500, 256), (40000, 768)])
+def test_gram_row_weights_inside_the_split_kernels(t, d):
+    """row_weight (ABI 14): the packed Stage-0 forward's square-root multiplicities applied where the Gram's kernels read the rows
+    (emcid_amd/layer_stats.py `_collect_packed`) — against the fp64 Gram of the weighted rows, against the Gram of rows multiplied
+    beforehand (the form before; same tolerance, sums in no fixed order), through SecondMoment.add directly and through its staging
+    buffer (short batches multiply in Python), and with a weight that makes a small feature the chunk's largest."""
+    from emcid_amd import runningstats
+    g = torch.Generator().manual_seed(3 * t + d)
+    X = torch.randn(t, d, generator=g)
+    X *= torch.exp2(torch.randint(-8, 8, (1, d), generator=g).float())
+    w = torch.randint(1, 400, (t,), generator=g).float().sqrt()
+    w[5] = 3.0e4                                         # one heavy row: the column maxima come from w x, not from x
+    Xd, wd = X.to(DEV), w.to(DEV)
+    ref = (X.double() * w.double()[:, None]).t() @ (X.double() * w.double()[:, None])
+    dd = ref.diagonal().clamp_min(1e-300).sqrt()
+    tol = 2e-6 * np.sqrt(t / 100 + 1)
+
+    def err(G):
+        return ((G.cpu().double() - ref).abs() / (dd[:, None] * dd[None, :] + 1e-300)).max().item()
+
+    assert hip.gram_takes_row_weight(Xd)
+    G = torch.zeros(d, d, dtype=torch.float32, device=DEV)
+    hip.gram_accumulate_(G, Xd, 0, row_weight=wd)
+    hip.symmetrize_lower_(G)
+    G0 = torch.zeros(d, d, dtype=torch.float32, device=DEV)
+    hip.gram_accumulate_(G0, Xd * wd[:, None], 0)
+    hip.symmetrize_lower_(G0)
+    assert err(G) <= tol and err(G0) <= tol, (err(G), err(G0))
+    assert ((G - G0).abs().cpu().double() / (dd[:, None] * dd[None, :] + 1e-300)).max().item() <= tol
+    # the deterministic exact-f32 path (ksplit = 1) takes the weights by a multiplication in hip.gram_accumulate_: same bits as
+    # the rows multiplied beforehand
+    G1 = torch.zeros(d, d, dtype=torch.float32, device=DEV)
+    hip.gram_accumulate_(G1, Xd, 1, row_weight=wd)
+    G1b = torch.zeros(d, d, dtype=torch.float32, device=DEV)
+    hip.gram_accumulate_(G1b, Xd * wd[:, None], 1)
+    assert torch.equal(G1, G1b)
+    # SecondMoment: one long batch (direct), then the same rows in short pieces (staged: multiplied in Python)
+    for piece in (t, 700):
+        sm = runningstats.SecondMoment(stage_tokens=2048)
+        for r0 in range(0, t, piece):
+            sm.add(Xd[r0:r0 + piece], count=int((wd[r0:r0 + piece] ** 2).sum().item()), row_weight=wd[r0:r0 + piece])
+        assert err(sm.mom2) <= tol, (piece, err(sm.mom2))
+        assert sm.count == sum(int((wd[r0:r0 + piece] ** 2).sum().item()) for r0 in range(0, t, piece))
+    cs = runningstats.CombinedStat(mom2=runningstats.SecondMoment(stage_tokens=2048))
+    cs.add(Xd, count=7, row_weight=wd)
+    assert err(cs.mom2.mom2) <= tol and cs.mom2.count == 7
