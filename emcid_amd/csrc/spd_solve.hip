@@ -2122,9 +2122,7 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
     // Np-row side as a launch of its own, instead of U = (Z^T Yt) X on the h-row side — 128 rows against 768 at SD dims
     // (61 + ~15 us instead of ~20 + 155 per layer).  EMCID_P_FIRST=0: the h-side form.
     const bool p_first = !shadow && use_inverse && Np < h;
-    static const int s_inverse = env_flag("EMCID_S_INVERSE", 1);
-    static const int xrow_env = env_flag("EMCID_XROW", 1);
-    const bool xrow = xrow_env && s_inverse && cholesky_takes_shadow(Np);       // (= the fused leaf / spine schedule runs)
+    const bool xrow = cholesky_takes_shadow(Np);       // (= the fused leaf / spine schedule runs)
     double *XT = base + ws.off_XT, *TT = base + ws.off_TT;
     EMCID_TRY(with_graph(make_key(6, {Yt, R, S, LS, RT, V, U, info_dev},
                                   {dp, Np, N, hp, (int64_t)(uintptr_t)Lb,
@@ -2145,7 +2143,7 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
                            Np, (int)Np, (int)hp);
         // Z^T = RT S^-1.  As block substitution this is 6 dependent launches on h rows (~140 us at N = 1000, latency-bound); with
         // XS = inv(LS) made explicit (one more halving level on top of the 512-block inverses, into S, which the factorization has
-        // consumed) it is two GEMMs against a triangle:  Z^T = (RT XS^T) XS.   EMCID_S_INVERSE=0 keeps the substitution.
+        // consumed) it is two GEMMs against a triangle:  Z^T = (RT XS^T) XS (the substitution stays for N the fused schedule does not take).
         if (xrow) {
             ScopedProf sp(KC_TRSM_DIAG, q);
             GemmShape f{RT, Np, XT, Np, (int)h, (int)Np, (int)Np, 0};
@@ -2156,7 +2154,7 @@ int emcid_edit_dual_apply_stage2_f64(int64_t N, int64_t d, int64_t h, const void
             b.tri = 2;       // B(k, n) = XS[k][n] = Xt[n][k], zero for k < n
             b.pair = 1;
             launch_gemm_f64<true, true>(b, EpiAxpby{RT, Np, 1.0, 0.0}, q);
-        } else if (s_inverse && Np <= 4096) {
+        } else if (Np <= 4096) {
             EMCID_TRY(build_full_inverse(LS, Np, Np, invS, S, Y2, 1, 0, 0, q));
             ScopedProf sp(KC_TRSM_DIAG, q);
             GemmShape f{RT, Np, S, Np, (int)h, (int)Np, (int)Np, 0};
@@ -2275,8 +2273,7 @@ int emcid_edit_dual_cols_stage2_f64(int64_t N, int64_t d, int64_t h, const void*
     const int64_t dp = ws.dp, Np = ws.Np, hp = ws.hp;
     const double* X = cov_inverse(cov_factor_ws, n_layers, dp, layer_index);
     const int w = n_tiles * NB;
-    static const int xrow_env = env_flag("EMCID_XROW", 1);
-    const bool xrow = xrow_env && cholesky_takes_shadow(Np);
+    const bool xrow = cholesky_takes_shadow(Np);
     EMCID_TRY(with_graph(make_key(8, {Yc, R, S, LS, RT, V, U, info_dev}, {dp, Np, N, hp, (int64_t)w + ((int64_t)xrow << 40)}), st, [&](hipStream_t q) {
         hipLaunchKernelGGL(add_identity_f64_kernel, dim3((unsigned)((Np + 255) / 256)), dim3(256), 0, q, S, (int)Np);
         const XrowJob xj{base + ws.off_XT, Np, base + ws.off_TT};

@@ -318,10 +318,10 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
     if graph is not None:
         # As soon as the prompts are tokenized their prefix trie is built and the unedited leading layers are LAUNCHED here,
         # so the GPU runs them underneath the rest of the host preparation (v* reads, statistics lookups).  The prompt list
-        # can also be cut into EMCID_PREP_CHUNKS slices, each launched before the next is tokenized; measured on 2 x EPYC
+        # could also be cut into slices (iter_prompt_chunks takes a count), each launched before the next is tokenized; measured on 2 x EPYC
         # 9575F (scripts/host_profile.py, configurations interleaved) every extra tokenizer call costs 3-4 ms of fixed
         # overhead (waking the backend's thread pool), more than the 2.9 ms of GPU time a second slice hides: default 1.
-        n_chunks = int(os.environ.get("EMCID_PREP_CHUNKS", "0")) or 1
+        n_chunks = 1
         first_edit = plan.layers[0]
         chunks: List[TrieChunk] = []
         try:

@@ -908,12 +908,11 @@ def apply_emcid_to_sdxl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
             print(f"New weights successfully inserted into {names}")
         return pipe, o1, o2
     p1, p2 = _sdxl_plans(pipe, requests, hparams, cache_name, stat_dir, stat_dir_2, verbose, shard, stage1)
-    # The two encoders are independent models (:1233 vs :1333): two HIP streams on one GPU (EMCID_SDXL_STREAMS=1: one after the
-    # other).  Measured for the 1 000-concept edit (scripts/bench_sdxl.py): 83.0 ms against 84.9 ms per apply call — TE2's
+    # The two encoders are independent models (:1233 vs :1333): two HIP streams on one GPU.  Measured for the 1 000-concept edit (scripts/bench_sdxl.py): 83.0 ms against 84.9 ms per apply call — TE2's
     # 26-layer prefix forward is 3/4 of the call and leaves little for TE1 to hide under.  With more ranks the encoders go to
     # disjoint rank groups instead (_sdxl_split above).
     dev2 = next(pipe.text_encoder_2.parameters()).device      # (v* may still be a pending upload: plan.zs_t is set lazily)
-    two_streams = os.environ.get("EMCID_SDXL_STREAMS", "2") == "2"
+    two_streams = True
     s2 = torch.cuda.Stream(device=dev2) if two_streams else torch.cuda.current_stream(dev2)
     if two_streams:
         s2.wait_stream(torch.cuda.current_stream(dev2))

@@ -261,7 +261,7 @@ class EditWorkspace:
     def __init__(self, N: int, d: int, h: int, device):
         self.key = (N, d, h)
         self.nbytes = edit_workspace_bytes(N, d, h)
-        self.buf = torch.empty(self.nbytes // 8, dtype=torch.float64, device=device)
+        self.buf = torch.zeros(self.nbytes // 8, dtype=torch.float64, device=device)      # (zero: padding the stages never write)
         self.info = torch.zeros(1, dtype=torch.int32, device=device)
 
 
@@ -295,7 +295,7 @@ class LuWorkspace:
     def __init__(self, N: int, d: int, h: int, device):
         self.key = (N, d, h)
         self.nbytes = int(load().emcid_edit_lu_workspace_bytes(N, d, h))
-        self.buf = torch.empty(self.nbytes // 8, dtype=torch.float64, device=device)
+        self.buf = torch.zeros(self.nbytes // 8, dtype=torch.float64, device=device)      # (zero: padding the stages never write)
         self.info = torch.zeros(1, dtype=torch.int32, device=device)
 
 

@@ -38,6 +38,10 @@ FORWARD_CHUNK = 512          # texts per encoder forward (x model_max_length tok
 MAX_VALUE_COLS = 8192        # value rows: projections are processed in groups of at most this many output columns (fp64 M x cols buffers)
 EDIT_CHUNK = 1024            # per-edit Grams: edits per batch (2 x chunk x d x d fp64 buffers)
 LAST_RUN: Dict[str, float] = {}
+# module switches (scripts/bench_uce.py flips them): the rows' forward ("packed" = the prefix-trie forward, else the hooked HF
+# forward) and the closed form's solver ("auto", or one of closed_form's methods)
+UCE_FORWARD = "packed"
+UCE_METHOD = "auto"
 
 
 # ---- host side: texts -> row windows -------------------------------------------------------------------------------
@@ -111,7 +115,7 @@ def _encode_rows_packed(pipe, ids: torch.Tensor, flat_sets: Sequence[np.ndarray]
 
 def _encode_rows(pipe, ids: torch.Tensor, flat_sets: Sequence[np.ndarray], tap_module: Optional[str]):
     """Context / value-source rows: the packed explicit forward when the encoder allows it, else the hooked HF forward."""
-    if os.environ.get("EMCID_UCE_FORWARD", "packed") == "packed":
+    if UCE_FORWARD == "packed":
         try:
             out = _encode_rows_packed(pipe, ids, flat_sets, tap_module)
             LAST_RUN["forward"] = "packed-trie"
@@ -412,7 +416,7 @@ def edit_model_uce(ldm_stable, old_text_, new_text_, retain_text_, add=False, la
     t1 = time.perf_counter()
     mods = dict(ldm_stable.unet.named_modules())
     new_ws = closed_form(Ko, Kn, Kr, seg_d, n, [mods[g].weight for g in wanted], [mods[g].bias for g in wanted], lamb,
-                         erase_scale, preserve_scale, technique, method=os.environ.get("EMCID_UCE_METHOD", "auto"))
+                         erase_scale, preserve_scale, technique, method=UCE_METHOD)
     for g, w in zip(wanted, new_ws):
         mods[g].weight = torch.nn.Parameter(w)
     torch.cuda.synchronize()

@@ -70,8 +70,7 @@ def apply_call():
     em.apply_emcid_to_sdxl_text_encoders(pipe, reqs, hp, dev, cache_name=cache, stat_dir=str(tmp / "s1"), stat_dir_2=str(tmp / "s2"),
                                          verbose=False)
 calls = {}
-for streams in ("1", "2"):
-    os.environ["EMCID_SDXL_STREAMS"] = streams
+for streams in ("2",):      # (round 3 compared one stream against two here — 84.9 against 83.0 ms; the one-stream switch is gone)
     for _ in range(2): apply_call()
     ts = []
     for _ in range(7):

@@ -28,12 +28,11 @@ def call():
 
 t0 = time.perf_counter(); call(); torch.cuda.synchronize(); first = time.perf_counter() - t0
 call(); call()
-configs = [c for c in os.environ.get("EMCID_PROFILE_CHUNKS", os.environ.get("EMCID_PREP_CHUNKS", "0")).split(",")]
+configs = ["1"]      # (round 2 compared prompt lists cut into 1 / 2 / 4 slices here; one slice won and the switch is gone)
 walls = {c: [] for c in configs}
 phases = {c: {} for c in configs}
 for rnd in range(n_calls):              # configurations interleaved call by call: box and clock drift hit all of them alike
     for c in configs:
-        os.environ["EMCID_PREP_CHUNKS"] = c
         edit_engine.TIMING.clear()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -1,6 +1,10 @@
 """End-to-end GPU parity: the drop-in entry points (HIP path) against the oracle and the golden vectors
 minted from the reference.  Run on the MI355X box:  python -m pytest tests -m gpu -x -q"""
 import copy
+import json
+import os
+
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -1426,3 +1430,44 @@ def test_cross_attn_cache_miss_runs_stage1_then_edits(tmp_path):
         assert any(not torch.equal(results[-1][n], w0[n]) for n in names)
     for n in results[0]:
         assert torch.equal(results[0][n], results[1][n])
+
+
+@pytest.mark.gpu
+def test_process_switches_leave_the_edit_unchanged(tmp_path):
+    """The switches no other test flips (README.md, "Switches"): each one in a child process of its own — several are read once
+    per process — making the same 40-concept SD-v1.4-dims edit twice (second call on cached factors / graphs / planes).  Every
+    switch here selects another ROUTE to the same arithmetic (the v* files read later, one ctypes call per launch instead of the
+    native layer runner, the HF tokenizer instead of its native twin, other thread counts, no hipGraph replay, no factor cache,
+    no stale-cache guard): the edited weights must come out as without it — to the last bit or two of fp32: the few-concept
+    solve contains K-split fp64 products that add their partials with f64 atomics (gemm_f64.h, `ksplit > 1`), so two runs of ONE
+    configuration already differ in an occasional last bit of one weight, which the next edited layer spreads
+    (profiles/r05_bits_probe.txt: forward bit-identical over 6 processes, solve with the explicit inverse identical over 40 calls
+    at every N, block substitution at N = 64 / 1000 four to five distinct results)."""
+    import subprocess, sys as _sys
+    reqs = syn.make_requests(40, ragged=True)
+    hp_d = syn.sd_hparams_dict(prefix="text_model.")
+    names = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers"]]
+    syn.write_vstar_cache(str(tmp_path / "cache") + "/", reqs, 768, seed=1, scale=0.5)
+    syn.write_stats_cache(tmp_path / "stats", names, 3072, hp_d["mom2_n_samples"], seed=2, t=6144)
+    child = str(Path(__file__).with_name("switch_child.py"))
+
+    def run(tag, **env):
+        out = tmp_path / f"{tag}.npz"
+        e = {k: v for k, v in os.environ.items() if not k.startswith("EMCID_")}
+        e.update(EMCID_MANAGE_THREADS="1", **env)
+        r = subprocess.run([_sys.executable, child, str(tmp_path), str(out)], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        return dict(np.load(out)), json.loads(r.stdout.strip().splitlines()[-1])
+
+    base, paths = run("base")
+    assert all(np.abs(v).max() > 0 for v in base.values())
+    switches = [("EMCID_EARLY_VSTAR", "0"), ("EMCID_NATIVE_LAYERS", "0"), ("EMCID_NATIVE_TEXT", "0"), ("EMCID_TOK_THREADS", "1"),
+                ("EMCID_READ_THREADS", "1"), ("EMCID_GRAPH", "0"), ("EMCID_FACTOR_CACHE", "0"), ("EMCID_WEIGHT_GUARD", "0"),
+                ("EMCID_TORCH_THREADS", "2"), ("EMCID_RAYON_THREADS", "2")]
+    for k, v in switches:
+        got, p = run(k, **{k: v})
+        for name in base:
+            assert np.abs(got[name] - base[name]).max() <= 2e-6 * np.abs(base[name]).max(), (k, name, np.abs(got[name] - base[name]).max())
+        if k == "EMCID_NATIVE_LAYERS":
+            assert int(p.get("native_layers", 0)) == 0 < int(paths.get("native_layers", 0)), (p, paths)      # the other route was taken
+
