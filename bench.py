@@ -222,6 +222,7 @@ def main():
     ap.add_argument("--concepts", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage0", action="store_true")
+    ap.add_argument("--no-gc-freeze", action="store_true", help="leave the cyclic collector as it is (default: gc.freeze() once the inputs exist)")
     ap.add_argument("--no-variants", action="store_true", help="skip the n100 / sdxl / cold_process records")
     ap.add_argument("--no-cpu-full", action="store_true", help="skip the full 1 000-concept runs of the CPU baseline (~1 min each)")
     ap.add_argument("--cpu-full-runs", type=int, default=3, help="full-size runs of the CPU baseline (median reported)")
@@ -243,7 +244,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from emcid_amd import emcid_main as em, hip, edit_engine
+    from emcid_amd import clip_forward, emcid_main as em, hip, edit_engine
     from emcid_amd.edit_engine import ConceptShard, run_encoder_edit, check_info
     from emcid_amd.emcid_hparams import EMCIDHyperParams
     from emcid_amd.nethook import get_parameter
@@ -305,8 +306,20 @@ def main():
             t1 = time.perf_counter()
             call(0 if first_set is None else first_set + i, **kw)
             per.append(time.perf_counter() - t1)
+            call_marks.append((dict(edit_engine.TIMING), dict(clip_forward.LAST_PATHS)))      # two small dict copies: ~2 us
         sync()
         return time.perf_counter() - t0, per
+
+    call_marks = []
+
+    def slowest_call(per, marks, first_set):
+        """host phases and path counters of the slowest of a series of calls, as differences of the running totals"""
+        i = max(range(len(per)), key=lambda j: per[j])
+        (t_a, p_a), (t_b, p_b) = (marks[i - 1] if i > 0 else ({}, {})), marks[i]
+        return {"index": i, "request_set": first_set + i, "ms": per[i] * 1e3,
+                "host_phases_ms": {k: round((v - t_a.get(k, 0.0)) * 1e3, 3) for k, v in t_b.items()} if i > 0 else None,
+                "path_counters": {k: v - p_a.get(k, 0) for k, v in p_b.items() if isinstance(v, (int, float)) and v != p_a.get(k, 0)} if i > 0 else None,
+                "over_median": per[i] / statistics.median(per)}
 
     def each_synced(k, fn):
         """k single calls, each between two synchronisations: milliseconds per call."""
@@ -319,6 +332,25 @@ def main():
             out.append((time.perf_counter() - t1) * 1e3)
         return out
 
+    # ---- the interpreter's cyclic collector --------------------------------------------------------------------------------
+    # The process holds 26 request sets (26 000 request dicts with their prompt lists) and a model: a full (generation-2)
+    # collection walks all of it, ~150-200 ms on the main thread, and its trigger is a count of allocations, so it lands on the
+    # SAME timed step in every process (profiles/r05_b_bench.json: step 16 of 20 took 150 ms in both processes of that box;
+    # profiles/r05_outlier.txt: the pause sits in whichever host phase allocates next).  A long-running editing service freezes
+    # what it has built (gc.freeze(): the standard remedy, the objects move to a permanent generation and are never walked
+    # again); this process does the same once its inputs exist.  Every collection inside the timed region is recorded.
+    import gc
+    gc.collect()
+    if not args.no_gc_freeze:
+        gc.freeze()
+    gc_events = []
+
+    def _gc_cb(phase, info, _t=[0.0]):
+        if phase == "start":
+            _t[0] = time.perf_counter()
+        else:
+            gc_events.append((info.get("generation"), (time.perf_counter() - _t[0]) * 1e3))
+    gc.callbacks.append(_gc_cb)
     # ---- the first call of the process: everything cold ------------------------------------------------------------------
     log(f"inputs ready ({len(sets)} request sets); first call")
     first_s, _ = timed_calls(1)
@@ -327,7 +359,13 @@ def main():
     for i in range(args.warmup):
         call(1 + i)
     edit_engine.TIMING.clear()
+    call_marks.clear()
+    gc_events.clear()
     elapsed, per_call = timed_calls(args.steps, first_set=1 + args.warmup)
+    gc_in_timed = {"frozen": not args.no_gc_freeze, "collections": len(gc_events),
+                   "by_generation_ms": {str(g): round(sum(ms for gg, ms in gc_events if gg == g), 3) for g in sorted({g for g, _ in gc_events})},
+                   "longest_ms": round(max((ms for _, ms in gc_events), default=0.0), 3)}
+    slowest = slowest_call(per_call, list(call_marks), 1 + args.warmup)
     host_phases = {k: round(v / args.steps * 1e3, 4) for k, v in edit_engine.TIMING.items()}      # host wall-clock per phase and call
     per_rank = None
     if world > 1:
@@ -574,7 +612,7 @@ def main():
                            "note": "same requests as the replay; a new lambda reuses the cached factor of C' (lam_ratio), a new "
                                    "edit_weight refactors the four 3072 x 3072 matrices on the side stream under the forward"},
         "first_call_ms": first_s * 1e3,
-        "host_phases_ms_per_call": host_phases,
+        "host_phases_ms_per_call": host_phases, "slowest_call": slowest, "gc_in_timed_region": gc_in_timed,
         "forward_gemm": {"this_run": ("emcid_linear_sp16_f32 (split-fp16 MFMA GEMM at fp32 accuracy, fused bias / activation / residual, "
                                        "native layer runner)" if split_gemm else
                                        "emcid_linear_f32 (own fp32-MFMA GEMM, fused bias / activation / residual)") if own_gemm

@@ -36,7 +36,12 @@ const char* header_value(const std::string& h, const char* key) {
 
 // 0 = row written; 1 = no such file; 2 = not servable here (caller: numpy).  `buf` is the thread's scratch.
 int read_one(const char* path, const char* member, int64_t width, float* out, std::vector<unsigned char>& buf) {
-    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    // O_NOATIME: the first read of a freshly written file moves its access time (relatime), i.e. dirties the inode and takes a
+    // journal handle — and that waits while the file system commits a large transaction (a burst of file creations a few seconds
+    // earlier: bench.py's 26 000 cache files; profiles/r05_outlier.txt: one call in twenty 150-210 ms, all of it in these reads).
+    // The flag needs the file's owner (or CAP_FOWNER): EPERM -> the plain open.
+    int fd = open(path, O_RDONLY | O_CLOEXEC | O_NOATIME);
+    if (fd < 0 && errno == EPERM) fd = open(path, O_RDONLY | O_CLOEXEC);
     if (fd < 0) return errno == ENOENT ? 1 : 2;
     struct stat st;
     if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 64 || st.st_size > (1 << 26)) {

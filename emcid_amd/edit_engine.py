@@ -18,6 +18,7 @@ Same K, Zc, A, X, R, dW as the reference's loop (same inputs to every step), 1 p
 2*L full ones.  Host work (tokenizing, subject search, v*/C loading) happens once in ``prepare``; ``run``
 touches only HBM-resident inputs — that is the region bench.py times.
 """
+import logging
 import os
 import threading
 import time
@@ -132,7 +133,8 @@ class EncoderEditPlan:
         at the first solve, i.e. after the forward up to the first edited layer has been launched."""
         if self.zs_pending is not None:
             with phase("vstar join + h2d"):
-                zs = self.zs_pending.result() if hasattr(self.zs_pending, "result") else self.zs_pending
+                with phase("vstar join (wait for the reader)"):
+                    zs = self.zs_pending.result() if hasattr(self.zs_pending, "result") else self.zs_pending
                 dev = next(self.text_encoder.parameters()).device
                 if dev.type == "cuda" and not zs.is_cuda:
                     # through a page-locked staging buffer, asynchronously: a pageable copy would make the host wait for
@@ -824,6 +826,8 @@ def run_checked(plan: EncoderEditPlan, keep_factors: bool = False, restore: bool
             raise
         plan.solver = "lu"
         plan.cov_factors = None
+        clip_forward.LAST_PATHS["lu_fallbacks"] = clip_forward.LAST_PATHS.get("lu_fallbacks", 0) + 1
+        logging.getLogger("emcid_amd").warning("a Cholesky factorization met a non-positive pivot: the pass is rerun with the pivoted-LU solver")
         edits = run_encoder_edit(plan, keep_factors=keep_factors, restore=restore)
         check_info(plan)
     return edits

@@ -23,6 +23,7 @@ otherwise.
 import functools
 import logging
 import os
+import time
 from copy import deepcopy
 from pathlib import Path
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
@@ -440,20 +441,33 @@ class _EarlyVstars:
         status = np.empty(n, dtype=np.uint8)
         threads = _read_threads()
 
-        def read(blob=blob, off=off, rows=rows, status=status):
+        times = [time.perf_counter(), 0.0, 0.0]      # submitted, started, finished (edit_engine.TIMING: "vstar reader ...")
+
+        def read(blob=blob, off=off, rows=rows, status=status, times=times):
             # (the buffers belong to this task, not to the object that waits for it: a plan that is dropped unrun must not free
             #  memory the reader is still writing)
-            return lib.emcid_read_npz_rows_f32(blob, off.ctypes.data, n, b"v_star", int(width), rows.data_ptr(), int(width),
-                                               status.ctypes.data, threads)
+            times[1] = time.perf_counter()
+            rc = lib.emcid_read_npz_rows_f32(blob, off.ctypes.data, n, b"v_star", int(width), rows.data_ptr(), int(width),
+                                             status.ctypes.data, threads)
+            times[2] = time.perf_counter()
+            return rc
 
         fut = _VSTAR_READER[1].submit(read)
-        return cls((requests, hparams, cache_name, suffix, stage1), dict(width=width, pin=pin), fut, rows, (blob, off, status))
+        self = cls((requests, hparams, cache_name, suffix, stage1), dict(width=width, pin=pin), fut, rows, (blob, off, status))
+        self.times = times
+        return self
 
     def wait(self):
         try:
-            return self.future.result()
+            rc = self.future.result()
         except Exception:
             return -1
+        t = getattr(self, "times", None)
+        if t is not None and t[2] > 0.0:       # where a slow join comes from: the worker thread starting late, or the reads themselves
+            edit_engine.TIMING["vstar reader queued"] = edit_engine.TIMING.get("vstar reader queued", 0.0) + (t[1] - t[0])
+            edit_engine.TIMING["vstar reader reading"] = edit_engine.TIMING.get("vstar reader reading", 0.0) + (t[2] - t[1])
+            self.times = None
+        return rc
 
     def result(self):
         rc = self.wait()

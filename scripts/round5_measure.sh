@@ -11,6 +11,7 @@ if [ "$2" = bench ]; then
   timeout -k 10 700 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err && echo bench ok
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -- python3 bench.py --no-cpu-baseline --no-stage0 --no-variants --no-gemm-ab > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_prof.err && echo prof ok
   f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1); cp "$f" gpurun_out/${tag}_bench_kernel_stats.csv; rm -rf gpurun_out/${tag}_prof
+  timeout -k 10 200 python scripts/soak.py > gpurun_out/${tag}_soak.txt 2>&1 && echo soak ok
   exit 0
 fi
 for s in qkv out fc1 fc2; do
