@@ -222,7 +222,7 @@ def main():
     ap.add_argument("--concepts", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage0", action="store_true")
-    ap.add_argument("--no-gc-freeze", action="store_true", help="leave the cyclic collector as it is (default: gc.freeze() once the inputs exist)")
+    ap.add_argument("--gc-freeze", action="store_true", help="gc.freeze() once the inputs exist (default: the collector as it is)")
     ap.add_argument("--no-variants", action="store_true", help="skip the n100 / sdxl / cold_process records")
     ap.add_argument("--no-cpu-full", action="store_true", help="skip the full 1 000-concept runs of the CPU baseline (~1 min each)")
     ap.add_argument("--cpu-full-runs", type=int, default=3, help="full-size runs of the CPU baseline (median reported)")
@@ -332,16 +332,12 @@ def main():
             out.append((time.perf_counter() - t1) * 1e3)
         return out
 
-    # ---- the interpreter's cyclic collector --------------------------------------------------------------------------------
-    # The process holds 26 request sets (26 000 request dicts with their prompt lists) and a model: a full (generation-2)
-    # collection walks all of it, ~150-200 ms on the main thread, and its trigger is a count of allocations, so it lands on the
-    # SAME timed step in every process (profiles/r05_b_bench.json: step 16 of 20 took 150 ms in both processes of that box;
-    # profiles/r05_outlier.txt: the pause sits in whichever host phase allocates next).  A long-running editing service freezes
-    # what it has built (gc.freeze(): the standard remedy, the objects move to a permanent generation and are never walked
-    # again); this process does the same once its inputs exist.  Every collection inside the timed region is recorded.
+    # ---- the interpreter's cyclic collector: every collection inside the timed region is recorded ------------------------------
+    # (the process holds 26 000 request dicts and a model; a full collection would walk all of it.  Measured: two generation-0
+    # collections, 0.4 ms, in the twenty timed steps, frozen or not — profiles/r05_outlier.txt; --gc-freeze is there to repeat that.)
     import gc
     gc.collect()
-    if not args.no_gc_freeze:
+    if args.gc_freeze:
         gc.freeze()
     gc_events = []
 
@@ -362,7 +358,7 @@ def main():
     call_marks.clear()
     gc_events.clear()
     elapsed, per_call = timed_calls(args.steps, first_set=1 + args.warmup)
-    gc_in_timed = {"frozen": not args.no_gc_freeze, "collections": len(gc_events),
+    gc_in_timed = {"frozen": bool(args.gc_freeze), "collections": len(gc_events),
                    "by_generation_ms": {str(g): round(sum(ms for gg, ms in gc_events if gg == g), 3) for g in sorted({g for g, _ in gc_events})},
                    "longest_ms": round(max((ms for _, ms in gc_events), default=0.0), 3)}
     slowest = slowest_call(per_call, list(call_marks), 1 + args.warmup)

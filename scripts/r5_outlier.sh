@@ -3,7 +3,7 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 for k in 1 2 3 4 5; do
-flag=--no-gc-freeze
+flag=
 timeout -k 10 300 python bench.py $flag --no-stage0 --no-cpu-baseline --no-gemm-ab --no-variants > gpurun_out/r05_outlier_$k.json 2> gpurun_out/r05_outlier_$k.err
 python - $k <<'PY'
 import json,sys
