@@ -999,20 +999,24 @@ int emcid_split_rows_f16(const float* X, int64_t ldx, int64_t rows, int64_t K, v
     return EMCID_OK;
 }
 
-int64_t emcid_gram_sp16_workspace_bytes(int64_t d) {
-    // planes of one chunk of X^T [d][32768] + the chunk's column maxima and inverse scales
-    return round_up(d, 64) * 32768 * 4 + 2 * round_up(d, 64) * 4 + 256;
+int64_t emcid_gram_sp16_workspace_bytes_for(int64_t d, int64_t t) {
+    // planes of one chunk of X^T [d][min(t, 32768) rounded up to 64] + the chunk's column maxima and inverse scales
+    const int64_t tc = round_up(t < 1 ? 1 : (t > 32768 ? 32768 : t), 64);
+    return round_up(d, 64) * tc * 4 + 2 * round_up(d, 64) * 4 + 256;
 }
+
+int64_t emcid_gram_sp16_workspace_bytes(int64_t d) { return emcid_gram_sp16_workspace_bytes_for(d, 32768); }
 
 int emcid_gram_accumulate_sp16_f32(const float* X, const float* row_weight, int64_t t, int64_t d, int64_t ldx, float* G, int64_t ldg,
                                    void* workspace, int64_t workspace_bytes, void* stream) {
     EMCID_CHECK_ARG(X && G && workspace && t >= 0 && d > 0 && ldx >= d && ldg >= d && d % 4 == 0 && ldx % 4 == 0 && aligned16(X));
-    EMCID_CHECK_ARG(workspace_bytes >= emcid_gram_sp16_workspace_bytes(d) && aligned16(workspace) && d < (1 << 20) && t < (1LL << 31));
+    EMCID_CHECK_ARG(workspace_bytes >= emcid_gram_sp16_workspace_bytes_for(d, t) && aligned16(workspace) && d < (1 << 20) && t < (1LL << 31));
     if (t == 0) return EMCID_OK;
     hipStream_t st = (hipStream_t)stream;
     const int64_t dr = round_up(d, 64);
     uint32_t* P = (uint32_t*)workspace;
-    unsigned* cmax = (unsigned*)((char*)workspace + dr * 32768 * 4);
+    const int64_t chunk_cap = round_up(std::min<int64_t>(t, 32768), 64);       // the workspace's plane area holds one chunk
+    unsigned* cmax = (unsigned*)((char*)workspace + dr * chunk_cap * 4);
     float* inv = (float*)(cmax + dr);
     const int side = (int)((d + 127) / 128), n_lower = side * (side + 1) / 2;
     ScopedProf sp(KC_GRAM, st);

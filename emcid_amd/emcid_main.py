@@ -277,14 +277,16 @@ def _native_vstar_rows(names: Sequence[Optional[str]], width: int, pin: bool):
 
 
 def load_v_stars(requests: Sequence[Dict], hparams, cache_name: Optional[str], suffix: str = "",
-                 stage1: Optional[Stage1Fn] = None, width: Optional[int] = None, pin: bool = False) -> torch.Tensor:
+                 stage1: Optional[Stage1Fn] = None, width: Optional[int] = None, pin: bool = False, native=None) -> torch.Tensor:
     """(N, hidden) fp32 on the host: one row per request, the transpose of the reference's ``zs`` (:977) — (N k, hidden), row
     ``rq * k + num``, for ``use_new_compute_z`` files of k = num_edit_tokens rows each (:972-975).  ``width``: the
     encoder's hidden size when the caller knows it (then every cache file is read by the native batch reader; files it does
     not serve, and every miss, take the per-file path below, which is the reference's: np.load, recompute on an unreadable
-    file :903-904, Stage 1 on a miss :905-969)."""
+    file :903-904, Stage 1 on a miss :905-969).  ``native``: (rows, status) of a native batch read of these very names that has
+    already been made (the early reader's), so that a miss does not read the hits a second time."""
     names = [vstar_cache_name(cache_name, request, hparams, idx, suffix) for idx, request in enumerate(requests)]
-    native = _native_vstar_rows(names, int(width), pin) if (width and cache_name is not None and len(names)) else None
+    if native is None:
+        native = _native_vstar_rows(names, int(width), pin) if (width and cache_name is not None and len(names)) else None
     new_z = bool(getattr(hparams, "use_new_compute_z", False))
     k_tok = int(getattr(hparams, "num_edit_tokens", 1) or 1)
     if native is not None and not native[1].any() and not (new_z and k_tok > 1):
@@ -414,7 +416,9 @@ class _EarlyVstars:
     unedited leading layers: the reader is one ctypes call that does not hold the interpreter lock, so it runs beside the host's
     remaining preparation and is (nearly) done when the first solve asks — with the GPU twice as fast as in round 3 the read had
     moved onto the critical path (profiles/r04_g_call_events.txt: the host reached the first solve 0.2 ms before the device).
-    Anything the native reader does not serve (a miss, a file for numpy, k-token files) falls back to load_v_stars at result()."""
+    Anything the native reader does not serve (a miss, a file for numpy, k-token files) falls back to load_v_stars at result().
+    The rows are a SNAPSHOT of the files as they are when ``prepare`` runs: a plan prepared early and run after its cache files were
+    rewritten edits towards the old targets (the lazy reader, EMCID_EARLY_VSTAR=0, reads at the first solve)."""
 
     def __init__(self, args, kwargs, future, rows, keep):
         self.args, self.kwargs, self.future, self.rows, self.keep = args, kwargs, future, rows, keep
@@ -460,7 +464,8 @@ class _EarlyVstars:
     def wait(self):
         try:
             rc = self.future.result()
-        except Exception:
+        except Exception as e:       # the per-file path below serves the call; say why the batch read did not
+            logging.getLogger("emcid_amd").warning("native v* batch read failed (%r): reading the cache files one by one", e)
             return -1
         t = getattr(self, "times", None)
         if t is not None and t[2] > 0.0:       # where a slow join comes from: the worker thread starting late, or the reads themselves
@@ -473,7 +478,9 @@ class _EarlyVstars:
         rc = self.wait()
         if rc is not None and rc >= 0 and not self.keep[2].any():
             return self.rows
-        return load_v_stars(*self.args, **self.kwargs)
+        # a miss or a file for numpy: the rows the batch read did serve are handed on (no second read of 999 hits for one miss)
+        native = (self.rows, self.keep[2]) if rc is not None and rc >= 0 else None
+        return load_v_stars(*self.args, **self.kwargs, native=native)
 
 
 class _LazyVstars:
@@ -505,7 +512,7 @@ def prepare_text_encoder_edit(text_encoder, tokenizer, requests, hparams, layers
         # runs (or the miss is reported) before statistics are read or computed
         if _any_vstar_missing(requests, hparams, cache_name, suffix):
             if early is not None:
-                early.wait()            # its buffers stay alive until the reader is out of them
+                return early.result()   # waits for the reader, hands the rows it did read to load_v_stars (Stage 1 for the misses)
             return load_v_stars(requests, hparams, cache_name, suffix, stage1, **how)
         return early if early is not None else _LazyVstars(requests, hparams, cache_name, suffix, stage1, **how)
 

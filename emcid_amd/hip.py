@@ -30,7 +30,7 @@ EXPORTS = [
     "emcid_edit_lu_workspace_bytes", "emcid_edit_layer_lu_f64", "emcid_lu_solve_f64",
     "emcid_edit_dual_cols_stage1_f64", "emcid_edit_dual_s", "emcid_edit_dual_u", "emcid_edit_dual_cols_stage2_f64",
     "emcid_apply_update2d_f32", "emcid_linear_f32", "emcid_linear_ws_f32", "emcid_linear_workspace_bytes",
-    "emcid_split_rows_f16", "emcid_linear_sp16_f32", "emcid_gram_sp16_workspace_bytes", "emcid_gram_accumulate_sp16_f32", "emcid_add_layernorm_sp16", "emcid_embed_layernorm_sp16",
+    "emcid_split_rows_f16", "emcid_linear_sp16_f32", "emcid_gram_sp16_workspace_bytes", "emcid_gram_sp16_workspace_bytes_for", "emcid_gram_accumulate_sp16_f32", "emcid_add_layernorm_sp16", "emcid_embed_layernorm_sp16",
     "emcid_tree_attention_sp16", "emcid_tree_attention_sp16_supported", "emcid_clip_workspace_bytes",
     "emcid_clip_layer_head_sp16", "emcid_clip_layer_tail_sp16", "emcid_clip_layers_sp16", "emcid_clip_edit_layer_tail_sp16",
 ]
@@ -113,6 +113,7 @@ def load():
         "emcid_linear_workspace_bytes": (i64, []),
         "emcid_split_rows_f16": (i32, [p, i64, i64, i64, p, i64, p, p, p]),
         "emcid_gram_sp16_workspace_bytes": (i64, [i64]),
+        "emcid_gram_sp16_workspace_bytes_for": (i64, [i64, i64]),
         "emcid_gram_accumulate_sp16_f32": (i32, [p, p, i64, i64, i64, p, i64, p, i64, p]),
         "emcid_add_layernorm_sp16": (i32, [p, i64, p, i64, p, p, C.c_float, i64, i64, p, p, p, i64, p, p, p, p]),
         "emcid_embed_layernorm_sp16": (i32, [p, i64, i64, p, i64, i64, p, p, p, p, C.c_float, i64, i64, p, p, p, i64, p, p]),
@@ -209,11 +210,14 @@ def gram_accumulate_(G: torch.Tensor, X: torch.Tensor, ksplit: int = 0, row_weig
             and X.data_ptr() % 16 == 0 and X.dtype == torch.float32 and G.dtype == torch.float32:
         key = (X.device.index if X.device.index is not None else torch.cuda.current_device(),
                torch.cuda.current_stream(X.device).cuda_stream, d)
+        # one workspace per (device, stream, d), sized for the largest batch seen there (403 MB at d = 3072 only when a batch
+        # reaches the 32 768-token chunk; a 2 048-token batch takes 25 MB)
+        need = int(load().emcid_gram_sp16_workspace_bytes_for(d, X.shape[0]))
         ws = _GRAM_WS.get(key)
-        if ws is None:
-            if len(_GRAM_WS) >= 8:
+        if ws is None or ws.numel() < need:
+            if ws is None and len(_GRAM_WS) >= 8:
                 _GRAM_WS.clear()
-            ws = _GRAM_WS[key] = torch.empty(int(load().emcid_gram_sp16_workspace_bytes(d)), dtype=torch.uint8, device=X.device)
+            ws = _GRAM_WS[key] = torch.empty(need, dtype=torch.uint8, device=X.device)
         _check(load().emcid_gram_accumulate_sp16_f32(_ptr(X, torch.float32, "X"),
                                                      _ptr(row_weight, torch.float32, "row_weight") if row_weight is not None else None,
                                                      X.shape[0], d, X.stride(0),

@@ -151,10 +151,12 @@ int emcid_debug_linear_sp16_stamps(long long* stamps_dev);
  * mom2 += a.t().mm(a)) like emcid_gram_accumulate_f32, with X^T carried as split-fp16 planes under per-FEATURE scales (the
  * contraction runs over the tokens; scales per 32 768-token chunk) and three f16 MFMAs per k-step; the lower 128 x 128 tiles, the
  * token range of a tile cut into parts whose scaled results are added into G with fp32 atomics (G is an accumulator: sums in no
- * fixed order, like the exact-f32 kernel's multi-slab mode).  d % 4 == 0; workspace: emcid_gram_sp16_workspace_bytes(d).
+ * fixed order, like the exact-f32 kernel's multi-slab mode: two runs of one job agree to rounding, not to the bit — the exact-f32
+ * kernel with ksplit = 1 is the bit-reproducible form).  d % 4 == 0; workspace: emcid_gram_sp16_workspace_bytes_for(d, t).
  * row_weight (ABI 14; [t] fp32 or NULL): row r enters as fl32(row_weight[r] * X[r, :]) — the packed Stage-0 forward's
  * square-root multiplicities (emcid_amd/layer_stats.py), applied where the rows are read instead of in a pass of their own. */
-int64_t emcid_gram_sp16_workspace_bytes(int64_t d);
+int64_t emcid_gram_sp16_workspace_bytes(int64_t d);                       /* for any t */
+int64_t emcid_gram_sp16_workspace_bytes_for(int64_t d, int64_t t);       /* for batches of at most t rows (ABI 14) */
 int emcid_gram_accumulate_sp16_f32(const float* X, const float* row_weight, int64_t t, int64_t d, int64_t ldx, float* G, int64_t ldg,
                                    void* workspace, int64_t workspace_bytes, void* stream);
 

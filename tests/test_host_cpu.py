@@ -875,7 +875,15 @@ def test_early_vstar_reader_survives_dropped_plans_and_falls_back(tmp_path):
     np.savez_compressed(name(3), v_star=vs[3])            # not served natively: the whole list goes through load_v_stars
     Path(name(7)).unlink()
     early = em._EarlyVstars.start(reqs, hp, cache, "", lambda r, sfx: torch.full((64,), 7.0), width=64, pin=False)
-    got = early.result()
+    # ... with the rows the batch read DID serve handed on: no second native read of the 398 hits (round-4 advisor, low)
+    calls = []
+    real = em._native_vstar_rows
+    em._native_vstar_rows = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        got = early.result()
+    finally:
+        em._native_vstar_rows = real
+    assert not calls
     assert torch.equal(got[3], ref[3]) and torch.equal(got[7], torch.full((64,), 7.0)) and torch.equal(got[8:], ref[8:])
     assert em._EarlyVstars.start(reqs, hp, None, "", None, width=64) is None          # nothing to read early without a cache
 
