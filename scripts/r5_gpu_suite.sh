@@ -1,14 +1,15 @@
-# the whole GPU suite + a quick headline run (round 5)
+# the whole GPU suite, build() + smoke(), and a quick headline run (round 5)
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r05_suite.txt 2>&1; echo "pytest rc $?" >> gpurun_out/r05_suite.txt
 tail -4 gpurun_out/r05_suite.txt
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
 timeout -k 10 200 python bench.py --steps 60 --warmup 5 --no-stage0 --no-cpu-baseline --no-gemm-ab --no-variants > gpurun_out/r05_quick.json 2> gpurun_out/r05_quick.err; echo "bench rc $?"
 python - <<PY
 import json
 d=json.loads(open("gpurun_out/r05_quick.json").read().strip().splitlines()[-1])
 print("ms", round(d["ms_per_step"],3), "median", round(d["ms_per_call_median"],3), "device", round(d["device_ms_per_step"],3), "linear", round(d["kernel_classes"]["linear"]["ms_per_step"],3), "frac", round(d["roofline"]["frac"],3), "solve", round(d["solve"]["ms_per_step"],3), round(d["solve"]["frac_f64_mfma_peak"],3))
-print({k: round(v["ms_per_step"],3) for k,v in d["kernel_classes"].items()})
+print("slowest", round(d["slowest_call"]["ms"],2), "max/median", round(d["slowest_call"]["over_median"],3))
 PY
 echo done

@@ -1466,8 +1466,11 @@ def test_process_switches_leave_the_edit_unchanged(tmp_path):
                 ("EMCID_TORCH_THREADS", "2"), ("EMCID_RAYON_THREADS", "2")]
     for k, v in switches:
         got, p = run(k, **{k: v})
+        # (without the factor cache every call is a cold one: its first edited layer substitutes with L instead of multiplying by
+        #  the explicit inverse — another order of fp64 sums, 3e-6 of the largest weight change after four layers)
+        bar = 2e-5 if k == "EMCID_FACTOR_CACHE" else 2e-6
         for name in base:
-            assert np.abs(got[name] - base[name]).max() <= 2e-6 * np.abs(base[name]).max(), (k, name, np.abs(got[name] - base[name]).max())
+            assert np.abs(got[name] - base[name]).max() <= bar * np.abs(base[name]).max(), (k, name, np.abs(got[name] - base[name]).max())
         if k == "EMCID_NATIVE_LAYERS":
             assert int(p.get("native_layers", 0)) == 0 < int(paths.get("native_layers", 0)), (p, paths)      # the other route was taken
 
