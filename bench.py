@@ -591,7 +591,7 @@ def main():
                               "cov_factor_cache": ("warm (keyed by statistics + edit_weight; any mom2_update_weight)"
                                                    if plan.factors_from_cache else "off"),
                               "vstar_files": "read from the files in every call (native batch reader, no in-process copy)",
-                              "gemm_selection": "none needed (own GEMM)" if own_gemm else "TunableOp table built in the first call"},
+                              "gemm_selection": "none needed (own GEMM)" if own_gemm else "torch F.linear, library-default selection"},
                    "backend": (dist.get_backend() if world > 1 else None),
                    "world_size_seen": (dist.get_world_size() if world > 1 else 1),
                    "parallelism": f"concept-shard x{world}"},
@@ -1147,7 +1147,7 @@ def stage1_record(device, n=16, steps=10, batch=8):
 
 def cold_child(workdir, n):
     """Child-process mode (`bench.py --cold-child WORKDIR`): ONE call in a process that has never edited — the reference's
-    one-call CLI user (scripts/run_emcid.py:99) — with the parent's TunableOp file in place; then the pieces of that
+    one-call CLI user (scripts/run_emcid.py:99); then the pieces of that
     call one at a time.  Prints one JSON line."""
     t_start = time.perf_counter()
     os.environ.setdefault("EMCID_MANAGE_THREADS", "1")
@@ -1203,21 +1203,14 @@ def cold_child(workdir, n):
         "vstar_reads_ms_first_call": first_phases.get("vstar join + h2d"),
         "first_call_minus_warm_ms": first_ms - warm_ms,
         "libraries_and_kernels_first_use_ms": first_ms - cold_stats_ms,
-        "note": "cold_process_ms = wall of the ONE apply_emcid_to_text_encoder call of a fresh process (model already in HBM, "
-                "an existing TunableOp table is loaded, nothing is tuned); call_with_cold_statistics_and_factors = the same "
-                "work in a process whose libraries and kernels have run before; the difference is first-use cost (code objects, "
-                "GEMM library initialisation, allocator growth)"}))
+        "note": "cold_process_ms = wall of the ONE apply_emcid_to_text_encoder call of a fresh process (model already in HBM); "
+                "call_with_cold_statistics_and_factors = the same work in a process whose libraries and kernels have run before; "
+                "the difference is first-use cost (code objects, graph captures, allocator growth)"}))
     return 0
 
 
 def cold_process_record(workdir, device):
     """Runs cold_child as a CHILD process (never an exec from this GPU-touching process) and returns its JSON."""
-    import torch
-    from emcid_amd import clip_forward
-    try:        # leave the GEMM table of this process on disk now (TunableOp itself writes it at exit)
-        torch.cuda.tunable.write_file(clip_forward._tunable_file(torch.device(device)))
-    except Exception:
-        pass
     env = dict(os.environ)
     r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "--cold-child", str(workdir)], env=env,
                        capture_output=True, text=True, timeout=600)

@@ -535,8 +535,8 @@ def run_encoder_edit(plan: EncoderEditPlan, keep_factors: bool = False, trace: b
                 # The explicit inverse factors X_l = inv(L_l) of the LATER layers (their two M-solves become two GEMMs) are
                 # built one layer ahead, on the side stream, exactly while the previous layer's solve sits in the
                 # latency-bound Cholesky of its N x N system (the chip is idle there): see ``lazy_inverse`` in solve().
-                # EMCID_INVERSE_FROM: first layer index that uses X; EMCID_INVERSE_LAZY=0: build them all right after the
-                # factorization instead (batched, underneath the forward — costs the forward more than it hides).
+                # (Building them all right after the factorization, batched underneath the forward, cost the forward more than it
+                # hid: HISTORY.md §5.)
                 first_x = min(L, 1)
                 lazy = keep_factors is False
                 if plan.shard.collective and not keep_factors and -(-d // hip.NB) >= plan.shard.world:
