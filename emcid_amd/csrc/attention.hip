@@ -132,18 +132,26 @@ __global__ __launch_bounds__(256) void tree_attention_f32_kernel(TreeAttnArgs a)
         const int64_t col = (int64_t)(live ? h : 0) * a.D + 4 * dl;
         v4f q4 = {0.f, 0.f, 0.f, 0.f};
         if (dok) q4 = *reinterpret_cast<const v4f*>(a.q + (int64_t)qi * a.ldq + col);   // q rows follow the QUERY order
-        for (int j0 = 0; j0 < nk; j0 += 4) {
-            const int j = j0 + slot;
-            float part = 0.f;
-            if (j < nk && dok) {
-                const v4f k4 = *reinterpret_cast<const v4f*>(a.k + (int64_t)pth[j] * a.ld + col);
-                part = q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
+        // sixteen keys per step: their four row reads go out together (one dependent read per 16 keys instead of per 4 — the
+        // kernel is latency-bound on long chains: Stage 0's captions, 1.19 ms per launch at 88 000 rows before)
+        for (int j0 = 0; j0 < nk; j0 += 16) {
+            v4f k4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = j0 + 4 * t + slot;
+                k4[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+                if (j < nk && dok) k4[t] = *reinterpret_cast<const v4f*>(a.k + (int64_t)pth[j] * a.ld + col);
             }
-            part += __shfl_xor(part, 8);
-            part += __shfl_xor(part, 4);
-            part += __shfl_xor(part, 2);
-            part += __shfl_xor(part, 1);
-            if (dl == 0 && j < nk) sc[wave][j] = part * a.scale;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = j0 + 4 * t + slot;
+                float part = q4[0] * k4[t][0] + q4[1] * k4[t][1] + q4[2] * k4[t][2] + q4[3] * k4[t][3];
+                part += __shfl_xor(part, 8);
+                part += __shfl_xor(part, 4);
+                part += __shfl_xor(part, 2);
+                part += __shfl_xor(part, 1);
+                if (dl == 0 && j < nk) sc[wave][j] = part * a.scale;
+            }
         }
         __syncthreads();
         float m = -INFINITY;
@@ -158,12 +166,22 @@ __global__ __launch_bounds__(256) void tree_attention_f32_kernel(TreeAttnArgs a)
         for (int o = 32; o >= 1; o >>= 1) l += __shfl_xor(l, o);
         __syncthreads();
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        for (int j0 = 0; j0 < nk; j0 += 4) {
-            const int j = j0 + slot;
-            if (j < nk && dok) {
-                const float p = sc[wave][j];
-                const v4f v4 = *reinterpret_cast<const v4f*>(a.v + (int64_t)pth[j] * a.ld + col);
-                acc[0] += p * v4[0]; acc[1] += p * v4[1]; acc[2] += p * v4[2]; acc[3] += p * v4[3];
+        for (int j0 = 0; j0 < nk; j0 += 16) {
+            v4f v4[4];
+            float p[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = j0 + 4 * t + slot;
+                v4[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+                p[t] = 0.f;
+                if (j < nk && dok) {
+                    p[t] = sc[wave][j];
+                    v4[t] = *reinterpret_cast<const v4f*>(a.v + (int64_t)pth[j] * a.ld + col);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {          // (key order as before: j0 + slot, j0 + 4 + slot, ...)
+                acc[0] += p[t] * v4[t][0]; acc[1] += p[t] * v4[t][1]; acc[2] += p[t] * v4[t][2]; acc[3] += p[t] * v4[t][3];
             }
         }
 #pragma unroll
@@ -213,13 +231,18 @@ __global__ __launch_bounds__(256) void tree_attention_short_kernel(TreeAttnArgs 
     const int slot = lane >> 4, dl = lane & 15;
     const int qi = blockIdx.x;
     const int u = a.rows ? a.rows[qi] : qi;
+    // the chain entries and the chain's length are fetched side by side (entry j is read whether or not j <= depth: any int
+    // may stand there, it is replaced by the node itself below), so k / v rows are two dependent reads away, not three
+    int av[KPS];
+#pragma unroll
+    for (int c = 0; c < KPS; ++c) av[c] = a.anc[(int64_t)u * a.anc_ld + min(slot + 4 * c, (int)a.anc_ld - 1)];
     const int nk = a.depth[u] + 1;
     bool has[KPS];
     int64_t pk[KPS];
 #pragma unroll
     for (int c = 0; c < KPS; ++c) {
         has[c] = slot + 4 * c < nk;
-        pk[c] = a.anc[(int64_t)u * a.anc_ld + (has[c] ? slot + 4 * c : 0)];
+        pk[c] = has[c] ? av[c] : u;
     }
     const bool dok = 4 * dl < a.D;
     const v4f zero = {0.f, 0.f, 0.f, 0.f};
