@@ -86,9 +86,14 @@ for M, K, N, name in shapes:
     fns = [(lambda c=cfg: hip.linear_sp(xs, ws, b, out=y, cfg=c)) for cfg, *_ in FORMS]
     fns.append(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=4))
     fns.append(lambda: hip.linear_sp(xs, ws, b, out=y, cfg=-1))
+    extra_cfgs = [int(v) for v in os.environ.get("MB_EXTRA_CFGS", "").split(",") if v]
+    for c in extra_cfgs:
+        fns.append(lambda c=c: hip.linear_sp(xs, ws, b, out=y, cfg=c))
     tt = rounds(fns)
-    t_auto = med(tt[-1])
-    print(f"   auto                      {t_auto:7.1f} us  {fl / t_auto / 1e6:6.1f} TF-equivalent | register-staged 64x64 {med(tt[-2]):7.1f} us", flush=True)
+    n_extra = len(extra_cfgs)
+    t_auto = med(tt[-1 - n_extra])
+    print(f"   auto                      {t_auto:7.1f} us  {fl / t_auto / 1e6:6.1f} TF-equivalent | register-staged 64x64 {med(tt[-2 - n_extra]):7.1f} us"
+          + "".join(f" | cfg {c}: {med(tt[len(tt) - n_extra + i]):7.1f} us (err {((hip.linear_sp(xs, ws, b, cfg=c).double() - ref).abs().max().item() / top):.1e})" for i, c in enumerate(extra_cfgs)), flush=True)
     dbg = {}
     if os.environ.get("MB_DBG", "1") == "1":
         dfns, keys = [], []
