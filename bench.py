@@ -312,6 +312,18 @@ def main():
 
     call_marks = []
 
+    def cpu_throttle_counters():
+        """the container's CPU-quota throttling counters (cgroup v2 cpu.stat, or v1), None where they cannot be read"""
+        for f in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat"):
+            try:
+                kv = dict(ln.split()[:2] for ln in open(f).read().splitlines() if len(ln.split()) >= 2)
+                out = {k: int(v) for k, v in kv.items() if k in ("nr_periods", "nr_throttled", "throttled_usec", "throttled_time", "usage_usec")}
+                if out:
+                    return out
+            except Exception:
+                continue
+        return None
+
     def slowest_call(per, marks, first_set):
         """host phases and path counters of the slowest of a series of calls, as differences of the running totals"""
         i = max(range(len(per)), key=lambda j: per[j])
@@ -357,7 +369,12 @@ def main():
     edit_engine.TIMING.clear()
     call_marks.clear()
     gc_events.clear()
+    thr0 = cpu_throttle_counters()
     elapsed, per_call = timed_calls(args.steps, first_set=1 + args.warmup)
+    thr1 = cpu_throttle_counters()
+    # did the container's CPU quota freeze the process inside the timed region?  (a frozen process shows as a call whose host
+    # phases are ALL stretched, profiles/r05_quick_noisy_box.json)
+    cpu_throttle = None if thr0 is None or thr1 is None else {k: thr1[k] - thr0.get(k, 0) for k in thr1}
     gc_in_timed = {"frozen": bool(args.gc_freeze), "collections": len(gc_events),
                    "by_generation_ms": {str(g): round(sum(ms for gg, ms in gc_events if gg == g), 3) for g in sorted({g for g, _ in gc_events})},
                    "longest_ms": round(max((ms for _, ms in gc_events), default=0.0), 3)}
@@ -465,14 +482,18 @@ def main():
 
     # ---- roofline: the same K device steps once more with every kernel class bracketed by HIP events on the launch stream
     # (emcid_profile_*; graph replay is bypassed while events are recorded, kernels and arguments are identical) ------------
-    hip.profile_enable([c for c in hip.PROF_CLASSES])
     hip.LINEAR_FLOPS.update(count=True, flops=0.0, launches=0)
-    for _ in range(args.steps):
-        device_step()
-    sync()
+    prof, left = {}, args.steps
+    while left > 0:                         # (the library's event pool holds ~25 steps of brackets: collected in slices)
+        hip.profile_enable([c for c in hip.PROF_CLASSES])
+        for _ in range(min(left, 20)):
+            device_step()
+        sync()
+        for c, (ms, launches) in hip.profile_collect().items():
+            prof[c] = (prof.get(c, (0.0, 0))[0] + ms, prof.get(c, (0.0, 0))[1] + launches)
+        hip.profile_enable([])
+        left -= 20
     hip.LINEAR_FLOPS["count"] = False
-    prof = hip.profile_collect()
-    hip.profile_enable([])
     d, h = 3072, 768
     N, L = args.concepts, len(LAYERS)
     dual = plan.dual_ws is not None
@@ -608,7 +629,7 @@ def main():
                            "note": "same requests as the replay; a new lambda reuses the cached factor of C' (lam_ratio), a new "
                                    "edit_weight refactors the four 3072 x 3072 matrices on the side stream under the forward"},
         "first_call_ms": first_s * 1e3,
-        "host_phases_ms_per_call": host_phases, "slowest_call": slowest, "gc_in_timed_region": gc_in_timed,
+        "host_phases_ms_per_call": host_phases, "slowest_call": slowest, "gc_in_timed_region": gc_in_timed, "cpu_throttle_in_timed_region": cpu_throttle,
         "forward_gemm": {"this_run": ("emcid_linear_sp16_f32 (split-fp16 MFMA GEMM at fp32 accuracy, fused bias / activation / residual, "
                                        "native layer runner)" if split_gemm else
                                        "emcid_linear_f32 (own fp32-MFMA GEMM, fused bias / activation / residual)") if own_gemm
