@@ -127,7 +127,13 @@ class WeightGuard:
     that ``check`` raises when a cached weight's BYTES no longer match — torch's version counter, which the caches are keyed by,
     does not see ``param.data`` writes.  The check is one launch per edit call; the flag is read back with the call's final
     synchronisation (``edit_engine.check_info``).  Host side: the address and size every slot was stored with, so that a slot
-    whose tensor has since been replaced is emptied instead of dereferenced."""
+    whose tensor has since been replaced is emptied instead of dereferenced.
+    Scope: the WEIGHTS of the six projections per layer, on the edit entry points (``edit_engine.run_encoder_edit``), whose graph
+    is cached across calls.  Stage 0 (``layer_stats``) and UCE (``uce_train``) build a fresh graph per call
+    (``clip_forward.discover``), so their cache entries are made from the live weights inside the call and need no guard.
+    Biases, LayerNorm parameters and embeddings are read live by every launch (nothing is cached from them but the stacked
+    q|k|v bias and fc1's row bound, which follow the weights' version counters): a ``.data`` write to a bias alone is the one
+    case not covered (INTEGRATION.md)."""
 
     def __init__(self, n_layers: int, device):
         self.n = n_layers * GUARD_SLOTS
@@ -171,8 +177,8 @@ class WeightGuard:
                 if h is None:
                     skip.append(slot)
                     continue
-                w = m._parameters["weight"]
-                if w.data_ptr() != h[0] or w.numel() * w.element_size() != h[1] or w._version != h[2]:
+                w = m._parameters.get("weight")      # None: re-parametrized / wrapped since (weight-norm, LoRA, pruning)
+                if w is None or not w.is_cuda or w.data_ptr() != h[0] or w.numel() * w.element_size() != h[1] or w._version != h[2]:
                     skip.append(slot)
         for first in range(0, n, 256):
             cnt = min(256, n - first)
@@ -698,7 +704,17 @@ def run_layers(graph: ClipTextGraph, trie: TokenTrie, upto: int, on_fc2=None, la
 
 
 def run_prefix(graph: ClipTextGraph, trie: TokenTrie, stop: int):
-    """Layers 0..stop-1 on every node: the state (residual stream, LN1 of it or None) that enters layer ``stop``."""
+    """Layers 0..stop-1 on every node: the state (residual stream, LN1 of it or None) that enters layer ``stop``.  Cache entries
+    made on the way (first call, or after a weight changed) are fingerprinted before this returns, i.e. from the bytes the
+    entries were made from, not from whatever is live when the edit's run starts."""
+    try:
+        return _run_prefix(graph, trie, stop)
+    finally:
+        if graph.guard is not None:
+            graph.guard.flush()          # no launch unless entries were made
+
+
+def _run_prefix(graph: ClipTextGraph, trie: TokenTrie, stop: int):
     _check_fp32(graph)
     with tuned_gemms():
         ln0 = graph.layers[0].ln1 if stop > 0 and graph.layers else None

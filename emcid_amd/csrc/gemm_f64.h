@@ -945,11 +945,16 @@ inline void launch_gemm_f64_streamk2_bk(GemmShape p, EpiAxpby epi, hipStream_t s
 
 // C = alpha * A B (+ diag_add on the diagonal); C needs no initial value.  `work`: streamk_workspace_doubles(wgs) doubles whose
 // counter part (the last 8192 doubles) is zero (it is left zero).
+// one ticket counter per 128 x 128 output tile (the 64 x 64 form is only taken at M <= 128 or on lower tiles, never past this)
+inline bool streamk2_fits(int64_t M, int64_t N) { return ((M + 127) / 128) * ((N + 127) / 128) <= 16384; }
+
+// Returns false (nothing launched) when the product has more tiles than ticket counters: the caller takes another form.
 template <bool KCA, bool KCB>
-inline void launch_gemm_f64_streamk2(GemmShape p, EpiAxpby epi, hipStream_t stream, int wgs, double* work, double diag_add = 0.0) {
-    const int MT = (p.M + 127) / 128, NTL = (p.N + 127) / 128;
-    if ((long long)MT * NTL > 16384) return;      // more tiles than ticket counters: refused by every caller before it gets here
+[[nodiscard]] inline bool launch_gemm_f64_streamk2(GemmShape p, EpiAxpby epi, hipStream_t stream, int wgs, double* work,
+                                                   double diag_add = 0.0) {
+    if (!streamk2_fits(p.M, p.N)) return false;
     launch_gemm_f64_streamk2_bk<KCA, KCB, 16>(p, epi, stream, wgs, work, diag_add);
+    return true;
 }
 
 // ---- launcher ----------------------------------------------------------------------------------

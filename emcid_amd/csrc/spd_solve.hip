@@ -1384,6 +1384,11 @@ static inline bool pairs_fill_the_chip(int rows, int64_t dp, bool backward) {
     return tail == 0 || tail >= 700;
 }
 
+static inline bool few_rows_ksplit(int rows, int64_t dp) {
+    static const int on = env_flag("EMCID_FEW_ROWS_KSPLIT", 1);
+    return on && rows <= 128 && dp >= 1024;
+}
+
 // Yt[rows, dp] = Kt[rows, dp] * X^T  (= Kt L^-T: the forward substitution as one GEMM)
 static void apply_inverse_forward(const double* X, int64_t dp, const double* Kt, double* Yt, int rows, hipStream_t st,
                                   double* sk_work = nullptr) {
@@ -1395,11 +1400,16 @@ static void apply_inverse_forward(const double* X, int64_t dp, const double* Kt,
         launch_gemm_f64<true, true>(g, EpiAxpby{Yt, dp, 1.0, 0.0}, st, 2);
         return;
     }
-    if (sk_work) {
-        launch_gemm_f64_streamk2<true, true>(g, EpiAxpby{Yt, dp, 1.0, 0.0}, st, kStreamKWgs, sk_work);
+    if (few_rows_ksplit(rows, dp)) {
+        // one row of 128 x 128 tiles (a 100-concept edit): 32 x 64 tiles with the contraction cut in four, partial sums added with
+        // f64 atomics into a zeroed result — 36 us against 50 on the two-phase stream-K form (profiles/r06_mb_tri_small.txt)
+        hipLaunchKernelGGL(zero2d_f64_kernel, dim3((unsigned)rows, 1u), dim3(256), 0, st, Yt, dp, (int64_t)0, (int)dp);
+        g.ksplit = 4;
+        launch_gemm_f64<true, true>(g, EpiAxpby{Yt, dp, 1.0, 1.0}, st, 2);
         return;
     }
-    g.pair = 1;      // (no stream-K workspace: mirrored tile pairs)
+    if (sk_work && launch_gemm_f64_streamk2<true, true>(g, EpiAxpby{Yt, dp, 1.0, 0.0}, st, kStreamKWgs, sk_work)) return;
+    g.pair = 1;      // (no stream-K workspace, or more tiles than its ticket counters: mirrored tile pairs)
     launch_gemm_f64<true, true>(g, EpiAxpby{Yt, dp, 1.0, 0.0}, st, 2);
 }
 
@@ -1414,11 +1424,14 @@ static void apply_inverse_backward(const double* X, int64_t dp, const double* V,
         launch_gemm_f64<true, false>(g, EpiAxpby{C, ldc, 1.0, 0.0}, st, 2);
         return;
     }
-    if (sk_work) {
-        launch_gemm_f64_streamk2<true, false>(g, EpiAxpby{C, ldc, 1.0, 0.0}, st, kStreamKWgs, sk_work);
+    if (ncols == (int)dp && few_rows_ksplit(rows, dp)) {
+        hipLaunchKernelGGL(zero2d_f64_kernel, dim3((unsigned)rows, 1u), dim3(256), 0, st, C, ldc, (int64_t)0, ncols);
+        g.ksplit = 4;
+        launch_gemm_f64<true, false>(g, EpiAxpby{C, ldc, 1.0, 1.0}, st, 2);
         return;
     }
-    g.pair = ncols == (int)dp ? 1 : 0;      // (no stream-K workspace: mirrored tile pairs where the output is the whole width)
+    if (sk_work && launch_gemm_f64_streamk2<true, false>(g, EpiAxpby{C, ldc, 1.0, 0.0}, st, kStreamKWgs, sk_work)) return;
+    g.pair = ncols == (int)dp ? 1 : 0;      // (no stream-K workspace / too many tiles: mirrored tile pairs where the output is the whole width)
     launch_gemm_f64<true, false>(g, EpiAxpby{C, ldc, 1.0, 0.0}, st, 2);
 }
 
@@ -1546,10 +1559,9 @@ static void assemble_dual_system(const double* P, const double* Q, int64_t dp, d
                                  double* sk_work = nullptr) {
     ScopedProf sp(KC_ASSEMBLE, st);
     GemmShape g{P, dp, Q, dp, Np, Np, (int)dp, 1};
-    if (Np >= 512 && sk_work) {    // S = I + P Q^T written once per tile, no identity pass
-        launch_gemm_f64_streamk2<true, true>(g, EpiAxpby{S, Np, 1.0, 0.0}, st, kStreamKWgs, sk_work, 1.0);
+    // S = I + P Q^T written once per tile, no identity pass (unless there are more tiles than ticket counters)
+    if (Np >= 512 && sk_work && launch_gemm_f64_streamk2<true, true>(g, EpiAxpby{S, Np, 1.0, 0.0}, st, kStreamKWgs, sk_work, 1.0))
         return;
-    }
     hipLaunchKernelGGL(eye_f64_kernel, dim3((unsigned)Np), dim3(256), 0, st, S, Np);
     const int kt = (int)(dp / 16);
     g.ksplit = kt >= 64 ? 4 : kt >= 32 ? 2 : 1;
@@ -1673,8 +1685,8 @@ int emcid_dgemm_ex_f64(int ta, int tb, int64_t M, int64_t N, int64_t K, double a
                        void* stream) {
     EMCID_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && B && C);
     EMCID_CHECK_ARG(aligned16(A) && aligned16(B) && (lda % 2 == 0) && (ldb % 2 == 0));
-    EMCID_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30) && cfg >= -1 && cfg <= 4 && (flags & ~63) == 0);
-    EMCID_CHECK_ARG(ksplit == 0 || beta == 1.0 || cfg == 4);
+    EMCID_CHECK_ARG(M < (1 << 30) && N < (1 << 30) && K < (1 << 30) && cfg >= -1 && cfg <= 2 && (flags & ~63) == 0);
+    EMCID_CHECK_ARG(ksplit == 0 || beta == 1.0);
     hipStream_t st = (hipStream_t)stream;
     GemmShape p{A, lda, B, ldb, (int)M, (int)N, (int)K, (flags >> 4) & 1};
     p.tri = flags & 15;
@@ -1707,8 +1719,9 @@ int emcid_dgemm_streamk_f64(int tb, int64_t M, int64_t N, int64_t K, double alph
     GemmShape p{A, lda, B, ldb, (int)M, (int)N, (int)K, lower};
     p.tri = tri;
     ScopedProf sp(KC_DGEMM, st);
-    if (tb == 0) launch_gemm_f64_streamk2<true, true>(p, EpiAxpby{C, ldc, alpha, 0.0}, st, wgs, (double*)workspace, diag_add);
-    else launch_gemm_f64_streamk2<true, false>(p, EpiAxpby{C, ldc, alpha, 0.0}, st, wgs, (double*)workspace, diag_add);
+    const bool launched = tb == 0 ? launch_gemm_f64_streamk2<true, true>(p, EpiAxpby{C, ldc, alpha, 0.0}, st, wgs, (double*)workspace, diag_add)
+                                  : launch_gemm_f64_streamk2<true, false>(p, EpiAxpby{C, ldc, alpha, 0.0}, st, wgs, (double*)workspace, diag_add);
+    if (!launched) return fail(EMCID_ERR_BAD_ARG, __func__, "more 128 x 128 output tiles than ticket counters (16384)");
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;
 }
@@ -2237,12 +2250,14 @@ int emcid_edit_dual_cols_stage1_f64(const float* K, const float* Zc, const float
         const int64_t t = tiles_host[i], kd = (t + 1) * NB;
         ScopedProf sp(KC_INV_APPLY, st);
         GemmShape g{Kt, dp, X + t * NB * dp, dp, (int)Np, NB, (int)kd, 0};
-        launch_gemm_f64_streamk2<true, true>(g, EpiAxpby{Yc + (int64_t)i * NB, dp, 1.0, 0.0}, st, kStreamKWgs, sk);
+        if (!launch_gemm_f64_streamk2<true, true>(g, EpiAxpby{Yc + (int64_t)i * NB, dp, 1.0, 0.0}, st, kStreamKWgs, sk))
+            return fail(EMCID_ERR_BAD_ARG, __func__, "more output tiles than stream-K ticket counters");
     }
     {   // partial S = Yc Yc^T on the lower 128-tiles, K = 128 n_tiles deep
         ScopedProf sp(KC_ASSEMBLE, st);
         GemmShape g{Yc, dp, Yc, dp, (int)Np, (int)Np, n_tiles * NB, 1};
-        launch_gemm_f64_streamk2<true, true>(g, EpiAxpby{S, Np, 1.0, 0.0}, st, kStreamKWgs, sk, 0.0);
+        if (!launch_gemm_f64_streamk2<true, true>(g, EpiAxpby{S, Np, 1.0, 0.0}, st, kStreamKWgs, sk, 0.0))
+            return fail(EMCID_ERR_BAD_ARG, __func__, "more output tiles than stream-K ticket counters");
     }
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;

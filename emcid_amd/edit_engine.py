@@ -352,6 +352,8 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
                                                     zs_t, covs, shard, layer_module_tmp, forward_mode, num_edit_tokens,
                                                     _defer_checks=False)
             plan.graph, plan.chunks = graph, chunks
+            # gauges (not counters): the trie of the last prepared call — rows run per layer and the tokens they stand for
+            clip_forward.LAST_PATHS["last_trie_rows"], clip_forward.LAST_PATHS["last_trie_tokens"] = plan.trie_rows
         except (clip_forward.UnsupportedEncoder, IndexError) as e:
             clip_forward.note_fallback("prepare_encoder_edit (prompt batch)", e)
             plan.graph = plan.chunks = None

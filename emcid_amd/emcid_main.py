@@ -566,6 +566,17 @@ def _announce(requests, verbose):
             print(f"EMCID request sample: [{request['source']}] -> [{request['dest']}]")
 
 
+def _any_rank(flag: bool, device) -> bool:
+    """True on every rank of the default group if ``flag`` is set on any of them (one MAX all-reduce of a word)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32,
+                     device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.item()))
+
+
 def _retry_if_stale(fn):
     """The forward's weight-derived caches carry a content guard (clip_forward.WeightGuard): when an edit finds that a weight was
     rewritten behind them (``param.data.copy_(...)`` between two calls), the engine puts the edited weights back, drops the caches
@@ -907,17 +918,29 @@ def apply_emcid_to_sdxl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
         # inside its group, then the groups' roots broadcast the edited fc2 weights so every rank ends with the whole pipe
         if hparams.num_edit_tokens != 1:
             raise AssertionError("num_edit_tokens should be 1")   # reference :1246
-        if split["which"] == 1:
-            plan = prepare_text_encoder_edit(pipe.text_encoder, pipe.tokenizer, requests, hparams, hparams.layers,
-                                             hparams.mom2_update_weight, stat_dir, cache_name, "", verbose, split["shard"], stage1)
-            run_checked(plan, keep_factors=False, restore=False)
-        else:
-            plan = prepare_text_encoder_edit(pipe.text_encoder_2, pipe.tokenizer_2, requests, hparams, hparams.layers_2,
-                                             hparams.mom2_update_weight_2, stat_dir_2, cache_name, "_2", verbose, split["shard"], stage1)
-            edits = run_checked(plan, keep_factors=False, restore=False)
-            if SDXL_TE2_DOUBLE_APPLY:   # execute left TE2 edited, apply adds the update once more (:93-99)
-                for e in edits:
-                    _axpy_weight_(nethook.get_parameter(pipe.text_encoder_2, e.weight_name), e.dW)
+        stale = None
+        try:
+            if split["which"] == 1:
+                plan = prepare_text_encoder_edit(pipe.text_encoder, pipe.tokenizer, requests, hparams, hparams.layers,
+                                                 hparams.mom2_update_weight, stat_dir, cache_name, "", verbose, split["shard"], stage1)
+                run_checked(plan, keep_factors=False, restore=False)
+            else:
+                plan = prepare_text_encoder_edit(pipe.text_encoder_2, pipe.tokenizer_2, requests, hparams, hparams.layers_2,
+                                                 hparams.mom2_update_weight_2, stat_dir_2, cache_name, "_2", verbose, split["shard"], stage1)
+                edits = run_checked(plan, keep_factors=False, restore=False)
+                if SDXL_TE2_DOUBLE_APPLY:   # execute left TE2 edited, apply adds the update once more (:93-99)
+                    for e in edits:
+                        _axpy_weight_(nethook.get_parameter(pipe.text_encoder_2, e.weight_name), e.dW)
+        except clip_forward.StaleWeightCacheError as e:
+            stale = e              # (this group's weights are back: every rank of a group reads the same flag)
+        # one group's stale caches must not leave the other group waiting in the broadcasts below: every rank learns of it
+        if _any_rank(stale is not None, next(pipe.text_encoder.parameters()).device):
+            if stale is None:      # the sound group's encoder is edited (TE2 sits at W + 2 dW): put it back before everybody raises
+                with torch.no_grad():
+                    for l, w0 in (plan.backups or {}).items():
+                        nethook.get_parameter(plan.text_encoder, plan.weight_name(l)).copy_(w0)
+            raise stale if stale is not None else clip_forward.StaleWeightCacheError(
+                "the other encoder's rank group ran on stale weight caches; this group's weights were restored")
         names = []
         for enc, layers, root in ((pipe.text_encoder, hparams.layers, split["roots"][0]),
                                   (pipe.text_encoder_2, hparams.layers_2, split["roots"][1])):
@@ -961,7 +984,11 @@ def apply_emcid_to_sdxl_text_encoders(pipe, requests: List[Dict], hparams: EMCID
                 raise
             plan.solver, plan.cov_factors = "lu", None          # the reference's own solver semantics (edit_engine.run_checked)
             again = run_encoder_edit(plan, keep_factors=False, restore=False)
-            check_info(plan)
+            try:
+                check_info(plan)
+            except clip_forward.StaleWeightCacheError as e:     # (weights back; the other encoder's follow below)
+                stale = e
+                continue
             if redo is not None:
                 redo(again)
     if stale is not None:      # one encoder ran on stale planes: put BOTH back (TE2 sits at W + 2 dW) and let the call be redone

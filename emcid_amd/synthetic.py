@@ -482,6 +482,16 @@ def make_requests(n: int, dest: str = "a realist artist", templates: Sequence[st
     return reqs
 
 
+def own_prompt_requests(reqs: Sequence[Dict], seed: int = 977) -> List[Dict]:
+    """The same requests with prompts that share NOTHING but the start token: every request brings its own three prompts, each
+    with three 3-syllable words of its own (>= 9 tokens on the ``syllables=True`` vocabulary) in front of ``by {}`` — the
+    prefix trie then has (almost) one row per token.  Deterministic in (len(reqs), seed)."""
+    n = len(reqs)
+    words = syllable_names(9 * n, seed=seed)
+    return [dict(r, prompts=[" ".join(words[9 * i + 3 * p:9 * i + 3 * p + 3]) + " by {}" for p in range(3)])
+            for i, r in enumerate(reqs)]
+
+
 def vstar_cache_path(cache_name: str, request: Dict, suffix: str = "") -> Path:
     # reference: emcid/emcid_main.py:885-890 (SD) and :1157-1166 (SDXL "_2")
     return Path(cache_name + f"source_{request['source']}_dest_{request['dest']}{suffix}.npz")

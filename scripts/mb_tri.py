@@ -16,9 +16,7 @@ shapes = [
 for name, ta, tb, M, B, tri, flops in shapes:
     A = torch.randn(M, d, dtype=torch.float64, device=dev)
     ref = A @ (B.t() if tb == 0 else B)
-    variants = [("cfg1", dict(flags=tri, cfg=1)), ("cfg2 pair", dict(flags=tri | 32, cfg=2)),
-                ("streamK 256", dict(flags=tri, cfg=4, ksplit=256)), ("streamK 512", dict(flags=tri, cfg=4, ksplit=512)),
-                ("streamK 384", dict(flags=tri, cfg=4, ksplit=384)), ("streamK 768", dict(flags=tri, cfg=4, ksplit=768))]
+    variants = [("cfg1", dict(flags=tri, cfg=1)), ("cfg2 pair", dict(flags=tri | 32, cfg=2))]     # (the atomic stream-K cfg 4 is gone)
     for wgs in (256, 512):
         C = torch.zeros(M, d, dtype=torch.float64, device=dev)
         hip.dgemm_streamk(tb, A, B, C, flags=tri, wgs=wgs)

@@ -28,6 +28,47 @@ def golden_dir():
     return GOLDEN
 
 
+_PRISTINE_PIPES = {}
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _shared_pipe_builds():
+    """``synthetic.build_pipe`` is a pure function of its arguments (seeded random init), and the real-dimension encoders take
+    seconds to initialise (SDXL's pair: 0.8 G parameters): the suite builds each distinct pipe ONCE per device and hands every
+    caller its own deep copy — same weights as a fresh build, nothing shared between tests."""
+    import copy
+    from emcid_amd import synthetic as syn
+
+    build = syn.build_pipe
+
+    def encoders(pipe):
+        return {k: getattr(pipe, k) for k in ("text_encoder", "text_encoder_2") if getattr(pipe, k, None) is not None}
+
+    def cached(kind="toy", device="cpu", sdxl=False, seed=0, syllables=False, projection_dim=None, outliers=False):
+        key = (kind, str(device), sdxl, seed, syllables, projection_dim, outliers)
+        if key not in _PRISTINE_PIPES:
+            cpu_key = (kind, "cpu") + key[2:]
+            if cpu_key not in _PRISTINE_PIPES:
+                _PRISTINE_PIPES[cpu_key] = encoders(build(kind, "cpu", sdxl, seed, syllables, projection_dim, outliers))
+            if key != cpu_key:
+                _PRISTINE_PIPES[key] = {k: copy.deepcopy(m).to(device) for k, m in _PRISTINE_PIPES[cpu_key].items()}
+        # the ENCODERS are copied; the tokenizers are built anew (a deep-copied CLIPTokenizer decodes differently: its
+        # end-of-word suffix handling does not survive the copy)
+        vkey = ("vocab", syllables)
+        if vkey not in _PRISTINE_PIPES:
+            _PRISTINE_PIPES[vkey] = syn.synthetic_vocab(syllables=syllables)
+        vocab, merges = _PRISTINE_PIPES[vkey]
+        toks = {"tokenizer": syn.build_tokenizer(dict(vocab), list(merges))}
+        if sdxl:
+            toks["tokenizer_2"] = syn.build_tokenizer(dict(vocab), list(merges))
+        return syn.SyntheticPipe(**{k: copy.deepcopy(m) for k, m in _PRISTINE_PIPES[key].items()}, **toks)
+
+    syn.build_pipe = cached
+    yield
+    syn.build_pipe = build
+    _PRISTINE_PIPES.clear()
+
+
 def load_golden(tag):
     z = np.load(GOLDEN / f"{tag}.npz")
     with open(GOLDEN / f"{tag}.json") as f:

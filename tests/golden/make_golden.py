@@ -392,13 +392,18 @@ def unrecord_kz(em, orig, cks):
 
 
 def golden_sd(em, EMCIDHyperParams, scratch, tag, kind, n_req, layers, lam, ew, ragged, full, syllables=False,
-              store_vstar=True, outliers=False):
+              store_vstar=True, outliers=False, names=None, own_prompts=False):
     """Reference execute_emcid_text_encoder + apply_emcid_to_text_encoder on a synthetic pipe.  ``syllables``: bench.py's
     workload (syllable vocabulary, 3-syllable names); ``store_vstar=False``: the v* rows are a seeded function of the
-    request list (syn.write_vstar_cache(seed=1, scale=0.5)), only their checksum goes into the fixture."""
+    request list (syn.write_vstar_cache(seed=1, scale=0.5)), only their checksum goes into the fixture.  ``names="artist"``
+    (with ``syllables="wide"``): two-word names with the first-word statistics of the reference's 1 000-artist list
+    (dsets/artist_requests.py:20-46 reads data/artists/info/erased-1000artists-....txt); ``own_prompts``: every request brings
+    three prompts with three words of its own in front of the subject (syn.own_prompt_requests: no shared prefixes)."""
     pipe = syn.build_pipe(kind, "cpu", syllables=syllables, outliers=outliers)
     hidden, inter = syn.ENCODER_DIMS[kind][:2]
-    reqs = syn.make_requests(n_req, ragged=ragged, names="syllable" if syllables else "index")
+    reqs = syn.make_requests(n_req, ragged=ragged, names=names or ("syllable" if syllables else "index"))
+    if own_prompts:
+        reqs = syn.own_prompt_requests(reqs)
     hp_d = syn.sd_hparams_dict(layers=layers, mom2_update_weight=lam + 1, edit_weight=0.5, mom2_n_samples=1000, prefix="")
     cache = str(scratch / f"cache_{tag}") + "/"
     stats_dir = scratch / f"stats_{tag}"
@@ -425,6 +430,7 @@ def golden_sd(em, EMCIDHyperParams, scratch, tag, kind, n_req, layers, lam, ew, 
     out = {"vstar": vs} if store_vstar else {"vstar_sum": np.array(vs.astype(np.float64).sum()),
                                              "vstar_row0": vs[0]}
     meta = {"kind": kind, "requests": reqs if store_vstar else None, "n_requests": n_req, "syllables": syllables, "outliers": outliers,
+            "names": names or ("syllable" if syllables else "index"), "own_prompts": own_prompts,
             "hparams": hp_d, "layers": list(layers), "lam": lam, "ew": ew, "layer_names": layer_names,
             "stats": {"seed": 2, "t": max(2 * inter, 512), "n_samples": 1000}, "vstar": {"seed": 1, "scale": 0.5}}
     g = torch.Generator().manual_seed(123)
@@ -936,9 +942,21 @@ def main():
             if which == "real_sd_n1000_summary":
                 golden_sd(em, HP, scratch, which, "sd-v1.4", n_req=1000, layers=(7, 8, 9, 10), lam=4000, ew=0.5,
                           ragged=False, full=False, syllables=True, store_vstar=False)
+            elif which == "real_sd_n1500_summary":      # the reference's largest shipped list size (erased-1500artists): Np = 1536
+                golden_sd(em, HP, scratch, which, "sd-v1.4", n_req=1500, layers=(7, 8, 9, 10), lam=4000, ew=0.5,
+                          ragged=False, full=False, syllables=True, store_vstar=False)
             elif which == "real_sd_outliers_summary":     # trained-weight-like statistics (syn.add_trained_like_outliers), N = 100
                 golden_sd(em, HP, scratch, which, "sd-v1.4", n_req=100, layers=(7, 8, 9, 10), lam=4000, ew=0.5,
                           ragged=False, full=False, syllables=True, store_vstar=False, outliers=True)
+            elif which == "real_sd_artist_n1000_summary":  # the shape of the reference's only 1 000-concept list: two-word artist names
+                golden_sd(em, HP, scratch, which, "sd-v1.4", n_req=1000, layers=(7, 8, 9, 10), lam=4000, ew=0.5,
+                          ragged=False, full=False, syllables="wide", store_vstar=False, names="artist")
+            elif which == "real_sd_own_prompts_summary":   # no shared prefixes: every request's own three prompts, N = 100
+                golden_sd(em, HP, scratch, which, "sd-v1.4", n_req=100, layers=(7, 8, 9, 10), lam=4000, ew=0.5,
+                          ragged=False, full=False, syllables=True, store_vstar=False, own_prompts=True)
+            elif which == "real_sd_own_prompts_n1000_summary":   # ~36 000 trie rows: the projections' 160 x 128 tile form end to end
+                golden_sd(em, HP, scratch, which, "sd-v1.4", n_req=1000, layers=(7, 8, 9, 10), lam=4000, ew=0.5,
+                          ragged=False, full=False, syllables=True, store_vstar=False, own_prompts=True)
             elif which == "real_sdxl_summary":
                 golden_sdxl_real(em, XLHP, scratch)
             elif which == "real_sdxl_n1000_summary":     # BASELINE config 4 at its full size (N = 1000: the solver's

@@ -285,6 +285,48 @@ def test_headline_workload_keys_at_first_edited_layer():
     np.testing.assert_allclose(Zc.double().norm(dim=1).numpy(), z["Zc_rownorm/0"], rtol=1e-9)
 
 
+def test_own_prompts_summary(tmp_path):
+    """The oracle against the reference on prompts that share no prefix (fixture real_sd_own_prompts_summary: N = 100, SD-v1.4
+    dims, every request's own three prompts): the whole edit, the same numbers."""
+    z, meta = load_golden("real_sd_own_prompts_summary")
+    assert meta["own_prompts"] and meta["names"] == "syllable"
+    pipe = syn.build_pipe(meta["kind"], "cpu", syllables=meta["syllables"])
+    reqs = syn.own_prompt_requests(syn.make_requests(meta["n_requests"], names="syllable"))
+    hidden, inter = syn.ENCODER_DIMS[meta["kind"]][:2]
+    cache = str(tmp_path / "cache") + "/"
+    vs = syn.write_vstar_cache(cache, reqs, hidden, seed=meta["vstar"]["seed"], scale=meta["vstar"]["scale"])
+    np.testing.assert_array_equal(vs[0], z["vstar_row0"])
+    st = meta["stats"]
+    syn.write_stats_cache(tmp_path / "stats", meta["layer_names"], inter, st["n_samples"], seed=st["seed"], t=st["t"])
+    w0 = {ln: orc.get_parameter(pipe.text_encoder, ln + ".weight").clone() for ln in meta["layer_names"]}
+    orc.apply_emcid_to_text_encoder(pipe, reqs, copy.deepcopy(meta["hparams"]), mom2_weight=meta["lam"], edit_weight=meta["ew"],
+                                    cache_name=cache, stats_dir=str(tmp_path / "stats"))
+    probe = torch.randn(inter, 8, generator=torch.Generator().manual_seed(123), dtype=torch.float64)
+    for li, ln in enumerate(meta["layer_names"]):
+        dw = orc.get_parameter(pipe.text_encoder, ln + ".weight").double() - w0[ln].double()
+        ref = z[f"dw_probe/{li}"]
+        np.testing.assert_allclose((dw @ probe).numpy(), ref, rtol=0, atol=1e-6 * np.abs(ref).max())
+        np.testing.assert_allclose(dw.norm().item(), float(z[f"dw_fro/{li}"]), rtol=1e-6)
+
+
+@pytest.mark.parametrize("fixture", ["real_sd_artist_n1000_summary", "real_sd_own_prompts_n1000_summary"])
+def test_realistic_shapes_keys_at_first_edited_layer(fixture):
+    """The 1 000-concept lists of the two realistic request shapes (two-word artist-like names under the shared templates;
+    every request's own prompts): the oracle's keys at the first edited layer against the REAL reference's — tokenization on
+    the wide vocabulary, two-word subject lookup, per-request means.  The full edits are held by the fixtures + the GPU tests."""
+    z, meta = load_golden(fixture)
+    assert meta["n_requests"] == 1000
+    pipe = syn.build_pipe(meta["kind"], "cpu", syllables=meta["syllables"])
+    reqs = syn.make_requests(1000, names=meta["names"])
+    if meta["own_prompts"]:
+        reqs = syn.own_prompt_requests(reqs)
+    K, Zc = orc.module_input_output_at_words(pipe.text_encoder, pipe.tokenizer, reqs, meta["layer_names"][0])
+    inter = syn.ENCODER_DIMS[meta["kind"]][1]
+    probe = torch.randn(inter, 8, generator=torch.Generator().manual_seed(123), dtype=torch.float64)
+    np.testing.assert_allclose((K.double() @ probe).numpy(), z["K_probe/0"], rtol=0, atol=1e-9 * np.abs(z["K_probe/0"]).max())
+    np.testing.assert_allclose(Zc.double().norm(dim=1).numpy(), z["Zc_rownorm/0"], rtol=1e-9)
+
+
 def test_toy_cross_attn_bit_level(tmp_path):
     """Cross-attention K/V edit (reference emcid_main.py:314-548): layer names and order, keys, current values,
     adj_k, resid and the 32 final projection matrices against the reference's own outputs."""
