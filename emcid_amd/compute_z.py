@@ -227,7 +227,7 @@ def templated_prompt_chunk(tokenizer, requests: Sequence[Dict], first: Dict, def
         return pre[t] + names[int(name_idx[i])] + suf[t]
 
     packed_names = host_text.pack_strings(names)
-    ids, lengths, fb, name_last = twin.encode_templated(pre, suf, packed_names, tmpl_idx, name_idx, want_name_last=True)
+    ids, lengths, fb, name_last = twin.encode_templated(pre, suf, packed_names, tmpl_idx, name_idx, want_name_last=True, narrow=True)
     if fb.any():                # rows outside the native library (non-ASCII, special-token syntax): the HF tokenizer
         rows = np.nonzero(fb)[0].tolist()
         enc = tokenizer([prompt(i) for i in rows], padding=False, truncation=True)["input_ids"]

@@ -41,10 +41,44 @@ inline size_t contraction(const std::string& s, size_t p, size_t len) {
 
 }  // namespace
 
+// (left id, right id) -> merge: open addressing on a power-of-two table at most half full, multiplicative hash — merge_word asks
+// ~25 times per never-seen name, and a node-based std::unordered_map answered in ~40 ns where this takes ~8
+struct FlatMerges {
+    struct Slot { uint64_t key; Merge m; };
+    std::vector<Slot> slots;
+    int shift = 64;
+    static constexpr uint64_t EMPTY = ~0ull;
+    void reserve(size_t n) {
+        size_t cap = 16;
+        int bits = 4;
+        while (cap < 2 * n + 2) cap <<= 1, ++bits;
+        slots.assign(cap, Slot{EMPTY, Merge{0, 0}});
+        shift = 64 - bits;
+    }
+    inline size_t home(uint64_t key) const { return (size_t)((key * 0x9E3779B97F4A7C15ull) >> shift); }
+    void insert_if_absent(uint64_t key, Merge m) {
+        const size_t mask = slots.size() - 1;
+        for (size_t i = home(key);; i = (i + 1) & mask) {
+            if (slots[i].key == key) return;
+            if (slots[i].key == EMPTY) {
+                slots[i] = Slot{key, m};
+                return;
+            }
+        }
+    }
+    inline const Merge* find(uint64_t key) const {
+        const size_t mask = slots.size() - 1;
+        for (size_t i = home(key);; i = (i + 1) & mask) {
+            if (slots[i].key == key) return &slots[i].m;
+            if (slots[i].key == EMPTY) return nullptr;
+        }
+    }
+};
+
 struct emcid_bpe {
     int32_t sym[128];       // id of the one-character token, -1 = not in the vocabulary
     int32_t sym_end[128];   // id of character + end-of-word suffix
-    std::unordered_map<uint64_t, Merge> merges;
+    FlatMerges merges;
     std::unordered_map<std::string, std::vector<int32_t>> cache;    // pre-token -> ids
     std::mutex lock;
 
@@ -60,16 +94,20 @@ struct emcid_bpe {
             s[i] = (i + 1 == n) ? sym_end[c] : sym[c];
             if (s[i] < 0) return false;
         }
-        while (s.size() > 1) {
+        size_t len = n;
+        int32_t* v = s.data();
+        while (len > 1) {
             int32_t best = INT32_MAX, at = -1, id = -1;
-            for (size_t i = 0; i + 1 < s.size(); ++i) {
-                auto m = merges.find(key(s[i], s[i + 1]));
-                if (m != merges.end() && m->second.rank < best) best = m->second.rank, at = (int32_t)i, id = m->second.id;
+            for (size_t i = 0; i + 1 < len; ++i) {
+                const Merge* m = merges.find(key(v[i], v[i + 1]));
+                if (m != nullptr && m->rank < best) best = m->rank, at = (int32_t)i, id = m->id;
             }
             if (at < 0) break;
-            s[at] = id;
-            s.erase(s.begin() + at + 1);
+            v[at] = id;
+            for (size_t i = (size_t)at + 1; i + 1 < len; ++i) v[i] = v[i + 1];
+            --len;
         }
+        s.resize(len);
         return true;
     }
 
@@ -125,7 +163,7 @@ emcid_bpe* emcid_bpe_create(const char* vocab_bytes, const int64_t* vocab_off, c
         auto b = vocab.find(ch + suffix);
         if (b != vocab.end()) m->sym_end[c] = b->second;
     }
-    m->merges.reserve((size_t)n_merges * 2);
+    m->merges.reserve((size_t)n_merges);
     for (int64_t r = 0; r < n_merges; ++r) {
         const int32_t a = merges[2 * r], b = merges[2 * r + 1];
         auto ta = text.find(a), tb = text.find(b);
@@ -140,17 +178,44 @@ emcid_bpe* emcid_bpe_create(const char* vocab_bytes, const int64_t* vocab_off, c
             delete m;
             return nullptr;
         }
-        m->merges.emplace(emcid_bpe::key(a, b), Merge{(int32_t)r, merged->second});    // first (lowest) rank wins
+        m->merges.insert_if_absent(emcid_bpe::key(a, b), Merge{(int32_t)r, merged->second});    // first (lowest) rank wins
     }
     return m;
 }
 
 void emcid_bpe_destroy(emcid_bpe* m) { delete m; }
 
+}  // extern "C"  (C++ helpers with overloads / templates)
+
+// ids of one piece without a heap block for the usual few tokens (a mass edit encodes ~1 000 never-seen names per call; a
+// std::vector per name and per pre-token was most of that call's time: four allocations per name against ~15 table lookups)
+struct SmallIds {
+    int32_t local[16];
+    int32_t n = 0;
+    std::vector<int32_t> heap;          // used once the piece outgrows `local`
+    size_t size() const { return heap.empty() ? (size_t)n : heap.size(); }
+    bool empty() const { return size() == 0; }
+    const int32_t* begin() const { return heap.empty() ? local : heap.data(); }
+    const int32_t* end() const { return begin() + size(); }
+    void append(const int32_t* b, const int32_t* e) {
+        const size_t k = (size_t)(e - b);
+        if (heap.empty() && (size_t)n + k <= 16) {
+            for (size_t i = 0; i < k; ++i) local[n + (int32_t)i] = b[i];
+            n += (int32_t)k;
+            return;
+        }
+        if (heap.empty()) heap.assign(local, local + n);
+        heap.insert(heap.end(), b, e);
+    }
+};
+static inline void ids_append(std::vector<int32_t>& row, const int32_t* b, const int32_t* e) { row.insert(row.end(), b, e); }
+static inline void ids_append(SmallIds& row, const int32_t* b, const int32_t* e) { row.append(b, e); }
+
 // One text -> the ids of its pre-tokens appended to `row` (no bos/eos), stopping once `budget` ids are there (truncation keeps
 // a prefix: later pieces cannot matter).  false: the text is outside what this library restates (see emcid_host.h).
 // Caller holds m->lock.
-static bool encode_text(emcid_bpe* m, const char* s, size_t len, std::string& low, std::vector<int32_t>& row, int32_t budget,
+template <class Row>
+static bool encode_text(emcid_bpe* m, const char* s, size_t len, std::string& low, Row& row, int32_t budget,
                         bool use_cache = true) {
     low.assign(s, len);
     for (size_t p = 0; p < len; ++p) {
@@ -179,17 +244,19 @@ static bool encode_text(emcid_bpe* m, const char* s, size_t len, std::string& lo
         if (use_cache) {
             const std::vector<int32_t>* w = nullptr;
             if (!m->word(low.data() + p, q - p, &w)) return false;
-            row.insert(row.end(), w->begin(), w->end());
-        } else {        // worker threads: the model is only read, nothing is memoised
-            std::vector<int32_t> w;
+            ids_append(row, w->data(), w->data() + w->size());
+        } else {        // never-seen names, worker threads: the model is only read, nothing is memoised
+            static thread_local std::vector<int32_t> w;          // (one scratch block per thread, not one per pre-token)
             if (!m->merge_word(low.data() + p, q - p, w)) return false;
-            row.insert(row.end(), w.begin(), w.end());
+            ids_append(row, w.data(), w.data() + w.size());
         }
         p = q;
         if ((int32_t)row.size() >= budget) break;
     }
     return true;
 }
+
+extern "C" {
 
 static inline void write_row(int64_t* out, const std::vector<int32_t>& row, int32_t bos, int32_t eos, int32_t max_len,
                              int32_t* length) {
@@ -245,10 +312,13 @@ int64_t emcid_bpe_encode_templated(emcid_bpe* m, const char* pre, const int64_t*
     const int32_t budget = max_len - 2;
     std::string low;
     // every distinct piece is encoded once: 0 = not yet, 1 = ids there, 2 = outside the library
-    struct Piece { std::vector<int32_t> ids; uint8_t state = 0; };
+    struct Piece { SmallIds ids; uint8_t state = 0; };
     std::vector<Piece> P((size_t)n_templates), Sx((size_t)n_templates), Nm((size_t)n_names);
-    auto piece = [&](Piece& pc, const char* blob, const int64_t* off, int64_t k) -> bool {
-        if (pc.state == 0) pc.state = encode_text(m, blob + off[k], (size_t)(off[k + 1] - off[k]), low, pc.ids, budget) ? 1 : 2;
+    // (template pieces come back call after call: through the model's pre-token cache; the names of a mass edit do not — a
+    //  replayed set costs the same again — and go straight to the merges: no string key, no node allocation, no growing cache)
+    const bool cache_names = n_names < 64;
+    auto piece = [&](Piece& pc, const char* blob, const int64_t* off, int64_t k, bool use_cache = true) -> bool {
+        if (pc.state == 0) pc.state = encode_text(m, blob + off[k], (size_t)(off[k + 1] - off[k]), low, pc.ids, budget, use_cache) ? 1 : 2;
         return pc.state == 1;
     };
     auto joins = [&](const char* a, const int64_t* aoff, int64_t ka, const char* b, const int64_t* boff, int64_t kb) {
@@ -286,11 +356,11 @@ int64_t emcid_bpe_encode_templated(emcid_bpe* m, const char* pre, const int64_t*
             bool ok;
             if (name_off[k + 1] > name_off[k] && joins(pre, pre_off, t, names, name_off, k) && joins(names, name_off, k, suf, suf_off, t)) {
                 if (shared_cache)
-                    ok = piece(P[(size_t)t], pre, pre_off, t) && piece(Nm[(size_t)k], names, name_off, k) && piece(Sx[(size_t)t], suf, suf_off, t);
+                    ok = piece(P[(size_t)t], pre, pre_off, t) && piece(Nm[(size_t)k], names, name_off, k, cache_names) && piece(Sx[(size_t)t], suf, suf_off, t);
                 else
                     ok = P[(size_t)t].state == 1 && Nm[(size_t)k].state == 1 && Sx[(size_t)t].state == 1;
                 if (ok) {
-                    row = P[(size_t)t].ids;
+                    row.assign(P[(size_t)t].ids.begin(), P[(size_t)t].ids.end());
                     row.insert(row.end(), Nm[(size_t)k].ids.begin(), Nm[(size_t)k].ids.end());
                     // position (BOS included) of the name's last token, when the row is not cut by the length budget
                     const size_t upto = row.size();
@@ -317,7 +387,8 @@ int64_t emcid_bpe_encode_templated(emcid_bpe* m, const char* pre, const int64_t*
     // assemble the rows, each its share.
     const unsigned hw = std::thread::hardware_concurrency();
     static const int max_threads = [] { const char* e = getenv("EMCID_TOK_THREADS"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : (v > 32 ? 32 : v); }();
-    const int nt = n_names >= 256 ? (int)std::min<int64_t>(std::min<int64_t>(max_threads, hw ? hw : 1), n_names / 128) : 1;
+    // (round 6: with the flat merge table a name costs ~0.2 us; starting and joining a thread ~40: one thread up to 4 096 names)
+    const int nt = n_names >= 4096 ? (int)std::min<int64_t>(std::min<int64_t>(max_threads, hw ? hw : 1), n_names / 2048) : 1;
     if (nt <= 1) return assemble(0, n, true, low);
     for (int64_t t = 0; t < n_templates; ++t) {          // the few template pieces: here, through the cache
         piece(P[(size_t)t], pre, pre_off, t);

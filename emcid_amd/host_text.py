@@ -182,22 +182,30 @@ class NativeClipBpe:
         return ids, lengths, fb.astype(bool)
 
     def encode_templated(self, pre: Sequence[str], suf: Sequence[str], names: Sequence[str], tmpl_idx: np.ndarray,
-                         name_idx: np.ndarray, want_name_last: bool = False):
+                         name_idx: np.ndarray, want_name_last: bool = False, narrow: bool = False):
         """``encode`` of the prompts ``pre[t] + names[k] + suf[t]`` for (t, k) = (tmpl_idx[i], name_idx[i]) without building
         the strings: (ids (B, max_len), lengths, fallback) exactly as ``encode`` gives for them.  ``want_name_last``: a fourth
-        array, the position of the name's last token in each row (-1 where the row is not a plain concatenation)."""
+        array, the position of the name's last token in each row (-1 where the row is not a plain concatenation).  ``narrow``:
+        ids (B, W) with W = min(max_len, longest prompt's characters + 2) — the same rows without the padding columns nothing
+        can reach."""
         n = len(tmpl_idx)
         pb, po = pack_strings(pre)
         sb, so = pack_strings(suf)
         nb, no = names if isinstance(names, tuple) else pack_strings(names)      # (bytes, offsets) from pack_strings, or strings
         tmpl_idx = np.ascontiguousarray(tmpl_idx, dtype=np.int32)
         name_idx = np.ascontiguousarray(name_idx, dtype=np.int32)
-        ids = np.empty((n, self.max_len), dtype=np.int64)
+        # a prompt has at most one token per character: rows as wide as the longest prompt's characters + BOS / EOS hold every
+        # row whole (same ids, lengths and cuts as model_max_length-wide rows; 3 000 rows of 77 are 1.8 MB of padding to write)
+        width = self.max_len
+        if narrow and len(no) > 1 and len(pre):
+            chars = int(np.diff(po).max()) + int(np.diff(no).max()) + int(np.diff(so).max()) + 2
+            width = max(2, min(self.max_len, chars))
+        ids = np.empty((n, width), dtype=np.int64)
         lengths = np.empty(n, dtype=np.int32)
         fb = np.empty(n, dtype=np.uint8)
         name_last = np.empty(n, dtype=np.int32) if want_name_last else None
         rc = self._lib.emcid_bpe_encode_templated(self._h, pb, _ptr(po), sb, _ptr(so), len(pre), nb, _ptr(no), len(no) - 1,
-                                                  _ptr(tmpl_idx), _ptr(name_idx), n, self.bos, self.eos, self.pad, self.max_len,
+                                                  _ptr(tmpl_idx), _ptr(name_idx), n, self.bos, self.eos, self.pad, width,
                                                   _ptr(ids), _ptr(lengths), _ptr(fb), _ptr(name_last) if want_name_last else None)
         if rc < 0:
             raise RuntimeError((self._lib.emcid_host_last_error() or b"").decode())

@@ -740,6 +740,7 @@ def test_templated_prompt_path_equals_generic_path(monkeypatch):
     assert cz.templated_prompt_chunk(tok, reqs, reqs[0]) is not None        # the fast path really serves the bench shape
     both(reqs)
     both(reqs, n_chunks=3)
+    both(syn.make_requests(4500, names="syllable", name_seed=5))      # >= 4 096 names: the threaded name encoding of libemcid_host
     names = syn.syllable_names(12)
     odd = []
     for i, nm in enumerate(names):

@@ -222,7 +222,7 @@ def test_quick_gelu_vs_torch():
 
 @pytest.mark.parametrize("U,H,D,max_depth", [(300, 3, 16, None), (300, 12, 64, 9), (400, 20, 64, 15), (300, 5, 32, 16),
                                              (700, 12, 64, 6), (300, 20, 64, 7), (300, 12, 64, 2), (300, 1, 8, 4),   # <= 8 nodes
-                                             (300, 12, 64, 40)])                                                      # general kernel
+                                             (300, 12, 64, 40), (300, 20, 64, 30), (200, 24, 32, 30)])                # general kernel (3 / 5 rounds, > 20 heads)
 def test_tree_attention_vs_dense_reference(U, H, D, max_depth):
     """Random trie: every node attends to its ancestor chain; compare with per-node dense softmax in torch.
     Short chains (mass-edit prompts) and long ones, CLIP-L and bigG head shapes."""
@@ -598,16 +598,17 @@ print("SHADOW_OK", worst)
 '''
 
 
-@pytest.mark.parametrize("mode", ["2", "0"])
-def test_shadow_product_forced_and_off(mode):
+def test_shadow_product_forced_and_off():
     """The product P = Yt X riding in the Cholesky leaf launches (EMCID_SHADOW_P=2: forced for every shape, i.e. 2 / 3 / 5 / 8
     leaf launches, an odd number of column tiles, every XCD-block grid) and the path without it (=0) against the oracle; the
-    switch is read once per process, hence the child process."""
+    switch is read once per process, hence the child processes (the two side by side: most of a child's seconds are its start)."""
     import os, subprocess, sys
     from conftest import REPO
-    env = dict(os.environ, EMCID_SHADOW_P=mode)
-    r = subprocess.run([sys.executable, "-c", _SHADOW_SCRIPT, str(REPO)], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "SHADOW_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    kids = [(mode, subprocess.Popen([sys.executable, "-c", _SHADOW_SCRIPT, str(REPO)], env=dict(os.environ, EMCID_SHADOW_P=mode),
+                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)) for mode in ("2", "0")]
+    for mode, kid in kids:
+        out, err = kid.communicate(timeout=600)
+        assert kid.returncode == 0 and "SHADOW_OK" in out, (mode, out[-2000:] + err[-4000:])
 
 
 @pytest.mark.parametrize("M,K,N", [(6400, 768, 2304), (6400, 768, 768), (6400, 3072, 768), (3072, 768, 3072), (1000, 3072, 768),
