@@ -632,6 +632,139 @@ SLD_PRESETS = {     # reference :2448-2466 (the "max" / "strong" configurations 
 }
 
 
+def compute_z_text_encoder_global(pipe, request: Dict, hparams, layer: int, device=None, noise_scheduler=None,
+                                  resolution: int = 512, rng_device=None) -> torch.Tensor:
+    """Stage 1 of a GLOBAL concept (``hparams.sld_supervision``; selected at reference emcid_main.py:911-918): one vector
+    added to the output of ``layer_module_tmp.format(layer)`` at the start token (``request["source"] == "[CLS]"``) or the last
+    position (``"[EOS]"``) of EVERY prompt of ``request["source_prompts"]``, optimised so that the UNet's prediction under the
+    edited embedding follows the safe-latent-diffusion supervision — the clean prediction steered away from
+    ``request["safe_words"]`` — or the esd form (reference: emcid/compute_z.py:77-312; same arguments, same return: the mean
+    initial state at that position + delta).
+
+    Results-identical restructuring as in ``compute_z_text_encoder``: the frozen encoder is hooked in place instead of deep-copied,
+    the clean encoder forwards run once, no loss log file.  Random draws in the reference's order (image flips, the VAE
+    posterior's noise ONCE before the loop — this variant samples its latents once, :203-205 —, per step latent noise and
+    timesteps).  Training images: ``request["training_img_paths"]`` / ``request["images"]``, or one image per prompt sampled from
+    the pipeline with its seed (``request["seeds"]``, :140-146 / :159-164); the reference's ``sld_generate`` (a second,
+    safe-latent-diffusion pipeline fetched from the hub, :155) is outside this repository: ablate-dest needs the images given."""
+    from PIL import Image
+    hp = hparams
+    te = pipe.text_encoder
+    dev = next(te.parameters()).device
+    rdev = torch.device(rng_device) if rng_device is not None else dev
+    host_draw = rdev.type == "cpu" and dev.type != "cpu"
+    tok = pipe.tokenizer
+    sched = noise_scheduler if noise_scheduler is not None else default_noise_scheduler()
+    objective = hp.objective
+    if objective not in ("ablate-source", "ablate-dest", "esd"):
+        raise ValueError(f"Objective {objective} can not be used for compute_z.")
+    source_prompts = list(request["source_prompts"])
+    if request["source"] == "[CLS]":
+        edit_idx = 0
+    elif request["source"] == "[EOS]":
+        edit_idx = -1
+    else:       # the reference leaves edit_idx unbound for any other source and stops at a NameError inside the hook (:108-111, :123)
+        raise NameError("name 'edit_idx' is not defined: compute_z_text_encoder_global edits '[CLS]' or '[EOS]' only")
+    if hp.sld_type not in SLD_PRESETS:
+        raise ValueError(f"sld_type {hp.sld_type} not supported")
+    sld = {k: torch.tensor(v).to(dev) for k, v in SLD_PRESETS[hp.sld_type].items()}
+    if objective != "esd" and "training_img_paths" in request:
+        images = [Image.open(path) for path in request["training_img_paths"]]
+    elif objective != "esd" and "images" in request:
+        images = request["images"]
+    elif objective == "ablate-dest":
+        raise NotImplementedError("ablate-dest without training images samples them with the reference's sld_generate "
+                                  "(StableDiffusionPipelineSafe from the hub, compute_z.py:155): pass request['images'] or "
+                                  "request['training_img_paths']")
+    else:
+        images = []
+        for prompt, seed in zip(source_prompts, request["seeds"]):
+            gen = torch.Generator(rdev if host_draw else dev).manual_seed(int(seed)) if seed is not None else None
+            images.append(pipe([prompt], guidance_scale=7.5, generator=gen).images[0])
+    pixels = preprocess_img(images, resolution).to(dev)
+    src_inp = tokenize_prompts(source_prompts, tok, dev)
+    safe_inp = tokenize_prompts(request["safe_words"], tok, dev)
+    uncond_inp = tokenize_prompts([""] * pixels.shape[0], tok, dev)
+    if len(src_inp["input_ids"]) != len(pixels):
+        raise AssertionError("The number of prompts and images should be the same.")
+    bsz = len(pixels)
+    frozen = [prm for m in (te, pipe.vae, pipe.unet) for prm in m.parameters() if prm.requires_grad]
+    for prm in frozen:
+        prm.requires_grad_(False)
+    delta = torch.zeros((te.config.hidden_size,), requires_grad=True, device=dev)
+    opt = torch.optim.Adam([delta], lr=hp.v_lr)
+    state = {"edit": False, "source_init": None}
+
+    def hook(mod, args, out):
+        if not state["edit"]:
+            return out
+        h = out[0] if isinstance(out, tuple) else out
+        if state["source_init"] is None:
+            state["source_init"] = h[:, edit_idx].detach().clone().mean(dim=0)
+        h = h.clone()
+        for i in range(bsz):          # prompt by prompt, like the reference's hook (:126-127): autograd sums in that order
+            h[i, edit_idx, :] += delta
+        return (h,) + tuple(out[1:]) if isinstance(out, tuple) else h
+
+    handle = get_module(te, hp.layer_module_tmp.format(layer)).register_forward_hook(hook)
+    try:
+        with torch.no_grad():
+            posterior = pipe.vae.encode(pixels).latent_dist
+            latents = posterior.sample(torch.default_generator) if host_draw else posterior.sample()
+            latents = latents * pipe.vae.config.scaling_factor
+            safety_repr = te(**safe_inp)[0]
+            source_repr = te(**src_inp)[0]
+            uncond_repr = te(**uncond_inp)[0]
+        for it in range(hp.v_num_grad_steps):
+            opt.zero_grad()
+            if host_draw:
+                noise = torch.randn(latents.shape, dtype=latents.dtype).to(dev)
+                timesteps = torch.randint(0, sched.config.num_train_timesteps, (bsz,)).long().to(dev)
+            else:
+                noise = torch.randn_like(latents, device=dev)
+                timesteps = torch.randint(0, sched.config.num_train_timesteps, (bsz,), device=dev).long()
+            noisy = sched.add_noise(latents, noise, timesteps)
+            state["edit"] = True
+            try:
+                edit_repr = te(**src_inp)[0]
+            finally:
+                state["edit"] = False
+            source_init = state["source_init"]
+            with torch.no_grad():
+                pred_source = pipe.unet(noisy, timesteps, source_repr).sample
+                pred_uncond = pipe.unet(noisy, timesteps, uncond_repr).sample
+                guidance = None
+                if hp.sld_supervision:      # StableDiffusionPipelineSafe's guidance (:232-248)
+                    pred_safety = pipe.unet(noisy, timesteps, safety_repr).sample
+                    scale = torch.clamp(torch.abs(pred_source - pred_safety) * sld["sld_guidance_scale"], max=1.0)
+                    concept_scale = torch.where((pred_source - pred_safety) >= sld["sld_threshold"], torch.zeros_like(scale), scale)
+                    guidance = torch.mul(pred_safety - pred_uncond, concept_scale)
+            edit_pred = pipe.unet(noisy, timesteps, edit_repr).sample
+            decay = hp.v_weight_decay * (torch.norm(delta) / torch.norm(source_init) ** 2)
+            if "ablate" in objective:
+                if getattr(hp, "use_sampled_noise", False):
+                    mse = F.mse_loss(noise, edit_pred, reduction="mean")
+                else:
+                    if guidance is None:      # the reference's NameError (:261: noise_guidance_safety is set under sld_supervision only)
+                        raise NameError("name 'noise_guidance_safety' is not defined: compute_z_text_encoder_global needs "
+                                        "hparams.sld_supervision (or use_sampled_noise / the esd objective)")
+                    mse = F.mse_loss(edit_pred, pred_source - guidance, reduction="mean")
+            else:
+                mse = F.mse_loss(edit_pred, pred_uncond - hp.esd_mu * (pred_source - pred_uncond), reduction="mean")
+            loss = mse + decay
+            loss.backward()
+            opt.step()
+            max_norm = hp.clamp_norm_factor * source_init.norm()
+            if delta.norm() > max_norm:
+                with torch.no_grad():
+                    delta[...] = delta * max_norm / delta.norm()
+    finally:
+        handle.remove()
+        for prm in frozen:
+            prm.requires_grad_(True)
+    return (state["source_init"] + delta).detach()
+
+
 def compute_z_unet_x_kv(pipe, request: Dict, hparams, device=None, noise_scheduler=None, resolution: int = 512,
                         rng_device=None) -> Dict[str, torch.Tensor]:
     """Stage 1 of the cross-attention sibling: the target vector of EVERY ``attn2.to_k`` / ``to_v`` projection of the UNet (16
@@ -1364,10 +1497,13 @@ def stage1_for(pipe, hparams, layer: int, batch_size: Optional[int] = None, **kw
     attribute serves all misses of a request list at once (compute_z_text_encoder_batched; EMCID_STAGE1_BATCH concepts per
     Adam step, default 8; 1 = one concept at a time)."""
     new_z = bool(getattr(hparams, "use_new_compute_z", False))      # (num_edit_tokens, hidden) per concept (emcid_main.py:927-936)
+    sld = bool(getattr(hparams, "sld_supervision", False))          # the global-concept form (emcid_main.py:911-918)
 
     def stage1(request, suffix=""):
         if suffix:
             raise ValueError("a suffixed v* belongs to SDXL's second encoder: use stage1_for_sdxl (compute_z_sdxl_text_encoders)")
+        if sld:              # the reference's order of the three tests (emcid_main.py:911-936)
+            return compute_z_text_encoder_global(pipe, request, hparams, layer, **kw)
         if new_z:
             return compute_z_text_encoder_v2(pipe, request, hparams, layer, **kw)
         return compute_z_text_encoder(pipe, request, hparams, layer, **kw)
@@ -1375,6 +1511,8 @@ def stage1_for(pipe, hparams, layer: int, batch_size: Optional[int] = None, **kw
     def batch(requests, suffix=""):
         if suffix:
             raise ValueError("a suffixed v* belongs to SDXL's second encoder: use stage1_for_sdxl (compute_z_sdxl_text_encoders)")
+        if sld:
+            return [compute_z_text_encoder_global(pipe, r, hparams, layer, **kw) for r in requests]
         if new_z:
             return [compute_z_text_encoder_v2(pipe, r, hparams, layer, **kw) for r in requests]
         import os

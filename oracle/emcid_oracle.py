@@ -485,6 +485,114 @@ def compute_z_text_encoder(pipe, request: Dict, hparams: Dict, layer: int, noise
     return (state["source_init"] + delta).detach()
 
 
+SLD_PRESETS = {     # compute_z.py:174-191 (the "max" / "strong" configurations of safe latent diffusion)
+    "max": dict(sld_guidance_scale=5000, sld_warmup_steps=0, sld_threshold=1.0, sld_momentum_scale=0.5, sld_mom_beta=0.7),
+    "strong": dict(sld_guidance_scale=2000, sld_warmup_steps=7, sld_threshold=0.025, sld_momentum_scale=0.5, sld_mom_beta=0.7),
+}
+
+
+def compute_z_text_encoder_global(pipe, request: Dict, hparams: Dict, layer: int, noise_scheduler, resolution: int = 512) -> torch.Tensor:
+    """The ``sld_supervision`` Stage 1 of a global concept (compute_z.py:77-312; selected at emcid_main.py:911-918), op for op: a
+    deep copy of the encoder whose ``layer_module_tmp.format(layer)`` output gets ``delta`` added at position 0 ("[CLS]") or -1
+    ("[EOS]") of EVERY source prompt; the latents are sampled ONCE before the loop (:203-205); per step latent noise, timesteps,
+    the edited encoder forward, the clean UNet predictions under the source / unconditional / safety embeddings, the
+    safe-latent-diffusion guidance (:232-248), the edited UNet prediction, MSE + weight decay, Adam, the L2 ball.  Training
+    images: ``training_img_paths`` / ``images``, or one per prompt from the pipeline with ``request["seeds"]`` (:140-146, :159-164);
+    the reference's own sampler of ablate-dest images (``sld_generate``: a hub pipeline, :155) is not restated."""
+    from copy import deepcopy
+    import torch.nn.functional as F
+    hp = lambda k, d=None: hparams.get(k, d)
+    device = next(pipe.text_encoder.parameters()).device
+    te_edit = deepcopy(pipe.text_encoder).to(device)
+    source_prompts = request["source_prompts"]
+    delta = torch.zeros((te_edit.config.hidden_size,), requires_grad=True, device=device)
+    state = {"source_init": None}
+    if request["source"] == "[CLS]":
+        edit_idx = 0
+    elif request["source"] == "[EOS]":
+        edit_idx = -1
+    else:
+        raise NameError("name 'edit_idx' is not defined")       # the reference's hook stops there (:108-111, :123)
+    opt = torch.optim.Adam([delta], lr=hp("v_lr"))
+    for m in (te_edit, pipe.vae, pipe.unet, pipe.text_encoder):
+        for prm in m.parameters():
+            prm.requires_grad = False
+    objective = hp("objective")
+    if objective not in ("ablate-source", "ablate-dest", "esd"):
+        raise ValueError(f"Objective {objective} can not be used for compute_z.")
+    if objective != "esd" and "training_img_paths" in request:
+        from PIL import Image
+        imgs = [Image.open(path) for path in request["training_img_paths"]]
+    elif objective != "esd" and "images" in request:
+        imgs = request["images"]
+    elif objective == "ablate-dest":
+        raise NotImplementedError("sld_generate (compute_z.py:155) is not restated: pass the training images")
+    else:
+        imgs = []
+        for prompt, seed in zip(source_prompts, request["seeds"]):
+            generator = torch.Generator(device).manual_seed(int(seed)) if seed is not None else None
+            imgs.append(pipe([prompt], guidance_scale=7.5, generator=generator).images[0])
+    img_batch = preprocess_img(imgs, resolution).to(device)
+    src_inp = tokenize_prompts(source_prompts, pipe.tokenizer, device)
+    safe_inp = tokenize_prompts(request["safe_words"], pipe.tokenizer, device)
+    uncond_inp = tokenize_prompts([""] * img_batch.shape[0], pipe.tokenizer, device)
+    assert len(src_inp["input_ids"]) == len(img_batch), "The number of prompts and images should be the same."
+    bsz = len(img_batch)
+    if hp("sld_type", "max") not in SLD_PRESETS:
+        raise ValueError(f"sld_type {hp('sld_type')} not supported")
+    sld = {k: torch.tensor(v).to(device) for k, v in SLD_PRESETS[hp("sld_type", "max")].items()}
+    with torch.no_grad():
+        latents = pipe.vae.encode(img_batch).latent_dist.sample() * pipe.vae.config.scaling_factor
+        safety_repr = pipe.text_encoder(**safe_inp)[0]
+        source_repr = pipe.text_encoder(**src_inp)[0]
+        uncond_repr = pipe.text_encoder(**uncond_inp)[0]
+
+    def hook(mod, args, out):
+        h = _hidden(out)
+        if state["source_init"] is None:
+            state["source_init"] = h[:, edit_idx].detach().clone().mean(dim=0)
+        for i in range(bsz):
+            h[i, edit_idx, :] += delta
+        return out
+
+    handle = get_module(te_edit, hparams["layer_module_tmp"].format(layer)).register_forward_hook(hook)
+    try:
+        for it in range(hp("v_num_grad_steps")):
+            opt.zero_grad()
+            noise = torch.randn_like(latents, device=device)
+            timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (bsz,), device=device).long()
+            noisy = noise_scheduler.add_noise(latents, noise, timesteps)
+            edit_repr = te_edit(**src_inp)[0]
+            with torch.no_grad():
+                pred_source = pipe.unet(noisy, timesteps, source_repr).sample
+                pred_uncond = pipe.unet(noisy, timesteps, uncond_repr).sample
+                if hp("sld_supervision", False):
+                    pred_safety = pipe.unet(noisy, timesteps, safety_repr).sample
+                    scale = torch.clamp(torch.abs((pred_source - pred_safety)) * sld["sld_guidance_scale"], max=1.0)
+                    concept_scale = torch.where((pred_source - pred_safety) >= sld["sld_threshold"], torch.zeros_like(scale), scale)
+                    guidance = torch.mul((pred_safety - pred_uncond), concept_scale)
+            edit_pred = pipe.unet(noisy, timesteps, edit_repr).sample
+            source_init = state["source_init"]
+            if "ablate" in objective:
+                if hp("use_sampled_noise", False):
+                    mse = F.mse_loss(noise, edit_pred, reduction="mean")
+                else:
+                    mse = F.mse_loss(edit_pred, pred_source - guidance, reduction="mean")
+                loss = mse + hp("v_weight_decay") * (torch.norm(delta) / torch.norm(source_init) ** 2)
+            else:
+                tmp = pred_uncond - hp("esd_mu") * (pred_source - pred_uncond)
+                loss = F.mse_loss(edit_pred, tmp, reduction="mean") + hp("v_weight_decay") * (torch.norm(delta) / torch.norm(source_init) ** 2)
+            loss.backward()
+            opt.step()
+            max_norm = hp("clamp_norm_factor") * source_init.norm()
+            if delta.norm() > max_norm:
+                with torch.no_grad():
+                    delta[...] = delta * max_norm / delta.norm()
+    finally:
+        handle.remove()
+    return (state["source_init"] + delta).detach()
+
+
 def compute_z_text_encoder_v2(pipe, request: Dict, hparams: Dict, layer: int, noise_scheduler, resolution: int = 512) -> torch.Tensor:
     """The ``use_new_compute_z`` Stage 1 (compute_z.py:1041-1357), op for op: ``num_edit_tokens`` vectors per concept — the
     last subject token, then (k >= 2) the EOS token and the k - 2 padding positions behind it, the prompts re-tokenized to

@@ -272,6 +272,55 @@ def golden_stage1_more(cz, EMCIDHyperParams, scratch, tag="toy_stage1_more"):
     print(f"[golden] {tag}: wrote {len(out)} arrays: " + ", ".join(f"{k}: |v*| {np.linalg.norm(out[k + '/v_star']):.4f}" for k in STAGE1_MORE_CASES))
 
 
+GLOBAL_STAGE1_CASES = {
+    # the sld_supervision Stage 1 of a global concept (compute_z.py:77-312): "[CLS]" with images sampled from the pipeline by
+    # per-prompt seeds ("max" preset), "[EOS]" with training images read from disk ("strong" preset, ablate-dest), and the esd form
+    "sld_max_cls": dict(hp=dict(objective="ablate-source", sld_supervision=True, sld_type="max", v_lr=0.05, v_weight_decay=5e-4,
+                                clamp_norm_factor=1.5, v_num_grad_steps=8), layer=3, seed=911, source="[CLS]", files=False),
+    "sld_strong_eos_files": dict(hp=dict(objective="ablate-dest", sld_supervision=True, sld_type="strong", v_lr=0.1, v_weight_decay=1e-3,
+                                         clamp_norm_factor=0.8, v_num_grad_steps=7), layer=2, seed=17, source="[EOS]", files=True),
+    "esd_cls": dict(hp=dict(objective="esd", esd_mu=1.0, sld_supervision=True, sld_type="max", v_lr=0.02, v_weight_decay=5e-4,
+                            clamp_norm_factor=1.2, v_num_grad_steps=6), layer=4, seed=5, source="[CLS]", files=False),
+}
+
+
+def golden_stage1_global(cz, EMCIDHyperParams, scratch, tag="toy_stage1_global"):
+    """The REAL reference's compute_z_text_encoder_global (compute_z.py:77-312; emcid_main.py:911-918 selects it under
+    ``sld_supervision``) on the synthetic pipe: UNet / VAE stand-ins, DDPM schedule stub; training images sampled by the reference
+    itself through ``pipe([prompt], generator=seeded)`` or read from PNG files it is pointed at."""
+    (scratch / "log").mkdir(exist_ok=True)
+    out, meta = {}, {"cases": {}, "resolution": STAGE1_RESOLUTION}
+    prompts = ["painting of tocife", "a photo by bamilo", "style of c0042"]
+    for name, c in GLOBAL_STAGE1_CASES.items():
+        pipe = syn.add_diffusion(syn.build_pipe("toy", "cpu"))
+        pipe.image_resolution = STAGE1_RESOLUTION
+        as_transformers_427(pipe.text_encoder)
+        hp_d = syn.sd_hparams_dict(layers=(1, 2, 3, 4), prefix="")
+        hp_d.update(c["hp"])
+        hp = EMCIDHyperParams(**hp_d)
+        request = {"source": c["source"], "dest": " ", "source_prompts": prompts, "safe_words": ["tocife", "bamilo, c0042", "artwork"],
+                   "seeds": [3, 14, 15], "indices": [0, 1, 2], "prompts": [], "seed_train": 2024}
+        run_req = dict(request)
+        if c["files"]:
+            imgs = syn.make_images(len(prompts), STAGE1_RESOLUTION, seed=31 + c["seed"])
+            paths = []
+            for i, im in enumerate(imgs):
+                f = scratch / f"global_{name}_{i}.png"
+                im.save(f)
+                paths.append(str(f))
+            run_req["training_img_paths"] = paths
+            out[f"{name}/images"] = np.stack([np.asarray(im) for im in imgs])
+        torch.manual_seed(c["seed"])
+        with contextlib.redirect_stdout(io.StringIO()):
+            v = cz.compute_z_text_encoder_global(pipe, run_req, hp, c["layer"], device="cpu")
+        out[f"{name}/v_star"] = v.detach().numpy()
+        meta["cases"][name] = {"hparams": hp_d, "layer": c["layer"], "seed": c["seed"], "request": request, "files": c["files"]}
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump(meta, f, indent=1)
+    print(f"[golden] {tag}: wrote {len(out)} arrays: " + ", ".join(f"{k}: |v*| {np.linalg.norm(out[k + '/v_star']):.4f}" for k in GLOBAL_STAGE1_CASES))
+
+
 XATTN_STAGE1_CASES = {
     # safe-latent-diffusion supervision with the request's own safe words ("max" preset), the esd supervision with replace_repr,
     # and the "strong" preset over the built-in list of safety concepts
@@ -971,6 +1020,8 @@ def main():
                 golden_stage1_sdxl(cz, XLHP, scratch)
             elif which == "toy_stage1_more":
                 golden_stage1_more(cz, HP, scratch)
+            elif which == "toy_stage1_global":
+                golden_stage1_global(cz, HP, scratch)
             elif which == "toy_xattn_stage1":
                 golden_xattn_stage1(cz, HP, scratch)
             elif which == "toy_multi_token":
@@ -990,6 +1041,7 @@ def main():
         golden_stage1(cz, HP, scratch)
         golden_stage1_sdxl(cz, XLHP, scratch)
         golden_stage1_more(cz, HP, scratch)
+        golden_stage1_global(cz, HP, scratch)
         golden_xattn_stage1(cz, HP, scratch)
         golden_multi_token(em, HP, scratch)
         if "--skip-real" not in sys.argv:

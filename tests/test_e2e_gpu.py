@@ -1042,6 +1042,32 @@ def test_stage1_on_gpu_matches_reference_golden(name):
     assert v.is_cuda and np.abs(v.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("name", ["sld_max_cls", "sld_strong_eos_files", "esd_cls"])
+def test_stage1_global_on_gpu_matches_reference_golden(name, tmp_path):
+    """The ``sld_supervision`` Stage 1 (compute_z_text_encoder_global, reference compute_z.py:77-312) on the MI355X with the
+    random draws taken from the host generator in the reference's order: the REAL reference's v* (minted on CPU) to fp32
+    rounding."""
+    from PIL import Image
+    from emcid_amd.compute_z import compute_z_text_encoder_global
+    z, meta = load_golden("toy_stage1_global")
+    c = meta["cases"][name]
+    pipe = syn.add_diffusion(syn.build_pipe("toy", DEV))
+    pipe.image_resolution = meta["resolution"]
+    request = dict(c["request"])
+    if c["files"]:
+        paths = []
+        for i, a in enumerate(z[f"{name}/images"]):
+            f = tmp_path / f"{name}_{i}.png"
+            Image.fromarray(a, "RGB").save(f)
+            paths.append(str(f))
+        request["training_img_paths"] = paths
+    torch.manual_seed(c["seed"])
+    v = compute_z_text_encoder_global(pipe, request, EMCIDHyperParams(**c["hparams"]), c["layer"],
+                                      noise_scheduler=syn.DDPMNoiseSchedule(), resolution=meta["resolution"], rng_device="cpu")
+    ref = z[f"{name}/v_star"]
+    assert v.is_cuda and np.abs(v.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
 def test_vstar_cache_miss_runs_stage1_then_edits(tmp_path):
     """A v* cache miss on a pipeline that carries a UNet and a VAE runs Stage 1 and writes the npz (reference
     emcid_main.py:905-969); the edit that follows equals an edit from that cache."""

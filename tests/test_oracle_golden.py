@@ -189,6 +189,51 @@ def test_stage1_v_star_matches_reference(name):
     assert all(p.requires_grad is False for p in pipe.text_encoder.parameters())      # synthetic encoders are frozen: left as found
 
 
+def _stage1_global_case(z, meta, name, tmp_path, device="cpu"):
+    from PIL import Image
+    c = meta["cases"][name]
+    pipe = syn.add_diffusion(syn.build_pipe("toy", device))
+    pipe.image_resolution = meta["resolution"]
+    request = dict(c["request"])
+    if c["files"]:          # the reference read its training images from PNG files: the same pixels, written out again
+        paths = []
+        for i, a in enumerate(z[f"{name}/images"]):
+            f = tmp_path / f"{name}_{i}.png"
+            Image.fromarray(a, "RGB").save(f)
+            paths.append(str(f))
+        request["training_img_paths"] = paths
+    return c, pipe, request
+
+
+@pytest.mark.parametrize("name", ["sld_max_cls", "sld_strong_eos_files", "esd_cls"])
+def test_stage1_global_v_star_matches_reference(name, tmp_path):
+    """The ``sld_supervision`` Stage 1 of a global concept (compute_z_text_encoder_global, compute_z.py:77-312; selected at
+    emcid_main.py:911-918): the oracle's op-for-op restatement reproduces the REAL reference's v* bit for bit (fixture
+    toy_stage1_global: "[CLS]" / "[EOS]", images sampled by per-prompt seeds or read from files, the "max" / "strong" presets, the
+    esd form); the product's loop (hooked in place, clean forwards hoisted) agrees to fp32 rounding."""
+    from emcid_amd.compute_z import compute_z_text_encoder_global, stage1_for
+    z, meta = load_golden("toy_stage1_global")
+    ref = z[f"{name}/v_star"]
+    c, pipe, request = _stage1_global_case(z, meta, name, tmp_path)
+    torch.manual_seed(c["seed"])
+    v = orc.compute_z_text_encoder_global(pipe, request, c["hparams"], c["layer"], syn.DDPMNoiseSchedule(), meta["resolution"])
+    np.testing.assert_array_equal(v.numpy(), ref)
+    c, pipe, request = _stage1_global_case(z, meta, name, tmp_path)
+    torch.manual_seed(c["seed"])
+    v = compute_z_text_encoder_global(pipe, request, EMCIDHyperParams(**c["hparams"]), c["layer"],
+                                      noise_scheduler=syn.DDPMNoiseSchedule(), resolution=meta["resolution"])
+    assert np.abs(v.numpy() - ref).max() <= 2e-6 * np.abs(ref).max()
+    # the dispatch of a v* cache miss (emcid_main.py:911-918: sld_supervision first) reaches the same function
+    c, pipe, request = _stage1_global_case(z, meta, name, tmp_path)
+    torch.manual_seed(c["seed"])
+    v2 = stage1_for(pipe, EMCIDHyperParams(**c["hparams"]), c["layer"], noise_scheduler=syn.DDPMNoiseSchedule(),
+                    resolution=meta["resolution"])(request)
+    assert torch.equal(v2, v)
+    with pytest.raises(NameError):          # any other source leaves the reference's edit_idx unbound (:108-111)
+        compute_z_text_encoder_global(pipe, dict(request, source="tocife"), EMCIDHyperParams(**c["hparams"]), c["layer"],
+                                      noise_scheduler=syn.DDPMNoiseSchedule(), resolution=meta["resolution"])
+
+
 def _multi_token_case(z, meta, tmp_path, device="cpu"):
     from PIL import Image
     te = pipe_from_golden(z, meta["kind"], device=device)
