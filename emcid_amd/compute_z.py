@@ -765,6 +765,161 @@ def compute_z_text_encoder_global(pipe, request: Dict, hparams, layer: int, devi
     return (state["source_init"] + delta).detach()
 
 
+CLIP_HUB_ID = "openai/clip-vit-large-patch14"      # reference compute_z.py:1376
+
+
+def default_clip_towers():
+    """(text tower with projection, vision tower with projection, processor) of the hub checkpoint the reference's
+    compute_z_text_encoder_v1 loads (compute_z.py:1376-1378, :1440): needs the files (no network here -> OSError)."""
+    from transformers import CLIPProcessor, CLIPTextModelWithProjection, CLIPVisionModelWithProjection
+    return (CLIPTextModelWithProjection.from_pretrained(CLIP_HUB_ID), CLIPVisionModelWithProjection.from_pretrained(CLIP_HUB_ID),
+            CLIPProcessor.from_pretrained(CLIP_HUB_ID))
+
+
+def compute_z_text_encoder_v1(pipe, request: Dict, hparams, layer: int, device=None, noise_scheduler=None,
+                              resolution: int = 512, rng_device=None, clip_towers=None) -> torch.Tensor:
+    """The ``txt_img_align_scale_factor != 0`` Stage 1 (reference: emcid/compute_z.py:1360-1648; selected at
+    emcid_main.py:919-926): as ``compute_z_text_encoder``, but the edited encoder is CLIP's text tower WITH its projection
+    (``clip_towers[0]``; the reference loads openai/clip-vit-large-patch14, whose text tower is SD-v1.x's encoder), the
+    text-alignment terms live in the projected space (``text_embeds`` against the projected pooled output of the destination
+    prompts), and — ``request["txt_img_align"]`` — the projected text embedding is pulled towards the CLIP image embedding of the
+    training images (``clip_towers[1]`` through ``clip_towers[2]``; "cos" or "l2", ablate-dest only as in the reference, where
+    any other objective stops at a NameError on ``dest_img_emb``).  The latents are sampled ONCE before the loop (:1483-1485);
+    one image per prompt (no ``samples_per_prompt``).  ``clip_towers``: default ``default_clip_towers()`` (hub files).
+
+    Restructured like the other forms (results identical): hooked in place — the tower is the caller's, restored afterwards —,
+    clean forwards hoisted, no loss log; random draws in the reference's order (pipeline sampling by ``seed_train``, image
+    flips, VAE posterior noise once, per step latent noise and timesteps)."""
+    from PIL import Image
+    hp = hparams
+    te = pipe.text_encoder
+    dev = next(te.parameters()).device
+    rdev = torch.device(rng_device) if rng_device is not None else dev
+    host_draw = rdev.type == "cpu" and dev.type != "cpu"
+    tok = pipe.tokenizer
+    sched = noise_scheduler if noise_scheduler is not None else default_noise_scheduler()
+    text_proj, vision_proj, processor = clip_towers if clip_towers is not None else default_clip_towers()
+    text_proj = text_proj.to(dev)
+    objective = hp.objective
+    if objective not in ("ablate-source", "ablate-dest", "esd"):
+        raise ValueError(f"Objective {objective} can not be used for compute_z.")
+    align_img = bool(request["txt_img_align"])                     # (KeyError without the field, like the reference :1436)
+    source_prompts = [p.format(request["source"]) for p in request["prompts"]]
+    dest_prompts = ["" for _ in request["prompts"]] if objective == "esd" else [p.format(request["dest"]) for p in request["prompts"]]
+    if objective != "esd" and "training_img_paths" in request:
+        images = [Image.open(path) for path in request["training_img_paths"]]
+    elif objective != "esd" and "images" in request:
+        images = request["images"]
+    else:
+        gen = torch.Generator(rdev if host_draw else dev).manual_seed(int(request["seed_train"])) if request["seed_train"] is not None else None
+        images = pipe(dest_prompts if objective == "ablate-dest" else source_prompts, guidance_scale=7.5, generator=gen).images
+    dest_img_emb = None
+    if objective == "ablate-dest" and align_img:
+        with torch.no_grad():
+            vision_proj = vision_proj.to(dev)
+            img_inp = processor(images=images, return_tensors="pt").to(dev)
+            dest_img_emb = vision_proj(**img_inp).image_embeds
+    pixels = preprocess_img(images, resolution).to(dev)
+    src_inp, dst_inp = tokenize_prompts(source_prompts, tok, dev), tokenize_prompts(dest_prompts, tok, dev)
+    finder = finder_for(tok)
+    src_lookup = [finder(ids, request["source"])[-1] - 1 for ids in src_inp["input_ids"].tolist()]
+    dst_lookup = [finder(ids, request["dest"])[-1] - 1 for ids in dst_inp["input_ids"].tolist()]
+    if not (len(src_inp["input_ids"]) == len(dst_inp["input_ids"]) == len(pixels)):
+        raise AssertionError("The number of prompts and images should be the same.")
+    bsz = len(pixels)
+    ar = torch.arange(bsz, device=dev)
+    src_idx, dst_idx = torch.tensor(src_lookup, device=dev), torch.tensor(dst_lookup, device=dev)
+    fim = load_fim(dev) if getattr(hp, "use_ewc", False) else None
+    frozen = [prm for m in (text_proj, te, pipe.vae, pipe.unet) for prm in m.parameters() if prm.requires_grad]
+    for prm in frozen:
+        prm.requires_grad_(False)
+    delta = torch.zeros((text_proj.config.hidden_size,), requires_grad=True, device=dev)
+    opt = torch.optim.Adam([delta], lr=hp.v_lr)
+    state = {"source_init": None}
+
+    def hook(mod, args, out):
+        h = out[0] if isinstance(out, tuple) else out
+        if state["source_init"] is None:
+            state["source_init"] = h[0, src_lookup[0]].detach().clone()
+        h = h.clone()
+        for i, idx in enumerate(src_lookup):          # prompt by prompt (:1412-1417): autograd sums delta's gradient in that order
+            if hp.replace_repr:
+                h[i, idx, :] = delta
+            else:
+                h[i, idx, :] += delta
+        return (h,) + tuple(out[1:]) if isinstance(out, tuple) else h
+
+    handle = get_module(text_proj, hp.layer_module_tmp.format(layer)).register_forward_hook(hook)
+    try:
+        with torch.no_grad():
+            posterior = pipe.vae.encode(pixels).latent_dist
+            latents = posterior.sample(torch.default_generator) if host_draw else posterior.sample()
+            latents = latents * pipe.vae.config.scaling_factor
+            out_d = te(**dst_inp)
+            dest_repr, dest_pool = out_d[0], out_d[1]
+            dest_emb = text_proj.text_projection(dest_pool)
+            source_repr = te(**src_inp)[0] if (objective == "esd" or hp.cal_text_repr_loss) else None
+            if hp.cal_text_repr_loss and hp.contrastive_text_loss:
+                neg_emb = text_proj.text_projection(te(**tokenize_prompts(request["negative_prompts"], tok, dev))[1])
+                single_emb = text_proj.text_projection(te(**tokenize_prompts([request["dest"]], tok, dev))[1])
+        for it in range(hp.v_num_grad_steps):
+            opt.zero_grad()
+            if host_draw:
+                noise = torch.randn(latents.shape, dtype=latents.dtype).to(dev)
+                timesteps = torch.randint(0, sched.config.num_train_timesteps, (bsz,)).long().to(dev)
+            else:
+                noise = torch.randn_like(latents, device=dev)
+                timesteps = torch.randint(0, sched.config.num_train_timesteps, (bsz,), device=dev).long()
+            noisy = sched.add_noise(latents, noise, timesteps)
+            out_e = text_proj(**src_inp)
+            edit_repr, edit_emb = out_e.last_hidden_state, out_e.text_embeds
+            source_init = state["source_init"]
+            edit_pred = pipe.unet(noisy, timesteps, edit_repr).sample
+            with torch.no_grad():
+                pred_dest = pipe.unet(noisy, timesteps, dest_repr).sample
+            decay = hp.v_weight_decay * (torch.norm(delta) / torch.norm(source_init) ** 2)
+            if "ablate" in objective:
+                mse = F.mse_loss(noise, edit_pred, reduction="mean") if getattr(hp, "use_sampled_noise", False) \
+                    else F.mse_loss(edit_pred, pred_dest, reduction="mean")
+                reg = float(hp.ewc_lambda) * torch.sum(fim * delta ** 2) / (2 * torch.norm(source_init) ** 2) if fim is not None else decay
+                loss = mse + reg
+            else:
+                with torch.no_grad():
+                    pred_source = pipe.unet(noisy, timesteps, source_repr).sample
+                loss = F.mse_loss(edit_pred, pred_dest - hp.esd_mu * (pred_source - pred_dest), reduction="mean") + decay
+            if hp.cal_text_repr_loss and objective != "esd":
+                scale = hp.text_repr_loss_scale_factor
+                if hp.contrastive_text_loss:
+                    emb = torch.cat([single_emb, neg_emb], dim=0)
+                    scores = torch.squeeze(-torch.cdist(edit_emb.unsqueeze(0), emb.unsqueeze(0)))
+                    loss = loss + scale * (-torch.log_softmax(scores, dim=1)[:, 0].mean(dim=0))
+                elif hp.align_object_token:
+                    loss = loss + scale * F.mse_loss(edit_repr[ar, src_idx, :], dest_repr[ar, dst_idx, :], reduction="mean")
+                else:
+                    loss = loss + scale * F.mse_loss(edit_emb, dest_emb, reduction="mean")
+            if align_img:
+                if dest_img_emb is None:          # the reference's NameError (:1441 defines it for ablate-dest only)
+                    raise NameError("name 'dest_img_emb' is not defined: txt_img_align needs the ablate-dest objective")
+                if hp.txt_img_align_loss_metric == "cos":
+                    align = -(F.cosine_similarity(edit_emb, dest_img_emb, dim=1).mean() - 1)
+                elif hp.txt_img_align_loss_metric == "l2":
+                    align = F.mse_loss(edit_emb, dest_img_emb, reduction="mean")
+                else:
+                    raise ValueError(f"txt_img_align_loss_metric {hp.txt_img_align_loss_metric} not supported")
+                loss = loss + hp.txt_img_align_scale_factor * align
+            loss.backward()
+            opt.step()
+            max_norm = hp.clamp_norm_factor * source_init.norm()
+            if delta.norm() > max_norm:
+                with torch.no_grad():
+                    delta[...] = delta * max_norm / delta.norm()
+    finally:
+        handle.remove()
+        for prm in frozen:
+            prm.requires_grad_(True)
+    return (state["source_init"] + delta).detach()
+
+
 def compute_z_unet_x_kv(pipe, request: Dict, hparams, device=None, noise_scheduler=None, resolution: int = 512,
                         rng_device=None) -> Dict[str, torch.Tensor]:
     """Stage 1 of the cross-attention sibling: the target vector of EVERY ``attn2.to_k`` / ``to_v`` projection of the UNet (16
@@ -1491,19 +1646,22 @@ def _stage1_optimise_group(pipe, te, mod, hp, members, steps, dev, fim=None):
         c.pop("draws", None)
 
 
-def stage1_for(pipe, hparams, layer: int, batch_size: Optional[int] = None, **kw):
+def stage1_for(pipe, hparams, layer: int, batch_size: Optional[int] = None, clip_towers=None, **kw):
     """The ``stage1=`` callable emcid_main's v* cache expects (``stage1(request, suffix) -> v*``) for a pipeline that carries
     a UNet and a VAE: Stage 1 on a cache miss, like the reference (emcid_main.py:905-969).  Its ``batch(requests, suffix)``
     attribute serves all misses of a request list at once (compute_z_text_encoder_batched; EMCID_STAGE1_BATCH concepts per
     Adam step, default 8; 1 = one concept at a time)."""
     new_z = bool(getattr(hparams, "use_new_compute_z", False))      # (num_edit_tokens, hidden) per concept (emcid_main.py:927-936)
     sld = bool(getattr(hparams, "sld_supervision", False))          # the global-concept form (emcid_main.py:911-918)
+    v1 = getattr(hparams, "txt_img_align_scale_factor", 0) != 0     # the projected-space form with CLIP's towers (emcid_main.py:919-926)
 
     def stage1(request, suffix=""):
         if suffix:
             raise ValueError("a suffixed v* belongs to SDXL's second encoder: use stage1_for_sdxl (compute_z_sdxl_text_encoders)")
         if sld:              # the reference's order of the three tests (emcid_main.py:911-936)
             return compute_z_text_encoder_global(pipe, request, hparams, layer, **kw)
+        if v1:
+            return compute_z_text_encoder_v1(pipe, request, hparams, layer, clip_towers=clip_towers, **kw)
         if new_z:
             return compute_z_text_encoder_v2(pipe, request, hparams, layer, **kw)
         return compute_z_text_encoder(pipe, request, hparams, layer, **kw)
@@ -1511,8 +1669,8 @@ def stage1_for(pipe, hparams, layer: int, batch_size: Optional[int] = None, **kw
     def batch(requests, suffix=""):
         if suffix:
             raise ValueError("a suffixed v* belongs to SDXL's second encoder: use stage1_for_sdxl (compute_z_sdxl_text_encoders)")
-        if sld:
-            return [compute_z_text_encoder_global(pipe, r, hparams, layer, **kw) for r in requests]
+        if sld or v1:
+            return [stage1(r, suffix) for r in requests]
         if new_z:
             return [compute_z_text_encoder_v2(pipe, r, hparams, layer, **kw) for r in requests]
         import os

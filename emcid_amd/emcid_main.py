@@ -534,14 +534,12 @@ def _default_stage1(pipe, hparams, stage1):
     """Stage 1 on a v* cache miss, like the reference (:905-969): when the caller gave no ``stage1=`` and the pipeline
     carries a UNet and a VAE, the missing v* is optimised by compute_z.compute_z_text_encoder at z_layer =
     hparams.layers[-1] (:868) and written to the cache — by compute_z_text_encoder_global under ``sld_supervision`` (:911-918:
-    a global concept at "[CLS]" / "[EOS]" under the safe-latent-diffusion supervision), by compute_z_text_encoder_v2,
-    (num_edit_tokens, hidden) per concept, under ``use_new_compute_z`` (:927-936).  Not built: the variant that fetches its own
-    hub checkpoints (``txt_img_align_scale_factor != 0`` -> compute_z_text_encoder_v1 with openai/clip-vit-large-patch14's text
-    and vision towers, :919-926; no shipped hparams file sets it): a miss then raises load_v_stars' NotImplementedError."""
+    a global concept at "[CLS]" / "[EOS]" under the safe-latent-diffusion supervision), by compute_z_text_encoder_v1 when
+    ``txt_img_align_scale_factor != 0`` (:919-926: CLIP's text tower with projection + the image-alignment term; its towers come
+    from the hub like the reference's — ``stage1=compute_z.stage1_for(pipe, hparams, layer, clip_towers=...)`` hands over local
+    ones), by compute_z_text_encoder_v2, (num_edit_tokens, hidden) per concept, under ``use_new_compute_z`` (:927-936)."""
     if stage1 is not None or getattr(pipe, "unet", None) is None or getattr(pipe, "vae", None) is None:
         return stage1
-    if getattr(hparams, "txt_img_align_scale_factor", 0) != 0 and not getattr(hparams, "sld_supervision", False):
-        return None
     from .compute_z import stage1_for
     return stage1_for(pipe, hparams, hparams.layers[-1])
 

@@ -250,6 +250,36 @@ def build_pipe(kind: str = "toy", device: str = "cpu", sdxl: bool = False, seed:
                          text_encoder_2=te2.to(device), tokenizer_2=build_tokenizer(vocab, merges))
 
 
+def build_clip_towers(pipe: "SyntheticPipe", projection_dim: int = 16, seed: int = 7, image_size: int = 32):
+    """Stand-ins for what the reference's compute_z_text_encoder_v1 fetches from the hub (openai/clip-vit-large-patch14,
+    emcid/compute_z.py:1376-1378, :1440): (CLIPTextModelWithProjection whose text tower carries ``pipe.text_encoder``'s weights —
+    the hub checkpoint's text tower IS SD-v1.x's encoder —, a small seeded CLIPVisionModelWithProjection, a CLIPProcessor for
+    ``image_size`` images).  Offline: built from configs, no files."""
+    from transformers import (CLIPImageProcessor, CLIPProcessor, CLIPTextConfig, CLIPTextModelWithProjection, CLIPVisionConfig,
+                              CLIPVisionModelWithProjection)
+    te = pipe.text_encoder
+    cfg = te.config.to_dict()
+    cfg["projection_dim"] = projection_dim
+    gen_state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    text = CLIPTextModelWithProjection(CLIPTextConfig(**cfg)).eval()
+    hidden = int(te.config.hidden_size)
+    vision = CLIPVisionModelWithProjection(CLIPVisionConfig(hidden_size=hidden, intermediate_size=2 * hidden, num_hidden_layers=2,
+                                                            num_attention_heads=2, image_size=image_size, patch_size=8,
+                                                            projection_dim=projection_dim)).eval()
+    torch.random.set_rng_state(gen_state)
+    inner = text.text_model if hasattr(text, "text_model") else text
+    src = te.text_model if hasattr(te, "text_model") else te
+    inner.load_state_dict({k: v.detach().cpu() for k, v in src.state_dict().items()}, strict=True)
+    for m in (text, vision):
+        for prm in m.parameters():
+            prm.requires_grad_(False)
+    proc = CLIPProcessor(image_processor=CLIPImageProcessor(size={"shortest_edge": image_size},
+                                                            crop_size={"height": image_size, "width": image_size}),
+                         tokenizer=pipe.tokenizer)
+    return text, vision, proc
+
+
 # ---- cross-attention K/V stand-in for the UNet -------------------------------------------------------------------
 # Channel widths of the 16 cross-attention blocks: SD-v1.4 [external: its UNet config], and a toy set.  The tree of
 # module NAMES is what the reference addresses (util/globals.py:37-38 through emcid/layer_stats.py:470-495).

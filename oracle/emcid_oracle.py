@@ -593,6 +593,135 @@ def compute_z_text_encoder_global(pipe, request: Dict, hparams: Dict, layer: int
     return (state["source_init"] + delta).detach()
 
 
+def compute_z_text_encoder_v1(pipe, request: Dict, hparams: Dict, layer: int, noise_scheduler, clip_towers, resolution: int = 512) -> torch.Tensor:
+    """The ``txt_img_align_scale_factor != 0`` Stage 1 (compute_z.py:1360-1648; selected at emcid_main.py:919-926), op for op.
+    ``clip_towers`` = (CLIPTextModelWithProjection, CLIPVisionModelWithProjection, CLIPProcessor): what the reference loads from
+    the hub (openai/clip-vit-large-patch14, :1376-1378, :1440).  The hooked model is the text tower with projection; the latents are
+    sampled once before the loop (:1483-1485); text-alignment terms in the projected space; the image-alignment term against the
+    CLIP embedding of the training images (ablate-dest)."""
+    import torch.nn.functional as F
+    hp = lambda k, d=None: hparams.get(k, d)
+    device = next(pipe.text_encoder.parameters()).device
+    te_edit, vision, processor = clip_towers
+    te_edit = te_edit.to(device)
+    tok = pipe.tokenizer
+    source_prompts = [p.format(request["source"]) for p in request["prompts"]]
+    objective = hp("objective")
+    dest_prompts = ["" for _ in request["prompts"]] if objective == "esd" else [p.format(request["dest"]) for p in request["prompts"]]
+    delta = torch.zeros((te_edit.config.hidden_size,), requires_grad=True, device=device)
+    state = {"source_init": None}
+    opt = torch.optim.Adam([delta], lr=hp("v_lr"))
+    for m in (te_edit, pipe.vae, pipe.unet, pipe.text_encoder):
+        for prm in m.parameters():
+            prm.requires_grad = False
+    generator = torch.Generator(device).manual_seed(int(request["seed_train"])) if request["seed_train"] is not None else None
+    if objective not in ("ablate-source", "ablate-dest", "esd"):
+        raise ValueError(f"Objective {objective} can not be used for compute_z.")
+    if objective != "esd" and "training_img_paths" in request:
+        from PIL import Image
+        imgs = [Image.open(path) for path in request["training_img_paths"]]
+    elif objective != "esd" and "images" in request:
+        imgs = request["images"]
+    else:
+        imgs = pipe(dest_prompts if objective == "ablate-dest" else source_prompts, guidance_scale=7.5, generator=generator).images
+    if objective == "ablate-dest" and request["txt_img_align"]:
+        with torch.no_grad():
+            vision = vision.to(device)
+            img_inp = processor(images=imgs, return_tensors="pt").to(device)
+            dest_img_emb = vision(**img_inp).image_embeds
+    img_batch = preprocess_img(imgs, resolution).to(device)
+    src_inp = tokenize_prompts(source_prompts, tok, device)
+    dst_inp = tokenize_prompts(dest_prompts, tok, device)
+    if hp("contrastive_text_loss", False):
+        neg_inp = tokenize_prompts(request["negative_prompts"], tok, device)
+    src_lookup = [find_token_range(tok, ids, request["source"])[-1] - 1 for ids in src_inp["input_ids"]]
+    dst_lookup = [find_token_range(tok, ids, request["dest"])[-1] - 1 for ids in dst_inp["input_ids"]]
+    assert len(src_inp["input_ids"]) == len(dst_inp["input_ids"]) == len(img_batch)
+    bsz = len(img_batch)
+    with torch.no_grad():
+        latents = pipe.vae.encode(img_batch).latent_dist.sample() * pipe.vae.config.scaling_factor
+        out_d = pipe.text_encoder(**dst_inp)
+        dest_repr, dest_pool = out_d[0], out_d[1]
+        dest_emb = te_edit.text_projection(dest_pool)
+        if objective == "esd" or hp("cal_text_repr_loss", False):
+            source_repr = pipe.text_encoder(**src_inp)[0]
+            if hp("contrastive_text_loss", False):
+                neg_emb = te_edit.text_projection(pipe.text_encoder(**neg_inp)[1])
+    fim = None
+    if hp("use_ewc", False):
+        with np.load(FIM_FILE, allow_pickle=True) as data:
+            fim = torch.from_numpy(np.asarray(data["mean.mean"])).to(device)
+
+    def hook(mod, args, out):
+        h = _hidden(out)
+        if state["source_init"] is None:
+            state["source_init"] = h[0, src_lookup[0]].detach().clone()
+        for i, idx in enumerate(src_lookup):
+            if hp("replace_repr", False):
+                h[i, idx, :] = delta
+            else:
+                h[i, idx, :] += delta
+        return out
+
+    handle = get_module(te_edit, hparams["layer_module_tmp"].format(layer)).register_forward_hook(hook)
+    try:
+        for it in range(hp("v_num_grad_steps")):
+            opt.zero_grad()
+            noise = torch.randn_like(latents, device=device)
+            timesteps = torch.randint(0, noise_scheduler.config.num_train_timesteps, (bsz,), device=device).long()
+            noisy = noise_scheduler.add_noise(latents, noise, timesteps)
+            out_e = te_edit(**src_inp)
+            edit_repr, edit_emb = out_e.last_hidden_state, out_e.text_embeds
+            with torch.no_grad():
+                if objective == "esd":
+                    pred_source = pipe.unet(noisy, timesteps, source_repr).sample
+            edit_pred = pipe.unet(noisy, timesteps, edit_repr).sample
+            pred_dest = pipe.unet(noisy, timesteps, dest_repr).sample
+            source_init = state["source_init"]
+            if "ablate" in objective:
+                if hp("use_sampled_noise", False):
+                    mse = F.mse_loss(noise, edit_pred, reduction="mean")
+                else:
+                    mse = F.mse_loss(edit_pred, pred_dest, reduction="mean")
+                if fim is not None:
+                    reg = hp("ewc_lambda", 1e4) * torch.sum(fim * delta ** 2) / (2 * torch.norm(source_init) ** 2)
+                else:
+                    reg = hp("v_weight_decay") * (torch.norm(delta) / torch.norm(source_init) ** 2)
+                loss = mse + reg
+            else:
+                tmp = pred_dest - hp("esd_mu") * (pred_source - pred_dest)
+                loss = F.mse_loss(edit_pred, tmp, reduction="mean") + hp("v_weight_decay") * (torch.norm(delta) / torch.norm(source_init) ** 2)
+            if hp("cal_text_repr_loss", False) and not objective == "esd":
+                scale = hp("text_repr_loss_scale_factor")
+                if hp("contrastive_text_loss", False):
+                    single = te_edit.text_projection(pipe.text_encoder(**tokenize_prompts([request["dest"]], tok, device)).pooler_output)
+                    emb = torch.cat([single, neg_emb], dim=0)
+                    scores = torch.squeeze(-torch.cdist(torch.unsqueeze(edit_emb, dim=0), torch.unsqueeze(emb, dim=0)))
+                    loss += scale * (-torch.log_softmax(scores, dim=1)[:, 0].mean(dim=0))
+                elif hp("align_object_token", False):
+                    loss += scale * F.mse_loss(edit_repr[torch.arange(bsz), src_lookup, :], dest_repr[torch.arange(bsz), dst_lookup, :],
+                                               reduction="mean")
+                else:
+                    loss += scale * F.mse_loss(edit_emb, dest_emb, reduction="mean")
+            if request["txt_img_align"]:
+                if hp("txt_img_align_loss_metric", "l2") == "cos":
+                    align = -(F.cosine_similarity(edit_emb, dest_img_emb, dim=1).mean() - 1)
+                elif hp("txt_img_align_loss_metric", "l2") == "l2":
+                    align = F.mse_loss(edit_emb, dest_img_emb, reduction="mean")
+                else:
+                    raise ValueError(f"txt_img_align_loss_metric {hp('txt_img_align_loss_metric')} not supported")
+                loss += hp("txt_img_align_scale_factor", 0.0) * align
+            loss.backward()
+            opt.step()
+            max_norm = hp("clamp_norm_factor") * source_init.norm()
+            if delta.norm() > max_norm:
+                with torch.no_grad():
+                    delta[...] = delta * max_norm / delta.norm()
+    finally:
+        handle.remove()
+    return (state["source_init"] + delta).detach()
+
+
 def compute_z_text_encoder_v2(pipe, request: Dict, hparams: Dict, layer: int, noise_scheduler, resolution: int = 512) -> torch.Tensor:
     """The ``use_new_compute_z`` Stage 1 (compute_z.py:1041-1357), op for op: ``num_edit_tokens`` vectors per concept — the
     last subject token, then (k >= 2) the EOS token and the k - 2 padding positions behind it, the prompts re-tokenized to

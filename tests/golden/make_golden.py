@@ -321,6 +321,58 @@ def golden_stage1_global(cz, EMCIDHyperParams, scratch, tag="toy_stage1_global")
     print(f"[golden] {tag}: wrote {len(out)} arrays: " + ", ".join(f"{k}: |v*| {np.linalg.norm(out[k + '/v_star']):.4f}" for k in GLOBAL_STAGE1_CASES))
 
 
+V1_STAGE1_CASES = {
+    # the txt_img_align Stage 1 (compute_z.py:1360-1648): ablate-dest with the image-alignment term ("cos" and "l2") on top of the
+    # projected-space text alignment; ablate-source without the image term, object-token alignment
+    "img_align_cos": dict(hp=dict(objective="ablate-dest", cal_text_repr_loss=True, text_repr_loss_scale_factor=0.01,
+                                  txt_img_align_scale_factor=0.05, txt_img_align_loss_metric="cos", v_lr=0.1, v_weight_decay=5e-4,
+                                  clamp_norm_factor=1.5, v_num_grad_steps=8), layer=3, seed=404, req={"txt_img_align": True}),
+    "img_align_l2_replace": dict(hp=dict(objective="ablate-dest", cal_text_repr_loss=False, replace_repr=True,
+                                         txt_img_align_scale_factor=0.2, txt_img_align_loss_metric="l2", v_lr=0.05, v_weight_decay=1e-3,
+                                         clamp_norm_factor=0.9, v_num_grad_steps=6), layer=2, seed=9, req={"txt_img_align": True}),
+    "no_img_object_token": dict(hp=dict(objective="ablate-source", cal_text_repr_loss=True, align_object_token=True,
+                                        text_repr_loss_scale_factor=0.05, txt_img_align_scale_factor=0.1, v_lr=0.1, v_weight_decay=5e-4,
+                                        clamp_norm_factor=1.2, v_num_grad_steps=7), layer=4, seed=31, req={"txt_img_align": False}),
+}
+
+
+def golden_stage1_v1(cz, EMCIDHyperParams, scratch, tag="toy_stage1_v1"):
+    """The REAL reference's compute_z_text_encoder_v1 (compute_z.py:1360-1648; emcid_main.py:919-926 selects it when
+    ``txt_img_align_scale_factor != 0``) on the synthetic pipe.  Shim 5 (this function only): the reference fetches
+    openai/clip-vit-large-patch14's text tower, vision tower and processor from the hub (:1376-1378, :1440) — no network here —,
+    so the three ``from_pretrained`` are pointed at emcid_amd.synthetic.build_clip_towers' offline stand-ins (the text tower
+    carries the pipe's own encoder weights, as the hub checkpoint does for SD-v1.x); everything else is the reference's code."""
+    (scratch / "log").mkdir(exist_ok=True)
+    out, meta = {}, {"cases": {}, "resolution": STAGE1_RESOLUTION, "towers": {"projection_dim": 16, "seed": 7}}
+    saved = (cz.CLIPTextModelWithProjection.from_pretrained, cz.CLIPVisionModelWithProjection.from_pretrained, cz.CLIPProcessor.from_pretrained)
+    try:
+        for name, c in V1_STAGE1_CASES.items():
+            pipe = syn.add_diffusion(syn.build_pipe("toy", "cpu"))
+            pipe.image_resolution = STAGE1_RESOLUTION
+            text, vision, proc = syn.build_clip_towers(pipe, image_size=STAGE1_RESOLUTION)
+            as_transformers_427(text)
+            cz.CLIPTextModelWithProjection.from_pretrained = staticmethod(lambda *_a, _m=text, **_k: _m)
+            cz.CLIPVisionModelWithProjection.from_pretrained = staticmethod(lambda *_a, _m=vision, **_k: _m)
+            cz.CLIPProcessor.from_pretrained = staticmethod(lambda *_a, _m=proc, **_k: _m)
+            hp_d = syn.sd_hparams_dict(layers=(1, 2, 3, 4), prefix="text_model.")      # the hooked model is the tower WITH projection
+            hp_d.update(c["hp"])
+            hp = EMCIDHyperParams(**hp_d)
+            request = {"source": "tocife", "dest": "a realist artist", "prompts": list(syn.ARTIST_TEMPLATES), "seed_train": 2024}
+            request.update(c["req"])
+            torch.manual_seed(c["seed"])
+            with contextlib.redirect_stdout(io.StringIO()):
+                v = cz.compute_z_text_encoder_v1(pipe, dict(request), hp, c["layer"], device="cpu")
+            out[f"{name}/v_star"] = v.detach().numpy()
+            meta["cases"][name] = {"hparams": hp_d, "layer": c["layer"], "seed": c["seed"], "request": request}
+    finally:
+        (cz.CLIPTextModelWithProjection.from_pretrained, cz.CLIPVisionModelWithProjection.from_pretrained,
+         cz.CLIPProcessor.from_pretrained) = saved
+    np.savez_compressed(OUT / f"{tag}.npz", **out)
+    with open(OUT / f"{tag}.json", "w") as f:
+        json.dump(meta, f, indent=1)
+    print(f"[golden] {tag}: wrote {len(out)} arrays: " + ", ".join(f"{k}: |v*| {np.linalg.norm(out[k + '/v_star']):.4f}" for k in V1_STAGE1_CASES))
+
+
 XATTN_STAGE1_CASES = {
     # safe-latent-diffusion supervision with the request's own safe words ("max" preset), the esd supervision with replace_repr,
     # and the "strong" preset over the built-in list of safety concepts
@@ -1022,6 +1074,8 @@ def main():
                 golden_stage1_more(cz, HP, scratch)
             elif which == "toy_stage1_global":
                 golden_stage1_global(cz, HP, scratch)
+            elif which == "toy_stage1_v1":
+                golden_stage1_v1(cz, HP, scratch)
             elif which == "toy_xattn_stage1":
                 golden_xattn_stage1(cz, HP, scratch)
             elif which == "toy_multi_token":
@@ -1042,6 +1096,7 @@ def main():
         golden_stage1_sdxl(cz, XLHP, scratch)
         golden_stage1_more(cz, HP, scratch)
         golden_stage1_global(cz, HP, scratch)
+        golden_stage1_v1(cz, HP, scratch)
         golden_xattn_stage1(cz, HP, scratch)
         golden_multi_token(em, HP, scratch)
         if "--skip-real" not in sys.argv:

@@ -1068,6 +1068,26 @@ def test_stage1_global_on_gpu_matches_reference_golden(name, tmp_path):
     assert v.is_cuda and np.abs(v.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("name", ["img_align_cos", "img_align_l2_replace", "no_img_object_token"])
+def test_stage1_v1_on_gpu_matches_reference_golden(name):
+    """The ``txt_img_align`` Stage 1 (compute_z_text_encoder_v1, reference compute_z.py:1360-1648) on the MI355X — CLIP's text
+    tower with projection hooked on the device, the vision tower's image embedding, autograd through the UNet stand-in — with the
+    random draws taken from the host generator in the reference's order: the REAL reference's v* (minted on CPU) to fp32 rounding."""
+    from emcid_amd.compute_z import compute_z_text_encoder_v1
+    z, meta = load_golden("toy_stage1_v1")
+    c = meta["cases"][name]
+    pipe = syn.add_diffusion(syn.build_pipe("toy", DEV))
+    pipe.image_resolution = meta["resolution"]
+    towers = syn.build_clip_towers(pipe, projection_dim=meta["towers"]["projection_dim"], seed=meta["towers"]["seed"],
+                                   image_size=meta["resolution"])
+    torch.manual_seed(c["seed"])
+    v = compute_z_text_encoder_v1(pipe, dict(c["request"]), EMCIDHyperParams(**c["hparams"]), c["layer"],
+                                  noise_scheduler=syn.DDPMNoiseSchedule(), resolution=meta["resolution"], rng_device="cpu",
+                                  clip_towers=towers)
+    ref = z[f"{name}/v_star"]
+    assert v.is_cuda and np.abs(v.cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
 def test_vstar_cache_miss_runs_stage1_then_edits(tmp_path):
     """A v* cache miss on a pipeline that carries a UNet and a VAE runs Stage 1 and writes the npz (reference
     emcid_main.py:905-969); the edit that follows equals an edit from that cache."""

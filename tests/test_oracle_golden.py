@@ -234,6 +234,46 @@ def test_stage1_global_v_star_matches_reference(name, tmp_path):
                                       noise_scheduler=syn.DDPMNoiseSchedule(), resolution=meta["resolution"])
 
 
+def _stage1_v1_case(meta, name, device="cpu"):
+    c = meta["cases"][name]
+    pipe = syn.add_diffusion(syn.build_pipe("toy", device))
+    pipe.image_resolution = meta["resolution"]
+    towers = syn.build_clip_towers(pipe, projection_dim=meta["towers"]["projection_dim"], seed=meta["towers"]["seed"],
+                                   image_size=meta["resolution"])
+    return c, pipe, towers, dict(c["request"])
+
+
+@pytest.mark.parametrize("name", ["img_align_cos", "img_align_l2_replace", "no_img_object_token"])
+def test_stage1_v1_v_star_matches_reference(name):
+    """The ``txt_img_align_scale_factor != 0`` Stage 1 (compute_z_text_encoder_v1, compute_z.py:1360-1648; selected at
+    emcid_main.py:919-926): the oracle's op-for-op restatement reproduces the REAL reference's v* bit for bit (fixture
+    toy_stage1_v1, minted with the three hub ``from_pretrained`` pointed at synthetic.build_clip_towers: cosine / l2 image
+    alignment on ablate-dest, replace_repr, object-token alignment without the image term); the product's loop agrees to fp32
+    rounding; the cache-miss dispatch reaches it; txt_img_align on another objective is the reference's NameError."""
+    from emcid_amd.compute_z import compute_z_text_encoder_v1, stage1_for
+    z, meta = load_golden("toy_stage1_v1")
+    ref = z[f"{name}/v_star"]
+    c, pipe, towers, request = _stage1_v1_case(meta, name)
+    torch.manual_seed(c["seed"])
+    v = orc.compute_z_text_encoder_v1(pipe, request, c["hparams"], c["layer"], syn.DDPMNoiseSchedule(), towers, meta["resolution"])
+    np.testing.assert_array_equal(v.numpy(), ref)
+    c, pipe, towers, request = _stage1_v1_case(meta, name)
+    torch.manual_seed(c["seed"])
+    v = compute_z_text_encoder_v1(pipe, request, EMCIDHyperParams(**c["hparams"]), c["layer"], noise_scheduler=syn.DDPMNoiseSchedule(),
+                                  resolution=meta["resolution"], clip_towers=towers)
+    assert np.abs(v.numpy() - ref).max() <= 2e-6 * np.abs(ref).max()
+    assert all(not p.requires_grad for p in towers[0].parameters())              # frozen towers are left as found
+    c, pipe, towers, request = _stage1_v1_case(meta, name)
+    torch.manual_seed(c["seed"])
+    v2 = stage1_for(pipe, EMCIDHyperParams(**c["hparams"]), c["layer"], clip_towers=towers, noise_scheduler=syn.DDPMNoiseSchedule(),
+                    resolution=meta["resolution"])(request)
+    assert torch.equal(v2, v)
+    if request["txt_img_align"]:
+        with pytest.raises(NameError):
+            compute_z_text_encoder_v1(pipe, request, EMCIDHyperParams(**dict(c["hparams"], objective="ablate-source", v_num_grad_steps=1)),
+                                      c["layer"], noise_scheduler=syn.DDPMNoiseSchedule(), resolution=meta["resolution"], clip_towers=towers)
+
+
 def _multi_token_case(z, meta, tmp_path, device="cpu"):
     from PIL import Image
     te = pipe_from_golden(z, meta["kind"], device=device)
