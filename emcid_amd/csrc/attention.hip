@@ -11,8 +11,6 @@
 // `causal` skips j > i (CLIP text is causal); an optional mask (bool keep-mask or additive float,
 // broadcastable over heads) covers right-padded prompts.
 #include "common.h"
-
-#include <algorithm>
 #include "sp16.h"
 
 namespace emcid {
@@ -115,14 +113,10 @@ struct TreeAttnArgs {
     uint32_t* P; int64_t ldp; float* inv_scale;        // the output as a split-fp16 matrix instead of `out` (short-chain kernel)
 };
 
-// R = rounds of four heads (H <= 4 R).  A wave owns heads wave, wave + 4, ...: ALL its heads' key rows are requested before the
-// first is used, then all their value rows (round 5 walked the rounds one after the other: two dependent gathers and three
-// barriers per round, 27 us per workgroup at twelve heads — Stage 0's 88 000-row launches took 1.16 ms, latency all of it).
-template <int R>
 __global__ __launch_bounds__(256) void tree_attention_f32_kernel(TreeAttnArgs a) {
     typedef float v4f __attribute__((ext_vector_type(4)));
     __shared__ int pth[128];
-    __shared__ float sc[4 * R][128];
+    __shared__ float sc[4][128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = lane >> 4, dl = lane & 15;
     const int qi = blockIdx.x;
@@ -131,97 +125,76 @@ __global__ __launch_bounds__(256) void tree_attention_f32_kernel(TreeAttnArgs a)
     if (tid < nk) pth[tid] = a.anc[(int64_t)u * a.anc_ld + tid];
     __syncthreads();
     const bool dok = 4 * dl < a.D;
-    bool live[R];
-    int64_t col[R];
-    v4f q4[R];
-#pragma unroll
-    for (int hh = 0; hh < R; ++hh) {
+    const int rounds = (a.H + 3) / 4;
+    for (int hh = 0; hh < rounds; ++hh) {
         const int h = hh * 4 + wave;
-        live[hh] = h < a.H;
-        col[hh] = (int64_t)(live[hh] ? h : 0) * a.D + 4 * dl;
-        q4[hh] = (v4f){0.f, 0.f, 0.f, 0.f};
-        if (dok) q4[hh] = *reinterpret_cast<const v4f*>(a.q + (int64_t)qi * a.ldq + col[hh]);   // q rows follow the QUERY order
-    }
-    // sixteen keys per step and head: their row reads go out together
-    for (int j0 = 0; j0 < nk; j0 += 16) {
-        v4f k4[R][4];
-#pragma unroll
-        for (int hh = 0; hh < R; ++hh)
+        const bool live = h < a.H;
+        const int64_t col = (int64_t)(live ? h : 0) * a.D + 4 * dl;
+        v4f q4 = {0.f, 0.f, 0.f, 0.f};
+        if (dok) q4 = *reinterpret_cast<const v4f*>(a.q + (int64_t)qi * a.ldq + col);   // q rows follow the QUERY order
+        // sixteen keys per step: their four row reads go out together (one dependent read per 16 keys instead of per 4 — the
+        // kernel is latency-bound on long chains: Stage 0's captions, 1.19 ms per launch at 88 000 rows before)
+        for (int j0 = 0; j0 < nk; j0 += 16) {
+            v4f k4[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int j = j0 + 4 * t + slot;
-                k4[hh][t] = (v4f){0.f, 0.f, 0.f, 0.f};
-                if (j < nk && dok) k4[hh][t] = *reinterpret_cast<const v4f*>(a.k + (int64_t)pth[j] * a.ld + col[hh]);
+                k4[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+                if (j < nk && dok) k4[t] = *reinterpret_cast<const v4f*>(a.k + (int64_t)pth[j] * a.ld + col);
             }
 #pragma unroll
-        for (int hh = 0; hh < R; ++hh)
-#pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int j = j0 + 4 * t + slot;
-                float part = q4[hh][0] * k4[hh][t][0] + q4[hh][1] * k4[hh][t][1] + q4[hh][2] * k4[hh][t][2] + q4[hh][3] * k4[hh][t][3];
+                float part = q4[0] * k4[t][0] + q4[1] * k4[t][1] + q4[2] * k4[t][2] + q4[3] * k4[t][3];
                 part += __shfl_xor(part, 8);
                 part += __shfl_xor(part, 4);
                 part += __shfl_xor(part, 2);
                 part += __shfl_xor(part, 1);
-                if (dl == 0 && j < nk) sc[4 * hh + wave][j] = part * a.scale;
+                if (dl == 0 && j < nk) sc[wave][j] = part * a.scale;
             }
-    }
-    __syncthreads();
-    float l[R];
-#pragma unroll
-    for (int hh = 0; hh < R; ++hh) {
-        float* row = sc[4 * hh + wave];
-        float m = -INFINITY;
-        for (int j = lane; j < nk; j += 64) m = fmaxf(m, row[j]);
-        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-        float sum = 0.f;
-        for (int j = lane; j < nk; j += 64) {
-            const float p = expf(row[j] - m);
-            row[j] = p;
-            sum += p;
         }
-        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
-        l[hh] = sum;
-    }
-    __syncthreads();
-    v4f acc[R];
-#pragma unroll
-    for (int hh = 0; hh < R; ++hh) acc[hh] = (v4f){0.f, 0.f, 0.f, 0.f};
-    for (int j0 = 0; j0 < nk; j0 += 16) {
-        v4f v4[R][4];
-        float p[R][4];
-#pragma unroll
-        for (int hh = 0; hh < R; ++hh)
+        __syncthreads();
+        float m = -INFINITY;
+        for (int j = lane; j < nk; j += 64) m = fmaxf(m, sc[wave][j]);
+        for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float l = 0.f;
+        for (int j = lane; j < nk; j += 64) {
+            const float p = expf(sc[wave][j] - m);
+            sc[wave][j] = p;
+            l += p;
+        }
+        for (int o = 32; o >= 1; o >>= 1) l += __shfl_xor(l, o);
+        __syncthreads();
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < nk; j0 += 16) {
+            v4f v4[4];
+            float p[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int j = j0 + 4 * t + slot;
-                v4[hh][t] = (v4f){0.f, 0.f, 0.f, 0.f};
-                p[hh][t] = 0.f;
+                v4[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+                p[t] = 0.f;
                 if (j < nk && dok) {
-                    p[hh][t] = sc[4 * hh + wave][j];
-                    v4[hh][t] = *reinterpret_cast<const v4f*>(a.v + (int64_t)pth[j] * a.ld + col[hh]);
+                    p[t] = sc[wave][j];
+                    v4[t] = *reinterpret_cast<const v4f*>(a.v + (int64_t)pth[j] * a.ld + col);
                 }
             }
 #pragma unroll
-        for (int hh = 0; hh < R; ++hh)
-#pragma unroll
             for (int t = 0; t < 4; ++t) {          // (key order as before: j0 + slot, j0 + 4 + slot, ...)
-                acc[hh][0] += p[hh][t] * v4[hh][t][0]; acc[hh][1] += p[hh][t] * v4[hh][t][1];
-                acc[hh][2] += p[hh][t] * v4[hh][t][2]; acc[hh][3] += p[hh][t] * v4[hh][t][3];
+                acc[0] += p[t] * v4[t][0]; acc[1] += p[t] * v4[t][1]; acc[2] += p[t] * v4[t][2]; acc[3] += p[t] * v4[t][3];
             }
-    }
-#pragma unroll
-    for (int hh = 0; hh < R; ++hh) {
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            acc[hh][e] += __shfl_xor(acc[hh][e], 16);
-            acc[hh][e] += __shfl_xor(acc[hh][e], 32);
+            acc[e] += __shfl_xor(acc[e], 16);
+            acc[e] += __shfl_xor(acc[e], 32);
         }
-        if (live[hh] && slot == 0 && dok) {
-            const float inv = 1.f / l[hh];
-            v4f o4 = {acc[hh][0] * inv, acc[hh][1] * inv, acc[hh][2] * inv, acc[hh][3] * inv};
-            *reinterpret_cast<v4f*>(a.out + (int64_t)qi * a.ldo + col[hh]) = o4;
+        if (live && slot == 0 && dok) {
+            const float inv = 1.f / l;
+            v4f o4 = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+            *reinterpret_cast<v4f*>(a.out + (int64_t)qi * a.ldo + col) = o4;
         }
+        __syncthreads();
     }
 }
 
@@ -401,20 +374,7 @@ extern "C" int emcid_tree_attention_f32(const float* q, int64_t ldq, const float
         if (anc_ld <= 8) launch_tree_attention_short<2, false>(a, rounds, (hipStream_t)stream);
         else launch_tree_attention_short<4, false>(a, rounds, (hipStream_t)stream);
     } else {
-        const dim3 grid((unsigned)n_rows), wg(256);
-        hipStream_t st = (hipStream_t)stream;
-        for (int64_t h0 = 0; h0 < H; h0 += 20) {      // twenty heads per launch: rounds of four heads, one wave per head and round
-            TreeAttnArgs b = a;
-            b.q += h0 * D, b.k += h0 * D, b.v += h0 * D, b.out += h0 * D;
-            b.H = (int)std::min<int64_t>(20, H - h0);
-            switch ((b.H + 3) / 4) {
-                case 1: hipLaunchKernelGGL(tree_attention_f32_kernel<1>, grid, wg, 0, st, b); break;
-                case 2: hipLaunchKernelGGL(tree_attention_f32_kernel<2>, grid, wg, 0, st, b); break;
-                case 3: hipLaunchKernelGGL(tree_attention_f32_kernel<3>, grid, wg, 0, st, b); break;
-                case 4: hipLaunchKernelGGL(tree_attention_f32_kernel<4>, grid, wg, 0, st, b); break;
-                default: hipLaunchKernelGGL(tree_attention_f32_kernel<5>, grid, wg, 0, st, b); break;
-            }
-        }
+        hipLaunchKernelGGL(tree_attention_f32_kernel, dim3((unsigned)n_rows), dim3(256), 0, (hipStream_t)stream, a);
     }
     EMCID_CHECK_LAUNCH();
     return EMCID_OK;

@@ -222,7 +222,7 @@ def test_quick_gelu_vs_torch():
 
 @pytest.mark.parametrize("U,H,D,max_depth", [(300, 3, 16, None), (300, 12, 64, 9), (400, 20, 64, 15), (300, 5, 32, 16),
                                              (700, 12, 64, 6), (300, 20, 64, 7), (300, 12, 64, 2), (300, 1, 8, 4),   # <= 8 nodes
-                                             (300, 12, 64, 40), (300, 20, 64, 30), (200, 24, 32, 30)])                # general kernel (3 / 5 rounds, > 20 heads)
+                                             (300, 12, 64, 40), (300, 20, 64, 30), (300, 24, 32, 30)])                # general kernel (3 / 5 / 6 rounds of four heads)
 def test_tree_attention_vs_dense_reference(U, H, D, max_depth):
     """Random trie: every node attends to its ancestor chain; compare with per-node dense softmax in torch.
     Short chains (mass-edit prompts) and long ones, CLIP-L and bigG head shapes."""
