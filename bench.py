@@ -543,7 +543,9 @@ def main():
             peak = F16_MFMA_PEAK_TFLOPS / 3.0
             lin["frac_f16_mfma_peak"] = lin["tflops"] / peak
             lin["mfma_tflops_executed"] = 3.0 * lin["tflops"]
-            pmc = REPO / "profiles" / "r05_pmc_linear_sp16.json"
+            pmc = REPO / "profiles" / "r06_pmc_linear_sp16.json"          # (this round's counter passes of the same kernels)
+            if not pmc.exists():
+                pmc = REPO / "profiles" / "r05_pmc_linear_sp16.json"
             traffic = traffic_note = None
             if pmc.exists():
                 with open(pmc) as fh:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condenses the four per-shape counter summaries of the split-fp16 projection kernel (scripts/round4_measure.sh:
 profiles/<tag>_pmc_sp16_{qkv,out,fc1,fc2}.json, made by pmc_passes.sh + pmc_summary.py from scripts/pmc_linear_sp16.py) into the
-file bench.py reads for `roofline.traffic`: profiles/r05_pmc_linear_sp16.json.  usage: pmc_sp16_traffic.py <tag> [rows=6400]"""
+file bench.py reads for `roofline.traffic`: profiles/<round>_pmc_linear_sp16.json (r06_a -> r06_pmc_linear_sp16.json).  usage: pmc_sp16_traffic.py <tag> [rows=6400]"""
 import json, sys
 from pathlib import Path
 
@@ -27,5 +27,6 @@ out = {"traffic_bytes_per_launch": total / len(shapes), "per_shape": per,
                f"tallies 128-B requests at 64 B) + WRITE_SIZE; Infinity-Cache hits are counted (the planes of the weights stay resident "
                f"there), so this is L2-miss traffic, not HBM traffic; algorithmic = 4 (rows K + N K + rows N [+ rows N residual]) bytes "
                f"(the split planes take 4 bytes per element like the fp32 matrices they stand for)"}
-(repo / "profiles" / "r05_pmc_linear_sp16.json").write_text(json.dumps(out, indent=1) + "\n")
+round_tag = tag.split("_")[0] if tag.startswith("r") else "r05"          # r06_a -> r06
+(repo / "profiles" / f"{round_tag}_pmc_linear_sp16.json").write_text(json.dumps(out, indent=1) + "\n")
 print(json.dumps({k: {kk: (round(vv, 3) if isinstance(vv, float) else vv) for kk, vv in v.items()} for k, v in per.items()}, indent=1))
