@@ -370,7 +370,7 @@ def test_rccl_column_sharded_solve_at_headline_size(tmp_path):
         np.testing.assert_allclose(np.abs(got[n]).max(), scale, rtol=1e-4)
 
 
-@pytest.mark.parametrize("ranks", [2, 4])
+@pytest.mark.parametrize("ranks", [4])          # (round 5 also ran 2 ranks: 14 s of the suite for a subset of what 4 ranks exercise)
 def test_bench_self_launch_gloo(tmp_path, ranks):
     """`python bench.py --gpus N` without a launcher: the script starts its own torch.distributed.run child before touching the
     GPU and the ranks (sharing this box's GPU, EMCID_BENCH_BACKEND=gloo: collectives staged through the host) produce ONE

@@ -338,9 +338,9 @@ def test_sdxl_real_dims_apply_vs_oracle(tmp_path):
     """BASELINE config 4 dims: TE1 768/3072 layers 8-10 (lam 4000) + TE2 1280/5120 layers 26-30 (lam 10000),
     two encoders on two HIP streams, TE2 double-apply quirk included — vs the oracle's CPU restatement."""
     reqs = syn.make_requests(12, names="syllable")
-    # (TE2 layers 28-30 of the shipped 26-30: the oracle runs two 32-layer forwards per edited layer on the host; all five are
+    # (TE2 layers 29-30 of the shipped 26-30: the oracle runs two 32-layer forwards per edited layer on the host; all five are
     #  held by the reference's own summaries, test_sdxl_edit_matches_reference_summary)
-    hp_d = syn.sdxl_hparams_dict(layers_2=(28, 29, 30))
+    hp_d = syn.sdxl_hparams_dict(layers_2=(29, 30))
     n1 = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers"]]
     n2 = [hp_d["rewrite_module_tmp"].format(l) for l in hp_d["layers_2"]]
     cache = str(tmp_path / "cache") + "/"

@@ -187,13 +187,15 @@ def test_uce_text_encoder_variant_at_sd_dims_vs_oracle():
     from emcid_amd import synthetic as syn
     ref_pipe = syn.build_pipe("sd-v1.4", "cpu", syllables=True)
     pipe = syn.SyntheticPipe(text_encoder=copy.deepcopy(ref_pipe.text_encoder).to(DEV), tokenizer=ref_pipe.tokenizer)
-    old = [r["source"] for r in syn.make_requests(5, names="syllable")]
-    new = ["a realist artist", "", "famous portrait", "drawing", "landscape painting with a portrait"]
-    retain = ["painting", "a photo of the artist"]
+    # (three edits and one retained text: the oracle forms the reference's per-row 3072 x 768 outer products on the host, 1.3 s
+    #  per text on the GPU box's cores — five edits and two retained texts were 20 s of the suite)
+    old = [r["source"] for r in syn.make_requests(3, names="syllable")]
+    new = ["a realist artist", "", "landscape painting with a portrait"]
+    retain = ["a photo of the artist"]
     want = orc.edit_text_encoder_uce(ref_pipe, old, new, retain, layer_to_edit=11, dtype=torch.float64)
     uce.edit_text_encoder_uce(pipe, old, new, retain, layer_to_edit=11)
     got = pipe.text_encoder.encoder.layers[11].mlp.fc2.weight.detach().cpu().double()
-    assert uce.LAST_RUN["rows"] > 5 * 60 and uce.LAST_RUN["retain_rows"] == 2 * 77
+    assert uce.LAST_RUN["rows"] > 3 * 60 and uce.LAST_RUN["retain_rows"] == 1 * 77
     # measured 5.1e-5: the GPU and CPU fp32 encoder forwards differ by ~1e-6, and lam = 0.1 against 3072-wide fc2 inputs
     # amplifies that (the closed form itself agrees with fp64 torch to 2e-7 on shared inputs, tests above)
     err = (got - want).abs().max().item() / want.abs().max().item()
