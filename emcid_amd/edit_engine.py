@@ -334,7 +334,7 @@ def prepare_encoder_edit(text_encoder, tokenizer, requests: Sequence[Dict], laye
                 if pc is None:
                     break
                 with phase("trie"):
-                    trie = clip_forward.build_trie(pc.ids, pc.lookup, device, tail=np.cumsum([0] + list(pc.counts)).astype(np.int64))
+                    trie = clip_forward.build_trie(pc.ids, pc.lookup, device, tail=pc.request_offsets())
                     seg = trie.tail
                 with phase("prefix launches"), torch.no_grad():
                     hs, x_ln1 = clip_forward.run_prefix(graph, trie, first_edit)
