@@ -543,6 +543,7 @@ def main():
             peak = F16_MFMA_PEAK_TFLOPS / 3.0
             lin["frac_f16_mfma_peak"] = lin["tflops"] / peak
             lin["mfma_tflops_executed"] = 3.0 * lin["tflops"]
+            held_clock = None
             pmc = REPO / "profiles" / "r06_pmc_linear_sp16.json"          # (this round's counter passes of the same kernels)
             if not pmc.exists():
                 pmc = REPO / "profiles" / "r05_pmc_linear_sp16.json"
@@ -552,6 +553,11 @@ def main():
                     rec = json.load(fh)
                 traffic = rec.get("traffic_bytes_per_launch")
                 traffic_note = f"STORED value from {pmc.relative_to(REPO)} (counter passes of the same kernels, not of this run): " + str(rec.get("note"))
+                # the clock the chip HELD in those launches (GRBM_GUI_ACTIVE / 8 / wall, MI355X_MICROARCH.md "DVFS give-back"),
+                # weighted by each shape's launch time: informational — `frac` stays against the 2.4 GHz peak
+                shapes_ = [v for v in (rec.get("per_shape") or {}).values() if v.get("clock_ghz") and v.get("avg_us")]
+                if shapes_:
+                    held_clock = sum(v["clock_ghz"] * v["avg_us"] for v in shapes_) / sum(v["avg_us"] for v in shapes_)
             roofline = {"bound": "mfma", "kernel": KERNEL_OF_CLASS["linear_sp16"], "class": "linear", "achieved": lin["tflops"],
                         "peak": peak, "unit": "TFLOP/s", "frac": lin["tflops"] / peak,
                         "dtype": "f32 (2 x fp16 split: 3 f16 MFMAs per k-step, fp32 accumulate)",
@@ -564,6 +570,13 @@ def main():
                         "launches_per_step": lin["launches_per_step"],
                         "flops_per_launch": lin["algorithmic_flops_per_step"] / lin["launches_per_step"],
                         "selection": "the kernel class with the most time per call over ALL classes (forward GEMMs and fp64 solve)",
+                        "held_clock_ghz": held_clock,
+                        "frac_at_held_clock": (lin["tflops"] / peak * 2.4 / held_clock) if held_clock else None,
+                        "held_clock_note": "informational: the shader clock the chip held in these kernels' counter passes (it lowers its "
+                                           "clock under MFMA load on random data; launch-time-weighted over the four shapes) and the same "
+                                           "fraction against the peak AT that clock; `frac` is against the 2.4 GHz peak.  The GRBM quotient reads HIGH on "
+                                           "dispatches this short (MI355X_MICROARCH.md): in-kernel stamps of the same loops read 1.75-1.93 GHz "
+                                           "(profiles/r05_mb_linear_sp16_rounds.txt), so this fraction is a lower bound of the at-clock one",
                         "next": (None if top is None else {"class": top, "ms_per_step": prof[top][0] / args.steps,
                                                            "frac_f64_mfma_peak": classes[top].get("frac_f64_mfma_peak")})}
         else:
