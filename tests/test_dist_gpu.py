@@ -385,7 +385,7 @@ def test_bench_self_launch_gloo(tmp_path, ranks):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--concepts", "200",
-                        "--no-cpu-baseline", "--no-stage0", "--no-variants"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--no-stage0", "--no-variants", "--no-gemm-ab"], env=env, capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-3000:]
     out = json.loads(lines[0])
